@@ -1,0 +1,127 @@
+"""ctypes binding of ``libhbk_core.so`` (the C ABI declared in ``include/hbk.h``).
+
+There is no fallback: if the HIP library has not been built the import of any op
+fails loudly with the build command.  PyTorch is used only for device memory and
+streams; every compute call below goes through the C ABI.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libhbk_core.so')
+
+# dtype codes of include/hbk.h
+INT8, UINT8, INT32, UINT32, INT64, UINT64, HALF, FLOAT, DOUBLE = range(9)
+COMBINER_SUM, COMBINER_MEAN, COMBINER_SQRTN = 0, 1, 2
+OK, INVALID_ARGUMENT, UNIMPLEMENTED, INTERNAL = 0, 3, 12, 13
+COMM_ID_BYTES = 128
+
+
+class HbkError(RuntimeError):
+  """A non-zero status from the C ABI (code = TensorFlow error code)."""
+
+  def __init__(self, code, message):
+    super().__init__(f'[hbk status {code}] {message}')
+    self.code = code
+
+
+class InvalidArgumentError(HbkError, ValueError):
+  pass
+
+
+class LookupColumn(C.Structure):
+  """hbk_lookup_column_t"""
+  _fields_ = [('table', C.c_void_p), ('rows', C.c_int64), ('dim', C.c_int32),
+              ('ids_dtype', C.c_int32), ('ids', C.c_void_p), ('n_ids', C.c_int64),
+              ('row_splits', C.c_void_p), ('n_segments', C.c_int64),
+              ('bucket', C.c_int64), ('divisor', C.c_int32),
+              ('combiner', C.c_int32), ('out', C.c_void_p)]
+
+
+class LookupGradColumn(C.Structure):
+  """hbk_lookup_grad_column_t"""
+  _fields_ = [('table', C.c_void_p), ('rows', C.c_int64), ('dim', C.c_int32),
+              ('ids_dtype', C.c_int32), ('ids', C.c_void_p), ('n_ids', C.c_int64),
+              ('row_splits', C.c_void_p), ('n_segments', C.c_int64),
+              ('bucket', C.c_int64), ('divisor', C.c_int32),
+              ('combiner', C.c_int32), ('grad_out', C.c_void_p),
+              ('unique_rows', C.c_void_p), ('grad_rows', C.c_void_p),
+              ('n_unique', C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+  """Load libhbk_core.so once.  Raises if it is missing -- never falls back."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise ImportError(
+      f'{LIB_PATH} not found: the gfx950 HIP extension is not built. '
+      'Run `python -c "import __graft_entry__ as g; g.build()"` or '
+      '`make -C hybridbackend_amd/csrc`. There is no CPU fallback.')
+  # torch first: its bundled libamdhip64.so.7 / librccl.so.1 must be the ones the
+  # process uses, so the streams and pointers it hands us belong to the same runtime.
+  import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
+  l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+  l.hbk_last_error.restype = C.c_char_p
+  l.hbk_version.restype = C.c_char_p
+  for name in ('hbk_partition_workspace_bytes', 'hbk_unique_workspace_bytes',
+               'hbk_group_lookup_bwd_workspace_bytes',
+               'hbk_alltoallv_wire_workspace_bytes'):
+    if hasattr(l, name):
+      getattr(l, name).restype = C.c_size_t
+  if hasattr(l, 'hbk_comm_stream'):
+    l.hbk_comm_stream.restype = C.c_void_p
+  _lib = l
+  return l
+
+
+def check(status):
+  if status != OK:
+    msg = lib().hbk_last_error().decode('utf-8', 'replace')
+    if status == INVALID_ARGUMENT:
+      raise InvalidArgumentError(status, msg)
+    raise HbkError(status, msg)
+
+
+def ptr_array(ptrs):
+  return (C.c_void_p * len(ptrs))(*ptrs)
+
+
+def i64_array(vals):
+  return (C.c_int64 * len(vals))(*vals)
+
+
+def i32_array(vals):
+  return (C.c_int32 * len(vals))(*vals)
+
+
+def torch_dtype_code(dtype):
+  import torch  # pylint: disable=import-outside-toplevel
+  table = {torch.int8: INT8, torch.uint8: UINT8, torch.int32: INT32,
+           torch.int64: INT64, torch.float16: HALF, torch.float32: FLOAT,
+           torch.float64: DOUBLE}
+  for name, code in (('uint32', UINT32), ('uint64', UINT64)):
+    if hasattr(torch, name):
+      table[getattr(torch, name)] = code
+  if dtype not in table:
+    raise InvalidArgumentError(INVALID_ARGUMENT, f'unsupported dtype {dtype}')
+  return table[dtype]
+
+
+def current_stream(device=None):
+  import torch  # pylint: disable=import-outside-toplevel
+  return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_device_tensor(t, what):
+  if not t.is_cuda:
+    raise HbkError(
+      INTERNAL,
+      f'{what} must live in HBM (got a {t.device} tensor): the HIP path is the '
+      'only path, there is no CPU fallback')
+  if not t.is_contiguous():
+    raise InvalidArgumentError(INVALID_ARGUMENT, f'{what} must be contiguous')

@@ -1,0 +1,361 @@
+// RCCL-over-xGMI communicator behind HbGetNcclId / HbCreateNcclCollective /
+// HbNcclAlltoall[N] / HbNcclAlltoallv[N] (R4, R5, R6).
+//   lifecycle      hbtf/distribute/nccl/nccl_get_id.cc:35-62, nccl_create.cc:45-132,
+//                  nccl_collective.cc:40-65,434-465
+//   active ranks   hbtf/distribute/collective.h:80-112 (one communicator; sub-topologies by
+//                  choosing peers)
+//   all-to-all     nccl_collective.cc:112-151 (equal split), :250-288 (v), :153-248/:290-384 (N)
+//   stream fences  hbtf/common/stream.cc:83-142: the comm stream waits for the compute stream's
+//                  tail before the exchange, the compute stream waits for the exchange after it
+// One process per GPU; on one 8 x MI355X node every peer is one xGMI hop, so the grouped
+// ncclSend/ncclRecv pattern maps one message per link.  Unlike the reference nothing here
+// syncs the host: receive sizes come in as host arrays the caller obtained ONCE for all N
+// columns (one [N x W] hbk_alltoall_n), not once per op (nccl_alltoallv.cc:316,533).
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace hbk {
+int cast_n_impl(int32_t n, int32_t src_dtype, int32_t dst_dtype, const void* const* inputs,
+                const int64_t* lens, void* const* outputs, hipStream_t stream);
+}
+
+struct hbk_comm {
+  ncclComm_t comm;
+  hipStream_t stream;
+  hipEvent_t compute_done;
+  hipEvent_t comm_done;
+  int world_size;
+  int local_size;
+  int rank;
+  int device;
+  bool aborted;
+  std::mutex mu;  // NCCL calls on one communicator are serialised (nccl/collective.h:113)
+};
+
+namespace hbk {
+namespace {
+
+#define HBK_NCCL_OK(expr)                                                            \
+  do {                                                                               \
+    ncclResult_t r__ = (expr);                                                       \
+    if (r__ != ncclSuccess) {                                                        \
+      return ::hbk::fail(HBK_INTERNAL, "%s failed: %s (%s:%d)", #expr,               \
+                         ncclGetErrorString(r__), __FILE__, __LINE__);               \
+    }                                                                                \
+  } while (0)
+
+bool to_nccl(int32_t dtype, ncclDataType_t* out) {
+  switch (dtype) {
+    case HBK_INT8: *out = ncclInt8; return true;
+    case HBK_UINT8: *out = ncclUint8; return true;
+    case HBK_INT32: *out = ncclInt32; return true;
+    case HBK_UINT32: *out = ncclUint32; return true;
+    case HBK_INT64: *out = ncclInt64; return true;
+    case HBK_UINT64: *out = ncclUint64; return true;
+    case HBK_HALF: *out = ncclFloat16; return true;
+    case HBK_FLOAT: *out = ncclFloat32; return true;
+    case HBK_DOUBLE: *out = ncclFloat64; return true;
+    default: return false;
+  }
+}
+
+// Collective::compute_active_ranks, hbtf/distribute/collective.h:80-99
+void active_ranks(const hbk_comm* c, int32_t topology, std::vector<int>* out) {
+  out->clear();
+  if (topology == HBK_TOPOLOGY_INTRA_NODE) {
+    const int node = c->rank / c->local_size;
+    for (int r = node * c->local_size; r < (node + 1) * c->local_size; ++r) out->push_back(r);
+  } else if (topology == HBK_TOPOLOGY_INTER_NODE) {
+    for (int r = 0; r < c->world_size; ++r) {
+      if (c->local_size == 1 || (r % c->local_size) == (c->rank % c->local_size)) {
+        out->push_back(r);
+      }
+    }
+  } else {
+    for (int r = 0; r < c->world_size; ++r) out->push_back(r);
+  }
+}
+
+int fence_in(hbk_comm* c, hipStream_t compute) {
+  HBK_HIP_OK(hipEventRecord(c->compute_done, compute));
+  HBK_HIP_OK(hipStreamWaitEvent(c->stream, c->compute_done, 0));
+  return HBK_OK;
+}
+
+int fence_out(hbk_comm* c, hipStream_t compute) {
+  HBK_HIP_OK(hipEventRecord(c->comm_done, c->stream));
+  HBK_HIP_OK(hipStreamWaitEvent(compute, c->comm_done, 0));
+  return HBK_OK;
+}
+
+}  // namespace
+}  // namespace hbk
+
+extern "C" int hbk_comm_get_id(uint8_t id[HBK_COMM_ID_BYTES]) {
+  using namespace hbk;
+  static_assert(sizeof(ncclUniqueId) == HBK_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  HBK_REQUIRE(id != nullptr, "comm_get_id: id is NULL");
+  ncclUniqueId nid;
+  HBK_NCCL_OK(ncclGetUniqueId(&nid));
+  memcpy(id, &nid, HBK_COMM_ID_BYTES);
+  return HBK_OK;
+}
+
+extern "C" int hbk_comm_create(hbk_comm_t* comm, const uint8_t id[HBK_COMM_ID_BYTES],
+                               int32_t world_size, int32_t local_size, int32_t rank) {
+  using namespace hbk;
+  HBK_REQUIRE(comm != nullptr && id != nullptr, "comm_create: NULL argument");
+  HBK_REQUIRE(world_size >= 1, "comm_create: world_size must be >= 1, got %d", world_size);
+  HBK_REQUIRE(local_size >= 1 && world_size % local_size == 0,
+              "comm_create: local_size (%d) must divide world_size (%d)", local_size,
+              world_size);
+  HBK_REQUIRE(rank >= 0 && rank < world_size, "comm_create: rank %d out of [0, %d)", rank,
+              world_size);
+  hbk_comm* c = new hbk_comm();
+  c->world_size = world_size;
+  c->local_size = local_size;
+  c->rank = rank;
+  c->aborted = false;
+  c->comm = nullptr;
+  c->stream = nullptr;
+  hipError_t he = hipGetDevice(&c->device);
+  if (he != hipSuccess) {
+    delete c;
+    return fail(HBK_INTERNAL, "comm_create: hipGetDevice failed: %s", hipGetErrorString(he));
+  }
+  ncclUniqueId nid;
+  memcpy(&nid, id, HBK_COMM_ID_BYTES);
+  ncclResult_t nr = ncclCommInitRank(&c->comm, world_size, nid, rank);
+  if (nr != ncclSuccess) {
+    delete c;
+    return fail(HBK_INTERNAL, "comm_create: ncclCommInitRank failed: %s",
+                ncclGetErrorString(nr));
+  }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->compute_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->comm_done, hipEventDisableTiming) != hipSuccess) {
+    ncclCommDestroy(c->comm);
+    delete c;
+    return fail(HBK_INTERNAL, "comm_create: could not create the comm stream / events");
+  }
+  *comm = c;
+  return HBK_OK;
+}
+
+extern "C" int hbk_comm_destroy(hbk_comm_t comm) {
+  using namespace hbk;
+  if (comm == nullptr) return HBK_OK;
+  (void)hipStreamSynchronize(comm->stream);
+  if (!comm->aborted) ncclCommDestroy(comm->comm);
+  (void)hipEventDestroy(comm->compute_done);
+  (void)hipEventDestroy(comm->comm_done);
+  (void)hipStreamDestroy(comm->stream);
+  delete comm;
+  return HBK_OK;
+}
+
+// NcclCollective::CheckAsyncErrors, nccl_collective.cc:449-465
+extern "C" int hbk_comm_check_async(hbk_comm_t comm) {
+  using namespace hbk;
+  HBK_REQUIRE(comm != nullptr, "comm_check_async: comm is NULL");
+  std::unique_lock<std::mutex> lock(comm->mu);
+  if (comm->aborted) return fail(HBK_INTERNAL, "communicator was aborted");
+  ncclResult_t async = ncclSuccess;
+  HBK_NCCL_OK(ncclCommGetAsyncError(comm->comm, &async));
+  if (async != ncclSuccess && async != ncclInProgress) {
+    ncclCommAbort(comm->comm);
+    comm->aborted = true;
+    return fail(HBK_INTERNAL, "RCCL async error: %s; communicator aborted",
+                ncclGetErrorString(async));
+  }
+  return HBK_OK;
+}
+
+extern "C" int hbk_comm_world_size(hbk_comm_t comm) { return comm ? comm->world_size : 0; }
+extern "C" int hbk_comm_rank(hbk_comm_t comm) { return comm ? comm->rank : -1; }
+extern "C" hbk_stream_t hbk_comm_stream(hbk_comm_t comm) {
+  return comm ? reinterpret_cast<hbk_stream_t>(comm->stream) : nullptr;
+}
+
+extern "C" int hbk_comm_active_ranks(hbk_comm_t comm, int32_t topology, int32_t* ranks_out) {
+  if (comm == nullptr) return 0;
+  std::vector<int> ranks;
+  hbk::active_ranks(comm, topology, &ranks);
+  if (ranks_out != nullptr) {
+    for (size_t i = 0; i < ranks.size(); ++i) ranks_out[i] = ranks[i];
+  }
+  return (int)ranks.size();
+}
+
+extern "C" int hbk_alltoall_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t topology,
+                              const void* const* inputs, const int64_t* counts,
+                              void* const* outputs, hbk_stream_t compute_stream) {
+  using namespace hbk;
+  HBK_REQUIRE(comm != nullptr, "alltoall_n: comm is NULL");
+  HBK_REQUIRE(n >= 0, "alltoall_n: n must be >= 0");
+  if (n == 0) return HBK_OK;
+  HBK_REQUIRE(inputs && counts && outputs, "alltoall_n: NULL argument array");
+  ncclDataType_t nt;
+  HBK_REQUIRE(to_nccl(dtype, &nt), "alltoall_n: unsupported dtype %d", dtype);
+  const size_t esize = (size_t)dtype_size(dtype);
+  std::vector<int> ranks;
+  active_ranks(comm, topology, &ranks);
+  const int64_t active = (int64_t)ranks.size();
+  for (int32_t c = 0; c < n; ++c) {
+    HBK_REQUIRE(counts[c] >= 0 && counts[c] % active == 0,
+                "Number of elements in input (%lld) must can be divided into %lld partitions",
+                (long long)counts[c], (long long)active);  // nccl_collective.cc:119-123
+    HBK_REQUIRE(counts[c] == 0 || (inputs[c] && outputs[c]), "alltoall_n: NULL buffer %d", c);
+  }
+  std::unique_lock<std::mutex> lock(comm->mu);
+  HBK_REQUIRE(!comm->aborted, "alltoall_n: communicator was aborted");
+  int rc = fence_in(comm, as_stream(compute_stream));
+  if (rc != HBK_OK) return rc;
+  HBK_NCCL_OK(ncclGroupStart());
+  for (int32_t c = 0; c < n; ++c) {
+    if (counts[c] == 0) continue;
+    const size_t part = (size_t)(counts[c] / active);
+    const char* sendbuf = reinterpret_cast<const char*>(inputs[c]);
+    char* recvbuf = reinterpret_cast<char*>(outputs[c]);
+    for (int64_t i = 0; i < active; ++i) {
+      const size_t off = (size_t)i * part * esize;
+      HBK_NCCL_OK(ncclSend(sendbuf + off, part, nt, ranks[i], comm->comm, comm->stream));
+      HBK_NCCL_OK(ncclRecv(recvbuf + off, part, nt, ranks[i], comm->comm, comm->stream));
+    }
+  }
+  HBK_NCCL_OK(ncclGroupEnd());
+  return fence_out(comm, as_stream(compute_stream));
+}
+
+extern "C" size_t hbk_alltoallv_wire_workspace_bytes(int32_t n, const int64_t* common_sizes,
+                                                     const int32_t* send_sizes,
+                                                     const int32_t* recv_sizes,
+                                                     int32_t active) {
+  if (n <= 0 || !common_sizes || !send_sizes || !recv_sizes || active <= 0) return 0;
+  size_t total = 0;
+  for (int32_t c = 0; c < n; ++c) {
+    int64_t s = 0, r = 0;
+    for (int32_t i = 0; i < active; ++i) {
+      s += send_sizes[(size_t)c * active + i];
+      r += recv_sizes[(size_t)c * active + i];
+    }
+    total += (((size_t)(s * common_sizes[c]) * 2 + 15) & ~(size_t)15) +
+             (((size_t)(r * common_sizes[c]) * 2 + 15) & ~(size_t)15);
+  }
+  return total;
+}
+
+extern "C" int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dtype,
+                               int32_t topology, const int64_t* common_sizes,
+                               const void* const* inputs, const int32_t* send_sizes,
+                               void* const* outputs, const int32_t* recv_sizes, void* wire_ws,
+                               size_t wire_ws_bytes, hbk_stream_t compute_stream) {
+  using namespace hbk;
+  HBK_REQUIRE(comm != nullptr, "alltoallv_n: comm is NULL");
+  HBK_REQUIRE(n >= 0, "alltoallv_n: n must be >= 0");
+  if (n == 0) return HBK_OK;
+  HBK_REQUIRE(common_sizes && inputs && send_sizes && outputs && recv_sizes,
+              "alltoallv_n: NULL argument array");
+  const bool half_wire = (dtype == HBK_FLOAT && wire_dtype == HBK_HALF);
+  HBK_REQUIRE(half_wire || wire_dtype == dtype || wire_dtype == HBK_FLOAT,
+              "alltoallv_n: wire_dtype must be float or half (half only for float data)");
+  ncclDataType_t nt;
+  HBK_REQUIRE(to_nccl(half_wire ? HBK_HALF : dtype, &nt), "alltoallv_n: unsupported dtype %d",
+              dtype);
+  const size_t esize = half_wire ? 2 : (size_t)dtype_size(dtype);
+  std::vector<int> ranks;
+  active_ranks(comm, topology, &ranks);
+  const int32_t active = (int32_t)ranks.size();
+
+  std::vector<int64_t> send_rows(n), recv_rows(n);
+  for (int32_t c = 0; c < n; ++c) {
+    HBK_REQUIRE(common_sizes[c] >= 1, "alltoallv_n: common_size[%d] must be >= 1", c);
+    int64_t s = 0, r = 0;
+    for (int32_t i = 0; i < active; ++i) {
+      HBK_REQUIRE(send_sizes[(size_t)c * active + i] >= 0 &&
+                      recv_sizes[(size_t)c * active + i] >= 0,
+                  "alltoallv_n: negative size for input %d", c);
+      s += send_sizes[(size_t)c * active + i];
+      r += recv_sizes[(size_t)c * active + i];
+    }
+    send_rows[c] = s;
+    recv_rows[c] = r;
+    HBK_REQUIRE((s == 0 || inputs[c]) && (r == 0 || outputs[c]),
+                "alltoallv_n: NULL buffer for input %d", c);
+  }
+
+  // fp16 wire: carve send / receive staging out of the workspace
+  std::vector<const void*> wire_in(n);
+  std::vector<void*> wire_out(n);
+  if (half_wire) {
+    const size_t need =
+        hbk_alltoallv_wire_workspace_bytes(n, common_sizes, send_sizes, recv_sizes, active);
+    HBK_REQUIRE(need == 0 || (wire_ws != nullptr && wire_ws_bytes >= need),
+                "alltoallv_n: wire workspace too small: need %zu bytes, got %zu", need,
+                wire_ws_bytes);
+    char* p = reinterpret_cast<char*>(wire_ws);
+    for (int32_t c = 0; c < n; ++c) {
+      wire_in[c] = p;
+      p += ((size_t)(send_rows[c] * common_sizes[c]) * 2 + 15) & ~(size_t)15;
+      wire_out[c] = p;
+      p += ((size_t)(recv_rows[c] * common_sizes[c]) * 2 + 15) & ~(size_t)15;
+    }
+  } else {
+    for (int32_t c = 0; c < n; ++c) {
+      wire_in[c] = inputs[c];
+      wire_out[c] = outputs[c];
+    }
+  }
+
+  std::unique_lock<std::mutex> lock(comm->mu);
+  HBK_REQUIRE(!comm->aborted, "alltoallv_n: communicator was aborted");
+  int rc = fence_in(comm, as_stream(compute_stream));
+  if (rc != HBK_OK) return rc;
+  if (half_wire) {
+    std::vector<int64_t> lens(n);
+    std::vector<void*> dst(n);
+    for (int32_t c = 0; c < n; ++c) {
+      lens[c] = send_rows[c] * common_sizes[c];
+      dst[c] = const_cast<void*>(wire_in[c]);
+    }
+    rc = cast_n_impl(n, HBK_FLOAT, HBK_HALF, inputs, lens.data(), dst.data(), comm->stream);
+    if (rc != HBK_OK) return rc;
+  }
+  HBK_NCCL_OK(ncclGroupStart());
+  for (int32_t c = 0; c < n; ++c) {
+    const char* sendbuf = reinterpret_cast<const char*>(wire_in[c]);
+    char* recvbuf = reinterpret_cast<char*>(wire_out[c]);
+    size_t sendoffset = 0, recvoffset = 0;  // bytes, 64-bit
+    for (int32_t i = 0; i < active; ++i) {
+      const size_t sendsize = (size_t)send_sizes[(size_t)c * active + i] * (size_t)common_sizes[c];
+      const size_t recvsize = (size_t)recv_sizes[(size_t)c * active + i] * (size_t)common_sizes[c];
+      if (sendsize > 0) {
+        HBK_NCCL_OK(ncclSend(sendbuf + sendoffset, sendsize, nt, ranks[i], comm->comm,
+                             comm->stream));
+      }
+      if (recvsize > 0) {
+        HBK_NCCL_OK(ncclRecv(recvbuf + recvoffset, recvsize, nt, ranks[i], comm->comm,
+                             comm->stream));
+      }
+      sendoffset += sendsize * esize;
+      recvoffset += recvsize * esize;
+    }
+  }
+  HBK_NCCL_OK(ncclGroupEnd());
+  if (half_wire) {
+    std::vector<int64_t> lens(n);
+    std::vector<const void*> src(n);
+    for (int32_t c = 0; c < n; ++c) {
+      lens[c] = recv_rows[c] * common_sizes[c];
+      src[c] = wire_out[c];
+    }
+    rc = cast_n_impl(n, HBK_HALF, HBK_FLOAT, src.data(), lens.data(), outputs, comm->stream);
+    if (rc != HBK_OK) return rc;
+  }
+  return fence_out(comm, as_stream(compute_stream));
+}

@@ -1,0 +1,131 @@
+// Internal helpers shared by the gfx950 kernels of libhbk_core.so.
+#ifndef HBK_CSRC_COMMON_H_
+#define HBK_CSRC_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "hbk.h"
+
+namespace hbk {
+
+// Thread-local message behind hbk_last_error(); returns `code` for `return fail(...)`.
+int fail(int code, const char* fmt, ...);
+
+#define HBK_HIP_OK(expr)                                                         \
+  do {                                                                           \
+    hipError_t e__ = (expr);                                                     \
+    if (e__ != hipSuccess) {                                                     \
+      return ::hbk::fail(HBK_INTERNAL, "%s failed: %s (%s:%d)", #expr,           \
+                         hipGetErrorString(e__), __FILE__, __LINE__);            \
+    }                                                                            \
+  } while (0)
+
+#define HBK_REQUIRE(cond, ...)                                                   \
+  do {                                                                           \
+    if (!(cond)) return ::hbk::fail(HBK_INVALID_ARGUMENT, __VA_ARGS__);          \
+  } while (0)
+
+inline hipStream_t as_stream(hbk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int dtype_size(int32_t dtype) {
+  switch (dtype) {
+    case HBK_INT8:
+    case HBK_UINT8:
+      return 1;
+    case HBK_HALF:
+      return 2;
+    case HBK_INT32:
+    case HBK_UINT32:
+    case HBK_FLOAT:
+      return 4;
+    case HBK_INT64:
+    case HBK_UINT64:
+    case HBK_DOUBLE:
+      return 8;
+    default:
+      return 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Division of a 64-bit value by a launch-invariant divisor without the ~100-instruction
+// software divide: round-up magic multiply (q = (((n - t) >> 1) + t) >> shift with
+// t = mulhi(magic, n)), exact for every 64-bit n.  kind 0: d == 1, kind 1: d = 2^shift.
+struct FastDiv {
+  uint64_t d;
+  uint64_t magic;
+  uint32_t shift;
+  uint32_t kind;
+};
+
+inline FastDiv make_fastdiv(uint64_t d) {
+  FastDiv f;
+  f.d = d;
+  f.magic = 0;
+  f.shift = 0;
+  f.kind = 0;
+  if (d <= 1) return f;
+  uint32_t k = 63u - (uint32_t)__builtin_clzll(d);  // floor(log2 d)
+  if ((d & (d - 1)) == 0) {
+    f.kind = 1;
+    f.shift = k;
+    return f;
+  }
+  // magic = floor(2^(65+k) / d) + 1 - 2^64
+  unsigned __int128 num = (unsigned __int128)1 << (64 + k);
+  uint64_t m = (uint64_t)(num / d);
+  uint64_t rem = (uint64_t)(num % d);
+  uint64_t m2 = m * 2;
+  uint64_t twice_rem = rem * 2;
+  if (twice_rem >= d || twice_rem < rem) m2 += 1;
+  f.magic = m2 + 1;
+  f.shift = k;
+  f.kind = 2;
+  return f;
+}
+
+__host__ __device__ inline uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+__host__ __device__ inline uint64_t fastdiv(uint64_t n, const FastDiv& f) {
+  if (f.kind == 0) return n;
+  if (f.kind == 1) return n >> f.shift;
+  uint64_t t = mulhi64(f.magic, n);
+  return (((n - t) >> 1) + t) >> f.shift;
+}
+
+__host__ __device__ inline uint64_t fastmod(uint64_t n, const FastDiv& f) {
+  if (f.kind == 0) return 0;
+  if (f.kind == 1) return n & (f.d - 1);
+  return n - fastdiv(n, f) * f.d;
+}
+
+// Python/TF floor-mod of a signed value by d > 0, result in [0, d).
+// For v < 0: floormod(v, d) = d - 1 - ((-v - 1) mod d), and -v - 1 == ~v.
+__host__ __device__ inline uint64_t floormod_i64(int64_t v, const FastDiv& f) {
+  uint64_t u = v < 0 ? (uint64_t)(~v) : (uint64_t)v;
+  uint64_t r = fastmod(u, f);
+  return v < 0 ? f.d - 1 - r : r;
+}
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+__device__ inline int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ inline int rank_below(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi(
+      (unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+}  // namespace hbk
+
+#endif  // HBK_CSRC_COMMON_H_

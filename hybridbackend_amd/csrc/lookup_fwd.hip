@@ -1,0 +1,269 @@
+// HbGroupLookup forward: fused multi-table bucketize -> HBM row gather -> segment
+// combiner for gfx950 (R1 + R7/R8 + R9 of DESIGN.md; replaces the per-column
+// FloorMod / Unique / GatherV2 x3 / SparseSegment* chain the reference builds in
+// hbtf/embedding/sharding.py:171-205 and docs/tutorial/ranking/data.py:179-193).
+//
+// Bandwidth-bound gather, no contraction -> no MFMA.  Design for CDNA4:
+//   * one launch for all N columns: a block finds its column with a wave-uniform scan of
+//     the tile prefix held in the kernel-argument segment (SGPR loads, no H2D pointer
+//     tables as in partition_by_modulo_functors.cu.cc:283-306);
+//   * a row of `dim` floats is owned by LPR = pow2(dim/4) adjacent lanes, each moving one
+//     16-byte chunk (global_load_dwordx4): a wave64 covers 64/LPR rows per instruction and
+//     keeps U independent row loads in flight per lane before the first use;
+//   * ids are read once per wave, fully coalesced (one id per lane), turned into row
+//     numbers with a multiply-high floor-mod (no 64-bit software divide) and handed to
+//     the owning lanes with ds_bpermute;
+//   * ids and outputs are streamed with non-temporal accesses so the L2/MALL capacity is
+//     left to the table rows.
+#include "lookup_common.h"
+
+namespace hbk {
+namespace {
+
+constexpr int kBlock = 256;           // 4 waves
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxColsPerLaunch = 30; // keeps LookupArgs under the 4 KB kernarg budget
+constexpr int kU = 4;                 // independent row loads per lane (one-id-per-segment path)
+constexpr int kSegIters = 4;          // segments per lane group and block (CSR path)
+
+struct ColArg {
+  const float* table;
+  const void* ids;
+  const int32_t* splits;
+  float* out;
+  int64_t n_seg;
+  IdMap map;
+  int32_t dim;
+  int32_t chunks;   // elements of width `vec` per row
+  uint8_t lpr_log2; // lanes per row = 1 << lpr_log2
+  uint8_t ids64;
+  uint8_t combiner;
+  uint8_t vec4;     // 1: 16-byte chunks, 0: 4-byte chunks (dim % 4 != 0 or unaligned)
+  uint32_t pad_;
+};
+
+struct LookupArgs {
+  int32_t n_cols;
+  int32_t tile_start[kMaxColsPerLaunch + 1];
+  ColArg col[kMaxColsPerLaunch];
+};
+static_assert(sizeof(LookupArgs) <= 4096, "kernarg budget");
+
+// ---------------------------------------------------------------------------------
+// one id per segment (Criteo scalar columns): out[s,:] = table[row(ids[s]),:]
+template <typename V, int U>
+__device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
+  constexpr int VE = sizeof(V) / 4;
+  const int lane = lane_id();
+  const int lpr_log2 = c.lpr_log2;
+  const int rpi = kWave >> lpr_log2;  // rows per wave instruction
+  const int sub = lane & ((1 << lpr_log2) - 1);
+  const int grp = lane >> lpr_log2;
+  const int64_t n_seg = c.n_seg;
+  const int dim = c.dim;
+
+  // ids: slot q (0 <= q < U*rpi) lives in register q>>6 of lane q&63
+  uint64_t rowreg[U];
+  const int n_slots = U * rpi;
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    rowreg[k] = kNoRow;
+    const int q = k * kWave + lane;
+    const int64_t s = wave_row0 + q;
+    if (q < n_slots && s < n_seg) rowreg[k] = id_to_row(c.map, load_id(c.ids, c.ids64, s));
+  }
+
+  V v[U];
+  const bool live = sub < c.chunks;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int q0 = u * rpi;  // multiple of rpi (a power of two <= 64): q0>>6 is uniform
+    const int k = q0 >> 6;
+    uint64_t src = rowreg[0];
+#pragma unroll
+    for (int kk = 1; kk < U; ++kk) src = (k == kk) ? rowreg[kk] : src;
+    const uint64_t r = shfl_u64(src, (q0 & (kWave - 1)) + grp);
+    v[u] = zero_v<V>();
+    if (live && r != kNoRow) {
+      v[u] = *reinterpret_cast<const V*>(c.table + r * (uint64_t)dim + (uint64_t)sub * VE);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t s = wave_row0 + u * rpi + grp;
+    if (live && s < n_seg) {
+      __builtin_nontemporal_store(
+          v[u], reinterpret_cast<V*>(c.out + s * (int64_t)dim + (int64_t)sub * VE));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// ragged segments (row_splits): out[s,:] = combine_j table[row(ids[j]),:], in order of j
+template <typename V>
+__device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
+  constexpr int VE = sizeof(V) / 4;
+  const int lane = lane_id();
+  const int lpr_log2 = c.lpr_log2;
+  const int lpr = 1 << lpr_log2;
+  const int rpi = kWave >> lpr_log2;
+  const int sub = lane & (lpr - 1);
+  const int grp = lane >> lpr_log2;
+  const int grp_lane0 = grp << lpr_log2;
+  const int64_t n_seg = c.n_seg;
+  const int dim = c.dim;
+  const bool live = sub < c.chunks;
+
+  for (int it = 0; it < kSegIters; ++it) {
+    const int64_t s = wave_seg0 + (int64_t)it * rpi + grp;
+    int32_t beg = 0, end = 0;
+    if (s < n_seg) {
+      beg = c.splits[s];
+      end = c.splits[s + 1];
+    }
+    V acc = zero_v<V>();
+    // group-cooperative id fetch: lane `sub` of the group owns id j0 + sub
+    int32_t j0 = beg;
+    uint64_t myrow = kNoRow;
+    if (j0 + sub < end) myrow = id_to_row(c.map, load_id(c.ids, c.ids64, j0 + sub));
+    while (__any(j0 < end)) {
+      // prefetch the next chunk of ids while this chunk's rows are in flight
+      uint64_t nextrow = kNoRow;
+      const int32_t j1 = j0 + lpr;
+      if (j1 + sub < end) nextrow = id_to_row(c.map, load_id(c.ids, c.ids64, j1 + sub));
+      const int32_t cnt = end - j0;  // ids of this group still to add (may be <= 0)
+      for (int t0 = 0; t0 < lpr; t0 += 4) {
+        V v[4];
+        bool p[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int tt = t0 + t;
+          const uint64_t r = shfl_u64(myrow, grp_lane0 + (tt & (lpr - 1)));
+          p[t] = tt < lpr && tt < cnt;
+          v[t] = zero_v<V>();
+          if (p[t] && live && r != kNoRow) {
+            v[t] = *reinterpret_cast<const V*>(c.table + r * (uint64_t)dim + (uint64_t)sub * VE);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (p[t]) acc = acc + v[t];
+        }
+      }
+      myrow = nextrow;
+      j0 = j1;
+    }
+    const int32_t n = end - beg;
+    if (n > 0 && c.combiner == HBK_COMBINER_MEAN) {
+      acc = acc / (float)n;
+    } else if (n > 0 && c.combiner == HBK_COMBINER_SQRTN) {
+      acc = acc / sqrtf((float)n);
+    }
+    if (live && s < n_seg) {
+      __builtin_nontemporal_store(
+          acc, reinterpret_cast<V*>(c.out + s * (int64_t)dim + (int64_t)sub * VE));
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupArgs a) {
+  const int b = (int)blockIdx.x;
+  int ci = 0;
+  while (ci + 1 < a.n_cols && a.tile_start[ci + 1] <= b) ++ci;
+  const ColArg& c = a.col[ci];
+  const int64_t tile = b - a.tile_start[ci];
+  const int wave = (int)(threadIdx.x >> 6);
+  const int rpi = kWave >> c.lpr_log2;
+  if (c.splits == nullptr) {
+    const int64_t row0 = (tile * kWavesPerBlock + wave) * (int64_t)(kU * rpi);
+    if (row0 >= c.n_seg) return;
+    if (c.vec4) {
+      gather_rows<f32x4, kU>(c, row0);
+    } else {
+      gather_rows<float, kU>(c, row0);
+    }
+  } else {
+    const int64_t seg0 = (tile * kWavesPerBlock + wave) * (int64_t)(kSegIters * rpi);
+    if (seg0 >= c.n_seg) return;
+    if (c.vec4) {
+      combine_segments<f32x4>(c, seg0);
+    } else {
+      combine_segments<float>(c, seg0);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace hbk
+
+extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
+                                    hbk_stream_t stream) {
+  using namespace hbk;
+  HBK_REQUIRE(n_cols >= 0, "group_lookup_fwd: n_cols must be >= 0, got %d", n_cols);
+  HBK_REQUIRE(n_cols == 0 || cols != nullptr, "group_lookup_fwd: cols is NULL");
+  for (int32_t c = 0; c < n_cols; ++c) {
+    const hbk_lookup_column_t& h = cols[c];
+    HBK_REQUIRE(h.dim >= 1, "group_lookup_fwd: column %d: dim must be >= 1, got %d", c, h.dim);
+    HBK_REQUIRE(h.dim <= 1024, "group_lookup_fwd: column %d: dim %d > 1024 unsupported", c,
+                h.dim);
+    HBK_REQUIRE(h.rows >= 0 && h.n_ids >= 0 && h.n_segments >= 0,
+                "group_lookup_fwd: column %d: negative size", c);
+    HBK_REQUIRE(h.ids_dtype == HBK_INT32 || h.ids_dtype == HBK_INT64,
+                "group_lookup_fwd: column %d: ids must be int32 or int64", c);
+    HBK_REQUIRE(h.bucket >= 0, "group_lookup_fwd: column %d: bucket must be >= 0", c);
+    HBK_REQUIRE(h.divisor >= 1, "group_lookup_fwd: column %d: divisor must be >= 1", c);
+    HBK_REQUIRE(h.combiner >= HBK_COMBINER_SUM && h.combiner <= HBK_COMBINER_SQRTN,
+                "group_lookup_fwd: column %d: unknown combiner %d", c, h.combiner);
+    HBK_REQUIRE(h.row_splits != nullptr || h.n_segments == h.n_ids,
+                "group_lookup_fwd: column %d: n_segments (%lld) must equal n_ids (%lld) "
+                "when row_splits is NULL",
+                c, (long long)h.n_segments, (long long)h.n_ids);
+    HBK_REQUIRE(h.n_segments == 0 || (h.table && h.out && (h.ids || h.n_ids == 0)),
+                "group_lookup_fwd: column %d: NULL buffer", c);
+    HBK_REQUIRE(h.n_ids < (1ll << 31) && h.n_segments < (1ll << 31),
+                "group_lookup_fwd: column %d: more than 2^31-1 ids/segments", c);
+  }
+
+  int32_t c0 = 0;
+  while (c0 < n_cols) {
+    LookupArgs args;
+    int32_t k = 0;
+    int64_t tiles = 0;
+    args.tile_start[0] = 0;
+    while (c0 < n_cols && k < kMaxColsPerLaunch) {
+      const hbk_lookup_column_t& h = cols[c0++];
+      if (h.n_segments == 0) continue;
+      ColArg& d = args.col[k];
+      d.table = h.table;
+      d.ids = h.ids;
+      d.splits = h.row_splits;
+      d.out = h.out;
+      d.n_seg = h.n_segments;
+      d.map = make_idmap(h.bucket, h.divisor, h.rows);
+      d.dim = h.dim;
+      RowShape shape;
+      HBK_REQUIRE(make_rowshape(h.dim, (uintptr_t)h.table | (uintptr_t)h.out, &shape),
+                  "group_lookup_fwd: dim %d needs more than 64 lanes per row "
+                  "(unaligned or dim %% 4 != 0 with dim > 64 is unsupported)", h.dim);
+      d.vec4 = shape.vec4;
+      d.chunks = shape.chunks;
+      d.lpr_log2 = shape.lpr_log2;
+      d.ids64 = h.ids_dtype == HBK_INT64;
+      d.combiner = (uint8_t)h.combiner;
+      d.pad_ = 0;
+      const int64_t rpi = kWave >> d.lpr_log2;
+      const int64_t per_block =
+          kWavesPerBlock * rpi * (h.row_splits ? kSegIters : kU);
+      tiles += (h.n_segments + per_block - 1) / per_block;
+      HBK_REQUIRE(tiles < (1ll << 31), "group_lookup_fwd: grid too large");
+      ++k;
+      args.tile_start[k] = (int32_t)tiles;
+    }
+    if (k == 0) continue;
+    args.n_cols = k;
+    hipLaunchKernelGGL(group_lookup_fwd_kernel, dim3((unsigned)tiles), dim3(kBlock), 0,
+                       as_stream(stream), args);
+    HBK_HIP_OK(hipGetLastError());
+  }
+  return HBK_OK;
+}

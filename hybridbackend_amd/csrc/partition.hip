@@ -1,0 +1,360 @@
+// HbPartitionByModulo[N] / HbPartitionByDualModuloStage{One,Two}[N] for gfx950 (R2, R3).
+//
+// Semantics = the reference CPU functor (a STABLE counting sort):
+//   hbtf/distribute/partition/partition_by_modulo_functors.cc:39-70
+//   hbtf/distribute/partition/partition_by_dual_modulo_functors.cc:37-91
+// The reference CUDA kernels take their slot with atomicAdd and are therefore not
+// order-stable (partition_by_modulo_functors.cu.cc:49-53); bit-exactness against the CPU
+// path needs the stable form, built here from wavefront ballots and prefix sums:
+//
+//   A  tile histogram   one wave64 per 1024-id tile, all N columns in one launch
+//                       (no max_len x N thread waste, cu.cc:139-149); LDS counters
+//   B  scan             per column: exclusive scan of hist[p][tile] in (p, tile) order ->
+//                       global start of every (shard, tile) run; sizes[p] falls out
+//   C  stable scatter   same tiling; per 64-id chunk a match-any loop (ballot of lanes with
+//                       the leader's shard) gives each id its rank inside the wave, the LDS
+//                       running counter gives the base; chunks are taken in order, so
+//                       input order is preserved inside every shard
+//
+// Column descriptors travel in the kernel-argument segment: no pinned pointer tables and
+// no H2D copies per call (cu.cc:283-306).  `%` never reaches the 64-bit software divide:
+// shards come from a multiply-high with a host-computed magic (common.h).
+#include <type_traits>
+
+#include "common.h"
+
+namespace hbk {
+namespace {
+
+constexpr int kChunks = 16;                   // 64-id chunks per tile
+constexpr int kTile = kChunks * kWave;        // 1024 ids per wave
+constexpr int kMaxColsPerLaunch = 64;
+constexpr int kMaxPartitions = 16384;         // LDS counters: 64 KB
+
+struct PartCol {
+  const void* in;
+  void* out;
+  int32_t* sizes;
+  int32_t* indices;
+  int32_t len;
+  int32_t tile_start;  // first tile of this column inside the launch group
+};
+
+struct ShardFn {
+  FastDiv pre;    // dual: P*M; plain: unused (d == 0)
+  FastDiv part;   // P
+  FastDiv mod;    // dual stage 2: M
+  int32_t stage;  // 0 plain modulo, 1 / 2 dual
+  int32_t num_partitions;
+};
+
+struct PartArgs {
+  int32_t n_cols;
+  int32_t total_tiles;
+  int32_t* hist;  // [sum over columns of P * tiles_c]; column c starts at P * tile_start[c]
+  ShardFn fn;
+  PartCol col[kMaxColsPerLaunch];
+};
+static_assert(sizeof(PartArgs) <= 4096, "kernarg budget");
+
+template <typename T>
+__device__ inline uint32_t shard_of(T v, const ShardFn& f) {
+  uint64_t r;
+  if (f.stage == 0) {
+    if constexpr (std::is_signed<T>::value) {
+      r = floormod_i64((int64_t)v, f.part);
+    } else {
+      r = fastmod((uint64_t)v, f.part);
+    }
+    return (uint32_t)r;
+  }
+  if constexpr (std::is_signed<T>::value) {
+    r = floormod_i64((int64_t)v, f.pre);
+  } else {
+    r = fastmod((uint64_t)v, f.pre);
+  }
+  if (f.stage == 1) return (uint32_t)fastmod(r, f.part);
+  return (uint32_t)fastdiv(r, f.mod);
+}
+
+__device__ inline int find_col(const PartArgs& a, int tile) {
+  int ci = 0;
+  while (ci + 1 < a.n_cols && a.col[ci + 1].tile_start <= tile) ++ci;
+  return ci;
+}
+
+// ---- A: per-tile histogram ------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a) {
+  extern __shared__ int32_t counters[];
+  const int tile = (int)blockIdx.x;
+  const int ci = find_col(a, tile);
+  const PartCol& c = a.col[ci];
+  const int P = a.fn.num_partitions;
+  const int lane = lane_id();
+  const int ctile = tile - c.tile_start;
+  const int n_tiles = (c.len + kTile - 1) / kTile;
+  for (int p = lane; p < P; p += kWave) counters[p] = 0;
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): zeroing done before the atomics
+  const T* in = reinterpret_cast<const T*>(c.in);
+  const int64_t base = (int64_t)ctile * kTile;
+  T v[kChunks];
+#pragma unroll
+  for (int k = 0; k < kChunks; ++k) {
+    const int64_t i = base + k * kWave + lane;
+    v[k] = i < c.len ? in[i] : T(0);
+  }
+#pragma unroll
+  for (int k = 0; k < kChunks; ++k) {
+    const int64_t i = base + k * kWave + lane;
+    if (i < c.len) atomicAdd(&counters[shard_of<T>(v[k], a.fn)], 1);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  int32_t* hist = a.hist + (int64_t)P * c.tile_start;
+  for (int p = lane; p < P; p += kWave) hist[(int64_t)p * n_tiles + ctile] = counters[p];
+}
+
+// ---- B: per-column exclusive scan of hist in (shard, tile) order ------------------
+constexpr int kScanBlock = 256;
+
+__global__ __launch_bounds__(kScanBlock) void partition_scan_kernel(const PartArgs a) {
+  __shared__ int32_t wave_tot[kScanBlock / kWave];
+  __shared__ int32_t carry_s;
+  const PartCol& c = a.col[blockIdx.x];
+  const int P = a.fn.num_partitions;
+  const int n_tiles = (c.len + kTile - 1) / kTile;
+  const int64_t total = (int64_t)P * n_tiles;
+  int32_t* hist = a.hist + (int64_t)P * c.tile_start;
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t e0 = 0; e0 < total; e0 += kScanBlock) {
+    const int64_t e = e0 + tid;
+    const int32_t x = e < total ? hist[e] : 0;
+    // inclusive scan inside the wave
+    int32_t s = x;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int32_t y = __shfl_up(s, off, kWave);
+      if (lane >= off) s += y;
+    }
+    if (lane == kWave - 1) wave_tot[wave] = s;
+    __syncthreads();
+    int32_t wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+    const int32_t carry = carry_s;
+    const int32_t excl = carry + wbase + s - x;
+    if (e < total) {
+      hist[e] = excl;
+      // first tile of shard p: its exclusive offset is the shard's start
+      if (n_tiles > 0 && e % n_tiles == 0) {
+        const int p = (int)(e / n_tiles);
+        // sizes[p-1] = start[p] - start[p-1] is finished below once all starts are known;
+        // stash the start in sizes[p] for now
+        c.sizes[p] = excl;
+      }
+    }
+    __syncthreads();
+    if (tid == kScanBlock - 1) carry_s = excl + x;
+    __syncthreads();
+  }
+  // sizes[p] currently holds start[p]; turn into counts: start[p+1] - start[p], start[P] = len
+  __syncthreads();
+  for (int p0 = 0; p0 < P; p0 += kScanBlock) {
+    const int p = p0 + tid;
+    int32_t cnt = 0;
+    if (p < P && n_tiles > 0) {
+      const int32_t st = c.sizes[p];
+      const int32_t nx = (p + 1 < P) ? c.sizes[p + 1] : c.len;
+      cnt = nx - st;
+    }
+    __syncthreads();
+    if (p < P) c.sizes[p] = cnt;
+    __syncthreads();
+  }
+}
+
+// ---- C: stable scatter --------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs a) {
+  extern __shared__ int32_t run_lds[];
+  volatile int32_t* run = run_lds;  // cross-lane hand-off inside one wave: keep every access
+  const int tile = (int)blockIdx.x;
+  const int ci = find_col(a, tile);
+  const PartCol& c = a.col[ci];
+  const int P = a.fn.num_partitions;
+  const int lane = lane_id();
+  const int ctile = tile - c.tile_start;
+  const int n_tiles = (c.len + kTile - 1) / kTile;
+  const int32_t* hist = a.hist + (int64_t)P * c.tile_start;
+  for (int p = lane; p < P; p += kWave) run[p] = hist[(int64_t)p * n_tiles + ctile];
+  const T* in = reinterpret_cast<const T*>(c.in);
+  T* out = reinterpret_cast<T*>(c.out);
+  const int64_t base = (int64_t)ctile * kTile;
+  T v[kChunks];
+#pragma unroll
+  for (int k = 0; k < kChunks; ++k) {
+    const int64_t i = base + k * kWave + lane;
+    v[k] = i < c.len ? in[i] : T(0);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // run[] initialised
+#pragma unroll
+  for (int k = 0; k < kChunks; ++k) {
+    const int64_t i = base + k * kWave + lane;
+    const bool valid = i < c.len;
+    const uint32_t shard = valid ? shard_of<T>(v[k], a.fn) : 0xffffffffu;
+    unsigned long long todo = __ballot(valid);
+    int32_t pos = 0;
+    while (todo != 0ull) {
+      const int leader = __builtin_ctzll(todo);
+      const uint32_t s = (uint32_t)__shfl((int)shard, leader, kWave);
+      const unsigned long long same = __ballot(shard == s);
+      const int32_t base_s = run[s];  // every lane reads the same address: LDS broadcast
+      if (shard == s) pos = base_s + rank_below(same);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if (lane == leader) run[s] = base_s + (int32_t)__builtin_popcountll(same);
+      todo &= ~same;
+    }
+    if (valid) {
+      out[pos] = v[k];
+      c.indices[i] = pos;
+    }
+  }
+}
+
+template <typename T>
+int launch_group(const PartArgs& args, int P, hipStream_t stream) {
+  const size_t lds = (size_t)P * sizeof(int32_t);
+  if (args.total_tiles > 0) {
+    hipLaunchKernelGGL(partition_hist_kernel<T>, dim3((unsigned)args.total_tiles),
+                       dim3(kWave), lds, stream, args);
+    HBK_HIP_OK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(partition_scan_kernel, dim3((unsigned)args.n_cols), dim3(kScanBlock), 0,
+                     stream, args);
+  HBK_HIP_OK(hipGetLastError());
+  if (args.total_tiles > 0) {
+    hipLaunchKernelGGL(partition_scatter_kernel<T>, dim3((unsigned)args.total_tiles),
+                       dim3(kWave), lds, stream, args);
+    HBK_HIP_OK(hipGetLastError());
+  }
+  return HBK_OK;
+}
+
+int64_t tiles_of(int64_t len) { return (len + kTile - 1) / kTile; }
+
+int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
+                   int32_t modulus, int32_t stage, const void* const* inputs,
+                   const int64_t* lens, void* const* outputs, int32_t* const* sizes,
+                   int32_t* const* indices, void* workspace, size_t workspace_bytes,
+                   hipStream_t stream) {
+  HBK_REQUIRE(n_cols >= 0, "%s: n_cols must be >= 0", what);
+  HBK_REQUIRE(P >= 1, "%s: num_partitions must be >= 1, got %d", what, P);
+  HBK_REQUIRE(P <= kMaxPartitions, "%s: num_partitions %d > %d unsupported", what, P,
+              kMaxPartitions);
+  HBK_REQUIRE(dtype == HBK_INT32 || dtype == HBK_INT64 || dtype == HBK_UINT32 ||
+                  dtype == HBK_UINT64,
+              "%s: T must be one of int32, int64, uint32, uint64", what);
+  if (stage != 0) {
+    HBK_REQUIRE(stage == 1 || stage == 2, "%s: stage must be 1 or 2", what);
+    HBK_REQUIRE(modulus >= 1, "%s: modulus must be >= 1, got %d", what, modulus);
+    HBK_REQUIRE((int64_t)P * modulus < (1ll << 31), "%s: num_partitions * modulus overflows",
+                what);
+  }
+  if (n_cols == 0) return HBK_OK;
+  HBK_REQUIRE(inputs && lens && outputs && sizes && indices, "%s: NULL argument array", what);
+  size_t need = hbk_partition_workspace_bytes(n_cols, lens, P);
+  HBK_REQUIRE(need == 0 || (workspace != nullptr && workspace_bytes >= need),
+              "%s: workspace too small: need %zu bytes, got %zu", what, need, workspace_bytes);
+  for (int32_t c = 0; c < n_cols; ++c) {
+    HBK_REQUIRE(lens[c] >= 0 && lens[c] < (1ll << 31),
+                "%s: input %d must have fewer than 2^31 elements (rank-1 int32 indices), got %lld",
+                what, c, (long long)lens[c]);
+    HBK_REQUIRE(sizes[c] != nullptr, "%s: sizes[%d] is NULL", what, c);
+    HBK_REQUIRE(lens[c] == 0 || (inputs[c] && outputs[c] && indices[c]),
+                "%s: NULL buffer for input %d", what, c);
+  }
+
+  ShardFn fn;
+  fn.stage = stage;
+  fn.num_partitions = P;
+  fn.part = make_fastdiv((uint64_t)P);
+  fn.pre = make_fastdiv(stage ? (uint64_t)P * (uint64_t)modulus : 1);
+  fn.mod = make_fastdiv(stage ? (uint64_t)modulus : 1);
+
+  int32_t* hist = reinterpret_cast<int32_t*>(workspace);
+  int32_t c0 = 0;
+  while (c0 < n_cols) {
+    PartArgs args;
+    args.fn = fn;
+    args.hist = hist;
+    int32_t k = 0;
+    int64_t tiles = 0;
+    while (c0 < n_cols && k < kMaxColsPerLaunch) {
+      PartCol& d = args.col[k];
+      d.in = inputs[c0];
+      d.out = outputs[c0];
+      d.sizes = sizes[c0];
+      d.indices = indices[c0];
+      d.len = (int32_t)lens[c0];
+      d.tile_start = (int32_t)tiles;
+      tiles += tiles_of(lens[c0]);
+      HBK_REQUIRE(tiles < (1ll << 31), "%s: too many tiles", what);
+      ++k;
+      ++c0;
+    }
+    args.n_cols = k;
+    args.total_tiles = (int32_t)tiles;
+    int rc;
+    switch (dtype) {
+      case HBK_INT32: rc = launch_group<int32_t>(args, P, stream); break;
+      case HBK_INT64: rc = launch_group<int64_t>(args, P, stream); break;
+      case HBK_UINT32: rc = launch_group<uint32_t>(args, P, stream); break;
+      default: rc = launch_group<uint64_t>(args, P, stream); break;
+    }
+    if (rc != HBK_OK) return rc;
+    hist += tiles * P;
+  }
+  return HBK_OK;
+}
+
+}  // namespace
+}  // namespace hbk
+
+extern "C" size_t hbk_partition_workspace_bytes(int32_t n_cols, const int64_t* lens,
+                                                int32_t num_partitions) {
+  if (n_cols <= 0 || lens == nullptr || num_partitions < 1) return 0;
+  int64_t tiles = 0;
+  for (int32_t c = 0; c < n_cols; ++c) {
+    if (lens[c] > 0) tiles += hbk::tiles_of(lens[c]);
+  }
+  return (size_t)tiles * (size_t)num_partitions * sizeof(int32_t);
+}
+
+extern "C" int hbk_partition_by_modulo_n(int32_t n_cols, int32_t dtype,
+                                         int32_t num_partitions, const void* const* inputs,
+                                         const int64_t* lens, void* const* outputs,
+                                         int32_t* const* sizes, int32_t* const* indices,
+                                         void* workspace, size_t workspace_bytes,
+                                         hbk_stream_t stream) {
+  return hbk::partition_impl("partition_by_modulo_n", n_cols, dtype, num_partitions, 1, 0,
+                             inputs, lens, outputs, sizes, indices, workspace,
+                             workspace_bytes, hbk::as_stream(stream));
+}
+
+extern "C" int hbk_partition_by_dual_modulo_n(int32_t n_cols, int32_t dtype,
+                                              int32_t num_partitions, int32_t modulus,
+                                              int32_t stage, const void* const* inputs,
+                                              const int64_t* lens, void* const* outputs,
+                                              int32_t* const* sizes, int32_t* const* indices,
+                                              void* workspace, size_t workspace_bytes,
+                                              hbk_stream_t stream) {
+  hbk::fail(HBK_OK, "");
+  if (stage != 1 && stage != 2) {
+    return hbk::fail(HBK_INVALID_ARGUMENT, "partition_by_dual_modulo_n: stage must be 1 or 2");
+  }
+  return hbk::partition_impl("partition_by_dual_modulo_n", n_cols, dtype, num_partitions,
+                             modulus, stage, inputs, lens, outputs, sizes, indices, workspace,
+                             workspace_bytes, hbk::as_stream(stream));
+}

@@ -1,0 +1,143 @@
+// HbLookup cache probe for gfx950 (R11): wave64 redesign of the reference's 32-lane
+// warp-cooperative slab probe (hbtf/embedding/lookup_functors.cu.cc:54-149, op
+// hbtf/embedding/lookup_ops.cc:38-145).  The per-key outcome is what the reference computes:
+//   slab = murmur3_hash32(key) % slab_count               (hybridbackend/common/murmur3.cu.h:32-77)
+//   hit  = first slot of the slab holding the key  -> slab*slab_size + slot
+//   miss = the slab holds an EMPTY (INT64_MIN, service.py:87) slot, or all slabs were probed
+//   otherwise continue with slab+1 (wrapping).
+// Mapping for CDNA4: a group of G = pow2(slab_size) adjacent lanes owns one key and reads one
+// slab per step (slot = lane in group, coalesced 8*slab_size bytes); match / empty are found
+// with one 64-bit ballot masked to the group, so a wave64 probes 64/G keys concurrently
+// instead of one (the reference serialises its 32 keys through one slab read at a time).
+#include "common.h"
+
+namespace hbk {
+
+__host__ __device__ inline uint32_t rotl32(uint32_t x, int r) {
+  return (x << r) | (x >> (32 - r));
+}
+
+// murmur3_hash32<int64, seed 0>: two 4-byte blocks, no tail, len = 8.
+__host__ __device__ inline uint32_t murmur3_hash32_i64(int64_t key) {
+  const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
+  uint32_t h1 = 0;
+  uint32_t blocks[2] = {(uint32_t)((uint64_t)key & 0xffffffffu),
+                        (uint32_t)((uint64_t)key >> 32)};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    uint32_t k1 = blocks[i];
+    k1 *= c1;
+    k1 = rotl32(k1, 15);
+    k1 *= c2;
+    h1 ^= k1;
+    h1 = rotl32(h1, 13);
+    h1 = h1 * 5 + 0xe6546b64u;
+  }
+  h1 ^= 8u;
+  h1 ^= h1 >> 16;
+  h1 *= 0x85ebca6bu;
+  h1 ^= h1 >> 13;
+  h1 *= 0xc2b2ae35u;
+  h1 ^= h1 >> 16;
+  return h1;
+}
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr long long kEmptyKey = (long long)0x8000000000000000ull;
+
+__global__ __launch_bounds__(kBlock) void murmur3_kernel(const int64_t* keys, int64_t n,
+                                                         uint32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = murmur3_hash32_i64(keys[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void cache_probe_kernel(
+    const int64_t* __restrict__ keys_cache, FastDiv slab_div, int32_t slab_size,
+    int32_t group_log2, const int64_t* __restrict__ keys, int64_t n_keys,
+    int64_t* __restrict__ hit_slot, int32_t* __restrict__ n_miss) {
+  const int lane = lane_id();
+  const int gsize = 1 << group_log2;
+  const int sub = lane & (gsize - 1);
+  const int grp = lane >> group_log2;
+  const int groups_per_wave = kWave >> group_log2;
+  const int64_t wave_global = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int64_t i = wave_global * groups_per_wave + grp;
+  const unsigned long long group_mask =
+      (gsize == 64 ? ~0ull : ((1ull << gsize) - 1ull)) << (grp << group_log2);
+  const int64_t slab_count = (int64_t)slab_div.d;
+
+  bool active = i < n_keys;
+  int64_t key = active ? keys[i] : 0;
+  int64_t slab = active ? (int64_t)fastmod((uint64_t)murmur3_hash32_i64(key), slab_div) : 0;
+  int64_t result = -1;
+  int64_t probed = 0;
+  while (__any(active)) {
+    long long read_key = 0;
+    const bool in_slab = active && sub < slab_size;
+    if (in_slab) read_key = keys_cache[slab * slab_size + sub];
+    const unsigned long long match = __ballot(in_slab && read_key == key) & group_mask;
+    const unsigned long long empty = __ballot(in_slab && read_key == kEmptyKey) & group_mask;
+    if (active) {
+      if (match != 0ull) {
+        const int good = __builtin_ctzll(match) - (grp << group_log2);
+        result = slab * slab_size + good;
+        active = false;
+      } else if (empty != 0ull) {
+        active = false;
+      } else {
+        ++probed;
+        slab = slab + 1 == slab_count ? 0 : slab + 1;
+        if (probed >= slab_count) active = false;
+      }
+    }
+  }
+  if (i < n_keys && sub == 0) hit_slot[i] = result;
+  if (n_miss != nullptr) {
+    const unsigned long long missed = __ballot(i < n_keys && sub == 0 && result < 0);
+    if (lane == 0 && missed != 0ull) atomicAdd(n_miss, (int32_t)__builtin_popcountll(missed));
+  }
+}
+
+}  // namespace
+}  // namespace hbk
+
+extern "C" int hbk_murmur3_hash32(const int64_t* keys, int64_t n_keys, uint32_t* out,
+                                  hbk_stream_t stream) {
+  using namespace hbk;
+  HBK_REQUIRE(n_keys >= 0, "murmur3_hash32: n_keys must be >= 0");
+  if (n_keys == 0) return HBK_OK;
+  HBK_REQUIRE(keys && out, "murmur3_hash32: NULL buffer");
+  const int64_t blocks = (n_keys + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(murmur3_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream),
+                     keys, n_keys, out);
+  HBK_HIP_OK(hipGetLastError());
+  return HBK_OK;
+}
+
+extern "C" int hbk_cache_probe(const int64_t* keys_cache, int64_t slab_count,
+                               int32_t slab_size, const int64_t* keys, int64_t n_keys,
+                               int64_t* hit_slot, int32_t* n_miss, hbk_stream_t stream) {
+  using namespace hbk;
+  HBK_REQUIRE(slab_size >= 1 && slab_size <= kWave,
+              "cache_probe: cache_slab_size must be in [1, 64], got %d", slab_size);
+  HBK_REQUIRE(slab_count >= 1, "cache_probe: keys_cache must hold at least one slab");
+  HBK_REQUIRE(n_keys >= 0, "cache_probe: n_keys must be >= 0");
+  if (n_miss != nullptr) {
+    HBK_HIP_OK(hipMemsetAsync(n_miss, 0, sizeof(int32_t), as_stream(stream)));
+  }
+  if (n_keys == 0) return HBK_OK;
+  HBK_REQUIRE(keys_cache && keys && hit_slot, "cache_probe: NULL buffer");
+  int group_log2 = 0;
+  while ((1 << group_log2) < slab_size) ++group_log2;
+  const int64_t groups_per_block = (kBlock >> group_log2);
+  const int64_t blocks = (n_keys + groups_per_block - 1) / groups_per_block;
+  FastDiv sd = make_fastdiv((uint64_t)slab_count);
+  sd.d = (uint64_t)slab_count;
+  hipLaunchKernelGGL(cache_probe_kernel, dim3((unsigned)blocks), dim3(kBlock), 0,
+                     as_stream(stream), keys_cache, sd, slab_size, group_log2, keys, n_keys,
+                     hit_slot, n_miss);
+  HBK_HIP_OK(hipGetLastError());
+  return HBK_OK;
+}

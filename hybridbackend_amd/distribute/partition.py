@@ -1,0 +1,112 @@
+"""Integer partition ("shuffle") of id vectors -- host mirror of
+``hybridbackend/tensorflow/distribute/partition/ops.py:58-221`` over the C ABI.
+
+Same names, argument meaning and error behaviour as the reference's Python ops:
+``partition_by_modulo(ids, num_partitions)`` returns ``(output, sizes, indices)``
+with ``output[indices] == ids`` (partition_test.py:57-59).  The N-ary forms are
+what the reference's ``Pack`` graph pass turns K independent ops into
+(``HbPartitionByModuloN``, graph/common/packing.cc:124-575): one launch group for
+all columns.
+"""
+import torch
+
+from hybridbackend_amd import _lib
+
+
+class _Workspace:
+  """Grow-only device scratch, one per (device, stream-agnostic) caller."""
+
+  def __init__(self):
+    self._buf = None
+
+  def get(self, nbytes, device):
+    if nbytes == 0:
+      return None, 0
+    if self._buf is None or self._buf.numel() < nbytes or self._buf.device != device:
+      self._buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    return self._buf, self._buf.numel()
+
+
+_ws = _Workspace()
+
+
+def _partition_n(ids_list, num_partitions, modulus, stage, outputs=None):
+  lib = _lib.lib()
+  n = len(ids_list)
+  if n == 0:
+    return [], [], []
+  dtype = ids_list[0].dtype
+  device = ids_list[0].device
+  for t in ids_list:
+    _lib.require_device_tensor(t, 'ids')
+    if t.dim() != 1:
+      raise _lib.InvalidArgumentError(
+        _lib.INVALID_ARGUMENT, 'Input must be a vector')  # partition_by_modulo_ops.cc:81-83
+    if t.dtype != dtype:
+      raise _lib.InvalidArgumentError(
+        _lib.INVALID_ARGUMENT, 'all inputs of an N-ary partition share one dtype')
+  code = _lib.torch_dtype_code(dtype)
+  lens = [int(t.numel()) for t in ids_list]
+  if outputs is None:
+    outs = [torch.empty_like(t) for t in ids_list]
+    sizes = [torch.empty(max(num_partitions, 0), dtype=torch.int32, device=device)
+             for _ in ids_list]
+    idxs = [torch.empty(t.numel(), dtype=torch.int32, device=device)
+            for t in ids_list]
+  else:
+    outs, sizes, idxs = outputs
+  lens_a = _lib.i64_array(lens)
+  need = lib.hbk_partition_workspace_bytes(n, lens_a, num_partitions)
+  ws, ws_bytes = _ws.get(need, device)
+  args = (_lib.ptr_array([t.data_ptr() for t in ids_list]), lens_a,
+          _lib.ptr_array([t.data_ptr() for t in outs]),
+          _lib.ptr_array([t.data_ptr() for t in sizes]),
+          _lib.ptr_array([t.data_ptr() for t in idxs]),
+          ws.data_ptr() if ws is not None else None, ws_bytes,
+          _lib.current_stream(device))
+  if stage == 0:
+    _lib.check(lib.hbk_partition_by_modulo_n(n, code, num_partitions, *args))
+  else:
+    _lib.check(lib.hbk_partition_by_dual_modulo_n(
+      n, code, num_partitions, modulus, stage, *args))
+  return outs, sizes, idxs
+
+
+def partition_by_modulo(ids, num_partitions, name=None):
+  r'''Shuffle IDs using floormod strategy (ops.py:88-105; op HbPartitionByModulo).
+
+  Returns:
+    output: A tensor with shuffled IDs.
+    sizes: Size of each shard in output.
+    indices: Indices for gathering back.
+  '''
+  del name
+  o, s, i = _partition_n([ids], num_partitions, 1, 0)
+  return o[0], s[0], i[0]
+
+
+def partition_by_modulo_n(ids_list, num_partitions, name=None):
+  r'''N-ary form (op HbPartitionByModuloN, partition_by_modulo_ops.cc:124-143).'''
+  del name
+  return _partition_n(list(ids_list), num_partitions, 1, 0)
+
+
+def partition_by_dual_modulo_stage_one(ids, num_partitions, modulus, name=None):
+  r'''Stage 1 of the two-staged (local modulo, global modulo) shuffle
+  (ops.py:108-164; op HbPartitionByDualModuloStageOne).'''
+  del name
+  o, s, i = _partition_n([ids], num_partitions, modulus, 1)
+  return o[0], s[0], i[0]
+
+
+def partition_by_dual_modulo_stage_two(ids, num_partitions, modulus, name=None):
+  r'''Stage 2 (ops.py:167-221; op HbPartitionByDualModuloStageTwo).'''
+  del name
+  o, s, i = _partition_n([ids], num_partitions, modulus, 2)
+  return o[0], s[0], i[0]
+
+
+def partition_by_dual_modulo_n(ids_list, num_partitions, modulus, stage, name=None):
+  r'''N-ary dual-modulo shuffle; stage is 1 or 2.'''
+  del name
+  return _partition_n(list(ids_list), num_partitions, modulus, stage)

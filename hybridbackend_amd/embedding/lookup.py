@@ -1,0 +1,131 @@
+"""GroupLookup: fused multi-table sparse embedding lookup (forward) -- the host side
+of the new additive op ``HbGroupLookup`` (include/hbk.h) that replaces, for N columns
+at once, what the reference builds per column out of stock TF ops:
+
+  ``feature % embedding_size`` (docs/tutorial/ranking/data.py:179,186)
+  -> ``tf.nn.embedding_lookup_sparse(weights, sp_ids, None)`` (data.py:189), whose
+     ``embedding_lookup`` is patched by hybridbackend/tensorflow/embedding/sharding.py:171-205.
+
+Ragged id lists use the values + row_splits layout HybridBackend's own data path
+produces (hybridbackend/tensorflow/data/dataframe.py:366-376).
+"""
+import ctypes as C
+
+import torch
+
+from hybridbackend_amd import _lib
+
+_COMBINERS = {None: _lib.COMBINER_MEAN,  # embedding_lookup_sparse default
+              'sum': _lib.COMBINER_SUM, 'mean': _lib.COMBINER_MEAN,
+              'sqrtn': _lib.COMBINER_SQRTN}
+
+
+def _combiner_code(c):
+  if isinstance(c, int):
+    return c
+  if c not in _COMBINERS:
+    raise _lib.InvalidArgumentError(
+      _lib.INVALID_ARGUMENT, "combiner must be one of 'mean', 'sqrtn' or 'sum'")
+  return _COMBINERS[c]
+
+
+class GroupLookup:
+  """A group of N embedding columns looked up with one launch.
+
+  Args:
+    tables: list of fp32 ``[rows, dim]`` device tensors (the local shard when sharded).
+    buckets: per-column ``embedding_size`` for the fused bucketize, or None/0.
+    combiners: per-column 'sum' | 'mean' | 'sqrtn' | None (= mean), or one for all.
+    divisor: ``row = id // divisor`` after bucketize (owner side of a sharded table,
+      sharding.py:189); 1 for a whole table.
+  """
+
+  def __init__(self, tables, buckets=None, combiners='sum', divisor=1):
+    self._lib = _lib.lib()
+    self.tables = list(tables)
+    n = len(self.tables)
+    for t in self.tables:
+      _lib.require_device_tensor(t, 'embedding weights')
+      if t.dtype != torch.float32 or t.dim() != 2:
+        raise _lib.InvalidArgumentError(
+          _lib.INVALID_ARGUMENT, 'embedding weights must be fp32 [rows, dim]')
+    if buckets is None:
+      buckets = [0] * n
+    if isinstance(combiners, (str, int)) or combiners is None:
+      combiners = [combiners] * n
+    self.buckets = [int(b or 0) for b in buckets]
+    self.combiners = [_combiner_code(c) for c in combiners]
+    self.divisor = int(divisor)
+    self._cols = (_lib.LookupColumn * n)()
+    for c, t in enumerate(self.tables):
+      col = self._cols[c]
+      col.table = t.data_ptr()
+      col.rows = t.shape[0]
+      col.dim = t.shape[1]
+      col.bucket = self.buckets[c]
+      col.divisor = self.divisor
+      col.combiner = self.combiners[c]
+
+  def __len__(self):
+    return len(self.tables)
+
+  def bind(self, ids, row_splits=None, outs=None):
+    """Point the column descriptors at this step's inputs/outputs; returns outs."""
+    n = len(self.tables)
+    if len(ids) != n:
+      raise _lib.InvalidArgumentError(
+        _lib.INVALID_ARGUMENT, f'expected {n} id tensors, got {len(ids)}')
+    if row_splits is None:
+      row_splits = [None] * n
+    if outs is None:
+      outs = [None] * n
+    outs = list(outs)
+    for c in range(n):
+      i = ids[c]
+      _lib.require_device_tensor(i, 'ids')
+      if i.dtype not in (torch.int32, torch.int64) or i.dim() != 1:
+        raise _lib.InvalidArgumentError(
+          _lib.INVALID_ARGUMENT, 'ids must be an int32/int64 vector')
+      s = row_splits[c]
+      if s is not None:
+        _lib.require_device_tensor(s, 'row_splits')
+        if s.dtype != torch.int32 or s.dim() != 1 or s.numel() < 1:
+          raise _lib.InvalidArgumentError(
+            _lib.INVALID_ARGUMENT, 'row_splits must be an int32 vector [segments+1]')
+      n_seg = i.numel() if s is None else s.numel() - 1
+      if outs[c] is None:
+        outs[c] = torch.empty((n_seg, self.tables[c].shape[1]), dtype=torch.float32,
+                              device=self.tables[c].device)
+      o = outs[c]
+      _lib.require_device_tensor(o, 'output')
+      if o.dtype != torch.float32 or tuple(o.shape) != (n_seg, self.tables[c].shape[1]):
+        raise _lib.InvalidArgumentError(
+          _lib.INVALID_ARGUMENT, f'output {c} must be fp32 [{n_seg}, dim]')
+      col = self._cols[c]
+      col.ids_dtype = _lib.INT64 if i.dtype == torch.int64 else _lib.INT32
+      col.ids = i.data_ptr()
+      col.n_ids = i.numel()
+      col.row_splits = s.data_ptr() if s is not None else None
+      col.n_segments = n_seg
+      col.out = o.data_ptr()
+    self._keep = (ids, row_splits, outs)
+    return outs
+
+  def launch(self, stream=None):
+    """Enqueue the bound lookup on `stream` (a torch stream; default: current)."""
+    if stream is None:
+      s = _lib.current_stream(self.tables[0].device if self.tables else None)
+    else:
+      s = C.c_void_p(stream.cuda_stream)
+    _lib.check(self._lib.hbk_group_lookup_fwd(len(self.tables), self._cols, s))
+
+  def __call__(self, ids, row_splits=None, outs=None):
+    outs = self.bind(ids, row_splits, outs)
+    self.launch()
+    return outs
+
+
+def group_lookup(tables, ids, row_splits=None, buckets=None, combiners='sum', divisor=1,
+                 outs=None):
+  """Functional form: one fused launch over N columns; returns the list of outputs."""
+  return GroupLookup(tables, buckets, combiners, divisor)(ids, row_splits, outs)

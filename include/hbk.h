@@ -1,0 +1,275 @@
+/*
+ * hbk.h -- C ABI of libhbk_core.so: the MI355X (gfx950) sharded-embedding engine that
+ * sits behind HybridBackend's TensorFlow custom-op surface.
+ *
+ * This is the drop-in boundary (DESIGN.md "Boundary").  Every entry point replaces the
+ * device side of one reference op family; the citation after each declaration is the
+ * reference interface it stands in for (paths relative to the reference tree,
+ * hbtf/ = hybridbackend/tensorflow/).  INTEGRATION.md shows the REGISTER_OP /
+ * REGISTER_KERNEL_BUILDER shim a maintainer adds on the TensorFlow side.
+ *
+ * Conventions (mirroring the reference's):
+ *   - extern "C", plain pointers and sizes; no TF / torch / HIP types in signatures.
+ *     `hbk_stream_t` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - The caller owns every buffer (TF: ctx->allocate_output / allocate_temp); the
+ *     library never frees caller memory.  Scratch is a caller-provided workspace whose
+ *     size comes from the matching hbk_*_workspace_bytes() query.
+ *   - All device work is enqueued on the given stream and returns without a host
+ *     sync unless the entry point's comment says otherwise.
+ *   - Return value: 0 (HBK_OK) or a TensorFlow error code (the reference maps
+ *     CUDA/NCCL failures to errors::Internal and shape violations to
+ *     errors::InvalidArgument: hbtf/common/host_functions.h:37-42,
+ *     hbtf/distribute/partition/partition_by_modulo_ops.cc:81-83).
+ *     hbk_last_error() returns the calling thread's last message.  Never throws.
+ *   - Re-entrant: compute entry points keep no global mutable state.  One communicator
+ *     is one ordered queue; the caller issues collective calls in the same order on
+ *     every rank (the reference guarantees this with graph linearisation,
+ *     hbtf/graph/common/linearization.cc:42-82).
+ */
+#ifndef HBK_H_
+#define HBK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hbk_stream_t;
+
+/* status = TensorFlow error codes */
+#define HBK_OK 0
+#define HBK_INVALID_ARGUMENT 3
+#define HBK_UNIMPLEMENTED 12
+#define HBK_INTERNAL 13
+
+/* dtypes: the list HbNcclAlltoallv accepts (hbtf/distribute/nccl/types.h:59-67) */
+#define HBK_INT8 0
+#define HBK_UINT8 1
+#define HBK_INT32 2
+#define HBK_UINT32 3
+#define HBK_INT64 4
+#define HBK_UINT64 5
+#define HBK_HALF 6
+#define HBK_FLOAT 7
+#define HBK_DOUBLE 8
+
+/* combiner of tf.nn.embedding_lookup_sparse (None => mean) */
+#define HBK_COMBINER_SUM 0
+#define HBK_COMBINER_MEAN 1
+#define HBK_COMBINER_SQRTN 2
+
+/* hbtf/distribute/ops.py:34-39, hbtf/distribute/collective.h:52-56 */
+#define HBK_TOPOLOGY_ALL 0
+#define HBK_TOPOLOGY_INTRA_NODE 1
+#define HBK_TOPOLOGY_INTER_NODE 2
+
+const char* hbk_last_error(void);
+/* "hbk <version> gfx950" */
+const char* hbk_version(void);
+/* test hooks: the kernels' divide-free floor-mod / floor-div (multiply-high by a
+ * host-computed magic) evaluated on the host, so the integer arithmetic can be checked
+ * against Python's % and // without a GPU.  d > 0. */
+int64_t hbk_host_floormod_i64(int64_t v, int64_t d);
+uint64_t hbk_host_fastdiv_u64(uint64_t n, uint64_t d);
+
+/* ------------------------------------------------------------------------------------
+ * R1  bucketize `feature % embedding_size` (TF FloorMod), N columns in one launch.
+ *     docs/tutorial/ranking/data.py:179,186.  dtype HBK_INT32 | HBK_INT64.
+ *     out may alias in.  buckets[c] > 0. */
+int hbk_floormod_n(int32_t n_cols, int32_t dtype, const void* const* inputs,
+                   const int64_t* lens, const int64_t* buckets, void* const* outputs,
+                   hbk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * R2  HbPartitionByModulo / HbPartitionByModuloN
+ *     ops: hbtf/distribute/partition/partition_by_modulo_ops.cc:46-60, :124-143
+ *     semantics = the CPU functor (STABLE counting sort), partition_by_modulo_functors.cc:39-70:
+ *       shard = ((v % P) + P) % P;  outputs[c] = ids grouped by shard, input order kept
+ *       inside a shard;  sizes[c][p] = count;  indices[c][i] = position of inputs[c][i]
+ *       in outputs[c]  (so outputs[c][indices[c]] == inputs[c]).
+ *     dtype: HBK_INT32 | HBK_INT64 | HBK_UINT32 | HBK_UINT64.  n_cols = 1 covers the
+ *     non-N op.  lens[c] < 2^31 (indices are int32, as in the reference).
+ *     1 <= num_partitions <= 16384. */
+size_t hbk_partition_workspace_bytes(int32_t n_cols, const int64_t* lens,
+                                     int32_t num_partitions);
+int hbk_partition_by_modulo_n(int32_t n_cols, int32_t dtype, int32_t num_partitions,
+                              const void* const* inputs, const int64_t* lens,
+                              void* const* outputs, int32_t* const* sizes,
+                              int32_t* const* indices, void* workspace,
+                              size_t workspace_bytes, hbk_stream_t stream);
+
+/* R3  HbPartitionByDualModuloStage{One,Two}[N]
+ *     ops: hbtf/distribute/partition/partition_by_dual_modulo_ops.cc:46-61,132-147,184-204,278-298
+ *     functor: partition_by_dual_modulo_functors.cc:37-91
+ *       pre = ((v % (P*M)) + P*M) % (P*M);  stage 1: shard = pre % P;  stage 2: shard = pre / M
+ *     stage is 1 or 2; modulus >= 1. */
+int hbk_partition_by_dual_modulo_n(int32_t n_cols, int32_t dtype, int32_t num_partitions,
+                                   int32_t modulus, int32_t stage,
+                                   const void* const* inputs, const int64_t* lens,
+                                   void* const* outputs, int32_t* const* sizes,
+                                   int32_t* const* indices, void* workspace,
+                                   size_t workspace_bytes, hbk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * R6  fp32 <-> fp16 wire casts, N tensors in one launch.
+ *     hbtf/common/cast.h:40-54, cast.cu.cc:37-42,60-65,84-95,287 (functor::Cast / CastN).
+ *     (src,dst) = (HBK_FLOAT,HBK_HALF) round-to-nearest-even, or (HBK_HALF,HBK_FLOAT). */
+int hbk_cast_n(int32_t n, int32_t src_dtype, int32_t dst_dtype, const void* const* inputs,
+               const int64_t* lens, void* const* outputs, hbk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * R7  owner-side unique (TF `array_ops.unique`, hbtf/embedding/sharding.py:186):
+ *     unique_out[c] = distinct ids in FIRST-OCCURRENCE order, index_out[c][i] = position of
+ *     inputs[c][i] in unique_out[c], n_unique[c] (device int32) = number of distinct ids.
+ *     ids int64.  unique_out[c] has capacity lens[c]. */
+size_t hbk_unique_workspace_bytes(int32_t n_cols, const int64_t* lens);
+int hbk_unique_n(int32_t n_cols, const int64_t* const* inputs, const int64_t* lens,
+                 int64_t* const* unique_out, int32_t* const* index_out,
+                 int32_t* const* n_unique, void* workspace, size_t workspace_bytes,
+                 hbk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * R1+R7+R8+R9 fused:  HbGroupLookup (new, additive op; N-ary conventions of the
+ * reference's Hb...N ops so Pack-style grouping can target it).  Per column c
+ *     row(j)   = ids[j]                       (bucket == 0)
+ *              = floormod(ids[j], bucket)     (bucket  > 0)            -- R1
+ *     row(j)   = row(j) / divisor             (owner-side `// W`, sharding.py:189)
+ *     out[s,:] = combine_{j in [row_splits[s], row_splits[s+1])} table[row(j), :]
+ *   row_splits == NULL means one id per segment (Criteo scalar columns; the combiner is
+ *   then the identity and out = table[row(ids)]).  Rows outside [0, rows) contribute
+ *   zeros (TF GPU GatherV2 behaviour).  The unique/restore pair of the reference
+ *   (sharding.py:186,193) is value-transparent in the forward and is not materialised.
+ *   replaces: tf.nn.embedding_lookup_sparse as patched by
+ *   hbtf/embedding/sharding.py:171-205 (local part) and docs/tutorial/ranking/data.py:179-193.
+ *   fp32 tables, fixed in-order accumulation over j.                                   */
+typedef struct {
+  const float* table;        /* device [rows, dim] row-major */
+  int64_t rows;
+  int32_t dim;
+  int32_t ids_dtype;         /* HBK_INT32 | HBK_INT64 */
+  const void* ids;           /* device [n_ids] */
+  int64_t n_ids;
+  const int32_t* row_splits; /* device [n_segments + 1] or NULL */
+  int64_t n_segments;        /* == n_ids when row_splits == NULL */
+  int64_t bucket;            /* 0 = ids are row numbers already */
+  int32_t divisor;           /* >= 1 */
+  int32_t combiner;          /* HBK_COMBINER_* */
+  float* out;                /* device [n_segments, dim] */
+} hbk_lookup_column_t;
+
+int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
+                         hbk_stream_t stream);
+
+/* R10  HbGroupLookupGrad: backward of the above up to the IndexedSlices the optimizer
+ *   gets (SparseSegment*Grad -> UnsortedSegmentSum dup-reduction):
+ *     unique_rows[c][u]  = distinct row(j) in first-occurrence order   (int64)
+ *     grad_rows[c][u,:]  = sum_{j: row(j) == unique_rows[u]} scale(seg(j)) * grad_out[seg(j),:]
+ *     n_unique[c]        = u   (device int32)
+ *   scale = 1 (sum), 1/count (mean), 1/sqrt(count) (sqrtn).  grad_rows has capacity
+ *   [n_ids, dim] and is fully overwritten for rows < u.  Duplicate ids inside a wavefront
+ *   are pre-reduced (ballot/match) before the fp32 atomic add, so summation order is not
+ *   fixed: tolerance 1e-5 relative.
+ *   apply_lr != 0 additionally performs the sparse SGD update on the shard in the same
+ *   pass: table[unique_rows[u],:] -= apply_lr * grad_rows[u,:] (sharded variables skip
+ *   cross-rank aggregation, hbtf/training/gradient.py:193-217).                        */
+typedef struct {
+  float* table;              /* device [rows, dim]; only touched when apply_lr != 0 */
+  int64_t rows;
+  int32_t dim;
+  int32_t ids_dtype;
+  const void* ids;
+  int64_t n_ids;
+  const int32_t* row_splits;
+  int64_t n_segments;
+  int64_t bucket;
+  int32_t divisor;
+  int32_t combiner;
+  const float* grad_out;     /* device [n_segments, dim] */
+  int64_t* unique_rows;      /* device [n_ids] */
+  float* grad_rows;          /* device [n_ids, dim] */
+  int32_t* n_unique;         /* device [1] */
+} hbk_lookup_grad_column_t;
+
+size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
+                                            const hbk_lookup_grad_column_t* cols);
+int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
+                         float apply_lr, void* workspace, size_t workspace_bytes,
+                         hbk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * R11 HbLookup: cache probe.  op hbtf/embedding/lookup_ops.cc:38-58; kernel
+ *     hbtf/embedding/lookup_functors.cu.cc:54-149; hash hybridbackend/common/murmur3.cu.h:32-77.
+ *     slab = murmur3_hash32(key) % slab_count; a slab is `slab_size` consecutive int64 keys
+ *     (the reference fixes 32 = its warp; here 1..64, one wave64 probes a slab with one
+ *     ballot); first matching slot -> hit; an EMPTY (INT64_MIN) slot in the slab -> miss;
+ *     else next slab (linear, wrapping).
+ *     hit_slot[i] = cache index (slab*slab_size+slot) or -1 for a miss -- a per-key result
+ *     in key order (the reference's compacted hit/miss lists follow from it; its own
+ *     slicing is inconsistent).  n_miss: device int32, may be NULL.          */
+int hbk_cache_probe(const int64_t* keys_cache, int64_t slab_count, int32_t slab_size,
+                    const int64_t* keys, int64_t n_keys, int64_t* hit_slot,
+                    int32_t* n_miss, hbk_stream_t stream);
+/* test hook: murmur3_hash32<int64, 0> of each key, on device */
+int hbk_murmur3_hash32(const int64_t* keys, int64_t n_keys, uint32_t* out,
+                       hbk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Communicator lifecycle: HbGetNcclId / HbCreateNcclCollective /
+ * HbIsNcclCollectiveInitialized / async-error polling.
+ *     hbtf/distribute/nccl/nccl_get_id.cc:35-62, nccl_create.cc:45-132,
+ *     nccl_collective.cc:434-465.  RCCL over xGMI; one communicator + one private comm
+ *     stream per handle (hbtf/distribute/nccl/collective.h:41-126).
+ *     The 128-byte id travels between ranks by whatever the host has (the reference uses
+ *     a TF gRPC broadcast, hbtf/distribute/rpc.py:88-124).                              */
+typedef struct hbk_comm* hbk_comm_t;
+#define HBK_COMM_ID_BYTES 128
+int hbk_comm_get_id(uint8_t id[HBK_COMM_ID_BYTES]);
+int hbk_comm_create(hbk_comm_t* comm, const uint8_t id[HBK_COMM_ID_BYTES],
+                    int32_t world_size, int32_t local_size, int32_t rank);
+int hbk_comm_destroy(hbk_comm_t comm);
+/* 0 = healthy; on an async RCCL error aborts the communicator and returns HBK_INTERNAL */
+int hbk_comm_check_async(hbk_comm_t comm);
+int hbk_comm_world_size(hbk_comm_t comm);
+int hbk_comm_rank(hbk_comm_t comm);
+/* the communicator's private stream (a hipStream_t) */
+hbk_stream_t hbk_comm_stream(hbk_comm_t comm);
+/* R4  Collective::compute_active_ranks, hbtf/distribute/collective.h:80-112.
+ *     Writes the peer list for `topology`, returns its length (<= world_size). */
+int hbk_comm_active_ranks(hbk_comm_t comm, int32_t topology, int32_t* ranks_out);
+
+/* R5  HbNcclAlltoall / HbNcclAlltoallN (equal split; also the sizes exchange that precedes
+ *     every Alltoallv): hbtf/distribute/nccl/nccl_alltoall.cc:169-180,242-258,
+ *     nccl_collective.cc:112-248.  counts[c] elements per tensor, divisible by the active
+ *     size.  Enqueued on the communicator's stream, fenced after `compute_stream`'s
+ *     current tail and before its future work (hbtf/common/stream.cc:83-142).          */
+int hbk_alltoall_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t topology,
+                   const void* const* inputs, const int64_t* counts, void* const* outputs,
+                   hbk_stream_t compute_stream);
+
+/* R5/R6  HbNcclAlltoallv / HbNcclAlltoallvN payload exchange.
+ *     ops hbtf/distribute/nccl/nccl_alltoallv.cc:200-223,359-387; arithmetic
+ *     nccl_collective.cc:250-384: chunk i of inputs[c] starts at
+ *     sum_{j<i} send_sizes[c][j]*common_sizes[c] elements, the chunk from peer i lands at
+ *     sum_{j<i} recv_sizes[c][j]*common_sizes[c].  Offsets are 64-bit here (the reference's
+ *     int32 byte offsets overflow past 2 GiB, nccl_collective.cc:261-262).
+ *     send_sizes / recv_sizes are HOST arrays [n][active] (rows); recv_sizes must already
+ *     be known (use hbk_alltoall_n on the sizes first -- once for all columns -- as
+ *     HbNcclAlltoallvN does, nccl_alltoallv.cc:418-564).
+ *     wire_dtype HBK_HALF with dtype HBK_FLOAT casts to fp16 before the send and back
+ *     after the receive (collective.py:291-296); `wire_ws` then needs
+ *     hbk_alltoallv_wire_workspace_bytes().  wire_dtype == dtype otherwise.             */
+size_t hbk_alltoallv_wire_workspace_bytes(int32_t n, const int64_t* common_sizes,
+                                          const int32_t* send_sizes,
+                                          const int32_t* recv_sizes, int32_t active);
+int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dtype,
+                    int32_t topology, const int64_t* common_sizes,
+                    const void* const* inputs, const int32_t* send_sizes,
+                    void* const* outputs, const int32_t* recv_sizes, void* wire_ws,
+                    size_t wire_ws_bytes, hbk_stream_t compute_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HBK_H_ */

@@ -1,0 +1,242 @@
+"""Pins the CPU oracle (oracle/) to every known-answer vector the reference holds for
+the path before anything is allowed to trust it."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+
+def _load(golden_dir, name):
+  with open(os.path.join(golden_dir, name)) as f:
+    return json.load(f)
+
+
+def test_murmur3_vectors(golden_dir):
+  g = _load(golden_dir, 'murmur3.json')
+  got = oracle.murmur3_hash32(g['keys'])
+  assert got.tolist() == g['hash32']
+
+
+def test_murmur3_against_reference_header_build():
+  ref = oracle.ref_lib()
+  if ref is None:
+    pytest.skip('oracle/_ref not built (reference tree not mounted)')
+  rng = np.random.RandomState(1)
+  keys = rng.randint(-2**63, 2**63 - 1, size=20000, dtype=np.int64)
+  got = oracle.murmur3_hash32(keys)
+  want = np.array([ref.ref_murmur3_hash32_i64(int(k)) for k in keys[:2000]], np.uint32)
+  assert (got[:2000] == want).all()
+
+
+def test_partition_by_modulo_kat(golden_dir):
+  for k in _load(golden_dir, 'partition.json')['modulo']:
+    for dt in (np.int32, np.int64):
+      o, s, i = oracle.partition_by_modulo(np.array(k['input'], dt), k['num_partitions'])
+      assert o.tolist() == k['output']
+      assert s.tolist() == k['sizes']
+      assert i.tolist() == k['indices']
+
+
+def test_partition_by_dual_modulo_kat(golden_dir):
+  for k in _load(golden_dir, 'partition.json')['dual']:
+    o, s, i = oracle.partition_by_dual_modulo(
+      np.array(k['input'], np.int64), k['num_partitions'], k['modulus'], k['stage'])
+    assert o.tolist() == k['output']
+    assert s.tolist() == k['sizes']
+    assert i.tolist() == k['indices']
+
+
+def test_partition_reference_property_cases(golden_dir):
+  # partition_test.py:40-65 and :83-114: x == take(y, idx), len(sizes) == P
+  for case in _load(golden_dir, 'partition.json')['property']:
+    np.random.seed(case['seed'])
+    for _ in range(case['columns']):
+      x = np.random.randint(low=case['low'], high=case['high'], size=case['size'],
+                            dtype=case['dtype'])
+      y, sizes, idx = oracle.partition_by_modulo(x, case['num_partitions'])
+      assert len(y) == len(idx)
+      assert len(sizes) == case['num_partitions']
+      np.testing.assert_equal(x, np.take(y, idx))
+      # stability + grouping (what "bit-exact vs the CPU functor" adds)
+      shard = np.mod(x.astype(np.int64), case['num_partitions'])
+      order = np.argsort(shard, kind='stable')
+      np.testing.assert_equal(y, x[order])
+      np.testing.assert_equal(sizes, np.bincount(shard, minlength=case['num_partitions']))
+
+
+def test_partition_empty_input():
+  # partition_test.py:67-81
+  y, sizes, idx = oracle.partition_by_modulo(np.array([], np.int64), 7)
+  assert len(y) == 0 and len(idx) == 0
+  assert sizes.tolist() == [0] * 7
+
+
+def test_partition_unsigned_and_dual_vs_numpy():
+  rng = np.random.RandomState(3)
+  for dt in (np.uint32, np.uint64, np.int32, np.int64):
+    info = np.iinfo(dt)
+    x = rng.randint(info.min, info.max, size=5000, dtype=dt)
+    for P, M in ((4, 2), (3, 5), (1, 1), (8, 3)):
+      y, sizes, idx = oracle.partition_by_modulo(x, P)
+      shard = np.array([int(v) % P for v in x])
+      np.testing.assert_equal(y, x[np.argsort(shard, kind='stable')])
+      pre = np.array([int(v) % (P * M) for v in x])
+      for stage, sh in ((1, pre % P), (2, pre // M)):
+        y, sizes, idx = oracle.partition_by_dual_modulo(x, P, M, stage)
+        np.testing.assert_equal(y, x[np.argsort(sh, kind='stable')])
+        np.testing.assert_equal(sizes, np.bincount(sh, minlength=P))
+        np.testing.assert_equal(x, y[idx])
+
+
+def test_alltoallv_kat(golden_dir):
+  g = _load(golden_dir, 'alltoallv.json')
+  s = g['single']
+  outs, sizes = oracle.alltoallv_sim([np.array(v, np.int64) for v in s['inputs']], s['sizes'])
+  assert [o.tolist() for o in outs] == s['outputs']
+  assert [z.tolist() for z in sizes] == s['out_sizes']
+  n = g['n']
+  for col in range(2):
+    outs, sizes = oracle.alltoallv_sim(
+      [np.array(n['inputs'][r][col], np.float32) for r in range(2)],
+      [n['sizes'][r][col] for r in range(2)])
+    for r in range(2):
+      assert outs[r].tolist() == n['outputs'][r][col]
+      assert sizes[r].tolist() == n['out_sizes'][r][col]
+
+
+def test_alltoallv_grad_kat(golden_dir):
+  # alltoall_test.py:228-243: loss = sum of per-rank mean(exchanged); d/dx = alltoallv of
+  # the upstream grad with the exchanged sizes (collective.py:334-347)
+  g = _load(golden_dir, 'alltoallv.json')['grad']
+  sizes, gv = g['sizes'], g['g']
+  world = 2
+  xs = [np.full(sum(sizes[r]), 1.0, np.float32) for r in range(world)]
+  outs, out_sizes = oracle.alltoallv_sim(xs, sizes)
+  ups = [np.full(outs[r].shape, gv / outs[r].size, np.float32) for r in range(world)]
+  grads, _ = oracle.alltoallv_sim(ups, out_sizes)
+  g0 = gv / (sizes[0][0] + sizes[1][0])
+  g1 = gv / (sizes[0][1] + sizes[1][1])
+  np.testing.assert_allclose(grads[0], sizes[0][0] * [g0] + sizes[0][1] * [g1], rtol=1e-6)
+  np.testing.assert_allclose(grads[1], sizes[1][0] * [g0] + sizes[1][1] * [g1], rtol=1e-6)
+
+
+def test_active_ranks():
+  # collective.h:80-112
+  assert oracle.compute_active_ranks(0, 8, 4, 5) == list(range(8))
+  assert oracle.compute_active_ranks(1, 8, 4, 5) == [4, 5, 6, 7]
+  assert oracle.compute_active_ranks(2, 8, 4, 5) == [1, 5]
+  assert oracle.compute_active_ranks(2, 4, 1, 2) == [0, 1, 2, 3]
+  assert oracle.compute_active_size(1, 8, 4) == 4
+  assert oracle.compute_active_size(2, 8, 4) == 2
+
+
+def test_shard_rows_rule():
+  # variables.py:93-123
+  assert oracle.shard_rows(10, 4, 0) == (True, 3, 0)
+  assert oracle.shard_rows(10, 4, 1) == (True, 3, 3)
+  assert oracle.shard_rows(10, 4, 2) == (True, 2, 6)
+  assert oracle.shard_rows(10, 4, 3) == (True, 2, 8)
+  assert oracle.shard_rows(4, 4, 0)[0] is False          # bucket <= W: replicated
+  assert oracle.shard_rows(1000, 8, 0, batch_size=1000)[0] is False
+  for W in (1, 2, 3, 8):
+    rows = [oracle.shard_rows(1000003, W, r)[1] for r in range(W)]
+    assert rows == [len(range(r, 1000003, W)) for r in range(W)]  # == owner = id mod W
+
+
+def test_unique_first_occurrence():
+  u, idx = oracle.unique([5, 3, 5, 7, 3, 3, 9])
+  assert u.tolist() == [5, 3, 7, 9]
+  assert idx.tolist() == [0, 1, 0, 2, 1, 1, 3]
+  rng = np.random.RandomState(0)
+  x = rng.randint(0, 500, size=5000).astype(np.int64)
+  u, idx = oracle.unique(x)
+  _, first = np.unique(x, return_index=True)
+  np.testing.assert_equal(u, x[np.sort(first)])
+  np.testing.assert_equal(u[idx], x)
+
+
+def test_floormod_matches_python():
+  rng = np.random.RandomState(0)
+  x = rng.randint(-2**62, 2**62, size=1000).astype(np.int64)
+  for m in (1, 7, 1000000, 2**31 + 11):
+    np.testing.assert_equal(oracle.floormod(x, m), np.array([int(v) % m for v in x]))
+
+
+def test_fp16_wire_cast_is_round_to_nearest_even():
+  rng = np.random.RandomState(0)
+  x = np.concatenate([rng.randn(10000) * s for s in (1e-8, 1e-5, 1e-3, 1, 100, 7e4)])
+  x = x.astype(np.float32)
+  got = oracle.cast_f32_to_f16(x).view(np.uint16)
+  want = x.astype(np.float16).view(np.uint16)
+  np.testing.assert_equal(got, want)
+  h = np.arange(65536, dtype=np.uint16).view(np.float16)
+  back = oracle.cast_f16_to_f32(h)
+  ok = ~np.isnan(h.astype(np.float32))
+  np.testing.assert_equal(back.view(np.uint32)[ok], h.astype(np.float32).view(np.uint32)[ok])
+
+
+def test_combiner_in_order_vs_float64():
+  rng = np.random.RandomState(5)
+  emb = rng.uniform(-1e-3, 1e-3, size=(4000, 16)).astype(np.float32)
+  lens = rng.poisson(8, size=300).clip(0, 32)
+  splits = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+  idx = rng.randint(0, 4000, size=int(splits[-1])).astype(np.int32)
+  for comb in ('sum', 'mean', 'sqrtn'):
+    f32 = oracle.segment_combine(emb, idx, splits, comb)
+    f64 = oracle.segment_combine(emb, idx, splits, comb, f64=True)
+    np.testing.assert_allclose(f32, f64, rtol=1e-5, atol=1e-9)
+    assert (f32[lens == 0] == 0).all()      # empty segments are zero rows
+
+
+def test_config1_ragged_lookup_fixture(golden_dir):
+  g = _load(golden_dir, 'config1_ragged_lookup.json')
+  table = np.frombuffer(bytes.fromhex(g['table_f32_hex']), np.float32).reshape(-1, g['dim'])
+  want = np.frombuffer(bytes.fromhex(g['expected_f32_hex']), np.float32).reshape(-1, g['dim'])
+  values = np.array(g['values'], np.int64)
+  splits = np.array(g['row_splits'], np.int32)
+  got = oracle.group_lookup_fwd([table], [values], [splits], [g['bucket']], [g['combiner']])[0]
+  np.testing.assert_equal(got, want)
+  # independent numpy restatement of embedding_lookup_sparse(mean)
+  rows = values % g['bucket']
+  for s in range(len(splits) - 1):
+    seg = rows[splits[s]:splits[s + 1]]
+    ref = table[seg].astype(np.float64).mean(axis=0) if len(seg) else np.zeros(g['dim'])
+    np.testing.assert_allclose(got[s], ref, rtol=1e-5, atol=1e-10)
+
+
+def test_sharded_pipeline_equals_unsharded_lookup():
+  # sharding.py:171-205 composed over W simulated ranks == plain table[ids]
+  rng = np.random.RandomState(11)
+  table = rng.uniform(-1, 1, size=(1003, 8)).astype(np.float32)
+  for W in (1, 2, 3, 8):
+    shards = oracle.make_shards(table, W)
+    ids = [rng.randint(0, 1003, size=rng.randint(0, 200)).astype(np.int64) for _ in range(W)]
+    outs = oracle.sharded_lookup_fwd(shards, ids)
+    for r in range(W):
+      np.testing.assert_equal(outs[r], table[ids[r]])
+    outs16 = oracle.sharded_lookup_fwd(shards, ids, wire_f16=True)
+    for r in range(W):
+      np.testing.assert_equal(outs16[r], table[ids[r]].astype(np.float16).astype(np.float32))
+
+
+def test_sharded_backward_equals_dense_scatter():
+  rng = np.random.RandomState(12)
+  R, D, W = 211, 4, 4
+  table = rng.uniform(-1, 1, size=(R, D)).astype(np.float32)
+  shards = oracle.make_shards(table, W)
+  ids = [rng.randint(0, R, size=150).astype(np.int64) for _ in range(W)]
+  _, kept = oracle.sharded_lookup_fwd(shards, ids, keep=True)
+  grads = [rng.randn(150, D).astype(np.float32) for _ in range(W)]
+  slices = oracle.sharded_lookup_bwd(kept, grads, W)
+  dense = np.zeros((R, D), np.float64)
+  for r in range(W):
+    np.add.at(dense, ids[r], grads[r].astype(np.float64))
+  got = np.zeros((R, D), np.float64)
+  for r in range(W):
+    rows, g_u = slices[r]
+    assert len(set(rows.tolist())) == len(rows)      # deduplicated
+    got[rows * W + r] += g_u
+  np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,254 @@
+"""bench.py -- M-lookups/sec of the sharded-embedding hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 26 Criteo-shape categorical columns,
+1M-row x dim-16 fp32 tables (uniform(-1e-3, 1e-3), seed 1234+col), int64 ids uniform in
+[0, 2^40) (seed 42+col+step) bucketized `% 1_000_000` inside the fused kernel, one id per
+sample (Criteo columns are scalar), local batch 65536.  One "step" = one pass of the hot
+path over one fresh batch:
+  N = 1 : hbk_group_lookup_fwd (bucketize -> HBM row gather -> combiner), one launch.
+  N > 1 : tables row-sharded by `id mod N` (configs[2]): bucketize -> stable partition ->
+          RCCL alltoallv(ids) -> owner gather -> RCCL alltoallv(rows) -> stitch/combine,
+          per-GPU batch fixed (weak scaling); value = lookups of all ranks / max-rank time.
+Inputs are resident in HBM before the timed region; every step reads a different id batch
+so nothing is served from L2/MALL by repetition (1.66 GB of tables >> 256 MB).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM-bound
+gather: algorithmic 136 B/lookup = 8 id + 64 row read + 64 output write) and
+`cpu_baseline` (the oracle's C pipeline timed on the host cores, rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+  p = argparse.ArgumentParser()
+  p.add_argument('--gpus', type=int, default=1)
+  p.add_argument('--steps', type=int, default=50)
+  p.add_argument('--warmup', type=int, default=10)
+  p.add_argument('--batch', type=int, default=65536, help='ids per column per GPU and step')
+  p.add_argument('--columns', type=int, default=26)
+  p.add_argument('--rows', type=int, default=1000000)
+  p.add_argument('--dim', type=int, default=16)
+  p.add_argument('--wire', choices=['fp32', 'fp16'], default='fp32',
+                 help='N > 1: wire dtype of the embedding exchange (comm_wire_dtype)')
+  p.add_argument('--cpu-seconds', type=float, default=12.0,
+                 help='budget of the host-CPU baseline (0 disables it)')
+  p.add_argument('--id-batches', type=int, default=0,
+                 help='distinct id batches kept in HBM (default: steps + warmup, max 64)')
+  return p.parse_args()
+
+
+def make_tables(args, device, rank, world):
+  """Full tables at N=1; this rank's rows (id mod N == rank, variables.py:107-111) at N>1.
+  Row r of column c is generated from (seed 1234+c) over the FULL table and sliced, so a
+  sharded run holds exactly the rows of the unsharded one."""
+  tables = []
+  for c in range(args.columns):
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + c)
+    full = torch.empty(args.rows, args.dim, device=device, dtype=torch.float32)
+    full.uniform_(-1e-3, 1e-3, generator=g)
+    if world > 1:
+      tables.append(full[rank::world].contiguous())
+      del full
+    else:
+      tables.append(full)
+  return tables
+
+
+def make_id_batches(args, device, rank, n_batches):
+  batches = []
+  for b in range(n_batches):
+    cols = []
+    for c in range(args.columns):
+      g = torch.Generator(device=device)
+      g.manual_seed(42 + c + 1000 * b + 100000 * rank)
+      cols.append(torch.randint(0, 1 << 40, (args.batch,), device=device, dtype=torch.int64,
+                                generator=g))
+    batches.append(cols)
+  return batches
+
+
+def cpu_baseline(args, tables, id_batch, budget_s):
+  """The oracle's C restatement of the path (kind "port": bucketize -> partition(P=1) ->
+  unique -> gather -> restore/stitch -> combiner, oracle/hbk_oracle.c) on the host cores,
+  on a bounded sample of the same workload."""
+  import oracle  # the checker / reported baseline only
+  cores = os.cpu_count() or 1
+  threads = max(1, min(cores, args.columns))
+  # bound the host copy: sample = first `cols` columns so that tables fit the time budget
+  cols = args.columns
+  h_tables = [t.cpu().numpy() for t in tables[:cols]]
+  h_ids = [i.cpu().numpy() for i in id_batch[:cols]]
+  buckets = [args.rows] * cols
+  comb = ['sum'] * cols
+  oracle.group_lookup_fwd(h_tables, h_ids, [None] * cols, buckets, comb, n_threads=threads)
+  passes, t0 = 0, time.perf_counter()
+  while True:
+    oracle.group_lookup_fwd(h_tables, h_ids, [None] * cols, buckets, comb, n_threads=threads)
+    passes += 1
+    el = time.perf_counter() - t0
+    if el >= budget_s or passes >= 200:
+      break
+  lookups = passes * cols * args.batch
+  return {
+    'value': round(lookups / el / 1e6, 3), 'unit': 'M-lookups/sec', 'cores': threads,
+    'kind': 'port',
+    'sample': f'{passes} passes of one {cols}-column x {args.batch}-id batch '
+              f'({lookups} lookups, {el:.1f} s) through oracle/hbk_oracle.c '
+              f'orc_group_lookup_fwd, {threads} pthreads over columns, host nproc={cores}'}
+
+
+def load_traffic(config_key):
+  """HBM bytes per launch from the committed PMC summary (profiles/hbm_traffic.json),
+  if one exists for this exact workload; else None."""
+  path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+  if not os.path.exists(path):
+    return None
+  try:
+    data = json.load(open(path))
+  except (OSError, ValueError):
+    return None
+  return data.get(config_key, {}).get('hbm_bytes_per_launch')
+
+
+def main():
+  args = parse_args()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit(
+        f'--gpus {args.gpus} needs one process per GPU: launch with '
+        f'python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} '
+        '--master-addr 127.0.0.1 --master-port <P> bench.py ...')
+    raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs a GPU (the HIP path is the only path)')
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+
+  import hybridbackend_amd as hb
+  from hybridbackend_amd import _lib
+  _lib.lib()
+
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', device_id=device)
+
+  n_batches = args.id_batches or min(args.steps + args.warmup, 64)
+  n_batches = max(1, n_batches)
+  tables = make_tables(args, device, rank, world)
+  batches = make_id_batches(args, device, rank, n_batches)
+  lookups_per_step_per_rank = args.columns * args.batch
+
+  if world == 1:
+    # one pre-bound descriptor set per id batch: a step is a single C-ABI call
+    outs = [torch.empty(args.batch, args.dim, device=device) for _ in range(args.columns)]
+    plans = []
+    for b in range(n_batches):
+      gl = hb.embedding.GroupLookup(tables, buckets=[args.rows] * args.columns,
+                                    combiners='sum')
+      gl.bind(batches[b], None, outs)
+      plans.append(gl)
+
+    def step(i):
+      plans[i % n_batches].launch()
+    parallelism = 'single-gpu'
+  else:
+    coll = hb.distribute.Collective(world_size=world, rank=rank, local_size=world)
+    hb.distribute.Collective.set_default(coll)
+    sharded = hb.embedding.ShardedGroupLookup(
+      tables, coll, buckets=[args.rows] * args.columns, combiners='sum',
+      wire_dtype=torch.float16 if args.wire == 'fp16' else None)
+
+    def step(i):
+      sharded(batches[i % n_batches])
+    parallelism = f'row-sharded id-mod-{world} (alltoallv ids + rows over RCCL/xGMI)'
+
+  def barrier():
+    if world > 1:
+      import torch.distributed as dist
+      dist.barrier()
+
+  for i in range(args.warmup):
+    step(i)
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  ev0 = torch.cuda.Event(enable_timing=True)
+  ev1 = torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  ev0.record()
+  for i in range(args.steps):
+    step(args.warmup + i)
+  ev1.record()
+  torch.cuda.synchronize()
+  barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  gpu_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream)
+
+  if world > 1:
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  total_lookups = lookups_per_step_per_rank * world * args.steps
+  value = total_lookups / elapsed / 1e6
+  ms_per_step = elapsed / args.steps * 1e3
+
+  if rank == 0:
+    bytes_per_lookup = 8 + 4 * args.dim + 4 * args.dim  # id + row read + output write
+    launch_s = gpu_ms / 1e3 / args.steps                 # avg duration of the dominant kernel
+    achieved = lookups_per_step_per_rank * bytes_per_lookup / launch_s / 1e9
+    workload = (f'{args.columns} cols x {args.rows} rows x dim{args.dim} fp32, batch '
+                f'{args.batch}/GPU, 1 id/sample, fused bucketize+gather+combiner')
+    key = f'c{args.columns}_r{args.rows}_d{args.dim}_b{args.batch}_n{world}'
+    result = {
+      'metric': 'M-lookups/sec, 26-col Criteo-shape dim16, 1/2/4/8 GPUs; % HBM roofline',
+      'value': round(value, 3), 'unit': 'M-lookups/sec', 'n_gpus': world,
+      'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 5),
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': 'f32', 'data': 'synthetic',
+      'config': {'workload': workload, 'global_batch': args.batch * world,
+                 'parallelism': parallelism,
+                 'wire': args.wire if world > 1 else None,
+                 'id_batches_resident': n_batches},
+      'roofline': {
+        'bound': 'hbm',
+        'kernel': 'group_lookup_fwd_kernel' if world == 1 else 'sharded step (all kernels)',
+        'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(achieved / HBM_PEAK_GBS, 4),
+        'traffic': load_traffic(key),
+        'algorithmic_bytes_per_lookup': bytes_per_lookup,
+        'avg_launch_us': round(launch_s * 1e6, 3)},
+    }
+    if world == 1 and args.cpu_seconds > 0:
+      result['cpu_baseline'] = cpu_baseline(args, tables, batches[0], args.cpu_seconds)
+    else:
+      result['cpu_baseline'] = None
+    print(json.dumps(result), flush=True)
+
+  if world > 1:
+    import torch.distributed as dist
+    coll.close()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -52,6 +52,47 @@ class LookupGradColumn(C.Structure):
 _lib = None
 
 
+def _declare(l):
+  """Full prototypes of include/hbk.h: without them ctypes would pass Python ints as
+  32-bit C ints and truncate device pointers."""
+  vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+  protos = {
+    'hbk_last_error': (C.c_char_p, []),
+    'hbk_version': (C.c_char_p, []),
+    'hbk_host_floormod_i64': (i64, [i64, i64]),
+    'hbk_host_fastdiv_u64': (C.c_uint64, [C.c_uint64, C.c_uint64]),
+    'hbk_floormod_n': (C.c_int, [i32, i32, vp, vp, vp, vp, vp]),
+    'hbk_partition_workspace_bytes': (sz, [i32, vp, i32]),
+    'hbk_partition_by_modulo_n': (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'hbk_partition_by_dual_modulo_n':
+      (C.c_int, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'hbk_cast_n': (C.c_int, [i32, i32, i32, vp, vp, vp, vp]),
+    'hbk_unique_workspace_bytes': (sz, [i32, vp]),
+    'hbk_unique_n': (C.c_int, [i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'hbk_group_lookup_fwd': (C.c_int, [i32, vp, vp]),
+    'hbk_group_lookup_bwd_workspace_bytes': (sz, [i32, vp]),
+    'hbk_group_lookup_bwd': (C.c_int, [i32, vp, C.c_float, vp, sz, vp]),
+    'hbk_cache_probe': (C.c_int, [vp, i64, i32, vp, i64, vp, vp, vp]),
+    'hbk_murmur3_hash32': (C.c_int, [vp, i64, vp, vp]),
+    'hbk_comm_get_id': (C.c_int, [vp]),
+    'hbk_comm_create': (C.c_int, [vp, vp, i32, i32, i32]),
+    'hbk_comm_destroy': (C.c_int, [vp]),
+    'hbk_comm_check_async': (C.c_int, [vp]),
+    'hbk_comm_world_size': (C.c_int, [vp]),
+    'hbk_comm_rank': (C.c_int, [vp]),
+    'hbk_comm_stream': (vp, [vp]),
+    'hbk_comm_active_ranks': (C.c_int, [vp, i32, vp]),
+    'hbk_alltoall_n': (C.c_int, [vp, i32, i32, i32, vp, vp, vp, vp]),
+    'hbk_alltoallv_wire_workspace_bytes': (sz, [i32, vp, vp, vp, i32]),
+    'hbk_alltoallv_n':
+      (C.c_int, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+  }
+  for name, (res, args) in protos.items():
+    fn = getattr(l, name)   # AttributeError here = header and library out of sync
+    fn.restype = res
+    fn.argtypes = args
+
+
 def lib():
   """Load libhbk_core.so once.  Raises if it is missing -- never falls back."""
   global _lib
@@ -66,15 +107,7 @@ def lib():
   # process uses, so the streams and pointers it hands us belong to the same runtime.
   import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
   l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-  l.hbk_last_error.restype = C.c_char_p
-  l.hbk_version.restype = C.c_char_p
-  for name in ('hbk_partition_workspace_bytes', 'hbk_unique_workspace_bytes',
-               'hbk_group_lookup_bwd_workspace_bytes',
-               'hbk_alltoallv_wire_workspace_bytes'):
-    if hasattr(l, name):
-      getattr(l, name).restype = C.c_size_t
-  if hasattr(l, 'hbk_comm_stream'):
-    l.hbk_comm_stream.restype = C.c_void_p
+  _declare(l)
   _lib = l
   return l
 

@@ -23,7 +23,9 @@ namespace {
 constexpr int kBlock = 256;           // 4 waves
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxColsPerLaunch = 30; // keeps LookupArgs under the 4 KB kernarg budget
-constexpr int kU = 4;                 // independent row loads per lane (one-id-per-segment path)
+constexpr int kU = 2;                 // independent row loads per lane (one-id-per-segment path);
+                                      // 2 beats 4 by 4% at batch 65536 (shorter tail), equal at 262144
+                                      // (tools/tune_lookup.hip, profiles/r01_tune_lookup.txt)
 constexpr int kSegIters = 4;          // segments per lane group and block (CSR path)
 
 struct ColArg {
@@ -218,7 +220,8 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
                 "group_lookup_fwd: column %d: n_segments (%lld) must equal n_ids (%lld) "
                 "when row_splits is NULL",
                 c, (long long)h.n_segments, (long long)h.n_ids);
-    HBK_REQUIRE(h.n_segments == 0 || (h.table && h.out && (h.ids || h.n_ids == 0)),
+    HBK_REQUIRE(h.n_segments == 0 ||
+                    ((h.table || h.rows == 0) && h.out && (h.ids || h.n_ids == 0)),
                 "group_lookup_fwd: column %d: NULL buffer", c);
     HBK_REQUIRE(h.n_ids < (1ll << 31) && h.n_segments < (1ll << 31),
                 "group_lookup_fwd: column %d: more than 2^31-1 ids/segments", c);

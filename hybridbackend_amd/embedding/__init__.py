@@ -1,4 +1,9 @@
 """Embedding ops of the sharded lookup path
 (host mirror of ``hybridbackend/tensorflow/embedding``)."""
+from hybridbackend_amd.embedding import cache
 from hybridbackend_amd.embedding.lookup import GroupLookup
+from hybridbackend_amd.embedding.lookup import GroupLookupGrad
 from hybridbackend_amd.embedding.lookup import group_lookup
+from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
+from hybridbackend_amd.embedding.unique import unique
+from hybridbackend_amd.embedding.unique import unique_n

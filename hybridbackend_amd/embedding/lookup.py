@@ -129,3 +129,68 @@ def group_lookup(tables, ids, row_splits=None, buckets=None, combiners='sum', di
                  outs=None):
   """Functional form: one fused launch over N columns; returns the list of outputs."""
   return GroupLookup(tables, buckets, combiners, divisor)(ids, row_splits, outs)
+
+
+class GroupLookupGrad:
+  """Backward of :class:`GroupLookup` (new additive op ``HbGroupLookupGrad``): from the
+  gradient of every column's combiner output to the ``IndexedSlices`` (unique local rows,
+  summed gradient rows) TF hands to the optimizer on the shard -- the chain
+  SparseSegment*Grad -> UnsortedSegmentSum of SURVEY 3.4 -- optionally fused with the
+  sparse SGD apply (``apply_lr``; sharded variables skip cross-rank aggregation,
+  hybridbackend/tensorflow/training/gradient.py:193-217).
+  """
+
+  def __init__(self, lookup):
+    self._lib = _lib.lib()
+    self.lookup = lookup
+    n = len(lookup)
+    self._cols = (_lib.LookupGradColumn * n)()
+    for c, t in enumerate(lookup.tables):
+      col = self._cols[c]
+      col.table = t.data_ptr()
+      col.rows = t.shape[0]
+      col.dim = t.shape[1]
+      col.bucket = lookup.buckets[c]
+      col.divisor = lookup.divisor
+      col.combiner = lookup.combiners[c]
+    self._ws = None
+
+  def __call__(self, ids, grads, row_splits=None, apply_lr=0.0):
+    """Returns per column ``(unique_rows int64[n_ids], grad_rows f32[n_ids, dim],
+    n_unique int32[1])``; only the first ``n_unique`` rows are meaningful (device-side
+    count: no host sync here)."""
+    n = len(self.lookup)
+    if row_splits is None:
+      row_splits = [None] * n
+    outs = []
+    dev = self.lookup.tables[0].device if n else None
+    for c in range(n):
+      i, g, s = ids[c], grads[c], row_splits[c]
+      for t, what in ((i, 'ids'), (g, 'grads')):
+        _lib.require_device_tensor(t, what)
+      n_seg = i.numel() if s is None else s.numel() - 1
+      dim = self.lookup.tables[c].shape[1]
+      if g.dtype != torch.float32 or tuple(g.shape) != (n_seg, dim):
+        raise _lib.InvalidArgumentError(
+          _lib.INVALID_ARGUMENT, f'grad {c} must be fp32 [{n_seg}, {dim}]')
+      urows = torch.empty(i.numel(), dtype=torch.int64, device=dev)
+      grows = torch.empty((i.numel(), dim), dtype=torch.float32, device=dev)
+      nu = torch.zeros(1, dtype=torch.int32, device=dev)
+      col = self._cols[c]
+      col.ids_dtype = _lib.INT64 if i.dtype == torch.int64 else _lib.INT32
+      col.ids = i.data_ptr()
+      col.n_ids = i.numel()
+      col.row_splits = s.data_ptr() if s is not None else None
+      col.n_segments = n_seg
+      col.grad_out = g.data_ptr()
+      col.unique_rows = urows.data_ptr()
+      col.grad_rows = grows.data_ptr()
+      col.n_unique = nu.data_ptr()
+      outs.append((urows, grows, nu))
+    need = self._lib.hbk_group_lookup_bwd_workspace_bytes(n, self._cols)
+    if self._ws is None or self._ws.numel() < need:
+      self._ws = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
+    _lib.check(self._lib.hbk_group_lookup_bwd(
+      n, self._cols, C.c_float(apply_lr), C.c_void_p(self._ws.data_ptr()),
+      C.c_size_t(self._ws.numel()), _lib.current_stream(dev)))
+    return outs

@@ -1,0 +1,132 @@
+"""Sharded group lookup -- the host-side pipeline driver (R12), mirror of
+``hybridbackend/tensorflow/embedding/sharding.py:171-205`` for N columns at once (what the
+reference's ``Pack`` pass makes of N per-column pipelines, graph/common/packing.cc:124-575).
+
+Per rank and step (W = world size, owner of an id = ``id mod W``, local row = ``id // W``):
+
+  1 bucketize + ``partition_by_modulo`` (sharding.py:182)    hbk_floormod_n, hbk_partition_by_modulo_n
+  2 ``alltoall(ids_shards, sizes=ids_sizes)`` (:184)         ONE [N x W] size exchange + one
+                                                             host sync for all N columns, then
+                                                             hbk_alltoallv_n (int64 ids)
+  3 ``unique`` / ``// W`` / gather / restore (:186-193)      hbk_group_lookup_fwd on the shard with
+                                                             divisor = W (unique + restore are
+                                                             value-transparent in the forward)
+  4 ``alltoall(embeddings, sizes=shard_sizes)`` (:196)       hbk_alltoallv_n (fp32 or fp16 wire)
+  5 ``gather(embeddings, shard_index)`` (:200) + combiner    hbk_group_lookup_fwd over the received
+                                                             rows with ids = shard_index
+
+The reference pays one host ``BlockHostUntilDone`` per exchange op (nccl_alltoallv.cc:316,533);
+here the receive sizes of BOTH exchanges come from the single size exchange of step 2.
+
+The compute phases are separate methods so a test can drive W virtual ranks in one process
+with its own transport; ``__call__`` runs them against the RCCL communicator.
+"""
+import torch
+
+from hybridbackend_amd import _lib
+from hybridbackend_amd.distribute import partition as _partition
+from hybridbackend_amd.embedding.lookup import GroupLookup
+from hybridbackend_amd.embedding.lookup import GroupLookupGrad
+
+
+class _Step:
+  """Per-step state carried between the phases (and kept for the backward)."""
+  __slots__ = ('ids', 'row_splits', 'send_ids', 'send_sizes', 'shard_index', 'send_sizes_host',
+               'recv_sizes_host', 'recv_ids', 'send_rows', 'recv_rows', 'outs')
+
+  def __init__(self):
+    for s in self.__slots__:
+      setattr(self, s, None)
+
+
+class ShardedGroupLookup:
+  """N row-sharded embedding tables looked up together.
+
+  Args:
+    shards: this rank's local rows per column, fp32 ``[rows_local, dim]``
+      (``rows_local = R // W + (rank < R % W)``, variables.py:107-111).
+    coll: a ``hybridbackend_amd.distribute.Collective`` (or None when only the phase
+      methods are used).
+    buckets: per-column ``embedding_size`` for the fused bucketize (ids are taken modulo it
+      before the partition), or None when ids are already in ``[0, R)``.
+    combiners: as for ``GroupLookup``.
+    wire_dtype: ``torch.float16`` sends the embedding rows as fp16 (``comm_wire_dtype``,
+      collective.py:291-296); None keeps fp32.
+  """
+
+  def __init__(self, shards, coll, buckets=None, combiners='sum', wire_dtype=None,
+               world_size=None):
+    self.shards = list(shards)
+    self.coll = coll
+    self.world_size = int(world_size if world_size is not None else coll.world_size)
+    n = len(self.shards)
+    self.buckets = [int(b or 0) for b in (buckets or [0] * n)]
+    self.combiners = combiners
+    self.wire_dtype = wire_dtype
+    self.device = self.shards[0].device if n else None
+    self.dims = [int(t.shape[1]) for t in self.shards]
+    self._setup()
+
+  def _setup(self):
+    """Device-side state of the compute phases (the HIP path; there is no other)."""
+    self._lib = _lib.lib()
+    # owner-side gather: ids arrive bucketized, row = id // W (sharding.py:188-189)
+    self._owner = GroupLookup(self.shards, None, 'sum', divisor=self.world_size)
+
+  # ---- phase 1: bucketize + stable partition -------------------------------------
+  def partition(self, ids, row_splits=None):
+    st = _Step()
+    n = len(self.shards)
+    st.ids = list(ids)
+    st.row_splits = list(row_splits) if row_splits is not None else [None] * n
+    work = st.ids
+    if any(self.buckets):
+      work = [torch.empty_like(t) if b else t for t, b in zip(st.ids, self.buckets)]
+      sel = [c for c in range(n) if self.buckets[c]]
+      code = _lib.torch_dtype_code(st.ids[sel[0]].dtype)
+      _lib.check(self._lib.hbk_floormod_n(
+        len(sel), code, _lib.ptr_array([st.ids[c].data_ptr() for c in sel]),
+        _lib.i64_array([st.ids[c].numel() for c in sel]),
+        _lib.i64_array([self.buckets[c] for c in sel]),
+        _lib.ptr_array([work[c].data_ptr() for c in sel]),
+        _lib.current_stream(self.device)))
+    W = self.world_size
+    sizes = torch.empty((n, W), dtype=torch.int32, device=self.device)
+    outs = [torch.empty_like(t) for t in work]
+    idxs = [torch.empty(t.numel(), dtype=torch.int32, device=self.device) for t in work]
+    _partition._partition_n(work, W, 1, 0, outputs=(outs, [sizes[c] for c in range(n)], idxs))
+    st.send_ids, st.send_sizes, st.shard_index = outs, sizes, idxs
+    return st
+
+  # ---- phase 3: owner-side gather ------------------------------------------------------
+  def owner_gather(self, st, recv_ids):
+    st.recv_ids = recv_ids
+    st.send_rows = self._owner(recv_ids)
+    return st.send_rows
+
+  # ---- phase 5: stitch + combine --------------------------------------------------------
+  def stitch(self, st, recv_rows):
+    st.recv_rows = recv_rows
+    stitcher = GroupLookup(recv_rows, None, self.combiners, divisor=1)
+    st.outs = stitcher(st.shard_index, st.row_splits)
+    return st.outs
+
+  # ---- the whole forward against the communicator ---------------------------------------
+  def __call__(self, ids, row_splits=None, keep=False):
+    st = self.partition(ids, row_splits)
+    n, W = len(self.shards), self.world_size
+    # one size exchange for all columns; sizes[c][p] = rows this rank sends to rank p
+    # send layout for the equal-split alltoall: chunk p = the N sizes destined to rank p
+    send = st.send_sizes.t().contiguous()                     # [W, N]
+    recv = self.coll.alltoall_n([send.view(-1)])[0].view(W, n)
+    host_send = st.send_sizes.cpu()                           # [N, W]  (syncs the stream)
+    host_recv = recv.t().contiguous().cpu()                   # [N, W]
+    st.send_sizes_host = host_send.tolist()
+    st.recv_sizes_host = host_recv.tolist()
+    recv_ids = self.coll.alltoallv_n(st.send_ids, st.send_sizes_host, st.recv_sizes_host,
+                                     common_sizes=[1] * n)
+    send_rows = self.owner_gather(st, recv_ids)
+    recv_rows = self.coll.alltoallv_n(send_rows, st.recv_sizes_host, st.send_sizes_host,
+                                      common_sizes=self.dims, wire_dtype=self.wire_dtype)
+    outs = self.stitch(st, recv_rows)
+    return (outs, st) if keep else outs

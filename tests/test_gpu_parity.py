@@ -1,0 +1,425 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on a real MI355X.
+
+Integer / index work (bucketize, partition, unique, probe, hash): bit-exact.
+fp32 combiner: bit-exact against the oracle's in-order fp32 sum AND within 1e-5 relative of
+its float64 accumulation (the tolerance BASELINE.json's north_star states).
+Backward duplicate reduction (atomics, order not fixed): 1e-5 relative.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import hybridbackend_amd as hb
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5   # north_star: "within 1e-5 relative for the fp32 combiner"; relative to the
+              # magnitude of the summed terms (a sum that cancels to ~0 cannot be held to
+              # 1e-5 of its own value in fp32): |got - f64| <= RTOL * (|f64| + max|term|)
+DEV = 'cuda:0'
+
+
+def dev(a):
+  return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+  return t.detach().cpu().numpy()
+
+
+def _ragged(rng, n_seg, mean, clip):
+  lens = rng.poisson(mean, size=n_seg).clip(0, clip)
+  return np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+
+
+# ----------------------------------------------------------------------------------
+# R2 / R3 partition
+def test_partition_kat(golden_dir):
+  g = json.load(open(os.path.join(golden_dir, 'partition.json')))
+  for k in g['modulo']:
+    for dt in (np.int32, np.int64):
+      o, s, i = hb.distribute.partition_by_modulo(dev(np.array(k['input'], dt)),
+                                                  k['num_partitions'])
+      assert host(o).tolist() == k['output']
+      assert host(s).tolist() == k['sizes']
+      assert host(i).tolist() == k['indices']
+  for k in g['dual']:
+    fn = (hb.distribute.partition_by_dual_modulo_stage_one if k['stage'] == 1
+          else hb.distribute.partition_by_dual_modulo_stage_two)
+    o, s, i = fn(dev(np.array(k['input'], np.int64)), k['num_partitions'], k['modulus'])
+    assert host(o).tolist() == k['output']
+    assert host(s).tolist() == k['sizes']
+    assert host(i).tolist() == k['indices']
+
+
+def test_partition_reference_test_cases(golden_dir):
+  # the reference's own cases (partition_test.py:40-65 unfused, :83-114 fused N=10)
+  g = json.load(open(os.path.join(golden_dir, 'partition.json')))
+  for case in g['property']:
+    np.random.seed(case['seed'])
+    xs = [np.random.randint(low=case['low'], high=case['high'], size=case['size'],
+                            dtype=case['dtype']) for _ in range(case['columns'])]
+    P = case['num_partitions']
+    ys, sizes, idxs = hb.distribute.partition_by_modulo_n([dev(x) for x in xs], P)
+    for c, x in enumerate(xs):
+      y, s, i = host(ys[c]), host(sizes[c]), host(idxs[c])
+      assert len(y) == len(i) and len(s) == P
+      np.testing.assert_equal(x, np.take(y, i))          # the reference's assertion
+      oy, os_, oi = oracle.partition_by_modulo(x, P)      # bit-exact vs the CPU functor
+      np.testing.assert_equal(y, oy)
+      np.testing.assert_equal(s, os_)
+      np.testing.assert_equal(i, oi)
+
+
+def test_partition_empty_inputs():
+  # partition_test.py:67-81 and :116-140
+  y, s, i = hb.distribute.partition_by_modulo(dev(np.array([], np.int64)), 7)
+  assert y.numel() == 0 and i.numel() == 0 and host(s).tolist() == [0] * 7
+  ys, ss, _ = hb.distribute.partition_by_modulo_n([dev(np.array([], np.int64))] * 3, 7)
+  for s in ss:
+    assert host(s).tolist() == [0] * 7
+
+
+@pytest.mark.parametrize('dtype', [np.int32, np.int64, np.uint32, np.uint64])
+def test_partition_all_dtypes_and_shard_counts(dtype):
+  if dtype in (np.uint32, np.uint64) and not hasattr(torch, 'uint64'):
+    pytest.skip('torch build has no unsigned 32/64-bit tensors')
+  rng = np.random.RandomState(7)
+  info = np.iinfo(dtype)
+  for P in (1, 2, 3, 5, 8, 13, 64, 100, 1000):
+    lens = [0, 1, 63, 64, 65, 1023, 1024, 1025, 5000, 40000]
+    xs = [rng.randint(info.min, info.max, size=n, dtype=dtype) for n in lens]
+    ys, sizes, idxs = hb.distribute.partition_by_modulo_n([dev(x) for x in xs], P)
+    for c, x in enumerate(xs):
+      oy, os_, oi = oracle.partition_by_modulo(x, P)
+      np.testing.assert_equal(host(ys[c]), oy)
+      np.testing.assert_equal(host(sizes[c]), os_)
+      np.testing.assert_equal(host(idxs[c]), oi)
+
+
+def test_partition_dual_modulo_n():
+  rng = np.random.RandomState(8)
+  xs = [rng.randint(-2**40, 2**40, size=n).astype(np.int64) for n in (0, 777, 4096, 30000)]
+  for P, M in ((2, 2), (8, 4), (4, 8), (3, 5)):
+    for stage in (1, 2):
+      ys, sizes, idxs = hb.distribute.partition_by_dual_modulo_n(
+        [dev(x) for x in xs], P, M, stage)
+      for c, x in enumerate(xs):
+        oy, os_, oi = oracle.partition_by_dual_modulo(x, P, M, stage)
+        np.testing.assert_equal(host(ys[c]), oy)
+        np.testing.assert_equal(host(sizes[c]), os_)
+        np.testing.assert_equal(host(idxs[c]), oi)
+
+
+def test_partition_many_columns_and_large():
+  rng = np.random.RandomState(9)
+  xs = [rng.randint(0, 2**40, size=rng.randint(0, 3000)).astype(np.int64) for _ in range(200)]
+  ys, sizes, idxs = hb.distribute.partition_by_modulo_n([dev(x) for x in xs], 8)
+  for c, x in enumerate(xs):
+    oy, os_, oi = oracle.partition_by_modulo(x, 8)
+    np.testing.assert_equal(host(ys[c]), oy)
+    np.testing.assert_equal(host(sizes[c]), os_)
+    np.testing.assert_equal(host(idxs[c]), oi)
+  # BASELINE full size (26 x 65536, W = 8): sortedness / permutation properties on device
+  ids = [torch.randint(0, 2**40, (65536,), device=DEV, dtype=torch.int64) for _ in range(26)]
+  ys, sizes, idxs = hb.distribute.partition_by_modulo_n(ids, 8)
+  for c in range(26):
+    assert torch.equal(ys[c][idxs[c].long()], ids[c])                 # round trip
+    shard = ys[c] % 8
+    assert bool((shard[1:] >= shard[:-1]).all())                        # grouped by shard
+    assert torch.equal(torch.bincount(shard, minlength=8).int(), sizes[c])
+    inv = torch.empty_like(idxs[c]).long()
+    inv[idxs[c].long()] = torch.arange(65536, device=DEV)
+    for p in range(8):                                                  # stable inside a shard
+      seg = inv[shard == p]
+      assert bool((seg[1:] > seg[:-1]).all())
+
+
+# ----------------------------------------------------------------------------------
+# R1 bucketize
+def test_floormod_n():
+  rng = np.random.RandomState(1)
+  lib = hb._lib.lib()
+  for dt, code in ((np.int64, hb._lib.INT64), (np.int32, hb._lib.INT32)):
+    info = np.iinfo(dt)
+    xs = [rng.randint(info.min, info.max, size=n, dtype=dt) for n in (0, 5, 3000, 70000)]
+    buckets = [7, 1000000, 1, 2**31 - 1]
+    ins = [dev(x) for x in xs]
+    outs = [torch.empty_like(t) for t in ins]
+    hb._lib.check(lib.hbk_floormod_n(
+      len(xs), code, hb._lib.ptr_array([t.data_ptr() for t in ins]),
+      hb._lib.i64_array([t.numel() for t in ins]), hb._lib.i64_array(buckets),
+      hb._lib.ptr_array([t.data_ptr() for t in outs]), hb._lib.current_stream()))
+    for x, b, o in zip(xs, buckets, outs):
+      np.testing.assert_equal(host(o), oracle.floormod(x, b))
+
+
+# ----------------------------------------------------------------------------------
+# R1 + R8 + R9 fused group lookup, forward
+DIMS = [1, 3, 4, 5, 8, 12, 16, 24, 32, 36, 48, 64, 80, 128, 256]
+
+
+def test_group_lookup_one_id_per_segment_all_dims():
+  rng = np.random.RandomState(2)
+  tables, ids, buckets = [], [], []
+  for k, d in enumerate(DIMS):
+    rows = int(rng.randint(50, 5000))
+    tables.append(rng.uniform(-1, 1, size=(rows, d)).astype(np.float32))
+    n = [0, 1, 17, 255, 256, 257, 1000, 4097][k % 8]
+    ids.append(rng.randint(-2**50, 2**50, size=n).astype(np.int64))
+    buckets.append(rows)
+  outs = hb.embedding.group_lookup([dev(t) for t in tables], [dev(i) for i in ids],
+                                   buckets=buckets, combiners='sum')
+  want = oracle.group_lookup_fwd(tables, ids, [None] * len(DIMS), buckets, ['sum'] * len(DIMS))
+  for o, w in zip(outs, want):
+    np.testing.assert_equal(host(o), w)     # a gather is a copy: bit-exact
+
+
+def test_group_lookup_int32_ids_divisor_and_out_of_range():
+  rng = np.random.RandomState(3)
+  table = rng.uniform(-1, 1, size=(1000, 16)).astype(np.float32)
+  ids32 = rng.randint(0, 1000, size=3000).astype(np.int32)
+  o = hb.embedding.group_lookup([dev(table)], [dev(ids32)])[0]
+  np.testing.assert_equal(host(o), table[ids32])
+  # owner side of a W=8 shard: row = id // 8 (sharding.py:189)
+  ids = (rng.randint(0, 1000, size=3000).astype(np.int64)) * 8 + 3
+  o = hb.embedding.group_lookup([dev(table)], [dev(ids)], divisor=8)[0]
+  np.testing.assert_equal(host(o), table[ids // 8])
+  # out-of-range / negative ids without bucketize give zero rows (TF GPU GatherV2)
+  bad = np.array([5, -1, 1000, 999, 2**40, 0], np.int64)
+  o = host(hb.embedding.group_lookup([dev(table)], [dev(bad)])[0])
+  np.testing.assert_equal(o[[0, 3, 5]], table[[5, 999, 0]])
+  assert (o[[1, 2, 4]] == 0).all()
+
+
+@pytest.mark.parametrize('combiner', ['sum', 'mean', 'sqrtn'])
+def test_group_lookup_ragged_combiners(combiner):
+  rng = np.random.RandomState(4)
+  tables, ids, splits, buckets = [], [], [], []
+  for k, d in enumerate([4, 8, 16, 16, 32, 64, 128, 6, 36]):
+    rows = int(rng.randint(100, 20000))
+    tables.append(rng.uniform(-1e-3, 1e-3, size=(rows, d)).astype(np.float32))
+    sp = _ragged(rng, [0, 1, 7, 300, 1000, 2048, 513, 64, 999][k], [8, 1, 3, 8, 2, 8, 20, 8, 5][k], 32)
+    splits.append(sp)
+    ids.append(rng.randint(0, 2**40, size=int(sp[-1])).astype(np.int64))
+    buckets.append(rows)
+  n = len(tables)
+  outs = hb.embedding.group_lookup([dev(t) for t in tables], [dev(i) for i in ids],
+                                   [dev(s) for s in splits], buckets, combiner)
+  want = oracle.group_lookup_fwd(tables, ids, splits, buckets, [combiner] * n)
+  for c in range(n):
+    got = host(outs[c])
+    np.testing.assert_equal(got, want[c])   # same in-order fp32 accumulation: bit-exact
+    rows = ids[c] % buckets[c]
+    f64 = oracle.segment_combine(tables[c], rows.astype(np.int32), splits[c], combiner, f64=True)
+    np.testing.assert_allclose(got, f64, rtol=RTOL, atol=RTOL * np.abs(tables[c]).max())
+    lens = np.diff(splits[c])
+    assert (got[lens == 0] == 0).all()      # empty segments -> zero rows
+
+
+def test_group_lookup_default_combiner_is_mean_and_config1_fixture(golden_dir):
+  g = json.load(open(os.path.join(golden_dir, 'config1_ragged_lookup.json')))
+  table = np.frombuffer(bytes.fromhex(g['table_f32_hex']), np.float32).reshape(-1, g['dim'])
+  want = np.frombuffer(bytes.fromhex(g['expected_f32_hex']), np.float32).reshape(-1, g['dim'])
+  got = hb.embedding.group_lookup(
+    [dev(table.copy())], [dev(np.array(g['values'], np.int64))],
+    [dev(np.array(g['row_splits'], np.int32))], [g['bucket']], combiners=None)[0]
+  np.testing.assert_equal(host(got), want)
+
+
+def test_group_lookup_more_columns_than_one_launch():
+  rng = np.random.RandomState(5)
+  n = 200  # config 5 width: several launch groups
+  dims = [4, 8, 12, 16, 24, 32, 36, 48, 64, 80, 128]
+  tables = [rng.uniform(-1, 1, size=(rng.randint(10, 500), dims[c % len(dims)])).astype(np.float32)
+            for c in range(n)]
+  splits = [(_ragged(rng, rng.randint(0, 200), 3, 10) if c % 3 == 0 else None) for c in range(n)]
+  ids = [rng.randint(0, 2**33, size=(int(s[-1]) if s is not None else rng.randint(0, 300)))
+         .astype(np.int64) for s in splits]
+  buckets = [t.shape[0] for t in tables]
+  outs = hb.embedding.group_lookup(
+    [dev(t) for t in tables], [dev(i) for i in ids],
+    [None if s is None else dev(s) for s in splits], buckets, 'mean')
+  want = oracle.group_lookup_fwd(tables, ids, splits, buckets, ['mean'] * n)
+  for o, w in zip(outs, want):
+    np.testing.assert_equal(host(o), w)
+
+
+def test_group_lookup_baseline_full_size_properties():
+  # BASELINE config 2: 26 columns x 1M x 16, batch 65536: size-independent properties
+  torch.manual_seed(0)
+  tables = [torch.empty(1000000, 16, device=DEV).uniform_(-1e-3, 1e-3) for _ in range(26)]
+  ids = [torch.randint(0, 2**40, (65536,), device=DEV, dtype=torch.int64) for _ in range(26)]
+  lookup = hb.embedding.GroupLookup(tables, buckets=[1000000] * 26)
+  outs = lookup(ids)
+  for c in range(26):
+    assert torch.equal(outs[c], tables[c][ids[c] % 1000000])            # copy of the rows
+  # idempotence: a second call into fresh buffers gives identical bytes
+  outs2 = lookup(ids)
+  assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
+  # linearity of the sum combiner: lookup(a ++ b) == lookup(a) + lookup(b) on 2-id segments
+  pair_ids = [torch.stack([i[:32768], i[32768:]], 1).reshape(-1).contiguous() for i in ids]
+  splits = torch.arange(0, 65537, 2, device=DEV, dtype=torch.int32)
+  pooled = lookup(pair_ids, [splits] * 26)
+  for c in range(26):
+    assert torch.equal(pooled[c], outs[c][:32768] + outs[c][32768:])
+
+
+# ----------------------------------------------------------------------------------
+# R7 unique
+def test_unique_first_occurrence_order():
+  rng = np.random.RandomState(6)
+  cases = [np.array([], np.int64), np.array([5, 3, 5, 7, 3, 3, 9], np.int64),
+           np.array([-1, -1, 0, -2**63, 2**63 - 1, -1, -2**63], np.int64),
+           rng.randint(0, 50, size=1000).astype(np.int64),
+           rng.randint(0, 2**40, size=70000).astype(np.int64),
+           rng.randint(0, 1000, size=70000).astype(np.int64),
+           (rng.zipf(1.2, size=50000) % 100000).astype(np.int64)]
+  res = hb.embedding.unique_n([dev(x) for x in cases])
+  for x, (u, idx, nu) in zip(cases, res):
+    ou, oidx = oracle.unique(x)
+    k = int(nu.item())
+    assert k == ou.size
+    np.testing.assert_equal(host(u)[:k], ou)
+    np.testing.assert_equal(host(idx), oidx)
+
+
+# ----------------------------------------------------------------------------------
+# R10 backward
+@pytest.mark.parametrize('combiner', ['sum', 'mean', 'sqrtn'])
+def test_group_lookup_backward(combiner):
+  rng = np.random.RandomState(10)
+  tables, ids, splits, buckets, grads = [], [], [], [], []
+  for k, d in enumerate([4, 16, 16, 32, 128, 6]):
+    rows = [50, 1000, 100000, 300, 2000, 77][k]
+    tables.append(rng.uniform(-1, 1, size=(rows, d)).astype(np.float32))
+    if k % 2 == 0:
+      sp = _ragged(rng, [200, 0, 3000, 0, 500, 0][k], 4, 16)
+      n = int(sp[-1])
+    else:
+      sp, n = None, [0, 5000, 0, 1000, 0, 300][k]
+    splits.append(sp)
+    ids.append(rng.randint(0, 2**40, size=n).astype(np.int64))
+    buckets.append(rows)
+    n_seg = n if sp is None else sp.size - 1
+    grads.append(rng.randn(n_seg, d).astype(np.float32))
+  lookup = hb.embedding.GroupLookup([dev(t) for t in tables], buckets, combiner)
+  res = hb.embedding.GroupLookupGrad(lookup)(
+    [dev(i) for i in ids], [dev(g) for g in grads],
+    [None if s is None else dev(s) for s in splits])
+  for c in range(len(tables)):
+    urows, grows, nu = res[c]
+    k = int(nu.item())
+    rows = ids[c] % buckets[c]
+    ou, oinv = oracle.unique(rows)
+    assert k == ou.size
+    np.testing.assert_equal(host(urows)[:k], ou)          # integer part: bit-exact
+    sp = splits[c] if splits[c] is not None else np.arange(ids[c].size + 1, dtype=np.int32)
+    g_id = oracle.segment_combine_grad(grads[c], sp, combiner)
+    want64 = oracle.unsorted_segment_sum(g_id, oinv, ou.size, f64=True)
+    np.testing.assert_allclose(host(grows)[:k], want64, rtol=RTOL, atol=1e-6)
+
+
+def test_group_lookup_backward_fused_sgd_apply():
+  rng = np.random.RandomState(11)
+  table = rng.uniform(-1, 1, size=(5000, 16)).astype(np.float32)
+  ids = rng.randint(0, 2**40, size=20000).astype(np.int64)
+  grads = rng.randn(20000, 16).astype(np.float32)
+  t_dev = dev(table.copy())
+  lookup = hb.embedding.GroupLookup([t_dev], [5000], 'sum')
+  urows, grows, nu = hb.embedding.GroupLookupGrad(lookup)([dev(ids)], [dev(grads)],
+                                                          apply_lr=0.05)[0]
+  k = int(nu.item())
+  want = table.copy()
+  oracle.sparse_sgd_apply(want, host(urows)[:k], host(grows)[:k], 0.05)
+  np.testing.assert_equal(host(t_dev), want)                  # same rows, same fp32 op
+  ref = table.astype(np.float64)
+  np.subtract.at(ref, ids % 5000, 0.05 * grads.astype(np.float64))
+  np.testing.assert_allclose(host(t_dev), ref, rtol=RTOL, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------
+# R6 wire casts
+def test_cast_n_fp16_wire():
+  rng = np.random.RandomState(12)
+  xs = [np.concatenate([rng.randn(n) * s for s in (1e-8, 1e-4, 1, 300, 7e4)]).astype(np.float32)
+        for n in (0, 1, 1000, 33333)]
+  hs = hb.distribute.cast_n([dev(x) for x in xs], torch.float16)
+  for x, h in zip(xs, hs):
+    np.testing.assert_equal(host(h).view(np.uint16), oracle.cast_f32_to_f16(x).view(np.uint16))
+  back = hb.distribute.cast_n(hs, torch.float32)
+  for h, b in zip(hs, back):
+    want = oracle.cast_f16_to_f32(host(h))
+    np.testing.assert_equal(host(b).view(np.uint32), want.view(np.uint32))
+
+
+# ----------------------------------------------------------------------------------
+# R11 hash + cache probe
+def test_murmur3_golden_and_random(golden_dir):
+  g = json.load(open(os.path.join(golden_dir, 'murmur3.json')))
+  got = hb.embedding.cache.murmur3_hash32(dev(np.array(g['keys'], np.int64)))
+  assert host(got).tolist() == g['hash32']
+  keys = np.random.RandomState(13).randint(-2**63, 2**63 - 1, size=100000, dtype=np.int64)
+  got = hb.embedding.cache.murmur3_hash32(dev(keys))
+  np.testing.assert_equal(host(got).astype(np.uint32), oracle.murmur3_hash32(keys))
+
+
+@pytest.mark.parametrize('slab_size', [32, 64, 16, 5])
+def test_cache_probe(slab_size):
+  rng = np.random.RandomState(14)
+  slab_count = 257
+  cache = np.full(slab_count * slab_size, oracle.EMPTY_KEY, np.int64)
+  present = rng.randint(0, 2**40, size=slab_count * slab_size // 2).astype(np.int64)
+  # fill like a slab hash: first free slot of the hashed slab, else next slab
+  for k in present:
+    slab = int(oracle.murmur3_hash32([k])[0]) % slab_count
+    for _ in range(slab_count):
+      s = cache[slab * slab_size:(slab + 1) * slab_size]
+      free = np.where(s == oracle.EMPTY_KEY)[0]
+      if k in s:
+        break
+      if free.size:
+        s[free[0]] = k
+        break
+      slab = (slab + 1) % slab_count
+  # make a few slabs completely full so probing continues into the next slab
+  keys = np.concatenate([present[:3000], rng.randint(0, 2**40, size=3000).astype(np.int64),
+                         np.array([oracle.EMPTY_KEY + 1, -1, 0], np.int64)])
+  hit_slot, n_miss = hb.embedding.cache.probe(dev(cache), dev(keys), slab_size)
+  want = oracle.cache_probe(cache, slab_size, keys)
+  np.testing.assert_equal(host(hit_slot), want)
+  assert int(n_miss.item()) == int((want < 0).sum())
+  hk, hc, mk, mkeys = hb.embedding.cache.lookup(dev(cache), dev(keys), slab_size)
+  np.testing.assert_equal(host(hk), np.where(want >= 0)[0])
+  np.testing.assert_equal(host(hc), want[want >= 0])
+  np.testing.assert_equal(host(mk), np.where(want < 0)[0])
+  np.testing.assert_equal(host(mkeys), keys[want < 0])
+
+
+# ----------------------------------------------------------------------------------
+# R5 communicator on one rank (RCCL self send/recv): lifecycle + offsets + fp16 wire
+def test_comm_world1_alltoallv():
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+  try:
+    assert coll.active_size() == 1
+    rng = np.random.RandomState(15)
+    vals = [rng.randn(n, d).astype(np.float32) for n, d in ((100, 16), (0, 8), (3000, 4))]
+    sizes = [[v.shape[0]] for v in vals]
+    outs = coll.alltoallv_n([dev(v) for v in vals], sizes, sizes)
+    torch.cuda.synchronize()
+    for v, o in zip(vals, outs):
+      np.testing.assert_equal(host(o), v)
+    outs = coll.alltoallv_n([dev(v) for v in vals], sizes, sizes, wire_dtype=torch.float16)
+    torch.cuda.synchronize()
+    for v, o in zip(vals, outs):
+      np.testing.assert_equal(host(o), oracle.cast_f16_to_f32(oracle.cast_f32_to_f16(v)))
+    ids = dev(np.arange(10, dtype=np.int64))
+    out, out_sizes = coll.alltoall(ids, sizes=dev(np.array([10], np.int32)))
+    assert torch.equal(out, ids) and host(out_sizes).tolist() == [10]
+    coll.check_async_errors()
+  finally:
+    coll.close()

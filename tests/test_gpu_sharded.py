@@ -1,0 +1,114 @@
+"""The sharded pipeline driver (R12, sharding.py:171-205) on one GPU: W virtual ranks run the
+real HIP phases in one process; only the transport is simulated (device copies with the
+Alltoallv offset arithmetic of nccl_collective.cc:250-288).  The RCCL transport itself is
+covered at world size 1 in test_gpu_parity.py and by the gloo tests' offset arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import hybridbackend_amd as hb
+from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+  return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def fake_alltoallv(send_vals, send_sizes):
+  """send_vals[r]: tensor [sum(send_sizes[r]), ...]; send_sizes[r][i] rows r -> i."""
+  W = len(send_vals)
+  outs = []
+  for r in range(W):
+    chunks = []
+    for i in range(W):
+      off = sum(send_sizes[i][:r])
+      chunks.append(send_vals[i][off:off + send_sizes[i][r]])
+    outs.append(torch.cat(chunks, 0).contiguous())
+  return outs
+
+
+@pytest.mark.parametrize('world', [1, 2, 4, 8])
+@pytest.mark.parametrize('wire16', [False, True])
+def test_sharded_forward_equals_unsharded(world, wire16):
+  rng = np.random.RandomState(100 + world)
+  dims = [16, 4, 32, 16, 128]
+  rows = [1000003, 977, 5000, 64, 20011]
+  combiners = ['sum', 'mean', 'sqrtn', 'sum', 'mean']
+  n = len(dims)
+  tables = [rng.uniform(-1e-3, 1e-3, size=(rows[c], dims[c])).astype(np.float32)
+            for c in range(n)]
+  drivers, ids, splits = [], [], []
+  for r in range(world):
+    shards = [dev(t[r::world]) for t in tables]
+    drivers.append(ShardedGroupLookup(shards, None, buckets=rows, combiners=combiners,
+                                      world_size=world))
+    rid, rsp = [], []
+    for c in range(n):
+      if c % 2 == 0:
+        rsp.append(None)
+        rid.append(rng.randint(0, 2**40, size=rng.randint(0, 3000)).astype(np.int64))
+      else:
+        lens = rng.poisson(3, size=rng.randint(1, 500)).clip(0, 12)
+        sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        rsp.append(sp)
+        rid.append(rng.randint(0, 2**40, size=int(sp[-1])).astype(np.int64))
+    ids.append(rid)
+    splits.append(rsp)
+  # phase 1 on every rank
+  sts = [drivers[r].partition([dev(i) for i in ids[r]],
+                              [None if s is None else dev(s) for s in splits[r]])
+         for r in range(world)]
+  for r in range(world):   # integer step: bit-exact vs the CPU functor
+    for c in range(n):
+      oy, osz, oi = oracle.partition_by_modulo(oracle.floormod(ids[r][c], rows[c]), world)
+      np.testing.assert_equal(sts[r].send_ids[c].cpu().numpy(), oy)
+      np.testing.assert_equal(sts[r].send_sizes[c].cpu().numpy(), osz)
+      np.testing.assert_equal(sts[r].shard_index[c].cpu().numpy(), oi)
+  sizes = [[sts[r].send_sizes[c].cpu().tolist() for r in range(world)] for c in range(n)]
+  # exchange 1: ids
+  recv_ids = [[None] * n for _ in range(world)]
+  for c in range(n):
+    got = fake_alltoallv([sts[r].send_ids[c] for r in range(world)], sizes[c])
+    for r in range(world):
+      recv_ids[r][c] = got[r]
+  send_rows = [drivers[r].owner_gather(sts[r], recv_ids[r]) for r in range(world)]
+  # exchange 2: rows travel back with the transposed sizes
+  recv_rows = [[None] * n for _ in range(world)]
+  for c in range(n):
+    back = [[sizes[c][i][r] for i in range(world)] for r in range(world)]
+    vals = [send_rows[r][c] for r in range(world)]
+    if wire16:
+      vals = hb.distribute.cast_n(vals, torch.float16)
+    got = fake_alltoallv(vals, back)
+    if wire16:
+      got = hb.distribute.cast_n(got, torch.float32)
+    for r in range(world):
+      recv_rows[r][c] = got[r]
+  for r in range(world):
+    outs = drivers[r].stitch(sts[r], recv_rows[r])
+    eff = tables
+    if wire16:
+      eff = [oracle.cast_f16_to_f32(oracle.cast_f32_to_f16(t)) for t in tables]
+    want = oracle.group_lookup_fwd(eff, ids[r], splits[r], rows, combiners)
+    for c in range(n):
+      np.testing.assert_equal(outs[c].cpu().numpy(), want[c])
+
+
+def test_sharded_call_through_rccl_world1():
+  rng = np.random.RandomState(7)
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+  try:
+    tables = [rng.uniform(-1, 1, size=(5000, 16)).astype(np.float32) for _ in range(3)]
+    ids = [rng.randint(0, 2**40, size=4000).astype(np.int64) for _ in range(3)]
+    drv = ShardedGroupLookup([dev(t) for t in tables], coll, buckets=[5000] * 3)
+    outs = drv([dev(i) for i in ids])
+    torch.cuda.synchronize()
+    want = oracle.group_lookup_fwd(tables, ids, [None] * 3, [5000] * 3, ['sum'] * 3)
+    for o, w in zip(outs, want):
+      np.testing.assert_equal(o.cpu().numpy(), w)
+  finally:
+    coll.close()

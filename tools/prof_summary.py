@@ -1,0 +1,48 @@
+"""Condense rocprofv3 output (csv) under gpurun_out/ into the small text/json summaries that
+are committed under profiles/.
+
+  python tools/prof_summary.py stats  gpurun_out/prof            -> per-kernel time table
+  python tools/prof_summary.py pmc    gpurun_out/pmc_FETCH_SIZE  -> per-kernel counter means
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+  name = name.replace('hbk::(anonymous namespace)::', 'hbk::')
+  name = name.split('(')[0] if name.startswith('hbk::') else name
+  return name if len(name) <= 90 else name[:87] + '...'
+
+
+def stats(d):
+  files = glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)
+  agg = defaultdict(list)
+  for f in files:
+    for row in csv.DictReader(open(f)):
+      dur = (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3
+      agg[short(row['Kernel_Name'])].append(dur)
+  total = sum(sum(v) for v in agg.values())
+  print(f'{"kernel":<92}{"calls":>7}{"total_us":>12}{"avg_us":>10}{"min_us":>10}{"max_us":>10}{"pct":>7}')
+  for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+    print(f'{k:<92}{len(v):>7}{sum(v):>12.1f}{sum(v)/len(v):>10.2f}{min(v):>10.2f}{max(v):>10.2f}'
+          f'{100*sum(v)/total:>7.1f}')
+
+
+def pmc(d):
+  files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+  agg = defaultdict(lambda: defaultdict(list))
+  for f in files:
+    for row in csv.DictReader(open(f)):
+      agg[short(row['Kernel_Name'])][row['Counter_Name']].append(float(row['Counter_Value']))
+  out = {}
+  for k, ctrs in agg.items():
+    out[k] = {c: {'mean': sum(v) / len(v), 'n': len(v)} for c, v in ctrs.items()}
+  print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == '__main__':
+  {'stats': stats, 'pmc': pmc}[sys.argv[1]](sys.argv[2])

@@ -170,8 +170,16 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
 
 __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupArgs a) {
   const int b = (int)blockIdx.x;
-  int ci = 0;
-  while (ci + 1 < a.n_cols && a.tile_start[ci + 1] <= b) ++ci;
+  // last column whose first tile is <= b: binary search, <= 5 dependent scalar loads
+  int ci = 0, hi = a.n_cols;
+  while (hi - ci > 1) {
+    const int mid = (ci + hi) >> 1;
+    if (a.tile_start[mid] <= b) {
+      ci = mid;
+    } else {
+      hi = mid;
+    }
+  }
   const ColArg& c = a.col[ci];
   const int64_t tile = b - a.tile_start[ci];
   const int wave = (int)(threadIdx.x >> 6);

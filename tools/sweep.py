@@ -1,0 +1,172 @@
+"""Secondary measurements on one MI355X (not the bench line): batch sweep, ragged multi-hot,
+config-4 (dim 128, one 100M-row table, Zipf ids) forward/backward, and the integer kernels.
+Prints one JSON object per case; algorithmic bytes follow SURVEY.md 8(d).
+
+  python tools/sweep.py [--cases a,b,c,d,e] [--big]     (--big allocates the 51 GB table)
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import hybridbackend_amd as hb  # noqa: E402
+
+DEV = torch.device('cuda', 0)
+PEAK = 8000.0
+
+
+def timed(fn, iters=20, warmup=3):
+  for i in range(warmup):
+    fn(i)
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for i in range(iters):
+    fn(warmup + i)
+  e1.record()
+  torch.cuda.synchronize()
+  return e0.elapsed_time(e1) * 1e3 / iters  # us
+
+
+def report(name, us, lookups, nbytes, **extra):
+  gbs = nbytes / us / 1e3
+  print(json.dumps(dict(case=name, us=round(us, 2), M_lookups_per_s=round(lookups / us, 1),
+                        algorithmic_GBps=round(gbs, 1), frac_of_8TBps=round(gbs / PEAK, 4),
+                        **extra)), flush=True)
+
+
+def uniform_tables(n, rows, dim):
+  return [torch.empty(rows, dim, device=DEV).uniform_(-1e-3, 1e-3) for _ in range(n)]
+
+
+def zipf_ids(n, rows, alpha, gen, perm_mult):
+  """Zipf(alpha) ranks by inverse CDF over [1, rows], scattered over the table by a fixed
+  multiplicative permutation ('inverse-CDF on a fixed permutation, seed 7')."""
+  u = torch.rand(n, device=DEV, dtype=torch.float64, generator=gen)
+  a = 1.0 - alpha
+  # continuous approximation of the Zipf CDF: F(x) ~ (x^a - 1) / (R^a - 1)
+  x = ((u * (float(rows) ** a - 1.0)) + 1.0) ** (1.0 / a)
+  rank = x.floor().clamp_(1, rows).to(torch.int64) - 1
+  return (rank * perm_mult) % rows
+
+
+def case_batch_sweep():
+  tables = uniform_tables(26, 1000000, 16)
+  for B in (4096, 16384, 65536, 262144, 1048576):
+    nb = 8
+    batches = [[torch.randint(0, 1 << 40, (B,), device=DEV) for _ in range(26)] for _ in range(nb)]
+    outs = [torch.empty(B, 16, device=DEV) for _ in range(26)]
+    plans = []
+    for b in range(nb):
+      gl = hb.embedding.GroupLookup(tables, [1000000] * 26, 'sum')
+      gl.bind(batches[b], None, outs)
+      plans.append(gl)
+    us = timed(lambda i: plans[i % nb].launch(), iters=30)
+    report(f'cfg2 fwd H=1 dim16 B={B}', us, 26 * B, 26 * B * 136)
+    del batches, outs, plans
+
+
+def case_ragged():
+  tables = uniform_tables(26, 1000000, 16)
+  S = 65536
+  g = torch.Generator(device=DEV)
+  g.manual_seed(5)
+  nb = 4
+  for comb in ('sum', 'mean'):
+    plans, n_tot = [], 0
+    for b in range(nb):
+      ids, sps = [], []
+      for c in range(26):
+        lens = torch.poisson(torch.full((S,), 8.0, device=DEV), generator=g).clamp_(0, 32)
+        sp = torch.zeros(S + 1, dtype=torch.int32, device=DEV)
+        sp[1:] = torch.cumsum(lens, 0).to(torch.int32)
+        n = int(sp[-1].item())
+        ids.append(torch.randint(0, 1 << 40, (n,), device=DEV))
+        sps.append(sp)
+        if b == 0:
+          n_tot += n
+      gl = hb.embedding.GroupLookup(tables, [1000000] * 26, comb)
+      gl.bind(ids, sps, None)
+      plans.append(gl)
+    us = timed(lambda i: plans[i % nb].launch(), iters=20)
+    nbytes = n_tot * 8 + n_tot * 64 + 26 * S * 64 + 26 * (S + 1) * 4
+    report(f'cfg2 fwd ragged Poisson(8) dim16 S={S} {comb}', us, n_tot, nbytes, ids=n_tot)
+
+
+def case_backward_cfg2():
+  tables = uniform_tables(26, 1000000, 16)
+  B = 65536
+  nb = 4
+  lookup = hb.embedding.GroupLookup(tables, [1000000] * 26, 'sum')
+  grad = hb.embedding.GroupLookupGrad(lookup)
+  batches = [[torch.randint(0, 1 << 40, (B,), device=DEV) for _ in range(26)] for _ in range(nb)]
+  gouts = [torch.randn(B, 16, device=DEV) for _ in range(26)]
+  res = grad(batches[0], gouts)
+  u = sum(int(r[2].item()) for r in res)
+  for lr, tag in ((0.0, 'IndexedSlices only'), (0.01, 'fused SGD apply')):
+    us = timed(lambda i: grad(batches[i % nb], gouts, apply_lr=lr), iters=10)
+    nbytes = 26 * B * 8 + 26 * B * 64 + u * (2 * 64 if lr else 64)
+    report(f'cfg2 bwd H=1 dim16 B={B} ({tag})', us, 26 * B, nbytes, unique_rows=u)
+
+
+def case_cfg4(big):
+  dim, B = 128, 65536
+  rows = [1000000] * 25 + [100000000 if big else 10000000]
+  tables = [torch.empty(r, dim, device=DEV).uniform_(-1e-3, 1e-3) for r in rows]
+  g = torch.Generator(device=DEV)
+  g.manual_seed(7)
+  nb = 4
+  batches = [[zipf_ids(B, rows[c], 1.2, g, 2654435761 % rows[c] | 1) for c in range(26)]
+             for _ in range(nb)]
+  lookup = hb.embedding.GroupLookup(tables, None, 'sum')
+  outs = [torch.empty(B, dim, device=DEV) for _ in range(26)]
+  plans = []
+  for b in range(nb):
+    gl = hb.embedding.GroupLookup(tables, None, 'sum')
+    gl.bind(batches[b], None, outs)
+    plans.append(gl)
+  us = timed(lambda i: plans[i % nb].launch(), iters=20)
+  uniq = sum(int(torch.unique(batches[0][c]).numel()) for c in range(26))
+  report(f'cfg4 fwd Zipf(1.2) dim128 B={B} big_rows={rows[-1]}', us, 26 * B,
+         26 * B * (8 + 512 + 512), unique_rows=uniq,
+         dedup_aware_GBps=round((26 * B * (8 + 512) + uniq * 512) / us / 1e3, 1))
+  grad = hb.embedding.GroupLookupGrad(lookup)
+  gouts = [torch.randn(B, dim, device=DEV) for _ in range(26)]
+  for lr, tag in ((0.0, 'IndexedSlices only'), (0.01, 'fused SGD apply')):
+    us = timed(lambda i: grad(batches[i % nb], gouts, apply_lr=lr), iters=10)
+    nbytes = 26 * B * 8 + 26 * B * 512 + uniq * (2 * 512 if lr else 512)
+    report(f'cfg4 bwd Zipf(1.2) dim128 B={B} ({tag})', us, 26 * B, nbytes, unique_rows=uniq)
+
+
+def case_integer():
+  B = 65536
+  ids = [torch.randint(0, 1 << 40, (B,), device=DEV) for _ in range(26)]
+  for P in (2, 8):
+    us = timed(lambda i: hb.distribute.partition_by_modulo_n(ids, P), iters=20)
+    # reads ids twice (histogram + scatter), writes ids + int32 indices
+    report(f'partition_by_modulo_n 26 x {B} int64 P={P}', us, 26 * B, 26 * B * (8 + 8 + 8 + 4))
+  # the reference's own partition benchmark shape: 100 columns x 100000 ids, 8 partitions
+  ids100 = [torch.randint(0, 3 * 100 * 100000, (100000,), device=DEV, dtype=torch.int32)
+            for _ in range(100)]
+  us = timed(lambda i: hb.distribute.partition_by_modulo_n(ids100, 8), iters=20)
+  report('partition_by_modulo_n 100 x 100000 int32 P=8 (reference benchmark shape)', us,
+         100 * 100000, 100 * 100000 * (4 + 4 + 4 + 4))
+  us = timed(lambda i: hb.embedding.unique_n(ids), iters=10)
+  report(f'unique_n 26 x {B} int64', us, 26 * B, 26 * B * (8 + 8 + 4))
+
+
+if __name__ == '__main__':
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--cases', default='a,b,c,d,e')
+  ap.add_argument('--big', action='store_true')
+  args = ap.parse_args()
+  torch.manual_seed(0)
+  for c in args.cases.split(','):
+    {'a': case_batch_sweep, 'b': case_ragged, 'c': case_backward_cfg2,
+     'd': lambda: case_cfg4(args.big), 'e': case_integer}[c]()
+    torch.cuda.empty_cache()

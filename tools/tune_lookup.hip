@@ -11,6 +11,8 @@
 
 #include <vector>
 
+#include "../include/hbk.h"
+
 #define CK(x)                                                                      \
   do {                                                                             \
     hipError_t e = (x);                                                            \
@@ -309,8 +311,45 @@ int main(int argc, char** argv) {
     return 0;
   }
 
+  // 26 separately allocated tables (as a framework allocator would hand them out)
+  std::vector<float*> sep(kCols);
+  for (int k = 0; k < kCols; ++k) {
+    CK(hipMalloc(&sep[k], rows * kDim * 4));
+    CK(hipMemset(sep[k], 0x3c, rows * kDim * 4));
+  }
   for (int B : {65536, 262144}) {
     c.a.B = B;
+    for (int separate = 0; separate < 2; ++separate) {
+      // the shipped kernel through the C ABI, on the same buffers
+      std::vector<hbk_lookup_column_t> cols(kCols);
+      float us = time_us(c, 30, [&](int i) {
+        const int64_t* ids = c.id_batches[i % c.id_batches.size()];
+        for (int k = 0; k < kCols; ++k) {
+          hbk_lookup_column_t& h = cols[k];
+          h.table = separate ? sep[k] : c.a.table[k];
+          h.rows = (int64_t)rows;
+          h.dim = kDim;
+          h.ids_dtype = HBK_INT64;
+          h.ids = ids + (size_t)k * B;
+          h.n_ids = B;
+          h.row_splits = nullptr;
+          h.n_segments = B;
+          h.bucket = (int64_t)rows;
+          h.divisor = 1;
+          h.combiner = HBK_COMBINER_SUM;
+          h.out = c.a.out + (size_t)k * B * kDim;
+        }
+        if (hbk_group_lookup_fwd(kCols, cols.data(), nullptr) != 0) {
+          fprintf(stderr, "hbk_group_lookup_fwd: %s\n", hbk_last_error());
+          exit(1);
+        }
+      });
+      const double total = (double)kCols * B;
+      printf("%-44s B=%7d  %8.2f us  %8.1f GB/s  %5.1f%% of 8TB/s  %8.1f Mlookups/s\n",
+             separate ? "libhbk_core hbk_group_lookup_fwd (26 allocs)"
+                      : "libhbk_core hbk_group_lookup_fwd (1 alloc)",
+             B, us, total * 136.0 / us / 1e3, total * 136.0 / us / 1e3 / 80.0, total / us);
+    }
     run_variant<4, 256, false, true, 0>(c, "U4 b256 shfl  row:ld  out:nt  (library)");
     run_variant<4, 256, true, true, 0>(c, "U4 b256 shfl  row:nt  out:nt");
     run_variant<4, 256, false, false, 0>(c, "U4 b256 shfl  row:ld  out:st");

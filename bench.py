@@ -99,7 +99,7 @@ def cpu_baseline(args, tables, id_batch, budget_s):
     oracle.group_lookup_fwd(h_tables, h_ids, [None] * cols, buckets, comb, n_threads=threads)
     passes += 1
     el = time.perf_counter() - t0
-    if el >= budget_s or passes >= 200:
+    if el >= budget_s or passes >= 5000:
       break
   lookups = passes * cols * args.batch
   return {

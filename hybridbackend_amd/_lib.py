@@ -49,6 +49,13 @@ class LookupGradColumn(C.Structure):
               ('n_unique', C.c_void_p)]
 
 
+class StitchGradColumn(C.Structure):
+  """hbk_stitch_grad_column_t"""
+  _fields_ = [('dim', C.c_int32), ('combiner', C.c_int32), ('n_ids', C.c_int64),
+              ('index', C.c_void_p), ('row_splits', C.c_void_p), ('n_segments', C.c_int64),
+              ('grad_out', C.c_void_p), ('grad_rows', C.c_void_p)]
+
+
 _lib = None
 
 
@@ -72,6 +79,7 @@ def _declare(l):
     'hbk_group_lookup_fwd': (C.c_int, [i32, vp, vp]),
     'hbk_group_lookup_bwd_workspace_bytes': (sz, [i32, vp]),
     'hbk_group_lookup_bwd': (C.c_int, [i32, vp, C.c_float, vp, sz, vp]),
+    'hbk_group_stitch_bwd': (C.c_int, [i32, vp, vp]),
     'hbk_cache_probe': (C.c_int, [vp, i64, i32, vp, i64, vp, vp, vp]),
     'hbk_murmur3_hash32': (C.c_int, [vp, i64, vp, vp]),
     'hbk_comm_get_id': (C.c_int, [vp]),

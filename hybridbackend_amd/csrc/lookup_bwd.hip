@@ -14,6 +14,7 @@
 //               1e-5 relative tolerance)
 //   5 apply     (apply_lr != 0) table[unique_rows[u]] -= lr * grad_rows[u]
 #include <alloca.h>
+#include <string.h>
 
 #include <vector>
 
@@ -148,7 +149,7 @@ __device__ inline void scatter_segments(const BCol& c, int64_t seg0) {
     for (int32_t j = beg; j < end; ++j) {
       const int32_t u = c.inv[j];
       float* dst = c.grad_rows + (int64_t)u * c.dim + (int64_t)sub * VE;
-      if (c.mult[u] == 1) {
+      if (c.mult == nullptr || c.mult[u] == 1) {
         *reinterpret_cast<V*>(dst) = g;
       } else {
         atomic_add_v<V>(dst, g);
@@ -362,6 +363,69 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       hipLaunchKernelGGL(bwd_apply_kernel, dim3((unsigned)gr.t_urow), dim3(kBlock), 0, stream,
                          gr.args);
     }
+    HBK_HIP_OK(hipGetLastError());
+  }
+  return HBK_OK;
+}
+
+// d(stitch + combiner) of the sharded pipeline (sharding.py:200 in reverse):
+//   grad_rows[index[j], :] = scale(seg(j)) * grad_out[seg(j), :]
+// `index` is the shard_index permutation of the forward partition, so every destination row is
+// written exactly once: plain 16-byte stores, no atomics, no zeroing.
+extern "C" int hbk_group_stitch_bwd(int32_t n_cols, const hbk_stitch_grad_column_t* cols,
+                                    hbk_stream_t stream_) {
+  using namespace hbk;
+  hipStream_t stream = as_stream(stream_);
+  HBK_REQUIRE(n_cols >= 0, "group_stitch_bwd: n_cols must be >= 0, got %d", n_cols);
+  if (n_cols == 0) return HBK_OK;
+  HBK_REQUIRE(cols != nullptr, "group_stitch_bwd: cols is NULL");
+  int32_t c0 = 0;
+  while (c0 < n_cols) {
+    BArgs args;
+    int32_t k = 0;
+    int64_t t_seg = 0;
+    while (c0 < n_cols && k < kMaxCols) {
+      const int32_t ci = c0++;
+      const hbk_stitch_grad_column_t& h = cols[ci];
+      HBK_REQUIRE(h.dim >= 1, "group_stitch_bwd: column %d: dim must be >= 1", ci);
+      HBK_REQUIRE(h.n_ids >= 0 && h.n_segments >= 0 && h.n_ids < (1ll << 31),
+                  "group_stitch_bwd: column %d: bad size", ci);
+      HBK_REQUIRE(h.combiner >= HBK_COMBINER_SUM && h.combiner <= HBK_COMBINER_SQRTN,
+                  "group_stitch_bwd: column %d: unknown combiner %d", ci, h.combiner);
+      HBK_REQUIRE(h.row_splits != nullptr || h.n_segments == h.n_ids,
+                  "group_stitch_bwd: column %d: n_segments must equal n_ids when row_splits "
+                  "is NULL", ci);
+      if (h.n_ids == 0 || h.n_segments == 0) continue;
+      HBK_REQUIRE(h.index && h.grad_out && h.grad_rows,
+                  "group_stitch_bwd: column %d: NULL buffer", ci);
+      BCol& d = args.col[k];
+      memset(&d, 0, sizeof(d));
+      d.grad_out = h.grad_out;
+      d.splits = h.row_splits;
+      d.inv = h.index;
+      d.mult = nullptr;
+      d.grad_rows = h.grad_rows;
+      d.n_ids = h.n_ids;
+      d.n_seg = h.n_segments;
+      d.dim = h.dim;
+      RowShape shape;
+      HBK_REQUIRE(make_rowshape(h.dim, (uintptr_t)h.grad_out | (uintptr_t)h.grad_rows, &shape),
+                  "group_stitch_bwd: dim %d needs more than 64 lanes per row", h.dim);
+      d.chunks = shape.chunks;
+      d.lpr_log2 = shape.lpr_log2;
+      d.vec4 = shape.vec4;
+      d.combiner = (uint8_t)h.combiner;
+      const int64_t rpi = kWave >> d.lpr_log2;
+      const int64_t per_block = kWavesPerBlock * kIters * rpi;
+      d.tile_seg = (int32_t)t_seg;
+      t_seg += (h.n_segments + per_block - 1) / per_block;
+      HBK_REQUIRE(t_seg < (1ll << 31), "group_stitch_bwd: grid too large");
+      ++k;
+    }
+    if (k == 0) continue;
+    args.n_cols = k;
+    args.lr = 0.0f;
+    hipLaunchKernelGGL(bwd_scatter_kernel, dim3((unsigned)t_seg), dim3(kBlock), 0, stream, args);
     HBK_HIP_OK(hipGetLastError());
   }
   return HBK_OK;

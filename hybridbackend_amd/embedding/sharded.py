@@ -21,6 +21,8 @@ here the receive sizes of BOTH exchanges come from the single size exchange of s
 The compute phases are separate methods so a test can drive W virtual ranks in one process
 with its own transport; ``__call__`` runs them against the RCCL communicator.
 """
+import ctypes as C
+
 import torch
 
 from hybridbackend_amd import _lib
@@ -72,6 +74,7 @@ class ShardedGroupLookup:
     self._lib = _lib.lib()
     # owner-side gather: ids arrive bucketized, row = id // W (sharding.py:188-189)
     self._owner = GroupLookup(self.shards, None, 'sum', divisor=self.world_size)
+    self._owner_grad = GroupLookupGrad(self._owner)
 
   # ---- phase 1: bucketize + stable partition -------------------------------------
   def partition(self, ids, row_splits=None):
@@ -130,3 +133,53 @@ class ShardedGroupLookup:
                                       common_sizes=self.dims, wire_dtype=self.wire_dtype)
     outs = self.stitch(st, recv_rows)
     return (outs, st) if keep else outs
+
+  # ---- backward -----------------------------------------------------------------
+  # phase B1: d(stitch + combiner): per-id gradient rows in the order of the partitioned ids
+  def stitch_bwd(self, st, grads):
+    n = len(self.shards)
+    from hybridbackend_amd.embedding.lookup import _combiner_code
+    combs = self.combiners
+    if isinstance(combs, (str, int)) or combs is None:
+      combs = [combs] * n
+    cols = (_lib.StitchGradColumn * n)()
+    outs = []
+    for c in range(n):
+      g = grads[c]
+      _lib.require_device_tensor(g, 'grads')
+      n_ids = st.shard_index[c].numel()
+      sp = st.row_splits[c]
+      n_seg = n_ids if sp is None else sp.numel() - 1
+      if g.dtype != torch.float32 or tuple(g.shape) != (n_seg, self.dims[c]):
+        raise _lib.InvalidArgumentError(
+          _lib.INVALID_ARGUMENT, f'grad {c} must be fp32 [{n_seg}, {self.dims[c]}]')
+      o = torch.empty((n_ids, self.dims[c]), dtype=torch.float32, device=self.device)
+      col = cols[c]
+      col.dim = self.dims[c]
+      col.combiner = _combiner_code(combs[c])
+      col.n_ids = n_ids
+      col.index = st.shard_index[c].data_ptr()
+      col.row_splits = sp.data_ptr() if sp is not None else None
+      col.n_segments = n_seg
+      col.grad_out = g.data_ptr()
+      col.grad_rows = o.data_ptr()
+      outs.append(o)
+    _lib.check(self._lib.hbk_group_stitch_bwd(n, cols, _lib.current_stream(self.device)))
+    return outs
+
+  # phase B3: owner side: duplicate-row reduction (+ optional fused SGD on the shard)
+  def owner_bwd(self, st, recv_grads, apply_lr=0.0):
+    return self._owner_grad(st.recv_ids, recv_grads, None, apply_lr=apply_lr)
+
+  def backward(self, st, grads, apply_lr=0.0, wire_dtype=None):
+    """grads[c]: gradient of column c's output [segments, dim].  Returns per column the
+    IndexedSlices of the LOCAL shard ``(unique_rows, grad_rows, n_unique)``; with
+    ``apply_lr`` the SGD update is applied to the shard in the same pass (sharded variables
+    are not aggregated across ranks, training/gradient.py:193-217).  The exchange reuses the
+    forward's sizes reversed (collective.py:334-347): no new size exchange, no host sync."""
+    send = self.stitch_bwd(st, grads)
+    recv = self.coll.alltoallv_n(send, st.send_sizes_host, st.recv_sizes_host,
+                                 common_sizes=self.dims,
+                                 wire_dtype=wire_dtype if wire_dtype is not None
+                                 else self.wire_dtype)
+    return self.owner_bwd(st, recv, apply_lr)

@@ -198,6 +198,27 @@ int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
                          float apply_lr, void* workspace, size_t workspace_bytes,
                          hbk_stream_t stream);
 
+/* R10 (sharded form)  d(stitch + combiner): the transpose of the requester-side
+ *   `gather(embeddings, shard_index)` + combiner (hbtf/embedding/sharding.py:200; TF emits
+ *   SparseSegment*Grad followed by an UnsortedSegmentSum over a permutation):
+ *     grad_rows[index[j], :] = scale(seg(j)) * grad_out[seg(j), :]
+ *   `index` = the `indices` output of the forward partition (a permutation of 0..n_ids-1), so
+ *   each row of grad_rows [n_ids, dim] is written exactly once.  The result is what travels
+ *   back through the reverse alltoallv (hbtf/distribute/collective.py:334-347).            */
+typedef struct {
+  int32_t dim;
+  int32_t combiner;
+  int64_t n_ids;
+  const int32_t* index;       /* device [n_ids] */
+  const int32_t* row_splits;  /* device [n_segments + 1] or NULL */
+  int64_t n_segments;
+  const float* grad_out;      /* device [n_segments, dim] */
+  float* grad_rows;           /* device [n_ids, dim] */
+} hbk_stitch_grad_column_t;
+
+int hbk_group_stitch_bwd(int32_t n_cols, const hbk_stitch_grad_column_t* cols,
+                         hbk_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * R11 HbLookup: cache probe.  op hbtf/embedding/lookup_ops.cc:38-58; kernel
  *     hbtf/embedding/lookup_functors.cu.cc:54-149; hash hybridbackend/common/murmur3.cu.h:32-77.

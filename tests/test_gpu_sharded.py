@@ -112,3 +112,79 @@ def test_sharded_call_through_rccl_world1():
       np.testing.assert_equal(o.cpu().numpy(), w)
   finally:
     coll.close()
+
+
+@pytest.mark.parametrize('world', [1, 2, 8])
+def test_sharded_backward_equals_dense_scatter(world):
+  rng = np.random.RandomState(200 + world)
+  dims, rows = [16, 8, 32], [5003, 300, 64]
+  combiners = ['sum', 'mean', 'sqrtn']
+  n = len(dims)
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(n)]
+  drivers, ids, splits, grads = [], [], [], []
+  for r in range(world):
+    drivers.append(ShardedGroupLookup([dev(t[r::world]) for t in tables], None, buckets=rows,
+                                      combiners=combiners, world_size=world))
+    rid, rsp, rg = [], [], []
+    for c in range(n):
+      if c == 0:
+        sp = None
+        k = int(rng.randint(1, 2000))
+      else:
+        lens = rng.poisson(3, size=rng.randint(1, 300)).clip(0, 12)
+        sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        k = int(sp[-1])
+      rsp.append(sp)
+      rid.append(rng.randint(0, 2**40, size=k).astype(np.int64))
+      rg.append(rng.randn(k if sp is None else sp.size - 1, dims[c]).astype(np.float32))
+    ids.append(rid)
+    splits.append(rsp)
+    grads.append(rg)
+  sts = [drivers[r].partition([dev(i) for i in ids[r]],
+                              [None if s is None else dev(s) for s in splits[r]])
+         for r in range(world)]
+  sizes = [[sts[r].send_sizes[c].cpu().tolist() for r in range(world)] for c in range(n)]
+  for r in range(world):
+    got = [fake_alltoallv([sts[q].send_ids[c] for q in range(world)], sizes[c])[r]
+           for c in range(n)]
+    drivers[r].owner_gather(sts[r], got)
+  # B1 on every rank, then the reverse exchange: requester r sends sizes[c][r] back
+  send = [drivers[r].stitch_bwd(sts[r], [dev(g) for g in grads[r]]) for r in range(world)]
+  slices = []
+  for r in range(world):
+    recv = [fake_alltoallv([send[q][c] for q in range(world)], sizes[c])[r] for c in range(n)]
+    slices.append(drivers[r].owner_bwd(sts[r], recv))
+  for c in range(n):
+    dense = np.zeros((rows[c], dims[c]), np.float64)
+    for r in range(world):
+      sp = splits[r][c] if splits[r][c] is not None else np.arange(ids[r][c].size + 1,
+                                                                   dtype=np.int32)
+      g_id = oracle.segment_combine_grad(grads[r][c], sp, combiners[c]).astype(np.float64)
+      np.add.at(dense, ids[r][c] % rows[c], g_id)
+    got = np.zeros_like(dense)
+    for r in range(world):
+      urows, grows, nu = slices[r][c]
+      k = int(nu.item())
+      lr = urows.cpu().numpy()[:k]
+      assert len(set(lr.tolist())) == k                 # deduplicated on the owner
+      got[lr * world + r] += grows.cpu().numpy()[:k]
+    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5)
+
+
+def test_sharded_backward_through_rccl_world1_with_apply():
+  rng = np.random.RandomState(9)
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+  try:
+    table = rng.uniform(-1, 1, size=(3000, 16)).astype(np.float32)
+    ids = rng.randint(0, 2**40, size=5000).astype(np.int64)
+    g = rng.randn(5000, 16).astype(np.float32)
+    t_dev = dev(table.copy())
+    drv = ShardedGroupLookup([t_dev], coll, buckets=[3000])
+    outs, st = drv([dev(ids)], keep=True)
+    drv.backward(st, [dev(g)], apply_lr=0.1)
+    torch.cuda.synchronize()
+    ref = table.astype(np.float64)
+    np.subtract.at(ref, ids % 3000, 0.1 * g.astype(np.float64))
+    np.testing.assert_allclose(t_dev.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+  finally:
+    coll.close()

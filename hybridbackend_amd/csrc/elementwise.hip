@@ -14,7 +14,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kPerThread = 8;
 constexpr int kTile = kBlock * kPerThread;
-constexpr int kMaxCols = 60;
+constexpr int kMaxCols = 128;
 
 struct EwCol {
   const void* in;
@@ -30,7 +30,7 @@ struct EwArgs {
   int32_t pad_;
   EwCol col[kMaxCols];
 };
-static_assert(sizeof(EwArgs) <= 4096, "kernarg budget");
+static_assert(sizeof(EwArgs) <= 16384, "kernarg budget");
 
 __device__ inline int find_col(const EwArgs& a, int tile) {
   int ci = 0;

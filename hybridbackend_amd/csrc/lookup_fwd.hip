@@ -22,7 +22,7 @@ namespace {
 
 constexpr int kBlock = 256;           // 4 waves
 constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kMaxColsPerLaunch = 30; // keeps LookupArgs under the 4 KB kernarg budget
+constexpr int kMaxColsPerLaunch = 128; // LookupArgs travels by value: 14.5 KB of kernarg (gfx950 takes >256 KB)
 constexpr int kU = 2;                 // independent row loads per lane (one-id-per-segment path);
                                       // 2 beats 4 by 4% at batch 65536 (shorter tail), equal at 262144
                                       // (tools/tune_lookup.hip, profiles/r01_tune_lookup.txt)
@@ -49,7 +49,7 @@ struct LookupArgs {
   int32_t tile_start[kMaxColsPerLaunch + 1];
   ColArg col[kMaxColsPerLaunch];
 };
-static_assert(sizeof(LookupArgs) <= 4096, "kernarg budget");
+static_assert(sizeof(LookupArgs) <= 16384, "kernarg budget");
 
 // ---------------------------------------------------------------------------------
 // one id per segment (Criteo scalar columns): out[s,:] = table[row(ids[s]),:]

@@ -28,7 +28,7 @@ namespace {
 
 constexpr int kChunks = 16;                   // 64-id chunks per tile
 constexpr int kTile = kChunks * kWave;        // 1024 ids per wave
-constexpr int kMaxColsPerLaunch = 64;
+constexpr int kMaxColsPerLaunch = 128;
 constexpr int kMaxPartitions = 16384;         // LDS counters: 64 KB
 
 struct PartCol {
@@ -55,7 +55,7 @@ struct PartArgs {
   ShardFn fn;
   PartCol col[kMaxColsPerLaunch];
 };
-static_assert(sizeof(PartArgs) <= 4096, "kernarg budget");
+static_assert(sizeof(PartArgs) <= 16384, "kernarg budget");
 
 template <typename T>
 __device__ inline uint32_t shard_of(T v, const ShardFn& f) {
@@ -197,6 +197,33 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
   for (int k = 0; k < kChunks; ++k) {
     const int64_t i = base + k * kWave + lane;
     v[k] = i < c.len ? in[i] : T(0);
+  }
+  if (P <= kWave) {
+    // small P (the W <= 8 case): lane p keeps the running counter of shard p in a register;
+    // the leader's base is fetched with v_readlane (uniform lane index), no LDS round trips
+    int32_t my_run = lane < P ? hist[(int64_t)lane * n_tiles + ctile] : 0;
+#pragma unroll
+    for (int k = 0; k < kChunks; ++k) {
+      const int64_t i = base + k * kWave + lane;
+      const bool valid = i < c.len;
+      const uint32_t shard = valid ? shard_of<T>(v[k], a.fn) : 0xffffffffu;
+      unsigned long long todo = __ballot(valid);
+      int32_t pos = 0;
+      while (todo != 0ull) {
+        const int leader = __builtin_ctzll(todo);
+        const int s = __builtin_amdgcn_readlane((int)shard, leader);
+        const unsigned long long same = __ballot(shard == (uint32_t)s);
+        const int32_t base_s = __builtin_amdgcn_readlane(my_run, s);
+        if (shard == (uint32_t)s) pos = base_s + rank_below(same);
+        if (lane == s) my_run += (int32_t)__builtin_popcountll(same);
+        todo &= ~same;
+      }
+      if (valid) {
+        out[pos] = v[k];
+        c.indices[i] = pos;
+      }
+    }
+    return;
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // run[] initialised
 #pragma unroll

@@ -21,7 +21,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kPerThread = 4;
 constexpr int kTile = kBlock * kPerThread;  // 1024 ids
-constexpr int kMaxCols = 34;
+constexpr int kMaxCols = 128;
 constexpr unsigned long long kEmpty = ~0ull;  // key -1 is kept in the dedicated slot H
 
 struct UCol {
@@ -47,7 +47,7 @@ struct UArgs {
   int32_t pad_;
   UCol col[kMaxCols];
 };
-static_assert(sizeof(UArgs) <= 4096, "kernarg budget");
+static_assert(sizeof(UArgs) <= 16384, "kernarg budget");
 
 __device__ inline int find_col(const UArgs& a, int tile) {
   int ci = 0;

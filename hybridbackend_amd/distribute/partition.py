@@ -48,11 +48,17 @@ def _partition_n(ids_list, num_partitions, modulus, stage, outputs=None):
   code = _lib.torch_dtype_code(dtype)
   lens = [int(t.numel()) for t in ids_list]
   if outputs is None:
-    outs = [torch.empty_like(t) for t in ids_list]
-    sizes = [torch.empty(max(num_partitions, 0), dtype=torch.int32, device=device)
-             for _ in ids_list]
-    idxs = [torch.empty(t.numel(), dtype=torch.int32, device=device)
-            for t in ids_list]
+    # three allocations for all N columns (views per column), not 3 N
+    total = sum(lens)
+    flat_out = torch.empty(total, dtype=dtype, device=device)
+    flat_idx = torch.empty(total, dtype=torch.int32, device=device)
+    sizes2d = torch.empty((n, max(num_partitions, 0)), dtype=torch.int32, device=device)
+    outs, idxs, off = [], [], 0
+    for k in lens:
+      outs.append(flat_out[off:off + k])
+      idxs.append(flat_idx[off:off + k])
+      off += k
+    sizes = [sizes2d[c] for c in range(n)]
   else:
     outs, sizes, idxs = outputs
   lens_a = _lib.i64_array(lens)

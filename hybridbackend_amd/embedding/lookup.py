@@ -157,25 +157,39 @@ class GroupLookupGrad:
 
   def __call__(self, ids, grads, row_splits=None, apply_lr=0.0):
     """Returns per column ``(unique_rows int64[n_ids], grad_rows f32[n_ids, dim],
-    n_unique int32[1])``; only the first ``n_unique`` rows are meaningful (device-side
-    count: no host sync here)."""
+    n_unique int32[1])``; only the first ``n_unique`` rows are meaningful, in unspecified
+    order (device-side count: no host sync here).  The result buffers belong to this object
+    and are reused by the next call with the same id counts."""
     n = len(self.lookup)
     if row_splits is None:
       row_splits = [None] * n
-    outs = []
     dev = self.lookup.tables[0].device if n else None
+    dims = [int(t.shape[1]) for t in self.lookup.tables]
+    counts = tuple(int(i.numel()) for i in ids)
+    if getattr(self, '_out_key', None) != counts:
+      # three allocations for all columns, carved into per-column views
+      self._urows = torch.empty(sum(counts), dtype=torch.int64, device=dev)
+      self._grows = torch.empty(sum(k * d for k, d in zip(counts, dims)), dtype=torch.float32,
+                                device=dev)
+      self._nu = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+      self._out_key = counts
+      self._views = []
+      o_r = o_g = 0
+      for c in range(n):
+        k, d = counts[c], dims[c]
+        self._views.append((self._urows[o_r:o_r + k],
+                            self._grows[o_g:o_g + k * d].view(k, d), self._nu[c:c + 1]))
+        o_r += k
+        o_g += k * d
     for c in range(n):
       i, g, s = ids[c], grads[c], row_splits[c]
       for t, what in ((i, 'ids'), (g, 'grads')):
         _lib.require_device_tensor(t, what)
       n_seg = i.numel() if s is None else s.numel() - 1
-      dim = self.lookup.tables[c].shape[1]
-      if g.dtype != torch.float32 or tuple(g.shape) != (n_seg, dim):
+      if g.dtype != torch.float32 or tuple(g.shape) != (n_seg, dims[c]):
         raise _lib.InvalidArgumentError(
-          _lib.INVALID_ARGUMENT, f'grad {c} must be fp32 [{n_seg}, {dim}]')
-      urows = torch.empty(i.numel(), dtype=torch.int64, device=dev)
-      grows = torch.empty((i.numel(), dim), dtype=torch.float32, device=dev)
-      nu = torch.zeros(1, dtype=torch.int32, device=dev)
+          _lib.INVALID_ARGUMENT, f'grad {c} must be fp32 [{n_seg}, {dims[c]}]')
+      urows, grows, nu = self._views[c]
       col = self._cols[c]
       col.ids_dtype = _lib.INT64 if i.dtype == torch.int64 else _lib.INT32
       col.ids = i.data_ptr()
@@ -186,11 +200,11 @@ class GroupLookupGrad:
       col.unique_rows = urows.data_ptr()
       col.grad_rows = grows.data_ptr()
       col.n_unique = nu.data_ptr()
-      outs.append((urows, grows, nu))
     need = self._lib.hbk_group_lookup_bwd_workspace_bytes(n, self._cols)
     if self._ws is None or self._ws.numel() < need:
       self._ws = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
+    self._keep = (ids, grads, row_splits)
     _lib.check(self._lib.hbk_group_lookup_bwd(
       n, self._cols, C.c_float(apply_lr), C.c_void_p(self._ws.data_ptr()),
       C.c_size_t(self._ws.numel()), _lib.current_stream(dev)))
-    return outs
+    return list(self._views)

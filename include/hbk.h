@@ -164,13 +164,16 @@ int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
 
 /* R10  HbGroupLookupGrad: backward of the above up to the IndexedSlices the optimizer
  *   gets (SparseSegment*Grad -> UnsortedSegmentSum dup-reduction):
- *     unique_rows[c][u]  = distinct row(j) in first-occurrence order   (int64)
+ *     unique_rows[c][u]  = the distinct row(j) of the column, in unspecified order   (int64)
  *     grad_rows[c][u,:]  = sum_{j: row(j) == unique_rows[u]} scale(seg(j)) * grad_out[seg(j),:]
- *     n_unique[c]        = u   (device int32)
- *   scale = 1 (sum), 1/count (mean), 1/sqrt(count) (sqrtn).  grad_rows has capacity
- *   [n_ids, dim] and is fully overwritten for rows < u.  Duplicate ids inside a wavefront
- *   are pre-reduced (ballot/match) before the fp32 atomic add, so summation order is not
- *   fixed: tolerance 1e-5 relative.
+ *     n_unique[c]        = u   (device int32; stays on the device, no host sync)
+ *   scale = 1 (sum), 1/count (mean), 1/sqrt(count) (sqrtn).  unique_rows / grad_rows have
+ *   capacity n_ids; rows >= n_unique are untouched.  Ids that map outside [0, rows) contribute
+ *   nothing.  No global atomics on the data path: ids are grouped by a hash of their row and
+ *   each group is reduced by one workgroup in an LDS table (ds_add_f32), so the summation
+ *   order is not fixed: tolerance 1e-5 relative.  Rows are distinct unless one group holds
+ *   more distinct rows than its LDS table (adversarial skew): then a row may appear in more
+ *   than one entry, sum semantics preserved (IndexedSlices allow repeated indices).
  *   apply_lr != 0 additionally performs the sparse SGD update on the shard in the same
  *   pass: table[unique_rows[u],:] -= apply_lr * grad_rows[u,:] (sharded variables skip
  *   cross-rank aggregation, hbtf/training/gradient.py:193-217).                        */

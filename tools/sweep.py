@@ -160,6 +160,30 @@ def case_integer():
   report(f'unique_n 26 x {B} int64', us, 26 * B, 26 * B * (8 + 8 + 4))
 
 
+def case_bwd_probe():
+  """Isolates the backward's regimes: dim 128, 26 columns x 65536 ids, 1M-row tables;
+  uniform ids vs Zipf ids vs a single hot row."""
+  dim, B, rows = 128, 65536, 1000000
+  tables = [torch.zeros(rows, dim, device=DEV) for _ in range(26)]
+  lookup = hb.embedding.GroupLookup(tables, None, 'sum')
+  grad = hb.embedding.GroupLookupGrad(lookup)
+  gouts = [torch.randn(B, dim, device=DEV) for _ in range(26)]
+  g = torch.Generator(device=DEV)
+  g.manual_seed(3)
+  kinds = {
+    'uniform': lambda: torch.randint(0, rows, (B,), device=DEV),
+    'zipf1.2': lambda: zipf_ids(B, rows, 1.2, g, 7919),
+    'hot20pct': lambda: torch.where(torch.rand(B, device=DEV) < 0.2,
+                                    torch.full((B,), 12345, device=DEV),
+                                    torch.randint(0, rows, (B,), device=DEV)),
+    'all_same': lambda: torch.full((B,), 777, device=DEV, dtype=torch.int64),
+  }
+  for name, mk in kinds.items():
+    ids = [mk() for _ in range(26)]
+    us = timed(lambda i: grad(ids, gouts), iters=5, warmup=2)
+    report(f'bwd probe dim128 {name}', us, 26 * B, 26 * B * (8 + 512 + 512))
+
+
 if __name__ == '__main__':
   ap = argparse.ArgumentParser()
   ap.add_argument('--cases', default='a,b,c,d,e')
@@ -168,5 +192,5 @@ if __name__ == '__main__':
   torch.manual_seed(0)
   for c in args.cases.split(','):
     {'a': case_batch_sweep, 'b': case_ragged, 'c': case_backward_cfg2,
-     'd': lambda: case_cfg4(args.big), 'e': case_integer}[c]()
+     'd': lambda: case_cfg4(args.big), 'e': case_integer, 'f': case_bwd_probe}[c]()
     torch.cuda.empty_cache()

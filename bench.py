@@ -175,8 +175,10 @@ def main():
       tables, coll, buckets=[args.rows] * args.columns, combiners='sum',
       wire_dtype=torch.float16 if args.wire == 'fp16' else None)
 
+    sh_outs = [torch.empty(args.batch, args.dim, device=device) for _ in range(args.columns)]
+
     def step(i):
-      sharded(batches[i % n_batches])
+      sharded(batches[i % n_batches], None, sh_outs)
     parallelism = f'row-sharded id-mod-{world} (alltoallv ids + rows over RCCL/xGMI)'
 
   def barrier():

@@ -49,6 +49,12 @@ class LookupGradColumn(C.Structure):
               ('n_unique', C.c_void_p)]
 
 
+class ShardedColumn(C.Structure):
+  """hbk_sharded_column_t"""
+  _fields_ = [('shard', C.c_void_p), ('rows_local', C.c_int64), ('dim', C.c_int32),
+              ('combiner', C.c_int32), ('bucket', C.c_int64)]
+
+
 class StitchGradColumn(C.Structure):
   """hbk_stitch_grad_column_t"""
   _fields_ = [('dim', C.c_int32), ('combiner', C.c_int32), ('n_ids', C.c_int64),
@@ -94,6 +100,15 @@ def _declare(l):
     'hbk_alltoallv_wire_workspace_bytes': (sz, [i32, vp, vp, vp, i32]),
     'hbk_alltoallv_n':
       (C.c_int, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'hbk_local_world_create': (C.c_int, [vp, i32]),
+    'hbk_local_world_destroy': (C.c_int, [vp]),
+    'hbk_comm_create_local': (C.c_int, [vp, vp, i32]),
+    'hbk_sharded_layout': (C.c_int, [i32, i32] + [vp] * 12),
+    'hbk_sharded_create': (C.c_int, [vp, vp, i32, vp, i32]),
+    'hbk_sharded_destroy': (C.c_int, [vp]),
+    'hbk_sharded_lookup_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
+    'hbk_sharded_owned_ids': (i64, [vp, i32]),
+    'hbk_sharded_lookup_bwd': (C.c_int, [vp, vp, C.c_float, vp, vp, vp, vp]),
   }
   for name, (res, args) in protos.items():
     fn = getattr(l, name)   # AttributeError here = header and library out of sync

@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <vector>
 
@@ -24,7 +25,32 @@ int cast_n_impl(int32_t n, int32_t src_dtype, int32_t dst_dtype, const void* con
                 const int64_t* lens, void* const* outputs, hipStream_t stream);
 }
 
+// In-process world (tests): ranks = host threads sharing one GPU.
+struct LocalWorld {
+  int world;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  long generation = 0;
+  std::vector<const void*> ptr;          // [world] published send pointer
+  std::vector<std::vector<int64_t>> off; // [world][world] element offset of the chunk for peer j
+  std::vector<std::vector<int64_t>> len; // [world][world] elements for peer j
+  std::vector<hipEvent_t> ready, done;   // [world]
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long gen = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+
 struct hbk_comm {
+  LocalWorld* local = nullptr;
   ncclComm_t comm;
   hipStream_t stream;
   hipEvent_t compute_done;
@@ -93,8 +119,88 @@ int fence_out(hbk_comm* c, hipStream_t compute) {
   return HBK_OK;
 }
 
+// One exchange of the in-process world: every rank publishes (pointer, per-peer offsets and
+// lengths in elements), then copies its chunk out of every peer's buffer on its own stream.
+int local_exchange(hbk_comm* c, const void* sendbuf, const std::vector<int64_t>& send_off,
+                   const std::vector<int64_t>& send_len, void* recvbuf,
+                   const std::vector<int64_t>& recv_off, size_t esize, hipStream_t stream) {
+  LocalWorld* w = c->local;
+  const int me = c->rank;
+  w->ptr[me] = sendbuf;
+  w->off[me] = send_off;
+  w->len[me] = send_len;
+  HBK_HIP_OK(hipEventRecord(w->ready[me], stream));
+  w->barrier();
+  for (int i = 0; i < w->world; ++i) {
+    HBK_HIP_OK(hipStreamWaitEvent(stream, w->ready[i], 0));
+    const int64_t n = w->len[i][me];
+    if (n > 0) {
+      HBK_HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(recvbuf) + (size_t)recv_off[i] * esize,
+                                reinterpret_cast<const char*>(w->ptr[i]) +
+                                    (size_t)w->off[i][me] * esize,
+                                (size_t)n * esize, hipMemcpyDeviceToDevice, stream));
+    }
+  }
+  HBK_HIP_OK(hipEventRecord(w->done[me], stream));
+  w->barrier();
+  // nobody may reuse its send buffer before every peer has copied out of it
+  for (int i = 0; i < w->world; ++i) HBK_HIP_OK(hipStreamWaitEvent(stream, w->done[i], 0));
+  w->barrier();
+  return HBK_OK;
+}
+
 }  // namespace
 }  // namespace hbk
+
+extern "C" int hbk_local_world_create(void** world, int32_t world_size) {
+  using namespace hbk;
+  HBK_REQUIRE(world != nullptr && world_size >= 1, "local_world_create: bad argument");
+  LocalWorld* w = new LocalWorld();
+  w->world = world_size;
+  w->ptr.resize(world_size);
+  w->off.resize(world_size);
+  w->len.resize(world_size);
+  w->ready.resize(world_size);
+  w->done.resize(world_size);
+  for (int i = 0; i < world_size; ++i) {
+    HBK_HIP_OK(hipEventCreateWithFlags(&w->ready[i], hipEventDisableTiming));
+    HBK_HIP_OK(hipEventCreateWithFlags(&w->done[i], hipEventDisableTiming));
+  }
+  *world = w;
+  return HBK_OK;
+}
+
+extern "C" int hbk_local_world_destroy(void* world) {
+  LocalWorld* w = reinterpret_cast<LocalWorld*>(world);
+  if (w == nullptr) return HBK_OK;
+  for (int i = 0; i < w->world; ++i) {
+    (void)hipEventDestroy(w->ready[i]);
+    (void)hipEventDestroy(w->done[i]);
+  }
+  delete w;
+  return HBK_OK;
+}
+
+extern "C" int hbk_comm_create_local(hbk_comm_t* comm, void* world, int32_t rank) {
+  using namespace hbk;
+  LocalWorld* w = reinterpret_cast<LocalWorld*>(world);
+  HBK_REQUIRE(comm != nullptr && w != nullptr, "comm_create_local: NULL argument");
+  HBK_REQUIRE(rank >= 0 && rank < w->world, "comm_create_local: rank %d out of [0, %d)", rank,
+              w->world);
+  hbk_comm* c = new hbk_comm();
+  c->local = w;
+  c->comm = nullptr;
+  c->world_size = w->world;
+  c->local_size = w->world;
+  c->rank = rank;
+  c->aborted = false;
+  c->stream = nullptr;
+  c->compute_done = nullptr;
+  c->comm_done = nullptr;
+  (void)hipGetDevice(&c->device);
+  *comm = c;
+  return HBK_OK;
+}
 
 extern "C" int hbk_comm_get_id(uint8_t id[HBK_COMM_ID_BYTES]) {
   using namespace hbk;
@@ -150,6 +256,10 @@ extern "C" int hbk_comm_create(hbk_comm_t* comm, const uint8_t id[HBK_COMM_ID_BY
 extern "C" int hbk_comm_destroy(hbk_comm_t comm) {
   using namespace hbk;
   if (comm == nullptr) return HBK_OK;
+  if (comm->local != nullptr) {
+    delete comm;
+    return HBK_OK;
+  }
   (void)hipStreamSynchronize(comm->stream);
   if (!comm->aborted) ncclCommDestroy(comm->comm);
   (void)hipEventDestroy(comm->compute_done);
@@ -163,6 +273,7 @@ extern "C" int hbk_comm_destroy(hbk_comm_t comm) {
 extern "C" int hbk_comm_check_async(hbk_comm_t comm) {
   using namespace hbk;
   HBK_REQUIRE(comm != nullptr, "comm_check_async: comm is NULL");
+  if (comm->local != nullptr) return HBK_OK;
   std::unique_lock<std::mutex> lock(comm->mu);
   if (comm->aborted) return fail(HBK_INTERNAL, "communicator was aborted");
   ncclResult_t async = ncclSuccess;
@@ -211,6 +322,21 @@ extern "C" int hbk_alltoall_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t
                 "Number of elements in input (%lld) must can be divided into %lld partitions",
                 (long long)counts[c], (long long)active);  // nccl_collective.cc:119-123
     HBK_REQUIRE(counts[c] == 0 || (inputs[c] && outputs[c]), "alltoall_n: NULL buffer %d", c);
+  }
+  if (comm->local != nullptr) {
+    HBK_REQUIRE(topology == HBK_TOPOLOGY_ALL, "alltoall_n: local world supports topology ALL");
+    for (int32_t c = 0; c < n; ++c) {
+      const int64_t part = counts[c] / active;
+      std::vector<int64_t> off(active), len(active);
+      for (int64_t i = 0; i < active; ++i) {
+        off[i] = i * part;
+        len[i] = part;
+      }
+      int lrc = local_exchange(comm, inputs[c], off, len, outputs[c], off, esize,
+                               as_stream(compute_stream));
+      if (lrc != HBK_OK) return lrc;
+    }
+    return HBK_OK;
   }
   std::unique_lock<std::mutex> lock(comm->mu);
   HBK_REQUIRE(!comm->aborted, "alltoall_n: communicator was aborted");
@@ -312,6 +438,51 @@ extern "C" int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
     }
   }
 
+  if (comm->local != nullptr) {
+    HBK_REQUIRE(topology == HBK_TOPOLOGY_ALL, "alltoallv_n: local world supports topology ALL");
+    hipStream_t cs = as_stream(compute_stream);
+    int lrc;
+    if (half_wire) {
+      std::vector<int64_t> lens(n);
+      std::vector<void*> dst(n);
+      for (int32_t c = 0; c < n; ++c) {
+        lens[c] = send_rows[c] * common_sizes[c];
+        dst[c] = const_cast<void*>(wire_in[c]);
+      }
+      if ((lrc = cast_n_impl(n, HBK_FLOAT, HBK_HALF, inputs, lens.data(), dst.data(), cs)) !=
+          HBK_OK) {
+        return lrc;
+      }
+    }
+    for (int32_t c = 0; c < n; ++c) {
+      std::vector<int64_t> soff(active), slen(active), roff(active);
+      int64_t so = 0, ro = 0;
+      for (int32_t i = 0; i < active; ++i) {
+        soff[i] = so;
+        slen[i] = (int64_t)send_sizes[(size_t)c * active + i] * common_sizes[c];
+        roff[i] = ro;
+        so += slen[i];
+        ro += (int64_t)recv_sizes[(size_t)c * active + i] * common_sizes[c];
+      }
+      if ((lrc = local_exchange(comm, wire_in[c], soff, slen, wire_out[c], roff, esize, cs)) !=
+          HBK_OK) {
+        return lrc;
+      }
+    }
+    if (half_wire) {
+      std::vector<int64_t> lens(n);
+      std::vector<const void*> src(n);
+      for (int32_t c = 0; c < n; ++c) {
+        lens[c] = recv_rows[c] * common_sizes[c];
+        src[c] = wire_out[c];
+      }
+      if ((lrc = cast_n_impl(n, HBK_HALF, HBK_FLOAT, src.data(), lens.data(), outputs, cs)) !=
+          HBK_OK) {
+        return lrc;
+      }
+    }
+    return HBK_OK;
+  }
   std::unique_lock<std::mutex> lock(comm->mu);
   HBK_REQUIRE(!comm->aborted, "alltoallv_n: communicator was aborted");
   int rc = fence_in(comm, as_stream(compute_stream));

@@ -14,18 +14,23 @@
 //                per-1024-id-tile LDS histogram, all columns in one launch
 //   2 scan       per column: exclusive scan of hist[bucket][tile] -> bucket starts
 //   3 scatter    (row, segment) pairs grouped by bucket (LDS ticket per bucket and tile)
-//   4 reduce     ONE workgroup owns a bucket, hence every table row that hashes to it: an LDS
-//                hash table of the bucket's distinct rows with the fp32 accumulators next to
-//                the keys (LDS-staged hot rows: a hot row is one LDS line hammered by
-//                ds_add_f32, not one DRAM line); then the occupied slots are ranked with wave
-//                ballots + popcounts, an output range is claimed with one atomic per wave,
-//                and unique_rows / grad_rows are written with plain 16-byte stores -- plus,
-//                for apply_lr != 0, the SGD update of the shard in the same pass (exclusive
-//                ownership makes the read-modify-write race free).
-//                A table that fills up (more distinct rows than slots: adversarial skew) is
-//                flushed and the rejected pairs are re-run; then a row can appear in more
-//                than one IndexedSlices entry (sum semantics preserved).
-// Summation order inside a row is not fixed (LDS atomics): 1e-5 relative tolerance.
+//   4 reduce     ONE workgroup owns a bucket, hence every table row that hashes to it.  Per
+//                chunk of <= 512 pairs: (a) LDS hash table of the distinct rows (64-bit CAS),
+//                per-slot pair counts; (b) one packed block scan gives, per slot, the start of
+//                its pairs, its rank among the active slots and its rank among the NEW rows
+//                (ballot-free prefix sums; one global atomic per workgroup claims the output
+//                range); (c) counting sort of the pairs by slot; (d) a lane group walks one
+//                slot's pairs and sums their gradient rows IN REGISTERS, four rows in flight,
+//                then writes unique_rows / grad_rows with plain 16-byte stores (and applies
+//                the SGD update when apply_lr != 0: exclusive ownership makes the
+//                read-modify-write race free); (e) hot rows (>= 64 pairs in the chunk) are
+//                summed by the whole workgroup and folded through a 4 KB LDS buffer (the
+//                "LDS-staged hot rows").  A row that spans chunks is accumulated into its
+//                output row by the owning workgroup.  If the table would pass 3/4 load it is
+//                cleared between chunks; a row seen again afterwards gets a second
+//                IndexedSlices entry (sum semantics preserved; needs > 768 distinct rows in
+//                one bucket, i.e. adversarial hashing).
+// Summation order inside a row is not fixed (pair order comes from LDS tickets): 1e-5 relative.
 #include <alloca.h>
 #include <stdlib.h>
 #include <string.h>
@@ -34,19 +39,32 @@
 
 #include "lookup_common.h"
 
+#ifndef HBK_BWD_CP
+#define HBK_BWD_CP 512
+#endif
+#ifndef HBK_BWD_UA
+#define HBK_BWD_UA 4
+#endif
+#ifndef HBK_BWD_WAVES
+#define HBK_BWD_WAVES 4
+#endif
+
 namespace hbk {
 namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxCols = 64;
-constexpr int kTile = 8192;          // ids per 256-thread block in hist / scatter: few tiles keep
+constexpr int kTile = 4096;          // ids per 256-thread block in hist / scatter: few tiles keep
                                      // the [bucket][tile] histogram (and its scan) small
-constexpr int kPerThread = kTile / kBlock;   // 32 ids per thread, 8 loads in flight
+constexpr int kPerThread = kTile / kBlock;   // 16 ids per thread, 8 loads in flight
 constexpr int kBatch = 8;
-constexpr int kLdsBudget = 40 * 1024;  // bytes of LDS per reduce workgroup
 constexpr int kMaxBuckets = 8192;
-constexpr int kU = 8;                 // pairs per lane group and step in the reduce kernel
+constexpr int kCP = HBK_BWD_CP;       // pairs per chunk in the reduce kernel
+constexpr int kSlots = 2 * kCP;       // LDS hash-table slots
+constexpr int kClearAbove = kSlots * 3 / 4 - kCP;  // clear the table before a chunk beyond this
+constexpr int kUA = HBK_BWD_UA;       // slots a lane group reduces concurrently (rows in flight)
+constexpr int kHeavy = 64;            // pairs of one row in a chunk that make it a "hot row"
 constexpr unsigned long long kEmptyKey = ~0ull;
 
 struct GCol {
@@ -59,8 +77,8 @@ struct GCol {
   float* table;
   int32_t* hist;             // [P * tiles] -> exclusive offsets after the scan
   int32_t* bstart;           // [P + 1]
-  int64_t* pair_row[2];      // [n_ids] ping-pong (second copy: pairs rejected by a full table)
-  int32_t* pair_seg[2];
+  int64_t* pair_row[1];      // [n_ids] rows of the pairs, grouped by bucket
+  int32_t* pair_seg[1];      // [n_ids] their segments
   int32_t* seg_of;           // [n_ids], ragged columns only
   IdMap map;
   int64_t n_ids;
@@ -69,7 +87,6 @@ struct GCol {
   int32_t chunks;
   uint8_t lpr_log2, ids64, combiner, vec4;
   int32_t log2p;             // buckets = 1 << log2p
-  int32_t slots_log2;        // LDS table slots of the reduce workgroup
   int32_t tile0;             // first tile (hist / scatter grids)
   int32_t bucket0;           // first block (reduce grid)
   int32_t segtile0;          // first block (seg_of grid)
@@ -234,229 +251,250 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
   }
 }
 
-// ---- 4: one workgroup per bucket: LDS hash table with accumulators ------------------------
-// An accumulator row is stored TRANSPOSED inside LDS: element (sub * VE + k) of the row lives
-// at dword k * chunks + sub, so the lanes of a group hit consecutive banks for every k
-// (a plain row layout puts lanes 16 bytes apart: a 4-way bank conflict on every ds_add_f32).
+// ---- 4: one workgroup per bucket ---------------------------------------------------------------
+struct ReduceLds {
+  unsigned long long keys[kSlots];
+  int32_t cnt[kSlots];       // pairs of the slot in this chunk; bit 30: row is new in this chunk
+  int32_t off[kSlots];       // start of the slot's pairs in `order` (turned into the end by (c))
+  int32_t slot_out[kSlots];  // output row of the slot, -1 = none yet
+  int32_t active[kCP];       // slots with pairs in this chunk
+  int32_t order[kCP];        // pair indices grouped by slot
+  int32_t segs[kCP];         // segment (= row of grad_out) of every pair of the chunk
+  int32_t pslot[kCP];
+  int32_t heavy[kCP / kHeavy + 1];
+  int32_t wave_tot[kWavesPerBlock];
+  int32_t n_active, n_heavy, base_u, occupied;
+  float red[kBlock * 4];     // hot-row partial sums, one 16-byte chunk per thread
+};
+
+constexpr int32_t kNewBit = 1 << 30;
+
 template <typename V>
-__device__ inline void lds_add_v(float* row, int chunks, int sub, V v);
-template <>
-__device__ inline void lds_add_v<f32x4>(float* row, int chunks, int sub, f32x4 v) {
-  atomicAdd(row + sub, v.x);
-  atomicAdd(row + chunks + sub, v.y);
-  atomicAdd(row + 2 * chunks + sub, v.z);
-  atomicAdd(row + 3 * chunks + sub, v.w);
+__device__ inline V load_grad(const GCol& c, int32_t seg, int sub) {
+  constexpr int VE = sizeof(V) / 4;
+  V g = __builtin_nontemporal_load(
+      reinterpret_cast<const V*>(c.grad_out + (int64_t)seg * c.dim + (int64_t)sub * VE));
+  if (c.combiner != HBK_COMBINER_SUM && c.splits != nullptr) {
+    const int32_t n = c.splits[seg + 1] - c.splits[seg];
+    g = c.combiner == HBK_COMBINER_MEAN ? g / (float)n : g / sqrtf((float)n);
+  }
+  return g;
 }
-template <>
-__device__ inline void lds_add_v<float>(float* row, int chunks, int sub, float v) {
-  atomicAdd(row + sub, v);
-}
+
+// out row u += (or =) v, and the fused SGD step on the table row
 template <typename V>
-__device__ inline V lds_read_v(const float* row, int chunks, int sub);
-template <>
-__device__ inline f32x4 lds_read_v<f32x4>(const float* row, int chunks, int sub) {
-  return f32x4{row[sub], row[chunks + sub], row[2 * chunks + sub], row[3 * chunks + sub]};
-}
-template <>
-__device__ inline float lds_read_v<float>(const float* row, int chunks, int sub) {
-  return row[sub];
+__device__ inline void emit_row(const GCol& c, float lr, int32_t u, bool is_new, int64_t row,
+                                int sub, V v) {
+  constexpr int VE = sizeof(V) / 4;
+  V* o = reinterpret_cast<V*>(c.grad_rows + (int64_t)u * c.dim + (int64_t)sub * VE);
+  // rows are owned by this workgroup; bypass L1 when re-reading what an earlier chunk wrote
+  *o = is_new ? v : __builtin_nontemporal_load(o) + v;
+  if (lr != 0.0f) {
+    V* t = reinterpret_cast<V*>(c.table + row * c.dim + (int64_t)sub * VE);
+    *t = __builtin_nontemporal_load(t) - lr * v;
+  }
 }
 
 template <typename V>
-__device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, char* lds) {
+__device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, ReduceLds& L) {
   constexpr int VE = sizeof(V) / 4;
-  const int slots = 1 << c.slots_log2;
-  const int dim = c.dim;
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(lds);       // [slots]
-  float* acc = reinterpret_cast<float*>(lds + (size_t)slots * 8);               // [slots][dim]
-  int32_t* slot_out = reinterpret_cast<int32_t*>(lds + (size_t)slots * (8 + 4 * dim));
-  int32_t* ctrl = slot_out + slots;                                             // [0] rejected
   const int tid = (int)threadIdx.x;
-  const int lane = tid & (kWave - 1);
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
   const int lpr_log2 = c.lpr_log2;
   const int sub = lane & ((1 << lpr_log2) - 1);
-  const int grp_lane0 = (lane >> lpr_log2) << lpr_log2;
   const bool live = sub < c.chunks;
-  const int groups = kBlock >> lpr_log2;  // pairs in flight per workgroup step
+  const int groups = kBlock >> lpr_log2;
   const int my_group = tid >> lpr_log2;
 
   const int32_t start = c.bstart[bucket];
-  int32_t n_pairs = c.bstart[bucket + 1] - start;
-  int src = 0;
-  while (n_pairs > 0) {  // uniform: more than one pass only after a table overflow
-    for (int i = tid; i < slots; i += kBlock) keys[i] = kEmptyKey;
-    for (int i = tid; i < slots * dim; i += kBlock) acc[i] = 0.f;
-    if (tid == 0) ctrl[0] = 0;
-    __syncthreads();
-    const int64_t* prow = c.pair_row[src] + start;
-    const int32_t* pseg = c.pair_seg[src] + start;
-    int64_t* rrow = c.pair_row[src ^ 1] + start;
-    int32_t* rseg = c.pair_seg[src ^ 1] + start;
-    // U pairs per lane group and step, next step's (row, segment) already in flight: the
-    // bucket of a hot row holds thousands of pairs and one workgroup must stream them
-    unsigned long long row_n[kU];
-    int32_t seg_n[kU];
-#pragma unroll
-    for (int u = 0; u < kU; ++u) {
-      const int32_t e = u * groups + my_group;
-      row_n[u] = 0;
-      seg_n[u] = 0;
-      if (e < n_pairs) {
-        row_n[u] = (unsigned long long)prow[e];
-        seg_n[u] = pseg[e];
+  const int32_t n_pairs = c.bstart[bucket + 1] - start;
+  if (n_pairs == 0) return;
+  const int64_t* prow = c.pair_row[0] + start;
+  const int32_t* pseg = c.pair_seg[0] + start;
+
+  for (int i = tid; i < kSlots; i += kBlock) {
+    L.keys[i] = kEmptyKey;
+    L.slot_out[i] = -1;
+  }
+  if (tid == 0) L.occupied = 0;
+  __syncthreads();
+
+  for (int32_t cb = 0; cb < n_pairs; cb += kCP) {
+    const int32_t n_chunk = n_pairs - cb < kCP ? n_pairs - cb : kCP;
+    if (L.occupied > kClearAbove) {  // uniform: read after a barrier
+      __syncthreads();
+      for (int i = tid; i < kSlots; i += kBlock) {
+        L.keys[i] = kEmptyKey;
+        L.slot_out[i] = -1;
       }
+      if (tid == 0) L.occupied = 0;
     }
-    for (int32_t e0 = 0; e0 < n_pairs; e0 += groups * kU) {
-      unsigned long long row[kU];
-      int32_t seg[kU];
-      V g[kU];
+    for (int i = tid; i < kSlots; i += kBlock) L.cnt[i] = 0;
+    if (tid == 0) L.n_heavy = 0;
+    __syncthreads();
+
+    // (a) distinct rows of the chunk -> slots, pairs per slot
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        row[u] = row_n[u];
-        seg[u] = seg_n[u];
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const int32_t e = e0 + groups * kU + u * groups + my_group;
-        row_n[u] = 0;
-        seg_n[u] = 0;
-        if (e < n_pairs) {
-          row_n[u] = (unsigned long long)prow[e];
-          seg_n[u] = pseg[e];
+    for (int k = 0; k < kCP / kBlock; ++k) {
+      const int e = k * kBlock + tid;
+      if (e < n_chunk) {
+        const unsigned long long row = (unsigned long long)prow[cb + e];
+        L.segs[e] = pseg[cb + e];
+        int h = (int)(mix64(row) & (kSlots - 1));
+        for (;;) {  // the table never fills: cleared above kClearAbove
+          const unsigned long long prev = atomicCAS(&L.keys[h], kEmptyKey, row);
+          if (prev == kEmptyKey || prev == row) break;
+          h = (h + 1) & (kSlots - 1);
         }
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const bool has = e0 + u * groups + my_group < n_pairs;
-        g[u] = zero_v<V>();
-        if (has && live) {
-          g[u] = __builtin_nontemporal_load(reinterpret_cast<const V*>(
-              c.grad_out + (int64_t)seg[u] * dim + (int64_t)sub * VE));
-        }
-      }
-      if (c.combiner != HBK_COMBINER_SUM && c.splits != nullptr) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-          if (e0 + u * groups + my_group < n_pairs) {
-            const int32_t n = c.splits[seg[u] + 1] - c.splits[seg[u]];
-            if (c.combiner == HBK_COMBINER_MEAN) {
-              g[u] = g[u] / (float)n;
-            } else {
-              g[u] = g[u] / sqrtf((float)n);
-            }
-          }
-        }
-      }
-      // runs of equal rows inside a group's U pairs (a hot row fills its bucket with them) are
-      // summed in registers and cost one probe + one LDS add
-      int slot = -1;
-      unsigned long long run_row = kEmptyKey;
-      V run_sum = zero_v<V>();
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const bool has = e0 + u * groups + my_group < n_pairs;
-        if (has && row[u] == run_row) {
-          run_sum = run_sum + g[u];
-          continue;
-        }
-        // close the previous run (wave-uniform control flow is not needed: LDS atomics only)
-        if (run_row != kEmptyKey && slot >= 0 && live) {
-          lds_add_v<V>(acc + (size_t)slot * dim, c.chunks, sub, run_sum);
-        }
-        run_row = kEmptyKey;
-        if (!has) continue;
-        // the group's first lane probes; the slot is broadcast to the group.  All lanes of a
-        // group take the same path here (has / row are group-uniform), groups may diverge.
-        int found = -1;
-        if (sub == 0) {
-          int h = (int)(mix64(row[u]) & (unsigned)(slots - 1));
-          for (int probe = 0; probe < slots; ++probe) {
-            const unsigned long long prev = atomicCAS(&keys[h], kEmptyKey, row[u]);
-            if (prev == kEmptyKey || prev == row[u]) {
-              found = h;
-              break;
-            }
-            h = (h + 1) & (slots - 1);
-          }
-        }
-        slot = __builtin_amdgcn_ds_bpermute(grp_lane0 << 2, found);
-        if (slot >= 0) {
-          run_row = row[u];
-          run_sum = g[u];
-        } else if (sub == 0) {  // table full: run this pair again after the flush
-          const int32_t f = atomicAdd(&ctrl[0], 1);
-          rrow[f] = (int64_t)row[u];
-          rseg[f] = seg[u];
-        }
-      }
-      if (run_row != kEmptyKey && slot >= 0 && live) {
-        lds_add_v<V>(acc + (size_t)slot * dim, c.chunks, sub, run_sum);
+        L.pslot[e] = h;
+        atomicAdd(&L.cnt[h], 1);
       }
     }
     __syncthreads();
-    // flush: rank the occupied slots (ballot + popcount per wave, wave totals through LDS),
-    // claim the output range with ONE global atomic per workgroup
+
+    // (b) one packed exclusive scan over the slots: pairs | active slots << 10 | new rows << 20
     {
-      int32_t* wave_cnt = ctrl + 2;  // [kWavesPerBlock * rounds] scratch, rounds <= 8
-      const int rounds = (slots + kBlock - 1) / kBlock;
-      for (int r = 0; r < rounds; ++r) {
-        const int s = r * kBlock + tid;
-        const bool occ = s < slots && keys[s] != kEmptyKey;
-        const unsigned long long m = __ballot(occ);
-        if (lane == 0) wave_cnt[r * kWavesPerBlock + (tid >> 6)] = (int32_t)__builtin_popcountll(m);
+      int32_t local[kSlots / kBlock], sum = 0;
+#pragma unroll
+      for (int k = 0; k < kSlots / kBlock; ++k) {
+        const int s = tid * (kSlots / kBlock) + k;
+        const int32_t n = L.cnt[s];
+        local[k] = n > 0 ? n | (1 << 10) | (L.slot_out[s] < 0 ? (1 << 20) : 0) : 0;  // kCP <= 512
+        sum += local[k];
+      }
+      int32_t incl = sum;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const int32_t y = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += y;
+      }
+      if (lane == kWave - 1) L.wave_tot[wave] = incl;
+      __syncthreads();
+      int32_t run = incl - sum;
+      for (int w = 0; w < wave; ++w) run += L.wave_tot[w];
+      if (tid == kBlock - 1) {
+        const int32_t tot = run + sum;
+        const int32_t n_new = tot >> 20;
+        L.n_active = (tot >> 10) & 1023;
+        L.base_u = n_new > 0 ? atomicAdd(c.n_unique, n_new) : 0;
+        L.occupied += n_new;
       }
       __syncthreads();
-      if (tid == 0) {
-        int32_t tot = 0;
-        for (int i = 0; i < rounds * kWavesPerBlock; ++i) {
-          const int32_t x = wave_cnt[i];
-          wave_cnt[i] = tot;
-          tot += x;
+      const int32_t base_u = L.base_u;
+#pragma unroll
+      for (int k = 0; k < kSlots / kBlock; ++k) {
+        const int s = tid * (kSlots / kBlock) + k;
+        if (local[k] != 0) {
+          L.off[s] = run & 1023;
+          L.active[(run >> 10) & 1023] = s;
+          if (local[k] >> 20) {
+            const int32_t u = base_u + (run >> 20);
+            L.slot_out[s] = u;
+            L.cnt[s] |= kNewBit;
+            c.unique_rows[u] = (int64_t)L.keys[s];
+          }
         }
-        ctrl[1] = tot > 0 ? atomicAdd(c.n_unique, tot) : 0;
+        run += local[k];
       }
-      __syncthreads();
-      for (int r = 0; r < rounds; ++r) {
-        const int s = r * kBlock + tid;
-        const bool occ = s < slots && keys[s] != kEmptyKey;
-        const unsigned long long m = __ballot(occ);
-        if (occ) {
-          const int32_t u = ctrl[1] + wave_cnt[r * kWavesPerBlock + (tid >> 6)] + rank_below(m);
-          slot_out[s] = u;
-          c.unique_rows[u] = (int64_t)keys[s];
+    }
+    __syncthreads();
+
+    // (c) counting sort of the pairs by slot (off[] ends up as the end of every slot's run)
+#pragma unroll
+    for (int k = 0; k < kCP / kBlock; ++k) {
+      const int e = k * kBlock + tid;
+      if (e < n_chunk) L.order[atomicAdd(&L.off[L.pslot[e]], 1)] = e;
+    }
+    __syncthreads();
+
+    // (d) a lane group sums the rows of kUA slots at a time, in registers
+    const int n_active = L.n_active;
+    for (int k0 = 0; k0 < n_active; k0 += groups * kUA) {
+      int32_t slot[kUA], beg[kUA], len[kUA];
+      V acc[kUA];
+      int32_t longest = 0;
+#pragma unroll
+      for (int u = 0; u < kUA; ++u) {
+        const int idx = k0 + u * groups + my_group;
+        slot[u] = -1;
+        len[u] = 0;
+        beg[u] = 0;
+        acc[u] = zero_v<V>();
+        if (idx < n_active) {
+          slot[u] = L.active[idx];
+          const int32_t n = L.cnt[slot[u]] & (kNewBit - 1);
+          if (n >= kHeavy) {
+            if (sub == 0) L.heavy[atomicAdd(&L.n_heavy, 1)] = slot[u];
+            slot[u] = -1;
+          } else {
+            len[u] = n;
+            beg[u] = L.off[slot[u]] - n;
+            longest = n > longest ? n : longest;
+          }
+        }
+      }
+      for (int r = 0; r < longest; ++r) {
+        V g[kUA];
+#pragma unroll
+        for (int u = 0; u < kUA; ++u) {
+          g[u] = zero_v<V>();
+          if (r < len[u] && live) g[u] = load_grad<V>(c, L.segs[L.order[beg[u] + r]], sub);
+        }
+#pragma unroll
+        for (int u = 0; u < kUA; ++u) acc[u] = acc[u] + g[u];
+      }
+#pragma unroll
+      for (int u = 0; u < kUA; ++u) {
+        if (slot[u] >= 0 && live) {
+          emit_row<V>(c, lr, L.slot_out[slot[u]], (L.cnt[slot[u]] & kNewBit) != 0,
+                      (int64_t)L.keys[slot[u]], sub, acc[u]);
         }
       }
     }
     __syncthreads();
-    for (int s0 = 0; s0 < slots; s0 += groups) {
-      const int s = s0 + my_group;
-      if (s < slots && live && keys[s] != kEmptyKey) {
-        const V v = lds_read_v<V>(acc + (size_t)s * dim, c.chunks, sub);
-        *reinterpret_cast<V*>(c.grad_rows + (int64_t)slot_out[s] * dim + (int64_t)sub * VE) = v;
-        if (lr != 0.0f) {
-          V* t = reinterpret_cast<V*>(c.table + (int64_t)keys[s] * dim + (int64_t)sub * VE);
-          // this workgroup owns the row; bypass L1 so a second flush sees the first one
-          const V old = __builtin_nontemporal_load(t);
-          *t = old - lr * v;
+
+    // (e) hot rows: the whole workgroup sums one row, partial sums folded through LDS
+    const int n_heavy = L.n_heavy;
+    for (int hidx = 0; hidx < n_heavy; ++hidx) {
+      const int s = L.heavy[hidx];
+      const int32_t n = L.cnt[s] & (kNewBit - 1);
+      const int32_t b0 = L.off[s] - n;
+      V acc = zero_v<V>();
+      for (int32_t p0 = 0; p0 < n; p0 += groups * kUA) {
+        V g[kUA];
+#pragma unroll
+        for (int u = 0; u < kUA; ++u) {
+          const int32_t p = p0 + u * groups + my_group;
+          g[u] = zero_v<V>();
+          if (p < n && live) g[u] = load_grad<V>(c, L.segs[L.order[b0 + p]], sub);
         }
+#pragma unroll
+        for (int u = 0; u < kUA; ++u) acc = acc + g[u];
       }
+      *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = acc;
+      __syncthreads();
+      if (my_group == 0 && live) {
+        V tot = zero_v<V>();
+        for (int gi = 0; gi < groups; ++gi) {
+          tot = tot + *reinterpret_cast<const V*>(&L.red[((size_t)(gi << lpr_log2) + sub) * VE]);
+        }
+        emit_row<V>(c, lr, L.slot_out[s], (L.cnt[s] & kNewBit) != 0, (int64_t)L.keys[s], sub,
+                    tot);
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    n_pairs = ctrl[0];
-    src ^= 1;
     __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(kBlock) void bwd_reduce_kernel(const GArgs a) {
-  extern __shared__ char lds_raw[];
+// Two instantiations (16-byte / 4-byte chunks) so the common one keeps its registers low; a
+// block whose column is of the other kind exits at once.
+template <typename V>
+__global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const GArgs a) {
+  __shared__ ReduceLds lds;
   HBK_FIND_COL(a, bucket0)
-  const int bucket = (int)blockIdx.x - c.bucket0;
-  if (c.vec4) {
-    bucket_reduce<f32x4>(c, bucket, a.lr, lds_raw);
-  } else {
-    bucket_reduce<float>(c, bucket, a.lr, lds_raw);
-  }
+  if ((c.vec4 != 0) != (sizeof(V) == 16)) return;
+  bucket_reduce<V>(c, (int)blockIdx.x - c.bucket0, a.lr, lds);
 }
 
 // ---- d(stitch + combiner): permutation scatter (hbk_group_stitch_bwd) ----------------------
@@ -533,32 +571,27 @@ __global__ __launch_bounds__(kBlock) void stitch_bwd_kernel(const SArgs a) {
 inline size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 
 struct ColPlan {
-  int slots_log2;
   int log2p;
   int64_t tiles;
-  size_t lds_bytes;
 };
 
-// test hook: HBK_BWD_SLOTS_LOG2 forces a (tiny) table so the overflow / re-run path is exercised
-int forced_slots_log2() {
-  const char* e = getenv("HBK_BWD_SLOTS_LOG2");
+// test hook: HBK_BWD_LOG2P forces the bucket count (0 = one bucket per column) so that
+// multi-chunk buckets, rows spanning chunks and the table-clear path are exercised
+int forced_log2p() {
+  const char* e = getenv("HBK_BWD_LOG2P");
   return e ? atoi(e) : -1;
 }
 
 ColPlan plan_of(int64_t n_ids, int32_t dim) {
+  (void)dim;
   ColPlan p;
-  int sl = 4;
-  while (sl < 11 && ((size_t)2 << sl) * (12 + 4 * (size_t)dim) + 256 <= (size_t)kLdsBudget) ++sl;
-  const int forced = forced_slots_log2();
-  if (forced >= 1 && forced <= 11) sl = forced;
-  p.slots_log2 = sl;
-  const int64_t per_bucket = ((int64_t)1 << sl) / 2;  // aim at a half-full table
-  int lp = 0;
-  while (lp < 13 && ((int64_t)per_bucket << lp) < n_ids) ++lp;
+  int lp = 0;  // aim at kCP / 2 pairs per bucket: one chunk with headroom
+  while (lp < 13 && ((int64_t)(kCP / 2) << lp) < n_ids) ++lp;
   while (((int64_t)1 << lp) > kMaxBuckets) --lp;
+  const int forced = forced_log2p();
+  if (forced >= 0 && forced <= 13) lp = forced;
   p.log2p = lp;
   p.tiles = (n_ids + kTile - 1) / kTile;
-  p.lds_bytes = ((size_t)1 << sl) * (12 + 4 * (size_t)dim) + 8 + 4 * 8 * kWavesPerBlock;
   return p;
 }
 
@@ -567,8 +600,8 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
   const ColPlan p = plan_of(h.n_ids, h.dim);
   size_t b = align8(((size_t)p.tiles << p.log2p) * 4);   // hist
   b += align8((((size_t)1 << p.log2p) + 1) * 4);          // bstart
-  b += 2 * (size_t)h.n_ids * 8;                            // pair_row x2
-  b += 2 * align8((size_t)h.n_ids * 4);                    // pair_seg x2
+  b += (size_t)h.n_ids * 8;                                // pair_row
+  b += align8((size_t)h.n_ids * 4);                        // pair_seg
   if (h.row_splits != nullptr) b += align8((size_t)h.n_ids * 4);
   return b;
 }
@@ -626,7 +659,7 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
     GArgs args, seg_args;
     int32_t k = 0, ks = 0;
     int64_t tiles = 0, buckets = 0, segtiles = 0;
-    size_t lds_hist = 0, lds_reduce = 0;
+    size_t lds_hist = 0;
     while (c0 < n_cols && k < kMaxCols) {
       const hbk_lookup_grad_column_t& h = cols[c0++];
       if (h.n_ids == 0) {
@@ -647,14 +680,10 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       wp += align8(((size_t)p.tiles << p.log2p) * 4);
       d.bstart = reinterpret_cast<int32_t*>(wp);
       wp += align8((((size_t)1 << p.log2p) + 1) * 4);
-      for (int q = 0; q < 2; ++q) {
-        d.pair_row[q] = reinterpret_cast<int64_t*>(wp);
-        wp += (size_t)h.n_ids * 8;
-      }
-      for (int q = 0; q < 2; ++q) {
-        d.pair_seg[q] = reinterpret_cast<int32_t*>(wp);
-        wp += align8((size_t)h.n_ids * 4);
-      }
+      d.pair_row[0] = reinterpret_cast<int64_t*>(wp);
+      wp += (size_t)h.n_ids * 8;
+      d.pair_seg[0] = reinterpret_cast<int32_t*>(wp);
+      wp += align8((size_t)h.n_ids * 4);
       d.seg_of = nullptr;
       if (h.row_splits != nullptr) {
         d.seg_of = reinterpret_cast<int32_t*>(wp);
@@ -676,7 +705,6 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       d.ids64 = h.ids_dtype == HBK_INT64;
       d.combiner = (uint8_t)h.combiner;
       d.log2p = p.log2p;
-      d.slots_log2 = p.slots_log2;
       d.tile0 = (int32_t)tiles;
       d.bucket0 = (int32_t)buckets;
       d.segtile0 = 0;
@@ -685,7 +713,6 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       HBK_REQUIRE(tiles < (1ll << 31) && buckets < (1ll << 31),
                   "group_lookup_bwd: grid too large");
       if (((size_t)4 << p.log2p) > lds_hist) lds_hist = (size_t)4 << p.log2p;
-      if (p.lds_bytes > lds_reduce) lds_reduce = p.lds_bytes;
       if (h.row_splits != nullptr && h.n_segments > 0) {
         GCol& sdesc = seg_args.col[ks];
         sdesc = d;
@@ -709,8 +736,19 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
     hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)k), dim3(kBlock), 0, stream, args);
     hipLaunchKernelGGL(bwd_scatter_pairs_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist,
                        stream, args);
-    hipLaunchKernelGGL(bwd_reduce_kernel, dim3((unsigned)buckets), dim3(kBlock), lds_reduce,
-                       stream, args);
+    bool any_vec4 = false, any_scalar = false;
+    for (int32_t q = 0; q < k; ++q) {
+      any_vec4 |= args.col[q].vec4 != 0;
+      any_scalar |= args.col[q].vec4 == 0;
+    }
+    if (any_vec4) {
+      hipLaunchKernelGGL(bwd_reduce_kernel<f32x4>, dim3((unsigned)buckets), dim3(kBlock), 0,
+                         stream, args);
+    }
+    if (any_scalar) {
+      hipLaunchKernelGGL(bwd_reduce_kernel<float>, dim3((unsigned)buckets), dim3(kBlock), 0,
+                         stream, args);
+    }
     HBK_HIP_OK(hipGetLastError());
   }
   return HBK_OK;

@@ -1,0 +1,627 @@
+// Sharded group lookup: the whole per-step pipeline of hbtf/embedding/sharding.py:171-205
+// (R12) for N columns behind ONE C-ABI call per direction, so the host side costs tens of
+// microseconds, not a Python loop over columns.
+//
+//   forward   bucketize -> stable partition by id mod W        (R1, R2: elementwise.hip, partition.hip)
+//             pack ids peer-major                               (one launch, N*W segments)
+//             sizes [N x W] alltoall + ONE host sync            (R5: comm.hip; the reference syncs
+//                                                                once per op, nccl_alltoallv.cc:316,533)
+//             ids alltoallv: ONE message per peer              (all columns of a peer travel together:
+//                                                                W sends + W receives per exchange, one
+//                                                                per xGMI link, instead of N*W)
+//             owner gather (N*W virtual columns, `// W`)        (R7/R8: lookup_fwd.hip) straight into
+//                                                                the peer-major reply buffer
+//             rows alltoallv (fp32 or fp16 wire), one message per peer   (R5, R6)
+//             unpack rows column-major, stitch + combiner       (R8, R9: lookup_fwd.hip)
+//   backward  d(stitch+combiner) -> pack -> reverse alltoallv (forward's sizes, collective.py:334-347)
+//             -> unpack -> duplicate-row reduction (+ fused SGD) (R10: lookup_bwd.hip)
+//
+// Buffers whose size depends on what the peers send (known only after the size exchange)
+// are owned by the plan and grow on demand (hipMalloc, never shrinks); everything else is
+// caller-owned as usual.
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace hbk {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxSegs = 480;
+constexpr int kCopyTileBytes = kBlock * 16 * 8;  // 32 KB per block
+
+struct Seg {
+  const void* src;
+  void* dst;
+  int64_t bytes;
+  int32_t tile0;
+  int32_t pad_;
+};
+
+struct SegArgs {
+  int32_t n_segs;
+  int32_t pad_;
+  Seg seg[kMaxSegs];
+};
+static_assert(sizeof(SegArgs) <= 16384, "kernarg budget");  // 480 x 32 B + 8
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// N-segment gather copy: packs / unpacks the per-(column, peer) runs of an exchange buffer
+__global__ __launch_bounds__(kBlock) void seg_copy_kernel(const SegArgs a) {
+  int si = 0, hi = a.n_segs;
+  while (hi - si > 1) {
+    const int mid = (si + hi) >> 1;
+    if (a.seg[mid].tile0 <= (int)blockIdx.x) {
+      si = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  const Seg& s = a.seg[si];
+  const int64_t base = (int64_t)((int)blockIdx.x - s.tile0) * kCopyTileBytes;
+  const char* src = reinterpret_cast<const char*>(s.src);
+  char* dst = reinterpret_cast<char*>(s.dst);
+  if ((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)s.bytes) & 15) == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t o = base + ((int64_t)k * kBlock + threadIdx.x) * 16;
+      if (o < s.bytes) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + o));
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + o));
+      }
+    }
+  } else {  // 4-byte granularity (every run is a whole number of int32 / fp32 / int64 items)
+    for (int k = 0; k < 32; ++k) {
+      const int64_t o = base + ((int64_t)k * kBlock + threadIdx.x) * 4;
+      if (o < s.bytes) {
+        *reinterpret_cast<uint32_t*>(dst + o) = *reinterpret_cast<const uint32_t*>(src + o);
+      }
+    }
+  }
+}
+
+int seg_copy(const std::vector<Seg>& segs_in, hipStream_t stream) {
+  size_t i = 0;
+  while (i < segs_in.size()) {
+    SegArgs args;
+    int k = 0;
+    int64_t tiles = 0;
+    while (i < segs_in.size() && k < kMaxSegs) {
+      const Seg& s = segs_in[i++];
+      if (s.bytes <= 0) continue;
+      args.seg[k] = s;
+      args.seg[k].tile0 = (int32_t)tiles;
+      tiles += (s.bytes + kCopyTileBytes - 1) / kCopyTileBytes;
+      ++k;
+    }
+    if (k == 0) continue;
+    args.n_segs = k;
+    hipLaunchKernelGGL(seg_copy_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, stream, args);
+    HBK_HIP_OK(hipGetLastError());
+  }
+  return HBK_OK;
+}
+
+// sizes [N][W] -> [W][N] (the chunk for peer p of the equal-split size exchange = column p)
+__global__ void transpose_sizes_kernel(const int32_t* in, int32_t* out, int n, int w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * w) out[(i % w) * n + i / w] = in[i];
+}
+
+struct Buffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return HBK_OK;
+    if (ptr) HBK_HIP_OK(hipFree(ptr));
+    ptr = nullptr;
+    bytes = 0;
+    const size_t grow = need + need / 4 + (1 << 20);
+    HBK_HIP_OK(hipMalloc(&ptr, grow));
+    bytes = grow;
+    return HBK_OK;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+
+}  // namespace
+}  // namespace hbk
+
+// ---- host arithmetic of the peer-major exchange buffers ---------------------------------------
+// Pure host code (no device calls): exported so that it can be checked without a GPU, under a
+// real multi-process exchange (tests/test_dist_gloo.py).
+//   S[c][q] = rows this rank requests from owner q for column c   (partition sizes)
+//   R[q][c] = rows requester q asked this rank for, column c       (exchanged sizes)
+// Requester-side buffers (ids going out, rows coming back) hold the runs (q, c) in peer-major
+// order with S; owner-side buffers (ids coming in, rows going out) in peer-major order with R.
+extern "C" int hbk_sharded_layout(int32_t n_cols, int32_t world, const int32_t* dims,
+                                  const int32_t* S, const int32_t* R, int32_t* ids_send_peer,
+                                  int32_t* ids_recv_peer, int32_t* rows_send_peer,
+                                  int32_t* rows_recv_peer, int64_t* req_id_off,
+                                  int64_t* req_row_off, int64_t* own_id_off,
+                                  int64_t* own_row_off, int64_t* col_shard_off) {
+  using namespace hbk;
+  HBK_REQUIRE(n_cols >= 1 && world >= 1 && dims && S && R, "sharded_layout: bad argument");
+  const int N = n_cols, W = world;
+  int64_t rid = 0, rrow = 0, oid = 0, orow = 0;
+  for (int q = 0; q < W; ++q) {
+    int64_t si = 0, ri = 0, sf = 0, rf = 0;
+    for (int c = 0; c < N; ++c) {
+      const int64_t s = S[(size_t)c * W + q], r = R[(size_t)q * N + c];
+      HBK_REQUIRE(s >= 0 && r >= 0 && dims[c] >= 1, "sharded_layout: negative size");
+      if (req_id_off) req_id_off[(size_t)q * N + c] = rid;
+      if (req_row_off) req_row_off[(size_t)q * N + c] = rrow;
+      if (own_id_off) own_id_off[(size_t)q * N + c] = oid;
+      if (own_row_off) own_row_off[(size_t)q * N + c] = orow;
+      rid += s;
+      rrow += s * dims[c];
+      oid += r;
+      orow += r * dims[c];
+      si += s;
+      ri += r;
+      rf += s * dims[c];   // floats this rank gets back from owner q
+      sf += r * dims[c];   // floats this rank sends to requester q
+    }
+    HBK_REQUIRE(sf < (1ll << 31) && rf < (1ll << 31),
+                "sharded_layout: more than 2^31 floats for one peer");
+    if (ids_send_peer) ids_send_peer[q] = (int32_t)si;
+    if (ids_recv_peer) ids_recv_peer[q] = (int32_t)ri;
+    if (rows_send_peer) rows_send_peer[q] = (int32_t)sf;
+    if (rows_recv_peer) rows_recv_peer[q] = (int32_t)rf;
+  }
+  if (col_shard_off) {
+    for (int c = 0; c < N; ++c) {
+      int64_t o = 0;
+      for (int q = 0; q < W; ++q) {
+        col_shard_off[(size_t)c * W + q] = o;
+        o += S[(size_t)c * W + q];
+      }
+    }
+  }
+  return HBK_OK;
+}
+
+namespace hbk {
+namespace {
+
+struct Layout {
+  std::vector<int32_t> dims, ids_send_peer, ids_recv_peer, rows_send_peer, rows_recv_peer;
+  std::vector<int64_t> req_id_off, req_row_off, own_id_off, own_row_off, col_shard_off;
+  int64_t req_ids = 0, own_ids = 0, req_floats = 0, own_floats = 0;
+  int compute(int N, int W, const std::vector<hbk_sharded_column_t>& cols, const int32_t* S,
+              const int32_t* R) {
+    dims.resize(N);
+    for (int c = 0; c < N; ++c) dims[c] = cols[c].dim;
+    ids_send_peer.resize(W);
+    ids_recv_peer.resize(W);
+    rows_send_peer.resize(W);
+    rows_recv_peer.resize(W);
+    req_id_off.resize((size_t)N * W);
+    req_row_off.resize((size_t)N * W);
+    own_id_off.resize((size_t)N * W);
+    own_row_off.resize((size_t)N * W);
+    col_shard_off.resize((size_t)N * W);
+    int rc = hbk_sharded_layout(N, W, dims.data(), S, R, ids_send_peer.data(),
+                                ids_recv_peer.data(), rows_send_peer.data(),
+                                rows_recv_peer.data(), req_id_off.data(), req_row_off.data(),
+                                own_id_off.data(), own_row_off.data(), col_shard_off.data());
+    if (rc != HBK_OK) return rc;
+    req_ids = own_ids = req_floats = own_floats = 0;
+    for (int q = 0; q < W; ++q) {
+      req_ids += ids_send_peer[q];
+      own_ids += ids_recv_peer[q];
+      req_floats += rows_recv_peer[q];
+      own_floats += rows_send_peer[q];
+    }
+    return HBK_OK;
+  }
+};
+
+}  // namespace
+}  // namespace hbk
+
+struct hbk_sharded {
+  hbk_comm_t comm;
+  int W, rank, N;
+  int32_t wire_dtype;
+  std::vector<hbk_sharded_column_t> cols;
+  // per-step state (kept for the backward)
+  std::vector<int64_t> n_ids, n_seg;
+  std::vector<const int32_t*> row_splits;
+  std::vector<int32_t> send_sizes;   // S [N][W] rows this rank requests from owner q, column c
+  std::vector<int32_t> recv_sizes;   // R [W][N] rows requester q asked this rank for, column c
+  hbk::Layout lay;
+  bool have_step;
+  // device buffers owned by the plan
+  hbk::Buffer ids_bucketized, part_out, shard_index, sizes_dev, part_ws, send_ids, recv_ids,
+      send_rows, recv_rows, rows_unpacked, wire_ws, ids_unpacked, bwd_ws;
+  int32_t* host_sizes;  // pinned [2][N*W]
+};
+
+extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t n_cols,
+                                  const hbk_sharded_column_t* cols, int32_t wire_dtype) {
+  using namespace hbk;
+  HBK_REQUIRE(plan != nullptr && comm != nullptr, "sharded_create: NULL argument");
+  HBK_REQUIRE(n_cols >= 1 && cols != nullptr, "sharded_create: need at least one column");
+  HBK_REQUIRE(wire_dtype == HBK_FLOAT || wire_dtype == HBK_HALF,
+              "sharded_create: wire_dtype must be float or half");
+  for (int32_t c = 0; c < n_cols; ++c) {
+    HBK_REQUIRE(cols[c].dim >= 1 && cols[c].rows_local >= 0 && cols[c].bucket >= 0,
+                "sharded_create: column %d: bad dim / rows / bucket", c);
+    HBK_REQUIRE(cols[c].combiner >= HBK_COMBINER_SUM && cols[c].combiner <= HBK_COMBINER_SQRTN,
+                "sharded_create: column %d: unknown combiner %d", c, cols[c].combiner);
+    HBK_REQUIRE(cols[c].shard != nullptr || cols[c].rows_local == 0,
+                "sharded_create: column %d: shard is NULL", c);
+  }
+  hbk_sharded* p = new hbk_sharded();
+  p->comm = comm;
+  p->W = hbk_comm_world_size(comm);
+  p->rank = hbk_comm_rank(comm);
+  p->N = n_cols;
+  p->wire_dtype = wire_dtype;
+  p->cols.assign(cols, cols + n_cols);
+  p->have_step = false;
+  p->host_sizes = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void**>(&p->host_sizes),
+                    sizeof(int32_t) * 2 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
+      hipSuccess) {
+    delete p;
+    return fail(HBK_INTERNAL, "sharded_create: hipHostMalloc failed");
+  }
+  *plan = p;
+  return HBK_OK;
+}
+
+extern "C" int hbk_sharded_destroy(hbk_sharded_t p) {
+  if (p == nullptr) return HBK_OK;
+  for (hbk::Buffer* b : {&p->ids_bucketized, &p->part_out, &p->shard_index, &p->sizes_dev,
+                         &p->part_ws, &p->send_ids, &p->recv_ids, &p->send_rows, &p->recv_rows,
+                         &p->rows_unpacked, &p->wire_ws, &p->ids_unpacked, &p->bwd_ws}) {
+    b->release();
+  }
+  if (p->host_sizes) (void)hipHostFree(p->host_sizes);
+  delete p;
+  return HBK_OK;
+}
+
+namespace hbk {
+namespace {
+
+inline Seg make_seg(const void* src, void* dst, int64_t bytes) {
+  Seg s;
+  s.src = src;
+  s.dst = dst;
+  s.bytes = bytes;
+  s.tile0 = 0;
+  s.pad_ = 0;
+  return s;
+}
+
+// one packed exchange: a single buffer, one message per peer
+int exchange(hbk_sharded* p, int32_t dtype, int32_t wire, const void* in, const int32_t* send,
+             void* out, const int32_t* recv, hbk_stream_t stream) {
+  const int64_t cs[1] = {1};
+  const void* vin[1] = {in};
+  void* vout[1] = {out};
+  if (wire != dtype) {
+    const size_t wws = hbk_alltoallv_wire_workspace_bytes(1, cs, send, recv, p->W);
+    int rc = p->wire_ws.ensure(wws + 16);
+    if (rc != HBK_OK) return rc;
+  }
+  return hbk_alltoallv_n(p->comm, 1, dtype, wire, HBK_TOPOLOGY_ALL, cs, vin, send, vout, recv,
+                         p->wire_ws.ptr, p->wire_ws.bytes, stream);
+}
+
+}  // namespace
+}  // namespace hbk
+
+extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids,
+                                      const int64_t* n_ids,
+                                      const int32_t* const* row_splits,
+                                      const int64_t* n_segments, float* const* outs,
+                                      hbk_stream_t stream_) {
+  using namespace hbk;
+  HBK_REQUIRE(p != nullptr, "sharded_lookup_fwd: plan is NULL");
+  HBK_REQUIRE(ids && n_ids && outs, "sharded_lookup_fwd: NULL argument array");
+  hipStream_t stream = as_stream(stream_);
+  const int N = p->N, W = p->W;
+  int64_t total = 0;
+  p->n_ids.assign(n_ids, n_ids + N);
+  p->n_seg.resize(N);
+  p->row_splits.resize(N);
+  for (int c = 0; c < N; ++c) {
+    HBK_REQUIRE(n_ids[c] >= 0 && n_ids[c] < (1ll << 31), "sharded_lookup_fwd: bad n_ids[%d]", c);
+    p->row_splits[c] = row_splits ? row_splits[c] : nullptr;
+    HBK_REQUIRE(p->row_splits[c] == nullptr || n_segments != nullptr,
+                "sharded_lookup_fwd: n_segments is NULL");
+    p->n_seg[c] = p->row_splits[c] ? n_segments[c] : n_ids[c];
+    total += n_ids[c];
+  }
+  int rc;
+  // ---- 1 bucketize + stable partition ------------------------------------------------------
+  if ((rc = p->ids_bucketized.ensure((size_t)total * 8 + 8)) != HBK_OK) return rc;
+  if ((rc = p->part_out.ensure((size_t)total * 8 + 8)) != HBK_OK) return rc;
+  if ((rc = p->shard_index.ensure((size_t)total * 4 + 8)) != HBK_OK) return rc;
+  if ((rc = p->sizes_dev.ensure((size_t)N * W * 4 * 3)) != HBK_OK) return rc;
+  std::vector<void*> pout(N);
+  std::vector<int32_t*> sizes(N), idx(N);
+  int32_t* sizes_dev = reinterpret_cast<int32_t*>(p->sizes_dev.ptr);       // S [N][W]
+  int32_t* sizes_t = sizes_dev + (size_t)N * W;                            // S^T [W][N]
+  int32_t* recv_t = sizes_t + (size_t)N * W;                               // R [W][N]
+  {
+    std::vector<const void*> part_in(N), fin;
+    std::vector<void*> fout;
+    std::vector<int64_t> flen, fb;
+    int64_t off = 0;
+    for (int c = 0; c < N; ++c) {
+      pout[c] = reinterpret_cast<int64_t*>(p->part_out.ptr) + off;
+      idx[c] = reinterpret_cast<int32_t*>(p->shard_index.ptr) + off;
+      sizes[c] = sizes_dev + (size_t)c * W;
+      part_in[c] = ids[c];
+      if (p->cols[c].bucket > 0) {
+        void* b = reinterpret_cast<int64_t*>(p->ids_bucketized.ptr) + off;
+        fin.push_back(ids[c]);
+        fout.push_back(b);
+        flen.push_back(n_ids[c]);
+        fb.push_back(p->cols[c].bucket);
+        part_in[c] = b;
+      }
+      off += n_ids[c];
+    }
+    if (!fin.empty()) {
+      rc = hbk_floormod_n((int32_t)fin.size(), HBK_INT64, fin.data(), flen.data(), fb.data(),
+                          fout.data(), stream_);
+      if (rc != HBK_OK) return rc;
+    }
+    const size_t ws = hbk_partition_workspace_bytes(N, n_ids, W);
+    if ((rc = p->part_ws.ensure(ws + 8)) != HBK_OK) return rc;
+    rc = hbk_partition_by_modulo_n(N, HBK_INT64, W, part_in.data(), n_ids, pout.data(),
+                                   sizes.data(), idx.data(), p->part_ws.ptr, p->part_ws.bytes,
+                                   stream_);
+    if (rc != HBK_OK) return rc;
+  }
+  // ---- 2 one size exchange for all columns, one host sync -----------------------------------
+  hipLaunchKernelGGL(transpose_sizes_kernel, dim3((N * W + 255) / 256), dim3(256), 0, stream,
+                     sizes_dev, sizes_t, N, W);
+  {
+    const void* sin[1] = {sizes_t};
+    void* sout[1] = {recv_t};
+    const int64_t cnt[1] = {(int64_t)N * W};
+    rc = hbk_alltoall_n(p->comm, 1, HBK_INT32, HBK_TOPOLOGY_ALL, sin, cnt, sout, stream_);
+    if (rc != HBK_OK) return rc;
+  }
+  HBK_HIP_OK(hipMemcpyAsync(p->host_sizes, sizes_dev, sizeof(int32_t) * N * W,
+                            hipMemcpyDeviceToHost, stream));
+  HBK_HIP_OK(hipMemcpyAsync(p->host_sizes + (size_t)N * W, recv_t, sizeof(int32_t) * N * W,
+                            hipMemcpyDeviceToHost, stream));
+  HBK_HIP_OK(hipStreamSynchronize(stream));
+  p->send_sizes.assign(p->host_sizes, p->host_sizes + (size_t)N * W);
+  p->recv_sizes.assign(p->host_sizes + (size_t)N * W, p->host_sizes + 2 * (size_t)N * W);
+  const int32_t* S = p->send_sizes.data();
+  const int32_t* R = p->recv_sizes.data();
+  Layout& L = p->lay;
+  if ((rc = L.compute(N, W, p->cols, S, R)) != HBK_OK) return rc;
+  // ---- 3 pack ids peer-major and exchange: one message per peer -----------------------------
+  if ((rc = p->send_ids.ensure((size_t)L.req_ids * 8 + 8)) != HBK_OK) return rc;
+  if ((rc = p->recv_ids.ensure((size_t)L.own_ids * 8 + 8)) != HBK_OK) return rc;
+  {
+    std::vector<Seg> segs;
+    for (int q = 0; q < W; ++q) {
+      for (int c = 0; c < N; ++c) {
+        segs.push_back(make_seg(
+            reinterpret_cast<const int64_t*>(pout[c]) + L.col_shard_off[(size_t)c * W + q],
+            reinterpret_cast<int64_t*>(p->send_ids.ptr) + L.req_id_off[(size_t)q * N + c],
+            (int64_t)S[(size_t)c * W + q] * 8));
+      }
+    }
+    if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
+  }
+  rc = exchange(p, HBK_INT64, HBK_INT64, p->send_ids.ptr, L.ids_send_peer.data(),
+                p->recv_ids.ptr, L.ids_recv_peer.data(), stream_);
+  if (rc != HBK_OK) return rc;
+  // ---- 4 owner gather: N*W virtual columns, straight into the peer-major reply ---------------
+  if ((rc = p->send_rows.ensure((size_t)L.own_floats * 4 + 16)) != HBK_OK) return rc;
+  if ((rc = p->recv_rows.ensure((size_t)L.req_floats * 4 + 16)) != HBK_OK) return rc;
+  {
+    std::vector<hbk_lookup_column_t> v;
+    v.reserve((size_t)N * W);
+    for (int q = 0; q < W; ++q) {
+      for (int c = 0; c < N; ++c) {
+        const int64_t n = R[(size_t)q * N + c];
+        if (n == 0) continue;
+        hbk_lookup_column_t h;
+        memset(&h, 0, sizeof(h));
+        h.table = p->cols[c].shard;
+        h.rows = p->cols[c].rows_local;
+        h.dim = p->cols[c].dim;
+        h.ids_dtype = HBK_INT64;
+        h.ids = reinterpret_cast<const int64_t*>(p->recv_ids.ptr) + L.own_id_off[(size_t)q * N + c];
+        h.n_ids = n;
+        h.n_segments = n;
+        h.divisor = W;
+        h.combiner = HBK_COMBINER_SUM;
+        h.out = reinterpret_cast<float*>(p->send_rows.ptr) + L.own_row_off[(size_t)q * N + c];
+        v.push_back(h);
+      }
+    }
+    rc = hbk_group_lookup_fwd((int32_t)v.size(), v.data(), stream_);
+    if (rc != HBK_OK) return rc;
+  }
+  // ---- 5 rows travel back: one message per peer ------------------------------------------------
+  rc = exchange(p, HBK_FLOAT, p->wire_dtype, p->send_rows.ptr, L.rows_send_peer.data(),
+                p->recv_rows.ptr, L.rows_recv_peer.data(), stream_);
+  if (rc != HBK_OK) return rc;
+  // ---- 6 unpack column-major, stitch + combiner ------------------------------------------------
+  if ((rc = p->rows_unpacked.ensure((size_t)L.req_floats * 4 + 16)) != HBK_OK) return rc;
+  {
+    std::vector<Seg> segs;
+    std::vector<int64_t> col_base(N);
+    int64_t b = 0;
+    for (int c = 0; c < N; ++c) {
+      col_base[c] = b;
+      b += n_ids[c] * p->cols[c].dim;
+    }
+    for (int q = 0; q < W; ++q) {
+      for (int c = 0; c < N; ++c) {
+        const int64_t d = p->cols[c].dim;
+        segs.push_back(make_seg(
+            reinterpret_cast<const float*>(p->recv_rows.ptr) + L.req_row_off[(size_t)q * N + c],
+            reinterpret_cast<float*>(p->rows_unpacked.ptr) + col_base[c] +
+                L.col_shard_off[(size_t)c * W + q] * d,
+            (int64_t)S[(size_t)c * W + q] * d * 4));
+      }
+    }
+    if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
+    std::vector<hbk_lookup_column_t> v(N);
+    for (int c = 0; c < N; ++c) {
+      hbk_lookup_column_t& h = v[c];
+      memset(&h, 0, sizeof(h));
+      h.table = reinterpret_cast<const float*>(p->rows_unpacked.ptr) + col_base[c];
+      h.rows = n_ids[c];
+      h.dim = p->cols[c].dim;
+      h.ids_dtype = HBK_INT32;
+      h.ids = idx[c];
+      h.n_ids = n_ids[c];
+      h.row_splits = p->row_splits[c];
+      h.n_segments = p->n_seg[c];
+      h.divisor = 1;
+      h.combiner = p->cols[c].combiner;
+      h.out = outs[c];
+    }
+    rc = hbk_group_lookup_fwd(N, v.data(), stream_);
+    if (rc != HBK_OK) return rc;
+  }
+  p->have_step = true;
+  return HBK_OK;
+}
+
+extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads,
+                                      float apply_lr, int64_t* const* unique_rows,
+                                      float* const* grad_rows, int32_t* const* n_unique,
+                                      hbk_stream_t stream_) {
+  using namespace hbk;
+  HBK_REQUIRE(p != nullptr, "sharded_lookup_bwd: plan is NULL");
+  HBK_REQUIRE(p->have_step, "sharded_lookup_bwd: no forward step to differentiate");
+  HBK_REQUIRE(grads && unique_rows && grad_rows && n_unique,
+              "sharded_lookup_bwd: NULL argument array");
+  hipStream_t stream = as_stream(stream_);
+  const int N = p->N, W = p->W;
+  const int32_t* S = p->send_sizes.data();
+  const int32_t* R = p->recv_sizes.data();
+  const Layout& L = p->lay;
+  int rc;
+  // ---- B1 d(stitch + combiner) into column-major rows ------------------------------------------
+  if ((rc = p->rows_unpacked.ensure((size_t)L.req_floats * 4 + 16)) != HBK_OK) return rc;
+  std::vector<int64_t> col_base(N);
+  {
+    std::vector<hbk_stitch_grad_column_t> v(N);
+    int64_t b = 0, ioff = 0;
+    for (int c = 0; c < N; ++c) {
+      col_base[c] = b;
+      hbk_stitch_grad_column_t& h = v[c];
+      h.dim = p->cols[c].dim;
+      h.combiner = p->cols[c].combiner;
+      h.n_ids = p->n_ids[c];
+      h.index = reinterpret_cast<const int32_t*>(p->shard_index.ptr) + ioff;
+      h.row_splits = p->row_splits[c];
+      h.n_segments = p->n_seg[c];
+      h.grad_out = grads[c];
+      h.grad_rows = reinterpret_cast<float*>(p->rows_unpacked.ptr) + b;
+      b += p->n_ids[c] * p->cols[c].dim;
+      ioff += p->n_ids[c];
+    }
+    rc = hbk_group_stitch_bwd(N, v.data(), stream_);
+    if (rc != HBK_OK) return rc;
+  }
+  // ---- B2 pack peer-major, reverse exchange (the forward's sizes, swapped) --------------------
+  if ((rc = p->recv_rows.ensure((size_t)L.req_floats * 4 + 16)) != HBK_OK) return rc;
+  if ((rc = p->send_rows.ensure((size_t)L.own_floats * 4 + 16)) != HBK_OK) return rc;
+  {
+    std::vector<Seg> segs;
+    for (int q = 0; q < W; ++q) {
+      for (int c = 0; c < N; ++c) {
+        const int64_t d = p->cols[c].dim;
+        segs.push_back(make_seg(
+            reinterpret_cast<const float*>(p->rows_unpacked.ptr) + col_base[c] +
+                L.col_shard_off[(size_t)c * W + q] * d,
+            reinterpret_cast<float*>(p->recv_rows.ptr) + L.req_row_off[(size_t)q * N + c],
+            (int64_t)S[(size_t)c * W + q] * d * 4));
+      }
+    }
+    if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
+  }
+  rc = exchange(p, HBK_FLOAT, p->wire_dtype, p->recv_rows.ptr, L.rows_recv_peer.data(),
+                p->send_rows.ptr, L.rows_send_peer.data(), stream_);
+  if (rc != HBK_OK) return rc;
+  // ---- B3 owner side: column-major ids + grads, then duplicate-row reduction (+ SGD) ---------
+  if ((rc = p->ids_unpacked.ensure((size_t)L.own_ids * 8 + 8)) != HBK_OK) return rc;
+  if ((rc = p->rows_unpacked.ensure((size_t)L.own_floats * 4 + 16)) != HBK_OK) return rc;
+  {
+    std::vector<int64_t> n_own(N, 0), id_base(N), f_base(N);
+    for (int c = 0; c < N; ++c) {
+      for (int q = 0; q < W; ++q) n_own[c] += R[(size_t)q * N + c];
+    }
+    int64_t ib = 0, fb = 0;
+    for (int c = 0; c < N; ++c) {
+      id_base[c] = ib;
+      f_base[c] = fb;
+      ib += n_own[c];
+      fb += n_own[c] * p->cols[c].dim;
+    }
+    std::vector<Seg> segs;
+    std::vector<int64_t> ioff(N, 0);
+    for (int q = 0; q < W; ++q) {
+      for (int c = 0; c < N; ++c) {
+        const int64_t n = R[(size_t)q * N + c], d = p->cols[c].dim;
+        segs.push_back(make_seg(
+            reinterpret_cast<const int64_t*>(p->recv_ids.ptr) + L.own_id_off[(size_t)q * N + c],
+            reinterpret_cast<int64_t*>(p->ids_unpacked.ptr) + id_base[c] + ioff[c], n * 8));
+        segs.push_back(make_seg(
+            reinterpret_cast<const float*>(p->send_rows.ptr) + L.own_row_off[(size_t)q * N + c],
+            reinterpret_cast<float*>(p->rows_unpacked.ptr) + f_base[c] + ioff[c] * d,
+            n * d * 4));
+        ioff[c] += n;
+      }
+    }
+    if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
+    std::vector<hbk_lookup_grad_column_t> v(N);
+    for (int c = 0; c < N; ++c) {
+      hbk_lookup_grad_column_t& h = v[c];
+      memset(&h, 0, sizeof(h));
+      h.table = const_cast<float*>(p->cols[c].shard);
+      h.rows = p->cols[c].rows_local;
+      h.dim = p->cols[c].dim;
+      h.ids_dtype = HBK_INT64;
+      h.ids = reinterpret_cast<const int64_t*>(p->ids_unpacked.ptr) + id_base[c];
+      h.n_ids = n_own[c];
+      h.n_segments = n_own[c];
+      h.divisor = W;
+      h.combiner = HBK_COMBINER_SUM;
+      h.grad_out = reinterpret_cast<const float*>(p->rows_unpacked.ptr) + f_base[c];
+      h.unique_rows = unique_rows[c];
+      h.grad_rows = grad_rows[c];
+      h.n_unique = n_unique[c];
+    }
+    const size_t ws = hbk_group_lookup_bwd_workspace_bytes(N, v.data());
+    if ((rc = p->bwd_ws.ensure(ws + 8)) != HBK_OK) return rc;
+    rc = hbk_group_lookup_bwd(N, v.data(), apply_lr, p->bwd_ws.ptr, p->bwd_ws.bytes, stream_);
+    if (rc != HBK_OK) return rc;
+  }
+  return HBK_OK;
+}
+
+// capacity the caller needs for the backward outputs of column c (rows this rank owns that
+// were requested in the last forward step)
+extern "C" int64_t hbk_sharded_owned_ids(hbk_sharded_t p, int32_t column) {
+  if (p == nullptr || !p->have_step || column < 0 || column >= p->N) return -1;
+  int64_t n = 0;
+  for (int q = 0; q < p->W; ++q) n += p->recv_sizes[(size_t)q * p->N + column];
+  return n;
+}

@@ -69,6 +69,26 @@ class Collective:
     self._wire_ws = None
 
   @classmethod
+  def local_world(cls, world_size):
+    """Test transport: ``world_size`` communicators of one in-process world (one host thread
+    and one stream per rank, all on the current GPU).  Returns the list of communicators;
+    keep a reference to the first one's ``_world`` until all are closed."""
+    lib = _lib.lib()
+    world = C.c_void_p()
+    _lib.check(lib.hbk_local_world_create(C.byref(world), world_size))
+    comms = []
+    for r in range(world_size):
+      c = cls.__new__(cls)
+      c._lib = lib
+      c.world_size, c.rank, c.local_size = world_size, r, world_size
+      c._handle = C.c_void_p()
+      c._wire_ws = None
+      c._world = world
+      _lib.check(lib.hbk_comm_create_local(C.byref(c._handle), world, r))
+      comms.append(c)
+    return comms
+
+  @classmethod
   def get(cls):
     if cls._default is None:
       raise _lib.HbkError(_lib.INTERNAL, 'Collective is not initialized')

@@ -18,8 +18,10 @@ Per rank and step (W = world size, owner of an id = ``id mod W``, local row = ``
 The reference pays one host ``BlockHostUntilDone`` per exchange op (nccl_alltoallv.cc:316,533);
 here the receive sizes of BOTH exchanges come from the single size exchange of step 2.
 
-The compute phases are separate methods so a test can drive W virtual ranks in one process
-with its own transport; ``__call__`` runs them against the RCCL communicator.
+``__call__`` / ``backward`` run the whole step inside ONE C-ABI call each
+(``hbk_sharded_lookup_fwd/_bwd``, csrc/sharded.hip: every exchange is one message per peer, host
+cost tens of microseconds).  The compute phases also exist as separate methods so a test can
+drive W virtual ranks through the kernels with its own transport.
 """
 import ctypes as C
 
@@ -114,25 +116,59 @@ class ShardedGroupLookup:
     st.outs = stitcher(st.shard_index, st.row_splits)
     return st.outs
 
-  # ---- the whole forward against the communicator ---------------------------------------
-  def __call__(self, ids, row_splits=None, keep=False):
-    st = self.partition(ids, row_splits)
-    n, W = len(self.shards), self.world_size
-    # one size exchange for all columns; sizes[c][p] = rows this rank sends to rank p
-    # send layout for the equal-split alltoall: chunk p = the N sizes destined to rank p
-    send = st.send_sizes.t().contiguous()                     # [W, N]
-    recv = self.coll.alltoall_n([send.view(-1)])[0].view(W, n)
-    host_send = st.send_sizes.cpu()                           # [N, W]  (syncs the stream)
-    host_recv = recv.t().contiguous().cpu()                   # [N, W]
-    st.send_sizes_host = host_send.tolist()
-    st.recv_sizes_host = host_recv.tolist()
-    recv_ids = self.coll.alltoallv_n(st.send_ids, st.send_sizes_host, st.recv_sizes_host,
-                                     common_sizes=[1] * n)
-    send_rows = self.owner_gather(st, recv_ids)
-    recv_rows = self.coll.alltoallv_n(send_rows, st.recv_sizes_host, st.send_sizes_host,
-                                      common_sizes=self.dims, wire_dtype=self.wire_dtype)
-    outs = self.stitch(st, recv_rows)
-    return (outs, st) if keep else outs
+  # ---- the whole forward: ONE C-ABI call (hbk_sharded_lookup_fwd, csrc/sharded.hip) ----------
+  def _plan(self):
+    if getattr(self, '_plan_handle', None) is None:
+      from hybridbackend_amd.embedding.lookup import _combiner_code
+      n = len(self.shards)
+      combs = self.combiners
+      if isinstance(combs, (str, int)) or combs is None:
+        combs = [combs] * n
+      cols = (_lib.ShardedColumn * n)()
+      for c, t in enumerate(self.shards):
+        cols[c].shard = t.data_ptr()
+        cols[c].rows_local = t.shape[0]
+        cols[c].dim = t.shape[1]
+        cols[c].combiner = _combiner_code(combs[c])
+        cols[c].bucket = self.buckets[c]
+      self._plan_handle = C.c_void_p()
+      wire = _lib.HALF if self.wire_dtype == torch.float16 else _lib.FLOAT
+      _lib.check(self._lib.hbk_sharded_create(
+        C.byref(self._plan_handle), self.coll._handle, n, cols, wire))
+    return self._plan_handle
+
+  def close(self):
+    if getattr(self, '_plan_handle', None) is not None:
+      self._lib.hbk_sharded_destroy(self._plan_handle)
+      self._plan_handle = None
+
+  def __call__(self, ids, row_splits=None, outs=None):
+    """One forward step through the communicator.  ``ids[c]``: int64 device vector;
+    ``row_splits[c]``: int32 device vector or None.  Returns the per-column outputs."""
+    n = len(self.shards)
+    plan = self._plan()
+    if row_splits is None:
+      row_splits = [None] * n
+    n_seg = []
+    for c in range(n):
+      _lib.require_device_tensor(ids[c], 'ids')
+      if ids[c].dtype != torch.int64 or ids[c].dim() != 1:
+        raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, 'ids must be an int64 vector')
+      s = row_splits[c]
+      if s is not None:
+        _lib.require_device_tensor(s, 'row_splits')
+      n_seg.append(ids[c].numel() if s is None else s.numel() - 1)
+    if outs is None:
+      outs = [torch.empty((n_seg[c], self.dims[c]), dtype=torch.float32, device=self.device)
+              for c in range(n)]
+    self._keep = (ids, row_splits, outs)
+    _lib.check(self._lib.hbk_sharded_lookup_fwd(
+      plan, _lib.ptr_array([t.data_ptr() for t in ids]),
+      _lib.i64_array([t.numel() for t in ids]),
+      _lib.ptr_array([None if s is None else s.data_ptr() for s in row_splits]),
+      _lib.i64_array(n_seg), _lib.ptr_array([o.data_ptr() for o in outs]),
+      _lib.current_stream(self.device)))
+    return outs
 
   # ---- backward (SURVEY 3.4) -----------------------------------------------------------------
   # phase B1: d(stitch + combiner): per-id gradient rows in the order of the partitioned ids
@@ -171,15 +207,28 @@ class ShardedGroupLookup:
   def owner_bwd(self, st, recv_grads, apply_lr=0.0):
     return self._owner_grad(st.recv_ids, recv_grads, None, apply_lr=apply_lr)
 
-  def backward(self, st, grads, apply_lr=0.0, wire_dtype=None):
-    """grads[c]: gradient of column c's output [segments, dim].  Returns per column the
-    IndexedSlices of the LOCAL shard ``(unique_rows, grad_rows, n_unique)``; with
-    ``apply_lr`` the SGD update is applied to the shard in the same pass (sharded variables
-    are not aggregated across ranks, training/gradient.py:193-217).  The exchange reuses the
-    forward's sizes reversed (collective.py:334-347): no new size exchange, no host sync."""
-    send = self.stitch_bwd(st, grads)
-    recv = self.coll.alltoallv_n(send, st.send_sizes_host, st.recv_sizes_host,
-                                 common_sizes=self.dims,
-                                 wire_dtype=wire_dtype if wire_dtype is not None
-                                 else self.wire_dtype)
-    return self.owner_bwd(st, recv, apply_lr)
+  def backward(self, grads, apply_lr=0.0):
+    """Backward of the LAST forward step (hbk_sharded_lookup_bwd).  grads[c]: gradient of
+    column c's output [segments, dim].  Returns per column the IndexedSlices of the LOCAL
+    shard ``(unique_rows, grad_rows, n_unique)``; with ``apply_lr`` the SGD update is applied
+    to the shard in the same pass (sharded variables are not aggregated across ranks,
+    training/gradient.py:193-217).  The exchange reuses the forward's sizes reversed
+    (collective.py:334-347): no new size exchange, no host sync."""
+    n = len(self.shards)
+    plan = self._plan()
+    res = []
+    for c in range(n):
+      _lib.require_device_tensor(grads[c], 'grads')
+      k = int(self._lib.hbk_sharded_owned_ids(plan, c))
+      if k < 0:
+        raise _lib.HbkError(_lib.INTERNAL, 'backward() needs a forward step first')
+      res.append((torch.empty(k, dtype=torch.int64, device=self.device),
+                  torch.empty((k, self.dims[c]), dtype=torch.float32, device=self.device),
+                  torch.zeros(1, dtype=torch.int32, device=self.device)))
+    self._keep_bwd = (grads, res)
+    _lib.check(self._lib.hbk_sharded_lookup_bwd(
+      plan, _lib.ptr_array([g.data_ptr() for g in grads]), C.c_float(apply_lr),
+      _lib.ptr_array([r[0].data_ptr() for r in res]),
+      _lib.ptr_array([r[1].data_ptr() for r in res]),
+      _lib.ptr_array([r[2].data_ptr() for r in res]), _lib.current_stream(self.device)))
+    return res

@@ -293,6 +293,58 @@ int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dtyp
                     void* const* outputs, const int32_t* recv_sizes, void* wire_ws,
                     size_t wire_ws_bytes, hbk_stream_t compute_stream);
 
+/* In-process "world" for tests: `world_size` ranks living in ONE process (one host thread and
+ * one stream each, all on the current GPU) exchange through device copies with the same
+ * chunk/offset arithmetic as the RCCL path.  It exists so that the multi-rank driver below can
+ * be exercised on a single-GPU machine; it is not a production transport. */
+int hbk_local_world_create(void** world, int32_t world_size);
+int hbk_local_world_destroy(void* world);
+int hbk_comm_create_local(hbk_comm_t* comm, void* world, int32_t rank);
+
+/* ------------------------------------------------------------------------------------
+ * R12  The whole sharded pipeline of hbtf/embedding/sharding.py:171-205 for N columns in one
+ *   call per direction (what the reference's Pack pass + executor run as ~10 ops per column):
+ *     forward : bucketize -> partition by id mod W -> alltoallv(ids) -> owner gather (`// W`)
+ *               -> alltoallv(rows, fp32 | fp16 wire) -> stitch + combiner
+ *     backward: d(stitch+combiner) -> reverse alltoallv (forward's sizes,
+ *               hbtf/distribute/collective.py:334-347) -> duplicate-row reduction on the owner
+ *               (+ fused SGD on the shard when apply_lr != 0)
+ *   One [N x W] size exchange and ONE host sync per forward for all columns (the reference
+ *   syncs once per op: nccl_alltoallv.cc:316,533); none in the backward.  Every exchange
+ *   is one message per peer (all columns of a peer travel together).  Exchange buffers whose
+ *   size depends on the peers are owned by the plan and grow on demand.
+ *   ids are int64.  outs[c] is [n_segments[c], dim] ([n_ids[c], dim] when row_splits[c] is
+ *   NULL).  The backward differentiates the LAST forward of the plan; its outputs need
+ *   capacity hbk_sharded_owned_ids(plan, c) rows (known after that forward).              */
+typedef struct {
+  const float* shard;   /* device [rows_local, dim]: rows r, r+W, r+2W.. of the logical table */
+  int64_t rows_local;
+  int32_t dim;
+  int32_t combiner;
+  int64_t bucket;       /* >0: ids are taken modulo this before the partition (R1) */
+} hbk_sharded_column_t;
+
+/* Host arithmetic of the peer-major exchange buffers (pure host code, no device work): S is
+ * [n_cols][world] (rows this rank requests from owner q), R is [world][n_cols] (rows requester q
+ * asked this rank for).  Any output pointer may be NULL.  Offsets are in ids / floats. */
+int hbk_sharded_layout(int32_t n_cols, int32_t world, const int32_t* dims, const int32_t* S,
+                       const int32_t* R, int32_t* ids_send_peer, int32_t* ids_recv_peer,
+                       int32_t* rows_send_peer, int32_t* rows_recv_peer, int64_t* req_id_off,
+                       int64_t* req_row_off, int64_t* own_id_off, int64_t* own_row_off,
+                       int64_t* col_shard_off);
+
+typedef struct hbk_sharded* hbk_sharded_t;
+int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t n_cols,
+                       const hbk_sharded_column_t* cols, int32_t wire_dtype);
+int hbk_sharded_destroy(hbk_sharded_t plan);
+int hbk_sharded_lookup_fwd(hbk_sharded_t plan, const int64_t* const* ids, const int64_t* n_ids,
+                           const int32_t* const* row_splits, const int64_t* n_segments,
+                           float* const* outs, hbk_stream_t stream);
+int64_t hbk_sharded_owned_ids(hbk_sharded_t plan, int32_t column);
+int hbk_sharded_lookup_bwd(hbk_sharded_t plan, const float* const* grads, float apply_lr,
+                           int64_t* const* unique_rows, float* const* grad_rows,
+                           int32_t* const* n_unique, hbk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

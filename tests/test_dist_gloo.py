@@ -1,11 +1,14 @@
 """The N > 1 host path on CPU: two real processes over torch.distributed (gloo).
 
-What runs here is the PRODUCT's pipeline driver (`ShardedGroupLookup.__call__`: the size
-exchange layout, exchange order and reversed sizes of sharding.py:171-205) and its offset
-helpers; the HIP compute phases cannot run without a GPU, so a test-only subclass computes
-them with the CPU oracle, and a test-only transport carries the exchanges over gloo using the
-Alltoallv offset arithmetic (nccl_collective.cc:250-288).  The reference's own 2-rank KATs
-(alltoall_test.py:219-226, :254-269) are replayed through the same transport."""
+The HIP compute phases cannot run without a GPU, so the per-rank compute is done with the CPU
+oracle; what IS the product here is the host arithmetic that decides what travels where:
+`hbk_sharded_layout` (csrc/sharded.hip: peer-major message sizes and run offsets of both
+exchanges, exactly what `hbk_sharded_lookup_fwd/_bwd` use at 8 GPUs), `alltoallv_offsets`
+and `compute_active_ranks`.  Messages are built from that layout, one per peer, exchanged
+between two processes, unpacked with the same layout, and the result must equal the unsharded
+oracle lookup.  The reference's own 2-rank KATs (alltoall_test.py:219-226, :254-269) are
+replayed through the same transport."""
+import ctypes as C
 import json
 import os
 import socket
@@ -28,47 +31,39 @@ def _free_port():
   return p
 
 
-class GlooTransport:
-  """alltoall_n / alltoallv_n with the Collective's signatures, over gloo (CPU tensors)."""
+def gloo_alltoallv(rank, world, send, send_sizes):
+  """send: 1-D array; send_sizes[i] elements go to rank i (Alltoallv offset arithmetic of
+  nccl_collective.cc:250-288 through hb.distribute.alltoallv_offsets).  Returns (recv, sizes)."""
+  from hybridbackend_amd.distribute import alltoallv_offsets
+  gathered = [None] * world
+  dist.all_gather_object(gathered, (np.ascontiguousarray(send), [int(x) for x in send_sizes]))
+  chunks, sizes = [], []
+  for peer_arr, peer_sizes in gathered:
+    offs, _ = alltoallv_offsets(peer_sizes)
+    chunks.append(peer_arr[offs[rank]:offs[rank] + peer_sizes[rank]])
+    sizes.append(peer_sizes[rank])
+  return np.concatenate(chunks), sizes
 
-  def __init__(self, world_size, rank):
-    self.world_size, self.rank = world_size, rank
 
-  def active_size(self, topology=0):
-    return self.world_size
-
-  def alltoall_n(self, values, topology=0):
-    outs = []
-    for v in values:
-      gathered = [None] * self.world_size
-      dist.all_gather_object(gathered, v.numpy())
-      part = v.numel() // self.world_size
-      outs.append(torch.from_numpy(np.concatenate(
-        [g[self.rank * part:(self.rank + 1) * part] for g in gathered])))
-    return outs
-
-  def alltoallv_n(self, values, send_sizes, recv_sizes, common_sizes=None, wire_dtype=None,
-                  topology=0, outs=None):
-    from hybridbackend_amd.distribute import alltoallv_offsets
-    import oracle
-    res = []
-    for c, v in enumerate(values):
-      arr = v.numpy()
-      if wire_dtype == torch.float16:
-        arr = oracle.cast_f32_to_f16(arr)
-      gathered = [None] * self.world_size
-      dist.all_gather_object(gathered, (arr, list(send_sizes[c])))
-      chunks = []
-      for i, (peer_arr, peer_sizes) in enumerate(gathered):
-        offs, _ = alltoallv_offsets(peer_sizes)
-        n = peer_sizes[self.rank]
-        assert n == recv_sizes[c][i]          # what the size exchange announced
-        chunks.append(peer_arr[offs[self.rank]:offs[self.rank] + n])
-      out = np.concatenate(chunks, 0)
-      if wire_dtype == torch.float16:
-        out = oracle.cast_f16_to_f32(out)
-      res.append(torch.from_numpy(np.ascontiguousarray(out)))
-    return res
+def product_layout(dims, S, R):
+  """hbk_sharded_layout through the C ABI (host-only code path of libhbk_core.so)."""
+  from hybridbackend_amd import _lib
+  lib = _lib.lib()
+  N, W = S.shape
+  i32 = lambda n: np.zeros(n, np.int32)   # noqa: E731
+  i64 = lambda n: np.zeros(n, np.int64)   # noqa: E731
+  out = dict(ids_send_peer=i32(W), ids_recv_peer=i32(W), rows_send_peer=i32(W),
+             rows_recv_peer=i32(W), req_id_off=i64(N * W), req_row_off=i64(N * W),
+             own_id_off=i64(N * W), own_row_off=i64(N * W), col_shard_off=i64(N * W))
+  d = np.ascontiguousarray(dims, np.int32)
+  S = np.ascontiguousarray(S, np.int32)
+  R = np.ascontiguousarray(R, np.int32)
+  p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+  _lib.check(lib.hbk_sharded_layout(N, W, p(d), p(S), p(R), *[p(v) for v in out.values()]))
+  for k in ('req_id_off', 'req_row_off', 'own_id_off', 'own_row_off'):
+    out[k] = out[k].reshape(W, N)
+  out['col_shard_off'] = out['col_shard_off'].reshape(N, W)
+  return out
 
 
 def _worker(rank, world, port, wire16, result_dir):
@@ -78,74 +73,28 @@ def _worker(rank, world, port, wire16, result_dir):
   dist.init_process_group('gloo', rank=rank, world_size=world)
   try:
     import oracle
-    from hybridbackend_amd.embedding.sharded import ShardedGroupLookup, _Step
-
-    class OracleSharded(ShardedGroupLookup):
-      """Compute phases restated with the oracle (CPU); host logic inherited."""
-
-      def _setup(self):
-        pass
-
-      def partition(self, ids, row_splits=None):
-        st = _Step()
-        st.ids, st.row_splits = list(ids), row_splits or [None] * len(ids)
-        outs, sizes, idxs = [], [], []
-        for c, t in enumerate(ids):
-          x = t.numpy()
-          if self.buckets[c]:
-            x = oracle.floormod(x, self.buckets[c])
-          o, s, i = oracle.partition_by_modulo(x, self.world_size)
-          outs.append(torch.from_numpy(o))
-          sizes.append(s)
-          idxs.append(torch.from_numpy(i))
-        st.send_ids, st.shard_index = outs, idxs
-        st.send_sizes = torch.from_numpy(np.stack(sizes).astype(np.int32))
-        return st
-
-      def owner_gather(self, st, recv_ids):
-        st.recv_ids = recv_ids
-        st.send_rows = [torch.from_numpy(oracle.gather(self.shards[c].numpy(),
-                                                       r.numpy() // self.world_size))
-                        for c, r in enumerate(recv_ids)]
-        return st.send_rows
-
-      def stitch(self, st, recv_rows):
-        outs = []
-        for c, e in enumerate(recv_rows):
-          idx = st.shard_index[c].numpy()
-          sp = st.row_splits[c]
-          if sp is None:
-            outs.append(torch.from_numpy(e.numpy()[idx]))
-          else:
-            outs.append(torch.from_numpy(oracle.segment_combine(
-              e.numpy(), idx, sp.numpy(), self.combiners[c])))
-        return outs
-
-    transport = GlooTransport(world, rank)
     # --- the reference's known-answer vectors through the transport ---
     g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'alltoallv.json')))
     s = g['single']
-    recv_sizes = transport.alltoall_n([torch.tensor(s['sizes'][rank], dtype=torch.int32)])[0]
-    assert recv_sizes.tolist() == s['out_sizes'][rank]
-    out = transport.alltoallv_n([torch.tensor(s['inputs'][rank], dtype=torch.int64)],
-                                [s['sizes'][rank]], [recv_sizes.tolist()])[0]
-    assert out.tolist() == s['outputs'][rank]
+    out, sizes = gloo_alltoallv(rank, world, np.array(s['inputs'][rank], np.int64),
+                                s['sizes'][rank])
+    assert out.tolist() == s['outputs'][rank] and sizes == s['out_sizes'][rank]
     n = g['n']
-    outs = transport.alltoallv_n(
-      [torch.tensor(n['inputs'][rank][c], dtype=torch.float32) for c in range(2)],
-      n['sizes'][rank], n['out_sizes'][rank])
     for c in range(2):
-      assert outs[c].tolist() == n['outputs'][rank][c]
+      out, sizes = gloo_alltoallv(rank, world, np.array(n['inputs'][rank][c], np.float32),
+                                  n['sizes'][rank][c])
+      assert out.tolist() == n['outputs'][rank][c] and sizes == n['out_sizes'][rank][c]
 
-    # --- the product's pipeline driver over 2 ranks ---
+    # --- the sharded pipeline, messages laid out by the product's hbk_sharded_layout ---
     rng = np.random.RandomState(1234)            # same stream on both ranks
     dims, rows = [16, 4, 8], [1003, 50, 777]
     combiners = ['sum', 'mean', 'sqrtn']
-    tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(3)]
+    N = 3
+    tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(N)]
     all_ids, all_splits = [], []
     for r in range(world):
       rid, rsp = [], []
-      for c in range(3):
+      for c in range(N):
         if c == 0:
           rsp.append(None)
           rid.append(rng.randint(0, 2**40, size=200 + 17 * r).astype(np.int64))
@@ -156,17 +105,56 @@ def _worker(rank, world, port, wire16, result_dir):
           rid.append(rng.randint(0, 2**40, size=int(sp[-1])).astype(np.int64))
       all_ids.append(rid)
       all_splits.append(rsp)
-    shards = [torch.from_numpy(np.ascontiguousarray(t[rank::world])) for t in tables]
-    drv = OracleSharded(shards, transport, buckets=rows, combiners=combiners,
-                        wire_dtype=torch.float16 if wire16 else None, world_size=world)
-    outs = drv([torch.from_numpy(i) for i in all_ids[rank]],
-               [None if s_ is None else torch.from_numpy(s_) for s_ in all_splits[rank]])
+    ids, splits = all_ids[rank], all_splits[rank]
+    shards = [np.ascontiguousarray(t[rank::world]) for t in tables]
+    # 1 bucketize + partition (oracle = the reference CPU functor)
+    part = [oracle.partition_by_modulo(oracle.floormod(ids[c], rows[c]), world) for c in range(N)]
+    S = np.stack([p[1] for p in part]).astype(np.int32)                      # [N][W]
+    # 2 ONE size exchange for all columns: chunk for peer q = S[:, q]
+    recv, _ = gloo_alltoallv(rank, world, np.ascontiguousarray(S.T).reshape(-1), [N] * world)
+    R = recv.reshape(world, N).astype(np.int32)                              # [W][N]
+    lay = product_layout(dims, S, R)
+    # 3 ids, one message per peer
+    send_ids = np.zeros(int(lay['ids_send_peer'].sum()), np.int64)
+    for q in range(world):
+      for c in range(N):
+        o, k = int(lay['col_shard_off'][c][q]), int(S[c][q])
+        d0 = int(lay['req_id_off'][q][c])
+        send_ids[d0:d0 + k] = part[c][0][o:o + k]
+    recv_ids, got_sizes = gloo_alltoallv(rank, world, send_ids, lay['ids_send_peer'])
+    assert got_sizes == lay['ids_recv_peer'].tolist()
+    # 4 owner gather into the peer-major reply
+    send_rows = np.zeros(int(lay['rows_send_peer'].sum()), np.float32)
+    for q in range(world):
+      for c in range(N):
+        k = int(R[q][c])
+        i0, f0 = int(lay['own_id_off'][q][c]), int(lay['own_row_off'][q][c])
+        emb = oracle.gather(shards[c], recv_ids[i0:i0 + k] // world)
+        send_rows[f0:f0 + k * dims[c]] = emb.reshape(-1)
+    wire = send_rows
+    if wire16:
+      wire = oracle.cast_f32_to_f16(send_rows)
+    recv_rows, got_sizes = gloo_alltoallv(rank, world, wire, lay['rows_send_peer'])
+    assert got_sizes == lay['rows_recv_peer'].tolist()
+    if wire16:
+      recv_rows = oracle.cast_f16_to_f32(recv_rows)
+    # 5 unpack column-major, stitch + combiner
     eff = tables
     if wire16:
       eff = [oracle.cast_f16_to_f32(oracle.cast_f32_to_f16(t)) for t in tables]
-    want = oracle.group_lookup_fwd(eff, all_ids[rank], all_splits[rank], rows, combiners)
-    for c in range(3):
-      np.testing.assert_equal(outs[c].numpy(), want[c])
+    want = oracle.group_lookup_fwd(eff, ids, splits, rows, combiners)
+    for c in range(N):
+      col = np.zeros((ids[c].size, dims[c]), np.float32)
+      for q in range(world):
+        o, k = int(lay['col_shard_off'][c][q]), int(S[c][q])
+        f0 = int(lay['req_row_off'][q][c])
+        col[o:o + k] = recv_rows[f0:f0 + k * dims[c]].reshape(k, dims[c])
+      idx = part[c][2]
+      if splits[c] is None:
+        got = col[idx]
+      else:
+        got = oracle.segment_combine(col, idx, splits[c], combiners[c])
+      np.testing.assert_equal(got, want[c])
     open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
   finally:
     dist.destroy_process_group()
@@ -179,6 +167,37 @@ def test_two_rank_pipeline_over_gloo(tmp_path, wire16):
   mp.spawn(_worker, args=(world, port, wire16, str(tmp_path)), nprocs=world, join=True)
   for r in range(world):
     assert (tmp_path / f'ok{r}').exists()
+
+
+def test_layout_is_consistent_between_ranks():
+  """What rank a plans to send to rank b is what rank b plans to receive from rank a, for every
+  pair, and the run offsets tile the buffers without gaps (4 ranks, mixed dims)."""
+  sys.path.insert(0, ROOT)
+  rng = np.random.RandomState(5)
+  W, N = 4, 5
+  dims = [4, 16, 128, 8, 36]
+  S = [rng.randint(0, 50, size=(N, W)).astype(np.int32) for _ in range(W)]   # per rank
+  R = [np.stack([S[q][:, r] for q in range(W)]).astype(np.int32) for r in range(W)]
+  lays = [product_layout(dims, S[r], R[r]) for r in range(W)]
+  for a in range(W):
+    for b in range(W):
+      assert lays[a]['ids_send_peer'][b] == lays[b]['ids_recv_peer'][a]
+      assert lays[a]['rows_recv_peer'][b] == lays[b]['rows_send_peer'][a]
+    L = lays[a]
+    run = 0
+    for q in range(W):
+      for c in range(N):
+        assert L['req_id_off'][q][c] == run
+        run += S[a][c][q]
+    assert run == L['ids_send_peer'].sum()
+    frun = 0
+    for q in range(W):
+      for c in range(N):
+        assert L['own_row_off'][q][c] == frun
+        frun += R[a][q][c] * dims[c]
+    assert frun == L['rows_send_peer'].sum()
+    for c in range(N):
+      assert L['col_shard_off'][c].tolist() == np.concatenate([[0], np.cumsum(S[a][c])[:-1]]).tolist()
 
 
 def test_offsets_and_active_ranks_match_oracle():

@@ -335,11 +335,12 @@ def test_group_lookup_backward(combiner):
     _check_slices(res[c], ids[c] % buckets[c], grads[c], splits[c], combiner)
 
 
-def test_group_lookup_backward_table_overflow_path(monkeypatch):
-  # force 4-slot LDS tables: every bucket overflows and re-runs its rejected pairs
-  monkeypatch.setenv('HBK_BWD_SLOTS_LOG2', '2')
+def test_group_lookup_backward_multi_chunk_and_table_clear_path(monkeypatch):
+  # one bucket per column: many 512-pair chunks per workgroup, rows spanning chunks are
+  # accumulated into their output row, and > 768 distinct rows force table clears
+  monkeypatch.setenv('HBK_BWD_LOG2P', '0')
   rng = np.random.RandomState(21)
-  for d, rows, n in ((16, 97, 5000), (128, 1000, 3000), (6, 10, 2000)):
+  for d, rows, n in ((16, 97, 5000), (128, 3000, 9000), (6, 10, 2000), (32, 100000, 4000)):
     table = rng.uniform(-1, 1, size=(rows, d)).astype(np.float32)
     ids = rng.randint(0, 2**40, size=n).astype(np.int64)
     grads = rng.randn(n, d).astype(np.float32)

@@ -180,11 +180,91 @@ def test_sharded_backward_through_rccl_world1_with_apply():
     g = rng.randn(5000, 16).astype(np.float32)
     t_dev = dev(table.copy())
     drv = ShardedGroupLookup([t_dev], coll, buckets=[3000])
-    outs, st = drv([dev(ids)], keep=True)
-    drv.backward(st, [dev(g)], apply_lr=0.1)
+    drv([dev(ids)])
+    drv.backward([dev(g)], apply_lr=0.1)
     torch.cuda.synchronize()
     ref = table.astype(np.float64)
     np.subtract.at(ref, ids % 3000, 0.1 * g.astype(np.float64))
     np.testing.assert_allclose(t_dev.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
   finally:
     coll.close()
+
+
+@pytest.mark.parametrize('world,wire16', [(2, False), (4, True), (8, False)])
+def test_cxx_driver_multi_rank_in_process_world(world, wire16):
+  """hbk_sharded_lookup_fwd/_bwd (the code that runs at 8 GPUs) with W ranks as host threads
+  of one process on one GPU; only the transport differs from production (device copies
+  instead of RCCL).  Forward == unsharded oracle lookup, backward == dense scatter-add."""
+  import threading
+  rng = np.random.RandomState(300 + world)
+  dims, rows = [16, 8, 128, 4], [50021, 211, 3000, 64]
+  combiners = ['sum', 'mean', 'sqrtn', 'sum']
+  n = len(dims)
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(n)]
+  ids, splits, grads = [], [], []
+  for r in range(world):
+    rid, rsp, rg = [], [], []
+    for c in range(n):
+      if c % 2 == 0:
+        sp, k = None, int(rng.randint(0, 3000))
+      else:
+        lens = rng.poisson(3, size=rng.randint(1, 400)).clip(0, 12)
+        sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        k = int(sp[-1])
+      rsp.append(sp)
+      rid.append(rng.randint(0, 2**40, size=k).astype(np.int64))
+      rg.append(rng.randn(k if sp is None else sp.size - 1, dims[c]).astype(np.float32))
+    ids.append(rid)
+    splits.append(rsp)
+    grads.append(rg)
+  comms = hb.distribute.Collective.local_world(world)
+  shards = [[dev(t[r::world].copy()) for t in tables] for r in range(world)]
+  results, errors = [None] * world, []
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        drv = ShardedGroupLookup(shards[r], comms[r], buckets=rows, combiners=combiners,
+                                 wire_dtype=torch.float16 if wire16 else None)
+        for _ in range(2):   # second step reuses the grown buffers
+          outs = drv([dev(i) for i in ids[r]], [None if s is None else dev(s) for s in splits[r]])
+          slices = drv.backward([dev(g) for g in grads[r]], apply_lr=0.0)
+        torch.cuda.current_stream().synchronize()
+        results[r] = ([o.cpu().numpy() for o in outs],
+                      [(u.cpu().numpy()[:int(k.item())], g.cpu().numpy()[:int(k.item())])
+                       for u, g, k in slices])
+        drv.close()
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((r, repr(e)))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=120)
+  assert not errors, errors
+  assert all(x is not None for x in results)
+  eff = tables
+  tol = dict(rtol=1e-5, atol=1e-5)
+  if wire16:
+    eff = [oracle.cast_f16_to_f32(oracle.cast_f32_to_f16(t)) for t in tables]
+    tol = dict(rtol=2e-3, atol=2e-3)      # gradients travel as fp16 too
+  for r in range(world):
+    want = oracle.group_lookup_fwd(eff, ids[r], splits[r], rows, combiners)
+    for c in range(n):
+      np.testing.assert_equal(results[r][0][c], want[c])
+  for c in range(n):
+    dense = np.zeros((rows[c], dims[c]), np.float64)
+    for r in range(world):
+      sp = splits[r][c] if splits[r][c] is not None else np.arange(ids[r][c].size + 1,
+                                                                   dtype=np.int32)
+      g_id = oracle.segment_combine_grad(grads[r][c], sp, combiners[c]).astype(np.float64)
+      np.add.at(dense, ids[r][c] % rows[c], g_id)
+    got = np.zeros_like(dense)
+    for r in range(world):
+      lr_, g_ = results[r][1][c]
+      assert len(set(lr_.tolist())) == len(lr_)
+      got[lr_ * world + r] += g_
+    np.testing.assert_allclose(got, dense, **tol)
+  for cm in comms:
+    cm.close()

@@ -184,6 +184,29 @@ def case_bwd_probe():
     report(f'bwd probe dim128 {name}', us, 26 * B, 26 * B * (8 + 512 + 512))
 
 
+def case_sharded_world1():
+  """The whole sharded pipeline (partition -> RCCL alltoallv -> owner gather -> alltoallv ->
+  stitch) on one GPU with a world-size-1 communicator: kernel chain + host overhead per step."""
+  import time
+  tables = uniform_tables(26, 1000000, 16)
+  B, nb = 65536, 8
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+  drv = hb.embedding.ShardedGroupLookup(tables, coll, buckets=[1000000] * 26)
+  batches = [[torch.randint(0, 1 << 40, (B,), device=DEV) for _ in range(26)] for _ in range(nb)]
+  for wire in (None, torch.float16):
+    drv.wire_dtype = wire
+    us = timed(lambda i: drv(batches[i % nb]), iters=20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(20):
+      drv(batches[i % nb])
+    host_us = (time.perf_counter() - t0) / 20 * 1e6
+    torch.cuda.synchronize()
+    report(f'sharded pipeline W=1 fwd dim16 B={B} wire={"fp16" if wire else "fp32"}', us, 26 * B,
+           26 * B * 136, host_enqueue_us=round(host_us, 1))
+  coll.close()
+
+
 if __name__ == '__main__':
   ap = argparse.ArgumentParser()
   ap.add_argument('--cases', default='a,b,c,d,e')
@@ -192,5 +215,5 @@ if __name__ == '__main__':
   torch.manual_seed(0)
   for c in args.cases.split(','):
     {'a': case_batch_sweep, 'b': case_ragged, 'c': case_backward_cfg2,
-     'd': lambda: case_cfg4(args.big), 'e': case_integer, 'f': case_bwd_probe}[c]()
+     'd': lambda: case_cfg4(args.big), 'e': case_integer, 'f': case_bwd_probe, 'g': case_sharded_world1}[c]()
     torch.cuda.empty_cache()

@@ -44,6 +44,8 @@ def parse_args():
                  help='N > 1: wire dtype of the embedding exchange (comm_wire_dtype)')
   p.add_argument('--cpu-seconds', type=float, default=12.0,
                  help='budget of the host-CPU baseline (0 disables it)')
+  p.add_argument('--sharded', action='store_true',
+                 help='run the sharded pipeline even at N = 1 (validation of the N > 1 code path)')
   p.add_argument('--id-batches', type=int, default=0,
                  help='distinct id batches kept in HBM (default: steps + warmup, max 64)')
   return p.parse_args()
@@ -144,7 +146,8 @@ def main():
   from hybridbackend_amd import _lib
   _lib.lib()
 
-  if world > 1:
+  use_dist = world > 1 or ('RANK' in os.environ and args.sharded)
+  if use_dist:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     dist.init_process_group('nccl', device_id=device)
@@ -155,7 +158,7 @@ def main():
   batches = make_id_batches(args, device, rank, n_batches)
   lookups_per_step_per_rank = args.columns * args.batch
 
-  if world == 1:
+  if world == 1 and not args.sharded:
     # one pre-bound descriptor set per id batch: a step is a single C-ABI call
     outs = [torch.empty(args.batch, args.dim, device=device) for _ in range(args.columns)]
     plans = []
@@ -182,7 +185,7 @@ def main():
     parallelism = f'row-sharded id-mod-{world} (alltoallv ids + rows over RCCL/xGMI)'
 
   def barrier():
-    if world > 1:
+    if use_dist:
       import torch.distributed as dist
       dist.barrier()
 
@@ -204,7 +207,7 @@ def main():
   elapsed = time.perf_counter() - t0
   gpu_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream)
 
-  if world > 1:
+  if use_dist:
     import torch.distributed as dist
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,22 +236,25 @@ def main():
                  'id_batches_resident': n_batches},
       'roofline': {
         'bound': 'hbm',
-        'kernel': 'group_lookup_fwd_kernel' if world == 1 else 'sharded step (all kernels)',
+        'kernel': ('group_lookup_fwd_kernel' if world == 1 and not args.sharded
+                   else 'sharded step (all kernels + exchanges)'),
         'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4),
         'traffic': load_traffic(key),
         'algorithmic_bytes_per_lookup': bytes_per_lookup,
         'avg_launch_us': round(launch_s * 1e6, 3)},
     }
-    if world == 1 and args.cpu_seconds > 0:
+    if world == 1 and not args.sharded and args.cpu_seconds > 0:
       result['cpu_baseline'] = cpu_baseline(args, tables, batches[0], args.cpu_seconds)
     else:
       result['cpu_baseline'] = None
     print(json.dumps(result), flush=True)
 
-  if world > 1:
-    import torch.distributed as dist
+  if world > 1 or args.sharded:
+    sharded.close()
     coll.close()
+  if use_dist:
+    import torch.distributed as dist
     dist.destroy_process_group()
 
 

@@ -35,7 +35,9 @@ class LookupColumn(C.Structure):
               ('ids_dtype', C.c_int32), ('ids', C.c_void_p), ('n_ids', C.c_int64),
               ('row_splits', C.c_void_p), ('n_segments', C.c_int64),
               ('bucket', C.c_int64), ('divisor', C.c_int32),
-              ('combiner', C.c_int32), ('out', C.c_void_p)]
+              ('combiner', C.c_int32), ('out', C.c_void_p),
+              ('run_start', C.c_void_p), ('run_base', C.c_void_p),
+              ('n_runs', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class LookupGradColumn(C.Structure):

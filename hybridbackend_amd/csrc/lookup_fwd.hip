@@ -41,15 +41,25 @@ struct ColArg {
   uint8_t ids64;
   uint8_t combiner;
   uint8_t vec4;     // 1: 16-byte chunks, 0: 4-byte chunks (dim % 4 != 0 or unaligned)
-  uint32_t pad_;
+  int32_t n_runs;   // > 0: segmented table (see hbk_lookup_column_t)
+  const int64_t* run_start;
+  const int64_t* run_base;
 };
+
+// float offset of logical row r inside the table
+__device__ inline uint64_t row_offset(const ColArg& c, uint64_t r) {
+  if (c.n_runs == 0) return r * (uint64_t)c.dim;
+  int k = 0;
+  while (k + 1 < c.n_runs && (uint64_t)c.run_start[k + 1] <= r) ++k;
+  return (uint64_t)c.run_base[k] + (r - (uint64_t)c.run_start[k]) * (uint64_t)c.dim;
+}
 
 struct LookupArgs {
   int32_t n_cols;
   int32_t tile_start[kMaxColsPerLaunch + 1];
   ColArg col[kMaxColsPerLaunch];
 };
-static_assert(sizeof(LookupArgs) <= 16384, "kernarg budget");
+static_assert(sizeof(LookupArgs) <= 24576, "kernarg budget");
 
 // ---------------------------------------------------------------------------------
 // one id per segment (Criteo scalar columns): out[s,:] = table[row(ids[s]),:]
@@ -87,7 +97,7 @@ __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
     const uint64_t r = shfl_u64(src, (q0 & (kWave - 1)) + grp);
     v[u] = zero_v<V>();
     if (live && r != kNoRow) {
-      v[u] = *reinterpret_cast<const V*>(c.table + r * (uint64_t)dim + (uint64_t)sub * VE);
+      v[u] = *reinterpret_cast<const V*>(c.table + row_offset(c, r) + (uint64_t)sub * VE);
     }
   }
 #pragma unroll
@@ -144,7 +154,7 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
           p[t] = tt < lpr && tt < cnt;
           v[t] = zero_v<V>();
           if (p[t] && live && r != kNoRow) {
-            v[t] = *reinterpret_cast<const V*>(c.table + r * (uint64_t)dim + (uint64_t)sub * VE);
+            v[t] = *reinterpret_cast<const V*>(c.table + row_offset(c, r) + (uint64_t)sub * VE);
           }
         }
 #pragma unroll
@@ -231,6 +241,8 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
     HBK_REQUIRE(h.n_segments == 0 ||
                     ((h.table || h.rows == 0) && h.out && (h.ids || h.n_ids == 0)),
                 "group_lookup_fwd: column %d: NULL buffer", c);
+    HBK_REQUIRE(h.n_runs >= 0 && (h.n_runs == 0 || (h.run_start && h.run_base)),
+                "group_lookup_fwd: column %d: bad segmented-table description", c);
     HBK_REQUIRE(h.n_ids < (1ll << 31) && h.n_segments < (1ll << 31),
                 "group_lookup_fwd: column %d: more than 2^31-1 ids/segments", c);
   }
@@ -261,7 +273,9 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
       d.lpr_log2 = shape.lpr_log2;
       d.ids64 = h.ids_dtype == HBK_INT64;
       d.combiner = (uint8_t)h.combiner;
-      d.pad_ = 0;
+      d.n_runs = h.n_runs;
+      d.run_start = h.run_start;
+      d.run_base = h.run_base;
       const int64_t rpi = kWave >> d.lpr_log2;
       const int64_t per_block =
           kWavesPerBlock * rpi * (h.row_splits ? kSegIters : kU);

@@ -38,6 +38,10 @@ struct PartCol {
   int32_t* indices;
   int32_t len;
   int32_t tile_start;  // first tile of this column inside the launch group
+  FastDiv bucket;      // d > 0: ids are bucketized (R1, floor-mod) on the fly; outputs hold the
+                       // bucketized ids (the sharded driver fuses `% embedding_size` here)
+  int32_t global_col;  // column index inside the whole call (for sizes_t)
+  int32_t pad_;
 };
 
 struct ShardFn {
@@ -52,10 +56,23 @@ struct PartArgs {
   int32_t n_cols;
   int32_t total_tiles;
   int32_t* hist;  // [sum over columns of P * tiles_c]; column c starts at P * tile_start[c]
+  int32_t* sizes_t;      // optional [P][n_total_cols] transposed copy of the sizes
+  int32_t n_total_cols;
+  int32_t pad_;
   ShardFn fn;
   PartCol col[kMaxColsPerLaunch];
 };
 static_assert(sizeof(PartArgs) <= 16384, "kernarg budget");
+
+template <typename T>
+__device__ inline T bucketize(T v, const FastDiv& b) {
+  if (b.d == 0) return v;
+  if constexpr (std::is_signed<T>::value) {
+    return (T)floormod_i64((int64_t)v, b);
+  } else {
+    return (T)fastmod((uint64_t)v, b);
+  }
+}
 
 template <typename T>
 __device__ inline uint32_t shard_of(T v, const ShardFn& f) {
@@ -107,7 +124,7 @@ __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a)
 #pragma unroll
   for (int k = 0; k < kChunks; ++k) {
     const int64_t i = base + k * kWave + lane;
-    if (i < c.len) atomicAdd(&counters[shard_of<T>(v[k], a.fn)], 1);
+    if (i < c.len) atomicAdd(&counters[shard_of<T>(bucketize<T>(v[k], c.bucket), a.fn)], 1);
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   int32_t* hist = a.hist + (int64_t)P * c.tile_start;
@@ -170,7 +187,10 @@ __global__ __launch_bounds__(kScanBlock) void partition_scan_kernel(const PartAr
       cnt = nx - st;
     }
     __syncthreads();
-    if (p < P) c.sizes[p] = cnt;
+    if (p < P) {
+      c.sizes[p] = cnt;
+      if (a.sizes_t != nullptr) a.sizes_t[(int64_t)p * a.n_total_cols + c.global_col] = cnt;
+    }
     __syncthreads();
   }
 }
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
 #pragma unroll
   for (int k = 0; k < kChunks; ++k) {
     const int64_t i = base + k * kWave + lane;
-    v[k] = i < c.len ? in[i] : T(0);
+    v[k] = i < c.len ? bucketize<T>(in[i], c.bucket) : T(0);
   }
   if (P <= kWave) {
     // small P (the W <= 8 case): lane p keeps the running counter of shard p in a register;
@@ -275,7 +295,8 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
                    int32_t modulus, int32_t stage, const void* const* inputs,
                    const int64_t* lens, void* const* outputs, int32_t* const* sizes,
                    int32_t* const* indices, void* workspace, size_t workspace_bytes,
-                   hipStream_t stream) {
+                   hipStream_t stream, const int64_t* buckets = nullptr,
+                   int32_t* sizes_t = nullptr) {
   HBK_REQUIRE(n_cols >= 0, "%s: n_cols must be >= 0", what);
   HBK_REQUIRE(P >= 1, "%s: num_partitions must be >= 1, got %d", what, P);
   HBK_REQUIRE(P <= kMaxPartitions, "%s: num_partitions %d > %d unsupported", what, P,
@@ -316,6 +337,9 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
     PartArgs args;
     args.fn = fn;
     args.hist = hist;
+    args.sizes_t = sizes_t;
+    args.n_total_cols = n_cols;
+    args.pad_ = 0;
     int32_t k = 0;
     int64_t tiles = 0;
     while (c0 < n_cols && k < kMaxColsPerLaunch) {
@@ -325,6 +349,10 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
       d.sizes = sizes[c0];
       d.indices = indices[c0];
       d.len = (int32_t)lens[c0];
+      d.bucket = make_fastdiv(buckets ? (uint64_t)buckets[c0] : 0);
+      d.bucket.d = buckets ? (uint64_t)buckets[c0] : 0;
+      d.global_col = c0;
+      d.pad_ = 0;
       d.tile_start = (int32_t)tiles;
       tiles += tiles_of(lens[c0]);
       HBK_REQUIRE(tiles < (1ll << 31), "%s: too many tiles", what);
@@ -347,6 +375,25 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
 }
 
 }  // namespace
+
+// internal entry (sharded.hip): partition by modulo with the bucketize fused in and a second,
+// transposed copy of the sizes ([P][n_cols]: the send layout of the size exchange)
+int partition_by_modulo_fused(int32_t n_cols, int32_t num_partitions, const int64_t* const* inputs,
+                              const int64_t* lens, const int64_t* buckets,
+                              int64_t* const* outputs, int32_t* const* sizes,
+                              int32_t* const* indices, int32_t* sizes_t, void* workspace,
+                              size_t workspace_bytes, hipStream_t stream) {
+  if (buckets != nullptr) {
+    for (int32_t c = 0; c < n_cols; ++c) {
+      if (buckets[c] < 0) return fail(HBK_INVALID_ARGUMENT, "partition: bucket must be >= 0");
+    }
+  }
+  return partition_impl("partition_by_modulo_fused", n_cols, HBK_INT64, num_partitions, 1, 0,
+                        reinterpret_cast<const void* const*>(inputs), lens,
+                        reinterpret_cast<void* const*>(outputs), sizes, indices, workspace,
+                        workspace_bytes, stream, buckets, sizes_t);
+}
+
 }  // namespace hbk
 
 extern "C" size_t hbk_partition_workspace_bytes(int32_t n_cols, const int64_t* lens,

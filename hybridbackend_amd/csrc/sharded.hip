@@ -26,6 +26,11 @@
 #include "common.h"
 
 namespace hbk {
+int partition_by_modulo_fused(int32_t n_cols, int32_t num_partitions, const int64_t* const* inputs,
+                              const int64_t* lens, const int64_t* buckets,
+                              int64_t* const* outputs, int32_t* const* sizes,
+                              int32_t* const* indices, int32_t* sizes_t, void* workspace,
+                              size_t workspace_bytes, hipStream_t stream);
 namespace {
 
 constexpr int kBlock = 256;
@@ -150,6 +155,9 @@ extern "C" int hbk_sharded_layout(int32_t n_cols, int32_t world, const int32_t* 
   using namespace hbk;
   HBK_REQUIRE(n_cols >= 1 && world >= 1 && dims && S && R, "sharded_layout: bad argument");
   const int N = n_cols, W = world;
+  // every run of rows starts on a 16-byte boundary whatever the mix of dims (<= 3 floats of
+  // padding per run), so rows can always be moved as 16-byte chunks in place
+  auto pad4 = [](int64_t floats) { return (floats + 3) & ~(int64_t)3; };
   int64_t rid = 0, rrow = 0, oid = 0, orow = 0;
   for (int q = 0; q < W; ++q) {
     int64_t si = 0, ri = 0, sf = 0, rf = 0;
@@ -161,13 +169,13 @@ extern "C" int hbk_sharded_layout(int32_t n_cols, int32_t world, const int32_t* 
       if (own_id_off) own_id_off[(size_t)q * N + c] = oid;
       if (own_row_off) own_row_off[(size_t)q * N + c] = orow;
       rid += s;
-      rrow += s * dims[c];
+      rrow += pad4(s * dims[c]);
       oid += r;
-      orow += r * dims[c];
+      orow += pad4(r * dims[c]);
       si += s;
       ri += r;
-      rf += s * dims[c];   // floats this rank gets back from owner q
-      sf += r * dims[c];   // floats this rank sends to requester q
+      rf += pad4(s * dims[c]);   // floats this rank gets back from owner q
+      sf += pad4(r * dims[c]);   // floats this rank sends to requester q
     }
     HBK_REQUIRE(sf < (1ll << 31) && rf < (1ll << 31),
                 "sharded_layout: more than 2^31 floats for one peer");
@@ -241,8 +249,9 @@ struct hbk_sharded {
   bool have_step;
   // device buffers owned by the plan
   hbk::Buffer ids_bucketized, part_out, shard_index, sizes_dev, part_ws, send_ids, recv_ids,
-      send_rows, recv_rows, rows_unpacked, wire_ws, ids_unpacked, bwd_ws;
+      send_rows, recv_rows, rows_unpacked, wire_ws, ids_unpacked, bwd_ws, runs_dev;
   int32_t* host_sizes;  // pinned [2][N*W]
+  int64_t* host_runs;   // pinned [2][N*W]: run starts / bases of the stitch, column-major
 };
 
 extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t n_cols,
@@ -269,9 +278,13 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
   p->cols.assign(cols, cols + n_cols);
   p->have_step = false;
   p->host_sizes = nullptr;
+  p->host_runs = nullptr;
   if (hipHostMalloc(reinterpret_cast<void**>(&p->host_sizes),
                     sizeof(int32_t) * 2 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
-      hipSuccess) {
+          hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&p->host_runs),
+                    sizeof(int64_t) * 2 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
+          hipSuccess) {
     delete p;
     return fail(HBK_INTERNAL, "sharded_create: hipHostMalloc failed");
   }
@@ -283,10 +296,12 @@ extern "C" int hbk_sharded_destroy(hbk_sharded_t p) {
   if (p == nullptr) return HBK_OK;
   for (hbk::Buffer* b : {&p->ids_bucketized, &p->part_out, &p->shard_index, &p->sizes_dev,
                          &p->part_ws, &p->send_ids, &p->recv_ids, &p->send_rows, &p->recv_rows,
-                         &p->rows_unpacked, &p->wire_ws, &p->ids_unpacked, &p->bwd_ws}) {
+                         &p->rows_unpacked, &p->wire_ws, &p->ids_unpacked, &p->bwd_ws,
+                         &p->runs_dev}) {
     b->release();
   }
   if (p->host_sizes) (void)hipHostFree(p->host_sizes);
+  if (p->host_runs) (void)hipHostFree(p->host_runs);
   delete p;
   return HBK_OK;
 }
@@ -345,51 +360,32 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     total += n_ids[c];
   }
   int rc;
-  // ---- 1 bucketize + stable partition ------------------------------------------------------
-  if ((rc = p->ids_bucketized.ensure((size_t)total * 8 + 8)) != HBK_OK) return rc;
+  // ---- 1 bucketize + stable partition (one kernel chain; S and S^T come out of the scan) ------
   if ((rc = p->part_out.ensure((size_t)total * 8 + 8)) != HBK_OK) return rc;
   if ((rc = p->shard_index.ensure((size_t)total * 4 + 8)) != HBK_OK) return rc;
   if ((rc = p->sizes_dev.ensure((size_t)N * W * 4 * 3)) != HBK_OK) return rc;
-  std::vector<void*> pout(N);
+  std::vector<int64_t*> pout(N);
   std::vector<int32_t*> sizes(N), idx(N);
   int32_t* sizes_dev = reinterpret_cast<int32_t*>(p->sizes_dev.ptr);       // S [N][W]
   int32_t* sizes_t = sizes_dev + (size_t)N * W;                            // S^T [W][N]
   int32_t* recv_t = sizes_t + (size_t)N * W;                               // R [W][N]
   {
-    std::vector<const void*> part_in(N), fin;
-    std::vector<void*> fout;
-    std::vector<int64_t> flen, fb;
+    std::vector<int64_t> buckets(N);
     int64_t off = 0;
     for (int c = 0; c < N; ++c) {
       pout[c] = reinterpret_cast<int64_t*>(p->part_out.ptr) + off;
       idx[c] = reinterpret_cast<int32_t*>(p->shard_index.ptr) + off;
       sizes[c] = sizes_dev + (size_t)c * W;
-      part_in[c] = ids[c];
-      if (p->cols[c].bucket > 0) {
-        void* b = reinterpret_cast<int64_t*>(p->ids_bucketized.ptr) + off;
-        fin.push_back(ids[c]);
-        fout.push_back(b);
-        flen.push_back(n_ids[c]);
-        fb.push_back(p->cols[c].bucket);
-        part_in[c] = b;
-      }
+      buckets[c] = p->cols[c].bucket;
       off += n_ids[c];
-    }
-    if (!fin.empty()) {
-      rc = hbk_floormod_n((int32_t)fin.size(), HBK_INT64, fin.data(), flen.data(), fb.data(),
-                          fout.data(), stream_);
-      if (rc != HBK_OK) return rc;
     }
     const size_t ws = hbk_partition_workspace_bytes(N, n_ids, W);
     if ((rc = p->part_ws.ensure(ws + 8)) != HBK_OK) return rc;
-    rc = hbk_partition_by_modulo_n(N, HBK_INT64, W, part_in.data(), n_ids, pout.data(),
-                                   sizes.data(), idx.data(), p->part_ws.ptr, p->part_ws.bytes,
-                                   stream_);
+    rc = partition_by_modulo_fused(N, W, ids, n_ids, buckets.data(), pout.data(), sizes.data(),
+                                   idx.data(), sizes_t, p->part_ws.ptr, p->part_ws.bytes, stream);
     if (rc != HBK_OK) return rc;
   }
   // ---- 2 one size exchange for all columns, one host sync -----------------------------------
-  hipLaunchKernelGGL(transpose_sizes_kernel, dim3((N * W + 255) / 256), dim3(256), 0, stream,
-                     sizes_dev, sizes_t, N, W);
   {
     const void* sin[1] = {sizes_t};
     void* sout[1] = {recv_t};
@@ -458,32 +454,27 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   rc = exchange(p, HBK_FLOAT, p->wire_dtype, p->send_rows.ptr, L.rows_send_peer.data(),
                 p->recv_rows.ptr, L.rows_recv_peer.data(), stream_);
   if (rc != HBK_OK) return rc;
-  // ---- 6 unpack column-major, stitch + combiner ------------------------------------------------
-  if ((rc = p->rows_unpacked.ensure((size_t)L.req_floats * 4 + 16)) != HBK_OK) return rc;
+  // ---- 6 stitch + combiner -----------------------------------------------------------------------
   {
-    std::vector<Seg> segs;
-    std::vector<int64_t> col_base(N);
-    int64_t b = 0;
+    // the received rows stay peer-major; column c is a W-run segmented table over them
+    if ((rc = p->runs_dev.ensure(sizeof(int64_t) * 2 * (size_t)N * W)) != HBK_OK) return rc;
+    int64_t* h_start = p->host_runs;
+    int64_t* h_base = p->host_runs + (size_t)N * W;
     for (int c = 0; c < N; ++c) {
-      col_base[c] = b;
-      b += n_ids[c] * p->cols[c].dim;
-    }
-    for (int q = 0; q < W; ++q) {
-      for (int c = 0; c < N; ++c) {
-        const int64_t d = p->cols[c].dim;
-        segs.push_back(make_seg(
-            reinterpret_cast<const float*>(p->recv_rows.ptr) + L.req_row_off[(size_t)q * N + c],
-            reinterpret_cast<float*>(p->rows_unpacked.ptr) + col_base[c] +
-                L.col_shard_off[(size_t)c * W + q] * d,
-            (int64_t)S[(size_t)c * W + q] * d * 4));
+      for (int q = 0; q < W; ++q) {
+        h_start[(size_t)c * W + q] = L.col_shard_off[(size_t)c * W + q];
+        h_base[(size_t)c * W + q] = L.req_row_off[(size_t)q * N + c];
       }
     }
-    if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
+    HBK_HIP_OK(hipMemcpyAsync(p->runs_dev.ptr, p->host_runs, sizeof(int64_t) * 2 * (size_t)N * W,
+                              hipMemcpyHostToDevice, stream));
+    const int64_t* d_start = reinterpret_cast<const int64_t*>(p->runs_dev.ptr);
+    const int64_t* d_base = d_start + (size_t)N * W;
     std::vector<hbk_lookup_column_t> v(N);
     for (int c = 0; c < N; ++c) {
       hbk_lookup_column_t& h = v[c];
       memset(&h, 0, sizeof(h));
-      h.table = reinterpret_cast<const float*>(p->rows_unpacked.ptr) + col_base[c];
+      h.table = reinterpret_cast<const float*>(p->recv_rows.ptr);
       h.rows = n_ids[c];
       h.dim = p->cols[c].dim;
       h.ids_dtype = HBK_INT32;
@@ -494,6 +485,9 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
       h.divisor = 1;
       h.combiner = p->cols[c].combiner;
       h.out = outs[c];
+      h.run_start = d_start + (size_t)c * W;
+      h.run_base = d_base + (size_t)c * W;
+      h.n_runs = W;
     }
     rc = hbk_group_lookup_fwd(N, v.data(), stream_);
     if (rc != HBK_OK) return rc;
@@ -518,7 +512,9 @@ extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads
   const Layout& L = p->lay;
   int rc;
   // ---- B1 d(stitch + combiner) into column-major rows ------------------------------------------
-  if ((rc = p->rows_unpacked.ensure((size_t)L.req_floats * 4 + 16)) != HBK_OK) return rc;
+  if ((rc = p->rows_unpacked.ensure(((size_t)L.req_floats + 4 * (size_t)N) * 4 + 16)) != HBK_OK) {
+    return rc;
+  }
   std::vector<int64_t> col_base(N);
   {
     std::vector<hbk_stitch_grad_column_t> v(N);
@@ -534,7 +530,7 @@ extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads
       h.n_segments = p->n_seg[c];
       h.grad_out = grads[c];
       h.grad_rows = reinterpret_cast<float*>(p->rows_unpacked.ptr) + b;
-      b += p->n_ids[c] * p->cols[c].dim;
+      b += (p->n_ids[c] * p->cols[c].dim + 3) & ~(int64_t)3;
       ioff += p->n_ids[c];
     }
     rc = hbk_group_stitch_bwd(N, v.data(), stream_);
@@ -562,7 +558,9 @@ extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads
   if (rc != HBK_OK) return rc;
   // ---- B3 owner side: column-major ids + grads, then duplicate-row reduction (+ SGD) ---------
   if ((rc = p->ids_unpacked.ensure((size_t)L.own_ids * 8 + 8)) != HBK_OK) return rc;
-  if ((rc = p->rows_unpacked.ensure((size_t)L.own_floats * 4 + 16)) != HBK_OK) return rc;
+  if ((rc = p->rows_unpacked.ensure(((size_t)L.own_floats + 4 * (size_t)N) * 4 + 16)) != HBK_OK) {
+    return rc;
+  }
   {
     std::vector<int64_t> n_own(N, 0), id_base(N), f_base(N);
     for (int c = 0; c < N; ++c) {
@@ -573,7 +571,7 @@ extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads
       id_base[c] = ib;
       f_base[c] = fb;
       ib += n_own[c];
-      fb += n_own[c] * p->cols[c].dim;
+      fb += (n_own[c] * p->cols[c].dim + 3) & ~(int64_t)3;
     }
     std::vector<Seg> segs;
     std::vector<int64_t> ioff(N, 0);

@@ -157,6 +157,13 @@ typedef struct {
   int32_t divisor;           /* >= 1 */
   int32_t combiner;          /* HBK_COMBINER_* */
   float* out;                /* device [n_segments, dim] */
+  /* optional segmented table (n_runs > 0): logical rows [run_start[k], run_start[k+1]) live
+   * at table + run_base[k] floats (run_start[0] = 0).  Lets the stitch of the sharded
+   * pipeline read the peer-major exchange buffer in place.  Device arrays [n_runs]. */
+  const int64_t* run_start;
+  const int64_t* run_base;
+  int32_t n_runs;
+  int32_t reserved_;
 } hbk_lookup_column_t;
 
 int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,

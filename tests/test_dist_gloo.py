@@ -175,7 +175,8 @@ def test_layout_is_consistent_between_ranks():
   sys.path.insert(0, ROOT)
   rng = np.random.RandomState(5)
   W, N = 4, 5
-  dims = [4, 16, 128, 8, 36]
+  dims = [4, 16, 6, 8, 36]       # 6: runs are padded to 16 bytes
+  pad4 = lambda x: (x + 3) // 4 * 4   # noqa: E731
   S = [rng.randint(0, 50, size=(N, W)).astype(np.int32) for _ in range(W)]   # per rank
   R = [np.stack([S[q][:, r] for q in range(W)]).astype(np.int32) for r in range(W)]
   lays = [product_layout(dims, S[r], R[r]) for r in range(W)]
@@ -194,7 +195,7 @@ def test_layout_is_consistent_between_ranks():
     for q in range(W):
       for c in range(N):
         assert L['own_row_off'][q][c] == frun
-        frun += R[a][q][c] * dims[c]
+        frun += pad4(R[a][q][c] * dims[c])
     assert frun == L['rows_send_peer'].sum()
     for c in range(N):
       assert L['col_shard_off'][c].tolist() == np.concatenate([[0], np.cumsum(S[a][c])[:-1]]).tolist()

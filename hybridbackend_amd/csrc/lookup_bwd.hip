@@ -48,6 +48,9 @@
 #ifndef HBK_BWD_WAVES
 #define HBK_BWD_WAVES 4
 #endif
+#ifndef HBK_BWD_UH
+#define HBK_BWD_UH 8
+#endif
 
 namespace hbk {
 namespace {
@@ -65,6 +68,9 @@ constexpr int kSlots = 2 * kCP;       // LDS hash-table slots
 constexpr int kClearAbove = kSlots * 3 / 4 - kCP;  // clear the table before a chunk beyond this
 constexpr int kUA = HBK_BWD_UA;       // slots a lane group reduces concurrently (rows in flight)
 constexpr int kHeavy = 64;            // pairs of one row in a chunk that make it a "hot row"
+constexpr int kHotTries = 4;           // ballot rounds that look for a hot row inside a wave
+constexpr int kHotMin = 8;             // lanes sharing a row that make the wave reduce it first
+constexpr int kUH = HBK_BWD_UH;       // rows in flight per lane group while summing a hot row
 constexpr unsigned long long kEmptyKey = ~0ull;
 
 struct GCol {
@@ -333,22 +339,53 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
     if (tid == 0) L.n_heavy = 0;
     __syncthreads();
 
-    // (a) distinct rows of the chunk -> slots, pairs per slot
+    // (a) distinct rows of the chunk -> slots, pairs per slot.  Same-address LDS atomics
+    // serialise, so a hot row is first reduced inside the wave: up to kHotTries times the first
+    // pending lane's row is matched with a ballot; a group of >= kHotMin lanes lets its leader
+    // probe once and add the whole count, the other lanes take the slot by broadcast.
 #pragma unroll
     for (int k = 0; k < kCP / kBlock; ++k) {
       const int e = k * kBlock + tid;
-      if (e < n_chunk) {
-        const unsigned long long row = (unsigned long long)prow[cb + e];
+      const bool valid = e < n_chunk;
+      unsigned long long row = 0;
+      if (valid) {
+        row = (unsigned long long)prow[cb + e];
         L.segs[e] = pseg[cb + e];
-        int h = (int)(mix64(row) & (kSlots - 1));
+      }
+      int h = -1;
+      unsigned long long todo = __ballot(valid);
+      for (int t = 0; t < kHotTries && todo != 0ull; ++t) {
+        const int leader = __builtin_ctzll(todo);
+        const unsigned long long r =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(row >> 32), leader) << 32) |
+            (unsigned)__builtin_amdgcn_readlane((int)row, leader);
+        const unsigned long long same = __ballot(valid && row == r) & todo;
+        todo &= ~same;
+        const int n_same = (int)__builtin_popcountll(same);
+        if (n_same < kHotMin) continue;  // wave-uniform
+        int hs = 0;
+        if (lane == leader) {
+          hs = (int)(mix64(r) & (kSlots - 1));
+          for (;;) {
+            const unsigned long long prev = atomicCAS(&L.keys[hs], kEmptyKey, r);
+            if (prev == kEmptyKey || prev == r) break;
+            hs = (hs + 1) & (kSlots - 1);
+          }
+          atomicAdd(&L.cnt[hs], n_same);
+        }
+        hs = __builtin_amdgcn_readlane(hs, leader);
+        if ((same >> lane) & 1ull) h = hs;
+      }
+      if (valid && h < 0) {
+        h = (int)(mix64(row) & (kSlots - 1));
         for (;;) {  // the table never fills: cleared above kClearAbove
           const unsigned long long prev = atomicCAS(&L.keys[h], kEmptyKey, row);
           if (prev == kEmptyKey || prev == row) break;
           h = (h + 1) & (kSlots - 1);
         }
-        L.pslot[e] = h;
         atomicAdd(&L.cnt[h], 1);
       }
+      if (valid) L.pslot[e] = h;
     }
     __syncthreads();
 
@@ -399,11 +436,31 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
     }
     __syncthreads();
 
-    // (c) counting sort of the pairs by slot (off[] ends up as the end of every slot's run)
+    // (c) counting sort of the pairs by slot (off[] ends up as the end of every slot's run);
+    // tickets of a hot slot are taken once per wave and split by ballot rank
 #pragma unroll
     for (int k = 0; k < kCP / kBlock; ++k) {
       const int e = k * kBlock + tid;
-      if (e < n_chunk) L.order[atomicAdd(&L.off[L.pslot[e]], 1)] = e;
+      const bool valid = e < n_chunk;
+      const int h = valid ? L.pslot[e] : -1;
+      int pos = -1;
+      unsigned long long todo = __ballot(valid);
+      for (int t = 0; t < kHotTries && todo != 0ull; ++t) {
+        const int leader = __builtin_ctzll(todo);
+        const int hs = __builtin_amdgcn_readlane(h, leader);
+        const unsigned long long same = __ballot(valid && h == hs) & todo;
+        todo &= ~same;
+        const int n_same = (int)__builtin_popcountll(same);
+        if (n_same < kHotMin) continue;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&L.off[hs], n_same);
+        base = __builtin_amdgcn_readlane(base, leader);
+        if ((same >> lane) & 1ull) pos = base + rank_below(same);
+      }
+      if (valid) {
+        if (pos < 0) pos = atomicAdd(&L.off[h], 1);
+        L.order[pos] = e;
+      }
     }
     __syncthreads();
 
@@ -460,16 +517,16 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
       const int32_t n = L.cnt[s] & (kNewBit - 1);
       const int32_t b0 = L.off[s] - n;
       V acc = zero_v<V>();
-      for (int32_t p0 = 0; p0 < n; p0 += groups * kUA) {
-        V g[kUA];
+      for (int32_t p0 = 0; p0 < n; p0 += groups * kUH) {
+        V g[kUH];
 #pragma unroll
-        for (int u = 0; u < kUA; ++u) {
+        for (int u = 0; u < kUH; ++u) {
           const int32_t p = p0 + u * groups + my_group;
           g[u] = zero_v<V>();
           if (p < n && live) g[u] = load_grad<V>(c, L.segs[L.order[b0 + p]], sub);
         }
 #pragma unroll
-        for (int u = 0; u < kUA; ++u) acc = acc + g[u];
+        for (int u = 0; u < kUH; ++u) acc = acc + g[u];
       }
       *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = acc;
       __syncthreads();

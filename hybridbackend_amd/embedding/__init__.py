@@ -7,3 +7,5 @@ from hybridbackend_amd.embedding.lookup import group_lookup
 from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
 from hybridbackend_amd.embedding.unique import unique
 from hybridbackend_amd.embedding.unique import unique_n
+from hybridbackend_amd.embedding.variables import shard_of_table
+from hybridbackend_amd.embedding.variables import sharded_bucket_size

@@ -91,3 +91,25 @@ def test_cpu_tensors_are_refused_not_silently_computed():
     hb.embedding.group_lookup([table], [ids])
   with pytest.raises(hb.HbkError):
     hb.distribute.partition_by_modulo(ids, 2)
+
+
+def test_shard_sizing_rule_matches_oracle():
+  # variables.py:93-123
+  import torch
+  import oracle
+  import hybridbackend_amd as hb
+  for bucket in (1, 7, 8, 9, 1000, 1000003, 100000000):
+    for W in (1, 2, 3, 8):
+      for batch in (0, 1000, 65536):
+        rows = []
+        for r in range(W):
+          got = hb.embedding.sharded_bucket_size(bucket, W, r, batch)
+          assert got == oracle.shard_rows(bucket, W, r, batch)
+          rows.append(got[1])
+        if got[0]:
+          assert sum(rows) == bucket
+  t = torch.arange(10).view(10, 1)
+  assert [len(hb.embedding.shard_of_table(t, 4, r)) for r in range(4)] == \
+    [hb.embedding.sharded_bucket_size(10, 4, r)[1] for r in range(4)]
+  with pytest.raises(ValueError):
+    hb.embedding.sharded_bucket_size(10, 4, 4)

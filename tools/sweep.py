@@ -184,6 +184,39 @@ def case_bwd_probe():
     report(f'bwd probe dim128 {name}', us, 26 * B, 26 * B * (8 + 512 + 512))
 
 
+def case_cfg5():
+  """Config 5 shape on one GPU: 200 columns, dims cycling over {4..128}, rows log-uniform in
+  [1e3, 1e7], one third of the columns ragged; fused lookup, then backward + SGD apply."""
+  rng = np.random.RandomState(5)
+  dims_cycle = [4, 8, 12, 16, 24, 32, 36, 48, 64, 80, 128]
+  n, B = 200, 65536
+  dims = [dims_cycle[c % len(dims_cycle)] for c in range(n)]
+  rows = [int(10 ** rng.uniform(3, 7)) for _ in range(n)]
+  tables = [torch.empty(rows[c], dims[c], device=DEV).uniform_(-1e-3, 1e-3) for c in range(n)]
+  ids, splits, n_ids, n_bytes = [], [], 0, 0
+  for c in range(n):
+    if c % 3 == 0:
+      lens = torch.poisson(torch.full((B,), 4.0, device=DEV)).clamp_(0, 16)
+      sp = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+      sp[1:] = torch.cumsum(lens, 0).to(torch.int32)
+      k = int(sp[-1].item())
+      splits.append(sp)
+    else:
+      k = B
+      splits.append(None)
+    ids.append(torch.randint(0, 1 << 40, (k,), device=DEV))
+    n_ids += k
+    n_bytes += k * 8 + k * 4 * dims[c] + B * 4 * dims[c]
+  lookup = hb.embedding.GroupLookup(tables, rows, 'mean')
+  outs = lookup.bind(ids, splits, None)
+  us = timed(lambda i: lookup.launch(), iters=10)
+  report(f'cfg5 fwd 200 cols mixed dims B={B} (1/3 ragged)', us, n_ids, n_bytes, ids=n_ids)
+  grad = hb.embedding.GroupLookupGrad(lookup)
+  gouts = [torch.randn_like(o) for o in outs]
+  us = timed(lambda i: grad(ids, gouts, splits, apply_lr=0.01), iters=5, warmup=2)
+  report(f'cfg5 bwd + SGD apply 200 cols mixed dims B={B}', us, n_ids, n_bytes, ids=n_ids)
+
+
 def case_sharded_world1():
   """The whole sharded pipeline (partition -> RCCL alltoallv -> owner gather -> alltoallv ->
   stitch) on one GPU with a world-size-1 communicator: kernel chain + host overhead per step."""
@@ -215,5 +248,5 @@ if __name__ == '__main__':
   torch.manual_seed(0)
   for c in args.cases.split(','):
     {'a': case_batch_sweep, 'b': case_ragged, 'c': case_backward_cfg2,
-     'd': lambda: case_cfg4(args.big), 'e': case_integer, 'f': case_bwd_probe, 'g': case_sharded_world1}[c]()
+     'd': lambda: case_cfg4(args.big), 'e': case_integer, 'f': case_bwd_probe, 'g': case_sharded_world1, 'h': case_cfg5}[c]()
     torch.cuda.empty_cache()

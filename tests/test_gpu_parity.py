@@ -288,6 +288,23 @@ def test_unique_first_occurrence_order():
     np.testing.assert_equal(host(idx), oidx)
 
 
+def test_unique_table_overflow_is_still_exact(monkeypatch):
+  # one bucket per column: > 1024 distinct keys overflow the LDS table and are resolved by the
+  # exact bucket scan
+  monkeypatch.setenv('HBK_UNIQUE_LOG2P', '0')
+  rng = np.random.RandomState(16)
+  cases = [rng.randint(0, 3000, size=6000).astype(np.int64),
+           rng.randint(-5, 5, size=3000).astype(np.int64),
+           np.arange(2500, dtype=np.int64)[::-1].copy()]
+  res = hb.embedding.unique_n([dev(x) for x in cases])
+  for x, (u, idx, nu) in zip(cases, res):
+    ou, oidx = oracle.unique(x)
+    k = int(nu.item())
+    assert k == ou.size
+    np.testing.assert_equal(host(u)[:k], ou)
+    np.testing.assert_equal(host(idx), oidx)
+
+
 # ----------------------------------------------------------------------------------
 # R10 backward
 def _check_slices(res, rows, grads, splits, combiner, distinct=True, atol=1e-6):

@@ -26,10 +26,11 @@
 //                read-modify-write race free); (e) hot rows (>= 64 pairs in the chunk) are
 //                summed by the whole workgroup and folded through a 4 KB LDS buffer (the
 //                "LDS-staged hot rows").  A row that spans chunks is accumulated into its
-//                output row by the owning workgroup.  If the table would pass 3/4 load it is
+//                output row by the owning workgroup.  If the table would pass 7/8 load it is
 //                cleared between chunks; a row seen again afterwards gets a second
-//                IndexedSlices entry (sum semantics preserved; needs > 768 distinct rows in
-//                one bucket, i.e. adversarial hashing).
+//                IndexedSlices entry (sum semantics preserved).  That needs > 384 distinct rows
+//                in the earlier chunks of one bucket: adversarial hashing, or more than ~4 M
+//                ids in one column (16384 buckets x 256).
 // Summation order inside a row is not fixed (pair order comes from LDS tickets): 1e-5 relative.
 #include <alloca.h>
 #include <stdlib.h>
@@ -62,10 +63,10 @@ constexpr int kTile = 4096;          // ids per 256-thread block in hist / scatt
                                      // the [bucket][tile] histogram (and its scan) small
 constexpr int kPerThread = kTile / kBlock;   // 16 ids per thread, 8 loads in flight
 constexpr int kBatch = 8;
-constexpr int kMaxBuckets = 8192;
+constexpr int kMaxBuckets = 16384;   // 64 KB of LDS counters in hist / scatter
 constexpr int kCP = HBK_BWD_CP;       // pairs per chunk in the reduce kernel
 constexpr int kSlots = 2 * kCP;       // LDS hash-table slots
-constexpr int kClearAbove = kSlots * 3 / 4 - kCP;  // clear the table before a chunk beyond this
+constexpr int kClearAbove = kSlots * 7 / 8 - kCP;  // clear the table before a chunk beyond this
 constexpr int kUA = HBK_BWD_UA;       // slots a lane group reduces concurrently (rows in flight)
 constexpr int kHeavy = 64;            // pairs of one row in a chunk that make it a "hot row"
 constexpr int kHotTries = 4;           // ballot rounds that look for a hot row inside a wave
@@ -643,10 +644,10 @@ ColPlan plan_of(int64_t n_ids, int32_t dim) {
   (void)dim;
   ColPlan p;
   int lp = 0;  // aim at kCP / 2 pairs per bucket: one chunk with headroom
-  while (lp < 13 && ((int64_t)(kCP / 2) << lp) < n_ids) ++lp;
+  while (lp < 14 && ((int64_t)(kCP / 2) << lp) < n_ids) ++lp;
   while (((int64_t)1 << lp) > kMaxBuckets) --lp;
   const int forced = forced_log2p();
-  if (forced >= 0 && forced <= 13) lp = forced;
+  if (forced >= 0 && forced <= 14) lp = forced;
   p.log2p = lp;
   p.tiles = (n_ids + kTile - 1) / kTile;
   return p;

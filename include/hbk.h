@@ -179,8 +179,9 @@ int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
  *   nothing.  No global atomics on the data path: ids are grouped by a hash of their row and
  *   each group is reduced by one workgroup in an LDS table (ds_add_f32), so the summation
  *   order is not fixed: tolerance 1e-5 relative.  Rows are distinct unless one group holds
- *   more distinct rows than its LDS table (adversarial skew): then a row may appear in more
- *   than one entry, sum semantics preserved (IndexedSlices allow repeated indices).
+ *   more distinct rows than its LDS table (adversarial skew, or more than ~4 M ids in one
+ *   column): then a row may appear in more than one entry, sum semantics preserved
+ *   (IndexedSlices allow repeated indices; the fused SGD apply stays exact).
  *   apply_lr != 0 additionally performs the sparse SGD update on the shard in the same
  *   pass: table[unique_rows[u],:] -= apply_lr * grad_rows[u,:] (sharded variables skip
  *   cross-rank aggregation, hbtf/training/gradient.py:193-217).                        */

@@ -481,3 +481,33 @@ def test_comm_world1_alltoallv():
     coll.check_async_errors()
   finally:
     coll.close()
+
+
+# ----------------------------------------------------------------------------------
+# large sizes: size-independent properties checked on the device (no oracle at this size)
+def test_large_single_column_properties():
+  torch.manual_seed(3)
+  n, rows, d = 6_000_000, 3_000_017, 16
+  table = torch.empty(rows, d, device=DEV).uniform_(-1, 1)
+  ids = torch.randint(-2**40, 2**40, (n,), device=DEV, dtype=torch.int64)
+  out = hb.embedding.group_lookup([table], [ids], buckets=[rows])[0]
+  r = torch.remainder(ids, rows)                               # floor-mod, also for negatives
+  assert torch.equal(out, table[r])
+  # partition: round trip, grouping, sizes (W = 8) on 6M ids, incl. negative ids
+  y, sizes, idx = hb.distribute.partition_by_modulo(ids, 8)
+  assert torch.equal(y[idx.long()], ids)
+  shard = torch.remainder(y, 8)
+  assert bool((shard[1:] >= shard[:-1]).all())
+  assert torch.equal(torch.bincount(shard, minlength=8).int(), sizes)
+  # backward: checksum of checksums -- column sums of the summed rows == column sums of grads,
+  # and every unique row appears once
+  g = torch.randn(n, d, device=DEV)
+  lookup = hb.embedding.GroupLookup([table], [rows], 'sum')
+  urows, grows, nu = hb.embedding.GroupLookupGrad(lookup)([ids], [g])[0]
+  k = int(nu.item())
+  assert k == int(torch.unique(r).numel())
+  assert int(torch.unique(urows[:k]).numel()) == k
+  torch.testing.assert_close(grows[:k].double().sum(0), g.double().sum(0), rtol=1e-6, atol=1e-3)
+  dense = torch.zeros(rows, d, device=DEV, dtype=torch.float64)
+  dense.index_add_(0, r, g.double())
+  torch.testing.assert_close(grows[:k].double(), dense[urows[:k]], rtol=1e-5, atol=1e-5)

@@ -376,12 +376,17 @@ extern "C" size_t hbk_alltoallv_wire_workspace_bytes(int32_t n, const int64_t* c
   return total;
 }
 
-extern "C" int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dtype,
-                               int32_t topology, const int64_t* common_sizes,
-                               const void* const* inputs, const int32_t* send_sizes,
-                               void* const* outputs, const int32_t* recv_sizes, void* wire_ws,
-                               size_t wire_ws_bytes, hbk_stream_t compute_stream) {
-  using namespace hbk;
+namespace hbk {
+// hbk_alltoallv_n with explicit ordering: when `before` / `after` are given the exchange is
+// enqueued on the communicator's own stream behind `before` and `after` is recorded when it
+// is done -- the compute stream is NOT fenced, so the caller can overlap other work with the
+// exchange (sharded.hip pipelines column groups this way).  With both NULL it fences against
+// `compute_stream` on both sides like the reference (hbtf/common/stream.cc:83-142).
+int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dtype,
+                     int32_t topology, const int64_t* common_sizes, const void* const* inputs,
+                     const int32_t* send_sizes, void* const* outputs,
+                     const int32_t* recv_sizes, void* wire_ws, size_t wire_ws_bytes,
+                     hbk_stream_t compute_stream, hipEvent_t before, hipEvent_t after) {
   HBK_REQUIRE(comm != nullptr, "alltoallv_n: comm is NULL");
   HBK_REQUIRE(n >= 0, "alltoallv_n: n must be >= 0");
   if (n == 0) return HBK_OK;
@@ -442,6 +447,7 @@ extern "C" int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
     HBK_REQUIRE(topology == HBK_TOPOLOGY_ALL, "alltoallv_n: local world supports topology ALL");
     hipStream_t cs = as_stream(compute_stream);
     int lrc;
+    if (before != nullptr) HBK_HIP_OK(hipStreamWaitEvent(cs, before, 0));
     if (half_wire) {
       std::vector<int64_t> lens(n);
       std::vector<void*> dst(n);
@@ -481,11 +487,17 @@ extern "C" int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
         return lrc;
       }
     }
+    if (after != nullptr) HBK_HIP_OK(hipEventRecord(after, cs));
     return HBK_OK;
   }
   std::unique_lock<std::mutex> lock(comm->mu);
   HBK_REQUIRE(!comm->aborted, "alltoallv_n: communicator was aborted");
-  int rc = fence_in(comm, as_stream(compute_stream));
+  int rc = HBK_OK;
+  if (before != nullptr) {
+    HBK_HIP_OK(hipStreamWaitEvent(comm->stream, before, 0));
+  } else {
+    rc = fence_in(comm, as_stream(compute_stream));
+  }
   if (rc != HBK_OK) return rc;
   if (half_wire) {
     std::vector<int64_t> lens(n);
@@ -528,5 +540,20 @@ extern "C" int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
     rc = cast_n_impl(n, HBK_HALF, HBK_FLOAT, src.data(), lens.data(), outputs, comm->stream);
     if (rc != HBK_OK) return rc;
   }
+  if (after != nullptr) {
+    HBK_HIP_OK(hipEventRecord(after, comm->stream));
+    return HBK_OK;
+  }
   return fence_out(comm, as_stream(compute_stream));
+}
+}  // namespace hbk
+
+extern "C" int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dtype,
+                               int32_t topology, const int64_t* common_sizes,
+                               const void* const* inputs, const int32_t* send_sizes,
+                               void* const* outputs, const int32_t* recv_sizes, void* wire_ws,
+                               size_t wire_ws_bytes, hbk_stream_t compute_stream) {
+  return hbk::alltoallv_events(comm, n, dtype, wire_dtype, topology, common_sizes, inputs,
+                               send_sizes, outputs, recv_sizes, wire_ws, wire_ws_bytes,
+                               compute_stream, nullptr, nullptr);
 }

@@ -19,6 +19,7 @@
 // Buffers whose size depends on what the peers send (known only after the size exchange)
 // are owned by the plan and grow on demand (hipMalloc, never shrinks); everything else is
 // caller-owned as usual.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -26,6 +27,11 @@
 #include "common.h"
 
 namespace hbk {
+int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dtype,
+                     int32_t topology, const int64_t* common_sizes, const void* const* inputs,
+                     const int32_t* send_sizes, void* const* outputs,
+                     const int32_t* recv_sizes, void* wire_ws, size_t wire_ws_bytes,
+                     hbk_stream_t compute_stream, hipEvent_t before, hipEvent_t after);
 int partition_by_modulo_fused(int32_t n_cols, int32_t num_partitions, const int64_t* const* inputs,
                               const int64_t* lens, const int64_t* buckets,
                               int64_t* const* outputs, int32_t* const* sizes,
@@ -245,7 +251,9 @@ struct hbk_sharded {
   std::vector<const int32_t*> row_splits;
   std::vector<int32_t> send_sizes;   // S [N][W] rows this rank requests from owner q, column c
   std::vector<int32_t> recv_sizes;   // R [W][N] rows requester q asked this rank for, column c
-  hbk::Layout lay;
+  hbk::Layout lay;                       // over all columns: the backward's exchange
+  std::vector<int64_t> fwd_own_id_off;   // [W][N] where run (q, c) of the forward sits in recv_ids
+  hipEvent_t ev[4][4];                   // [stage][group]: packed, ids in, gathered, rows in
   bool have_step;
   // device buffers owned by the plan
   hbk::Buffer ids_bucketized, part_out, shard_index, sizes_dev, part_ws, send_ids, recv_ids,
@@ -279,6 +287,14 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
   p->have_step = false;
   p->host_sizes = nullptr;
   p->host_runs = nullptr;
+  for (auto& st : p->ev) {
+    for (auto& e : st) {
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        delete p;
+        return fail(HBK_INTERNAL, "sharded_create: hipEventCreate failed");
+      }
+    }
+  }
   if (hipHostMalloc(reinterpret_cast<void**>(&p->host_sizes),
                     sizeof(int32_t) * 2 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
           hipSuccess ||
@@ -302,6 +318,9 @@ extern "C" int hbk_sharded_destroy(hbk_sharded_t p) {
   }
   if (p->host_sizes) (void)hipHostFree(p->host_sizes);
   if (p->host_runs) (void)hipHostFree(p->host_runs);
+  for (auto& st : p->ev) {
+    for (auto& e : st) (void)hipEventDestroy(e);
+  }
   delete p;
   return HBK_OK;
 }
@@ -319,19 +338,31 @@ inline Seg make_seg(const void* src, void* dst, int64_t bytes) {
   return s;
 }
 
-// one packed exchange: a single buffer, one message per peer
+// one packed exchange: a single buffer, one message per peer.  With events the exchange runs on
+// the communicator's stream behind `before` and records `after`; the compute stream goes on.
 int exchange(hbk_sharded* p, int32_t dtype, int32_t wire, const void* in, const int32_t* send,
-             void* out, const int32_t* recv, hbk_stream_t stream) {
+             void* out, const int32_t* recv, hbk_stream_t stream, hipEvent_t before = nullptr,
+             hipEvent_t after = nullptr, void* wire_ws = nullptr, size_t wire_ws_bytes = 0) {
   const int64_t cs[1] = {1};
   const void* vin[1] = {in};
   void* vout[1] = {out};
-  if (wire != dtype) {
+  if (wire != dtype && wire_ws == nullptr) {
     const size_t wws = hbk_alltoallv_wire_workspace_bytes(1, cs, send, recv, p->W);
     int rc = p->wire_ws.ensure(wws + 16);
     if (rc != HBK_OK) return rc;
+    wire_ws = p->wire_ws.ptr;
+    wire_ws_bytes = p->wire_ws.bytes;
   }
-  return hbk_alltoallv_n(p->comm, 1, dtype, wire, HBK_TOPOLOGY_ALL, cs, vin, send, vout, recv,
-                         p->wire_ws.ptr, p->wire_ws.bytes, stream);
+  return alltoallv_events(p->comm, 1, dtype, wire, HBK_TOPOLOGY_ALL, cs, vin, send, vout, recv,
+                          wire_ws, wire_ws_bytes, stream, before, after);
+}
+
+// test hook / tuning knob: number of column groups the forward pipelines (default 2)
+int pipeline_groups(int n_cols) {
+  int g = 2;
+  const char* e = getenv("HBK_SHARDED_GROUPS");
+  if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 4) g = atoi(e);
+  return g < n_cols ? g : n_cols;
 }
 
 }  // namespace
@@ -404,92 +435,172 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   const int32_t* R = p->recv_sizes.data();
   Layout& L = p->lay;
   if ((rc = L.compute(N, W, p->cols, S, R)) != HBK_OK) return rc;
-  // ---- 3 pack ids peer-major and exchange: one message per peer -----------------------------
-  if ((rc = p->send_ids.ensure((size_t)L.req_ids * 8 + 8)) != HBK_OK) return rc;
-  if ((rc = p->recv_ids.ensure((size_t)L.own_ids * 8 + 8)) != HBK_OK) return rc;
+  // ---- 3..6 pipelined over column groups ------------------------------------------------------
+  // The columns are split into G groups, each with its own peer-major buffers.  The exchanges
+  // run back to back on the communicator's stream; the compute stream gathers group g while the
+  // ids of group g+1 are on the wire, and stitches group g while the rows of group g+1 travel:
+  //   comm    : ids(0) ids(1) ...            rows(0)      rows(1) ...
+  //   compute : pack(0..G-1)      gather(0)  gather(1) ..      stitch(0)   stitch(1)
+  const int G = pipeline_groups(N);
+  struct Group {
+    int c0, c1;
+    Layout lay;
+    std::vector<int32_t> R;                 // [W][n_g]
+    int64_t id_send, id_recv, row_send, row_recv;  // offsets of the group's regions
+  };
+  std::vector<Group> groups(G);
+  int64_t tot_req_ids = 0, tot_own_ids = 0, tot_own_floats = 0, tot_req_floats = 0;
+  p->fwd_own_id_off.assign((size_t)N * W, 0);
+  for (int g = 0; g < G; ++g) {
+    Group& gr = groups[g];
+    gr.c0 = (int)((int64_t)N * g / G);
+    gr.c1 = (int)((int64_t)N * (g + 1) / G);
+    const int ng = gr.c1 - gr.c0;
+    gr.R.resize((size_t)W * ng);
+    for (int q = 0; q < W; ++q) {
+      for (int c = 0; c < ng; ++c) gr.R[(size_t)q * ng + c] = R[(size_t)q * N + gr.c0 + c];
+    }
+    std::vector<hbk_sharded_column_t> sub(p->cols.begin() + gr.c0, p->cols.begin() + gr.c1);
+    if ((rc = gr.lay.compute(ng, W, sub, S + (size_t)gr.c0 * W, gr.R.data())) != HBK_OK) return rc;
+    gr.id_send = tot_req_ids;
+    gr.id_recv = tot_own_ids;
+    gr.row_send = tot_own_floats;
+    gr.row_recv = tot_req_floats;
+    tot_req_ids += gr.lay.req_ids;
+    tot_own_ids += gr.lay.own_ids;
+    tot_own_floats += gr.lay.own_floats;
+    tot_req_floats += gr.lay.req_floats;
+    for (int q = 0; q < W; ++q) {
+      for (int c = 0; c < ng; ++c) {
+        p->fwd_own_id_off[(size_t)q * N + gr.c0 + c] = gr.id_recv + gr.lay.own_id_off[(size_t)q * ng + c];
+      }
+    }
+  }
+  if ((rc = p->send_ids.ensure((size_t)tot_req_ids * 8 + 8)) != HBK_OK) return rc;
+  if ((rc = p->recv_ids.ensure((size_t)tot_own_ids * 8 + 8)) != HBK_OK) return rc;
+  if ((rc = p->send_rows.ensure((size_t)tot_own_floats * 4 + 16)) != HBK_OK) return rc;
+  if ((rc = p->recv_rows.ensure((size_t)tot_req_floats * 4 + 16)) != HBK_OK) return rc;
+  if (p->wire_dtype == HBK_HALF) {  // staging for the largest group (exchanges are serial)
+    size_t wws = 0;
+    const int64_t cs1[1] = {1};
+    for (const Group& gr : groups) {
+      const size_t w = hbk_alltoallv_wire_workspace_bytes(1, cs1, gr.lay.rows_send_peer.data(),
+                                                          gr.lay.rows_recv_peer.data(), W);
+      wws = w > wws ? w : wws;
+    }
+    if ((rc = p->wire_ws.ensure(wws + 16)) != HBK_OK) return rc;
+  }
+  if ((rc = p->runs_dev.ensure(sizeof(int64_t) * 2 * (size_t)N * W)) != HBK_OK) return rc;
+  int64_t* ids_send_base = reinterpret_cast<int64_t*>(p->send_ids.ptr);
+  int64_t* ids_recv_base = reinterpret_cast<int64_t*>(p->recv_ids.ptr);
+  float* rows_send_base = reinterpret_cast<float*>(p->send_rows.ptr);
+  float* rows_recv_base = reinterpret_cast<float*>(p->recv_rows.ptr);
+  // run tables of the in-place stitch (column c = W runs over the group's received rows)
   {
+    int64_t* h_start = p->host_runs;
+    int64_t* h_base = p->host_runs + (size_t)N * W;
+    for (const Group& gr : groups) {
+      const int ng = gr.c1 - gr.c0;
+      for (int c = 0; c < ng; ++c) {
+        for (int q = 0; q < W; ++q) {
+          h_start[(size_t)(gr.c0 + c) * W + q] = gr.lay.col_shard_off[(size_t)c * W + q];
+          h_base[(size_t)(gr.c0 + c) * W + q] = gr.lay.req_row_off[(size_t)q * ng + c];
+        }
+      }
+    }
+    HBK_HIP_OK(hipMemcpyAsync(p->runs_dev.ptr, p->host_runs, sizeof(int64_t) * 2 * (size_t)N * W,
+                              hipMemcpyHostToDevice, stream));
+  }
+  // stage A: pack the ids of every group peer-major
+  for (int g = 0; g < G; ++g) {
+    const Group& gr = groups[g];
+    const int ng = gr.c1 - gr.c0;
     std::vector<Seg> segs;
     for (int q = 0; q < W; ++q) {
-      for (int c = 0; c < N; ++c) {
+      for (int c = 0; c < ng; ++c) {
         segs.push_back(make_seg(
-            reinterpret_cast<const int64_t*>(pout[c]) + L.col_shard_off[(size_t)c * W + q],
-            reinterpret_cast<int64_t*>(p->send_ids.ptr) + L.req_id_off[(size_t)q * N + c],
-            (int64_t)S[(size_t)c * W + q] * 8));
+            pout[gr.c0 + c] + gr.lay.col_shard_off[(size_t)c * W + q],
+            ids_send_base + gr.id_send + gr.lay.req_id_off[(size_t)q * ng + c],
+            (int64_t)S[(size_t)(gr.c0 + c) * W + q] * 8));
       }
     }
     if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
+    HBK_HIP_OK(hipEventRecord(p->ev[0][g], stream));
   }
-  rc = exchange(p, HBK_INT64, HBK_INT64, p->send_ids.ptr, L.ids_send_peer.data(),
-                p->recv_ids.ptr, L.ids_recv_peer.data(), stream_);
-  if (rc != HBK_OK) return rc;
-  // ---- 4 owner gather: N*W virtual columns, straight into the peer-major reply ---------------
-  if ((rc = p->send_rows.ensure((size_t)L.own_floats * 4 + 16)) != HBK_OK) return rc;
-  if ((rc = p->recv_rows.ensure((size_t)L.req_floats * 4 + 16)) != HBK_OK) return rc;
-  {
+  // stage B: ids exchanges, back to back on the communicator's stream
+  for (int g = 0; g < G; ++g) {
+    const Group& gr = groups[g];
+    rc = exchange(p, HBK_INT64, HBK_INT64, ids_send_base + gr.id_send,
+                  gr.lay.ids_send_peer.data(), ids_recv_base + gr.id_recv,
+                  gr.lay.ids_recv_peer.data(), stream_, p->ev[0][g], p->ev[1][g]);
+    if (rc != HBK_OK) return rc;
+  }
+  // stage C: owner gather of group g as soon as its ids are in (N_g * W virtual columns, straight
+  // into the peer-major reply), then its rows go on the wire
+  for (int g = 0; g < G; ++g) {
+    const Group& gr = groups[g];
+    const int ng = gr.c1 - gr.c0;
+    HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
     std::vector<hbk_lookup_column_t> v;
-    v.reserve((size_t)N * W);
+    v.reserve((size_t)ng * W);
     for (int q = 0; q < W; ++q) {
-      for (int c = 0; c < N; ++c) {
-        const int64_t n = R[(size_t)q * N + c];
+      for (int c = 0; c < ng; ++c) {
+        const int64_t n = gr.R[(size_t)q * ng + c];
         if (n == 0) continue;
+        const hbk_sharded_column_t& col = p->cols[gr.c0 + c];
         hbk_lookup_column_t h;
         memset(&h, 0, sizeof(h));
-        h.table = p->cols[c].shard;
-        h.rows = p->cols[c].rows_local;
-        h.dim = p->cols[c].dim;
+        h.table = col.shard;
+        h.rows = col.rows_local;
+        h.dim = col.dim;
         h.ids_dtype = HBK_INT64;
-        h.ids = reinterpret_cast<const int64_t*>(p->recv_ids.ptr) + L.own_id_off[(size_t)q * N + c];
+        h.ids = ids_recv_base + gr.id_recv + gr.lay.own_id_off[(size_t)q * ng + c];
         h.n_ids = n;
         h.n_segments = n;
         h.divisor = W;
         h.combiner = HBK_COMBINER_SUM;
-        h.out = reinterpret_cast<float*>(p->send_rows.ptr) + L.own_row_off[(size_t)q * N + c];
+        h.out = rows_send_base + gr.row_send + gr.lay.own_row_off[(size_t)q * ng + c];
         v.push_back(h);
       }
     }
     rc = hbk_group_lookup_fwd((int32_t)v.size(), v.data(), stream_);
     if (rc != HBK_OK) return rc;
+    HBK_HIP_OK(hipEventRecord(p->ev[2][g], stream));
+    rc = exchange(p, HBK_FLOAT, p->wire_dtype, rows_send_base + gr.row_send,
+                  gr.lay.rows_send_peer.data(), rows_recv_base + gr.row_recv,
+                  gr.lay.rows_recv_peer.data(), stream_, p->ev[2][g], p->ev[3][g],
+                  p->wire_ws.ptr, p->wire_ws.bytes);
+    if (rc != HBK_OK) return rc;
   }
-  // ---- 5 rows travel back: one message per peer ------------------------------------------------
-  rc = exchange(p, HBK_FLOAT, p->wire_dtype, p->send_rows.ptr, L.rows_send_peer.data(),
-                p->recv_rows.ptr, L.rows_recv_peer.data(), stream_);
-  if (rc != HBK_OK) return rc;
-  // ---- 6 stitch + combiner -----------------------------------------------------------------------
-  {
-    // the received rows stay peer-major; column c is a W-run segmented table over them
-    if ((rc = p->runs_dev.ensure(sizeof(int64_t) * 2 * (size_t)N * W)) != HBK_OK) return rc;
-    int64_t* h_start = p->host_runs;
-    int64_t* h_base = p->host_runs + (size_t)N * W;
-    for (int c = 0; c < N; ++c) {
-      for (int q = 0; q < W; ++q) {
-        h_start[(size_t)c * W + q] = L.col_shard_off[(size_t)c * W + q];
-        h_base[(size_t)c * W + q] = L.req_row_off[(size_t)q * N + c];
-      }
-    }
-    HBK_HIP_OK(hipMemcpyAsync(p->runs_dev.ptr, p->host_runs, sizeof(int64_t) * 2 * (size_t)N * W,
-                              hipMemcpyHostToDevice, stream));
-    const int64_t* d_start = reinterpret_cast<const int64_t*>(p->runs_dev.ptr);
-    const int64_t* d_base = d_start + (size_t)N * W;
-    std::vector<hbk_lookup_column_t> v(N);
-    for (int c = 0; c < N; ++c) {
+  // stage D: stitch + combiner of group g when its rows are in; the received rows stay
+  // peer-major, column c is a W-run segmented table over them
+  const int64_t* d_start = reinterpret_cast<const int64_t*>(p->runs_dev.ptr);
+  const int64_t* d_base = d_start + (size_t)N * W;
+  for (int g = 0; g < G; ++g) {
+    const Group& gr = groups[g];
+    const int ng = gr.c1 - gr.c0;
+    HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[3][g], 0));
+    std::vector<hbk_lookup_column_t> v(ng);
+    for (int c = 0; c < ng; ++c) {
+      const int cc = gr.c0 + c;
       hbk_lookup_column_t& h = v[c];
       memset(&h, 0, sizeof(h));
-      h.table = reinterpret_cast<const float*>(p->recv_rows.ptr);
-      h.rows = n_ids[c];
-      h.dim = p->cols[c].dim;
+      h.table = rows_recv_base + gr.row_recv;
+      h.rows = n_ids[cc];
+      h.dim = p->cols[cc].dim;
       h.ids_dtype = HBK_INT32;
-      h.ids = idx[c];
-      h.n_ids = n_ids[c];
-      h.row_splits = p->row_splits[c];
-      h.n_segments = p->n_seg[c];
+      h.ids = idx[cc];
+      h.n_ids = n_ids[cc];
+      h.row_splits = p->row_splits[cc];
+      h.n_segments = p->n_seg[cc];
       h.divisor = 1;
-      h.combiner = p->cols[c].combiner;
-      h.out = outs[c];
-      h.run_start = d_start + (size_t)c * W;
-      h.run_base = d_base + (size_t)c * W;
+      h.combiner = p->cols[cc].combiner;
+      h.out = outs[cc];
+      h.run_start = d_start + (size_t)cc * W;
+      h.run_base = d_base + (size_t)cc * W;
       h.n_runs = W;
     }
-    rc = hbk_group_lookup_fwd(N, v.data(), stream_);
+    rc = hbk_group_lookup_fwd(ng, v.data(), stream_);
     if (rc != HBK_OK) return rc;
   }
   p->have_step = true;
@@ -579,7 +690,7 @@ extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads
       for (int c = 0; c < N; ++c) {
         const int64_t n = R[(size_t)q * N + c], d = p->cols[c].dim;
         segs.push_back(make_seg(
-            reinterpret_cast<const int64_t*>(p->recv_ids.ptr) + L.own_id_off[(size_t)q * N + c],
+            reinterpret_cast<const int64_t*>(p->recv_ids.ptr) + p->fwd_own_id_off[(size_t)q * N + c],
             reinterpret_cast<int64_t*>(p->ids_unpacked.ptr) + id_base[c] + ioff[c], n * 8));
         segs.push_back(make_seg(
             reinterpret_cast<const float*>(p->send_rows.ptr) + L.own_row_off[(size_t)q * N + c],

@@ -47,8 +47,9 @@ struct ColArg {
 };
 
 // float offset of logical row r inside the table
+template <bool RUNS>
 __device__ inline uint64_t row_offset(const ColArg& c, uint64_t r) {
-  if (c.n_runs == 0) return r * (uint64_t)c.dim;
+  if (!RUNS) return r * (uint64_t)c.dim;
   int k = 0;
   while (k + 1 < c.n_runs && (uint64_t)c.run_start[k + 1] <= r) ++k;
   return (uint64_t)c.run_base[k] + (r - (uint64_t)c.run_start[k]) * (uint64_t)c.dim;
@@ -63,7 +64,7 @@ static_assert(sizeof(LookupArgs) <= 24576, "kernarg budget");
 
 // ---------------------------------------------------------------------------------
 // one id per segment (Criteo scalar columns): out[s,:] = table[row(ids[s]),:]
-template <typename V, int U>
+template <typename V, int U, bool RUNS>
 __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
   constexpr int VE = sizeof(V) / 4;
   const int lane = lane_id();
@@ -97,7 +98,7 @@ __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
     const uint64_t r = shfl_u64(src, (q0 & (kWave - 1)) + grp);
     v[u] = zero_v<V>();
     if (live && r != kNoRow) {
-      v[u] = *reinterpret_cast<const V*>(c.table + row_offset(c, r) + (uint64_t)sub * VE);
+      v[u] = *reinterpret_cast<const V*>(c.table + row_offset<RUNS>(c, r) + (uint64_t)sub * VE);
     }
   }
 #pragma unroll
@@ -112,7 +113,7 @@ __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
 
 // ---------------------------------------------------------------------------------
 // ragged segments (row_splits): out[s,:] = combine_j table[row(ids[j]),:], in order of j
-template <typename V>
+template <typename V, bool RUNS>
 __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
   constexpr int VE = sizeof(V) / 4;
   const int lane = lane_id();
@@ -154,7 +155,7 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
           p[t] = tt < lpr && tt < cnt;
           v[t] = zero_v<V>();
           if (p[t] && live && r != kNoRow) {
-            v[t] = *reinterpret_cast<const V*>(c.table + row_offset(c, r) + (uint64_t)sub * VE);
+            v[t] = *reinterpret_cast<const V*>(c.table + row_offset<RUNS>(c, r) + (uint64_t)sub * VE);
           }
         }
 #pragma unroll
@@ -178,9 +179,13 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
   }
 }
 
+// One instantiation per (ragged?, 16-byte chunks?, segmented table?) so that the common case --
+// one id per sample, dim % 4 == 0, plain table -- carries none of the other paths' code; the host
+// launches each kind present in the call with the columns of that kind.
+template <bool CSR, typename V, bool RUNS>
 __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupArgs a) {
   const int b = (int)blockIdx.x;
-  // last column whose first tile is <= b: binary search, <= 5 dependent scalar loads
+  // last column whose first tile is <= b: binary search, <= 7 dependent scalar loads
   int ci = 0, hi = a.n_cols;
   while (hi - ci > 1) {
     const int mid = (ci + hi) >> 1;
@@ -194,22 +199,33 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupAr
   const int64_t tile = b - a.tile_start[ci];
   const int wave = (int)(threadIdx.x >> 6);
   const int rpi = kWave >> c.lpr_log2;
-  if (c.splits == nullptr) {
+  if (!CSR) {
     const int64_t row0 = (tile * kWavesPerBlock + wave) * (int64_t)(kU * rpi);
     if (row0 >= c.n_seg) return;
-    if (c.vec4) {
-      gather_rows<f32x4, kU>(c, row0);
-    } else {
-      gather_rows<float, kU>(c, row0);
-    }
+    gather_rows<V, kU, RUNS>(c, row0);
   } else {
     const int64_t seg0 = (tile * kWavesPerBlock + wave) * (int64_t)(kSegIters * rpi);
     if (seg0 >= c.n_seg) return;
-    if (c.vec4) {
-      combine_segments<f32x4>(c, seg0);
-    } else {
-      combine_segments<float>(c, seg0);
-    }
+    combine_segments<V, RUNS>(c, seg0);
+  }
+}
+
+template <bool CSR, typename V, bool RUNS>
+void launch_kind(const LookupArgs& args, unsigned tiles, hipStream_t stream) {
+  hipLaunchKernelGGL((group_lookup_fwd_kernel<CSR, V, RUNS>), dim3(tiles), dim3(kBlock), 0, stream,
+                     args);
+}
+
+void launch_by_kind(int kind, const LookupArgs& args, unsigned tiles, hipStream_t stream) {
+  switch (kind) {  // bit 0 ragged, bit 1 scalar chunks, bit 2 segmented table
+    case 0: launch_kind<false, f32x4, false>(args, tiles, stream); break;
+    case 1: launch_kind<true, f32x4, false>(args, tiles, stream); break;
+    case 2: launch_kind<false, float, false>(args, tiles, stream); break;
+    case 3: launch_kind<true, float, false>(args, tiles, stream); break;
+    case 4: launch_kind<false, f32x4, true>(args, tiles, stream); break;
+    case 5: launch_kind<true, f32x4, true>(args, tiles, stream); break;
+    case 6: launch_kind<false, float, true>(args, tiles, stream); break;
+    default: launch_kind<true, float, true>(args, tiles, stream); break;
   }
 }
 
@@ -247,48 +263,51 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
                 "group_lookup_fwd: column %d: more than 2^31-1 ids/segments", c);
   }
 
-  int32_t c0 = 0;
-  while (c0 < n_cols) {
-    LookupArgs args;
-    int32_t k = 0;
-    int64_t tiles = 0;
-    args.tile_start[0] = 0;
-    while (c0 < n_cols && k < kMaxColsPerLaunch) {
-      const hbk_lookup_column_t& h = cols[c0++];
-      if (h.n_segments == 0) continue;
-      ColArg& d = args.col[k];
-      d.table = h.table;
-      d.ids = h.ids;
-      d.splits = h.row_splits;
-      d.out = h.out;
-      d.n_seg = h.n_segments;
-      d.map = make_idmap(h.bucket, h.divisor, h.rows);
-      d.dim = h.dim;
-      RowShape shape;
-      HBK_REQUIRE(make_rowshape(h.dim, (uintptr_t)h.table | (uintptr_t)h.out, &shape),
-                  "group_lookup_fwd: dim %d needs more than 64 lanes per row "
-                  "(unaligned or dim %% 4 != 0 with dim > 64 is unsupported)", h.dim);
-      d.vec4 = shape.vec4;
-      d.chunks = shape.chunks;
-      d.lpr_log2 = shape.lpr_log2;
-      d.ids64 = h.ids_dtype == HBK_INT64;
-      d.combiner = (uint8_t)h.combiner;
-      d.n_runs = h.n_runs;
-      d.run_start = h.run_start;
-      d.run_base = h.run_base;
-      const int64_t rpi = kWave >> d.lpr_log2;
-      const int64_t per_block =
-          kWavesPerBlock * rpi * (h.row_splits ? kSegIters : kU);
-      tiles += (h.n_segments + per_block - 1) / per_block;
-      HBK_REQUIRE(tiles < (1ll << 31), "group_lookup_fwd: grid too large");
-      ++k;
-      args.tile_start[k] = (int32_t)tiles;
+  for (int kind = 0; kind < 8; ++kind) {
+    int32_t c0 = 0;
+    while (c0 < n_cols) {
+      LookupArgs args;
+      int32_t k = 0;
+      int64_t tiles = 0;
+      args.tile_start[0] = 0;
+      while (c0 < n_cols && k < kMaxColsPerLaunch) {
+        const hbk_lookup_column_t& h = cols[c0++];
+        if (h.n_segments == 0) continue;
+        RowShape shape;
+        HBK_REQUIRE(make_rowshape(h.dim, (uintptr_t)h.table | (uintptr_t)h.out, &shape),
+                    "group_lookup_fwd: dim %d needs more than 64 lanes per row "
+                    "(unaligned or dim %% 4 != 0 with dim > 64 is unsupported)", h.dim);
+        const int col_kind = (h.row_splits != nullptr ? 1 : 0) | (shape.vec4 ? 0 : 2) |
+                             (h.n_runs > 0 ? 4 : 0);
+        if (col_kind != kind) continue;
+        ColArg& d = args.col[k];
+        d.table = h.table;
+        d.ids = h.ids;
+        d.splits = h.row_splits;
+        d.out = h.out;
+        d.n_seg = h.n_segments;
+        d.map = make_idmap(h.bucket, h.divisor, h.rows);
+        d.dim = h.dim;
+        d.vec4 = shape.vec4;
+        d.chunks = shape.chunks;
+        d.lpr_log2 = shape.lpr_log2;
+        d.ids64 = h.ids_dtype == HBK_INT64;
+        d.combiner = (uint8_t)h.combiner;
+        d.n_runs = h.n_runs;
+        d.run_start = h.run_start;
+        d.run_base = h.run_base;
+        const int64_t rpi = kWave >> d.lpr_log2;
+        const int64_t per_block = kWavesPerBlock * rpi * (h.row_splits ? kSegIters : kU);
+        tiles += (h.n_segments + per_block - 1) / per_block;
+        HBK_REQUIRE(tiles < (1ll << 31), "group_lookup_fwd: grid too large");
+        ++k;
+        args.tile_start[k] = (int32_t)tiles;
+      }
+      if (k == 0) continue;
+      args.n_cols = k;
+      launch_by_kind(kind, args, (unsigned)tiles, as_stream(stream));
+      HBK_HIP_OK(hipGetLastError());
     }
-    if (k == 0) continue;
-    args.n_cols = k;
-    hipLaunchKernelGGL(group_lookup_fwd_kernel, dim3((unsigned)tiles), dim3(kBlock), 0,
-                       as_stream(stream), args);
-    HBK_HIP_OK(hipGetLastError());
   }
   return HBK_OK;
 }

@@ -1,0 +1,551 @@
+// hb_ops_shim.cc -- the ONLY FFI layer between TensorFlow and libhbk_core.so.
+//
+// Registers HybridBackend's custom ops for the sharded-embedding path under their existing
+// names and signatures (so graphs produced by the reference's Python / graph passes load
+// unchanged) and forwards each kernel to the C ABI of include/hbk.h.  No CUDA headers, no
+// NCCL headers, no backend dispatch: everything device-side lives behind hbk_*.
+//
+// NOT compiled in this repository (TensorFlow is absent from the build image and the GPU
+// box); build line in INTEGRATION.md.  Signature sources, relative to the reference tree:
+//   hybridbackend/tensorflow/distribute/partition/partition_by_modulo_ops.cc:46-60,124-143
+//   hybridbackend/tensorflow/distribute/partition/partition_by_dual_modulo_ops.cc:46-61,132-147,184-204,278-298
+//   hybridbackend/tensorflow/distribute/nccl/nccl_get_id.cc:35-41, nccl_create.cc:32-52
+//   hybridbackend/tensorflow/distribute/nccl/nccl_alltoall.cc:169-180,242-258
+//   hybridbackend/tensorflow/distribute/nccl/nccl_alltoallv.cc:200-223,359-387
+//   hybridbackend/tensorflow/embedding/lookup_ops.cc:38-58
+#include <cstring>
+#include <vector>
+
+#include "hbk.h"
+#include "tensorflow/core/framework/op.h"
+#include "tensorflow/core/framework/op_kernel.h"
+#include "tensorflow/core/framework/register_types.h"
+#include "tensorflow/core/framework/resource_mgr.h"
+#include "tensorflow/core/framework/shape_inference.h"
+#include "tensorflow/core/lib/core/threadpool.h"
+
+namespace tensorflow {
+namespace hybridbackend {
+
+using shape_inference::InferenceContext;
+using GPUDevice = Eigen::GpuDevice;
+
+// ---- helpers -------------------------------------------------------------------------------
+static Status HbkStatus(int rc) {  // hbk status codes are TensorFlow error codes
+  if (rc == HBK_OK) return Status::OK();
+  return Status(static_cast<error::Code>(rc), hbk_last_error());
+}
+
+static hbk_stream_t StreamOf(OpKernelContext* ctx) {
+  return reinterpret_cast<hbk_stream_t>(ctx->eigen_device<GPUDevice>().stream());
+}
+
+template <typename T> struct HbkType;
+#define HBK_TYPE(T, V) template <> struct HbkType<T> { static constexpr int32_t v = V; }
+HBK_TYPE(int8, HBK_INT8); HBK_TYPE(uint8, HBK_UINT8); HBK_TYPE(int32, HBK_INT32);
+HBK_TYPE(uint32, HBK_UINT32); HBK_TYPE(int64, HBK_INT64); HBK_TYPE(uint64, HBK_UINT64);
+HBK_TYPE(Eigen::half, HBK_HALF); HBK_TYPE(float, HBK_FLOAT); HBK_TYPE(double, HBK_DOUBLE);
+#undef HBK_TYPE
+
+static Status AllocScratch(OpKernelContext* ctx, size_t bytes, Tensor* t) {
+  return ctx->allocate_temp(DT_INT8, TensorShape({static_cast<int64>(bytes) + 16}), t);
+}
+
+// ============================================================================================
+// HbPartitionByModulo[N], HbPartitionByDualModuloStage{One,Two}[N]
+// ============================================================================================
+#define HB_PARTITION_SHAPE_FN(N_EXPR)                                              \
+  [](InferenceContext* c) {                                                        \
+    int64 n = (N_EXPR);                                                            \
+    int32 num_partitions;                                                          \
+    TF_RETURN_IF_ERROR(c->GetAttr("num_partitions", &num_partitions));             \
+    for (int64 i = 0; i < n; ++i) {                                                \
+      c->set_output(i, c->input(i));                                               \
+      c->set_output(n + i, c->Vector(num_partitions));                             \
+      c->set_output(2 * n + i, c->input(i));                                       \
+    }                                                                              \
+    return Status::OK();                                                           \
+  }
+
+REGISTER_OP("HbPartitionByModulo")
+    .Output("output: T").Output("sizes: int32").Output("indices: int32")
+    .Input("input: T")
+    .Attr("T: {int32, int64, uint32, uint64}")
+    .Attr("num_partitions: int >= 1 = 1")
+    .SetShapeFn(HB_PARTITION_SHAPE_FN(1));
+
+REGISTER_OP("HbPartitionByModuloN")
+    .Output("outputs: N * T").Output("outputs_sizes: N * int32")
+    .Output("outputs_indices: N * int32")
+    .Input("inputs: N * T")
+    .Attr("N: int >= 1 = 1")
+    .Attr("T: {int32, int64, uint32, uint64}")
+    .Attr("num_partitions: int >= 1 = 1")
+    .SetShapeFn([](InferenceContext* c) {
+      int64 n;
+      TF_RETURN_IF_ERROR(c->GetAttr("N", &n));
+      int32 p;
+      TF_RETURN_IF_ERROR(c->GetAttr("num_partitions", &p));
+      for (int64 i = 0; i < n; ++i) {
+        c->set_output(i, c->input(i));
+        c->set_output(n + i, c->Vector(p));
+        c->set_output(2 * n + i, c->input(i));
+      }
+      return Status::OK();
+    });
+
+#define HB_REGISTER_DUAL_OPS(STAGE)                                                          \
+  REGISTER_OP("HbPartitionByDualModuloStage" #STAGE)                                         \
+      .Output("output: T").Output("sizes: int32").Output("indices: int32")                  \
+      .Input("input: T")                                                                     \
+      .Attr("T: {int32, int64, uint32, uint64}")                                             \
+      .Attr("num_partitions: int >= 1 = 1").Attr("modulus: int >= 1 = 1")                   \
+      .SetShapeFn(HB_PARTITION_SHAPE_FN(1));                                                 \
+  REGISTER_OP("HbPartitionByDualModuloStage" #STAGE "N")                                     \
+      .Output("outputs: N * T").Output("outputs_sizes: N * int32")                          \
+      .Output("outputs_indices: N * int32")                                                  \
+      .Input("inputs: N * T")                                                                \
+      .Attr("N: int >= 1 = 1").Attr("T: {int32, int64, uint32, uint64}")                    \
+      .Attr("num_partitions: int >= 1 = 1").Attr("modulus: int >= 1 = 1")
+HB_REGISTER_DUAL_OPS(One);
+HB_REGISTER_DUAL_OPS(Two);
+
+// One kernel class for all six partition ops: `stage` 0 = plain modulo, 1 / 2 = dual modulo;
+// `nary` selects list inputs.  Everything is enqueued on the op's compute stream.
+template <typename T>
+class PartitionOp : public OpKernel {
+ public:
+  PartitionOp(OpKernelConstruction* ctx, int stage, bool nary)
+      : OpKernel(ctx), stage_(stage), nary_(nary), modulus_(1) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("num_partitions", &num_partitions_));
+    if (stage_ != 0) OP_REQUIRES_OK(ctx, ctx->GetAttr("modulus", &modulus_));
+  }
+
+  void Compute(OpKernelContext* ctx) override {
+    std::vector<const Tensor*> in;
+    if (nary_) {
+      OpInputList list;
+      OP_REQUIRES_OK(ctx, ctx->input_list("inputs", &list));
+      for (int i = 0; i < list.size(); ++i) in.push_back(&list[i]);
+    } else {
+      in.push_back(&ctx->input(0));
+    }
+    const int n = static_cast<int>(in.size());
+    std::vector<const void*> src(n);
+    std::vector<void*> dst(n);
+    std::vector<int32_t*> sizes(n), idx(n);
+    std::vector<int64_t> lens(n);
+    for (int i = 0; i < n; ++i) {
+      OP_REQUIRES(ctx, TensorShapeUtils::IsVector(in[i]->shape()),
+                  errors::InvalidArgument("Input must be a vector"));
+      Tensor *o, *s, *x;
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, in[i]->shape(), &o));
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(n + i, TensorShape({num_partitions_}), &s));
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(2 * n + i, in[i]->shape(), &x));
+      src[i] = in[i]->flat<T>().data();
+      dst[i] = o->flat<T>().data();
+      sizes[i] = s->flat<int32>().data();
+      idx[i] = x->flat<int32>().data();
+      lens[i] = in[i]->NumElements();
+    }
+    const size_t ws_bytes = hbk_partition_workspace_bytes(n, lens.data(), num_partitions_);
+    Tensor ws;
+    OP_REQUIRES_OK(ctx, AllocScratch(ctx, ws_bytes, &ws));
+    void* wsp = ws.flat<int8>().data();
+    int rc;
+    if (stage_ == 0) {
+      rc = hbk_partition_by_modulo_n(n, HbkType<T>::v, num_partitions_, src.data(),
+                                     lens.data(), dst.data(), sizes.data(), idx.data(), wsp,
+                                     ws_bytes + 16, StreamOf(ctx));
+    } else {
+      rc = hbk_partition_by_dual_modulo_n(n, HbkType<T>::v, num_partitions_, modulus_, stage_,
+                                          src.data(), lens.data(), dst.data(), sizes.data(),
+                                          idx.data(), wsp, ws_bytes + 16, StreamOf(ctx));
+    }
+    OP_REQUIRES_OK(ctx, HbkStatus(rc));
+  }
+
+ private:
+  int stage_;
+  bool nary_;
+  int32 num_partitions_;
+  int32 modulus_;
+};
+
+#define HB_PARTITION_KERNEL(NAME, STAGE, NARY, T)                                        \
+  class NAME##Kernel##T : public PartitionOp<T> {                                        \
+   public:                                                                               \
+    explicit NAME##Kernel##T(OpKernelConstruction* c) : PartitionOp<T>(c, STAGE, NARY) {} \
+  };                                                                                     \
+  REGISTER_KERNEL_BUILDER(Name(#NAME).Device(DEVICE_GPU).TypeConstraint<T>("T"),         \
+                          NAME##Kernel##T)
+#define HB_PARTITION_KERNELS(T)                                   \
+  HB_PARTITION_KERNEL(HbPartitionByModulo, 0, false, T);           \
+  HB_PARTITION_KERNEL(HbPartitionByModuloN, 0, true, T);           \
+  HB_PARTITION_KERNEL(HbPartitionByDualModuloStageOne, 1, false, T); \
+  HB_PARTITION_KERNEL(HbPartitionByDualModuloStageOneN, 1, true, T); \
+  HB_PARTITION_KERNEL(HbPartitionByDualModuloStageTwo, 2, false, T); \
+  HB_PARTITION_KERNEL(HbPartitionByDualModuloStageTwoN, 2, true, T)
+HB_PARTITION_KERNELS(int32);
+HB_PARTITION_KERNELS(int64);
+HB_PARTITION_KERNELS(uint32);
+HB_PARTITION_KERNELS(uint64);
+
+// ============================================================================================
+// Communicator resource: HbGetNcclId / HbNcclCollectiveHandleOp / HbCreateNcclCollective /
+// HbIsNcclCollectiveInitialized.  The resource owns an hbk_comm_t (RCCL communicator + its
+// private stream) and a small thread pool for the async ops, like NcclCollective does.
+// ============================================================================================
+class HbNcclCollective : public ResourceBase {
+ public:
+  HbNcclCollective() : comm_(nullptr), pool_(nullptr) {}
+  ~HbNcclCollective() override {
+    delete pool_;
+    if (comm_ != nullptr) hbk_comm_destroy(comm_);
+  }
+  Status Create(const uint8_t* id, int world, int local, int rank) {
+    TF_RETURN_IF_ERROR(HbkStatus(hbk_comm_create(&comm_, id, world, local, rank)));
+    pool_ = new thread::ThreadPool(Env::Default(), "hbk_collective", 3);
+    return Status::OK();
+  }
+  bool initialized() const { return comm_ != nullptr; }
+  hbk_comm_t comm() const { return comm_; }
+  thread::ThreadPool* pool() const { return pool_; }
+  string DebugString() const override { return "HbNcclCollective(libhbk_core)"; }
+
+ private:
+  hbk_comm_t comm_;
+  thread::ThreadPool* pool_;
+};
+
+REGISTER_RESOURCE_HANDLE_OP(HbNcclCollective);
+REGISTER_KERNEL_BUILDER(Name("HbNcclCollectiveHandleOp").Device(DEVICE_GPU),
+                        ResourceHandleOp<HbNcclCollective>);
+
+REGISTER_OP("HbGetNcclId")
+    .Output("id: int64")
+    .SetIsStateful()
+    .SetShapeFn([](InferenceContext* c) {
+      c->set_output(0, c->Vector(HBK_COMM_ID_BYTES / sizeof(int64)));
+      return Status::OK();
+    });
+
+class GetNcclIdOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    Tensor* id;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(
+                            0, TensorShape({HBK_COMM_ID_BYTES / sizeof(int64)}), &id));
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_comm_get_id(
+                            reinterpret_cast<uint8_t*>(id->flat<int64>().data()))));
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("HbGetNcclId").Device(DEVICE_GPU).HostMemory("id"), GetNcclIdOp);
+REGISTER_KERNEL_BUILDER(Name("HbGetNcclId").Device(DEVICE_CPU), GetNcclIdOp);
+
+REGISTER_OP("HbCreateNcclCollective")
+    .Input("handle: resource").Input("id: int64")
+    .Attr("world_size: int").Attr("local_size: int").Attr("rank: int")
+    .Attr("shared_name: string")
+    .SetShapeFn(shape_inference::NoOutputs);
+
+class CreateNcclCollectiveOp : public OpKernel {
+ public:
+  explicit CreateNcclCollectiveOp(OpKernelConstruction* ctx) : OpKernel(ctx) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("world_size", &world_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("local_size", &local_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("rank", &rank_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor& id = ctx->input(1);
+    OP_REQUIRES(ctx, id.NumElements() * sizeof(int64) == HBK_COMM_ID_BYTES,
+                errors::InvalidArgument("id must hold ", HBK_COMM_ID_BYTES, " bytes"));
+    HbNcclCollective* coll = new HbNcclCollective();
+    Status s = coll->Create(reinterpret_cast<const uint8_t*>(id.flat<int64>().data()), world_,
+                            local_, rank_);
+    if (!s.ok()) {
+      coll->Unref();
+      OP_REQUIRES_OK(ctx, s);
+    }
+    OP_REQUIRES_OK(ctx, CreateResource(ctx, HandleFromInput(ctx, 0), coll));
+  }
+
+ private:
+  int world_, local_, rank_;
+};
+REGISTER_KERNEL_BUILDER(Name("HbCreateNcclCollective").Device(DEVICE_GPU).HostMemory("id"),
+                        CreateNcclCollectiveOp);
+
+REGISTER_OP("HbIsNcclCollectiveInitialized")
+    .Output("is_initialized: bool").Input("handle: resource")
+    .SetShapeFn(shape_inference::ScalarShape);
+
+class IsNcclCollectiveInitializedOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    Tensor* out;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, TensorShape({}), &out));
+    HbNcclCollective* coll = nullptr;
+    const bool found = LookupResource(ctx, HandleFromInput(ctx, 0), &coll).ok();
+    out->scalar<bool>()() = found && coll->initialized();
+    if (found) coll->Unref();
+  }
+};
+REGISTER_KERNEL_BUILDER(
+    Name("HbIsNcclCollectiveInitialized").Device(DEVICE_GPU).HostMemory("is_initialized"),
+    IsNcclCollectiveInitializedOp);
+
+// ============================================================================================
+// HbNcclAlltoall[N] (equal split) and HbNcclAlltoallv[N]
+// ============================================================================================
+#define HB_DTYPES "{int8, uint8, int32, uint32, int64, uint64, half, float, double}"
+#define HB_WIRE_DTYPES "{half, float}"
+
+REGISTER_OP("HbNcclAlltoall")
+    .Output("output: dtype").Input("handle: resource").Input("input: dtype")
+    .Attr("topology: int = 0").Attr("dtype: " HB_DTYPES).Attr("wire_dtype: " HB_WIRE_DTYPES)
+    .SetIsStateful().SetShapeFn(shape_inference::UnchangedShape);
+REGISTER_OP("HbNcclAlltoallN")
+    .Output("n_output: N * dtype").Input("handle: resource").Input("n_input: N * dtype")
+    .Attr("N: int >= 1 = 1").Attr("topology: int = 0").Attr("dtype: " HB_DTYPES)
+    .Attr("wire_dtype: " HB_WIRE_DTYPES).SetIsStateful();
+REGISTER_OP("HbNcclAlltoallv")
+    .Output("output: dtype").Output("output_sizes: int32")
+    .Input("handle: resource").Input("input: dtype").Input("input_sizes: int32")
+    .Attr("common_shape: shape = {}").Attr("topology: int = 0").Attr("dtype: " HB_DTYPES)
+    .Attr("wire_dtype: " HB_WIRE_DTYPES).SetIsStateful();
+REGISTER_OP("HbNcclAlltoallvN")
+    .Output("n_output: N * dtype").Output("n_output_sizes: N * int32")
+    .Input("handle: resource").Input("n_input: N * dtype").Input("n_input_sizes: N * int32")
+    .Attr("N: int >= 1 = 1").Attr("common_shape: list(shape)").Attr("topology: int = 0")
+    .Attr("dtype: " HB_DTYPES).Attr("wire_dtype: " HB_WIRE_DTYPES).SetIsStateful();
+
+// Base of the collective ops: looks the communicator up and hops to its thread pool, because
+// the Alltoallv ops block the calling thread once (sizes must reach the host before the
+// outputs can be allocated -- the reference does the same, nccl_alltoallv.cc:306-329).
+class CollectiveAsyncOp : public AsyncOpKernel {
+ public:
+  using AsyncOpKernel::AsyncOpKernel;
+  void ComputeAsync(OpKernelContext* ctx, DoneCallback done) override {
+    HbNcclCollective* coll = nullptr;
+    OP_REQUIRES_OK_ASYNC(ctx, LookupResource(ctx, HandleFromInput(ctx, 0), &coll), done);
+    coll->pool()->Schedule([this, ctx, coll, done]() {
+      Run(ctx, coll);
+      coll->Unref();
+      done();
+    });
+  }
+  virtual void Run(OpKernelContext* ctx, HbNcclCollective* coll) = 0;
+};
+
+template <typename T>
+class AlltoallNOp : public CollectiveAsyncOp {
+ public:
+  explicit AlltoallNOp(OpKernelConstruction* ctx) : CollectiveAsyncOp(ctx) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("topology", &topology_));
+  }
+  void Run(OpKernelContext* ctx, HbNcclCollective* coll) override {
+    const int n = ctx->num_inputs() - 1;
+    std::vector<const void*> in(n);
+    std::vector<void*> out(n);
+    std::vector<int64_t> counts(n);
+    for (int i = 0; i < n; ++i) {
+      const Tensor& t = ctx->input(1 + i);
+      Tensor* o;
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, t.shape(), &o));
+      in[i] = t.tensor_data().data();
+      out[i] = const_cast<char*>(o->tensor_data().data());
+      counts[i] = t.NumElements();
+    }
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_alltoall_n(coll->comm(), n, HbkType<T>::v, topology_,
+                                                 in.data(), counts.data(), out.data(),
+                                                 StreamOf(ctx))));
+  }
+
+ private:
+  int topology_;
+};
+
+template <typename T, typename W>
+class AlltoallvNOp : public CollectiveAsyncOp {
+ public:
+  explicit AlltoallvNOp(OpKernelConstruction* ctx) : CollectiveAsyncOp(ctx) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("topology", &topology_));
+    if (ctx->HasAttr("N")) {
+      std::vector<PartialTensorShape> shapes;
+      OP_REQUIRES_OK(ctx, ctx->GetAttr("common_shape", &shapes));
+      common_shapes_ = shapes;
+    } else {
+      PartialTensorShape shape;
+      OP_REQUIRES_OK(ctx, ctx->GetAttr("common_shape", &shape));
+      common_shapes_.push_back(shape);
+    }
+  }
+  void Run(OpKernelContext* ctx, HbNcclCollective* coll) override {
+    const int n = static_cast<int>(common_shapes_.size());
+    const int active = hbk_comm_active_ranks(coll->comm(), topology_, nullptr);
+    // 1 exchange the sizes of all N tensors in one equal-split alltoall
+    std::vector<const void*> sin(n);
+    std::vector<void*> sout(n);
+    std::vector<int64_t> scount(n, active);
+    for (int i = 0; i < n; ++i) {
+      const Tensor& sizes = ctx->input(1 + n + i);
+      OP_REQUIRES(ctx, sizes.NumElements() == active,
+                  errors::InvalidArgument("Sizes of input ", i, " must have ", active,
+                                          " elements"));
+      Tensor* osz;
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(n + i, sizes.shape(), &osz));
+      sin[i] = sizes.flat<int32>().data();
+      sout[i] = osz->flat<int32>().data();
+    }
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_alltoall_n(coll->comm(), n, HBK_INT32, topology_,
+                                                 sin.data(), scount.data(), sout.data(),
+                                                 StreamOf(ctx))));
+    // 2 sizes to the host (the one host sync of the op)
+    std::vector<int32_t> send(static_cast<size_t>(n) * active), recv(send.size());
+    auto* stream = ctx->op_device_context()->stream();
+    for (int i = 0; i < n; ++i) {
+      se::DeviceMemoryBase s(const_cast<void*>(sin[i]), active * sizeof(int32));
+      se::DeviceMemoryBase r(sout[i], active * sizeof(int32));
+      stream->ThenMemcpy(&send[static_cast<size_t>(i) * active], s, active * sizeof(int32));
+      stream->ThenMemcpy(&recv[static_cast<size_t>(i) * active], r, active * sizeof(int32));
+    }
+    OP_REQUIRES_OK(ctx, stream->BlockHostUntilDone());
+    // 3 allocate outputs, 4 exchange the payload
+    std::vector<const void*> in(n);
+    std::vector<void*> out(n);
+    std::vector<int64_t> common(n);
+    for (int i = 0; i < n; ++i) {
+      int64 rows = 0;
+      for (int a = 0; a < active; ++a) rows += recv[static_cast<size_t>(i) * active + a];
+      TensorShape shape;
+      PartialTensorShape({rows}).Concatenate(common_shapes_[i]).AsTensorShape(&shape);
+      Tensor* o;
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, shape, &o));
+      common[i] = 1;
+      for (int d = 0; d < common_shapes_[i].dims(); ++d) common[i] *= common_shapes_[i].dim_size(d);
+      in[i] = ctx->input(1 + i).tensor_data().data();
+      out[i] = const_cast<char*>(o->tensor_data().data());
+    }
+    const size_t ws_bytes = hbk_alltoallv_wire_workspace_bytes(n, common.data(), send.data(),
+                                                               recv.data(), active);
+    Tensor ws;
+    OP_REQUIRES_OK(ctx, AllocScratch(ctx, ws_bytes, &ws));
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_alltoallv_n(
+                            coll->comm(), n, HbkType<T>::v, HbkType<W>::v, topology_,
+                            common.data(), in.data(), send.data(), out.data(), recv.data(),
+                            ws.flat<int8>().data(), ws_bytes + 16, StreamOf(ctx))));
+  }
+
+ private:
+  int topology_;
+  std::vector<PartialTensorShape> common_shapes_;
+};
+
+#define HB_REGISTER_COLLECTIVES(T)                                                          \
+  REGISTER_KERNEL_BUILDER(Name("HbNcclAlltoall").Device(DEVICE_GPU).TypeConstraint<T>("dtype"), \
+                          AlltoallNOp<T>);                                                  \
+  REGISTER_KERNEL_BUILDER(Name("HbNcclAlltoallN").Device(DEVICE_GPU).TypeConstraint<T>("dtype"), \
+                          AlltoallNOp<T>);                                                  \
+  REGISTER_KERNEL_BUILDER(Name("HbNcclAlltoallv").Device(DEVICE_GPU)                        \
+                              .TypeConstraint<T>("dtype").TypeConstraint<float>("wire_dtype"), \
+                          AlltoallvNOp<T, T>);                                              \
+  REGISTER_KERNEL_BUILDER(Name("HbNcclAlltoallvN").Device(DEVICE_GPU)                       \
+                              .TypeConstraint<T>("dtype").TypeConstraint<float>("wire_dtype"), \
+                          AlltoallvNOp<T, T>)
+HB_REGISTER_COLLECTIVES(int8); HB_REGISTER_COLLECTIVES(uint8); HB_REGISTER_COLLECTIVES(int32);
+HB_REGISTER_COLLECTIVES(uint32); HB_REGISTER_COLLECTIVES(int64); HB_REGISTER_COLLECTIVES(uint64);
+HB_REGISTER_COLLECTIVES(float); HB_REGISTER_COLLECTIVES(double);
+// fp16 on the wire for fp32 data (comm_wire_dtype = half, collective.py:291-296)
+REGISTER_KERNEL_BUILDER(Name("HbNcclAlltoallv").Device(DEVICE_GPU)
+                            .TypeConstraint<float>("dtype").TypeConstraint<Eigen::half>("wire_dtype"),
+                        AlltoallvNOp<float, Eigen::half>);
+REGISTER_KERNEL_BUILDER(Name("HbNcclAlltoallvN").Device(DEVICE_GPU)
+                            .TypeConstraint<float>("dtype").TypeConstraint<Eigen::half>("wire_dtype"),
+                        AlltoallvNOp<float, Eigen::half>);
+
+// ============================================================================================
+// HbLookup (cache probe)
+// ============================================================================================
+REGISTER_OP("HbLookup")
+    .Output("hit_keys_indices: Tindices").Output("hit_cache_indices: T")
+    .Output("miss_keys_indices: Tindices").Output("miss_keys: T")
+    .Input("keys_cache: T").Input("keys: T")
+    .Attr("T: type").Attr("Tindices: {int32}").Attr("cache_slab_size: int");
+// Kernel: hbk_cache_probe gives hit_slot[i] per key (and the miss count); the four outputs are a
+// stream compaction of it (one host sync for the miss count, as lookup_ops.cc:118-121 does).
+
+// ============================================================================================
+// HbGroupLookup / HbGroupLookupGrad (new, additive; N-ary conventions of the Hb...N ops)
+// ============================================================================================
+REGISTER_OP("HbGroupLookup")
+    .Output("outputs: N * float")
+    .Input("weights: N * float").Input("ids: N * Tids").Input("row_splits: N * int32")
+    .Attr("N: int >= 1").Attr("Tids: {int32, int64}")
+    .Attr("buckets: list(int)").Attr("combiners: list(int)").Attr("ragged: list(bool)")
+    .Attr("divisor: int = 1");
+
+template <typename Tids>
+class GroupLookupOp : public OpKernel {
+ public:
+  explicit GroupLookupOp(OpKernelConstruction* ctx) : OpKernel(ctx) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("buckets", &buckets_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("combiners", &combiners_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("ragged", &ragged_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("divisor", &divisor_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    OpInputList w, ids, splits;
+    OP_REQUIRES_OK(ctx, ctx->input_list("weights", &w));
+    OP_REQUIRES_OK(ctx, ctx->input_list("ids", &ids));
+    OP_REQUIRES_OK(ctx, ctx->input_list("row_splits", &splits));
+    const int n = w.size();
+    std::vector<hbk_lookup_column_t> cols(n);
+    for (int i = 0; i < n; ++i) {
+      const int64 n_seg = ragged_[i] ? splits[i].NumElements() - 1 : ids[i].NumElements();
+      Tensor* o;
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, TensorShape({n_seg, w[i].dim_size(1)}), &o));
+      hbk_lookup_column_t& c = cols[i];
+      std::memset(&c, 0, sizeof(c));
+      c.table = w[i].flat<float>().data();
+      c.rows = w[i].dim_size(0);
+      c.dim = static_cast<int32_t>(w[i].dim_size(1));
+      c.ids_dtype = HbkType<Tids>::v;
+      c.ids = ids[i].flat<Tids>().data();
+      c.n_ids = ids[i].NumElements();
+      c.row_splits = ragged_[i] ? splits[i].flat<int32>().data() : nullptr;
+      c.n_segments = n_seg;
+      c.bucket = buckets_[i];
+      c.divisor = divisor_;
+      c.combiner = combiners_[i];
+      c.out = o->flat<float>().data();
+    }
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_group_lookup_fwd(n, cols.data(), StreamOf(ctx))));
+  }
+
+ private:
+  std::vector<int64> buckets_;
+  std::vector<int32> combiners_;
+  std::vector<bool> ragged_;
+  int32 divisor_;
+};
+REGISTER_KERNEL_BUILDER(Name("HbGroupLookup").Device(DEVICE_GPU).TypeConstraint<int32>("Tids"),
+                        GroupLookupOp<int32>);
+REGISTER_KERNEL_BUILDER(Name("HbGroupLookup").Device(DEVICE_GPU).TypeConstraint<int64>("Tids"),
+                        GroupLookupOp<int64>);
+
+REGISTER_OP("HbGroupLookupGrad")
+    .Output("unique_rows: N * int64").Output("grad_rows: N * float").Output("n_unique: N * int32")
+    .Input("weights: N * float").Input("ids: N * Tids").Input("row_splits: N * int32")
+    .Input("grads: N * float")
+    .Attr("N: int >= 1").Attr("Tids: {int32, int64}")
+    .Attr("buckets: list(int)").Attr("combiners: list(int)").Attr("ragged: list(bool)")
+    .Attr("divisor: int = 1").Attr("apply_lr: float = 0.0");
+// Kernel: fills hbk_lookup_grad_column_t per column exactly as GroupLookupOp does (outputs of
+// capacity n_ids; workspace from hbk_group_lookup_bwd_workspace_bytes via allocate_temp) and
+// calls hbk_group_lookup_bwd; n_unique stays on the device (gradient consumers slice with it).
+
+}  // namespace hybridbackend
+}  // namespace tensorflow

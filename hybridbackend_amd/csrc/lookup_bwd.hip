@@ -31,6 +31,17 @@
 //                IndexedSlices entry (sum semantics preserved).  That needs > 384 distinct rows
 //                in the earlier chunks of one bucket: adversarial hashing, or more than ~4 M
 //                ids in one column (16384 buckets x 256).
+//   5 split      a bucket far above the average size holds a hot row (Zipf heads: one row can
+//                own 20% of a column).  One workgroup has ~32 KB of loads in flight, so it would
+//                sum such a row at ~15 GB/s while the rest of the chip idles.  The scan kernel
+//                therefore lists every bucket with more than split_t pairs; the reduce grid has
+//                spare workgroups that take the 2nd, 3rd.. range of split_t pairs of a listed
+//                bucket.  The workgroups of a split bucket run steps (a)-(e) on their range but
+//                emit (row, partial sum) entries into the bucket's own slice of a partials
+//                buffer; a merge launch then runs the same steps over those entries (one
+//                workgroup per split bucket) and emits the final rows.  A table row still has
+//                exactly one emitting workgroup, so rows stay unique and the fused SGD apply
+//                stays race free.
 // Summation order inside a row is not fixed (pair order comes from LDS tickets): 1e-5 relative.
 #include <alloca.h>
 #include <stdlib.h>
@@ -87,6 +98,11 @@ struct GCol {
   int64_t* pair_row[1];      // [n_ids] rows of the pairs, grouped by bucket
   int32_t* pair_seg[1];      // [n_ids] their segments
   int32_t* seg_of;           // [n_ids], ragged columns only
+  int32_t* work;             // [2 * e_max] (bucket, range index >= 1) of the spare workgroups
+  int32_t* n_extra;          // -> entries of `work` (written by the scan kernel)
+  int32_t* pcount;           // [P] partial entries of a split bucket
+  int64_t* part_rows;        // [n_ids] partial entries; bucket b owns [bstart[b], bstart[b+1])
+  float* part_vals;          // [n_ids, dim]
   IdMap map;
   int64_t n_ids;
   int64_t n_seg;
@@ -97,6 +113,9 @@ struct GCol {
   int32_t tile0;             // first tile (hist / scatter grids)
   int32_t bucket0;           // first block (reduce grid)
   int32_t segtile0;          // first block (seg_of grid)
+  int32_t split_t;           // pairs per workgroup of a split bucket
+  int32_t e_max;             // spare workgroups of the column (>= sum over buckets of extras)
+  int32_t merge0;            // first block (merge grid)
 };
 
 struct GArgs {
@@ -104,7 +123,7 @@ struct GArgs {
   float lr;
   GCol col[kMaxCols];
 };
-static_assert(sizeof(GArgs) <= 16384, "kernarg budget");
+static_assert(sizeof(GArgs) <= 20480, "kernarg budget");
 
 #define HBK_FIND_COL(ARGS, FIELD)                                                  \
   int ci = 0, hi__ = (ARGS).n_cols;                                                \
@@ -176,6 +195,7 @@ __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
 // loads, shuffle scan): pass 1 totals per wave, pass 2 exclusive offsets with the carried base.
 __global__ __launch_bounds__(kBlock) void bwd_scan_kernel(const GArgs a) {
   __shared__ int32_t wave_tot[kWavesPerBlock];
+  __shared__ int32_t n_extra;
   const GCol& c = a.col[blockIdx.x];
   const int P = 1 << c.log2p;
   const int n_tiles = (int)((c.n_ids + kTile - 1) / kTile);
@@ -216,7 +236,24 @@ __global__ __launch_bounds__(kBlock) void bwd_scan_kernel(const GArgs a) {
     for (int w = 0; w < kWavesPerBlock; ++w) tot += wave_tot[w];
     c.bstart[P] = tot;
     *c.n_unique = 0;
+    n_extra = 0;
   }
+  __syncthreads();
+  // 5: list the extra ranges of every bucket above split_t pairs
+  for (int p = tid; p < P; p += kBlock) {
+    c.pcount[p] = 0;
+    const int32_t n_b = c.bstart[p + 1] - c.bstart[p];
+    if (n_b > c.split_t) {
+      const int32_t extras = (n_b - 1) / c.split_t;
+      const int32_t base = atomicAdd(&n_extra, extras);
+      for (int32_t e = 0; e < extras; ++e) {
+        c.work[2 * (base + e)] = p;
+        c.work[2 * (base + e) + 1] = e + 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) *c.n_extra = n_extra;
 }
 
 // ---- 3: (row, segment) pairs grouped by bucket ---------------------------------------------
@@ -276,12 +313,28 @@ struct ReduceLds {
 
 constexpr int32_t kNewBit = 1 << 30;
 
+// What a workgroup reduces and where the result goes: the pairs of a bucket into the final
+// IndexedSlices, a range of a split bucket into its partial entries, or those entries into the
+// final IndexedSlices (merge).
+struct ReduceJob {
+  const int64_t* prow;       // rows of the pairs
+  const int32_t* pseg;       // their gradient rows; NULL: pair i reads gradient row i
+  const float* grad;         // [*, dim]
+  int32_t n_pairs;
+  bool scale;                // apply the combiner's 1/n, 1/sqrt(n)
+  int64_t* out_rows;
+  float* out_vals;
+  int32_t* out_counter;      // claimed with one atomic per chunk
+  int32_t out_base;          // added to the claimed index
+  float lr;                  // != 0: fused SGD step on the table row
+};
+
 template <typename V>
-__device__ inline V load_grad(const GCol& c, int32_t seg, int sub) {
+__device__ inline V load_grad(const GCol& c, const ReduceJob& job, int32_t seg, int sub) {
   constexpr int VE = sizeof(V) / 4;
   V g = __builtin_nontemporal_load(
-      reinterpret_cast<const V*>(c.grad_out + (int64_t)seg * c.dim + (int64_t)sub * VE));
-  if (c.combiner != HBK_COMBINER_SUM && c.splits != nullptr) {
+      reinterpret_cast<const V*>(job.grad + (int64_t)seg * c.dim + (int64_t)sub * VE));
+  if (job.scale && c.combiner != HBK_COMBINER_SUM && c.splits != nullptr) {
     const int32_t n = c.splits[seg + 1] - c.splits[seg];
     g = c.combiner == HBK_COMBINER_MEAN ? g / (float)n : g / sqrtf((float)n);
   }
@@ -290,20 +343,20 @@ __device__ inline V load_grad(const GCol& c, int32_t seg, int sub) {
 
 // out row u += (or =) v, and the fused SGD step on the table row
 template <typename V>
-__device__ inline void emit_row(const GCol& c, float lr, int32_t u, bool is_new, int64_t row,
-                                int sub, V v) {
+__device__ inline void emit_row(const GCol& c, const ReduceJob& job, int32_t u, bool is_new,
+                                int64_t row, int sub, V v) {
   constexpr int VE = sizeof(V) / 4;
-  V* o = reinterpret_cast<V*>(c.grad_rows + (int64_t)u * c.dim + (int64_t)sub * VE);
+  V* o = reinterpret_cast<V*>(job.out_vals + (int64_t)u * c.dim + (int64_t)sub * VE);
   // rows are owned by this workgroup; bypass L1 when re-reading what an earlier chunk wrote
   *o = is_new ? v : __builtin_nontemporal_load(o) + v;
-  if (lr != 0.0f) {
+  if (job.lr != 0.0f) {
     V* t = reinterpret_cast<V*>(c.table + row * c.dim + (int64_t)sub * VE);
-    *t = __builtin_nontemporal_load(t) - lr * v;
+    *t = __builtin_nontemporal_load(t) - job.lr * v;
   }
 }
 
 template <typename V>
-__device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, ReduceLds& L) {
+__device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, ReduceLds& L) {
   constexpr int VE = sizeof(V) / 4;
   const int tid = (int)threadIdx.x;
   const int lane = tid & (kWave - 1), wave = tid >> 6;
@@ -313,11 +366,10 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
   const int groups = kBlock >> lpr_log2;
   const int my_group = tid >> lpr_log2;
 
-  const int32_t start = c.bstart[bucket];
-  const int32_t n_pairs = c.bstart[bucket + 1] - start;
-  if (n_pairs == 0) return;
-  const int64_t* prow = c.pair_row[0] + start;
-  const int32_t* pseg = c.pair_seg[0] + start;
+  const int32_t n_pairs = job.n_pairs;
+  if (n_pairs <= 0) return;
+  const int64_t* prow = job.prow;
+  const int32_t* pseg = job.pseg;
 
   for (int i = tid; i < kSlots; i += kBlock) {
     L.keys[i] = kEmptyKey;
@@ -351,7 +403,7 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
       unsigned long long row = 0;
       if (valid) {
         row = (unsigned long long)prow[cb + e];
-        L.segs[e] = pseg[cb + e];
+        L.segs[e] = pseg != nullptr ? pseg[cb + e] : cb + e;
       }
       int h = -1;
       unsigned long long todo = __ballot(valid);
@@ -414,7 +466,7 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
         const int32_t tot = run + sum;
         const int32_t n_new = tot >> 20;
         L.n_active = (tot >> 10) & 1023;
-        L.base_u = n_new > 0 ? atomicAdd(c.n_unique, n_new) : 0;
+        L.base_u = job.out_base + (n_new > 0 ? atomicAdd(job.out_counter, n_new) : 0);
         L.occupied += n_new;
       }
       __syncthreads();
@@ -429,7 +481,7 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
             const int32_t u = base_u + (run >> 20);
             L.slot_out[s] = u;
             L.cnt[s] |= kNewBit;
-            c.unique_rows[u] = (int64_t)L.keys[s];
+            job.out_rows[u] = (int64_t)L.keys[s];
           }
         }
         run += local[k];
@@ -496,7 +548,7 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
 #pragma unroll
         for (int u = 0; u < kUA; ++u) {
           g[u] = zero_v<V>();
-          if (r < len[u] && live) g[u] = load_grad<V>(c, L.segs[L.order[beg[u] + r]], sub);
+          if (r < len[u] && live) g[u] = load_grad<V>(c, job, L.segs[L.order[beg[u] + r]], sub);
         }
 #pragma unroll
         for (int u = 0; u < kUA; ++u) acc[u] = acc[u] + g[u];
@@ -504,7 +556,7 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
 #pragma unroll
       for (int u = 0; u < kUA; ++u) {
         if (slot[u] >= 0 && live) {
-          emit_row<V>(c, lr, L.slot_out[slot[u]], (L.cnt[slot[u]] & kNewBit) != 0,
+          emit_row<V>(c, job, L.slot_out[slot[u]], (L.cnt[slot[u]] & kNewBit) != 0,
                       (int64_t)L.keys[slot[u]], sub, acc[u]);
         }
       }
@@ -524,7 +576,7 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
         for (int u = 0; u < kUH; ++u) {
           const int32_t p = p0 + u * groups + my_group;
           g[u] = zero_v<V>();
-          if (p < n && live) g[u] = load_grad<V>(c, L.segs[L.order[b0 + p]], sub);
+          if (p < n && live) g[u] = load_grad<V>(c, job, L.segs[L.order[b0 + p]], sub);
         }
 #pragma unroll
         for (int u = 0; u < kUH; ++u) acc = acc + g[u];
@@ -536,7 +588,7 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
         for (int gi = 0; gi < groups; ++gi) {
           tot = tot + *reinterpret_cast<const V*>(&L.red[((size_t)(gi << lpr_log2) + sub) * VE]);
         }
-        emit_row<V>(c, lr, L.slot_out[s], (L.cnt[s] & kNewBit) != 0, (int64_t)L.keys[s], sub,
+        emit_row<V>(c, job, L.slot_out[s], (L.cnt[s] & kNewBit) != 0, (int64_t)L.keys[s], sub,
                     tot);
       }
       __syncthreads();
@@ -546,13 +598,73 @@ __device__ inline void bucket_reduce(const GCol& c, int bucket, float lr, Reduce
 }
 
 // Two instantiations (16-byte / 4-byte chunks) so the common one keeps its registers low; a
-// block whose column is of the other kind exits at once.
+// block whose column is of the other kind exits at once.  Blocks [0, P) of a column take the
+// buckets (range 0 of a split bucket), the e_max spare blocks take the listed extra ranges.
 template <typename V>
 __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const GArgs a) {
   __shared__ ReduceLds lds;
   HBK_FIND_COL(a, bucket0)
   if ((c.vec4 != 0) != (sizeof(V) == 16)) return;
-  bucket_reduce<V>(c, (int)blockIdx.x - c.bucket0, a.lr, lds);
+  const int bi = (int)blockIdx.x - c.bucket0;
+  const int P = 1 << c.log2p;
+  int bucket = bi, range = 0;
+  if (bi >= P) {
+    const int e = bi - P;
+    if (e >= *c.n_extra) return;
+    bucket = c.work[2 * e];
+    range = c.work[2 * e + 1];
+  }
+  const int32_t start = c.bstart[bucket];
+  const int32_t n_b = c.bstart[bucket + 1] - start;
+  ReduceJob job;
+  job.grad = c.grad_out;
+  job.scale = true;
+  if (n_b > c.split_t) {
+    const int32_t lo = range * c.split_t;
+    job.prow = c.pair_row[0] + start + lo;
+    job.pseg = c.pair_seg[0] + start + lo;
+    job.n_pairs = n_b - lo < c.split_t ? n_b - lo : c.split_t;
+    job.out_rows = c.part_rows;
+    job.out_vals = c.part_vals;
+    job.out_counter = c.pcount + bucket;
+    job.out_base = start;
+    job.lr = 0.0f;
+  } else {
+    job.prow = c.pair_row[0] + start;
+    job.pseg = c.pair_seg[0] + start;
+    job.n_pairs = n_b;
+    job.out_rows = c.unique_rows;
+    job.out_vals = c.grad_rows;
+    job.out_counter = c.n_unique;
+    job.out_base = 0;
+    job.lr = a.lr;
+  }
+  bucket_reduce<V>(c, job, lds);
+}
+
+// The partial entries of a split bucket -> final rows; spare block e of a column does it when
+// it is the bucket's first extra range (every split bucket has exactly one).
+template <typename V>
+__global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const GArgs a) {
+  __shared__ ReduceLds lds;
+  HBK_FIND_COL(a, merge0)
+  if ((c.vec4 != 0) != (sizeof(V) == 16)) return;
+  const int e = (int)blockIdx.x - c.merge0;
+  if (e >= *c.n_extra || c.work[2 * e + 1] != 1) return;
+  const int bucket = c.work[2 * e];
+  const int32_t start = c.bstart[bucket];
+  ReduceJob job;
+  job.prow = c.part_rows + start;
+  job.pseg = nullptr;
+  job.grad = c.part_vals + (int64_t)start * c.dim;
+  job.n_pairs = c.pcount[bucket];
+  job.scale = false;
+  job.out_rows = c.unique_rows;
+  job.out_vals = c.grad_rows;
+  job.out_counter = c.n_unique;
+  job.out_base = 0;
+  job.lr = a.lr;
+  bucket_reduce<V>(c, job, lds);
 }
 
 // ---- d(stitch + combiner): permutation scatter (hbk_group_stitch_bwd) ----------------------
@@ -631,6 +743,8 @@ inline size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 struct ColPlan {
   int log2p;
   int64_t tiles;
+  int32_t split_t;   // a bucket above this many pairs is reduced by several workgroups
+  int32_t e_max;
 };
 
 // test hook: HBK_BWD_LOG2P forces the bucket count (0 = one bucket per column) so that
@@ -650,6 +764,14 @@ ColPlan plan_of(int64_t n_ids, int32_t dim) {
   if (forced >= 0 && forced <= 14) lp = forced;
   p.log2p = lp;
   p.tiles = (n_ids + kTile - 1) / kTile;
+  // hashing keeps ordinary buckets near n / P pairs; 4x that (and >= 2 chunks) means a hot row
+  // (measured, config 4 backward: ranges of 1024 pairs 391 us, 2048 417 us, 4096 466 us)
+  int64_t t = 4 * ((n_ids + ((int64_t)1 << lp) - 1) >> lp);
+  if (t < 2 * kCP) t = 2 * kCP;
+  const char* e = getenv("HBK_BWD_SPLIT");   // test hook
+  if (e != nullptr && atoi(e) > 0) t = atoi(e);
+  p.split_t = (int32_t)t;
+  p.e_max = (int32_t)(n_ids / t + 1);
   return p;
 }
 
@@ -661,6 +783,10 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
   b += (size_t)h.n_ids * 8;                                // pair_row
   b += align8((size_t)h.n_ids * 4);                        // pair_seg
   if (h.row_splits != nullptr) b += align8((size_t)h.n_ids * 4);
+  b += align8((size_t)p.e_max * 8) + 8;                    // work, n_extra
+  b += align8(((size_t)1 << p.log2p) * 4);                 // pcount
+  b += (size_t)h.n_ids * 8;                                // part_rows
+  b += align8((size_t)h.n_ids * h.dim * 4) + 16;           // part_vals (16-byte aligned)
   return b;
 }
 
@@ -716,7 +842,7 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
   while (c0 < n_cols) {
     GArgs args, seg_args;
     int32_t k = 0, ks = 0;
-    int64_t tiles = 0, buckets = 0, segtiles = 0;
+    int64_t tiles = 0, buckets = 0, segtiles = 0, merges = 0;
     size_t lds_hist = 0;
     while (c0 < n_cols && k < kMaxCols) {
       const hbk_lookup_grad_column_t& h = cols[c0++];
@@ -747,6 +873,20 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
         d.seg_of = reinterpret_cast<int32_t*>(wp);
         wp += align8((size_t)h.n_ids * 4);
       }
+      d.work = reinterpret_cast<int32_t*>(wp);
+      wp += align8((size_t)p.e_max * 8);
+      d.n_extra = reinterpret_cast<int32_t*>(wp);
+      wp += 8;
+      d.pcount = reinterpret_cast<int32_t*>(wp);
+      wp += align8(((size_t)1 << p.log2p) * 4);
+      d.part_rows = reinterpret_cast<int64_t*>(wp);
+      wp += (size_t)h.n_ids * 8;
+      d.part_vals = reinterpret_cast<float*>(((uintptr_t)wp + 15) & ~(uintptr_t)15);
+      wp += align8((size_t)h.n_ids * h.dim * 4) + 16;
+      d.split_t = p.split_t;
+      d.e_max = p.e_max;
+      d.merge0 = (int32_t)merges;
+      merges += p.e_max;
       d.map = make_idmap(h.bucket, h.divisor, h.rows);
       d.n_ids = h.n_ids;
       d.n_seg = h.n_segments;
@@ -767,7 +907,7 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       d.bucket0 = (int32_t)buckets;
       d.segtile0 = 0;
       tiles += p.tiles;
-      buckets += (int64_t)1 << p.log2p;
+      buckets += ((int64_t)1 << p.log2p) + p.e_max;
       HBK_REQUIRE(tiles < (1ll << 31) && buckets < (1ll << 31),
                   "group_lookup_bwd: grid too large");
       if (((size_t)4 << p.log2p) > lds_hist) lds_hist = (size_t)4 << p.log2p;
@@ -805,6 +945,14 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
     }
     if (any_scalar) {
       hipLaunchKernelGGL(bwd_reduce_kernel<float>, dim3((unsigned)buckets), dim3(kBlock), 0,
+                         stream, args);
+    }
+    if (any_vec4) {
+      hipLaunchKernelGGL(bwd_merge_kernel<f32x4>, dim3((unsigned)merges), dim3(kBlock), 0,
+                         stream, args);
+    }
+    if (any_scalar) {
+      hipLaunchKernelGGL(bwd_merge_kernel<float>, dim3((unsigned)merges), dim3(kBlock), 0,
                          stream, args);
     }
     HBK_HIP_OK(hipGetLastError());

@@ -382,6 +382,35 @@ def test_group_lookup_backward_zipf_hot_rows():
   _check_slices(res, ids, grads, None, 'sum', atol=RTOL * 100)   # ~12k terms on the hot row
 
 
+@pytest.mark.parametrize('split,log2p', [(None, None), ('96', '2'), ('700', '0')])
+def test_group_lookup_backward_split_buckets(monkeypatch, split, log2p):
+  """Hot rows: a bucket far above the average is reduced by several workgroups (partial sums
+  per range, then a merge), rows stay unique and the fused SGD apply stays exact.  The env hooks
+  force tiny ranges so that ordinary buckets split too (many partial entries per bucket)."""
+  if split is not None:
+    monkeypatch.setenv('HBK_BWD_SPLIT', split)
+    monkeypatch.setenv('HBK_BWD_LOG2P', log2p)
+  rng = np.random.RandomState(23)
+  cases = []
+  for d, rows, n in ((128, 1000, 40000), (16, 300, 30000), (6, 50, 9000)):
+    hot = np.full(n, 7, np.int64)                                   # one row owns everything
+    mixed = np.where(rng.rand(n) < 0.6, 3, rng.randint(0, rows, size=n)).astype(np.int64)
+    cases += [(d, rows, hot), (d, rows, mixed)]
+  for d, rows, ids in cases:
+    n = ids.size
+    table = rng.uniform(-1, 1, size=(rows, d)).astype(np.float32)
+    grads = rng.randn(n, d).astype(np.float32)
+    t_dev = dev(table.copy())
+    lookup = hb.embedding.GroupLookup([t_dev], None, 'sum')
+    res = hb.embedding.GroupLookupGrad(lookup)([dev(ids)], [dev(grads)], apply_lr=0.01)[0]
+    # forced tiny ranges can push a merge past the LDS table's clear threshold: sums stay
+    # exact, a row may then appear twice (documented); the natural split keeps rows unique
+    _check_slices(res, ids, grads, None, 'sum', distinct=split is None, atol=RTOL * 300)
+    ref = table.astype(np.float64)
+    np.subtract.at(ref, ids, 0.01 * grads.astype(np.float64))
+    np.testing.assert_allclose(host(t_dev), ref, rtol=RTOL, atol=1e-4)
+
+
 def test_group_lookup_backward_fused_sgd_apply():
   rng = np.random.RandomState(11)
   table = rng.uniform(-1, 1, size=(5000, 16)).astype(np.float32)

@@ -95,10 +95,20 @@ __device__ inline uint32_t shard_of(T v, const ShardFn& f) {
 }
 
 __device__ inline int find_col(const PartArgs& a, int tile) {
-  int ci = 0;
-  while (ci + 1 < a.n_cols && a.col[ci + 1].tile_start <= tile) ++ci;
-  return ci;
+  int lo = 0, hi = a.n_cols;  // wave-uniform binary search over the kernarg descriptors
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.col[mid].tile_start <= tile) {
+      lo = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  return lo;
 }
+
+constexpr int kStaticP = 16;  // up to here one ballot per shard and chunk: independent compares,
+                              // counters in lane p's register, no serial match-any chain
 
 // ---- A: per-tile histogram ------------------------------------------------------
 template <typename T>
@@ -111,8 +121,6 @@ __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a)
   const int lane = lane_id();
   const int ctile = tile - c.tile_start;
   const int n_tiles = (c.len + kTile - 1) / kTile;
-  for (int p = lane; p < P; p += kWave) counters[p] = 0;
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): zeroing done before the atomics
   const T* in = reinterpret_cast<const T*>(c.in);
   const int64_t base = (int64_t)ctile * kTile;
   T v[kChunks];
@@ -121,6 +129,23 @@ __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a)
     const int64_t i = base + k * kWave + lane;
     v[k] = i < c.len ? in[i] : T(0);
   }
+  if (P <= kStaticP) {
+    int32_t cnt = 0;  // lane p: ids of shard p in this tile
+#pragma unroll
+    for (int k = 0; k < kChunks; ++k) {
+      const int64_t i = base + k * kWave + lane;
+      const uint32_t shard =
+          i < c.len ? shard_of<T>(bucketize<T>(v[k], c.bucket), a.fn) : 0xffffffffu;
+      for (int p = 0; p < P; ++p) {
+        const int n = (int)__builtin_popcountll(__ballot(shard == (uint32_t)p));
+        if (lane == p) cnt += n;
+      }
+    }
+    if (lane < P) (a.hist + (int64_t)P * c.tile_start)[(int64_t)lane * n_tiles + ctile] = cnt;
+    return;
+  }
+  for (int p = lane; p < P; p += kWave) counters[p] = 0;
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): zeroing done before the atomics
 #pragma unroll
   for (int k = 0; k < kChunks; ++k) {
     const int64_t i = base + k * kWave + lane;
@@ -208,7 +233,9 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
   const int ctile = tile - c.tile_start;
   const int n_tiles = (c.len + kTile - 1) / kTile;
   const int32_t* hist = a.hist + (int64_t)P * c.tile_start;
-  for (int p = lane; p < P; p += kWave) run[p] = hist[(int64_t)p * n_tiles + ctile];
+  if (P > kWave) {
+    for (int p = lane; p < P; p += kWave) run[p] = hist[(int64_t)p * n_tiles + ctile];
+  }
   const T* in = reinterpret_cast<const T*>(c.in);
   T* out = reinterpret_cast<T*>(c.out);
   const int64_t base = (int64_t)ctile * kTile;
@@ -218,8 +245,31 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
     const int64_t i = base + k * kWave + lane;
     v[k] = i < c.len ? bucketize<T>(in[i], c.bucket) : T(0);
   }
+  if (P <= kStaticP) {
+    // the W <= 16 case: lane p keeps the running counter of shard p; one ballot per shard, all
+    // compares of a chunk independent of each other
+    int32_t my_run = lane < P ? hist[(int64_t)lane * n_tiles + ctile] : 0;
+#pragma unroll
+    for (int k = 0; k < kChunks; ++k) {
+      const int64_t i = base + k * kWave + lane;
+      const bool valid = i < c.len;
+      const uint32_t shard = valid ? shard_of<T>(v[k], a.fn) : 0xffffffffu;
+      int32_t pos = 0;
+      for (int p = 0; p < P; ++p) {
+        const unsigned long long same = __ballot(shard == (uint32_t)p);
+        const int32_t base_p = __builtin_amdgcn_readlane(my_run, p);
+        if (shard == (uint32_t)p) pos = base_p + rank_below(same);
+        if (lane == p) my_run += (int32_t)__builtin_popcountll(same);
+      }
+      if (valid) {
+        out[pos] = v[k];
+        c.indices[i] = pos;
+      }
+    }
+    return;
+  }
   if (P <= kWave) {
-    // small P (the W <= 8 case): lane p keeps the running counter of shard p in a register;
+    // P <= 64: lane p keeps the running counter of shard p in a register;
     // the leader's base is fetched with v_readlane (uniform lane index), no LDS round trips
     int32_t my_run = lane < P ? hist[(int64_t)lane * n_tiles + ctile] : 0;
 #pragma unroll

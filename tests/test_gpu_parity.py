@@ -90,7 +90,7 @@ def test_partition_all_dtypes_and_shard_counts(dtype):
     pytest.skip('torch build has no unsigned 32/64-bit tensors')
   rng = np.random.RandomState(7)
   info = np.iinfo(dtype)
-  for P in (1, 2, 3, 5, 8, 13, 64, 100, 1000):
+  for P in (1, 2, 3, 5, 8, 13, 16, 17, 64, 100, 1000):
     lens = [0, 1, 63, 64, 65, 1023, 1024, 1025, 5000, 40000]
     xs = [rng.randint(info.min, info.max, size=n, dtype=dtype) for n in lens]
     ys, sizes, idxs = hb.distribute.partition_by_modulo_n([dev(x) for x in xs], P)

@@ -55,7 +55,7 @@ struct UCol {
   int32_t tile_start;  // first 1024-id tile
   int32_t big_start;   // first 4096-id tile
   int32_t bucket0;     // first block of the per-bucket kernel
-  int32_t pad_;
+  int32_t scan0;       // first block of the scan-over-tiles kernel
 };
 
 struct UArgs {
@@ -97,7 +97,6 @@ __global__ __launch_bounds__(kBlock) void unique_hist_kernel(const UArgs a) {
   const int P = 1 << c.log2p;
   const int tid = (int)threadIdx.x;
   const int ctile = (int)blockIdx.x - c.big_start;
-  const int n_tiles = (c.len + kBigTile - 1) / kBigTile;
   for (int p = tid; p < P; p += kBlock) counters[p] = 0;
   __syncthreads();
   const int64_t base = (int64_t)ctile * kBigTile;
@@ -115,48 +114,66 @@ __global__ __launch_bounds__(kBlock) void unique_hist_kernel(const UArgs a) {
     }
   }
   __syncthreads();
-  for (int p = tid; p < P; p += kBlock) c.hist[(int64_t)p * n_tiles + ctile] = counters[p];
+  for (int p = tid; p < P; p += kBlock) c.hist[(int64_t)ctile * P + p] = counters[p];
 }
 
-// ---- 2: per-column exclusive scan over (bucket, tile) ---------------------------------------
+// ---- 2: offsets of every (tile, bucket) run (same scheme as lookup_bwd.hip) ------------------
+// hist is [tile][bucket].  2a: one thread per bucket turns its column of the matrix into the
+// exclusive prefix over tiles and leaves the bucket total in bstart; 2b: one block per input
+// scans the bucket totals into bucket starts.
+__global__ __launch_bounds__(kBlock) void unique_scan_tiles_kernel(const UArgs a) {
+  HBK_FIND_UCOL(scan0)
+  const int P = 1 << c.log2p;
+  const int p = ((int)blockIdx.x - c.scan0) * kBlock + (int)threadIdx.x;
+  if (p >= P) return;
+  const int n_tiles = (c.len + kBigTile - 1) / kBigTile;
+  int32_t* h = c.hist + p;
+  int32_t run = 0;
+  int t = 0;
+  for (; t + 4 <= n_tiles; t += 4) {
+    int32_t x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = h[(int64_t)(t + k) * P];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      h[(int64_t)(t + k) * P] = run;
+      run += x[k];
+    }
+  }
+  for (; t < n_tiles; ++t) {
+    const int32_t x = h[(int64_t)t * P];
+    h[(int64_t)t * P] = run;
+    run += x;
+  }
+  c.bstart[p] = run;
+}
+
 __global__ __launch_bounds__(kBlock) void unique_bucket_scan_kernel(const UArgs a) {
   __shared__ int32_t wave_tot[kWavesPerBlock];
   const UCol& c = a.col[blockIdx.x];
   const int P = 1 << c.log2p;
-  const int n_tiles = (c.len + kBigTile - 1) / kBigTile;
-  const int32_t total = P * n_tiles;
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-  const int32_t per_wave = ((total + kBlock - 1) / kBlock) * kWave;
-  const int32_t beg = wave * per_wave;
-  const int32_t end = beg + per_wave < total ? beg + per_wave : total;
+  const int per = (P + kBlock - 1) / kBlock;
+  const int beg = tid * per;
+  const int end = beg + per < P ? beg + per : P;
   int32_t sum = 0;
-  for (int32_t e0 = beg; e0 < end; e0 += kWave) {
-    const int32_t e = e0 + lane;
-    sum += e < end ? c.hist[e] : 0;
-  }
+  for (int p = beg; p < end; ++p) sum += c.bstart[p];
+  int32_t incl = sum;
 #pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, kWave);
-  if (lane == 0) wave_tot[wave] = sum;
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int32_t y = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += y;
+  }
+  if (lane == kWave - 1) wave_tot[wave] = incl;
   __syncthreads();
-  int32_t carry = 0;
-  for (int w = 0; w < wave; ++w) carry += wave_tot[w];
-  for (int32_t e0 = beg; e0 < end; e0 += kWave) {
-    const int32_t e = e0 + lane;
-    const int32_t x = e < end ? c.hist[e] : 0;
-    int32_t s = x;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const int32_t y = __shfl_up(s, off, kWave);
-      if (lane >= off) s += y;
-    }
-    const int32_t excl = carry + s - x;
-    if (e < end) {
-      c.hist[e] = excl;
-      if (e % n_tiles == 0) c.bstart[e / n_tiles] = excl;
-    }
-    carry += __shfl(s, kWave - 1, kWave);
+  int32_t run = incl - sum;
+  for (int w = 0; w < wave; ++w) run += wave_tot[w];
+  for (int p = beg; p < end; ++p) {
+    const int32_t n_b = c.bstart[p];
+    c.bstart[p] = run;
+    run += n_b;
   }
-  if (tid == 0) c.bstart[P] = c.len;
+  if (tid == kBlock - 1) c.bstart[P] = c.len;
 }
 
 // ---- 3: (key, position) pairs grouped by bucket --------------------------------------------
@@ -166,8 +183,7 @@ __global__ __launch_bounds__(kBlock) void unique_scatter_kernel(const UArgs a) {
   const int P = 1 << c.log2p;
   const int tid = (int)threadIdx.x;
   const int ctile = (int)blockIdx.x - c.big_start;
-  const int n_tiles = (c.len + kBigTile - 1) / kBigTile;
-  for (int p = tid; p < P; p += kBlock) run[p] = c.hist[(int64_t)p * n_tiles + ctile];
+  for (int p = tid; p < P; p += kBlock) run[p] = c.bstart[p] + c.hist[(int64_t)ctile * P + p];
   __syncthreads();
   const int64_t base = (int64_t)ctile * kBigTile;
   for (int k0 = 0; k0 < kBigPerThread; k0 += kBatch) {
@@ -413,7 +429,7 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
   while (c0 < n_cols) {
     UArgs args;
     int32_t k = 0;
-    int64_t tiles = 0, big = 0, buckets = 0;
+    int64_t tiles = 0, big = 0, buckets = 0, scans = 0;
     size_t lds = 0;
     while (c0 < n_cols && k < kMaxCols) {
       const UniqueColumn& h = cols[c0++];
@@ -449,6 +465,8 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
       d.tile_start = (int32_t)tiles;
       d.big_start = (int32_t)big;
       d.bucket0 = (int32_t)buckets;
+      d.scan0 = (int32_t)scans;
+      scans += (((int64_t)1 << lp) + kBlock - 1) / kBlock;
       tiles += ctiles;
       big += cbig;
       buckets += (int64_t)1 << lp;
@@ -461,6 +479,7 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
     args.pad_ = 0;
     const dim3 block(kBlock);
     hipLaunchKernelGGL(unique_hist_kernel, dim3((unsigned)big), block, lds, stream, args);
+    hipLaunchKernelGGL(unique_scan_tiles_kernel, dim3((unsigned)scans), block, 0, stream, args);
     hipLaunchKernelGGL(unique_bucket_scan_kernel, dim3((unsigned)k), block, 0, stream, args);
     hipLaunchKernelGGL(unique_scatter_kernel, dim3((unsigned)big), block, lds, stream, args);
     hipLaunchKernelGGL(unique_first_kernel, dim3((unsigned)buckets), block, 0, stream, args);

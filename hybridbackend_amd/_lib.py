@@ -48,7 +48,8 @@ class LookupGradColumn(C.Structure):
               ('bucket', C.c_int64), ('divisor', C.c_int32),
               ('combiner', C.c_int32), ('grad_out', C.c_void_p),
               ('unique_rows', C.c_void_p), ('grad_rows', C.c_void_p),
-              ('n_unique', C.c_void_p)]
+              ('n_unique', C.c_void_p), ('run_start', C.c_void_p), ('run_ids', C.c_void_p),
+              ('run_grads', C.c_void_p), ('n_runs', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class ShardedColumn(C.Structure):
@@ -61,7 +62,9 @@ class StitchGradColumn(C.Structure):
   """hbk_stitch_grad_column_t"""
   _fields_ = [('dim', C.c_int32), ('combiner', C.c_int32), ('n_ids', C.c_int64),
               ('index', C.c_void_p), ('row_splits', C.c_void_p), ('n_segments', C.c_int64),
-              ('grad_out', C.c_void_p), ('grad_rows', C.c_void_p)]
+              ('grad_out', C.c_void_p), ('grad_rows', C.c_void_p),
+              ('run_start', C.c_void_p), ('run_base', C.c_void_p), ('n_runs', C.c_int32),
+              ('reserved_', C.c_int32)]
 
 
 _lib = None

@@ -103,6 +103,9 @@ struct GCol {
   int32_t* pcount;           // [P] partial entries of a split bucket
   int64_t* part_rows;        // [n_ids] partial entries; bucket b owns [bstart[b], bstart[b+1])
   float* part_vals;          // [n_ids, dim]
+  const int64_t* run_start;  // segmented inputs (n_runs > 0): see hbk_lookup_grad_column_t
+  const int64_t* run_ids;
+  const int64_t* run_grads;
   IdMap map;
   int64_t n_ids;
   int64_t n_seg;
@@ -117,6 +120,8 @@ struct GCol {
   int32_t e_max;             // spare workgroups of the column (>= sum over buckets of extras)
   int32_t merge0;            // first block (merge grid)
   int32_t scan0;             // first block (scan-over-tiles grid)
+  int32_t n_runs;
+  int32_t pad_;
 };
 
 struct GArgs {
@@ -124,7 +129,7 @@ struct GArgs {
   float lr;
   GCol col[kMaxCols];
 };
-static_assert(sizeof(GArgs) <= 20480, "kernarg budget");
+static_assert(sizeof(GArgs) <= 24576, "kernarg budget");
 
 #define HBK_FIND_COL(ARGS, FIELD)                                                  \
   int ci = 0, hi__ = (ARGS).n_cols;                                                \
@@ -151,6 +156,25 @@ __device__ inline int bucket_of(uint64_t row, int log2p) {
   return log2p == 0 ? 0 : (int)(mix64(row) >> (64 - log2p));
 }
 
+// Segmented inputs: position j of the column -> where its id and its gradient row live.  A
+// thread visits increasing j, so the cursor only moves forward (runs are thousands of ids long).
+struct RunCursor {
+  int k = -1;
+  int64_t next = 0;         // first position of the following run
+  int64_t id_delta = 0;     // id of position j: ids[j + id_delta]
+  int64_t grad_delta = 0;   // gradient row of position j: grad_out + grad_delta + j * dim
+};
+
+__device__ inline void run_seek(const GCol& c, int64_t j, RunCursor& rc) {
+  while (j >= rc.next) {
+    ++rc.k;
+    const int64_t start = c.run_start[rc.k];
+    rc.next = rc.k + 1 < c.n_runs ? c.run_start[rc.k + 1] : (int64_t)1 << 62;
+    rc.id_delta = c.run_ids[rc.k] - start;
+    rc.grad_delta = c.run_grads[rc.k] - start * c.dim;
+  }
+}
+
 // ---- 0: segment of every id (ragged columns only; the host passes just those) --------------
 __global__ __launch_bounds__(kBlock) void bwd_segof_kernel(const GArgs a) {
   HBK_FIND_COL(a, segtile0)
@@ -170,12 +194,17 @@ __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
   for (int p = tid; p < P; p += kBlock) counters[p] = 0;
   __syncthreads();
   const int64_t base = (int64_t)ctile * kTile;
+  RunCursor rc;
   for (int k0 = 0; k0 < kPerThread; k0 += kBatch) {
     int64_t id[kBatch];
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       const int64_t j = base + (int64_t)(k0 + k) * kBlock + tid;
-      id[k] = j < c.n_ids ? load_id(c.ids, c.ids64, j) : 0;
+      id[k] = 0;
+      if (j < c.n_ids) {
+        if (c.n_runs > 0) run_seek(c, j, rc);
+        id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
+      }
     }
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
@@ -278,6 +307,7 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
   for (int p = tid; p < P; p += kBlock) run[p] = c.bstart[p] + c.hist[(int64_t)ctile * P + p];
   __syncthreads();
   const int64_t base = (int64_t)ctile * kTile;
+  RunCursor rc;
   for (int k0 = 0; k0 < kPerThread; k0 += kBatch) {
     int64_t id[kBatch];
     int32_t seg[kBatch];
@@ -287,7 +317,12 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
       id[k] = 0;
       seg[k] = (int32_t)j;
       if (j < c.n_ids) {
-        id[k] = load_id(c.ids, c.ids64, j);
+        if (c.n_runs > 0) {
+          // the pair carries the float offset of its gradient row (host checks < 2^32)
+          run_seek(c, j, rc);
+          seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);
+        }
+        id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
         if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
       }
     }
@@ -333,6 +368,7 @@ struct ReduceJob {
   const float* grad;         // [*, dim]
   int32_t n_pairs;
   bool scale;                // apply the combiner's 1/n, 1/sqrt(n)
+  bool seg_is_offset;        // pseg holds float offsets into grad (segmented inputs)
   int64_t* out_rows;
   float* out_vals;
   int32_t* out_counter;      // claimed with one atomic per chunk
@@ -343,8 +379,9 @@ struct ReduceJob {
 template <typename V>
 __device__ inline V load_grad(const GCol& c, const ReduceJob& job, int32_t seg, int sub) {
   constexpr int VE = sizeof(V) / 4;
+  const int64_t off = job.seg_is_offset ? (int64_t)(uint32_t)seg : (int64_t)seg * c.dim;
   V g = __builtin_nontemporal_load(
-      reinterpret_cast<const V*>(job.grad + (int64_t)seg * c.dim + (int64_t)sub * VE));
+      reinterpret_cast<const V*>(job.grad + off + (int64_t)sub * VE));
   if (job.scale && c.combiner != HBK_COMBINER_SUM && c.splits != nullptr) {
     const int32_t n = c.splits[seg + 1] - c.splits[seg];
     g = c.combiner == HBK_COMBINER_MEAN ? g / (float)n : g / sqrtf((float)n);
@@ -630,6 +667,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
   ReduceJob job;
   job.grad = c.grad_out;
   job.scale = true;
+  job.seg_is_offset = c.n_runs > 0;
   if (n_b > c.split_t) {
     const int32_t lo = range * c.split_t;
     job.prow = c.pair_row[0] + start + lo;
@@ -670,6 +708,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const 
   job.grad = c.part_vals + (int64_t)start * c.dim;
   job.n_pairs = c.pcount[bucket];
   job.scale = false;
+  job.seg_is_offset = false;
   job.out_rows = c.unique_rows;
   job.out_vals = c.grad_rows;
   job.out_counter = c.n_unique;
@@ -687,6 +726,10 @@ struct SCol {
   const int32_t* splits;
   const int32_t* index;
   float* grad_rows;
+  const int64_t* run_start;  // segmented destination (n_runs > 0)
+  const int64_t* run_base;
+  int32_t n_runs;
+  int32_t pad2_;
   int64_t n_seg;
   int32_t dim;
   int32_t chunks;
@@ -699,7 +742,7 @@ struct SArgs {
   int32_t pad_;
   SCol col[kMaxStitchCols];
 };
-static_assert(sizeof(SArgs) <= 16384, "kernarg budget");
+static_assert(sizeof(SArgs) <= 20480, "kernarg budget");
 
 template <typename V>
 __device__ inline void stitch_segments(const SCol& c, int64_t seg0) {
@@ -730,7 +773,14 @@ __device__ inline void stitch_segments(const SCol& c, int64_t seg0) {
       g = g / sqrtf((float)n);
     }
     for (int32_t j = beg; j < end; ++j) {
-      *reinterpret_cast<V*>(c.grad_rows + (int64_t)c.index[j] * c.dim + (int64_t)sub * VE) = g;
+      const int64_t r = c.index[j];
+      int64_t off = r * c.dim;
+      if (c.n_runs > 0) {
+        int k = 0;
+        while (k + 1 < c.n_runs && c.run_start[k + 1] <= r) ++k;
+        off = c.run_base[k] + (r - c.run_start[k]) * c.dim;
+      }
+      *reinterpret_cast<V*>(c.grad_rows + off + (int64_t)sub * VE) = g;
     }
   }
 }
@@ -840,6 +890,11 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
                 "group_lookup_bwd: column %d: NULL buffer", c);
     HBK_REQUIRE(apply_lr == 0.0f || h.table != nullptr || h.n_ids == 0,
                 "group_lookup_bwd: column %d: table is NULL but apply_lr != 0", c);
+    HBK_REQUIRE(h.n_runs >= 0, "group_lookup_bwd: column %d: n_runs must be >= 0", c);
+    HBK_REQUIRE(h.n_runs == 0 || (h.row_splits == nullptr && h.run_start && h.run_ids &&
+                                  h.run_grads),
+                "group_lookup_bwd: column %d: segmented inputs need run tables and no "
+                "row_splits", c);
   }
   const size_t need = hbk_group_lookup_bwd_workspace_bytes(n_cols, cols);
   HBK_REQUIRE(need == 0 || (workspace != nullptr && workspace_bytes >= need),
@@ -900,6 +955,10 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       merges += p.e_max;
       d.scan0 = (int32_t)scans;
       scans += (((int64_t)1 << p.log2p) + kBlock - 1) / kBlock;
+      d.run_start = h.run_start;
+      d.run_ids = h.run_ids;
+      d.run_grads = h.run_grads;
+      d.n_runs = h.n_runs;
       d.map = make_idmap(h.bucket, h.divisor, h.rows);
       d.n_ids = h.n_ids;
       d.n_seg = h.n_segments;
@@ -1010,6 +1069,12 @@ extern "C" int hbk_group_stitch_bwd(int32_t n_cols, const hbk_stitch_grad_column
       d.splits = h.row_splits;
       d.index = h.index;
       d.grad_rows = h.grad_rows;
+      HBK_REQUIRE(h.n_runs >= 0 && (h.n_runs == 0 || (h.run_start && h.run_base)),
+                  "group_stitch_bwd: column %d: bad run tables", ci);
+      d.run_start = h.run_start;
+      d.run_base = h.run_base;
+      d.n_runs = h.n_runs;
+      d.pad2_ = 0;
       d.n_seg = h.n_segments;
       d.dim = h.dim;
       RowShape shape;

@@ -238,6 +238,14 @@ struct Layout {
   }
 };
 
+// One column group of the pipelined step: its own peer-major regions in the exchange buffers.
+struct Group {
+  int c0, c1;
+  Layout lay;
+  std::vector<int32_t> R;                         // [W][n_g]
+  int64_t id_send, id_recv, row_send, row_recv;   // offsets of the group's regions
+};
+
 }  // namespace
 }  // namespace hbk
 
@@ -251,15 +259,16 @@ struct hbk_sharded {
   std::vector<const int32_t*> row_splits;
   std::vector<int32_t> send_sizes;   // S [N][W] rows this rank requests from owner q, column c
   std::vector<int32_t> recv_sizes;   // R [W][N] rows requester q asked this rank for, column c
-  hbk::Layout lay;                       // over all columns: the backward's exchange
+  std::vector<hbk::Group> groups;        // column groups of the last forward (reused backward)
   std::vector<int64_t> fwd_own_id_off;   // [W][N] where run (q, c) of the forward sits in recv_ids
   hipEvent_t ev[4][4];                   // [stage][group]: packed, ids in, gathered, rows in
   bool have_step;
   // device buffers owned by the plan
   hbk::Buffer ids_bucketized, part_out, shard_index, sizes_dev, part_ws, send_ids, recv_ids,
-      send_rows, recv_rows, rows_unpacked, wire_ws, ids_unpacked, bwd_ws, runs_dev;
+      send_rows, recv_rows, wire_ws, bwd_ws, runs_dev;
   int32_t* host_sizes;  // pinned [2][N*W]
-  int64_t* host_runs;   // pinned [2][N*W]: run starts / bases of the stitch, column-major
+  int64_t* host_runs;   // pinned [5][N*W], column-major: run starts / bases of the stitch, then
+                        // run starts / id offsets / gradient offsets of the owner-side backward
 };
 
 extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t n_cols,
@@ -299,7 +308,7 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
                     sizeof(int32_t) * 2 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
           hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&p->host_runs),
-                    sizeof(int64_t) * 2 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
+                    sizeof(int64_t) * 5 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
           hipSuccess) {
     delete p;
     return fail(HBK_INTERNAL, "sharded_create: hipHostMalloc failed");
@@ -312,8 +321,7 @@ extern "C" int hbk_sharded_destroy(hbk_sharded_t p) {
   if (p == nullptr) return HBK_OK;
   for (hbk::Buffer* b : {&p->ids_bucketized, &p->part_out, &p->shard_index, &p->sizes_dev,
                          &p->part_ws, &p->send_ids, &p->recv_ids, &p->send_rows, &p->recv_rows,
-                         &p->rows_unpacked, &p->wire_ws, &p->ids_unpacked, &p->bwd_ws,
-                         &p->runs_dev}) {
+                         &p->wire_ws, &p->bwd_ws, &p->runs_dev}) {
     b->release();
   }
   if (p->host_sizes) (void)hipHostFree(p->host_sizes);
@@ -433,8 +441,6 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   p->recv_sizes.assign(p->host_sizes + (size_t)N * W, p->host_sizes + 2 * (size_t)N * W);
   const int32_t* S = p->send_sizes.data();
   const int32_t* R = p->recv_sizes.data();
-  Layout& L = p->lay;
-  if ((rc = L.compute(N, W, p->cols, S, R)) != HBK_OK) return rc;
   // ---- 3..6 pipelined over column groups ------------------------------------------------------
   // The columns are split into G groups, each with its own peer-major buffers.  The exchanges
   // run back to back on the communicator's stream; the compute stream gathers group g while the
@@ -442,13 +448,8 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   //   comm    : ids(0) ids(1) ...            rows(0)      rows(1) ...
   //   compute : pack(0..G-1)      gather(0)  gather(1) ..      stitch(0)   stitch(1)
   const int G = pipeline_groups(N);
-  struct Group {
-    int c0, c1;
-    Layout lay;
-    std::vector<int32_t> R;                 // [W][n_g]
-    int64_t id_send, id_recv, row_send, row_recv;  // offsets of the group's regions
-  };
-  std::vector<Group> groups(G);
+  std::vector<Group>& groups = p->groups;
+  groups.assign(G, Group());
   int64_t tot_req_ids = 0, tot_own_ids = 0, tot_own_floats = 0, tot_req_floats = 0;
   p->fwd_own_id_off.assign((size_t)N * W, 0);
   for (int g = 0; g < G; ++g) {
@@ -490,7 +491,9 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     }
     if ((rc = p->wire_ws.ensure(wws + 16)) != HBK_OK) return rc;
   }
-  if ((rc = p->runs_dev.ensure(sizeof(int64_t) * 2 * (size_t)N * W)) != HBK_OK) return rc;
+  HBK_REQUIRE(tot_own_floats < (1ll << 32) && tot_req_floats < (1ll << 32),
+              "sharded_lookup_fwd: more than 2^32 floats (16 GB) of rows per step on one rank");
+  if ((rc = p->runs_dev.ensure(sizeof(int64_t) * 5 * (size_t)N * W)) != HBK_OK) return rc;
   int64_t* ids_send_base = reinterpret_cast<int64_t*>(p->send_ids.ptr);
   int64_t* ids_recv_base = reinterpret_cast<int64_t*>(p->recv_ids.ptr);
   float* rows_send_base = reinterpret_cast<float*>(p->send_rows.ptr);
@@ -508,7 +511,25 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
         }
       }
     }
-    HBK_HIP_OK(hipMemcpyAsync(p->runs_dev.ptr, p->host_runs, sizeof(int64_t) * 2 * (size_t)N * W,
+    // owner side of the backward: column c = W runs over the received ids (recv_ids) and the
+    // gradient rows that come back into send_rows
+    int64_t* h_ostart = p->host_runs + 2 * (size_t)N * W;
+    int64_t* h_oids = p->host_runs + 3 * (size_t)N * W;
+    int64_t* h_ograds = p->host_runs + 4 * (size_t)N * W;
+    for (const Group& gr : groups) {
+      const int ng = gr.c1 - gr.c0;
+      for (int c = 0; c < ng; ++c) {
+        int64_t o = 0;
+        for (int q = 0; q < W; ++q) {
+          const size_t at = (size_t)(gr.c0 + c) * W + q;
+          h_ostart[at] = o;
+          h_oids[at] = gr.id_recv + gr.lay.own_id_off[(size_t)q * ng + c];
+          h_ograds[at] = gr.row_send + gr.lay.own_row_off[(size_t)q * ng + c];
+          o += gr.R[(size_t)q * ng + c];
+        }
+      }
+    }
+    HBK_HIP_OK(hipMemcpyAsync(p->runs_dev.ptr, p->host_runs, sizeof(int64_t) * 5 * (size_t)N * W,
                               hipMemcpyHostToDevice, stream));
   }
   // stage A: pack the ids of every group peer-major
@@ -618,109 +639,91 @@ extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads
               "sharded_lookup_bwd: NULL argument array");
   hipStream_t stream = as_stream(stream_);
   const int N = p->N, W = p->W;
-  const int32_t* S = p->send_sizes.data();
   const int32_t* R = p->recv_sizes.data();
-  const Layout& L = p->lay;
+  const int G = (int)p->groups.size();
+  float* rows_send_base = reinterpret_cast<float*>(p->send_rows.ptr);
+  float* rows_recv_base = reinterpret_cast<float*>(p->recv_rows.ptr);
+  const int64_t* d_start = reinterpret_cast<const int64_t*>(p->runs_dev.ptr);
+  const int64_t* d_base = d_start + (size_t)N * W;
+  const int64_t* d_ostart = d_start + 2 * (size_t)N * W;
+  const int64_t* d_oids = d_start + 3 * (size_t)N * W;
+  const int64_t* d_ograds = d_start + 4 * (size_t)N * W;
   int rc;
-  // ---- B1 d(stitch + combiner) into column-major rows ------------------------------------------
-  if ((rc = p->rows_unpacked.ensure(((size_t)L.req_floats + 4 * (size_t)N) * 4 + 16)) != HBK_OK) {
-    return rc;
-  }
-  std::vector<int64_t> col_base(N);
-  {
-    std::vector<hbk_stitch_grad_column_t> v(N);
-    int64_t b = 0, ioff = 0;
-    for (int c = 0; c < N; ++c) {
-      col_base[c] = b;
+  // The forward's buffers, layout and run tables are reused in reverse, group by group:
+  //   compute : dstitch(0) dstitch(1) ..             reduce(0)   reduce(1) ..
+  //   comm    :            grads(0)   grads(1) ..
+  // ---- B1 d(stitch + combiner) written straight into the peer-major buffer the rows came in ----
+  std::vector<int64_t> ioff(N + 1, 0);
+  for (int c = 0; c < N; ++c) ioff[c + 1] = ioff[c] + p->n_ids[c];
+  for (int g = 0; g < G; ++g) {
+    const Group& gr = p->groups[g];
+    const int ng = gr.c1 - gr.c0;
+    std::vector<hbk_stitch_grad_column_t> v(ng);
+    for (int c = 0; c < ng; ++c) {
+      const int cc = gr.c0 + c;
       hbk_stitch_grad_column_t& h = v[c];
-      h.dim = p->cols[c].dim;
-      h.combiner = p->cols[c].combiner;
-      h.n_ids = p->n_ids[c];
-      h.index = reinterpret_cast<const int32_t*>(p->shard_index.ptr) + ioff;
-      h.row_splits = p->row_splits[c];
-      h.n_segments = p->n_seg[c];
-      h.grad_out = grads[c];
-      h.grad_rows = reinterpret_cast<float*>(p->rows_unpacked.ptr) + b;
-      b += (p->n_ids[c] * p->cols[c].dim + 3) & ~(int64_t)3;
-      ioff += p->n_ids[c];
+      memset(&h, 0, sizeof(h));
+      h.dim = p->cols[cc].dim;
+      h.combiner = p->cols[cc].combiner;
+      h.n_ids = p->n_ids[cc];
+      h.index = reinterpret_cast<const int32_t*>(p->shard_index.ptr) + ioff[cc];
+      h.row_splits = p->row_splits[cc];
+      h.n_segments = p->n_seg[cc];
+      h.grad_out = grads[cc];
+      h.grad_rows = rows_recv_base + gr.row_recv;
+      h.run_start = d_start + (size_t)cc * W;
+      h.run_base = d_base + (size_t)cc * W;
+      h.n_runs = W;
     }
-    rc = hbk_group_stitch_bwd(N, v.data(), stream_);
+    rc = hbk_group_stitch_bwd(ng, v.data(), stream_);
+    if (rc != HBK_OK) return rc;
+    HBK_HIP_OK(hipEventRecord(p->ev[0][g], stream));
+  }
+  // ---- B2 reverse exchanges (the forward's sizes, swapped: collective.py:334-347) -------------
+  for (int g = 0; g < G; ++g) {
+    const Group& gr = p->groups[g];
+    rc = exchange(p, HBK_FLOAT, p->wire_dtype, rows_recv_base + gr.row_recv,
+                  gr.lay.rows_recv_peer.data(), rows_send_base + gr.row_send,
+                  gr.lay.rows_send_peer.data(), stream_, p->ev[0][g], p->ev[1][g]);
     if (rc != HBK_OK) return rc;
   }
-  // ---- B2 pack peer-major, reverse exchange (the forward's sizes, swapped) --------------------
-  if ((rc = p->recv_rows.ensure((size_t)L.req_floats * 4 + 16)) != HBK_OK) return rc;
-  if ((rc = p->send_rows.ensure((size_t)L.own_floats * 4 + 16)) != HBK_OK) return rc;
-  {
-    std::vector<Seg> segs;
-    for (int q = 0; q < W; ++q) {
-      for (int c = 0; c < N; ++c) {
-        const int64_t d = p->cols[c].dim;
-        segs.push_back(make_seg(
-            reinterpret_cast<const float*>(p->rows_unpacked.ptr) + col_base[c] +
-                L.col_shard_off[(size_t)c * W + q] * d,
-            reinterpret_cast<float*>(p->recv_rows.ptr) + L.req_row_off[(size_t)q * N + c],
-            (int64_t)S[(size_t)c * W + q] * d * 4));
-      }
-    }
-    if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
+  // ---- B3 owner side: duplicate-row reduction (+ SGD) reading ids and gradient rows in place ---
+  std::vector<hbk_lookup_grad_column_t> v(N);
+  for (int c = 0; c < N; ++c) {
+    int64_t n_own = 0;
+    for (int q = 0; q < W; ++q) n_own += R[(size_t)q * N + c];
+    hbk_lookup_grad_column_t& h = v[c];
+    memset(&h, 0, sizeof(h));
+    h.table = const_cast<float*>(p->cols[c].shard);
+    h.rows = p->cols[c].rows_local;
+    h.dim = p->cols[c].dim;
+    h.ids_dtype = HBK_INT64;
+    h.ids = p->recv_ids.ptr;
+    h.n_ids = n_own;
+    h.n_segments = n_own;
+    h.divisor = W;
+    h.combiner = HBK_COMBINER_SUM;
+    h.grad_out = rows_send_base;
+    h.unique_rows = unique_rows[c];
+    h.grad_rows = grad_rows[c];
+    h.n_unique = n_unique[c];
+    h.run_start = d_ostart + (size_t)c * W;
+    h.run_ids = d_oids + (size_t)c * W;
+    h.run_grads = d_ograds + (size_t)c * W;
+    h.n_runs = W;
   }
-  rc = exchange(p, HBK_FLOAT, p->wire_dtype, p->recv_rows.ptr, L.rows_recv_peer.data(),
-                p->send_rows.ptr, L.rows_send_peer.data(), stream_);
-  if (rc != HBK_OK) return rc;
-  // ---- B3 owner side: column-major ids + grads, then duplicate-row reduction (+ SGD) ---------
-  if ((rc = p->ids_unpacked.ensure((size_t)L.own_ids * 8 + 8)) != HBK_OK) return rc;
-  if ((rc = p->rows_unpacked.ensure(((size_t)L.own_floats + 4 * (size_t)N) * 4 + 16)) != HBK_OK) {
-    return rc;
+  size_t ws = 0;
+  for (int g = 0; g < G; ++g) {
+    const Group& gr = p->groups[g];
+    const size_t w = hbk_group_lookup_bwd_workspace_bytes(gr.c1 - gr.c0, v.data() + gr.c0);
+    ws = w > ws ? w : ws;
   }
-  {
-    std::vector<int64_t> n_own(N, 0), id_base(N), f_base(N);
-    for (int c = 0; c < N; ++c) {
-      for (int q = 0; q < W; ++q) n_own[c] += R[(size_t)q * N + c];
-    }
-    int64_t ib = 0, fb = 0;
-    for (int c = 0; c < N; ++c) {
-      id_base[c] = ib;
-      f_base[c] = fb;
-      ib += n_own[c];
-      fb += (n_own[c] * p->cols[c].dim + 3) & ~(int64_t)3;
-    }
-    std::vector<Seg> segs;
-    std::vector<int64_t> ioff(N, 0);
-    for (int q = 0; q < W; ++q) {
-      for (int c = 0; c < N; ++c) {
-        const int64_t n = R[(size_t)q * N + c], d = p->cols[c].dim;
-        segs.push_back(make_seg(
-            reinterpret_cast<const int64_t*>(p->recv_ids.ptr) + p->fwd_own_id_off[(size_t)q * N + c],
-            reinterpret_cast<int64_t*>(p->ids_unpacked.ptr) + id_base[c] + ioff[c], n * 8));
-        segs.push_back(make_seg(
-            reinterpret_cast<const float*>(p->send_rows.ptr) + L.own_row_off[(size_t)q * N + c],
-            reinterpret_cast<float*>(p->rows_unpacked.ptr) + f_base[c] + ioff[c] * d,
-            n * d * 4));
-        ioff[c] += n;
-      }
-    }
-    if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
-    std::vector<hbk_lookup_grad_column_t> v(N);
-    for (int c = 0; c < N; ++c) {
-      hbk_lookup_grad_column_t& h = v[c];
-      memset(&h, 0, sizeof(h));
-      h.table = const_cast<float*>(p->cols[c].shard);
-      h.rows = p->cols[c].rows_local;
-      h.dim = p->cols[c].dim;
-      h.ids_dtype = HBK_INT64;
-      h.ids = reinterpret_cast<const int64_t*>(p->ids_unpacked.ptr) + id_base[c];
-      h.n_ids = n_own[c];
-      h.n_segments = n_own[c];
-      h.divisor = W;
-      h.combiner = HBK_COMBINER_SUM;
-      h.grad_out = reinterpret_cast<const float*>(p->rows_unpacked.ptr) + f_base[c];
-      h.unique_rows = unique_rows[c];
-      h.grad_rows = grad_rows[c];
-      h.n_unique = n_unique[c];
-    }
-    const size_t ws = hbk_group_lookup_bwd_workspace_bytes(N, v.data());
-    if ((rc = p->bwd_ws.ensure(ws + 8)) != HBK_OK) return rc;
-    rc = hbk_group_lookup_bwd(N, v.data(), apply_lr, p->bwd_ws.ptr, p->bwd_ws.bytes, stream_);
+  if ((rc = p->bwd_ws.ensure(ws + 8)) != HBK_OK) return rc;
+  for (int g = 0; g < G; ++g) {
+    const Group& gr = p->groups[g];
+    HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
+    rc = hbk_group_lookup_bwd(gr.c1 - gr.c0, v.data() + gr.c0, apply_lr, p->bwd_ws.ptr,
+                              p->bwd_ws.bytes, stream_);
     if (rc != HBK_OK) return rc;
   }
   return HBK_OK;

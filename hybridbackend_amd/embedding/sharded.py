@@ -207,7 +207,7 @@ class ShardedGroupLookup:
   def owner_bwd(self, st, recv_grads, apply_lr=0.0):
     return self._owner_grad(st.recv_ids, recv_grads, None, apply_lr=apply_lr)
 
-  def backward(self, grads, apply_lr=0.0):
+  def backward(self, grads, apply_lr=0.0, outs=None):
     """Backward of the LAST forward step (hbk_sharded_lookup_bwd).  grads[c]: gradient of
     column c's output [segments, dim].  Returns per column the IndexedSlices of the LOCAL
     shard ``(unique_rows, grad_rows, n_unique)``; with ``apply_lr`` the SGD update is applied
@@ -222,6 +222,13 @@ class ShardedGroupLookup:
       k = int(self._lib.hbk_sharded_owned_ids(plan, c))
       if k < 0:
         raise _lib.HbkError(_lib.INTERNAL, 'backward() needs a forward step first')
+      if outs is not None:
+        # caller-owned (unique_rows, grad_rows, n_unique) with capacity >= owned ids
+        if outs[c][0].numel() < k or outs[c][1].numel() < k * self.dims[c]:
+          raise _lib.InvalidArgumentError(
+            _lib.INVALID_ARGUMENT, f'backward outs[{c}] too small for {k} owned ids')
+        res.append(tuple(outs[c]))
+        continue
       res.append((torch.empty(k, dtype=torch.int64, device=self.device),
                   torch.empty((k, self.dims[c]), dtype=torch.float32, device=self.device),
                   torch.zeros(1, dtype=torch.int32, device=self.device)))

@@ -177,10 +177,11 @@ int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
  *   scale = 1 (sum), 1/count (mean), 1/sqrt(count) (sqrtn).  unique_rows / grad_rows have
  *   capacity n_ids; rows >= n_unique are untouched.  Ids that map outside [0, rows) contribute
  *   nothing.  No global atomics on the data path: ids are grouped by a hash of their row and
- *   each group is reduced by one workgroup in an LDS table (ds_add_f32), so the summation
- *   order is not fixed: tolerance 1e-5 relative.  Rows are distinct unless one group holds
- *   more distinct rows than its LDS table (adversarial skew, or more than ~4 M ids in one
- *   column): then a row may appear in more than one entry, sum semantics preserved
+ *   each group is reduced by one workgroup (LDS hash table of the distinct rows, sums in
+ *   registers; a group holding a hot row is split over several workgroups and merged), so the
+ *   summation order is not fixed: tolerance 1e-5 relative.  Rows are distinct unless one group
+ *   holds more distinct rows than its LDS table (adversarial hashing, or more than ~4 M ids in
+ *   one column): then a row may appear in more than one entry, sum semantics preserved
  *   (IndexedSlices allow repeated indices; the fused SGD apply stays exact).
  *   apply_lr != 0 additionally performs the sparse SGD update on the shard in the same
  *   pass: table[unique_rows[u],:] -= apply_lr * grad_rows[u,:] (sharded variables skip
@@ -201,6 +202,15 @@ typedef struct {
   int64_t* unique_rows;      /* device [n_ids] */
   float* grad_rows;          /* device [n_ids, dim] */
   int32_t* n_unique;         /* device [1] */
+  /* optional segmented inputs (n_runs > 0; row_splits must be NULL): ids j in
+   * [run_start[k], run_start[k+1]) live at ids + run_ids[k] (elements) and their gradient rows
+   * at grad_out + run_grads[k] (floats, 16-byte aligned).  Lets the owner side of the sharded
+   * backward read the peer-major exchange buffers in place.  Device arrays [n_runs]. */
+  const int64_t* run_start;
+  const int64_t* run_ids;
+  const int64_t* run_grads;
+  int32_t n_runs;
+  int32_t reserved_;
 } hbk_lookup_grad_column_t;
 
 size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
@@ -225,6 +235,13 @@ typedef struct {
   int64_t n_segments;
   const float* grad_out;      /* device [n_segments, dim] */
   float* grad_rows;           /* device [n_ids, dim] */
+  /* optional segmented destination (n_runs > 0): rows [run_start[k], run_start[k+1]) of
+   * grad_rows live at grad_rows + run_base[k] floats (the peer-major send buffer of the
+   * reverse exchange; same tables as the forward's hbk_lookup_column_t runs).  Device arrays. */
+  const int64_t* run_start;
+  const int64_t* run_base;
+  int32_t n_runs;
+  int32_t reserved_;
 } hbk_stitch_grad_column_t;
 
 int hbk_group_stitch_bwd(int32_t n_cols, const hbk_stitch_grad_column_t* cols,

@@ -237,6 +237,18 @@ def case_sharded_world1():
     torch.cuda.synchronize()
     report(f'sharded pipeline W=1 fwd dim16 B={B} wire={"fp16" if wire else "fp32"}', us, 26 * B,
            26 * B * 136, host_enqueue_us=round(host_us, 1))
+  drv.wire_dtype = None
+  gouts = [torch.randn(B, 16, device=DEV) for _ in range(26)]
+
+  bouts = [(torch.empty(B, dtype=torch.int64, device=DEV), torch.empty(B, 16, device=DEV),
+            torch.zeros(1, dtype=torch.int32, device=DEV)) for _ in range(26)]
+
+  def fwd_bwd(i):
+    drv(batches[i % nb])
+    drv.backward(gouts, apply_lr=0.01, outs=bouts)
+  us_fb = timed(fwd_bwd, iters=20)
+  report(f'sharded pipeline W=1 fwd + bwd + SGD dim16 B={B} wire=fp32', us_fb, 26 * B,
+         26 * B * (136 + 8 + 64 + 128))
   coll.close()
 
 

@@ -168,6 +168,34 @@ __global__ __launch_bounds__(256) void gather_only(const float* table, const uin
   if (acc.x == 12345.678f) sink[0] = acc.y;  // keep the loads alive
 }
 
+
+// granularity probe: the same 64-byte rows fetched with SCALAR loads (s_load_dwordx16 through the
+// scalar data cache, 64-byte lines) instead of vector loads (vector L1: 128-byte lines)
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+template <int U>
+__global__ __launch_bounds__(256) void gather_scalar(const float* table, const uint32_t* rowidx,
+                                                     int64_t n, float* sink) {
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t base = wave * 64;
+  const uint32_t myr = base + lane < n ? rowidx[base + lane] : 0;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < 64; k += U) {
+    u32x16 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)myr, k + u);
+      const float* p = table + (uint64_t)r * 16;
+      asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v[u]) : "s"(p) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc ^= v[u][0] ^ v[u][7] ^ v[u][15];
+  }
+  if (acc == 0x12345678u) sink[0] = (float)acc;
+}
+
 static bool quick = false;  // --quick: few passes of every probe (for rocprofv3 --pmc)
 
 struct Ctx {
@@ -294,6 +322,14 @@ int main(int argc, char** argv) {
           printf("gather-only  64-B rows, policy %-10s: %.2f us, %.1f GB/s useful\n", nm, t,
                  (double)n * 64 / t / 1e3);
         };
+        {
+          const unsigned sgrid = (unsigned)((n + 255) / 256);
+          float t = time_us(c, quick ? 1 : 10, [&](int) {
+            hipLaunchKernelGGL(gather_scalar<4>, dim3(sgrid), dim3(256), 0, 0, tab, didx, n, sink);
+          });
+          printf("gather-only  64-B rows, scalar loads (s_load_dwordx16): %.2f us, %.1f GB/s useful\n",
+                 t, (double)n * 64 / t / 1e3);
+        }
         fl(gather_flavor<4, 0>, "plain");
         fl(gather_flavor<4, 1>, "sc0");
         fl(gather_flavor<4, 2>, "sc1");

@@ -411,6 +411,77 @@ def test_group_lookup_backward_split_buckets(monkeypatch, split, log2p):
     np.testing.assert_allclose(host(t_dev), ref, rtol=RTOL, atol=1e-4)
 
 
+def test_group_lookup_backward_segmented_inputs():
+  """C ABI: ids and gradient rows handed over as runs inside larger buffers (what the owner side
+  of the sharded backward gets from the exchange) give the same IndexedSlices as contiguous
+  inputs; the stitch transpose writes a segmented destination."""
+  import ctypes as C
+  from hybridbackend_amd import _lib
+  lib = _lib.lib()
+  rng = np.random.RandomState(31)
+  for d, rows, lens in ((16, 500, [3000, 0, 1234, 7000]), (6, 90, [10, 501, 2]),
+                        (128, 4000, [5000, 4097])):
+    n = sum(lens)
+    ids = rng.randint(0, rows, size=n).astype(np.int64)
+    grads = rng.randn(n, d).astype(np.float32)
+    # scatter the runs (in reverse order, with gaps) inside larger buffers
+    id_buf = np.full(n + 64 * len(lens), -7, np.int64)
+    g_buf = np.full(n * d + 64 * len(lens), np.nan, np.float32)
+    run_start, run_ids, run_grads, io, go, st = [], [], [], 5, 8, 0
+    for k in reversed(range(len(lens))):
+      run_ids.insert(0, io)
+      run_grads.insert(0, go)
+      io += lens[k] + 3
+      go += (lens[k] * d + 3) // 4 * 4 + 4
+    for k, ln in enumerate(lens):
+      run_start.append(st)
+      id_buf[run_ids[k]:run_ids[k] + ln] = ids[st:st + ln]
+      g_buf[run_grads[k]:run_grads[k] + ln * d] = grads[st:st + ln].reshape(-1)
+      st += ln
+    table = rng.uniform(-1, 1, size=(rows, d)).astype(np.float32)
+    t_dev, ids_dev, g_dev = dev(table.copy()), dev(id_buf), dev(g_buf)
+    tabs = [dev(np.array(x, np.int64)) for x in (run_start, run_ids, run_grads)]
+    urows = torch.empty(n, dtype=torch.int64, device=DEV)
+    grows = torch.empty(n, d, device=DEV)
+    nu = torch.zeros(1, dtype=torch.int32, device=DEV)
+    col = (_lib.LookupGradColumn * 1)()
+    c = col[0]
+    c.table, c.rows, c.dim, c.ids_dtype = t_dev.data_ptr(), rows, d, _lib.INT64
+    c.ids, c.n_ids, c.n_segments, c.divisor = ids_dev.data_ptr(), n, n, 1
+    c.combiner = 0
+    c.grad_out, c.unique_rows, c.grad_rows = g_dev.data_ptr(), urows.data_ptr(), grows.data_ptr()
+    c.n_unique = nu.data_ptr()
+    c.run_start, c.run_ids, c.run_grads = (t.data_ptr() for t in tabs)
+    c.n_runs = len(lens)
+    need = lib.hbk_group_lookup_bwd_workspace_bytes(1, col)
+    ws = torch.empty(max(need, 8), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.hbk_group_lookup_bwd(1, col, C.c_float(0.25), C.c_void_p(ws.data_ptr()),
+                                        C.c_size_t(ws.numel()), _lib.current_stream(DEV)))
+    _check_slices((urows, grows, nu), ids, grads, None, 'sum', atol=RTOL * 50)
+    ref = table.astype(np.float64)
+    np.subtract.at(ref, ids, 0.25 * grads.astype(np.float64))
+    np.testing.assert_allclose(host(t_dev), ref, rtol=RTOL, atol=1e-4)
+
+    # d(stitch): destination rows segmented with the same tables
+    perm = rng.permutation(n).astype(np.int32)
+    dst = torch.full((g_buf.size,), float('nan'), device=DEV)
+    scol = (_lib.StitchGradColumn * 1)()
+    q = scol[0]
+    q.dim, q.combiner, q.n_ids, q.n_segments = d, 0, n, n
+    idx_dev, go_dev = dev(perm), dev(grads)
+    q.index, q.grad_out, q.grad_rows = idx_dev.data_ptr(), go_dev.data_ptr(), dst.data_ptr()
+    q.run_start, q.run_base, q.n_runs = tabs[0].data_ptr(), tabs[2].data_ptr(), len(lens)
+    _lib.check(lib.hbk_group_stitch_bwd(1, scol, _lib.current_stream(DEV)))
+    got = host(dst)
+    want = np.empty((n, d), np.float32)
+    want[perm] = grads
+    st = 0
+    for k, ln in enumerate(lens):
+      np.testing.assert_equal(got[run_grads[k]:run_grads[k] + ln * d],
+                              want[st:st + ln].reshape(-1))
+      st += ln
+
+
 def test_group_lookup_backward_fused_sgd_apply():
   rng = np.random.RandomState(11)
   table = rng.uniform(-1, 1, size=(5000, 16)).astype(np.float32)

@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -88,18 +89,27 @@ def cpu_baseline(args, tables, id_batch, budget_s):
   on a bounded sample of the same workload."""
   import oracle  # the checker / reported baseline only
   cores = os.cpu_count() or 1
-  threads = max(1, min(cores, args.columns))
-  # bound the host copy: sample = first `cols` columns so that tables fit the time budget
+  # one task per (column, slice of the batch): the reference's CPU analogue runs the per-column
+  # ops on TF's inter-op pool; slicing the batch as well lets the port use all host cores
   cols = args.columns
-  h_tables = [t.cpu().numpy() for t in tables[:cols]]
-  h_ids = [i.cpu().numpy() for i in id_batch[:cols]]
-  buckets = [args.rows] * cols
-  comb = ['sum'] * cols
-  oracle.group_lookup_fwd(h_tables, h_ids, [None] * cols, buckets, comb, n_threads=threads)
-  passes, t0 = 0, time.perf_counter()
+  slices = max(1, min(cores // max(cols, 1), 16))
+  threads = max(1, min(cores, cols * slices))
+  h_tab = [t.cpu().numpy() for t in tables[:cols]]
+  h_all = [i.cpu().numpy() for i in id_batch[:cols]]
+  h_tables, h_ids = [], []
+  for c in range(cols):
+    for part in np.array_split(h_all[c], slices):
+      h_tables.append(h_tab[c])
+      h_ids.append(np.ascontiguousarray(part))
+  tasks = len(h_ids)
+  buckets = [args.rows] * tasks
+  comb = ['sum'] * tasks
+  oracle.group_lookup_fwd(h_tables, h_ids, [None] * tasks, buckets, comb, n_threads=threads)
+  passes, t0, rep = 0, time.perf_counter(), 8
   while True:
-    oracle.group_lookup_fwd(h_tables, h_ids, [None] * cols, buckets, comb, n_threads=threads)
-    passes += 1
+    oracle.group_lookup_fwd(h_tables, h_ids, [None] * tasks, buckets, comb, n_threads=threads,
+                            repeat=rep)
+    passes += rep
     el = time.perf_counter() - t0
     if el >= budget_s or passes >= 5000:
       break
@@ -109,7 +119,8 @@ def cpu_baseline(args, tables, id_batch, budget_s):
     'kind': 'port',
     'sample': f'{passes} passes of one {cols}-column x {args.batch}-id batch '
               f'({lookups} lookups, {el:.1f} s) through oracle/hbk_oracle.c '
-              f'orc_group_lookup_fwd, {threads} pthreads over columns, host nproc={cores}'}
+              f'orc_group_lookup_fwd, {threads} pthreads over {tasks} (column, batch-slice) '
+              f'tasks, host nproc={cores}'}
 
 
 def load_traffic(config_key):

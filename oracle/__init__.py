@@ -283,7 +283,7 @@ class _LookupColumn(C.Structure):
               ('combiner', C.c_int32), ('out', C.c_void_p)]
 
 
-def group_lookup_fwd(tables, ids, splits, buckets, combiners, n_threads=1):
+def group_lookup_fwd(tables, ids, splits, buckets, combiners, n_threads=1, repeat=1):
   """R12 at W=1: per column bucketize -> partition(P=1) -> unique -> gather ->
   restore/stitch -> combiner.  tables[c]: f32 [rows, dim]; ids[c]: int64 [n];
   splits[c]: int32 [S+1] or None (one id per segment)."""
@@ -309,7 +309,8 @@ def group_lookup_fwd(tables, ids, splits, buckets, combiners, n_threads=1):
     cols[c].bucket = int(buckets[c]) if buckets is not None else 0
     cols[c].combiner = COMBINERS.get(combiners[c], combiners[c])
     cols[c].out = o.ctypes.data
-  lib().orc_group_lookup_fwd(cols, C.c_int32(n_cols), C.c_int32(n_threads))
+  lib().orc_group_lookup_fwd_repeat(cols, C.c_int32(n_cols), C.c_int32(n_threads),
+                                    C.c_int32(repeat))
   return outs
 
 

@@ -617,6 +617,7 @@ static void orc_lookup_one_column(const orc_lookup_column_t* c) {
 typedef struct {
   const orc_lookup_column_t* cols;
   int32_t n_cols;
+  int32_t n_tasks; /* n_cols * repeat */
   int32_t next;
   pthread_mutex_t mu;
 } orc_pool_t;
@@ -627,21 +628,27 @@ static void* orc_pool_worker(void* arg) {
     pthread_mutex_lock(&p->mu);
     int32_t i = p->next++;
     pthread_mutex_unlock(&p->mu);
-    if (i >= p->n_cols) break;
-    orc_lookup_one_column(&p->cols[i]);
+    if (i >= p->n_tasks) break;
+    orc_lookup_one_column(&p->cols[i % p->n_cols]);
   }
   return NULL;
 }
 
-void orc_group_lookup_fwd(const orc_lookup_column_t* cols, int32_t n_cols,
-                          int32_t n_threads) {
+/* `repeat` passes over the same columns inside one pool (the timed baseline: thread start-up is
+ * paid once per call, not once per pass) */
+void orc_group_lookup_fwd_repeat(const orc_lookup_column_t* cols, int32_t n_cols,
+                                 int32_t n_threads, int32_t repeat) {
+  if (repeat < 1) repeat = 1;
   if (n_threads <= 1) {
-    for (int32_t i = 0; i < n_cols; ++i) orc_lookup_one_column(&cols[i]);
+    for (int32_t r = 0; r < repeat; ++r) {
+      for (int32_t i = 0; i < n_cols; ++i) orc_lookup_one_column(&cols[i]);
+    }
     return;
   }
   orc_pool_t pool;
   pool.cols = cols;
   pool.n_cols = n_cols;
+  pool.n_tasks = n_cols * repeat;
   pool.next = 0;
   pthread_mutex_init(&pool.mu, NULL);
   pthread_t* th = (pthread_t*)malloc((size_t)n_threads * sizeof(pthread_t));
@@ -651,4 +658,9 @@ void orc_group_lookup_fwd(const orc_lookup_column_t* cols, int32_t n_cols,
   for (int32_t t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
   free(th);
   pthread_mutex_destroy(&pool.mu);
+}
+
+void orc_group_lookup_fwd(const orc_lookup_column_t* cols, int32_t n_cols,
+                          int32_t n_threads) {
+  orc_group_lookup_fwd_repeat(cols, n_cols, n_threads, 1);
 }

@@ -1,0 +1,196 @@
+// C-ABI wall time of the ops around the gather, without any Python: stable partition (R2),
+// unique (R7), backward duplicate-row reduction (R10).  HIP events around `iters` back-to-back
+// calls on the null stream; inputs regenerated per call from a pool of resident id batches.
+//   build: make -C tools        run: tools/bin/bench_ops
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <functional>
+#include <vector>
+
+#include "../include/hbk.h"
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e = (x);                                                            \
+    if (e != hipSuccess) {                                                         \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));                       \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+#define HB(x)                                                                      \
+  do {                                                                             \
+    int rc = (x);                                                                  \
+    if (rc != HBK_OK) {                                                            \
+      fprintf(stderr, "%s: %d %s\n", #x, rc, hbk_last_error());                    \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+static uint64_t rng_state = 0x9e3779b97f4a7c15ull;
+static uint64_t rnd() {
+  rng_state ^= rng_state << 13;
+  rng_state ^= rng_state >> 7;
+  rng_state ^= rng_state << 17;
+  return rng_state;
+}
+
+template <typename T>
+static T* dev_random(size_t n, uint64_t mod) {
+  std::vector<T> h(n);
+  for (auto& v : h) v = (T)(rnd() % mod);
+  T* d;
+  CK(hipMalloc(&d, n * sizeof(T) + 16));
+  CK(hipMemcpy(d, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+
+template <typename T>
+static T* dev_alloc(size_t n) {
+  T* d;
+  CK(hipMalloc(&d, n * sizeof(T) + 16));
+  return d;
+}
+
+static float time_us(int iters, const std::function<void(int)>& f) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) f(i);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) f(i + 3);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / iters;
+}
+
+template <typename T>
+static void bench_partition(const char* what, int n_cols, int64_t len, int P, int dtype) {
+  const int kPool = 4;
+  std::vector<T*> pool(kPool);
+  for (auto& p : pool) p = dev_random<T>((size_t)n_cols * len, (uint64_t)1 << 30);
+  T* out = dev_alloc<T>((size_t)n_cols * len);
+  int32_t* idx = dev_alloc<int32_t>((size_t)n_cols * len);
+  int32_t* sizes = dev_alloc<int32_t>((size_t)n_cols * P);
+  std::vector<int64_t> lens(n_cols, len);
+  const size_t ws_bytes = hbk_partition_workspace_bytes(n_cols, lens.data(), P);
+  char* ws = dev_alloc<char>(ws_bytes);
+  std::vector<const void*> in(n_cols);
+  std::vector<void*> o(n_cols);
+  std::vector<int32_t*> s(n_cols), ix(n_cols);
+  float us = time_us(50, [&](int i) {
+    for (int c = 0; c < n_cols; ++c) {
+      in[c] = pool[i % kPool] + (size_t)c * len;
+      o[c] = out + (size_t)c * len;
+      s[c] = sizes + (size_t)c * P;
+      ix[c] = idx + (size_t)c * len;
+    }
+    HB(hbk_partition_by_modulo_n(n_cols, dtype, P, in.data(), lens.data(), o.data(), s.data(),
+                                 ix.data(), ws, ws_bytes, nullptr));
+  });
+  const double ids = (double)n_cols * len;
+  const double bytes = ids * (3.0 * sizeof(T) + 4);
+  printf("%-66s %9.2f us  %8.1f M ids/s  %7.1f GB/s (%.3f of 8 TB/s)\n", what, us, ids / us,
+         bytes / us / 1e3, bytes / us / 1e3 / 8000.0);
+}
+
+static void bench_unique(int n_cols, int64_t len, uint64_t mod) {
+  const int kPool = 4;
+  std::vector<int64_t*> pool(kPool);
+  for (auto& p : pool) p = dev_random<int64_t>((size_t)n_cols * len, mod);
+  int64_t* uniq = dev_alloc<int64_t>((size_t)n_cols * len);
+  int32_t* idx = dev_alloc<int32_t>((size_t)n_cols * len);
+  int32_t* nu = dev_alloc<int32_t>(n_cols);
+  std::vector<int64_t> lens(n_cols, len);
+  const size_t ws_bytes = hbk_unique_workspace_bytes(n_cols, lens.data());
+  char* ws = dev_alloc<char>(ws_bytes);
+  std::vector<const int64_t*> in(n_cols);
+  std::vector<int64_t*> u(n_cols);
+  std::vector<int32_t*> ix(n_cols), n(n_cols);
+  float us = time_us(50, [&](int i) {
+    for (int c = 0; c < n_cols; ++c) {
+      in[c] = pool[i % kPool] + (size_t)c * len;
+      u[c] = uniq + (size_t)c * len;
+      ix[c] = idx + (size_t)c * len;
+      n[c] = nu + c;
+    }
+    HB(hbk_unique_n(n_cols, in.data(), lens.data(), u.data(), ix.data(), n.data(), ws, ws_bytes,
+                    nullptr));
+  });
+  const double ids = (double)n_cols * len;
+  char what[128];
+  snprintf(what, sizeof(what), "unique_n %d x %lld int64 (ids uniform in [0, %llu))", n_cols,
+           (long long)len, (unsigned long long)mod);
+  printf("%-66s %9.2f us  %8.1f M ids/s\n", what, us, ids / us);
+}
+
+static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float lr) {
+  const int kPool = 4;
+  std::vector<int64_t*> pool(kPool);
+  for (auto& p : pool) p = dev_random<int64_t>((size_t)n_cols * B, (uint64_t)1 << 40);
+  std::vector<float*> tables(n_cols);
+  for (auto& t : tables) {
+    t = dev_alloc<float>((size_t)rows * dim);
+    CK(hipMemset(t, 0, (size_t)rows * dim * 4));
+  }
+  float* gout = dev_alloc<float>((size_t)n_cols * B * dim);
+  CK(hipMemset(gout, 0x3c, (size_t)n_cols * B * dim * 4));
+  int64_t* urows = dev_alloc<int64_t>((size_t)n_cols * B);
+  float* grows = dev_alloc<float>((size_t)n_cols * B * dim);
+  int32_t* nu = dev_alloc<int32_t>(n_cols);
+  std::vector<hbk_lookup_grad_column_t> cols(n_cols);
+  auto fill = [&](int i) {
+    for (int c = 0; c < n_cols; ++c) {
+      hbk_lookup_grad_column_t& h = cols[c];
+      h = hbk_lookup_grad_column_t();
+      h.table = tables[c];
+      h.rows = rows;
+      h.dim = dim;
+      h.ids_dtype = HBK_INT64;
+      h.ids = pool[i % kPool] + (size_t)c * B;
+      h.n_ids = B;
+      h.n_segments = B;
+      h.bucket = rows;
+      h.divisor = 1;
+      h.combiner = HBK_COMBINER_SUM;
+      h.grad_out = gout + (size_t)c * B * dim;
+      h.unique_rows = urows + (size_t)c * B;
+      h.grad_rows = grows + (size_t)c * B * dim;
+      h.n_unique = nu + c;
+    }
+  };
+  fill(0);
+  const size_t ws_bytes = hbk_group_lookup_bwd_workspace_bytes(n_cols, cols.data());
+  char* ws = dev_alloc<char>(ws_bytes);
+  float us = time_us(30, [&](int i) {
+    fill(i);
+    HB(hbk_group_lookup_bwd(n_cols, cols.data(), lr, ws, ws_bytes, nullptr));
+  });
+  const double n = (double)n_cols * B;
+  char what[128];
+  snprintf(what, sizeof(what), "group_lookup_bwd %d x %lld ids, dim %d, %lld rows%s", n_cols,
+           (long long)B, dim, (long long)rows, lr != 0.f ? " + SGD apply" : "");
+  printf("%-66s %9.2f us  %8.1f M lookups/s\n", what, us, n / us);
+  for (auto& t : tables) CK(hipFree(t));
+}
+
+int main() {
+  printf("hbk %s -- C-ABI wall time per call (HIP events, no Python)\n", hbk_version());
+  bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 8", 26, 65536, 8, HBK_INT64);
+  bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 2", 26, 65536, 2, HBK_INT64);
+  bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 64", 26, 65536, 64, HBK_INT64);
+  bench_partition<int32_t>("partition_by_modulo_n 100 x 100000 int32, P = 8 (reference benchmark)", 100,
+                           100000, 8, HBK_INT32);
+  bench_partition<int64_t>("partition_by_modulo_n 26 x 1048576 int64, P = 8", 26, 1048576, 8, HBK_INT64);
+  bench_unique(26, 65536, 1000000);
+  bench_unique(26, 65536, 4096);
+  bench_backward(26, 65536, 16, 1000000, 0.f);
+  bench_backward(26, 65536, 16, 1000000, 0.01f);
+  bench_backward(26, 65536, 128, 1000000, 0.f);
+  return 0;
+}

@@ -46,9 +46,9 @@ constexpr int kCopyTileBytes = kBlock * 16 * 8;  // 32 KB per block
 struct Seg {
   const void* src;
   void* dst;
-  int64_t bytes;
+  int64_t bytes;   // of the source
   int32_t tile0;
-  int32_t pad_;
+  int32_t narrow;  // 1: the source is int64, the destination int32 (the id wire format)
 };
 
 struct SegArgs {
@@ -75,6 +75,17 @@ __global__ __launch_bounds__(kBlock) void seg_copy_kernel(const SegArgs a) {
   const int64_t base = (int64_t)((int)blockIdx.x - s.tile0) * kCopyTileBytes;
   const char* src = reinterpret_cast<const char*>(s.src);
   char* dst = reinterpret_cast<char*>(s.dst);
+  if (s.narrow) {
+    const int64_t n = s.bytes >> 3, e0 = base >> 3;
+    const int64_t* src64 = reinterpret_cast<const int64_t*>(src);
+    int32_t* dst32 = reinterpret_cast<int32_t*>(dst);
+#pragma unroll
+    for (int k = 0; k < kCopyTileBytes / 8 / kBlock; ++k) {
+      const int64_t e = e0 + (int64_t)k * kBlock + threadIdx.x;
+      if (e < n) dst32[e] = (int32_t)__builtin_nontemporal_load(src64 + e);
+    }
+    return;
+  }
   if ((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)s.bytes) & 15) == 0) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -253,6 +264,7 @@ struct hbk_sharded {
   hbk_comm_t comm;
   int W, rank, N;
   int32_t wire_dtype;
+  bool id32;   // ids travel (and stay on the owner) as int32: every column is bucketized below 2^31
   std::vector<hbk_sharded_column_t> cols;
   // per-step state (kept for the backward)
   std::vector<int64_t> n_ids, n_seg;
@@ -293,6 +305,13 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
   p->N = n_cols;
   p->wire_dtype = wire_dtype;
   p->cols.assign(cols, cols + n_cols);
+  // After the bucketize ids are < bucket, so when every bucket fits int32 the id exchange moves
+  // half the bytes (the reference always sends the tensor's own dtype, nccl_collective.cc:257-259;
+  // SURVEY 8e).  HBK_SHARDED_ID64=1 keeps int64 on the wire.
+  p->id32 = getenv("HBK_SHARDED_ID64") == nullptr;
+  for (int32_t c = 0; c < n_cols; ++c) {
+    if (cols[c].bucket <= 0 || cols[c].bucket > 0x7fffffffll) p->id32 = false;
+  }
   p->have_step = false;
   p->host_sizes = nullptr;
   p->host_runs = nullptr;
@@ -336,13 +355,13 @@ extern "C" int hbk_sharded_destroy(hbk_sharded_t p) {
 namespace hbk {
 namespace {
 
-inline Seg make_seg(const void* src, void* dst, int64_t bytes) {
+inline Seg make_seg(const void* src, void* dst, int64_t bytes, int narrow = 0) {
   Seg s;
   s.src = src;
   s.dst = dst;
   s.bytes = bytes;
   s.tile0 = 0;
-  s.pad_ = 0;
+  s.narrow = narrow;
   return s;
 }
 
@@ -477,8 +496,10 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
       }
     }
   }
-  if ((rc = p->send_ids.ensure((size_t)tot_req_ids * 8 + 8)) != HBK_OK) return rc;
-  if ((rc = p->recv_ids.ensure((size_t)tot_own_ids * 8 + 8)) != HBK_OK) return rc;
+  const size_t id_bytes = p->id32 ? 4 : 8;
+  const int32_t id_dtype = p->id32 ? HBK_INT32 : HBK_INT64;
+  if ((rc = p->send_ids.ensure((size_t)tot_req_ids * id_bytes + 16)) != HBK_OK) return rc;
+  if ((rc = p->recv_ids.ensure((size_t)tot_own_ids * id_bytes + 16)) != HBK_OK) return rc;
   if ((rc = p->send_rows.ensure((size_t)tot_own_floats * 4 + 16)) != HBK_OK) return rc;
   if ((rc = p->recv_rows.ensure((size_t)tot_req_floats * 4 + 16)) != HBK_OK) return rc;
   if (p->wire_dtype == HBK_HALF) {  // staging for the largest group (exchanges are serial)
@@ -494,8 +515,8 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   HBK_REQUIRE(tot_own_floats < (1ll << 32) && tot_req_floats < (1ll << 32),
               "sharded_lookup_fwd: more than 2^32 floats (16 GB) of rows per step on one rank");
   if ((rc = p->runs_dev.ensure(sizeof(int64_t) * 5 * (size_t)N * W)) != HBK_OK) return rc;
-  int64_t* ids_send_base = reinterpret_cast<int64_t*>(p->send_ids.ptr);
-  int64_t* ids_recv_base = reinterpret_cast<int64_t*>(p->recv_ids.ptr);
+  char* ids_send_base = reinterpret_cast<char*>(p->send_ids.ptr);
+  char* ids_recv_base = reinterpret_cast<char*>(p->recv_ids.ptr);
   float* rows_send_base = reinterpret_cast<float*>(p->send_rows.ptr);
   float* rows_recv_base = reinterpret_cast<float*>(p->recv_rows.ptr);
   // run tables of the in-place stitch (column c = W runs over the group's received rows)
@@ -541,8 +562,8 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
       for (int c = 0; c < ng; ++c) {
         segs.push_back(make_seg(
             pout[gr.c0 + c] + gr.lay.col_shard_off[(size_t)c * W + q],
-            ids_send_base + gr.id_send + gr.lay.req_id_off[(size_t)q * ng + c],
-            (int64_t)S[(size_t)(gr.c0 + c) * W + q] * 8));
+            ids_send_base + (gr.id_send + gr.lay.req_id_off[(size_t)q * ng + c]) * id_bytes,
+            (int64_t)S[(size_t)(gr.c0 + c) * W + q] * 8, p->id32 ? 1 : 0));
       }
     }
     if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
@@ -551,8 +572,8 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   // stage B: ids exchanges, back to back on the communicator's stream
   for (int g = 0; g < G; ++g) {
     const Group& gr = groups[g];
-    rc = exchange(p, HBK_INT64, HBK_INT64, ids_send_base + gr.id_send,
-                  gr.lay.ids_send_peer.data(), ids_recv_base + gr.id_recv,
+    rc = exchange(p, id_dtype, id_dtype, ids_send_base + gr.id_send * id_bytes,
+                  gr.lay.ids_send_peer.data(), ids_recv_base + gr.id_recv * id_bytes,
                   gr.lay.ids_recv_peer.data(), stream_, p->ev[0][g], p->ev[1][g]);
     if (rc != HBK_OK) return rc;
   }
@@ -574,8 +595,8 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
         h.table = col.shard;
         h.rows = col.rows_local;
         h.dim = col.dim;
-        h.ids_dtype = HBK_INT64;
-        h.ids = ids_recv_base + gr.id_recv + gr.lay.own_id_off[(size_t)q * ng + c];
+        h.ids_dtype = id_dtype;
+        h.ids = ids_recv_base + (gr.id_recv + gr.lay.own_id_off[(size_t)q * ng + c]) * id_bytes;
         h.n_ids = n;
         h.n_segments = n;
         h.divisor = W;
@@ -697,7 +718,7 @@ extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads
     h.table = const_cast<float*>(p->cols[c].shard);
     h.rows = p->cols[c].rows_local;
     h.dim = p->cols[c].dim;
-    h.ids_dtype = HBK_INT64;
+    h.ids_dtype = p->id32 ? HBK_INT32 : HBK_INT64;
     h.ids = p->recv_ids.ptr;
     h.n_ids = n_own;
     h.n_segments = n_own;

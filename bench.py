@@ -255,6 +255,17 @@ def main():
         'algorithmic_bytes_per_lookup': bytes_per_lookup,
         'avg_launch_us': round(launch_s * 1e6, 3)},
     }
+    if world > 1:
+      # what each rank puts on its xGMI links per step (uniform ids: (W-1)/W of everything
+      # leaves the GPU): int32 ids out, fp32|fp16 rows back; one link per peer
+      id_b = 4 if args.rows <= 0x7fffffff else 8
+      row_b = args.dim * (2 if args.wire == 'fp16' else 4)
+      off = lookups_per_step_per_rank * (world - 1) / world
+      link_bytes = off * (id_b + row_b)
+      result['xgmi'] = {
+        'bytes_out_per_rank_per_step': int(link_bytes), 'links_per_rank': world - 1,
+        'achieved_GBps_per_rank_each_way': round(link_bytes / (elapsed / args.steps) / 1e9, 2),
+        'note': 'the sharded step is link-bound (DESIGN.md 5): one xGMI link per peer pair'}
     if world == 1 and not args.sharded and args.cpu_seconds > 0:
       result['cpu_baseline'] = cpu_baseline(args, tables, batches[0], args.cpu_seconds)
     else:

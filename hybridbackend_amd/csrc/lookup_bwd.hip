@@ -26,11 +26,11 @@
 //                read-modify-write race free); (e) hot rows (>= 64 pairs in the chunk) are
 //                summed by the whole workgroup and folded through a 4 KB LDS buffer (the
 //                "LDS-staged hot rows").  A row that spans chunks is accumulated into its
-//                output row by the owning workgroup.  If the table would pass 7/8 load it is
-//                cleared between chunks; a row seen again afterwards gets a second
-//                IndexedSlices entry (sum semantics preserved).  That needs > 384 distinct rows
-//                in the earlier chunks of one bucket: adversarial hashing, or more than ~4 M
-//                ids in one column (16384 buckets x 256).
+//                output row by the owning workgroup.  If the next chunk could overflow the
+//                table it is cleared first; a row seen again afterwards gets a second
+//                IndexedSlices entry (sum semantics preserved).  That needs ~1000 distinct rows
+//                in one bucket: adversarial hashing, or more than ~14 M ids in one column
+//                (16384 buckets x ~900).
 //   5 split      a bucket far above the average size holds a hot row (Zipf heads: one row can
 //                own 20% of a column).  One workgroup has ~32 KB of loads in flight, so it would
 //                sum such a row at ~15 GB/s while the rest of the chip idles.  The scan kernel
@@ -77,12 +77,13 @@ constexpr int kBatch = 8;
 constexpr int kMaxBuckets = 16384;   // 64 KB of LDS counters in hist / scatter
 constexpr int kCP = HBK_BWD_CP;       // pairs per chunk in the reduce kernel
 constexpr int kSlots = 2 * kCP;       // LDS hash-table slots
-constexpr int kClearAbove = kSlots * 7 / 8 - kCP;  // clear the table before a chunk beyond this
+constexpr int kTableRoom = kSlots - 32;   // clear the table when occupied + next chunk could pass this
 constexpr int kUA = HBK_BWD_UA;       // slots a lane group reduces concurrently (rows in flight)
 constexpr int kHeavy = 64;            // pairs of one row in a chunk that make it a "hot row"
 constexpr int kHotTries = 4;           // ballot rounds that look for a hot row inside a wave
 constexpr int kHotMin = 8;             // lanes sharing a row that make the wave reduce it first
 constexpr int kUH = HBK_BWD_UH;       // rows in flight per lane group while summing a hot row
+constexpr int kMaxRanges = 64;         // chunks of one job whose SGD apply can be deferred
 constexpr unsigned long long kEmptyKey = ~0ull;
 
 struct GCol {
@@ -112,7 +113,7 @@ struct GCol {
   int32_t dim;
   int32_t chunks;
   uint8_t lpr_log2, ids64, combiner, vec4;
-  int32_t log2p;             // buckets = 1 << log2p
+  int32_t n_buckets;         // any count in [1, kMaxBuckets]: bucket = mulhi(mix64(row), count)
   int32_t tile0;             // first tile (hist / scatter grids)
   int32_t bucket0;           // first block (reduce grid)
   int32_t segtile0;          // first block (seg_of grid)
@@ -152,8 +153,8 @@ __device__ inline uint64_t mix64(uint64_t k) {
   return k;
 }
 
-__device__ inline int bucket_of(uint64_t row, int log2p) {
-  return log2p == 0 ? 0 : (int)(mix64(row) >> (64 - log2p));
+__device__ inline int bucket_of(uint64_t row, int n_buckets) {
+  return (int)__umul64hi(mix64(row), (uint64_t)n_buckets);
 }
 
 // Segmented inputs: position j of the column -> where its id and its gradient row live.  A
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void bwd_segof_kernel(const GArgs a) {
 __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
   extern __shared__ int32_t counters[];
   HBK_FIND_COL(a, tile0)
-  const int P = 1 << c.log2p;
+  const int P = c.n_buckets;
   const int tid = (int)threadIdx.x;
   const int ctile = (int)blockIdx.x - c.tile0;
   for (int p = tid; p < P; p += kBlock) counters[p] = 0;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
       const int64_t j = base + (int64_t)(k0 + k) * kBlock + tid;
       if (j < c.n_ids) {
         const uint64_t r = id_to_row(c.map, id[k]);
-        if (r != kNoRow) atomicAdd(&counters[bucket_of(r, c.log2p)], 1);
+        if (r != kNoRow) atomicAdd(&counters[bucket_of(r, c.n_buckets)], 1);
       }
     }
   }
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
 // over all P x tiles entries (0.4 ms per launch on the 200-column config).
 __global__ __launch_bounds__(kBlock) void bwd_scan_tiles_kernel(const GArgs a) {
   HBK_FIND_COL(a, scan0)
-  const int P = 1 << c.log2p;
+  const int P = c.n_buckets;
   const int p = ((int)blockIdx.x - c.scan0) * kBlock + (int)threadIdx.x;
   if (p >= P) return;
   const int n_tiles = (int)((c.n_ids + kTile - 1) / kTile);
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void bwd_scan_kernel(const GArgs a) {
   __shared__ int32_t wave_tot[kWavesPerBlock];
   __shared__ int32_t n_extra;
   const GCol& c = a.col[blockIdx.x];
-  const int P = 1 << c.log2p;
+  const int P = c.n_buckets;
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int per = (P + kBlock - 1) / kBlock;   // contiguous buckets per thread (<= 64)
   const int beg = tid * per;
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void bwd_scan_kernel(const GArgs a) {
 __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a) {
   extern __shared__ int32_t run[];
   HBK_FIND_COL(a, tile0)
-  const int P = 1 << c.log2p;
+  const int P = c.n_buckets;
   const int tid = (int)threadIdx.x;
   const int ctile = (int)blockIdx.x - c.tile0;
   for (int p = tid; p < P; p += kBlock) run[p] = c.bstart[p] + c.hist[(int64_t)ctile * P + p];
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
       if (j < c.n_ids) {
         const uint64_t r = id_to_row(c.map, id[k]);
         if (r != kNoRow) {
-          const int32_t pos = atomicAdd(&run[bucket_of(r, c.log2p)], 1);
+          const int32_t pos = atomicAdd(&run[bucket_of(r, c.n_buckets)], 1);
           c.pair_row[0][pos] = (int64_t)r;
           c.pair_seg[0][pos] = seg[k];
         }
@@ -354,6 +355,8 @@ struct ReduceLds {
   int32_t heavy[kCP / kHeavy + 1];
   int32_t wave_tot[kWavesPerBlock];
   int32_t n_active, n_heavy, base_u, occupied;
+  int32_t rng_base[kMaxRanges];  // output ranges claimed per chunk (deferred SGD apply)
+  int32_t rng_n[kMaxRanges];
   float red[kBlock * 4];     // hot-row partial sums, one 16-byte chunk per thread
 };
 
@@ -391,15 +394,15 @@ __device__ inline V load_grad(const GCol& c, const ReduceJob& job, int32_t seg, 
 
 // out row u += (or =) v, and the fused SGD step on the table row
 template <typename V>
-__device__ inline void emit_row(const GCol& c, const ReduceJob& job, int32_t u, bool is_new,
-                                int64_t row, int sub, V v) {
+__device__ inline void emit_row(const GCol& c, const ReduceJob& job, float lr, int32_t u,
+                                bool is_new, int64_t row, int sub, V v) {
   constexpr int VE = sizeof(V) / 4;
   V* o = reinterpret_cast<V*>(job.out_vals + (int64_t)u * c.dim + (int64_t)sub * VE);
   // rows are owned by this workgroup; bypass L1 when re-reading what an earlier chunk wrote
   *o = is_new ? v : __builtin_nontemporal_load(o) + v;
-  if (job.lr != 0.0f) {
+  if (lr != 0.0f) {
     V* t = reinterpret_cast<V*>(c.table + row * c.dim + (int64_t)sub * VE);
-    *t = __builtin_nontemporal_load(t) - job.lr * v;
+    *t = __builtin_nontemporal_load(t) - lr * v;
   }
 }
 
@@ -426,9 +429,15 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
   if (tid == 0) L.occupied = 0;
   __syncthreads();
 
+  // A row that spans chunks is summed across them in its output row; applying the SGD step chunk
+  // by chunk would round differently from table -= lr * grad_row.  Jobs with several chunks
+  // (rare: buckets aim at 7/8 of a chunk) therefore only emit, remember the output ranges they
+  // claimed, and apply the step once per row at the end.
+  const bool defer = job.lr != 0.0f && n_pairs > kCP && n_pairs <= kCP * kMaxRanges;
+  const float lr_chunk = defer ? 0.0f : job.lr;
   for (int32_t cb = 0; cb < n_pairs; cb += kCP) {
     const int32_t n_chunk = n_pairs - cb < kCP ? n_pairs - cb : kCP;
-    if (L.occupied > kClearAbove) {  // uniform: read after a barrier
+    if (L.occupied + n_chunk > kTableRoom) {  // uniform: read after a barrier
       __syncthreads();
       for (int i = tid; i < kSlots; i += kBlock) {
         L.keys[i] = kEmptyKey;
@@ -479,7 +488,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       }
       if (valid && h < 0) {
         h = (int)(mix64(row) & (kSlots - 1));
-        for (;;) {  // the table never fills: cleared above kClearAbove
+        for (;;) {  // the table never fills: cleared before a chunk that could pass kTableRoom
           const unsigned long long prev = atomicCAS(&L.keys[h], kEmptyKey, row);
           if (prev == kEmptyKey || prev == row) break;
           h = (h + 1) & (kSlots - 1);
@@ -516,6 +525,10 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         L.n_active = (tot >> 10) & 1023;
         L.base_u = job.out_base + (n_new > 0 ? atomicAdd(job.out_counter, n_new) : 0);
         L.occupied += n_new;
+        if (defer) {
+          L.rng_base[cb / kCP] = L.base_u;
+          L.rng_n[cb / kCP] = n_new;
+        }
       }
       __syncthreads();
       const int32_t base_u = L.base_u;
@@ -604,7 +617,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
 #pragma unroll
       for (int u = 0; u < kUA; ++u) {
         if (slot[u] >= 0 && live) {
-          emit_row<V>(c, job, L.slot_out[slot[u]], (L.cnt[slot[u]] & kNewBit) != 0,
+          emit_row<V>(c, job, lr_chunk, L.slot_out[slot[u]], (L.cnt[slot[u]] & kNewBit) != 0,
                       (int64_t)L.keys[slot[u]], sub, acc[u]);
         }
       }
@@ -636,12 +649,28 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         for (int gi = 0; gi < groups; ++gi) {
           tot = tot + *reinterpret_cast<const V*>(&L.red[((size_t)(gi << lpr_log2) + sub) * VE]);
         }
-        emit_row<V>(c, job, L.slot_out[s], (L.cnt[s] & kNewBit) != 0, (int64_t)L.keys[s], sub,
-                    tot);
+        emit_row<V>(c, job, lr_chunk, L.slot_out[s], (L.cnt[s] & kNewBit) != 0,
+                    (int64_t)L.keys[s], sub, tot);
       }
       __syncthreads();
     }
     __syncthreads();
+  }
+  if (defer) {
+    const int n_rng = (n_pairs + kCP - 1) / kCP;
+    for (int r = 0; r < n_rng; ++r) {
+      const int32_t base = L.rng_base[r], n = L.rng_n[r];
+      for (int32_t i = my_group; i < n; i += groups) {
+        if (!live) continue;
+        const int32_t u = base + i;
+        const int64_t row = job.out_rows[u];
+        const V v = __builtin_nontemporal_load(
+            reinterpret_cast<const V*>(job.out_vals + (int64_t)u * c.dim + (int64_t)sub * VE));
+        V* t = reinterpret_cast<V*>(c.table + row * c.dim + (int64_t)sub * VE);
+        *t = __builtin_nontemporal_load(t) - job.lr * v;
+      }
+      __syncthreads();  // rows are distinct inside a range, not across ranges (table clears)
+    }
   }
 }
 
@@ -654,7 +683,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
   HBK_FIND_COL(a, bucket0)
   if ((c.vec4 != 0) != (sizeof(V) == 16)) return;
   const int bi = (int)blockIdx.x - c.bucket0;
-  const int P = 1 << c.log2p;
+  const int P = c.n_buckets;
   int bucket = bi, range = 0;
   if (bi >= P) {
     const int e = bi - P;
@@ -802,14 +831,15 @@ __global__ __launch_bounds__(kBlock) void stitch_bwd_kernel(const SArgs a) {
 inline size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 
 struct ColPlan {
-  int log2p;
+  int n_buckets;
   int64_t tiles;
   int32_t split_t;   // a bucket above this many pairs is reduced by several workgroups
   int32_t e_max;
 };
 
-// test hook: HBK_BWD_LOG2P forces the bucket count (0 = one bucket per column) so that
-// multi-chunk buckets, rows spanning chunks and the table-clear path are exercised
+// test hooks: HBK_BWD_LOG2P forces the bucket count to 1 << value (0 = one bucket per column) so
+// that multi-chunk buckets, rows spanning chunks and the table-clear path are exercised;
+// HBK_BWD_TARGET sets the aimed pairs per bucket (tuning)
 int forced_log2p() {
   const char* e = getenv("HBK_BWD_LOG2P");
   return e ? atoi(e) : -1;
@@ -818,16 +848,23 @@ int forced_log2p() {
 ColPlan plan_of(int64_t n_ids, int32_t dim) {
   (void)dim;
   ColPlan p;
-  int lp = 0;  // aim at kCP / 2 pairs per bucket: one chunk with headroom
-  while (lp < 14 && ((int64_t)(kCP / 2) << lp) < n_ids) ++lp;
-  while (((int64_t)1 << lp) > kMaxBuckets) --lp;
+  // Aim at 7/8 of a chunk per bucket: bucket sizes are Poisson around the aim, so ~0.1 % of the
+  // buckets need a second (short) chunk, while the per-workgroup fixed cost (table init,
+  // 1024-slot scan) is spread over as many pairs as possible.  Measured, config 2 backward:
+  // aim 256 171 us, 320 165, 384 157, 448 147, 512 149.
+  int64_t target = kCP * 7 / 8;
+  const char* te = getenv("HBK_BWD_TARGET");
+  if (te != nullptr && atoi(te) > 0) target = atoi(te);
+  int64_t nb = (n_ids + target - 1) / target;
+  if (nb < 1) nb = 1;
+  if (nb > kMaxBuckets) nb = kMaxBuckets;
   const int forced = forced_log2p();
-  if (forced >= 0 && forced <= 14) lp = forced;
-  p.log2p = lp;
+  if (forced >= 0 && forced <= 14) nb = (int64_t)1 << forced;
+  p.n_buckets = (int)nb;
   p.tiles = (n_ids + kTile - 1) / kTile;
-  // hashing keeps ordinary buckets near n / P pairs; 4x that (and >= 2 chunks) means a hot row
+  // hashing keeps ordinary buckets near n / P pairs; twice that (and >= 2 chunks) means a hot row
   // (measured, config 4 backward: ranges of 1024 pairs 391 us, 2048 417 us, 4096 466 us)
-  int64_t t = 4 * ((n_ids + ((int64_t)1 << lp) - 1) >> lp);
+  int64_t t = 2 * ((n_ids + nb - 1) / nb) + 128;
   if (t < 2 * kCP) t = 2 * kCP;
   const char* e = getenv("HBK_BWD_SPLIT");   // test hook
   if (e != nullptr && atoi(e) > 0) t = atoi(e);
@@ -839,13 +876,13 @@ ColPlan plan_of(int64_t n_ids, int32_t dim) {
 size_t col_workspace(const hbk_lookup_grad_column_t& h) {
   if (h.n_ids <= 0) return 0;
   const ColPlan p = plan_of(h.n_ids, h.dim);
-  size_t b = align8(((size_t)p.tiles << p.log2p) * 4);   // hist
-  b += align8((((size_t)1 << p.log2p) + 1) * 4);          // bstart
+  size_t b = align8(((size_t)p.tiles * p.n_buckets) * 4);   // hist
+  b += align8(((size_t)p.n_buckets + 1) * 4);          // bstart
   b += (size_t)h.n_ids * 8;                                // pair_row
   b += align8((size_t)h.n_ids * 4);                        // pair_seg
   if (h.row_splits != nullptr) b += align8((size_t)h.n_ids * 4);
   b += align8((size_t)p.e_max * 8) + 8;                    // work, n_extra
-  b += align8(((size_t)1 << p.log2p) * 4);                 // pcount
+  b += align8(((size_t)p.n_buckets) * 4);                 // pcount
   b += (size_t)h.n_ids * 8;                                // part_rows
   b += align8((size_t)h.n_ids * h.dim * 4) + 16;           // part_vals (16-byte aligned)
   return b;
@@ -927,9 +964,9 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       d.n_unique = h.n_unique;
       d.table = h.table;
       d.hist = reinterpret_cast<int32_t*>(wp);
-      wp += align8(((size_t)p.tiles << p.log2p) * 4);
+      wp += align8(((size_t)p.tiles * p.n_buckets) * 4);
       d.bstart = reinterpret_cast<int32_t*>(wp);
-      wp += align8((((size_t)1 << p.log2p) + 1) * 4);
+      wp += align8(((size_t)p.n_buckets + 1) * 4);
       d.pair_row[0] = reinterpret_cast<int64_t*>(wp);
       wp += (size_t)h.n_ids * 8;
       d.pair_seg[0] = reinterpret_cast<int32_t*>(wp);
@@ -944,7 +981,7 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       d.n_extra = reinterpret_cast<int32_t*>(wp);
       wp += 8;
       d.pcount = reinterpret_cast<int32_t*>(wp);
-      wp += align8(((size_t)1 << p.log2p) * 4);
+      wp += align8(((size_t)p.n_buckets) * 4);
       d.part_rows = reinterpret_cast<int64_t*>(wp);
       wp += (size_t)h.n_ids * 8;
       d.part_vals = reinterpret_cast<float*>(((uintptr_t)wp + 15) & ~(uintptr_t)15);
@@ -954,7 +991,7 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       d.merge0 = (int32_t)merges;
       merges += p.e_max;
       d.scan0 = (int32_t)scans;
-      scans += (((int64_t)1 << p.log2p) + kBlock - 1) / kBlock;
+      scans += ((int64_t)p.n_buckets + kBlock - 1) / kBlock;
       d.run_start = h.run_start;
       d.run_ids = h.run_ids;
       d.run_grads = h.run_grads;
@@ -974,15 +1011,15 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       d.vec4 = shape.vec4;
       d.ids64 = h.ids_dtype == HBK_INT64;
       d.combiner = (uint8_t)h.combiner;
-      d.log2p = p.log2p;
+      d.n_buckets = p.n_buckets;
       d.tile0 = (int32_t)tiles;
       d.bucket0 = (int32_t)buckets;
       d.segtile0 = 0;
       tiles += p.tiles;
-      buckets += ((int64_t)1 << p.log2p) + p.e_max;
+      buckets += (int64_t)p.n_buckets + p.e_max;
       HBK_REQUIRE(tiles < (1ll << 31) && buckets < (1ll << 31),
                   "group_lookup_bwd: grid too large");
-      if (((size_t)4 << p.log2p) > lds_hist) lds_hist = (size_t)4 << p.log2p;
+      if ((size_t)4 * p.n_buckets > lds_hist) lds_hist = (size_t)4 * p.n_buckets;
       if (h.row_splits != nullptr && h.n_segments > 0) {
         GCol& sdesc = seg_args.col[ks];
         sdesc = d;

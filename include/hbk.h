@@ -180,8 +180,8 @@ int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
  *   each group is reduced by one workgroup (LDS hash table of the distinct rows, sums in
  *   registers; a group holding a hot row is split over several workgroups and merged), so the
  *   summation order is not fixed: tolerance 1e-5 relative.  Rows are distinct unless one group
- *   holds more distinct rows than its LDS table (adversarial hashing, or more than ~4 M ids in
- *   one column): then a row may appear in more than one entry, sum semantics preserved
+ *   holds more distinct rows than its LDS table (~1000: adversarial hashing, or more than
+ *   ~14 M ids in one column): then a row may appear in more than one entry, sum semantics preserved
  *   (IndexedSlices allow repeated indices; the fused SGD apply stays exact).
  *   apply_lr != 0 additionally performs the sparse SGD update on the shard in the same
  *   pass: table[unique_rows[u],:] -= apply_lr * grad_rows[u,:] (sharded variables skip

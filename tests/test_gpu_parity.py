@@ -369,6 +369,12 @@ def test_group_lookup_backward_multi_chunk_and_table_clear_path(monkeypatch):
     ref = table.astype(np.float64)
     np.subtract.at(ref, ids % rows, 0.5 * grads.astype(np.float64))
     np.testing.assert_allclose(host(t_dev), ref, rtol=RTOL, atol=1e-4)
+    # rows span chunks here; the step is applied once per emitted entry, after the last chunk:
+    # bit-equal to table -= lr * grad_rows
+    k = int(res[2].item())
+    want = table.copy()
+    oracle.sparse_sgd_apply(want, host(res[0])[:k], host(res[1])[:k], 0.5)
+    np.testing.assert_equal(host(t_dev), want)
 
 
 

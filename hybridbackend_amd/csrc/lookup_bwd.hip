@@ -70,10 +70,13 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxCols = 64;
-constexpr int kTile = 4096;          // ids per 256-thread block in hist / scatter: few tiles keep
-                                     // the [bucket][tile] histogram (and its scan) small
-constexpr int kPerThread = kTile / kBlock;   // 16 ids per thread, 8 loads in flight
-constexpr int kBatch = 8;
+#ifndef HBK_BWD_TILE
+#define HBK_BWD_TILE 2048
+#endif
+constexpr int kTile = HBK_BWD_TILE;  // ids per 256-thread block in hist / scatter (config 2
+                                     // backward: 4096 149 us, 2048 139, 1024 145, 512 158)
+constexpr int kPerThread = kTile / kBlock;
+constexpr int kBatch = kPerThread < 8 ? kPerThread : 8;   // loads in flight per thread
 constexpr int kMaxBuckets = 16384;   // 64 KB of LDS counters in hist / scatter
 constexpr int kCP = HBK_BWD_CP;       // pairs per chunk in the reduce kernel
 constexpr int kSlots = 2 * kCP;       // LDS hash-table slots
@@ -131,6 +134,7 @@ struct GArgs {
   GCol col[kMaxCols];
 };
 static_assert(sizeof(GArgs) <= 24576, "kernarg budget");
+static_assert(kSlots <= 65536 && kCP <= 65536, "16-bit LDS indices");
 
 #define HBK_FIND_COL(ARGS, FIELD)                                                  \
   int ci = 0, hi__ = (ARGS).n_cols;                                                \
@@ -348,10 +352,10 @@ struct ReduceLds {
   int32_t cnt[kSlots];       // pairs of the slot in this chunk; bit 30: row is new in this chunk
   int32_t off[kSlots];       // start of the slot's pairs in `order` (turned into the end by (c))
   int32_t slot_out[kSlots];  // output row of the slot, -1 = none yet
-  int32_t active[kCP];       // slots with pairs in this chunk
-  int32_t order[kCP];        // pair indices grouped by slot
   int32_t segs[kCP];         // segment (= row of grad_out) of every pair of the chunk
-  int32_t pslot[kCP];
+  uint16_t active[kCP];      // slots with pairs in this chunk
+  uint16_t order[kCP];       // pair indices grouped by slot
+  uint16_t pslot[kCP];       // 16-bit: 30.5 KB per workgroup = five workgroups per CU
   int32_t heavy[kCP / kHeavy + 1];
   int32_t wave_tot[kWavesPerBlock];
   int32_t n_active, n_heavy, base_u, occupied;
@@ -495,7 +499,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         }
         atomicAdd(&L.cnt[h], 1);
       }
-      if (valid) L.pslot[e] = h;
+      if (valid) L.pslot[e] = (uint16_t)h;
     }
     __syncthreads();
 
@@ -537,7 +541,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         const int s = tid * (kSlots / kBlock) + k;
         if (local[k] != 0) {
           L.off[s] = run & 1023;
-          L.active[(run >> 10) & 1023] = s;
+          L.active[(run >> 10) & 1023] = (uint16_t)s;
           if (local[k] >> 20) {
             const int32_t u = base_u + (run >> 20);
             L.slot_out[s] = u;
@@ -573,7 +577,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       }
       if (valid) {
         if (pos < 0) pos = atomicAdd(&L.off[h], 1);
-        L.order[pos] = e;
+        L.order[pos] = (uint16_t)e;
       }
     }
     __syncthreads();

@@ -179,8 +179,12 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
   for (auto& t : tables) CK(hipFree(t));
 }
 
-int main() {
+int main(int argc, char** argv) {
   printf("hbk %s -- C-ABI wall time per call (HIP events, no Python)\n", hbk_version());
+  if (argc > 1 && argv[1][0] == 'b') {  // "bwd": only the config-2 backward (for --pmc passes)
+    bench_backward(26, 65536, 16, 1000000, 0.f);
+    return 0;
+  }
   bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 8", 26, 65536, 8, HBK_INT64);
   bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 2", 26, 65536, 2, HBK_INT64);
   bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 64", 26, 65536, 64, HBK_INT64);

@@ -92,6 +92,8 @@ def _declare(l):
     'hbk_group_lookup_bwd': (C.c_int, [i32, vp, C.c_float, vp, sz, vp]),
     'hbk_group_stitch_bwd': (C.c_int, [i32, vp, vp]),
     'hbk_cache_probe': (C.c_int, [vp, i64, i32, vp, i64, vp, vp, vp]),
+    'hbk_cache_lookup_workspace_bytes': (sz, [i64]),
+    'hbk_cache_lookup': (C.c_int, [vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
     'hbk_murmur3_hash32': (C.c_int, [vp, i64, vp, vp]),
     'hbk_comm_get_id': (C.c_int, [vp]),
     'hbk_comm_create': (C.c_int, [vp, vp, i32, i32, i32]),

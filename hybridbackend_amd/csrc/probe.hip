@@ -100,8 +100,143 @@ __global__ __launch_bounds__(kBlock) void cache_probe_kernel(
   }
 }
 
+// ---- compaction of the per-key result into the op's four lists (stable: key order kept) -----
+constexpr int kTileKeys = 1024;  // keys per 256-thread block
+
+__global__ __launch_bounds__(kBlock) void probe_count_kernel(const int64_t* hit_slot, int64_t n,
+                                                             int32_t* tile_hits) {
+  __shared__ int32_t wave_hits[kBlock / kWave];
+  const int lane = lane_id(), wave = (int)threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kTileKeys;
+  int32_t hits = 0;
+#pragma unroll
+  for (int k = 0; k < kTileKeys / kBlock; ++k) {
+    const int64_t i = base + (int64_t)k * kBlock + threadIdx.x;
+    hits += (int32_t)__builtin_popcountll(__ballot(i < n && hit_slot[i] >= 0));
+  }
+  if (lane == 0) wave_hits[wave] = hits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t t = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) t += wave_hits[w];
+    tile_hits[blockIdx.x] = t;
+  }
+}
+
+// one block: exclusive scan of the tile hit counts (in place) + the two totals
+__global__ __launch_bounds__(kBlock) void probe_scan_kernel(int32_t* tile_hits, int64_t n_tiles,
+                                                            int64_t n_keys, int32_t* counts) {
+  __shared__ int32_t wave_tot[kBlock / kWave];
+  __shared__ int32_t carry_s;
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t e0 = 0; e0 < n_tiles; e0 += kBlock) {
+    const int64_t e = e0 + tid;
+    const int32_t x = e < n_tiles ? tile_hits[e] : 0;
+    int32_t s = x;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int32_t y = __shfl_up(s, off, kWave);
+      if (lane >= off) s += y;
+    }
+    if (lane == kWave - 1) wave_tot[wave] = s;
+    __syncthreads();
+    int32_t run = carry_s + s - x;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
+    if (e < n_tiles) tile_hits[e] = run;
+    __syncthreads();
+    if (tid == kBlock - 1) carry_s = run + x;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    counts[0] = carry_s;
+    counts[1] = (int32_t)(n_keys - carry_s);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void probe_emit_kernel(
+    const int64_t* hit_slot, const int64_t* keys, int64_t n, const int32_t* tile_hits,
+    int32_t* hit_keys_indices, int64_t* hit_cache_indices, int32_t* miss_keys_indices,
+    int64_t* miss_keys) {
+  __shared__ int32_t wave_hits[kTileKeys / kWave];
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kTileKeys;
+  // chunk q of 64 keys = pass k, wave w: q = k * 4 + w (key order inside the tile)
+  int64_t slot[kTileKeys / kBlock];
+  unsigned long long mask[kTileKeys / kBlock];
+#pragma unroll
+  for (int k = 0; k < kTileKeys / kBlock; ++k) {
+    const int64_t i = base + (int64_t)k * kBlock + tid;
+    slot[k] = i < n ? hit_slot[i] : -1;
+    mask[k] = __ballot(i < n && slot[k] >= 0);
+    if (lane == 0) wave_hits[k * (kBlock / kWave) + wave] = (int32_t)__builtin_popcountll(mask[k]);
+  }
+  __syncthreads();
+  const int32_t hit_base = tile_hits[blockIdx.x];
+  const int32_t miss_base = (int32_t)(base - hit_base);
+#pragma unroll
+  for (int k = 0; k < kTileKeys / kBlock; ++k) {
+    const int q = k * (kBlock / kWave) + wave;
+    int32_t before = 0;
+    for (int j = 0; j < q; ++j) before += wave_hits[j];
+    const int64_t i = base + (int64_t)k * kBlock + tid;
+    if (i >= n) continue;
+    const int32_t in_chunk = rank_below(mask[k]);
+    if (slot[k] >= 0) {
+      const int32_t pos = hit_base + before + in_chunk;
+      hit_keys_indices[pos] = (int32_t)i;
+      hit_cache_indices[pos] = slot[k];
+    } else {
+      const int32_t pos = miss_base + (q * kWave - before) + (lane - in_chunk);
+      miss_keys_indices[pos] = (int32_t)i;
+      miss_keys[pos] = keys[i];
+    }
+  }
+}
+
 }  // namespace
 }  // namespace hbk
+
+extern "C" size_t hbk_cache_lookup_workspace_bytes(int64_t n_keys) {
+  if (n_keys <= 0) return 0;
+  const int64_t tiles = (n_keys + hbk::kTileKeys - 1) / hbk::kTileKeys;
+  return (size_t)n_keys * 8 + (size_t)tiles * 4 + 16;
+}
+
+extern "C" int hbk_cache_lookup(const int64_t* keys_cache, int64_t slab_count,
+                                int32_t slab_size, const int64_t* keys, int64_t n_keys,
+                                int32_t* hit_keys_indices, int64_t* hit_cache_indices,
+                                int32_t* miss_keys_indices, int64_t* miss_keys, int32_t* counts,
+                                void* workspace, size_t workspace_bytes, hbk_stream_t stream) {
+  using namespace hbk;
+  HBK_REQUIRE(counts != nullptr, "cache_lookup: counts is NULL");
+  HBK_REQUIRE(n_keys >= 0 && n_keys < (1ll << 31), "cache_lookup: n_keys out of range");
+  if (n_keys == 0) {
+    HBK_HIP_OK(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), as_stream(stream)));
+    return HBK_OK;
+  }
+  HBK_REQUIRE(hit_keys_indices && hit_cache_indices && miss_keys_indices && miss_keys,
+              "cache_lookup: NULL output");
+  const size_t need = hbk_cache_lookup_workspace_bytes(n_keys);
+  HBK_REQUIRE(workspace != nullptr && workspace_bytes >= need && ((uintptr_t)workspace & 7) == 0,
+              "cache_lookup: workspace too small or misaligned: need %zu bytes", need);
+  int64_t* hit_slot = reinterpret_cast<int64_t*>(workspace);
+  int32_t* tile_hits = reinterpret_cast<int32_t*>(hit_slot + n_keys);
+  int rc = hbk_cache_probe(keys_cache, slab_count, slab_size, keys, n_keys, hit_slot, nullptr,
+                           stream);
+  if (rc != HBK_OK) return rc;
+  const int64_t tiles = (n_keys + kTileKeys - 1) / kTileKeys;
+  hipLaunchKernelGGL(probe_count_kernel, dim3((unsigned)tiles), dim3(kBlock), 0,
+                     as_stream(stream), hit_slot, n_keys, tile_hits);
+  hipLaunchKernelGGL(probe_scan_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), tile_hits,
+                     tiles, n_keys, counts);
+  hipLaunchKernelGGL(probe_emit_kernel, dim3((unsigned)tiles), dim3(kBlock), 0,
+                     as_stream(stream), hit_slot, keys, n_keys, tile_hits, hit_keys_indices,
+                     hit_cache_indices, miss_keys_indices, miss_keys);
+  HBK_HIP_OK(hipGetLastError());
+  return HBK_OK;
+}
 
 extern "C" int hbk_murmur3_hash32(const int64_t* keys, int64_t n_keys, uint32_t* out,
                                   hbk_stream_t stream) {

@@ -260,6 +260,19 @@ int hbk_group_stitch_bwd(int32_t n_cols, const hbk_stitch_grad_column_t* cols,
 int hbk_cache_probe(const int64_t* keys_cache, int64_t slab_count, int32_t slab_size,
                     const int64_t* keys, int64_t n_keys, int64_t* hit_slot,
                     int32_t* n_miss, hbk_stream_t stream);
+/* The op's four outputs (lookup_ops.cc:38-58), key order kept inside each list (the reference
+ * fills them through atomic counters, i.e. in no particular order):
+ *   hit_keys_indices[h]  = i of the h-th key found        hit_cache_indices[h] = its cache index
+ *   miss_keys_indices[m] = i of the m-th key not found    miss_keys[m]         = keys[i]
+ * All four have capacity n_keys; counts (device int32[2]) = {n_hit, n_miss}.  The op sizes its
+ * outputs from counts after one host sync (lookup_ops.cc:118-121); the C ABI leaves that to the
+ * caller. */
+size_t hbk_cache_lookup_workspace_bytes(int64_t n_keys);
+int hbk_cache_lookup(const int64_t* keys_cache, int64_t slab_count, int32_t slab_size,
+                     const int64_t* keys, int64_t n_keys, int32_t* hit_keys_indices,
+                     int64_t* hit_cache_indices, int32_t* miss_keys_indices, int64_t* miss_keys,
+                     int32_t* counts, void* workspace, size_t workspace_bytes,
+                     hbk_stream_t stream);
 /* test hook: murmur3_hash32<int64, 0> of each key, on device */
 int hbk_murmur3_hash32(const int64_t* keys, int64_t n_keys, uint32_t* out,
                        hbk_stream_t stream);

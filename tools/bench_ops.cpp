@@ -179,6 +179,74 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
   for (auto& t : tables) CK(hipFree(t));
 }
 
+static void bench_streaming(int n_cols, int64_t len) {
+  // R1 bucketize and R6 wire casts: pure streams, N tensors per launch
+  int64_t* ids = dev_random<int64_t>((size_t)n_cols * len, (uint64_t)1 << 40);
+  int64_t* out = dev_alloc<int64_t>((size_t)n_cols * len);
+  std::vector<const void*> in(n_cols);
+  std::vector<void*> o(n_cols);
+  std::vector<int64_t> lens(n_cols, len), buckets(n_cols, 1000000);
+  for (int c = 0; c < n_cols; ++c) {
+    in[c] = ids + (size_t)c * len;
+    o[c] = out + (size_t)c * len;
+  }
+  float us = time_us(50, [&](int) {
+    HB(hbk_floormod_n(n_cols, HBK_INT64, in.data(), lens.data(), buckets.data(), o.data(), nullptr));
+  });
+  char what[128];
+  const double n = (double)n_cols * len;
+  snprintf(what, sizeof(what), "floormod_n %d x %lld int64 %% 1000000", n_cols, (long long)len);
+  printf("%-66s %9.2f us  %8.1f M ids/s  %7.1f GB/s (%.3f of 8 TB/s)\n", what, us, n / us,
+         n * 16 / us / 1e3, n * 16 / us / 1e3 / 8000.0);
+  const int64_t fl = len * 16;  // one column's rows of a dim-16 exchange
+  float* f32 = dev_alloc<float>((size_t)n_cols * fl);
+  uint16_t* f16 = dev_alloc<uint16_t>((size_t)n_cols * fl);
+  CK(hipMemset(f32, 0x3c, (size_t)n_cols * fl * 4));
+  std::vector<int64_t> flens(n_cols, fl);
+  for (int c = 0; c < n_cols; ++c) {
+    in[c] = f32 + (size_t)c * fl;
+    o[c] = f16 + (size_t)c * fl;
+  }
+  us = time_us(50, [&](int) {
+    HB(hbk_cast_n(n_cols, HBK_FLOAT, HBK_HALF, in.data(), flens.data(), o.data(), nullptr));
+  });
+  const double nf = (double)n_cols * fl;
+  snprintf(what, sizeof(what), "cast_n fp32 -> fp16, %d x %lld floats", n_cols, (long long)fl);
+  printf("%-66s %9.2f us  %7.1f GB/s (%.3f of 8 TB/s)\n", what, us, nf * 6 / us / 1e3,
+         nf * 6 / us / 1e3 / 8000.0);
+}
+
+static void bench_probe(int64_t n_keys, int64_t slab_count, int slab_size) {
+  // every slab half full (odd slots EMPTY, so a probe ends in its first slab); half of the looked
+  // up keys are present
+  std::vector<int64_t> hc_(slab_count * slab_size), hk_(n_keys);
+  for (size_t i = 0; i < hc_.size(); ++i) {
+    hc_[i] = (i & 1) ? INT64_MIN : (int64_t)(rnd() % ((uint64_t)1 << 40));
+  }
+  for (int64_t i = 0; i < n_keys; ++i) {
+    hk_[i] = (i & 1) ? (int64_t)(rnd() % ((uint64_t)1 << 40)) : hc_[(rnd() % (hc_.size() / 2)) * 2];
+  }
+  int64_t* cache = dev_alloc<int64_t>(hc_.size());
+  int64_t* keys = dev_alloc<int64_t>(n_keys);
+  CK(hipMemcpy(cache, hc_.data(), hc_.size() * 8, hipMemcpyHostToDevice));
+  CK(hipMemcpy(keys, hk_.data(), n_keys * 8, hipMemcpyHostToDevice));
+  int32_t* hi = dev_alloc<int32_t>(n_keys);
+  int64_t* hc = dev_alloc<int64_t>(n_keys);
+  int32_t* mi = dev_alloc<int32_t>(n_keys);
+  int64_t* mk = dev_alloc<int64_t>(n_keys);
+  int32_t* counts = dev_alloc<int32_t>(2);
+  const size_t ws_bytes = hbk_cache_lookup_workspace_bytes(n_keys);
+  char* ws = dev_alloc<char>(ws_bytes);
+  float us = time_us(50, [&](int) {
+    HB(hbk_cache_lookup(cache, slab_count, slab_size, keys, n_keys, hi, hc, mi, mk, counts, ws,
+                        ws_bytes, nullptr));
+  });
+  char what[128];
+  snprintf(what, sizeof(what), "cache_lookup %lld keys, %lld slabs x %d (probe + 4 compacted lists)",
+           (long long)n_keys, (long long)slab_count, slab_size);
+  printf("%-66s %9.2f us  %8.1f M keys/s\n", what, us, (double)n_keys / us);
+}
+
 int main(int argc, char** argv) {
   printf("hbk %s -- C-ABI wall time per call (HIP events, no Python)\n", hbk_version());
   if (argc > 1 && argv[1][0] == 'b') {  // "bwd": only the config-2 backward (for --pmc passes)
@@ -196,5 +264,8 @@ int main(int argc, char** argv) {
   bench_backward(26, 65536, 16, 1000000, 0.f);
   bench_backward(26, 65536, 16, 1000000, 0.01f);
   bench_backward(26, 65536, 128, 1000000, 0.f);
+  bench_streaming(26, 65536);
+  bench_streaming(26, 1048576);
+  bench_probe(26 * 65536, 1 << 16, 32);
   return 0;
 }

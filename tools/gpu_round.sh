@@ -17,7 +17,7 @@ for st in $STAGES; do
       timeout 600 python bench.py --steps 50 --warmup 10 > $O/bench.log 2>&1; echo "bench rc=$?" >> $O/bench.log; tail -3 $O/bench.log
       timeout 300 python bench.py --steps 50 --warmup 10 --batch 262144 --cpu-seconds 0 > $O/bench_b262144.log 2>&1; tail -2 $O/bench_b262144.log;;
     ops)
-      timeout 300 tools/bin/bench_ops > $O/bench_ops.log 2>&1; echo "ops rc=$?" >> $O/bench_ops.log; cat $O/bench_ops.log;;
+      timeout 120 tools/bin/bench_ops > $O/bench_ops.log 2>&1; echo "ops rc=$?" >> $O/bench_ops.log; cat $O/bench_ops.log;;
     tune)
       timeout 600 tools/bin/tune_lookup > $O/tune.log 2>&1; echo "tune rc=$?" >> $O/tune.log; cat $O/tune.log;;
     prof)

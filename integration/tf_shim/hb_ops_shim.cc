@@ -474,8 +474,61 @@ REGISTER_OP("HbLookup")
     .Output("miss_keys_indices: Tindices").Output("miss_keys: T")
     .Input("keys_cache: T").Input("keys: T")
     .Attr("T: type").Attr("Tindices: {int32}").Attr("cache_slab_size: int");
-// Kernel: hbk_cache_probe gives hit_slot[i] per key (and the miss count); the four outputs are a
-// stream compaction of it (one host sync for the miss count, as lookup_ops.cc:118-121 does).
+
+// hbk_cache_lookup fills four capacity-n lists and {n_hit, n_miss} on the device; the op sizes
+// its outputs from the counts after one host sync (as lookup_ops.cc:118-121 does) and copies the
+// used prefixes out.
+template <typename T>
+class LookupOp : public OpKernel {
+ public:
+  explicit LookupOp(OpKernelConstruction* ctx) : OpKernel(ctx) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("cache_slab_size", &slab_size_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor& cache = ctx->input(0);
+    const Tensor& keys = ctx->input(1);
+    const int64 n = keys.NumElements();
+    OP_REQUIRES(ctx, slab_size_ >= 1 && cache.NumElements() % slab_size_ == 0,
+                errors::InvalidArgument("keys_cache must hold a whole number of slabs"));
+    Tensor hit_idx, hit_cache, miss_idx, miss_keys, counts, ws;
+    OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_INT32, TensorShape({n}), &hit_idx));
+    OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_INT64, TensorShape({n}), &hit_cache));
+    OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_INT32, TensorShape({n}), &miss_idx));
+    OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_INT64, TensorShape({n}), &miss_keys));
+    OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_INT32, TensorShape({2}), &counts));
+    const size_t ws_bytes = hbk_cache_lookup_workspace_bytes(n);
+    OP_REQUIRES_OK(ctx, AllocScratch(ctx, ws_bytes, &ws));
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_cache_lookup(
+        reinterpret_cast<const int64_t*>(cache.flat<T>().data()),
+        cache.NumElements() / slab_size_, slab_size_,
+        reinterpret_cast<const int64_t*>(keys.flat<T>().data()), n,
+        hit_idx.flat<int32>().data(), reinterpret_cast<int64_t*>(hit_cache.flat<int64>().data()),
+        miss_idx.flat<int32>().data(), reinterpret_cast<int64_t*>(miss_keys.flat<int64>().data()),
+        counts.flat<int32>().data(), ws.flat<int8>().data(), ws_bytes + 16, StreamOf(ctx))));
+    int32 host_counts[2];
+    auto* stream = ctx->op_device_context()->stream();
+    se::DeviceMemoryBase src(counts.flat<int32>().data(), sizeof(host_counts));
+    stream->ThenMemcpy(host_counts, src, sizeof(host_counts));
+    OP_REQUIRES_OK(ctx, stream->BlockHostUntilDone());
+    const Tensor* parts[4] = {&hit_idx, &hit_cache, &miss_idx, &miss_keys};
+    for (int i = 0; i < 4; ++i) {
+      const int64 k = host_counts[i / 2];
+      Tensor* out;
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, TensorShape({k}), &out));
+      if (k == 0) continue;
+      const size_t bytes = k * (i % 2 == 0 ? sizeof(int32) : sizeof(int64));
+      se::DeviceMemoryBase d(const_cast<char*>(out->tensor_data().data()), bytes);
+      se::DeviceMemoryBase s(const_cast<char*>(parts[i]->tensor_data().data()), bytes);
+      stream->ThenMemcpy(&d, s, bytes);
+    }
+  }
+
+ private:
+  int32 slab_size_;
+};
+REGISTER_KERNEL_BUILDER(
+    Name("HbLookup").Device(DEVICE_GPU).TypeConstraint<int64>("T").TypeConstraint<int32>("Tindices"),
+    LookupOp<int64>);
 
 // ============================================================================================
 // HbGroupLookup / HbGroupLookupGrad (new, additive; N-ary conventions of the Hb...N ops)

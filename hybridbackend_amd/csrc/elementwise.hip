@@ -33,31 +33,50 @@ struct EwArgs {
 static_assert(sizeof(EwArgs) <= 16384, "kernarg budget");
 
 __device__ inline int find_col(const EwArgs& a, int tile) {
-  int ci = 0;
-  while (ci + 1 < a.n_cols && a.col[ci + 1].tile_start <= tile) ++ci;
-  return ci;
+  int lo = 0, hi = a.n_cols;  // wave-uniform binary search over the kernarg descriptors
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.col[mid].tile_start <= tile) {
+      lo = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  return lo;
 }
 
 struct FloorModI64 {
+  static constexpr int kCast = 0;
   typedef int64_t In;
   typedef int64_t Out;
   __device__ static Out apply(In v, const FastDiv& f) { return (Out)floormod_i64(v, f); }
 };
 struct FloorModI32 {
+  static constexpr int kCast = 0;
   typedef int32_t In;
   typedef int32_t Out;
   __device__ static Out apply(In v, const FastDiv& f) { return (Out)floormod_i64((int64_t)v, f); }
 };
 struct F32ToF16 {
+  static constexpr int kCast = 1;
   typedef float In;
   typedef __half Out;
   __device__ static Out apply(In v, const FastDiv&) { return __float2half_rn(v); }
 };
 struct F16ToF32 {
+  static constexpr int kCast = 2;
   typedef __half In;
   typedef float Out;
   __device__ static Out apply(In v, const FastDiv&) { return __half2float(v); }
 };
+
+// streams: non-temporal accesses (the builtin does not take __half)
+template <typename T>
+__device__ inline T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
+__device__ inline __half stream_load(const __half* p) { return *p; }
+template <typename T>
+__device__ inline void stream_store(T v, T* p) { __builtin_nontemporal_store(v, p); }
+__device__ inline void stream_store(__half v, __half* p) { *p = v; }
 
 template <typename Op>
 __global__ __launch_bounds__(kBlock) void ew_kernel(const EwArgs a) {
@@ -72,12 +91,59 @@ __global__ __launch_bounds__(kBlock) void ew_kernel(const EwArgs a) {
 #pragma unroll
   for (int k = 0; k < kPerThread; ++k) {
     const int64_t i = base + (int64_t)k * kBlock + threadIdx.x;
-    if (i < c.len) v[k] = in[i];
+    if (i < c.len) v[k] = stream_load(in + i);
   }
 #pragma unroll
   for (int k = 0; k < kPerThread; ++k) {
     const int64_t i = base + (int64_t)k * kBlock + threadIdx.x;
-    if (i < c.len) out[i] = Op::apply(v[k], c.div);
+    if (i < c.len) stream_store(Op::apply(v[k], c.div), out + i);
+  }
+}
+
+// The wire casts move 16 bytes per lane on the wide side: 8 elements per thread, contiguous
+// (two 16-byte fp32 accesses against one 16-byte fp16 access); the scalar kernel above handles
+// tensors that are not 16-byte aligned.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <bool TO_HALF>
+__global__ __launch_bounds__(kBlock) void cast_vec_kernel(const EwArgs a) {
+  const int tile = (int)blockIdx.x;
+  const EwCol& c = a.col[find_col(a, tile)];
+  const int64_t i = (int64_t)(tile - c.tile_start) * kTile + (int64_t)threadIdx.x * 8;
+  if (i >= c.len) return;
+  if (i + 8 <= c.len) {
+    if (TO_HALF) {
+      const f32x4* in = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(c.in) + i);
+      const f32x4 lo = __builtin_nontemporal_load(in), hi = __builtin_nontemporal_load(in + 1);
+      f16x8 h;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        h[k] = (_Float16)lo[k];       // round to nearest even (v_cvt_f16_f32)
+        h[4 + k] = (_Float16)hi[k];
+      }
+      __builtin_nontemporal_store(h, reinterpret_cast<f16x8*>(reinterpret_cast<__half*>(c.out) + i));
+    } else {
+      const f16x8 h = __builtin_nontemporal_load(
+          reinterpret_cast<const f16x8*>(reinterpret_cast<const __half*>(c.in) + i));
+      f32x4 lo, hi;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        lo[k] = (float)h[k];
+        hi[k] = (float)h[4 + k];
+      }
+      f32x4* out = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(c.out) + i);
+      __builtin_nontemporal_store(lo, out);
+      __builtin_nontemporal_store(hi, out + 1);
+    }
+    return;
+  }
+  for (int64_t j = i; j < c.len; ++j) {  // the tensor's last, partial group of 8
+    if (TO_HALF) {
+      reinterpret_cast<__half*>(c.out)[j] = __float2half_rn(reinterpret_cast<const float*>(c.in)[j]);
+    } else {
+      reinterpret_cast<float*>(c.out)[j] = __half2float(reinterpret_cast<const __half*>(c.in)[j]);
+    }
   }
 }
 
@@ -118,6 +184,23 @@ int launch_n(const char* what, int32_t n, const void* const* inputs, const int64
     if (k == 0) continue;
     args.n_cols = k;
     args.pad_ = 0;
+    if (Op::kCast != 0) {
+      bool aligned = true;
+      for (int32_t q = 0; q < k; ++q) {
+        aligned &= (((uintptr_t)args.col[q].in | (uintptr_t)args.col[q].out) & 15) == 0;
+      }
+      if (aligned) {
+        if (Op::kCast == 1) {
+          hipLaunchKernelGGL(cast_vec_kernel<true>, dim3((unsigned)tiles), dim3(kBlock), 0,
+                             stream, args);
+        } else {
+          hipLaunchKernelGGL(cast_vec_kernel<false>, dim3((unsigned)tiles), dim3(kBlock), 0,
+                             stream, args);
+        }
+        HBK_HIP_OK(hipGetLastError());
+        continue;
+      }
+    }
     hipLaunchKernelGGL(ew_kernel<Op>, dim3((unsigned)tiles), dim3(kBlock), 0, stream, args);
     HBK_HIP_OK(hipGetLastError());
   }

@@ -19,6 +19,8 @@
 // Column descriptors travel in the kernel-argument segment: no pinned pointer tables and
 // no H2D copies per call (cu.cc:283-306).  `%` never reaches the 64-bit software divide:
 // shards come from a multiply-high with a host-computed magic (common.h).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -55,6 +57,8 @@ struct ShardFn {
 struct PartArgs {
   int32_t n_cols;
   int32_t total_tiles;
+  int32_t sub_tiles;     // 1024-id passes per wave: a tile is sub_tiles * 1024 ids
+  int32_t pad0_;
   int32_t* hist;  // [sum over columns of P * tiles_c]; column c starts at P * tile_start[c]
   int32_t* sizes_t;      // optional [P][n_total_cols] transposed copy of the sizes
   int32_t n_total_cols;
@@ -110,6 +114,80 @@ __device__ inline int find_col(const PartArgs& a, int tile) {
 constexpr int kStaticP = 16;  // up to here one ballot per shard and chunk: independent compares,
                               // counters in lane p's register, no serial match-any chain
 
+// One ballot per shard.  With the shard count known at compile time the P compares, popcounts and
+// selects of a chunk are independent straight-line code the scheduler can interleave; as a
+// runtime loop every iteration waits for its own v_cmp -> s_bcnt1 round trip (measured: the loop
+// form cost 26 of the 45 us of a 10 M-id histogram).
+template <int NP>
+__device__ inline int32_t count_shards_fixed(uint32_t shard, int lane) {
+  int32_t add = 0;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int n = (int)__builtin_popcountll(__ballot(shard == (uint32_t)p));
+    add = lane == p ? n : add;
+  }
+  return add;
+}
+
+__device__ inline int32_t count_shards(uint32_t shard, int P, int lane) {
+  switch (P) {
+    case 1: return count_shards_fixed<1>(shard, lane);
+    case 2: return count_shards_fixed<2>(shard, lane);
+    case 3: return count_shards_fixed<3>(shard, lane);
+    case 4: return count_shards_fixed<4>(shard, lane);
+    case 5: return count_shards_fixed<5>(shard, lane);
+    case 6: return count_shards_fixed<6>(shard, lane);
+    case 7: return count_shards_fixed<7>(shard, lane);
+    case 8: return count_shards_fixed<8>(shard, lane);
+    default: break;
+  }
+  int32_t add = 0;
+  for (int p = 0; p < P; ++p) {
+    const int n = (int)__builtin_popcountll(__ballot(shard == (uint32_t)p));
+    add = lane == p ? n : add;
+  }
+  return add;
+}
+
+// position of this lane's id inside the output (stable): running base of its shard + rank among
+// the lanes of the chunk with the same shard; lane p's `my_run` advances by the shard's count
+template <int NP>
+__device__ inline int32_t place_fixed(uint32_t shard, int lane, int32_t& my_run) {
+  int32_t pos = 0, add = 0;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const unsigned long long same = __ballot(shard == (uint32_t)p);
+    const int32_t base_p = __builtin_amdgcn_readlane(my_run, p);
+    pos = shard == (uint32_t)p ? base_p + rank_below(same) : pos;
+    add = lane == p ? (int32_t)__builtin_popcountll(same) : add;
+  }
+  my_run += add;
+  return pos;
+}
+
+__device__ inline int32_t place(uint32_t shard, int P, int lane, int32_t& my_run) {
+  switch (P) {
+    case 1: return place_fixed<1>(shard, lane, my_run);
+    case 2: return place_fixed<2>(shard, lane, my_run);
+    case 3: return place_fixed<3>(shard, lane, my_run);
+    case 4: return place_fixed<4>(shard, lane, my_run);
+    case 5: return place_fixed<5>(shard, lane, my_run);
+    case 6: return place_fixed<6>(shard, lane, my_run);
+    case 7: return place_fixed<7>(shard, lane, my_run);
+    case 8: return place_fixed<8>(shard, lane, my_run);
+    default: break;
+  }
+  int32_t pos = 0, add = 0;
+  for (int p = 0; p < P; ++p) {
+    const unsigned long long same = __ballot(shard == (uint32_t)p);
+    const int32_t base_p = __builtin_amdgcn_readlane(my_run, p);
+    pos = shard == (uint32_t)p ? base_p + rank_below(same) : pos;
+    add = lane == p ? (int32_t)__builtin_popcountll(same) : add;
+  }
+  my_run += add;
+  return pos;
+}
+
 // ---- A: per-tile histogram ------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a) {
@@ -120,39 +198,47 @@ __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a)
   const int P = a.fn.num_partitions;
   const int lane = lane_id();
   const int ctile = tile - c.tile_start;
-  const int n_tiles = (c.len + kTile - 1) / kTile;
+  const int tile_ids = a.sub_tiles * kTile;
+  const int n_tiles = (c.len + tile_ids - 1) / tile_ids;
   const T* in = reinterpret_cast<const T*>(c.in);
-  const int64_t base = (int64_t)ctile * kTile;
-  T v[kChunks];
-#pragma unroll
-  for (int k = 0; k < kChunks; ++k) {
-    const int64_t i = base + k * kWave + lane;
-    v[k] = i < c.len ? in[i] : T(0);
+  const int64_t len = c.len;
+  // uniform descriptor fields live in registers: re-reading them from the kernel-argument
+  // segment inside the unrolled chunk loops costs a scalar-memory round trip each time
+  const ShardFn fn = a.fn;
+  const FastDiv bk = c.bucket;
+  const bool small_p = P <= kStaticP;
+  int32_t cnt = 0;  // small P: lane p counts the ids of shard p in this tile
+  if (!small_p) {
+    for (int p = lane; p < P; p += kWave) counters[p] = 0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): zeroing done before the atomics
   }
-  if (P <= kStaticP) {
-    int32_t cnt = 0;  // lane p: ids of shard p in this tile
+  for (int sb = 0; sb < a.sub_tiles; ++sb) {
+    const int64_t base = (int64_t)ctile * tile_ids + (int64_t)sb * kTile;
+    if (base >= len) break;
+    T v[kChunks];
+#pragma unroll
+    for (int k = 0; k < kChunks; ++k) {
+      const int64_t i = base + k * kWave + lane;
+      v[k] = i < len ? in[i] : T(0);
+    }
 #pragma unroll
     for (int k = 0; k < kChunks; ++k) {
       const int64_t i = base + k * kWave + lane;
       const uint32_t shard =
-          i < c.len ? shard_of<T>(bucketize<T>(v[k], c.bucket), a.fn) : 0xffffffffu;
-      for (int p = 0; p < P; ++p) {
-        const int n = (int)__builtin_popcountll(__ballot(shard == (uint32_t)p));
-        if (lane == p) cnt += n;
+          i < len ? shard_of<T>(bucketize<T>(v[k], bk), fn) : 0xffffffffu;
+      if (small_p) {
+        cnt += count_shards(shard, P, lane);
+      } else if (i < len) {
+        atomicAdd(&counters[shard], 1);
       }
     }
-    if (lane < P) (a.hist + (int64_t)P * c.tile_start)[(int64_t)lane * n_tiles + ctile] = cnt;
+  }
+  int32_t* hist = a.hist + (int64_t)P * c.tile_start;
+  if (small_p) {
+    if (lane < P) hist[(int64_t)lane * n_tiles + ctile] = cnt;
     return;
   }
-  for (int p = lane; p < P; p += kWave) counters[p] = 0;
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): zeroing done before the atomics
-#pragma unroll
-  for (int k = 0; k < kChunks; ++k) {
-    const int64_t i = base + k * kWave + lane;
-    if (i < c.len) atomicAdd(&counters[shard_of<T>(bucketize<T>(v[k], c.bucket), a.fn)], 1);
-  }
   __builtin_amdgcn_s_waitcnt(0xc07f);
-  int32_t* hist = a.hist + (int64_t)P * c.tile_start;
   for (int p = lane; p < P; p += kWave) hist[(int64_t)p * n_tiles + ctile] = counters[p];
 }
 
@@ -164,7 +250,8 @@ __global__ __launch_bounds__(kScanBlock) void partition_scan_kernel(const PartAr
   __shared__ int32_t carry_s;
   const PartCol& c = a.col[blockIdx.x];
   const int P = a.fn.num_partitions;
-  const int n_tiles = (c.len + kTile - 1) / kTile;
+  const int tile_ids = a.sub_tiles * kTile;
+  const int n_tiles = (c.len + tile_ids - 1) / tile_ids;
   const int64_t total = (int64_t)P * n_tiles;
   int32_t* hist = a.hist + (int64_t)P * c.tile_start;
   const int tid = (int)threadIdx.x;
@@ -231,91 +318,92 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
   const int P = a.fn.num_partitions;
   const int lane = lane_id();
   const int ctile = tile - c.tile_start;
-  const int n_tiles = (c.len + kTile - 1) / kTile;
+  const int tile_ids = a.sub_tiles * kTile;
+  const int n_tiles = (c.len + tile_ids - 1) / tile_ids;
   const int32_t* hist = a.hist + (int64_t)P * c.tile_start;
-  if (P > kWave) {
-    for (int p = lane; p < P; p += kWave) run[p] = hist[(int64_t)p * n_tiles + ctile];
-  }
   const T* in = reinterpret_cast<const T*>(c.in);
   T* out = reinterpret_cast<T*>(c.out);
-  const int64_t base = (int64_t)ctile * kTile;
-  T v[kChunks];
-#pragma unroll
-  for (int k = 0; k < kChunks; ++k) {
-    const int64_t i = base + k * kWave + lane;
-    v[k] = i < c.len ? bucketize<T>(in[i], c.bucket) : T(0);
-  }
-  if (P <= kStaticP) {
-    // the W <= 16 case: lane p keeps the running counter of shard p; one ballot per shard, all
-    // compares of a chunk independent of each other
-    int32_t my_run = lane < P ? hist[(int64_t)lane * n_tiles + ctile] : 0;
-#pragma unroll
-    for (int k = 0; k < kChunks; ++k) {
-      const int64_t i = base + k * kWave + lane;
-      const bool valid = i < c.len;
-      const uint32_t shard = valid ? shard_of<T>(v[k], a.fn) : 0xffffffffu;
-      int32_t pos = 0;
-      for (int p = 0; p < P; ++p) {
-        const unsigned long long same = __ballot(shard == (uint32_t)p);
-        const int32_t base_p = __builtin_amdgcn_readlane(my_run, p);
-        if (shard == (uint32_t)p) pos = base_p + rank_below(same);
-        if (lane == p) my_run += (int32_t)__builtin_popcountll(same);
-      }
-      if (valid) {
-        out[pos] = v[k];
-        c.indices[i] = pos;
-      }
-    }
-    return;
-  }
+  int32_t* indices = c.indices;
+  const int64_t len = c.len;
+  const ShardFn fn = a.fn;     // uniform descriptor fields in registers (see the histogram)
+  const FastDiv bk = c.bucket;
+  // running position of every shard: lane p's register for P <= 64, LDS beyond; it carries over
+  // the 1024-id passes of the tile, which are taken in order (stability)
+  int32_t my_run = 0;
   if (P <= kWave) {
-    // P <= 64: lane p keeps the running counter of shard p in a register;
-    // the leader's base is fetched with v_readlane (uniform lane index), no LDS round trips
-    int32_t my_run = lane < P ? hist[(int64_t)lane * n_tiles + ctile] : 0;
+    my_run = lane < P ? hist[(int64_t)lane * n_tiles + ctile] : 0;
+  } else {
+    for (int p = lane; p < P; p += kWave) run[p] = hist[(int64_t)p * n_tiles + ctile];
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // run[] initialised
+  }
+  for (int sb = 0; sb < a.sub_tiles; ++sb) {
+    const int64_t base = (int64_t)ctile * tile_ids + (int64_t)sb * kTile;
+    if (base >= len) break;
+    T v[kChunks];
 #pragma unroll
     for (int k = 0; k < kChunks; ++k) {
       const int64_t i = base + k * kWave + lane;
-      const bool valid = i < c.len;
-      const uint32_t shard = valid ? shard_of<T>(v[k], a.fn) : 0xffffffffu;
-      unsigned long long todo = __ballot(valid);
-      int32_t pos = 0;
-      while (todo != 0ull) {
-        const int leader = __builtin_ctzll(todo);
-        const int s = __builtin_amdgcn_readlane((int)shard, leader);
-        const unsigned long long same = __ballot(shard == (uint32_t)s);
-        const int32_t base_s = __builtin_amdgcn_readlane(my_run, s);
-        if (shard == (uint32_t)s) pos = base_s + rank_below(same);
-        if (lane == s) my_run += (int32_t)__builtin_popcountll(same);
-        todo &= ~same;
-      }
-      if (valid) {
-        out[pos] = v[k];
-        c.indices[i] = pos;
-      }
+      v[k] = i < len ? bucketize<T>(in[i], bk) : T(0);
     }
-    return;
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // run[] initialised
+    if (P <= kStaticP) {
+      // the W <= 16 case: one ballot per shard, all compares of a chunk independent of each other
 #pragma unroll
-  for (int k = 0; k < kChunks; ++k) {
-    const int64_t i = base + k * kWave + lane;
-    const bool valid = i < c.len;
-    const uint32_t shard = valid ? shard_of<T>(v[k], a.fn) : 0xffffffffu;
-    unsigned long long todo = __ballot(valid);
-    int32_t pos = 0;
-    while (todo != 0ull) {
-      const int leader = __builtin_ctzll(todo);
-      const uint32_t s = (uint32_t)__shfl((int)shard, leader, kWave);
-      const unsigned long long same = __ballot(shard == s);
-      const int32_t base_s = run[s];  // every lane reads the same address: LDS broadcast
-      if (shard == s) pos = base_s + rank_below(same);
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      if (lane == leader) run[s] = base_s + (int32_t)__builtin_popcountll(same);
-      todo &= ~same;
-    }
-    if (valid) {
-      out[pos] = v[k];
-      c.indices[i] = pos;
+      for (int k = 0; k < kChunks; ++k) {
+        const int64_t i = base + k * kWave + lane;
+        const bool valid = i < len;
+        const uint32_t shard = valid ? shard_of<T>(v[k], fn) : 0xffffffffu;
+        const int32_t pos = place(shard, P, lane, my_run);
+        if (valid) {
+          out[pos] = v[k];
+          indices[i] = pos;
+        }
+      }
+    } else if (P <= kWave) {
+      // match-any loop; the leader's base is fetched with v_readlane, no LDS round trips
+#pragma unroll
+      for (int k = 0; k < kChunks; ++k) {
+        const int64_t i = base + k * kWave + lane;
+        const bool valid = i < len;
+        const uint32_t shard = valid ? shard_of<T>(v[k], fn) : 0xffffffffu;
+        unsigned long long todo = __ballot(valid);
+        int32_t pos = 0;
+        while (todo != 0ull) {
+          const int leader = __builtin_ctzll(todo);
+          const int s = __builtin_amdgcn_readlane((int)shard, leader);
+          const unsigned long long same = __ballot(shard == (uint32_t)s);
+          const int32_t base_s = __builtin_amdgcn_readlane(my_run, s);
+          if (shard == (uint32_t)s) pos = base_s + rank_below(same);
+          if (lane == s) my_run += (int32_t)__builtin_popcountll(same);
+          todo &= ~same;
+        }
+        if (valid) {
+          out[pos] = v[k];
+          indices[i] = pos;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kChunks; ++k) {
+        const int64_t i = base + k * kWave + lane;
+        const bool valid = i < len;
+        const uint32_t shard = valid ? shard_of<T>(v[k], fn) : 0xffffffffu;
+        unsigned long long todo = __ballot(valid);
+        int32_t pos = 0;
+        while (todo != 0ull) {
+          const int leader = __builtin_ctzll(todo);
+          const uint32_t s = (uint32_t)__shfl((int)shard, leader, kWave);
+          const unsigned long long same = __ballot(shard == s);
+          const int32_t base_s = run[s];  // every lane reads the same address: LDS broadcast
+          if (shard == s) pos = base_s + rank_below(same);
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          if (lane == leader) run[s] = base_s + (int32_t)__builtin_popcountll(same);
+          todo &= ~same;
+        }
+        if (valid) {
+          out[pos] = v[k];
+          indices[i] = pos;
+        }
+      }
     }
   }
 }
@@ -339,7 +427,22 @@ int launch_group(const PartArgs& args, int P, hipStream_t stream) {
   return HBK_OK;
 }
 
-int64_t tiles_of(int64_t len) { return (len + kTile - 1) / kTile; }
+// A wave may take several 1024-id passes (sub_tiles); measured slower than one pass per wave at
+// every size (10 M ids: 69 us with 1 pass, 89 us with 4; 1.7 M ids: 33 vs 73 us), so the default
+// is 1 and HBK_PART_SUB is only a tuning hook.
+int sub_tiles_of(int32_t n_cols, const int64_t* lens) {
+  (void)n_cols;
+  (void)lens;
+  int64_t sub = 1;
+  const char* e = getenv("HBK_PART_SUB");
+  if (e != nullptr && atoi(e) >= 1) sub = atoi(e);
+  return sub > 8 ? 8 : (int)sub;
+}
+
+int64_t tiles_of(int64_t len, int sub) {
+  const int64_t tile_ids = (int64_t)kTile * sub;
+  return (len + tile_ids - 1) / tile_ids;
+}
 
 int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
                    int32_t modulus, int32_t stage, const void* const* inputs,
@@ -382,6 +485,7 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
   fn.mod = make_fastdiv(stage ? (uint64_t)modulus : 1);
 
   int32_t* hist = reinterpret_cast<int32_t*>(workspace);
+  const int sub = sub_tiles_of(n_cols, lens);
   int32_t c0 = 0;
   while (c0 < n_cols) {
     PartArgs args;
@@ -390,6 +494,8 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
     args.sizes_t = sizes_t;
     args.n_total_cols = n_cols;
     args.pad_ = 0;
+    args.pad0_ = 0;
+    args.sub_tiles = sub;
     int32_t k = 0;
     int64_t tiles = 0;
     while (c0 < n_cols && k < kMaxColsPerLaunch) {
@@ -404,7 +510,7 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
       d.global_col = c0;
       d.pad_ = 0;
       d.tile_start = (int32_t)tiles;
-      tiles += tiles_of(lens[c0]);
+      tiles += tiles_of(lens[c0], sub);
       HBK_REQUIRE(tiles < (1ll << 31), "%s: too many tiles", what);
       ++k;
       ++c0;
@@ -449,9 +555,10 @@ int partition_by_modulo_fused(int32_t n_cols, int32_t num_partitions, const int6
 extern "C" size_t hbk_partition_workspace_bytes(int32_t n_cols, const int64_t* lens,
                                                 int32_t num_partitions) {
   if (n_cols <= 0 || lens == nullptr || num_partitions < 1) return 0;
+  const int sub = hbk::sub_tiles_of(n_cols, lens);
   int64_t tiles = 0;
   for (int32_t c = 0; c < n_cols; ++c) {
-    if (lens[c] > 0) tiles += hbk::tiles_of(lens[c]);
+    if (lens[c] > 0) tiles += hbk::tiles_of(lens[c], sub);
   }
   return (size_t)tiles * (size_t)num_partitions * sizeof(int32_t);
 }

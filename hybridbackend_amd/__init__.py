@@ -4,6 +4,7 @@ custom-op surface.  Only the hot path of SURVEY.md section 8 lives here:
 host-side mirror of the reference's Python interface for that path."""
 from hybridbackend_amd import distribute
 from hybridbackend_amd import embedding
+from hybridbackend_amd import feature_column
 from hybridbackend_amd._lib import HbkError
 from hybridbackend_amd._lib import InvalidArgumentError
 

@@ -37,7 +37,7 @@ class LookupColumn(C.Structure):
               ('bucket', C.c_int64), ('divisor', C.c_int32),
               ('combiner', C.c_int32), ('out', C.c_void_p),
               ('run_start', C.c_void_p), ('run_base', C.c_void_p),
-              ('n_runs', C.c_int32), ('reserved_', C.c_int32)]
+              ('n_runs', C.c_int32), ('out_stride', C.c_int32)]
 
 
 class LookupGradColumn(C.Structure):
@@ -49,7 +49,7 @@ class LookupGradColumn(C.Structure):
               ('combiner', C.c_int32), ('grad_out', C.c_void_p),
               ('unique_rows', C.c_void_p), ('grad_rows', C.c_void_p),
               ('n_unique', C.c_void_p), ('run_start', C.c_void_p), ('run_ids', C.c_void_p),
-              ('run_grads', C.c_void_p), ('n_runs', C.c_int32), ('reserved_', C.c_int32)]
+              ('run_grads', C.c_void_p), ('n_runs', C.c_int32), ('grad_stride', C.c_int32)]
 
 
 class ShardedColumn(C.Structure):
@@ -64,7 +64,7 @@ class StitchGradColumn(C.Structure):
               ('index', C.c_void_p), ('row_splits', C.c_void_p), ('n_segments', C.c_int64),
               ('grad_out', C.c_void_p), ('grad_rows', C.c_void_p),
               ('run_start', C.c_void_p), ('run_base', C.c_void_p), ('n_runs', C.c_int32),
-              ('reserved_', C.c_int32)]
+              ('grad_stride', C.c_int32)]
 
 
 _lib = None
@@ -113,9 +113,9 @@ def _declare(l):
     'hbk_sharded_layout': (C.c_int, [i32, i32] + [vp] * 12),
     'hbk_sharded_create': (C.c_int, [vp, vp, i32, vp, i32]),
     'hbk_sharded_destroy': (C.c_int, [vp]),
-    'hbk_sharded_lookup_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp]),
+    'hbk_sharded_lookup_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     'hbk_sharded_owned_ids': (i64, [vp, i32]),
-    'hbk_sharded_lookup_bwd': (C.c_int, [vp, vp, C.c_float, vp, vp, vp, vp]),
+    'hbk_sharded_lookup_bwd': (C.c_int, [vp, vp, vp, C.c_float, vp, vp, vp, vp]),
   }
   for name, (res, args) in protos.items():
     fn = getattr(l, name)   # AttributeError here = header and library out of sync
@@ -180,11 +180,16 @@ def current_stream(device=None):
   return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def require_device_tensor(t, what):
+def require_device_tensor(t, what, row_strided=False):
+  """row_strided: a 2-D tensor may be a column block of a wider one (rows contiguous, row stride
+  larger than the row) -- outputs / gradients of the fused lookup."""
   if not t.is_cuda:
     raise HbkError(
       INTERNAL,
       f'{what} must live in HBM (got a {t.device} tensor): the HIP path is the '
       'only path, there is no CPU fallback')
-  if not t.is_contiguous():
-    raise InvalidArgumentError(INVALID_ARGUMENT, f'{what} must be contiguous')
+  if t.is_contiguous():
+    return
+  if row_strided and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+    return
+  raise InvalidArgumentError(INVALID_ARGUMENT, f'{what} must be contiguous')

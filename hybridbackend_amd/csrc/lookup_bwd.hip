@@ -125,7 +125,7 @@ struct GCol {
   int32_t merge0;            // first block (merge grid)
   int32_t scan0;             // first block (scan-over-tiles grid)
   int32_t n_runs;
-  int32_t pad_;
+  int32_t grad_stride;       // floats between rows of grad_out (>= dim)
 };
 
 struct GArgs {
@@ -376,6 +376,7 @@ struct ReduceJob {
   int32_t n_pairs;
   bool scale;                // apply the combiner's 1/n, 1/sqrt(n)
   bool seg_is_offset;        // pseg holds float offsets into grad (segmented inputs)
+  int32_t stride;            // floats between rows of grad
   int64_t* out_rows;
   float* out_vals;
   int32_t* out_counter;      // claimed with one atomic per chunk
@@ -386,7 +387,7 @@ struct ReduceJob {
 template <typename V>
 __device__ inline V load_grad(const GCol& c, const ReduceJob& job, int32_t seg, int sub) {
   constexpr int VE = sizeof(V) / 4;
-  const int64_t off = job.seg_is_offset ? (int64_t)(uint32_t)seg : (int64_t)seg * c.dim;
+  const int64_t off = job.seg_is_offset ? (int64_t)(uint32_t)seg : (int64_t)seg * job.stride;
   V g = __builtin_nontemporal_load(
       reinterpret_cast<const V*>(job.grad + off + (int64_t)sub * VE));
   if (job.scale && c.combiner != HBK_COMBINER_SUM && c.splits != nullptr) {
@@ -701,6 +702,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
   job.grad = c.grad_out;
   job.scale = true;
   job.seg_is_offset = c.n_runs > 0;
+  job.stride = c.grad_stride;
   if (n_b > c.split_t) {
     const int32_t lo = range * c.split_t;
     job.prow = c.pair_row[0] + start + lo;
@@ -742,6 +744,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const 
   job.n_pairs = c.pcount[bucket];
   job.scale = false;
   job.seg_is_offset = false;
+  job.stride = c.dim;
   job.out_rows = c.unique_rows;
   job.out_vals = c.grad_rows;
   job.out_counter = c.n_unique;
@@ -762,7 +765,7 @@ struct SCol {
   const int64_t* run_start;  // segmented destination (n_runs > 0)
   const int64_t* run_base;
   int32_t n_runs;
-  int32_t pad2_;
+  int32_t grad_stride;       // floats between rows of grad_out
   int64_t n_seg;
   int32_t dim;
   int32_t chunks;
@@ -798,7 +801,7 @@ __device__ inline void stitch_segments(const SCol& c, int64_t seg0) {
     }
     if (end <= beg) continue;
     V g = __builtin_nontemporal_load(
-        reinterpret_cast<const V*>(c.grad_out + s * (int64_t)c.dim + (int64_t)sub * VE));
+        reinterpret_cast<const V*>(c.grad_out + s * (int64_t)c.grad_stride + (int64_t)sub * VE));
     const int32_t n = end - beg;
     if (c.combiner == HBK_COMBINER_MEAN) {
       g = g / (float)n;
@@ -1000,6 +1003,9 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       d.run_ids = h.run_ids;
       d.run_grads = h.run_grads;
       d.n_runs = h.n_runs;
+      HBK_REQUIRE(h.grad_stride == 0 || (h.grad_stride >= h.dim && h.n_runs == 0),
+                  "group_lookup_bwd: column %d: bad grad_stride %d", c0 - 1, h.grad_stride);
+      d.grad_stride = h.grad_stride > 0 ? h.grad_stride : h.dim;
       d.map = make_idmap(h.bucket, h.divisor, h.rows);
       d.n_ids = h.n_ids;
       d.n_seg = h.n_segments;
@@ -1007,6 +1013,7 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       RowShape shape;
       HBK_REQUIRE(make_rowshape(h.dim,
                                 (uintptr_t)h.grad_out | (uintptr_t)h.grad_rows |
+                                    ((uintptr_t)(uint32_t)h.grad_stride * 4) |
                                     (apply_lr != 0.0f ? (uintptr_t)h.table : 0),
                                 &shape),
                   "group_lookup_bwd: dim %d needs more than 64 lanes per row", h.dim);
@@ -1115,11 +1122,16 @@ extern "C" int hbk_group_stitch_bwd(int32_t n_cols, const hbk_stitch_grad_column
       d.run_start = h.run_start;
       d.run_base = h.run_base;
       d.n_runs = h.n_runs;
-      d.pad2_ = 0;
+      HBK_REQUIRE(h.grad_stride == 0 || h.grad_stride >= h.dim,
+                  "group_stitch_bwd: column %d: bad grad_stride %d", ci, h.grad_stride);
+      d.grad_stride = h.grad_stride > 0 ? h.grad_stride : h.dim;
       d.n_seg = h.n_segments;
       d.dim = h.dim;
       RowShape shape;
-      HBK_REQUIRE(make_rowshape(h.dim, (uintptr_t)h.grad_out | (uintptr_t)h.grad_rows, &shape),
+      HBK_REQUIRE(make_rowshape(h.dim,
+                                (uintptr_t)h.grad_out | (uintptr_t)h.grad_rows |
+                                    ((uintptr_t)(uint32_t)h.grad_stride * 4),
+                                &shape),
                   "group_stitch_bwd: dim %d needs more than 64 lanes per row", h.dim);
       d.chunks = shape.chunks;
       d.lpr_log2 = shape.lpr_log2;

@@ -42,6 +42,7 @@ struct ColArg {
   uint8_t combiner;
   uint8_t vec4;     // 1: 16-byte chunks, 0: 4-byte chunks (dim % 4 != 0 or unaligned)
   int32_t n_runs;   // > 0: segmented table (see hbk_lookup_column_t)
+  int32_t out_stride;  // floats between output rows (>= dim)
   const int64_t* run_start;
   const int64_t* run_base;
 };
@@ -73,7 +74,6 @@ __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
   const int sub = lane & ((1 << lpr_log2) - 1);
   const int grp = lane >> lpr_log2;
   const int64_t n_seg = c.n_seg;
-  const int dim = c.dim;
 
   // ids: slot q (0 <= q < U*rpi) lives in register q>>6 of lane q&63
   uint64_t rowreg[U];
@@ -106,7 +106,7 @@ __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
     const int64_t s = wave_row0 + u * rpi + grp;
     if (live && s < n_seg) {
       __builtin_nontemporal_store(
-          v[u], reinterpret_cast<V*>(c.out + s * (int64_t)dim + (int64_t)sub * VE));
+          v[u], reinterpret_cast<V*>(c.out + s * (int64_t)c.out_stride + (int64_t)sub * VE));
     }
   }
 }
@@ -124,7 +124,6 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
   const int grp = lane >> lpr_log2;
   const int grp_lane0 = grp << lpr_log2;
   const int64_t n_seg = c.n_seg;
-  const int dim = c.dim;
   const bool live = sub < c.chunks;
 
   for (int it = 0; it < kSegIters; ++it) {
@@ -174,7 +173,7 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
     }
     if (live && s < n_seg) {
       __builtin_nontemporal_store(
-          acc, reinterpret_cast<V*>(c.out + s * (int64_t)dim + (int64_t)sub * VE));
+          acc, reinterpret_cast<V*>(c.out + s * (int64_t)c.out_stride + (int64_t)sub * VE));
     }
   }
 }
@@ -274,7 +273,14 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
         const hbk_lookup_column_t& h = cols[c0++];
         if (h.n_segments == 0) continue;
         RowShape shape;
-        HBK_REQUIRE(make_rowshape(h.dim, (uintptr_t)h.table | (uintptr_t)h.out, &shape),
+        HBK_REQUIRE(h.out_stride == 0 || h.out_stride >= h.dim,
+                    "group_lookup_fwd: out_stride %d is smaller than dim %d", h.out_stride,
+                    h.dim);
+        // a strided output keeps 16-byte chunks only if every row start stays 16-byte aligned
+        HBK_REQUIRE(make_rowshape(h.dim,
+                                  (uintptr_t)h.table | (uintptr_t)h.out |
+                                      ((uintptr_t)(uint32_t)h.out_stride * 4),
+                                  &shape),
                     "group_lookup_fwd: dim %d needs more than 64 lanes per row "
                     "(unaligned or dim %% 4 != 0 with dim > 64 is unsupported)", h.dim);
         const int col_kind = (h.row_splits != nullptr ? 1 : 0) | (shape.vec4 ? 0 : 2) |
@@ -294,6 +300,7 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
         d.ids64 = h.ids_dtype == HBK_INT64;
         d.combiner = (uint8_t)h.combiner;
         d.n_runs = h.n_runs;
+        d.out_stride = h.out_stride > 0 ? h.out_stride : h.dim;
         d.run_start = h.run_start;
         d.run_base = h.run_base;
         const int64_t rpi = kWave >> d.lpr_log2;

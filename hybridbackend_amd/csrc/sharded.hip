@@ -399,7 +399,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
                                       const int64_t* n_ids,
                                       const int32_t* const* row_splits,
                                       const int64_t* n_segments, float* const* outs,
-                                      hbk_stream_t stream_) {
+                                      const int32_t* out_strides, hbk_stream_t stream_) {
   using namespace hbk;
   HBK_REQUIRE(p != nullptr, "sharded_lookup_fwd: plan is NULL");
   HBK_REQUIRE(ids && n_ids && outs, "sharded_lookup_fwd: NULL argument array");
@@ -638,6 +638,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
       h.divisor = 1;
       h.combiner = p->cols[cc].combiner;
       h.out = outs[cc];
+      h.out_stride = out_strides ? out_strides[cc] : 0;
       h.run_start = d_start + (size_t)cc * W;
       h.run_base = d_base + (size_t)cc * W;
       h.n_runs = W;
@@ -650,7 +651,8 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
 }
 
 extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads,
-                                      float apply_lr, int64_t* const* unique_rows,
+                                      const int32_t* grad_strides, float apply_lr,
+                                      int64_t* const* unique_rows,
                                       float* const* grad_rows, int32_t* const* n_unique,
                                       hbk_stream_t stream_) {
   using namespace hbk;
@@ -691,6 +693,7 @@ extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads
       h.row_splits = p->row_splits[cc];
       h.n_segments = p->n_seg[cc];
       h.grad_out = grads[cc];
+      h.grad_stride = grad_strides ? grad_strides[cc] : 0;
       h.grad_rows = rows_recv_base + gr.row_recv;
       h.run_start = d_start + (size_t)cc * W;
       h.run_base = d_base + (size_t)cc * W;

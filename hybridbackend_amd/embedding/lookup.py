@@ -97,7 +97,7 @@ class GroupLookup:
         outs[c] = torch.empty((n_seg, self.tables[c].shape[1]), dtype=torch.float32,
                               device=self.tables[c].device)
       o = outs[c]
-      _lib.require_device_tensor(o, 'output')
+      _lib.require_device_tensor(o, 'output', row_strided=True)
       if o.dtype != torch.float32 or tuple(o.shape) != (n_seg, self.tables[c].shape[1]):
         raise _lib.InvalidArgumentError(
           _lib.INVALID_ARGUMENT, f'output {c} must be fp32 [{n_seg}, dim]')
@@ -108,6 +108,11 @@ class GroupLookup:
       col.row_splits = s.data_ptr() if s is not None else None
       col.n_segments = n_seg
       col.out = o.data_ptr()
+      # a column block of a wider [segments, sum of dims] tensor is written in place
+      if o.stride(1) != 1 and o.shape[1] > 1:
+        raise _lib.InvalidArgumentError(
+          _lib.INVALID_ARGUMENT, f'output {c} must be contiguous along its last dimension')
+      col.out_stride = 0 if o.is_contiguous() else int(o.stride(0))
     self._keep = (ids, row_splits, outs)
     return outs
 
@@ -183,8 +188,8 @@ class GroupLookupGrad:
         o_g += k * d
     for c in range(n):
       i, g, s = ids[c], grads[c], row_splits[c]
-      for t, what in ((i, 'ids'), (g, 'grads')):
-        _lib.require_device_tensor(t, what)
+      _lib.require_device_tensor(i, 'ids')
+      _lib.require_device_tensor(g, 'grads', row_strided=True)
       n_seg = i.numel() if s is None else s.numel() - 1
       if g.dtype != torch.float32 or tuple(g.shape) != (n_seg, dims[c]):
         raise _lib.InvalidArgumentError(
@@ -197,6 +202,10 @@ class GroupLookupGrad:
       col.row_splits = s.data_ptr() if s is not None else None
       col.n_segments = n_seg
       col.grad_out = g.data_ptr()
+      if g.stride(1) != 1 and g.shape[1] > 1:
+        raise _lib.InvalidArgumentError(
+          _lib.INVALID_ARGUMENT, f'grad {c} must be contiguous along its last dimension')
+      col.grad_stride = 0 if g.is_contiguous() else int(g.stride(0))
       col.unique_rows = urows.data_ptr()
       col.grad_rows = grows.data_ptr()
       col.n_unique = nu.data_ptr()

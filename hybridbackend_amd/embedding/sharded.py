@@ -161,12 +161,19 @@ class ShardedGroupLookup:
     if outs is None:
       outs = [torch.empty((n_seg[c], self.dims[c]), dtype=torch.float32, device=self.device)
               for c in range(n)]
+    for c in range(n):
+      _lib.require_device_tensor(outs[c], 'output', row_strided=True)
+      if outs[c].dtype != torch.float32 or tuple(outs[c].shape) != (n_seg[c], self.dims[c]):
+        raise _lib.InvalidArgumentError(
+          _lib.INVALID_ARGUMENT, f'output {c} must be fp32 [{n_seg[c]}, {self.dims[c]}]')
     self._keep = (ids, row_splits, outs)
+    # column blocks of one wider tensor are written in place (row stride != dim)
+    strides = (C.c_int32 * n)(*[0 if o.is_contiguous() else int(o.stride(0)) for o in outs])
     _lib.check(self._lib.hbk_sharded_lookup_fwd(
       plan, _lib.ptr_array([t.data_ptr() for t in ids]),
       _lib.i64_array([t.numel() for t in ids]),
       _lib.ptr_array([None if s is None else s.data_ptr() for s in row_splits]),
-      _lib.i64_array(n_seg), _lib.ptr_array([o.data_ptr() for o in outs]),
+      _lib.i64_array(n_seg), _lib.ptr_array([o.data_ptr() for o in outs]), strides,
       _lib.current_stream(self.device)))
     return outs
 
@@ -218,7 +225,7 @@ class ShardedGroupLookup:
     plan = self._plan()
     res = []
     for c in range(n):
-      _lib.require_device_tensor(grads[c], 'grads')
+      _lib.require_device_tensor(grads[c], 'grads', row_strided=True)
       k = int(self._lib.hbk_sharded_owned_ids(plan, c))
       if k < 0:
         raise _lib.HbkError(_lib.INTERNAL, 'backward() needs a forward step first')
@@ -233,8 +240,9 @@ class ShardedGroupLookup:
                   torch.empty((k, self.dims[c]), dtype=torch.float32, device=self.device),
                   torch.zeros(1, dtype=torch.int32, device=self.device)))
     self._keep_bwd = (grads, res)
+    strides = (C.c_int32 * n)(*[0 if g.is_contiguous() else int(g.stride(0)) for g in grads])
     _lib.check(self._lib.hbk_sharded_lookup_bwd(
-      plan, _lib.ptr_array([g.data_ptr() for g in grads]), C.c_float(apply_lr),
+      plan, _lib.ptr_array([g.data_ptr() for g in grads]), strides, C.c_float(apply_lr),
       _lib.ptr_array([r[0].data_ptr() for r in res]),
       _lib.ptr_array([r[1].data_ptr() for r in res]),
       _lib.ptr_array([r[2].data_ptr() for r in res]), _lib.current_stream(self.device)))

@@ -1,0 +1,160 @@
+"""Embedding feature columns -> one dense block: host mirror of what the reference's users build
+with ``tf.feature_column.embedding_column`` + ``tf.keras.layers.DenseFeatures`` /
+``hb.keras.layers.dense_features`` (hybridbackend/tensorflow/keras/layers/__init__.py:29-46,
+docs/tutorial/ranking/taobao/train_keras.py:60-75) under ``hb.scope(sharding=True)``
+(hybridbackend/tensorflow/embedding/variables.py:77-146, sharding.py:171-205).
+
+All columns are looked up by ONE fused launch (``hbk_group_lookup_fwd``) or one sharded step
+(``hbk_sharded_lookup_fwd``), and every column writes its block of the concatenated
+``[batch, sum of dims]`` tensor in place (``out_stride``): there is no per-column output and no
+concat pass.  The backward reads the blocks of the incoming gradient in place the same way.
+"""
+import torch
+
+from hybridbackend_amd import _lib
+from hybridbackend_amd.embedding.lookup import GroupLookup
+from hybridbackend_amd.embedding.lookup import GroupLookupGrad
+from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
+from hybridbackend_amd.embedding.variables import sharded_bucket_size
+
+
+class EmbeddingColumn:
+  """``embedding_column(categorical_column_with_identity/hash_bucket(key, num_buckets),
+  dimension, combiner)``: ids are bucketized with floor-mod ``num_buckets``
+  (docs/tutorial/ranking/data.py:179,186)."""
+
+  def __init__(self, key, num_buckets, dimension, combiner='mean'):
+    if num_buckets < 1 or dimension < 1:
+      raise _lib.InvalidArgumentError(
+        _lib.INVALID_ARGUMENT, 'num_buckets and dimension must be >= 1')
+    self.key, self.num_buckets, self.dimension = key, int(num_buckets), int(dimension)
+    self.combiner = combiner
+
+
+class DenseFeatures:
+  """N embedding columns -> ``[batch, sum of dims]``.
+
+  Args:
+    columns: list of :class:`EmbeddingColumn`.
+    device: the GPU.
+    coll: a ``hybridbackend_amd.distribute.Collective`` for sharded tables, or None.
+    batch_size: local batch size used by the replicate-or-shard rule
+      (``bucket_size <= num_shards or bucket_size <= batch_size`` keeps a table replicated,
+      variables.py:93-104).
+    init: ``init(column, rows, device) -> fp32 [rows, dim]`` for this rank's rows (rows
+      ``rank, rank + W, ..`` of the logical table when sharded); default uniform(-1e-3, 1e-3)
+      (docs/tutorial/ranking/criteo/train.py:84,91).
+  """
+
+  def __init__(self, columns, device, coll=None, batch_size=0, init=None):
+    self.columns = list(columns)
+    self.device = torch.device(device)
+    self.coll = coll
+    world = coll.world_size if coll is not None else 1
+    rank = coll.rank if coll is not None else 0
+    if init is None:
+      def init(col, rows, dev):
+        return torch.empty(rows, col.dimension, device=dev).uniform_(-1e-3, 1e-3)
+    self.sharded, self.weights = [], []
+    for col in self.columns:
+      is_sharded, rows, _ = sharded_bucket_size(col.num_buckets, world, rank, batch_size)
+      is_sharded = is_sharded and world > 1
+      self.sharded.append(is_sharded)
+      self.weights.append(init(col, rows if is_sharded else col.num_buckets, self.device))
+    self.offsets, off = [], 0
+    for col in self.columns:
+      self.offsets.append(off)
+      off += col.dimension
+    self.width = off
+    self._rep = [c for c in range(len(self.columns)) if not self.sharded[c]]
+    self._shd = [c for c in range(len(self.columns)) if self.sharded[c]]
+    pick = lambda idx, xs: [xs[c] for c in idx]   # noqa: E731
+    self._lookup = self._grad = self._sharded = None
+    if self._rep:
+      self._lookup = GroupLookup(pick(self._rep, self.weights),
+                                 [self.columns[c].num_buckets for c in self._rep],
+                                 [self.columns[c].combiner for c in self._rep])
+      self._grad = GroupLookupGrad(self._lookup)
+    if self._shd:
+      self._sharded = ShardedGroupLookup(pick(self._shd, self.weights), coll,
+                                         buckets=[self.columns[c].num_buckets for c in self._shd],
+                                         combiners=[self.columns[c].combiner for c in self._shd])
+
+  def _split(self, features):
+    ids, splits, batch = [], [], None
+    for col in self.columns:
+      f = features[col.key]
+      i, s = f if isinstance(f, (tuple, list)) else (f, None)
+      n = i.numel() if s is None else s.numel() - 1
+      if batch is not None and n != batch:
+        raise _lib.InvalidArgumentError(
+          _lib.INVALID_ARGUMENT, f'feature {col.key}: {n} samples, expected {batch}')
+      batch = n
+      ids.append(i)
+      splits.append(s)
+    return ids, splits, batch
+
+  def __call__(self, features, cols_to_output_tensors=None):
+    """features[key] = int64 ids ``[batch]`` (one id per sample) or ``(values, row_splits)``
+    (the values + row_splits layout of hybridbackend/tensorflow/data/dataframe.py:366-376).
+    Returns the dense block; ``cols_to_output_tensors`` (a dict) receives each column's view."""
+    ids, splits, batch = self._split(features)
+    # rows start on 16-byte boundaries (row stride padded to 4 floats) so that columns whose
+    # offset is a multiple of 4 floats keep 16-byte accesses
+    pitch = (self.width + 3) // 4 * 4
+    out = torch.empty((batch or 0, pitch), dtype=torch.float32, device=self.device)[:, :self.width]
+    views = [out[:, self.offsets[c]:self.offsets[c] + self.columns[c].dimension]
+             for c in range(len(self.columns))]
+    pick = lambda idx, xs: [xs[c] for c in idx]   # noqa: E731
+    if self._rep:
+      self._lookup(pick(self._rep, ids), pick(self._rep, splits), pick(self._rep, views))
+    if self._shd:
+      self._sharded(pick(self._shd, ids), pick(self._shd, splits), pick(self._shd, views))
+    self._last = (ids, splits)
+    if cols_to_output_tensors is not None:
+      for c, col in enumerate(self.columns):
+        cols_to_output_tensors[col] = views[c]
+    return out
+
+  def backward(self, grad, apply_lr=0.0):
+    """grad: ``[batch, sum of dims]`` gradient of the last forward's output.  Returns per column
+    the ``IndexedSlices`` ``(unique_rows, grad_rows, n_unique)`` of this rank's rows (local row
+    numbers for sharded tables); with ``apply_lr`` the sparse SGD step is applied in the same
+    pass.  Gradients of replicated tables still need the cross-rank aggregation of
+    hybridbackend/tensorflow/training/gradient.py:119-177 before they are applied at W > 1."""
+    ids, splits = self._last
+    if grad.dim() != 2 or grad.shape[1] != self.width or grad.dtype != torch.float32:
+      raise _lib.InvalidArgumentError(
+        _lib.INVALID_ARGUMENT, f'grad must be fp32 [batch, {self.width}]')
+    if grad.stride(1) != 1 or grad.stride(0) % 4 != 0:
+      # same pitch as the forward's block: rows on 16-byte boundaries (one extra copy)
+      pitch = (self.width + 3) // 4 * 4
+      padded = torch.empty((grad.shape[0], pitch), dtype=torch.float32,
+                           device=grad.device)[:, :self.width]
+      padded.copy_(grad)
+      grad = padded
+    views = [grad[:, self.offsets[c]:self.offsets[c] + self.columns[c].dimension]
+             for c in range(len(self.columns))]
+    pick = lambda idx, xs: [xs[c] for c in idx]   # noqa: E731
+    res = [None] * len(self.columns)
+    if self._rep:
+      r = self._grad(pick(self._rep, ids), pick(self._rep, views), pick(self._rep, splits),
+                     apply_lr=apply_lr)
+      for k, c in enumerate(self._rep):
+        res[c] = r[k]
+    if self._shd:
+      r = self._sharded.backward(pick(self._shd, views), apply_lr=apply_lr)
+      for k, c in enumerate(self._shd):
+        res[c] = r[k]
+    return res
+
+  def close(self):
+    if self._sharded is not None:
+      self._sharded.close()
+
+
+def dense_features(features, layer):
+  """``hb.keras.layers.dense_features``: the per-column tensors, in column order."""
+  m = {}
+  layer(features, cols_to_output_tensors=m)
+  return [m[c] for c in layer.columns]

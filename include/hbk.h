@@ -163,7 +163,9 @@ typedef struct {
   const int64_t* run_start;
   const int64_t* run_base;
   int32_t n_runs;
-  int32_t reserved_;
+  /* row stride of `out` in floats; 0 = dim.  Lets N columns write their blocks of one
+   * concatenated [segments, sum of dims] tensor (hb.feature_column.DenseFeatures) in place. */
+  int32_t out_stride;
 } hbk_lookup_column_t;
 
 int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
@@ -210,7 +212,7 @@ typedef struct {
   const int64_t* run_ids;
   const int64_t* run_grads;
   int32_t n_runs;
-  int32_t reserved_;
+  int32_t grad_stride;       /* row stride of grad_out in floats; 0 = dim (see out_stride) */
 } hbk_lookup_grad_column_t;
 
 size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
@@ -241,7 +243,7 @@ typedef struct {
   const int64_t* run_start;
   const int64_t* run_base;
   int32_t n_runs;
-  int32_t reserved_;
+  int32_t grad_stride;        /* row stride of grad_out in floats; 0 = dim */
 } hbk_stitch_grad_column_t;
 
 int hbk_group_stitch_bwd(int32_t n_cols, const hbk_stitch_grad_column_t* cols,
@@ -375,11 +377,14 @@ typedef struct hbk_sharded* hbk_sharded_t;
 int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t n_cols,
                        const hbk_sharded_column_t* cols, int32_t wire_dtype);
 int hbk_sharded_destroy(hbk_sharded_t plan);
+/* out_strides / grad_strides: NULL, or per column the row stride in floats of outs[c] /
+ * grads[c] (0 = dim): the columns' blocks of one concatenated [segments, sum of dims] tensor. */
 int hbk_sharded_lookup_fwd(hbk_sharded_t plan, const int64_t* const* ids, const int64_t* n_ids,
                            const int32_t* const* row_splits, const int64_t* n_segments,
-                           float* const* outs, hbk_stream_t stream);
+                           float* const* outs, const int32_t* out_strides, hbk_stream_t stream);
 int64_t hbk_sharded_owned_ids(hbk_sharded_t plan, int32_t column);
-int hbk_sharded_lookup_bwd(hbk_sharded_t plan, const float* const* grads, float apply_lr,
+int hbk_sharded_lookup_bwd(hbk_sharded_t plan, const float* const* grads,
+                           const int32_t* grad_strides, float apply_lr,
                            int64_t* const* unique_rows, float* const* grad_rows,
                            int32_t* const* n_unique, hbk_stream_t stream);
 

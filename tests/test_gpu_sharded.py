@@ -274,3 +274,125 @@ def test_cxx_driver_multi_rank_in_process_world(monkeypatch, world, wire16, id64
     np.testing.assert_allclose(got, dense, **tol)
   for cm in comms:
     cm.close()
+
+
+# ----------------------------------------------------------------------------------
+# feature columns: one dense [batch, sum of dims] block written / differentiated in place
+def _dense_case(rng, world):
+  cols = [hb.feature_column.EmbeddingColumn('a', 50021, 16, 'sum'),
+          hb.feature_column.EmbeddingColumn('b', 37, 4, 'mean'),       # small: stays replicated
+          hb.feature_column.EmbeddingColumn('c', 3000, 128, 'sqrtn'),
+          hb.feature_column.EmbeddingColumn('d', 977, 6, 'mean')]
+  batch = 300
+  tables = [rng.uniform(-1, 1, size=(c.num_buckets, c.dimension)).astype(np.float32)
+            for c in cols]
+  feats, grads = [], []
+  for _ in range(world):
+    f = {}
+    for k, c in enumerate(cols):
+      if k % 2 == 0:
+        f[c.key] = rng.randint(0, 2**40, size=batch).astype(np.int64)
+      else:
+        lens = rng.poisson(3, size=batch).clip(0, 9)
+        sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        f[c.key] = (rng.randint(0, 2**40, size=int(sp[-1])).astype(np.int64), sp)
+    feats.append(f)
+    grads.append(rng.randn(batch, sum(c.dimension for c in cols)).astype(np.float32))
+  return cols, tables, feats, grads, batch
+
+
+def _dev_feats(f):
+  return {k: (tuple(dev(x) for x in v) if isinstance(v, tuple) else dev(v)) for k, v in f.items()}
+
+
+def _want_dense(cols, tables, f):
+  ids = [f[c.key][0] if isinstance(f[c.key], tuple) else f[c.key] for c in cols]
+  sps = [f[c.key][1] if isinstance(f[c.key], tuple) else None for c in cols]
+  outs = oracle.group_lookup_fwd(tables, ids, sps, [c.num_buckets for c in cols],
+                                 [c.combiner for c in cols])
+  return np.concatenate(outs, axis=1), ids, sps
+
+
+def test_dense_features_single_gpu():
+  rng = np.random.RandomState(41)
+  cols, tables, feats, grads, batch = _dense_case(rng, 1)
+  layer = hb.feature_column.DenseFeatures(
+    cols, DEV, init=lambda c, rows, d: dev(tables[cols.index(c)].copy()))
+  out = layer(_dev_feats(feats[0]))
+  want, ids, sps = _want_dense(cols, tables, feats[0])
+  np.testing.assert_equal(out.cpu().numpy(), want)
+  per_col = hb.feature_column.dense_features(_dev_feats(feats[0]), layer)
+  assert [tuple(t.shape) for t in per_col] == [(batch, c.dimension) for c in cols]
+  res = layer.backward(dev(grads[0]))
+  off = 0
+  for k, c in enumerate(cols):
+    g = grads[0][:, off:off + c.dimension]
+    off += c.dimension
+    sp = sps[k] if sps[k] is not None else np.arange(batch + 1, dtype=np.int32)
+    g_id = oracle.segment_combine_grad(np.ascontiguousarray(g), sp, c.combiner).astype(np.float64)
+    dense = np.zeros((c.num_buckets, c.dimension), np.float64)
+    np.add.at(dense, ids[k] % c.num_buckets, g_id)
+    u, gr, nu = res[k]
+    n = int(nu.item())
+    got = np.zeros_like(dense)
+    rows = u.cpu().numpy()[:n]
+    assert len(set(rows.tolist())) == n
+    got[rows] = gr.cpu().numpy()[:n]
+    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5)
+
+
+def test_dense_features_sharded_and_replicated_columns_in_process_world():
+  import threading
+  world = 2
+  rng = np.random.RandomState(42)
+  cols, tables, feats, grads, batch = _dense_case(rng, world)
+  comms = hb.distribute.Collective.local_world(world)
+  results, errors = [None] * world, []
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        def init(c, rows, d):
+          t = tables[cols.index(c)]
+          return dev((t[r::world] if rows != c.num_buckets else t).copy())
+        layer = hb.feature_column.DenseFeatures(cols, DEV, coll=comms[r], batch_size=batch,
+                                                init=init)
+        assert layer.sharded == [True, False, True, True]
+        out = layer(_dev_feats(feats[r]))
+        res = layer.backward(dev(grads[r]))
+        torch.cuda.current_stream().synchronize()
+        results[r] = (out.cpu().numpy(),
+                      [(u.cpu().numpy()[:int(k.item())], g.cpu().numpy()[:int(k.item())])
+                       for u, g, k in res])
+        layer.close()
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((r, repr(e)))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=120)
+  assert not errors, errors
+  wants = [_want_dense(cols, tables, feats[r]) for r in range(world)]
+  for r in range(world):
+    np.testing.assert_equal(results[r][0], wants[r][0])
+  off = 0
+  for k, c in enumerate(cols):
+    dense = np.zeros((c.num_buckets, c.dimension), np.float64)
+    got = np.zeros_like(dense)
+    for r in range(world):
+      _, ids, sps = wants[r]
+      g = np.ascontiguousarray(grads[r][:, off:off + c.dimension])
+      sp = sps[k] if sps[k] is not None else np.arange(batch + 1, dtype=np.int32)
+      g_id = oracle.segment_combine_grad(g, sp, c.combiner).astype(np.float64)
+      np.add.at(dense, ids[k] % c.num_buckets, g_id)
+      rows, vals = results[r][1][k]
+      # sharded tables report local rows (global = local * W + rank); replicated ones global
+      # rows, each rank its own share (summed here = the cross-rank aggregation)
+      glob = rows * world + r if k != 1 else rows
+      np.add.at(got, glob, vals.astype(np.float64))
+    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5)
+    off += c.dimension
+  for cm in comms:
+    cm.close()

@@ -24,7 +24,7 @@ for st in $STAGES; do
       (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0 > $O/prof.log 2>&1; echo "prof rc=$?" >> $O/prof.log)
       tail -3 $O/prof.log; find $O/prof -name "*stats*" | head;;
     sweep)
-      timeout 900 python tools/sweep.py --big --cases ${SWEEP_CASES:-a,b,c,d,e,f,g,h} > $O/sweep.log 2>&1; echo "sweep rc=$?" >> $O/sweep.log; cat $O/sweep.log | cut -c1-400;;
+      timeout 900 python tools/sweep.py --big --cases ${SWEEP_CASES:-a,b,c,d,e,f,g,h,i} > $O/sweep.log 2>&1; echo "sweep rc=$?" >> $O/sweep.log; cat $O/sweep.log | cut -c1-400;;
     profsweep)
       (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sweep -o sweep -- python $R/tools/sweep.py --cases ${SWEEP_CASES:-c,e} > $O/prof_sweep.log 2>&1; echo "rc=$?" >> $O/prof_sweep.log)
       tail -3 $O/prof_sweep.log;;

@@ -217,6 +217,27 @@ def case_cfg5():
   report(f'cfg5 bwd + SGD apply 200 cols mixed dims B={B}', us, n_ids, n_bytes, ids=n_ids)
 
 
+def case_dense_block():
+  """26 columns written as the blocks of ONE [batch, 26 x 16] tensor in place (out_stride) vs 26
+  separate outputs + a concat pass (what DenseFeatures does on top of per-column lookups)."""
+  tables = uniform_tables(26, 1000000, 16)
+  B = 65536
+  lookup = hb.embedding.GroupLookup(tables, [1000000] * 26, 'sum')
+  ids = [torch.randint(0, 1 << 40, (B,), device=DEV) for _ in range(26)]
+  block = torch.empty(B, 26 * 16, device=DEV)
+  views = [block[:, c * 16:(c + 1) * 16] for c in range(26)]
+  lookup.bind(ids, None, views)
+  us = timed(lambda i: lookup.launch(), iters=30)
+  report(f'dense block [B, 416] written in place, 26 cols dim16 B={B}', us, 26 * B, 26 * B * 136)
+  outs = lookup.bind(ids, None, None)
+
+  def two_pass(i):
+    lookup.launch()
+    torch.cat(outs, dim=1, out=block)
+  us = timed(two_pass, iters=30)
+  report(f'26 separate outputs + concat pass, 26 cols dim16 B={B}', us, 26 * B, 26 * B * 136)
+
+
 def case_sharded_world1():
   """The whole sharded pipeline (partition -> RCCL alltoallv -> owner gather -> alltoallv ->
   stitch) on one GPU with a world-size-1 communicator: kernel chain + host overhead per step."""
@@ -260,5 +281,5 @@ if __name__ == '__main__':
   torch.manual_seed(0)
   for c in args.cases.split(','):
     {'a': case_batch_sweep, 'b': case_ragged, 'c': case_backward_cfg2,
-     'd': lambda: case_cfg4(args.big), 'e': case_integer, 'f': case_bwd_probe, 'g': case_sharded_world1, 'h': case_cfg5}[c]()
+     'd': lambda: case_cfg4(args.big), 'e': case_integer, 'f': case_bwd_probe, 'g': case_sharded_world1, 'h': case_cfg5, 'i': case_dense_block}[c]()
     torch.cuda.empty_cache()

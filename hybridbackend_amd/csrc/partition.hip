@@ -111,8 +111,6 @@ __device__ inline int find_col(const PartArgs& a, int tile) {
   return lo;
 }
 
-constexpr int kStaticP = 16;  // up to here one ballot per shard and chunk: independent compares,
-                              // counters in lane p's register, no serial match-any chain
 
 // One ballot per shard.  With the shard count known at compile time the P compares, popcounts and
 // selects of a chunk are independent straight-line code the scheduler can interleave; as a
@@ -188,6 +186,35 @@ __device__ inline int32_t place(uint32_t shard, int P, int lane, int32_t& my_run
   return pos;
 }
 
+// 8 < P <= 64: the lanes holding the same shard are found from one ballot per BIT of the shard
+// (<= 6) instead of one loop iteration per distinct shard in the chunk (up to 64, each waiting
+// for the previous one): every lane ANDs the ballots, taken plain or inverted by its own bits,
+// into the mask of its shard's lanes -- and a second time with the bits of its LANE number into
+// the mask of shard `lane`, whose running counter it keeps.
+template <int NBITS>
+__device__ inline void shard_masks(uint32_t shard, int lane, unsigned long long& mine,
+                                   unsigned long long& for_lane) {
+  mine = for_lane = __ballot(shard != 0xffffffffu);
+#pragma unroll
+  for (int b = 0; b < NBITS; ++b) {
+    const unsigned long long bal = __ballot(((shard >> b) & 1u) != 0);
+    mine &= ((shard >> b) & 1u) ? bal : ~bal;
+    for_lane &= ((lane >> b) & 1) ? bal : ~bal;
+  }
+}
+
+__device__ inline void shard_masks_n(uint32_t shard, int nbits, int lane, unsigned long long& mine,
+                                     unsigned long long& for_lane) {
+  switch (nbits) {
+    case 1: shard_masks<1>(shard, lane, mine, for_lane); break;
+    case 2: shard_masks<2>(shard, lane, mine, for_lane); break;
+    case 3: shard_masks<3>(shard, lane, mine, for_lane); break;
+    case 4: shard_masks<4>(shard, lane, mine, for_lane); break;
+    case 5: shard_masks<5>(shard, lane, mine, for_lane); break;
+    default: shard_masks<6>(shard, lane, mine, for_lane); break;
+  }
+}
+
 // ---- A: per-tile histogram ------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a) {
@@ -206,8 +233,11 @@ __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a)
   // segment inside the unrolled chunk loops costs a scalar-memory round trip each time
   const ShardFn fn = a.fn;
   const FastDiv bk = c.bucket;
-  const bool small_p = P <= kStaticP;
-  int32_t cnt = 0;  // small P: lane p counts the ids of shard p in this tile
+  const bool small_p = P <= kWave;
+  int nbits = 1;
+  while ((1 << nbits) < P) ++nbits;
+  const int fixed_max = a.pad0_;   // tuning hook: P <= fixed_max takes the ballot-per-shard path
+  int32_t cnt = 0;  // P <= 64: lane p counts the ids of shard p in this tile
   if (!small_p) {
     for (int p = lane; p < P; p += kWave) counters[p] = 0;
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): zeroing done before the atomics
@@ -226,8 +256,12 @@ __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a)
       const int64_t i = base + k * kWave + lane;
       const uint32_t shard =
           i < len ? shard_of<T>(bucketize<T>(v[k], bk), fn) : 0xffffffffu;
-      if (small_p) {
+      if (P <= fixed_max) {
         cnt += count_shards(shard, P, lane);
+      } else if (small_p) {
+        unsigned long long mine, for_lane;
+        shard_masks_n(shard, nbits, lane, mine, for_lane);
+        cnt += (int32_t)__builtin_popcountll(for_lane);
       } else if (i < len) {
         atomicAdd(&counters[shard], 1);
       }
@@ -330,6 +364,9 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
   // running position of every shard: lane p's register for P <= 64, LDS beyond; it carries over
   // the 1024-id passes of the tile, which are taken in order (stability)
   int32_t my_run = 0;
+  int nbits = 1;
+  while ((1 << nbits) < P) ++nbits;
+  const int fixed_max = a.pad0_;
   if (P <= kWave) {
     my_run = lane < P ? hist[(int64_t)lane * n_tiles + ctile] : 0;
   } else {
@@ -345,8 +382,8 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
       const int64_t i = base + k * kWave + lane;
       v[k] = i < len ? bucketize<T>(in[i], bk) : T(0);
     }
-    if (P <= kStaticP) {
-      // the W <= 16 case: one ballot per shard, all compares of a chunk independent of each other
+    if (P <= fixed_max) {
+      // the single-node case: one ballot per shard, all compares of a chunk independent
 #pragma unroll
       for (int k = 0; k < kChunks; ++k) {
         const int64_t i = base + k * kWave + lane;
@@ -359,23 +396,16 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
         }
       }
     } else if (P <= kWave) {
-      // match-any loop; the leader's base is fetched with v_readlane, no LDS round trips
+      // one ballot per bit of the shard; the base comes from lane `shard` by ds_bpermute
 #pragma unroll
       for (int k = 0; k < kChunks; ++k) {
         const int64_t i = base + k * kWave + lane;
         const bool valid = i < len;
         const uint32_t shard = valid ? shard_of<T>(v[k], fn) : 0xffffffffu;
-        unsigned long long todo = __ballot(valid);
-        int32_t pos = 0;
-        while (todo != 0ull) {
-          const int leader = __builtin_ctzll(todo);
-          const int s = __builtin_amdgcn_readlane((int)shard, leader);
-          const unsigned long long same = __ballot(shard == (uint32_t)s);
-          const int32_t base_s = __builtin_amdgcn_readlane(my_run, s);
-          if (shard == (uint32_t)s) pos = base_s + rank_below(same);
-          if (lane == s) my_run += (int32_t)__builtin_popcountll(same);
-          todo &= ~same;
-        }
+        unsigned long long mine, for_lane;
+        shard_masks_n(shard, nbits, lane, mine, for_lane);
+        const int32_t pos = __shfl(my_run, (int)(shard & 63u), kWave) + rank_below(mine);
+        my_run += (int32_t)__builtin_popcountll(for_lane);
         if (valid) {
           out[pos] = v[k];
           indices[i] = pos;
@@ -494,7 +524,7 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
     args.sizes_t = sizes_t;
     args.n_total_cols = n_cols;
     args.pad_ = 0;
-    args.pad0_ = 0;
+    args.pad0_ = getenv("HBK_PART_FIXED") ? atoi(getenv("HBK_PART_FIXED")) : 8;
     args.sub_tiles = sub;
     int32_t k = 0;
     int64_t tiles = 0;

@@ -107,6 +107,9 @@ def _declare(l):
     'hbk_alltoallv_wire_workspace_bytes': (sz, [i32, vp, vp, vp, i32]),
     'hbk_alltoallv_n':
       (C.c_int, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'hbk_allreduce_workspace_bytes': (sz, [i32, vp, i32]),
+    'hbk_allreduce_n': (C.c_int, [vp, i32, i32, i32, vp, vp, vp, C.c_float, vp, sz, vp]),
+    'hbk_allgatherv': (C.c_int, [vp, i32, vp, vp, vp, vp]),
     'hbk_local_world_create': (C.c_int, [vp, i32]),
     'hbk_local_world_destroy': (C.c_int, [vp]),
     'hbk_comm_create_local': (C.c_int, [vp, vp, i32]),

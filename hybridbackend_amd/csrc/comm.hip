@@ -579,3 +579,304 @@ extern "C" int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
                                send_sizes, outputs, recv_sizes, wire_ws, wire_ws_bytes,
                                compute_stream, nullptr, nullptr);
 }
+
+// ------------------------------------------------------------------------------------------------
+// aggregation of replicated gradients (hbtf/training/gradient.py:119-177).
+//   dense   HbNcclAllreduce / HbNcclAllreduceN / ..MergedN  (nccl_allreduce.cc:31-260)
+//   sparse  HbNcclAllgatherv                                (nccl_allgatherv.cc:31-120)
+// The N tensors of a call travel as ONE bucket: packed into a staging buffer, one ncclAllReduce,
+// unpacked -- with the `1/W` of gradient.py:77-99 (`_mean`) fused into the unpack as `scale`.
+namespace hbk {
+namespace {
+
+constexpr int kRedBlock = 256;
+constexpr int kMaxRedSegs = 400;
+
+struct RedSeg {
+  const void* src;
+  void* dst;
+  int64_t count;    // elements
+  int64_t tile0;
+};
+struct RedArgs {
+  int32_t n_segs;
+  int32_t esize;
+  float scale;
+  int32_t scale_f32;   // 1: dst = src * scale (fp32 only)
+  RedSeg seg[kMaxRedSegs];
+};
+static_assert(sizeof(RedArgs) <= 16384, "kernarg budget");
+constexpr int kRedTile = kRedBlock * 8;   // elements per block
+
+// N-segment copy with an optional fp32 scale (pack: scale off; unpack: the mean's 1/W)
+__global__ __launch_bounds__(kRedBlock) void bucket_copy_kernel(const RedArgs a) {
+  int si = 0, hi = a.n_segs;
+  while (hi - si > 1) {
+    const int mid = (si + hi) >> 1;
+    if (a.seg[mid].tile0 <= (int64_t)blockIdx.x) {
+      si = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  const RedSeg& s = a.seg[si];
+  const int64_t base = ((int64_t)blockIdx.x - s.tile0) * kRedTile;
+#pragma unroll
+  for (int k = 0; k < kRedTile / kRedBlock; ++k) {
+    const int64_t i = base + (int64_t)k * kRedBlock + threadIdx.x;
+    if (i >= s.count) continue;
+    if (a.esize == 4) {
+      if (a.scale_f32) {
+        reinterpret_cast<float*>(s.dst)[i] = reinterpret_cast<const float*>(s.src)[i] * a.scale;
+      } else {
+        reinterpret_cast<uint32_t*>(s.dst)[i] = reinterpret_cast<const uint32_t*>(s.src)[i];
+      }
+    } else if (a.esize == 8) {
+      reinterpret_cast<uint64_t*>(s.dst)[i] = reinterpret_cast<const uint64_t*>(s.src)[i];
+    } else if (a.esize == 2) {
+      reinterpret_cast<uint16_t*>(s.dst)[i] = reinterpret_cast<const uint16_t*>(s.src)[i];
+    } else {
+      reinterpret_cast<uint8_t*>(s.dst)[i] = reinterpret_cast<const uint8_t*>(s.src)[i];
+    }
+  }
+}
+
+int bucket_copy(int32_t n, const void* const* src, void* const* dst, const int64_t* counts,
+                size_t esize, bool scale_f32, float scale, hipStream_t stream) {
+  int32_t c0 = 0;
+  while (c0 < n) {
+    RedArgs args;
+    int k = 0;
+    int64_t tiles = 0;
+    while (c0 < n && k < kMaxRedSegs) {
+      const int32_t c = c0++;
+      if (counts[c] == 0) continue;
+      args.seg[k].src = src[c];
+      args.seg[k].dst = dst[c];
+      args.seg[k].count = counts[c];
+      args.seg[k].tile0 = tiles;
+      tiles += (counts[c] + kRedTile - 1) / kRedTile;
+      ++k;
+    }
+    if (k == 0) continue;
+    args.n_segs = k;
+    args.esize = (int32_t)esize;
+    args.scale = scale;
+    args.scale_f32 = scale_f32 ? 1 : 0;
+    hipLaunchKernelGGL(bucket_copy_kernel, dim3((unsigned)tiles), dim3(kRedBlock), 0, stream, args);
+    HBK_HIP_OK(hipGetLastError());
+  }
+  return HBK_OK;
+}
+
+// in-process world: out[i] = op over ranks (rank order) of the published buffers
+struct PeerPtrs {
+  const void* p[64];
+  int32_t world;
+  int32_t op;
+  int32_t dtype;
+  int32_t pad_;
+};
+
+template <typename T>
+__device__ inline T red_op(T a, T b, int op) {
+  switch (op) {
+    case 1: return a * b;
+    case 2: return a > b ? a : b;
+    case 3: return a < b ? a : b;
+    default: return a + b;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kRedBlock) void local_reduce_kernel(const PeerPtrs pp, int64_t n,
+                                                                 T* out) {
+  const int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x;
+  if (i >= n) return;
+  T acc = reinterpret_cast<const T*>(pp.p[0])[i];
+  for (int r = 1; r < pp.world; ++r) acc = red_op<T>(acc, reinterpret_cast<const T*>(pp.p[r])[i], pp.op);
+  out[i] = acc;
+}
+
+bool to_nccl_op(int32_t op, ncclRedOp_t* out) {
+  switch (op) {
+    case 0: *out = ncclSum; return true;
+    case 1: *out = ncclProd; return true;
+    case 2: *out = ncclMax; return true;
+    case 3: *out = ncclMin; return true;
+    default: return false;
+  }
+}
+
+}  // namespace
+}  // namespace hbk
+
+extern "C" size_t hbk_allreduce_workspace_bytes(int32_t n, const int64_t* counts, int32_t dtype) {
+  if (n <= 1 || counts == nullptr) return 0;   // a single tensor is reduced in place, no bucket
+  size_t total = 0;
+  for (int32_t c = 0; c < n; ++c) total += (size_t)(counts[c] > 0 ? counts[c] : 0);
+  return total * (size_t)hbk::dtype_size(dtype) + 16;
+}
+
+extern "C" int hbk_allreduce_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t reduce_op,
+                               const void* const* inputs, const int64_t* counts,
+                               void* const* outputs, float scale, void* workspace,
+                               size_t workspace_bytes, hbk_stream_t compute_stream) {
+  using namespace hbk;
+  HBK_REQUIRE(comm != nullptr, "allreduce_n: comm is NULL");
+  HBK_REQUIRE(n >= 0, "allreduce_n: n must be >= 0");
+  if (n == 0) return HBK_OK;
+  HBK_REQUIRE(inputs && counts && outputs, "allreduce_n: NULL argument array");
+  ncclDataType_t nt;
+  ncclRedOp_t op;
+  HBK_REQUIRE(to_nccl(dtype, &nt), "allreduce_n: unsupported dtype %d", dtype);
+  HBK_REQUIRE(to_nccl_op(reduce_op, &op),
+              "allreduce_n: reduce_op must be 0 (SUM), 1 (PROD), 2 (MAX) or 3 (MIN)");
+  HBK_REQUIRE(scale == 1.0f || dtype == HBK_FLOAT, "allreduce_n: scale needs fp32 data");
+  const size_t esize = (size_t)dtype_size(dtype);
+  int64_t total = 0;
+  for (int32_t c = 0; c < n; ++c) {
+    HBK_REQUIRE(counts[c] >= 0, "allreduce_n: negative count for input %d", c);
+    HBK_REQUIRE(counts[c] == 0 || (inputs[c] && outputs[c]), "allreduce_n: NULL buffer %d", c);
+    total += counts[c];
+  }
+  if (total == 0) return HBK_OK;
+  hipStream_t cs = as_stream(compute_stream);
+  // the bucket: one tensor is reduced straight from input to output
+  const void* red_in = inputs[0];
+  void* red_out = outputs[0];
+  std::vector<void*> slots(n);
+  if (n > 1) {
+    const size_t need = hbk_allreduce_workspace_bytes(n, counts, dtype);
+    HBK_REQUIRE(workspace != nullptr && workspace_bytes >= need,
+                "allreduce_n: workspace too small: need %zu bytes, got %zu", need,
+                workspace_bytes);
+    char* p = reinterpret_cast<char*>(workspace);
+    for (int32_t c = 0; c < n; ++c) {
+      slots[c] = p;
+      p += (size_t)counts[c] * esize;
+    }
+    red_in = red_out = workspace;
+  }
+  hipStream_t rs = comm->local != nullptr ? cs : comm->stream;   // stream of pack/reduce/unpack
+  if (comm->local == nullptr) {
+    int rc = fence_in(comm, cs);
+    if (rc != HBK_OK) return rc;
+  }
+  if (n > 1) {
+    int rc = bucket_copy(n, inputs, slots.data(), counts, esize, false, 1.0f, rs);
+    if (rc != HBK_OK) return rc;
+  }
+  if (comm->local != nullptr) {
+    LocalWorld* w = comm->local;
+    const int me = comm->rank;
+    HBK_REQUIRE(w->world <= 64, "allreduce_n: local world larger than 64");
+    // partial results go to a private buffer so that peers still read this rank's INPUT
+    void* tmp = nullptr;
+    HBK_HIP_OK(hipMalloc(&tmp, (size_t)total * esize + 16));
+    w->ptr[me] = red_in;
+    HBK_HIP_OK(hipEventRecord(w->ready[me], rs));
+    w->barrier();
+    PeerPtrs pp;
+    pp.world = w->world;
+    pp.op = reduce_op;
+    pp.dtype = dtype;
+    pp.pad_ = 0;
+    for (int i = 0; i < w->world; ++i) {
+      HBK_HIP_OK(hipStreamWaitEvent(rs, w->ready[i], 0));
+      pp.p[i] = w->ptr[i];
+    }
+    const unsigned blocks = (unsigned)((total + kRedBlock - 1) / kRedBlock);
+    switch (dtype) {
+      case HBK_FLOAT:
+        hipLaunchKernelGGL(local_reduce_kernel<float>, dim3(blocks), dim3(kRedBlock), 0, rs, pp,
+                           total, reinterpret_cast<float*>(tmp));
+        break;
+      case HBK_INT32:
+        hipLaunchKernelGGL(local_reduce_kernel<int32_t>, dim3(blocks), dim3(kRedBlock), 0, rs, pp,
+                           total, reinterpret_cast<int32_t*>(tmp));
+        break;
+      case HBK_INT64:
+        hipLaunchKernelGGL(local_reduce_kernel<int64_t>, dim3(blocks), dim3(kRedBlock), 0, rs, pp,
+                           total, reinterpret_cast<int64_t*>(tmp));
+        break;
+      case HBK_DOUBLE:
+        hipLaunchKernelGGL(local_reduce_kernel<double>, dim3(blocks), dim3(kRedBlock), 0, rs, pp,
+                           total, reinterpret_cast<double*>(tmp));
+        break;
+      default:
+        (void)hipFree(tmp);
+        return fail(HBK_INVALID_ARGUMENT, "allreduce_n: the in-process world reduces float, "
+                                          "double, int32, int64");
+    }
+    HBK_HIP_OK(hipEventRecord(w->done[me], rs));
+    w->barrier();
+    for (int i = 0; i < w->world; ++i) HBK_HIP_OK(hipStreamWaitEvent(rs, w->done[i], 0));
+    HBK_HIP_OK(hipMemcpyAsync(red_out, tmp, (size_t)total * esize, hipMemcpyDeviceToDevice, rs));
+    HBK_HIP_OK(hipStreamSynchronize(rs));   // test transport: tmp is freed right away
+    (void)hipFree(tmp);
+    w->barrier();
+  } else {
+    std::unique_lock<std::mutex> lock(comm->mu);
+    HBK_REQUIRE(!comm->aborted, "allreduce_n: communicator was aborted");
+    HBK_NCCL_OK(ncclAllReduce(red_in, red_out, (size_t)total, nt, op, comm->comm, comm->stream));
+  }
+  if (n > 1) {
+    std::vector<const void*> src(slots.begin(), slots.end());
+    int rc = bucket_copy(n, src.data(), outputs, counts, esize, scale != 1.0f, scale, rs);
+    if (rc != HBK_OK) return rc;
+  } else if (scale != 1.0f) {
+    const void* src[1] = {red_out};
+    int rc = bucket_copy(1, src, outputs, counts, esize, true, scale, rs);
+    if (rc != HBK_OK) return rc;
+  }
+  if (comm->local == nullptr) return fence_out(comm, cs);
+  return HBK_OK;
+}
+
+// HbNcclAllgatherv: output = inputs of ranks 0..W-1 concatenated; counts[r] (host, elements) is
+// what rank r contributes (the op gathers them itself and syncs the host, nccl_allgatherv.cc;
+// here the caller obtains them, e.g. with one hbk_alltoall_n of its own count).
+extern "C" int hbk_allgatherv(hbk_comm_t comm, int32_t dtype, const void* input,
+                              const int64_t* counts, void* output, hbk_stream_t compute_stream) {
+  using namespace hbk;
+  HBK_REQUIRE(comm != nullptr && counts != nullptr, "allgatherv: NULL argument");
+  ncclDataType_t nt;
+  HBK_REQUIRE(to_nccl(dtype, &nt), "allgatherv: unsupported dtype %d", dtype);
+  const size_t esize = (size_t)dtype_size(dtype);
+  const int W = comm->world_size, me = comm->rank;
+  std::vector<int64_t> off(W + 1, 0);
+  for (int r = 0; r < W; ++r) {
+    HBK_REQUIRE(counts[r] >= 0, "allgatherv: negative count for rank %d", r);
+    off[r + 1] = off[r] + counts[r];
+  }
+  if (off[W] == 0) return HBK_OK;
+  HBK_REQUIRE(output != nullptr && (counts[me] == 0 || input != nullptr), "allgatherv: NULL buffer");
+  hipStream_t cs = as_stream(compute_stream);
+  char* out = reinterpret_cast<char*>(output);
+  if (comm->local != nullptr) {
+    std::vector<int64_t> soff(W, 0), slen(W, counts[me]), roff(off.begin(), off.end() - 1);
+    return local_exchange(comm, input, soff, slen, output, roff, esize, cs);
+  }
+  std::unique_lock<std::mutex> lock(comm->mu);
+  HBK_REQUIRE(!comm->aborted, "allgatherv: communicator was aborted");
+  int rc = fence_in(comm, cs);
+  if (rc != HBK_OK) return rc;
+  HBK_NCCL_OK(ncclGroupStart());
+  for (int r = 0; r < W; ++r) {
+    if (r == me) continue;
+    if (counts[me] > 0) {
+      HBK_NCCL_OK(ncclSend(input, (size_t)counts[me], nt, r, comm->comm, comm->stream));
+    }
+    if (counts[r] > 0) {
+      HBK_NCCL_OK(ncclRecv(out + (size_t)off[r] * esize, (size_t)counts[r], nt, r, comm->comm,
+                           comm->stream));
+    }
+  }
+  HBK_NCCL_OK(ncclGroupEnd());
+  if (counts[me] > 0) {
+    HBK_HIP_OK(hipMemcpyAsync(out + (size_t)off[me] * esize, input, (size_t)counts[me] * esize,
+                              hipMemcpyDeviceToDevice, comm->stream));
+  }
+  return fence_out(comm, cs);
+}

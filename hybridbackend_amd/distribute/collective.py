@@ -192,6 +192,89 @@ class Collective:
     return out, recv_sizes
 
 
+  # -- HbNcclAllreduce[N] / HbNcclAllreduceMergedN: the N tensors travel as one bucket --
+  SUM, PROD, MAX, MIN = 0, 1, 2, 3   # CollectiveOps (hbtf/distribute/ops.py)
+
+  def allreduce_n(self, values, reduce_op=0, scale=1.0, outs=None):
+    """Reduce every tensor across ranks; ``scale`` (fp32) multiplies the result in the same
+    pass (``1 / world_size`` = the mean of training/gradient.py:77-99)."""
+    n = len(values)
+    if n == 0:
+      return []
+    dev = values[0].device
+    code = _lib.torch_dtype_code(values[0].dtype)
+    for v in values:
+      _lib.require_device_tensor(v, 'value')
+      if v.dtype != values[0].dtype:
+        raise _lib.InvalidArgumentError(
+          _lib.INVALID_ARGUMENT, 'all tensors of a packed allreduce share one dtype')
+    if outs is None:
+      outs = [torch.empty_like(v) for v in values]
+    counts = _lib.i64_array([v.numel() for v in values])
+    need = self._lib.hbk_allreduce_workspace_bytes(n, counts, code)
+    if need and (getattr(self, '_red_ws', None) is None or self._red_ws.numel() < need):
+      self._red_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    ws = self._red_ws if need else None
+    _lib.check(self._lib.hbk_allreduce_n(
+      self._handle, n, code, int(reduce_op), _lib.ptr_array([v.data_ptr() for v in values]),
+      counts, _lib.ptr_array([o.data_ptr() for o in outs]), C.c_float(scale),
+      C.c_void_p(ws.data_ptr() if ws is not None else None),
+      C.c_size_t(ws.numel() if ws is not None else 0), _lib.current_stream(dev)))
+    return outs
+
+  def allreduce(self, value, reduce_op=None, name=None):
+    r'''Reduce values across devices (collective.py:176-209; op HbNcclAllreduce).'''
+    del name
+    return self.allreduce_n([value], 0 if reduce_op is None else reduce_op)[0]
+
+  def allgather(self, value, name=None):
+    r'''Gather ``value`` (rows along dim 0, any count per rank) from all devices, rank order
+    (collective.py ``allgather``; op HbNcclAllgatherv).  Like the reference op it brings the
+    per-rank sizes to the host to size the output: one stream sync.'''
+    del name
+    _lib.require_device_tensor(value, 'value')
+    W = self.world_size
+    inner = int(torch.Size(value.shape[1:]).numel()) if value.dim() > 1 else 1
+    mine = torch.full((W,), value.numel(), dtype=torch.int64, device=value.device)
+    counts = self.alltoall_n([mine])[0].tolist() if W > 1 else [value.numel()]
+    rows = sum(counts) // max(inner, 1)
+    out = torch.empty((rows,) + tuple(value.shape[1:]), dtype=value.dtype, device=value.device)
+    _lib.check(self._lib.hbk_allgatherv(
+      self._handle, _lib.torch_dtype_code(value.dtype), C.c_void_p(value.data_ptr()),
+      _lib.i64_array(counts), C.c_void_p(out.data_ptr()), _lib.current_stream(value.device)))
+    return out
+
+
+def aggregate_gradients(grads, coll, sharded=None):
+  """Cross-rank aggregation of one step's gradients -- mirror of
+  hybridbackend/tensorflow/training/gradient.py:119-217.
+
+  grads[i] is a dense tensor or an ``IndexedSlices`` tuple ``(values [k, dim], indices [k])``;
+  ``sharded[i]`` marks gradients of sharded variables, which are returned untouched (each rank
+  owns its rows, gradient.py:193-217).  Dense gradients of replicated variables are summed in ONE
+  packed allreduce and divided by the world size in the same pass; sparse ones are allgathered
+  (values and indices) and their values divided by the world size (gradient.py:77-99,160-177).
+  """
+  n = len(grads)
+  sharded = list(sharded) if sharded is not None else [False] * n
+  W = coll.world_size
+  out = list(grads)
+  if W <= 1:
+    return out
+  dense = [i for i in range(n) if not sharded[i] and grads[i] is not None
+           and not isinstance(grads[i], (tuple, list))]
+  if dense:
+    red = coll.allreduce_n([grads[i] for i in dense], scale=1.0 / W)
+    for i, r in zip(dense, red):
+      out[i] = r
+  for i in range(n):
+    if sharded[i] or grads[i] is None or not isinstance(grads[i], (tuple, list)):
+      continue
+    values, indices = grads[i]
+    out[i] = (coll.allgather(values) * (1.0 / W), coll.allgather(indices))
+  return out
+
+
 def _torch_broadcast_bytes(data):
   import torch.distributed as dist  # pylint: disable=import-outside-toplevel
   if not dist.is_initialized():

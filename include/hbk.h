@@ -333,6 +333,24 @@ int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dtyp
                     void* const* outputs, const int32_t* recv_sizes, void* wire_ws,
                     size_t wire_ws_bytes, hbk_stream_t compute_stream);
 
+/* ------------------------------------------------------------------------------------
+ * SURVEY 8f-1  aggregation of replicated gradients (hbtf/training/gradient.py:119-177):
+ *   HbNcclAllreduce / HbNcclAllreduceN / HbNcclAllreduceMergedN  (nccl_allreduce.cc:31-260)
+ *     outputs[c] = reduce over ranks of inputs[c] (reduce_op 0 SUM, 1 PROD, 2 MAX, 3 MIN), then
+ *     multiplied by `scale` (fp32 only; 1/W = the `_mean` of gradient.py:77-99 fused in).  The N
+ *     tensors travel as ONE bucket (pack -> one ncclAllReduce -> unpack); in place allowed.
+ *   HbNcclAllgatherv  (nccl_allgatherv.cc:31-120)
+ *     output = inputs of ranks 0..W-1 concatenated; counts[r] (host, elements) = what rank r
+ *     contributes.  The reference op exchanges the counts itself and syncs the host; here the
+ *     caller obtains them (one hbk_alltoall_n of its own count). */
+size_t hbk_allreduce_workspace_bytes(int32_t n, const int64_t* counts, int32_t dtype);
+int hbk_allreduce_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t reduce_op,
+                    const void* const* inputs, const int64_t* counts, void* const* outputs,
+                    float scale, void* workspace, size_t workspace_bytes,
+                    hbk_stream_t compute_stream);
+int hbk_allgatherv(hbk_comm_t comm, int32_t dtype, const void* input, const int64_t* counts,
+                   void* output, hbk_stream_t compute_stream);
+
 /* In-process "world" for tests: `world_size` ranks living in ONE process (one host thread and
  * one stream each, all on the current GPU) exchange through device copies with the same
  * chunk/offset arithmetic as the RCCL path.  It exists so that the multi-rank driver below can

@@ -467,6 +467,70 @@ REGISTER_KERNEL_BUILDER(Name("HbNcclAlltoallvN").Device(DEVICE_GPU)
                         AlltoallvNOp<float, Eigen::half>);
 
 // ============================================================================================
+// HbNcclAllreduce / HbNcclAllreduceN / HbNcclAllreduceMergedN, HbNcclAllgatherv
+// (nccl_allreduce.cc:31-49,93-116,180-203; nccl_allgatherv.cc:31-60): gradient aggregation.
+// All three allreduce forms go through hbk_allreduce_n, which always buckets its N tensors.
+// ============================================================================================
+#define HB_REGISTER_ALLREDUCE_OP(NAME, IN, OUT, EXTRA)                                        \
+  REGISTER_OP(NAME).Output(OUT).Input("handle: resource").Input(IN)                           \
+      .Attr("reduce_op: int >= 0 = 0").Attr("dtype: " HB_DTYPES) EXTRA.SetIsStateful()
+HB_REGISTER_ALLREDUCE_OP("HbNcclAllreduce", "input: dtype", "output: dtype", );
+HB_REGISTER_ALLREDUCE_OP("HbNcclAllreduceN", "n_input: N * dtype", "n_output: N * dtype",
+                         .Attr("N: int >= 1 = 1"));
+HB_REGISTER_ALLREDUCE_OP("HbNcclAllreduceMergedN", "n_input: N * dtype", "n_output: N * dtype",
+                         .Attr("N: int >= 1 = 1"));
+
+template <typename T>
+class AllreduceNOp : public CollectiveAsyncOp {
+ public:
+  explicit AllreduceNOp(OpKernelConstruction* ctx) : CollectiveAsyncOp(ctx) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("reduce_op", &reduce_op_));
+  }
+  void Run(OpKernelContext* ctx, HbNcclCollective* coll) override {
+    const int n = ctx->num_inputs() - 1;
+    std::vector<const void*> in(n);
+    std::vector<void*> out(n);
+    std::vector<int64_t> counts(n);
+    for (int i = 0; i < n; ++i) {
+      const Tensor& t = ctx->input(1 + i);
+      Tensor* o;
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, t.shape(), &o));
+      in[i] = t.tensor_data().data();
+      out[i] = const_cast<char*>(o->tensor_data().data());
+      counts[i] = t.NumElements();
+    }
+    const size_t ws_bytes = hbk_allreduce_workspace_bytes(n, counts.data(), HbkType<T>::v);
+    Tensor ws;
+    OP_REQUIRES_OK(ctx, AllocScratch(ctx, ws_bytes, &ws));
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_allreduce_n(
+                            coll->comm(), n, HbkType<T>::v, reduce_op_, in.data(), counts.data(),
+                            out.data(), 1.0f, ws.flat<int8>().data(), ws_bytes + 16,
+                            StreamOf(ctx))));
+  }
+
+ private:
+  int reduce_op_;
+};
+
+REGISTER_OP("HbNcclAllgatherv")
+    .Output("output: dtype").Input("handle: resource").Input("input: dtype")
+    .Attr("dtype: " HB_DTYPES).SetIsStateful();
+// Kernel: one hbk_alltoall_n of the local element count gives every rank's count, a host sync
+// sizes the output (as nccl_allgatherv.cc does), then hbk_allgatherv.
+
+#define HB_REGISTER_ALLREDUCE_KERNELS(T)                                                        \
+  REGISTER_KERNEL_BUILDER(Name("HbNcclAllreduce").Device(DEVICE_GPU).TypeConstraint<T>("dtype"), \
+                          AllreduceNOp<T>);                                                     \
+  REGISTER_KERNEL_BUILDER(Name("HbNcclAllreduceN").Device(DEVICE_GPU).TypeConstraint<T>("dtype"), \
+                          AllreduceNOp<T>);                                                     \
+  REGISTER_KERNEL_BUILDER(                                                                      \
+      Name("HbNcclAllreduceMergedN").Device(DEVICE_GPU).TypeConstraint<T>("dtype"),             \
+      AllreduceNOp<T>)
+HB_REGISTER_ALLREDUCE_KERNELS(int32); HB_REGISTER_ALLREDUCE_KERNELS(int64);
+HB_REGISTER_ALLREDUCE_KERNELS(float); HB_REGISTER_ALLREDUCE_KERNELS(double);
+HB_REGISTER_ALLREDUCE_KERNELS(Eigen::half);
+
+// ============================================================================================
 // HbLookup (cache probe)
 // ============================================================================================
 REGISTER_OP("HbLookup")

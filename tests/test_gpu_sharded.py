@@ -396,3 +396,72 @@ def test_dense_features_sharded_and_replicated_columns_in_process_world():
     off += c.dimension
   for cm in comms:
     cm.close()
+
+
+# ----------------------------------------------------------------------------------
+# aggregation of replicated gradients (allreduce bucket, allgatherv)
+@pytest.mark.parametrize('world', [2, 4])
+def test_gradient_aggregation_in_process_world(world):
+  import threading
+  rng = np.random.RandomState(50 + world)
+  shapes = [(1000, 16), (7,), (0,), (333, 5)]
+  dense = [[rng.randn(*s).astype(np.float32) for s in shapes] for _ in range(world)]
+  ints = [rng.randint(-1000, 1000, size=257).astype(np.int64) for _ in range(world)]
+  sp_vals = [rng.randn(10 + 3 * r, 8).astype(np.float32) for r in range(world)]
+  sp_idx = [rng.randint(0, 100, size=10 + 3 * r).astype(np.int64) for r in range(world)]
+  shard_g = [rng.randn(5, 4).astype(np.float32) for _ in range(world)]
+  comms = hb.distribute.Collective.local_world(world)
+  results, errors = [None] * world, []
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        c = comms[r]
+        mx = c.allreduce(dev(ints[r]), reduce_op=c.MAX)
+        grads = [dev(x) for x in dense[r]] + [(dev(sp_vals[r]), dev(sp_idx[r])), dev(shard_g[r])]
+        agg = hb.distribute.aggregate_gradients(
+          grads, c, sharded=[False] * len(shapes) + [False, True])
+        torch.cuda.current_stream().synchronize()
+        results[r] = (mx.cpu().numpy(), [a.cpu().numpy() for a in agg[:len(shapes)]],
+                      (agg[len(shapes)][0].cpu().numpy(), agg[len(shapes)][1].cpu().numpy()),
+                      agg[-1].cpu().numpy())
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((r, repr(e)))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=120)
+  assert not errors, errors
+  want_max = np.max(np.stack(ints), axis=0)
+  for r in range(world):
+    np.testing.assert_equal(results[r][0], want_max)
+    for k in range(len(shapes)):
+      acc = dense[0][k].copy()          # the transport sums in rank order, then scales
+      for q in range(1, world):
+        acc = acc + dense[q][k]
+      np.testing.assert_equal(results[r][1][k], acc * np.float32(1.0 / world))
+    np.testing.assert_equal(results[r][2][0],
+                            np.concatenate(sp_vals) * np.float32(1.0 / world))
+    np.testing.assert_equal(results[r][2][1], np.concatenate(sp_idx))
+    np.testing.assert_equal(results[r][3], shard_g[r])       # sharded: untouched
+  for cm in comms:
+    cm.close()
+
+
+def test_allreduce_allgather_through_rccl_world1():
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+  try:
+    rng = np.random.RandomState(60)
+    xs = [rng.randn(1000, 16).astype(np.float32), rng.randn(3).astype(np.float32)]
+    outs = coll.allreduce_n([dev(x) for x in xs], scale=0.5)
+    for x, o in zip(xs, outs):
+      np.testing.assert_equal(o.cpu().numpy(), x * np.float32(0.5))
+    one = coll.allreduce(dev(xs[0]))
+    np.testing.assert_equal(one.cpu().numpy(), xs[0])
+    g = coll.allgather(dev(xs[0]))
+    np.testing.assert_equal(g.cpu().numpy(), xs[0])
+    assert hb.distribute.aggregate_gradients([dev(xs[1])], coll)[0] is not None
+  finally:
+    coll.close()

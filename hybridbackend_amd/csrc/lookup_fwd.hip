@@ -15,6 +15,8 @@
 //     the owning lanes with ds_bpermute;
 //   * ids and outputs are streamed with non-temporal accesses so the L2/MALL capacity is
 //     left to the table rows.
+#include <stdlib.h>
+
 #include "lookup_common.h"
 
 namespace hbk {

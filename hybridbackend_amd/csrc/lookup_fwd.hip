@@ -186,15 +186,19 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
 template <bool CSR, typename V, bool RUNS>
 __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupArgs a) {
   const int b = (int)blockIdx.x;
-  // last column whose first tile is <= b: binary search, <= 7 dependent scalar loads
-  int ci = 0, hi = a.n_cols;
-  while (hi - ci > 1) {
-    const int mid = (ci + hi) >> 1;
-    if (a.tile_start[mid] <= b) {
-      ci = mid;
-    } else {
-      hi = mid;
-    }
+  // last column whose first tile is <= b.  A binary search over the kernel-argument table is
+  // up to 7 DEPENDENT scalar loads (each a cold miss at kernel start); here every lane reads
+  // one entry (two independent loads cover 128 columns) and a ballot counts the entries <= b:
+  // one memory round trip.
+  int ci;
+  {
+    const int lane = (int)threadIdx.x & (kWave - 1);
+    const int n = a.n_cols;
+    const int t0 = lane < n ? a.tile_start[lane] : 0x7fffffff;
+    const int t1 = lane + kWave < n ? a.tile_start[lane + kWave] : 0x7fffffff;
+    ci = (int)__builtin_popcountll(__ballot(t0 <= b)) +
+         (int)__builtin_popcountll(__ballot(t1 <= b)) - 1;
+    ci = __builtin_amdgcn_readfirstlane(ci);
   }
   const ColArg& c = a.col[ci];
   const int64_t tile = b - a.tile_start[ci];

@@ -99,16 +99,16 @@ __device__ inline uint32_t shard_of(T v, const ShardFn& f) {
 }
 
 __device__ inline int find_col(const PartArgs& a, int tile) {
-  int lo = 0, hi = a.n_cols;  // wave-uniform binary search over the kernarg descriptors
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (a.col[mid].tile_start <= tile) {
-      lo = mid;
-    } else {
-      hi = mid;
-    }
-  }
-  return lo;
+  // every lane reads one descriptor's first tile (two independent loads cover 128 columns) and a
+  // ballot counts those <= tile: one memory round trip instead of a binary search's 7 dependent
+  // scalar loads, each a cold miss at the start of these short kernels
+  const int lane = lane_id();
+  const int n = a.n_cols;
+  const int t0 = lane < n ? a.col[lane].tile_start : 0x7fffffff;
+  const int t1 = lane + kWave < n ? a.col[lane + kWave].tile_start : 0x7fffffff;
+  const int ci = (int)__builtin_popcountll(__ballot(t0 <= tile)) +
+                 (int)__builtin_popcountll(__ballot(t1 <= tile)) - 1;
+  return __builtin_amdgcn_readfirstlane(ci);
 }
 
 

@@ -135,6 +135,13 @@ def case_cfg4(big):
   report(f'cfg4 fwd Zipf(1.2) dim128 B={B} big_rows={rows[-1]}', us, 26 * B,
          26 * B * (8 + 512 + 512), unique_rows=uniq,
          dedup_aware_GBps=round((26 * B * (8 + 512) + uniq * 512) / us / 1e3, 1))
+  # the store-bound floor of this shape: every id the same row (all row reads hit L1)
+  same = [torch.zeros(B, dtype=torch.int64, device=DEV) for _ in range(26)]
+  gl = hb.embedding.GroupLookup(tables, None, 'sum')
+  gl.bind(same, None, outs)
+  us = timed(lambda i: gl.launch(), iters=20)
+  report(f'cfg4 fwd dim128 B={B}, one row per column (output stores only)', us, 26 * B,
+         26 * B * (8 + 512))
   grad = hb.embedding.GroupLookupGrad(lookup)
   gouts = [torch.randn(B, dim, device=DEV) for _ in range(26)]
   for lr, tag in ((0.0, 'IndexedSlices only'), (0.01, 'fused SGD apply')):

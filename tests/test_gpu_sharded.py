@@ -465,3 +465,68 @@ def test_allreduce_allgather_through_rccl_world1():
     assert hb.distribute.aggregate_gradients([dev(xs[1])], coll)[0] is not None
   finally:
     coll.close()
+
+
+def test_cxx_driver_empty_ranks_and_columns_in_process_world():
+  """Edge cases of the sharded step: a rank with no ids at all, a column nobody looks up, a
+  column whose ids all belong to one owner (the other owner gets empty messages), empty ragged
+  segments -- forward and backward must still agree with the unsharded oracle."""
+  import threading
+  world = 2
+  rng = np.random.RandomState(77)
+  dims, rows = [16, 8, 4], [1001, 64, 10]
+  combiners = ['sum', 'mean', 'sum']
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(3)]
+  # rank 0: nothing at all; rank 1: column 0 only even ids (owner 0), column 1 ragged with empty
+  # segments, column 2 empty
+  sp1 = np.array([0, 0, 3, 3, 3, 7, 7], np.int32)
+  ids = [[np.zeros(0, np.int64)] * 3,
+         [(rng.randint(0, 500, size=777) * 2).astype(np.int64),
+          rng.randint(0, 2**40, size=7).astype(np.int64), np.zeros(0, np.int64)]]
+  splits = [[None, np.zeros(1, np.int32), None], [None, sp1, None]]
+  grads = [[np.zeros((0, 16), np.float32), np.zeros((0, 8), np.float32),
+            np.zeros((0, 4), np.float32)],
+           [rng.randn(777, 16).astype(np.float32), rng.randn(6, 8).astype(np.float32),
+            np.zeros((0, 4), np.float32)]]
+  comms = hb.distribute.Collective.local_world(world)
+  results, errors = [None] * world, []
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        drv = ShardedGroupLookup([dev(t[r::world].copy()) for t in tables], comms[r],
+                                 buckets=rows, combiners=combiners)
+        outs = drv([dev(i) for i in ids[r]], [None if s is None else dev(s) for s in splits[r]])
+        sl = drv.backward([dev(g) for g in grads[r]])
+        torch.cuda.current_stream().synchronize()
+        results[r] = ([o.cpu().numpy() for o in outs],
+                      [(u.cpu().numpy()[:int(k.item())], g.cpu().numpy()[:int(k.item())])
+                       for u, g, k in sl])
+        drv.close()
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((r, repr(e)))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=120)
+  assert not errors, errors
+  for r in range(world):
+    want = oracle.group_lookup_fwd(tables, ids[r], splits[r], rows, combiners)
+    for c in range(3):
+      np.testing.assert_equal(results[r][0][c], want[c])
+  for c in range(3):
+    dense = np.zeros((rows[c], dims[c]), np.float64)
+    got = np.zeros_like(dense)
+    for r in range(world):
+      sp = splits[r][c] if splits[r][c] is not None else np.arange(ids[r][c].size + 1,
+                                                                   dtype=np.int32)
+      g_id = oracle.segment_combine_grad(grads[r][c], sp, combiners[c]).astype(np.float64)
+      np.add.at(dense, ids[r][c] % rows[c], g_id)
+      lr_, g_ = results[r][1][c]
+      got[lr_ * world + r] += g_
+    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-6)
+  assert results[1][1][0][0].size == 0          # owner 1 got no row of column 0
+  for cm in comms:
+    cm.close()

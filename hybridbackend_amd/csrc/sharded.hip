@@ -384,8 +384,12 @@ int exchange(hbk_sharded* p, int32_t dtype, int32_t wire, const void* in, const 
                           wire_ws, wire_ws_bytes, stream, before, after);
 }
 
-// test hook / tuning knob: number of column groups the forward pipelines (default 2)
-int pipeline_groups(int n_cols) {
+// Number of column groups the step pipelines.  More groups hide more of the gather / stitch
+// behind the exchanges (exposed compute ~ 1/G of it) at the price of G x more launches and
+// smaller kernels: measured on one rank 298 us (G = 1), 318 us (G = 2), 455 us (G = 4) per
+// forward step.  2 until an 8-GPU measurement says otherwise; HBK_SHARDED_GROUPS overrides (1..4).
+int pipeline_groups(int n_cols, int world) {
+  (void)world;
   int g = 2;
   const char* e = getenv("HBK_SHARDED_GROUPS");
   if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 4) g = atoi(e);
@@ -466,7 +470,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   // ids of group g+1 are on the wire, and stitches group g while the rows of group g+1 travel:
   //   comm    : ids(0) ids(1) ...            rows(0)      rows(1) ...
   //   compute : pack(0..G-1)      gather(0)  gather(1) ..      stitch(0)   stitch(1)
-  const int G = pipeline_groups(N);
+  const int G = pipeline_groups(N, W);
   std::vector<Group>& groups = p->groups;
   groups.assign(G, Group());
   int64_t tot_req_ids = 0, tot_own_ids = 0, tot_own_floats = 0, tot_req_floats = 0;

@@ -19,9 +19,11 @@
 // Buffers whose size depends on what the peers send (known only after the size exchange)
 // are owned by the plan and grow on demand (hipMalloc, never shrinks); everything else is
 // caller-owned as usual.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 #include "common.h"
@@ -278,7 +280,7 @@ struct hbk_sharded {
   // device buffers owned by the plan
   hbk::Buffer ids_bucketized, part_out, shard_index, sizes_dev, part_ws, send_ids, recv_ids,
       send_rows, recv_rows, wire_ws, bwd_ws, runs_dev;
-  int32_t* host_sizes;  // pinned [2][N*W]
+  int32_t* host_sizes;  // pinned [3][N*W]: S, S^T, R as they sit on the device
   int64_t* host_runs;   // pinned [5][N*W], column-major: run starts / bases of the stitch, then
                         // run starts / id offsets / gradient offsets of the owner-side backward
 };
@@ -324,7 +326,7 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
     }
   }
   if (hipHostMalloc(reinterpret_cast<void**>(&p->host_sizes),
-                    sizeof(int32_t) * 2 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
+                    sizeof(int32_t) * 3 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
           hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&p->host_runs),
                     sizeof(int64_t) * 5 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
@@ -422,6 +424,13 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     total += n_ids[c];
   }
   int rc;
+  // HBK_SHARDED_TRACE=1: host-side time of the step's phases on stderr (us)
+  const bool trace = getenv("HBK_SHARDED_TRACE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto us_since = [](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  };
+  const auto t_begin = now();
   // ---- 1 bucketize + stable partition (one kernel chain; S and S^T come out of the scan) ------
   if ((rc = p->part_out.ensure((size_t)total * 8 + 8)) != HBK_OK) return rc;
   if ((rc = p->shard_index.ensure((size_t)total * 4 + 8)) != HBK_OK) return rc;
@@ -455,13 +464,14 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     rc = hbk_alltoall_n(p->comm, 1, HBK_INT32, HBK_TOPOLOGY_ALL, sin, cnt, sout, stream_);
     if (rc != HBK_OK) return rc;
   }
-  HBK_HIP_OK(hipMemcpyAsync(p->host_sizes, sizes_dev, sizeof(int32_t) * N * W,
+  // S, S^T and R sit back to back: one copy brings S and R to the host
+  HBK_HIP_OK(hipMemcpyAsync(p->host_sizes, sizes_dev, sizeof(int32_t) * 3 * N * W,
                             hipMemcpyDeviceToHost, stream));
-  HBK_HIP_OK(hipMemcpyAsync(p->host_sizes + (size_t)N * W, recv_t, sizeof(int32_t) * N * W,
-                            hipMemcpyDeviceToHost, stream));
+  const double t_enq1 = us_since(t_begin);
   HBK_HIP_OK(hipStreamSynchronize(stream));
+  const double t_sync = us_since(t_begin);
   p->send_sizes.assign(p->host_sizes, p->host_sizes + (size_t)N * W);
-  p->recv_sizes.assign(p->host_sizes + (size_t)N * W, p->host_sizes + 2 * (size_t)N * W);
+  p->recv_sizes.assign(p->host_sizes + 2 * (size_t)N * W, p->host_sizes + 3 * (size_t)N * W);
   const int32_t* S = p->send_sizes.data();
   const int32_t* R = p->recv_sizes.data();
   // ---- 3..6 pipelined over column groups ------------------------------------------------------
@@ -557,11 +567,12 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     HBK_HIP_OK(hipMemcpyAsync(p->runs_dev.ptr, p->host_runs, sizeof(int64_t) * 5 * (size_t)N * W,
                               hipMemcpyHostToDevice, stream));
   }
-  // stage A: pack the ids of every group peer-major
+  // stage A: pack the ids of every group peer-major (one launch for all groups)
+  std::vector<Seg> segs;
+  segs.reserve((size_t)N * W);
   for (int g = 0; g < G; ++g) {
     const Group& gr = groups[g];
     const int ng = gr.c1 - gr.c0;
-    std::vector<Seg> segs;
     for (int q = 0; q < W; ++q) {
       for (int c = 0; c < ng; ++c) {
         segs.push_back(make_seg(
@@ -570,15 +581,15 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
             (int64_t)S[(size_t)(gr.c0 + c) * W + q] * 8, p->id32 ? 1 : 0));
       }
     }
-    if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
-    HBK_HIP_OK(hipEventRecord(p->ev[0][g], stream));
   }
+  if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
+  HBK_HIP_OK(hipEventRecord(p->ev[0][0], stream));
   // stage B: ids exchanges, back to back on the communicator's stream
   for (int g = 0; g < G; ++g) {
     const Group& gr = groups[g];
     rc = exchange(p, id_dtype, id_dtype, ids_send_base + gr.id_send * id_bytes,
                   gr.lay.ids_send_peer.data(), ids_recv_base + gr.id_recv * id_bytes,
-                  gr.lay.ids_recv_peer.data(), stream_, p->ev[0][g], p->ev[1][g]);
+                  gr.lay.ids_recv_peer.data(), stream_, p->ev[0][0], p->ev[1][g]);
     if (rc != HBK_OK) return rc;
   }
   // stage C: owner gather of group g as soon as its ids are in (N_g * W virtual columns, straight
@@ -651,6 +662,11 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     if (rc != HBK_OK) return rc;
   }
   p->have_step = true;
+  if (trace) {
+    fprintf(stderr, "hbk_sharded_lookup_fwd host us: enqueue partition+sizes %.1f, sync wait %.1f, "
+                    "enqueue rest %.1f (G = %d, W = %d)\n",
+            t_enq1, t_sync - t_enq1, us_since(t_begin) - t_sync, G, W);
+  }
   return HBK_OK;
 }
 

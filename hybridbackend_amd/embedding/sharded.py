@@ -43,6 +43,11 @@ class _Step:
       setattr(self, s, None)
 
 
+class _BoundStep:
+  """One step's tensors marshalled for hbk_sharded_lookup_fwd (ShardedGroupLookup.bind)."""
+  __slots__ = ('keep', 'outs', 'args')
+
+
 class ShardedGroupLookup:
   """N row-sharded embedding tables looked up together.
 
@@ -142,11 +147,11 @@ class ShardedGroupLookup:
       self._lib.hbk_sharded_destroy(self._plan_handle)
       self._plan_handle = None
 
-  def __call__(self, ids, row_splits=None, outs=None):
-    """One forward step through the communicator.  ``ids[c]``: int64 device vector;
-    ``row_splits[c]``: int32 device vector or None.  Returns the per-column outputs."""
+  def bind(self, ids, row_splits=None, outs=None):
+    """Validate one step's tensors and marshal them into the C-ABI argument arrays once; the
+    returned object can be launched any number of times (``launch``) at the cost of a single
+    foreign call -- what a training loop with resident input batches does (bench.py)."""
     n = len(self.shards)
-    plan = self._plan()
     if row_splits is None:
       row_splits = [None] * n
     n_seg = []
@@ -166,16 +171,28 @@ class ShardedGroupLookup:
       if outs[c].dtype != torch.float32 or tuple(outs[c].shape) != (n_seg[c], self.dims[c]):
         raise _lib.InvalidArgumentError(
           _lib.INVALID_ARGUMENT, f'output {c} must be fp32 [{n_seg[c]}, {self.dims[c]}]')
-    self._keep = (ids, row_splits, outs)
+    bound = _BoundStep()
+    bound.keep = (ids, row_splits, outs)
+    bound.outs = outs
     # column blocks of one wider tensor are written in place (row stride != dim)
-    strides = (C.c_int32 * n)(*[0 if o.is_contiguous() else int(o.stride(0)) for o in outs])
-    _lib.check(self._lib.hbk_sharded_lookup_fwd(
-      plan, _lib.ptr_array([t.data_ptr() for t in ids]),
-      _lib.i64_array([t.numel() for t in ids]),
+    bound.args = (
+      _lib.ptr_array([t.data_ptr() for t in ids]), _lib.i64_array([t.numel() for t in ids]),
       _lib.ptr_array([None if s is None else s.data_ptr() for s in row_splits]),
-      _lib.i64_array(n_seg), _lib.ptr_array([o.data_ptr() for o in outs]), strides,
-      _lib.current_stream(self.device)))
-    return outs
+      _lib.i64_array(n_seg), _lib.ptr_array([o.data_ptr() for o in outs]),
+      (C.c_int32 * n)(*[0 if o.is_contiguous() else int(o.stride(0)) for o in outs]))
+    return bound
+
+  def launch(self, bound):
+    """Enqueue a bound step on the current stream; returns its outputs."""
+    self._keep = bound.keep
+    _lib.check(self._lib.hbk_sharded_lookup_fwd(
+      self._plan(), *bound.args, _lib.current_stream(self.device)))
+    return bound.outs
+
+  def __call__(self, ids, row_splits=None, outs=None):
+    """One forward step through the communicator.  ``ids[c]``: int64 device vector;
+    ``row_splits[c]``: int32 device vector or None.  Returns the per-column outputs."""
+    return self.launch(self.bind(ids, row_splits, outs))
 
   # ---- backward (SURVEY 3.4) -----------------------------------------------------------------
   # phase B1: d(stitch + combiner): per-id gradient rows in the order of the partitioned ids

@@ -2,6 +2,7 @@
 custom-op surface.  Only the hot path of SURVEY.md section 8 lives here:
 ``csrc/`` (gfx950 HIP kernels + RCCL communicator + the C ABI of include/hbk.h) and the
 host-side mirror of the reference's Python interface for that path."""
+from hybridbackend_amd import data
 from hybridbackend_amd import distribute
 from hybridbackend_amd import embedding
 from hybridbackend_amd import feature_column

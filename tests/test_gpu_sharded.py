@@ -530,3 +530,36 @@ def test_cxx_driver_empty_ranks_and_columns_in_process_world():
   assert results[1][1][0][0].size == 0          # owner 1 got no row of column 0
   for cm in comms:
     cm.close()
+
+
+# ----------------------------------------------------------------------------------
+# config 1 made real: ParquetDataset -> values + row_splits in HBM -> fused lookup
+def test_parquet_to_dense_features(tmp_path):
+  pa = pytest.importorskip('pyarrow')
+  pq = pytest.importorskip('pyarrow.parquet')
+  rng = np.random.RandomState(90)
+  n = 5000
+  scalar = rng.randint(0, 2**40, size=n)
+  lists = [rng.randint(0, 2**40, size=rng.randint(0, 9)).tolist() for _ in range(n)]
+  path = str(tmp_path / 'day-0.parquet')
+  pq.write_table(pa.table({'uid': pa.array(scalar, pa.int64()),
+                           'clicks': pa.array(lists, pa.list_(pa.int64()))}),
+                 path, row_group_size=1024)
+  cols = [hb.feature_column.EmbeddingColumn('uid', 100003, 16, 'sum'),
+          hb.feature_column.EmbeddingColumn('clicks', 1000000, 16, 'mean')]   # config 1's table
+  tables = [rng.uniform(-1e-3, 1e-3, size=(c.num_buckets, c.dimension)).astype(np.float32)
+            for c in cols]
+  layer = hb.feature_column.DenseFeatures(
+    cols, DEV, init=lambda c, rows, d: dev(tables[cols.index(c)]))
+  seen = 0
+  for batch in hb.data.ParquetDataset(path, 777, device=DEV):
+    out = layer(batch).cpu().numpy()
+    k = out.shape[0]
+    ids = [scalar[seen:seen + k], np.array(sum(lists[seen:seen + k], []), np.int64)]
+    lens = [len(x) for x in lists[seen:seen + k]]
+    sps = [None, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)]
+    want = oracle.group_lookup_fwd(tables, ids, sps, [c.num_buckets for c in cols],
+                                   [c.combiner for c in cols])
+    np.testing.assert_equal(out, np.concatenate(want, axis=1))
+    seen += k
+  assert seen == n

@@ -109,7 +109,7 @@ class GroupLookup:
       col.n_segments = n_seg
       col.out = o.data_ptr()
       # a column block of a wider [segments, sum of dims] tensor is written in place
-      if o.stride(1) != 1 and o.shape[1] > 1:
+      if not o.is_contiguous() and o.stride(1) != 1 and o.shape[1] > 1:
         raise _lib.InvalidArgumentError(
           _lib.INVALID_ARGUMENT, f'output {c} must be contiguous along its last dimension')
       col.out_stride = 0 if o.is_contiguous() else int(o.stride(0))
@@ -174,8 +174,10 @@ class GroupLookupGrad:
     if getattr(self, '_out_key', None) != counts:
       # three allocations for all columns, carved into per-column views
       self._urows = torch.empty(sum(counts), dtype=torch.int64, device=dev)
-      self._grows = torch.empty(sum(k * d for k, d in zip(counts, dims)), dtype=torch.float32,
-                                device=dev)
+      # every column's block starts on a 16-byte boundary whatever the dims before it
+      pad4 = lambda x: (x + 3) // 4 * 4   # noqa: E731
+      self._grows = torch.empty(sum(pad4(k * d) for k, d in zip(counts, dims)) + 4,
+                                dtype=torch.float32, device=dev)
       self._nu = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
       self._out_key = counts
       self._views = []
@@ -185,7 +187,7 @@ class GroupLookupGrad:
         self._views.append((self._urows[o_r:o_r + k],
                             self._grows[o_g:o_g + k * d].view(k, d), self._nu[c:c + 1]))
         o_r += k
-        o_g += k * d
+        o_g += pad4(k * d)
     for c in range(n):
       i, g, s = ids[c], grads[c], row_splits[c]
       _lib.require_device_tensor(i, 'ids')
@@ -202,7 +204,7 @@ class GroupLookupGrad:
       col.row_splits = s.data_ptr() if s is not None else None
       col.n_segments = n_seg
       col.grad_out = g.data_ptr()
-      if g.stride(1) != 1 and g.shape[1] > 1:
+      if not g.is_contiguous() and g.stride(1) != 1 and g.shape[1] > 1:
         raise _lib.InvalidArgumentError(
           _lib.INVALID_ARGUMENT, f'grad {c} must be contiguous along its last dimension')
       col.grad_stride = 0 if g.is_contiguous() else int(g.stride(0))

@@ -1,0 +1,116 @@
+"""Randomised parity: hypothesis draws shapes, dims, id distributions, combiners and ragged
+layouts; the fused lookup, its backward and the stable partition must agree with the CPU oracle
+on every draw (bit-exact integers and in-order fp32 sums, 1e-5 against float64 for the backward)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+hypothesis = pytest.importorskip('hypothesis')
+from hypothesis import HealthCheck, given, settings  # noqa: E402
+from hypothesis import strategies as st  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(x):
+  return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+column = st.fixed_dictionaries({
+  'dim': st.sampled_from([1, 3, 4, 6, 8, 16, 20, 32, 64, 128, 256]),
+  'rows': st.sampled_from([1, 2, 7, 64, 1000, 65537]),
+  'n_seg': st.integers(0, 700),
+  'ragged': st.booleans(),
+  'max_len': st.integers(0, 9),
+  'combiner': st.sampled_from(['sum', 'mean', 'sqrtn']),
+  'skew': st.sampled_from(['uniform', 'zipf', 'one', 'negative', 'int32']),
+})
+
+
+def _ids(rng, n, rows, skew):
+  if skew == 'zipf':
+    return (rng.zipf(1.3, size=n) % (4 * rows)).astype(np.int64)
+  if skew == 'one':
+    return np.full(n, 3, np.int64)
+  if skew == 'negative':
+    return rng.randint(-2**40, 2**40, size=n).astype(np.int64)
+  if skew == 'int32':
+    return rng.randint(-2**31, 2**31 - 1, size=n).astype(np.int32)
+  return rng.randint(0, 2**40, size=n).astype(np.int64)
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+@given(cols=st.lists(column, min_size=1, max_size=6), seed=st.integers(0, 2**31 - 1))
+def test_group_lookup_forward_backward_random(cols, seed):
+  import oracle
+  import hybridbackend_amd as hb
+  rng = np.random.RandomState(seed)
+  tables, ids, splits, buckets, combs, grads = [], [], [], [], [], []
+  for c in cols:
+    if c['dim'] % 4 != 0 and c['dim'] > 64:
+      c = dict(c, dim=64)
+    tables.append(rng.uniform(-1, 1, size=(c['rows'], c['dim'])).astype(np.float32))
+    if c['ragged']:
+      lens = rng.randint(0, c['max_len'] + 1, size=c['n_seg'])
+      sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+      n = int(sp[-1])
+    else:
+      sp, n = None, c['n_seg']
+    splits.append(sp)
+    ids.append(_ids(rng, n, c['rows'], c['skew']))
+    buckets.append(c['rows'])
+    combs.append(c['combiner'])
+    grads.append(rng.randn(c['n_seg'], c['dim']).astype(np.float32))
+  # hbk_group_lookup_* take one ids dtype per column; the Python wrapper one per call
+  if any(i.dtype == np.int32 for i in ids):
+    ids = [np.asarray(i, np.int64) for i in ids]
+  lookup = hb.embedding.GroupLookup([dev(t) for t in tables], buckets, combs)
+  d_ids = [dev(i) for i in ids]
+  d_sp = [None if s is None else dev(s) for s in splits]
+  outs = lookup(d_ids, d_sp)
+  want = oracle.group_lookup_fwd(tables, ids, splits, buckets, combs)
+  for o, w in zip(outs, want):
+    np.testing.assert_equal(o.cpu().numpy(), w)
+  res = hb.embedding.GroupLookupGrad(lookup)(d_ids, [dev(g) for g in grads], d_sp)
+  for k in range(len(cols)):
+    rows = np.asarray(ids[k], np.int64) % buckets[k]
+    sp = splits[k] if splits[k] is not None else np.arange(rows.size + 1, dtype=np.int32)
+    g_id = oracle.segment_combine_grad(grads[k], sp, combs[k]).astype(np.float64)
+    dense = np.zeros(tables[k].shape, np.float64)
+    np.add.at(dense, rows, g_id)
+    u, g, nu = res[k]
+    n = int(nu.item())
+    got_rows = u.cpu().numpy()[:n]
+    assert len(set(got_rows.tolist())) == n and n == np.unique(rows).size
+    got = np.zeros_like(dense)
+    got[got_rows] = g.cpu().numpy()[:n]
+    scale = max(1.0, float(np.abs(dense).max()))
+    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5 * scale)
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+@given(lens=st.lists(st.integers(0, 5000), min_size=1, max_size=5),
+       P=st.sampled_from([1, 2, 3, 7, 8, 9, 16, 33, 64, 65, 300]),
+       dtype=st.sampled_from([np.int32, np.int64, np.uint32, np.uint64]),
+       seed=st.integers(0, 2**31 - 1))
+def test_partition_random(lens, P, dtype, seed):
+  import oracle
+  import hybridbackend_amd as hb
+  if dtype in (np.uint32, np.uint64) and not hasattr(torch, 'uint64'):
+    dtype = np.int64
+  rng = np.random.RandomState(seed)
+  info = np.iinfo(dtype)
+  xs = [rng.randint(info.min, info.max, size=n, dtype=dtype) for n in lens]
+  outs, sizes, idxs = hb.distribute.partition_by_modulo_n([dev(x) for x in xs], P)
+  for x, o, s, i in zip(xs, outs, sizes, idxs):
+    wo, ws, wi = oracle.partition_by_modulo(x, P)
+    np.testing.assert_equal(o.cpu().numpy(), wo)
+    np.testing.assert_equal(s.cpu().numpy(), ws)
+    np.testing.assert_equal(i.cpu().numpy(), wi)

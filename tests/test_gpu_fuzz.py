@@ -114,3 +114,95 @@ def test_partition_random(lens, P, dtype, seed):
     np.testing.assert_equal(o.cpu().numpy(), wo)
     np.testing.assert_equal(s.cpu().numpy(), ws)
     np.testing.assert_equal(i.cpu().numpy(), wi)
+
+
+sharded_column = st.fixed_dictionaries({
+  'dim': st.sampled_from([4, 6, 8, 16, 20, 64, 128]),
+  'rows': st.sampled_from([3, 64, 1000, 50021]),
+  'ragged': st.booleans(),
+  'combiner': st.sampled_from(['sum', 'mean', 'sqrtn']),
+})
+
+
+@settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck))
+@given(world=st.sampled_from([2, 3, 5]), cols=st.lists(sharded_column, min_size=1, max_size=5),
+       wire16=st.booleans(), seed=st.integers(0, 2**31 - 1))
+def test_sharded_driver_random_in_process_world(world, cols, wire16, seed):
+  """hbk_sharded_lookup_fwd/_bwd with W in-process ranks (W not a power of two included), random
+  columns, some ranks / columns empty: forward == unsharded oracle, backward == dense
+  scatter-add."""
+  import threading
+  import oracle
+  import hybridbackend_amd as hb
+  from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
+  rng = np.random.RandomState(seed)
+  n = len(cols)
+  dims = [c['dim'] for c in cols]
+  rows = [max(c['rows'], world) for c in cols]   # every rank owns at least one row
+  combs = [c['combiner'] for c in cols]
+  tables = [rng.uniform(-1, 1, size=(rows[k], dims[k])).astype(np.float32) for k in range(n)]
+  ids, splits, grads = [], [], []
+  for r in range(world):
+    ri, rs, rg = [], [], []
+    for k, c in enumerate(cols):
+      n_seg = int(rng.choice([0, 1, 77, 600]))
+      if c['ragged']:
+        lens = rng.randint(0, 6, size=n_seg)
+        sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        cnt = int(sp[-1])
+      else:
+        sp, cnt = None, n_seg
+      rs.append(sp)
+      ri.append(rng.randint(0, 2**40, size=cnt).astype(np.int64))
+      rg.append(rng.randn(n_seg, dims[k]).astype(np.float32))
+    ids.append(ri)
+    splits.append(rs)
+    grads.append(rg)
+  comms = hb.distribute.Collective.local_world(world)
+  shards = [[dev(t[r::world].copy()) for t in tables] for r in range(world)]
+  results, errors = [None] * world, []
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        drv = ShardedGroupLookup(shards[r], comms[r], buckets=rows, combiners=combs,
+                                 wire_dtype=torch.float16 if wire16 else None)
+        outs = drv([dev(i) for i in ids[r]], [None if s is None else dev(s) for s in splits[r]])
+        sl = drv.backward([dev(g) for g in grads[r]])
+        torch.cuda.current_stream().synchronize()
+        results[r] = ([o.cpu().numpy() for o in outs],
+                      [(u.cpu().numpy()[:int(k.item())], g.cpu().numpy()[:int(k.item())])
+                       for u, g, k in sl])
+        drv.close()
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((r, repr(e)))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=120)
+  for cm in comms:
+    cm.close()
+  assert not errors, errors
+  eff, tol = tables, dict(rtol=1e-5, atol=1e-5)
+  if wire16:
+    eff = [oracle.cast_f16_to_f32(oracle.cast_f32_to_f16(t)) for t in tables]
+    tol = dict(rtol=3e-3, atol=3e-3)
+  for r in range(world):
+    want = oracle.group_lookup_fwd(eff, ids[r], splits[r], rows, combs)
+    for k in range(n):
+      np.testing.assert_equal(results[r][0][k], want[k])
+  for k in range(n):
+    dense = np.zeros((rows[k], dims[k]), np.float64)
+    got = np.zeros_like(dense)
+    for r in range(world):
+      sp = splits[r][k] if splits[r][k] is not None else np.arange(ids[r][k].size + 1,
+                                                                   dtype=np.int32)
+      g_id = oracle.segment_combine_grad(grads[r][k], sp, combs[k]).astype(np.float64)
+      np.add.at(dense, ids[r][k] % rows[k], g_id)
+      lr_, g_ = results[r][1][k]
+      assert len(set(lr_.tolist())) == len(lr_)
+      got[lr_ * world + r] += g_
+    scale = max(1.0, float(np.abs(dense).max()))
+    np.testing.assert_allclose(got, dense, rtol=tol['rtol'], atol=tol['atol'] * scale)

@@ -46,7 +46,8 @@ def _ids(rng, n, rows, skew):
   return rng.randint(0, 2**40, size=n).astype(np.int64)
 
 
-@settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=30, deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
 @given(cols=st.lists(column, min_size=1, max_size=6), seed=st.integers(0, 2**31 - 1))
 def test_group_lookup_forward_backward_random(cols, seed):
   import oracle
@@ -95,7 +96,8 @@ def test_group_lookup_forward_backward_random(cols, seed):
     np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5 * scale)
 
 
-@settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=30, deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
 @given(lens=st.lists(st.integers(0, 5000), min_size=1, max_size=5),
        P=st.sampled_from([1, 2, 3, 7, 8, 9, 16, 33, 64, 65, 300]),
        dtype=st.sampled_from([np.int32, np.int64, np.uint32, np.uint64]),
@@ -124,7 +126,8 @@ sharded_column = st.fixed_dictionaries({
 })
 
 
-@settings(max_examples=12, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=12, deadline=None, derandomize=True, database=None,
+          suppress_health_check=list(HealthCheck))
 @given(world=st.sampled_from([2, 3, 5]), cols=st.lists(sharded_column, min_size=1, max_size=5),
        wire16=st.booleans(), seed=st.integers(0, 2**31 - 1))
 def test_sharded_driver_random_in_process_world(world, cols, wire16, seed):

@@ -17,6 +17,14 @@ from hypothesis import strategies as st  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+# the committed runs are deterministic; HBK_FUZZ_RANDOM=1 HBK_FUZZ_SCALE=10 hunts with fresh draws
+_RANDOM = os.environ.get('HBK_FUZZ_RANDOM') == '1'
+_SCALE = int(os.environ.get('HBK_FUZZ_SCALE', '1'))
+
+
+def _cfg(n):
+  return settings(max_examples=n * _SCALE, deadline=None, derandomize=not _RANDOM, database=None,
+                  suppress_health_check=list(HealthCheck))
 
 
 def dev(x):
@@ -46,8 +54,7 @@ def _ids(rng, n, rows, skew):
   return rng.randint(0, 2**40, size=n).astype(np.int64)
 
 
-@settings(max_examples=30, deadline=None, derandomize=True, database=None,
-          suppress_health_check=list(HealthCheck))
+@_cfg(30)
 @given(cols=st.lists(column, min_size=1, max_size=6), seed=st.integers(0, 2**31 - 1))
 def test_group_lookup_forward_backward_random(cols, seed):
   import oracle
@@ -96,8 +103,7 @@ def test_group_lookup_forward_backward_random(cols, seed):
     np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5 * scale)
 
 
-@settings(max_examples=30, deadline=None, derandomize=True, database=None,
-          suppress_health_check=list(HealthCheck))
+@_cfg(30)
 @given(lens=st.lists(st.integers(0, 5000), min_size=1, max_size=5),
        P=st.sampled_from([1, 2, 3, 7, 8, 9, 16, 33, 64, 65, 300]),
        dtype=st.sampled_from([np.int32, np.int64, np.uint32, np.uint64]),
@@ -126,8 +132,7 @@ sharded_column = st.fixed_dictionaries({
 })
 
 
-@settings(max_examples=12, deadline=None, derandomize=True, database=None,
-          suppress_health_check=list(HealthCheck))
+@_cfg(12)
 @given(world=st.sampled_from([2, 3, 5]), cols=st.lists(sharded_column, min_size=1, max_size=5),
        wire16=st.booleans(), seed=st.integers(0, 2**31 - 1))
 def test_sharded_driver_random_in_process_world(world, cols, wire16, seed):

@@ -99,8 +99,10 @@ def test_group_lookup_forward_backward_random(cols, seed):
     assert len(set(got_rows.tolist())) == n and n == np.unique(rows).size
     got = np.zeros_like(dense)
     got[got_rows] = g.cpu().numpy()[:n]
-    scale = max(1.0, float(np.abs(dense).max()))
-    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5 * scale)
+    # fp32 sums in an order that is not fixed: 1e-5 relative to the magnitude of the summed terms
+    mag = np.zeros_like(dense)
+    np.add.at(mag, rows, np.abs(g_id))
+    assert np.all(np.abs(got - dense) <= 1e-5 * np.maximum(mag, 1e-30) + 1e-12)
 
 
 @_cfg(30)
@@ -212,5 +214,13 @@ def test_sharded_driver_random_in_process_world(world, cols, wire16, seed):
       lr_, g_ = results[r][1][k]
       assert len(set(lr_.tolist())) == len(lr_)
       got[lr_ * world + r] += g_
-    scale = max(1.0, float(np.abs(dense).max()))
-    np.testing.assert_allclose(got, dense, rtol=tol['rtol'], atol=tol['atol'] * scale)
+    mag = np.zeros_like(dense)
+    for r in range(world):
+      sp = splits[r][k] if splits[r][k] is not None else np.arange(ids[r][k].size + 1,
+                                                                   dtype=np.int32)
+      np.add.at(mag, ids[r][k] % rows[k],
+                np.abs(oracle.segment_combine_grad(grads[r][k], sp, combs[k]).astype(np.float64)))
+    # fp16 wire: terms below the fp16 normal range (6e-5) carry an absolute error of one
+    # denormal step (6e-8) each
+    floor = 1e-5 if wire16 else 1e-12
+    assert np.all(np.abs(got - dense) <= tol['rtol'] * np.maximum(mag, 1e-30) + floor)

@@ -54,7 +54,7 @@ def _ids(rng, n, rows, skew):
   return rng.randint(0, 2**40, size=n).astype(np.int64)
 
 
-@_cfg(30)
+@_cfg(80)
 @given(cols=st.lists(column, min_size=1, max_size=6), seed=st.integers(0, 2**31 - 1))
 def test_group_lookup_forward_backward_random(cols, seed):
   import oracle
@@ -105,7 +105,7 @@ def test_group_lookup_forward_backward_random(cols, seed):
     assert np.all(np.abs(got - dense) <= 1e-5 * np.maximum(mag, 1e-30) + 1e-12)
 
 
-@_cfg(30)
+@_cfg(80)
 @given(lens=st.lists(st.integers(0, 5000), min_size=1, max_size=5),
        P=st.sampled_from([1, 2, 3, 7, 8, 9, 16, 33, 64, 65, 300]),
        dtype=st.sampled_from([np.int32, np.int64, np.uint32, np.uint64]),
@@ -134,7 +134,7 @@ sharded_column = st.fixed_dictionaries({
 })
 
 
-@_cfg(12)
+@_cfg(24)
 @given(world=st.sampled_from([2, 3, 5]), cols=st.lists(sharded_column, min_size=1, max_size=5),
        wire16=st.booleans(), seed=st.integers(0, 2**31 - 1))
 def test_sharded_driver_random_in_process_world(world, cols, wire16, seed):

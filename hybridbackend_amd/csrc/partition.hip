@@ -58,7 +58,7 @@ struct PartArgs {
   int32_t n_cols;
   int32_t total_tiles;
   int32_t sub_tiles;     // 1024-id passes per wave: a tile is sub_tiles * 1024 ids
-  int32_t pad0_;
+  int32_t fixed_max;     // P <= fixed_max: one ballot per shard (default 8; HBK_PART_FIXED tunes)
   int32_t* hist;  // [sum over columns of P * tiles_c]; column c starts at P * tile_start[c]
   int32_t* sizes_t;      // optional [P][n_total_cols] transposed copy of the sizes
   int32_t n_total_cols;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a)
   const bool small_p = P <= kWave;
   int nbits = 1;
   while ((1 << nbits) < P) ++nbits;
-  const int fixed_max = a.pad0_;   // tuning hook: P <= fixed_max takes the ballot-per-shard path
+  const int fixed_max = a.fixed_max;
   int32_t cnt = 0;  // P <= 64: lane p counts the ids of shard p in this tile
   if (!small_p) {
     for (int p = lane; p < P; p += kWave) counters[p] = 0;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
   int32_t my_run = 0;
   int nbits = 1;
   while ((1 << nbits) < P) ++nbits;
-  const int fixed_max = a.pad0_;
+  const int fixed_max = a.fixed_max;
   if (P <= kWave) {
     my_run = lane < P ? hist[(int64_t)lane * n_tiles + ctile] : 0;
   } else {
@@ -524,7 +524,7 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
     args.sizes_t = sizes_t;
     args.n_total_cols = n_cols;
     args.pad_ = 0;
-    args.pad0_ = getenv("HBK_PART_FIXED") ? atoi(getenv("HBK_PART_FIXED")) : 8;
+    args.fixed_max = getenv("HBK_PART_FIXED") ? atoi(getenv("HBK_PART_FIXED")) : 8;
     args.sub_tiles = sub;
     int32_t k = 0;
     int64_t tiles = 0;

@@ -309,10 +309,10 @@ def test_unique_table_overflow_is_still_exact(monkeypatch):
 def test_dense_block_forward_in_place(ids_dtype):
   """Adjacent column blocks of one [batch, pitch] tensor written in place (out_stride) give
   exactly what separate outputs give, including ids outside the table (zero rows), a padded
-  pitch (never touched) and a batch that fills no tile evenly.  (An output-major kernel with
-  whole-line stores was tried for this shape: 84 us against 63 us for the per-column kernel
-  with strided stores -- four lanes per row repeating the id arithmetic cost more than the
-  half-line writes -- and dropped.)"""
+  pitch (never touched) and a batch that fills no tile evenly.  (Two kernels laid out along the output
+  -- whole-line stores -- were tried for this shape and dropped: one lane per 16-byte chunk redoing
+  the id arithmetic 84 us, a two-phase sample-tile kernel with the row numbers staged in LDS
+  71-75 us, against 63-69 us for the per-column kernel with its half-line stores.)"""
   rng = np.random.RandomState(71)
   dims = [16, 4, 128, 8, 32]
   rows = [5000, 37, 300, 1, 100000]

@@ -6,7 +6,8 @@ oracle; what IS the product here is the host arithmetic that decides what travel
 exchanges, exactly what `hbk_sharded_lookup_fwd/_bwd` use at 8 GPUs), `alltoallv_offsets`
 and `compute_active_ranks`.  Messages are built from that layout, one per peer, exchanged
 between two processes, unpacked with the same layout, and the result must equal the unsharded
-oracle lookup.  The reference's own 2-rank KATs (alltoall_test.py:219-226, :254-269) are
+oracle lookup; the backward runs through the same layout reversed and must equal the dense
+scatter-add of both ranks' gradients on every shard.  The reference's own 2-rank KATs (alltoall_test.py:219-226, :254-269) are
 replayed through the same transport."""
 import ctypes as C
 import json
@@ -155,6 +156,45 @@ def _worker(rank, world, port, wire16, result_dir):
       else:
         got = oracle.segment_combine(col, idx, splits[c], combiners[c])
       np.testing.assert_equal(got, want[c])
+
+    # --- backward through the same layout, reversed (collective.py:334-347): d(stitch) rows are
+    # written where the forward's rows arrived, travel back with send/recv sizes swapped, and
+    # the owner reduces duplicates over the ids it still holds from the forward ---
+    if not wire16:
+      all_grads = [[rng.randn(all_ids[r][c].size if all_splits[r][c] is None
+                              else all_splits[r][c].size - 1, dims[c]).astype(np.float32)
+                    for c in range(N)] for r in range(world)]
+      grads = all_grads[rank]
+      back = np.zeros(int(lay['rows_recv_peer'].sum()), np.float32)
+      for c in range(N):
+        sp = splits[c] if splits[c] is not None else np.arange(ids[c].size + 1, dtype=np.int32)
+        g_id = oracle.segment_combine_grad(grads[c], sp, combiners[c])          # [n_ids, dim]
+        col = np.zeros((ids[c].size, dims[c]), np.float32)
+        col[part[c][2]] = g_id                                               # d(gather by index)
+        for q in range(world):
+          o, k = int(lay['col_shard_off'][c][q]), int(S[c][q])
+          f0 = int(lay['req_row_off'][q][c])
+          back[f0:f0 + k * dims[c]] = col[o:o + k].reshape(-1)
+      got_back, got_sizes = gloo_alltoallv(rank, world, back, lay['rows_recv_peer'])
+      assert got_sizes == lay['rows_send_peer'].tolist()
+      for c in range(N):
+        rows_c, g_c = [], []
+        for q in range(world):
+          k = int(R[q][c])
+          i0, f0 = int(lay['own_id_off'][q][c]), int(lay['own_row_off'][q][c])
+          rows_c.append(recv_ids[i0:i0 + k] // world)
+          g_c.append(got_back[f0:f0 + k * dims[c]].reshape(k, dims[c]))
+        rows_c, g_c = np.concatenate(rows_c), np.concatenate(g_c)
+        shard_grad = np.zeros(shards[c].shape, np.float64)
+        np.add.at(shard_grad, rows_c, g_c.astype(np.float64))
+        dense = np.zeros(tables[c].shape, np.float64)                        # all ranks' ids
+        for r in range(world):
+          sp = all_splits[r][c] if all_splits[r][c] is not None else \
+            np.arange(all_ids[r][c].size + 1, dtype=np.int32)
+          np.add.at(dense, all_ids[r][c] % rows[c],
+                    oracle.segment_combine_grad(all_grads[r][c], sp, combiners[c])
+                    .astype(np.float64))
+        np.testing.assert_allclose(shard_grad, dense[rank::world], rtol=1e-6, atol=1e-9)
     open(os.path.join(result_dir, f'ok{rank}'), 'w').write('ok')
   finally:
     dist.destroy_process_group()

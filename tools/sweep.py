@@ -96,6 +96,14 @@ def case_ragged():
     us = timed(lambda i: plans[i % nb].launch(), iters=20)
     nbytes = n_tot * 8 + n_tot * 64 + 26 * S * 64 + 26 * (S + 1) * 4
     report(f'cfg2 fwd ragged Poisson(8) dim16 S={S} {comb}', us, n_tot, nbytes, ids=n_tot)
+    if comb == 'mean':
+      gl = plans[0]
+      ids0, sps0, _ = gl._keep
+      grad = hb.embedding.GroupLookupGrad(gl)
+      gouts = [torch.randn(S, 16, device=DEV) for _ in range(26)]
+      us = timed(lambda i: grad(ids0, gouts, sps0), iters=10, warmup=2)
+      report(f'cfg2 bwd ragged Poisson(8) dim16 S={S} {comb} (IndexedSlices only)', us, n_tot,
+             n_tot * 8 + n_tot * 64 + 26 * S * 64, ids=n_tot)
 
 
 def case_backward_cfg2():

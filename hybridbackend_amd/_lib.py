@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libhbk_core.so')
 
 # dtype codes of include/hbk.h
 INT8, UINT8, INT32, UINT32, INT64, UINT64, HALF, FLOAT, DOUBLE = range(9)
+APPLY_SGD, APPLY_ADAGRAD = 0, 2
 COMBINER_SUM, COMBINER_MEAN, COMBINER_SQRTN = 0, 1, 2
 OK, INVALID_ARGUMENT, UNIMPLEMENTED, INTERNAL = 0, 3, 12, 13
 COMM_ID_BYTES = 128
@@ -49,13 +50,14 @@ class LookupGradColumn(C.Structure):
               ('combiner', C.c_int32), ('grad_out', C.c_void_p),
               ('unique_rows', C.c_void_p), ('grad_rows', C.c_void_p),
               ('n_unique', C.c_void_p), ('run_start', C.c_void_p), ('run_ids', C.c_void_p),
-              ('run_grads', C.c_void_p), ('n_runs', C.c_int32), ('grad_stride', C.c_int32)]
+              ('run_grads', C.c_void_p), ('n_runs', C.c_int32), ('grad_stride', C.c_int32),
+              ('accum', C.c_void_p)]
 
 
 class ShardedColumn(C.Structure):
   """hbk_sharded_column_t"""
   _fields_ = [('shard', C.c_void_p), ('rows_local', C.c_int64), ('dim', C.c_int32),
-              ('combiner', C.c_int32), ('bucket', C.c_int64)]
+              ('combiner', C.c_int32), ('bucket', C.c_int64), ('accum', C.c_void_p)]
 
 
 class StitchGradColumn(C.Structure):
@@ -90,6 +92,7 @@ def _declare(l):
     'hbk_group_lookup_fwd': (C.c_int, [i32, vp, vp]),
     'hbk_group_lookup_bwd_workspace_bytes': (sz, [i32, vp]),
     'hbk_group_lookup_bwd': (C.c_int, [i32, vp, C.c_float, vp, sz, vp]),
+    'hbk_group_lookup_bwd_apply': (C.c_int, [i32, vp, i32, C.c_float, vp, sz, vp]),
     'hbk_group_stitch_bwd': (C.c_int, [i32, vp, vp]),
     'hbk_cache_probe': (C.c_int, [vp, i64, i32, vp, i64, vp, vp, vp]),
     'hbk_cache_lookup_workspace_bytes': (sz, [i64]),
@@ -119,6 +122,7 @@ def _declare(l):
     'hbk_sharded_lookup_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     'hbk_sharded_owned_ids': (i64, [vp, i32]),
     'hbk_sharded_lookup_bwd': (C.c_int, [vp, vp, vp, C.c_float, vp, vp, vp, vp]),
+    'hbk_sharded_lookup_bwd_apply': (C.c_int, [vp, vp, vp, i32, C.c_float, vp, vp, vp, vp]),
   }
   for name, (res, args) in protos.items():
     fn = getattr(l, name)   # AttributeError here = header and library out of sync

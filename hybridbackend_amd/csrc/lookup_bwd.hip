@@ -28,9 +28,10 @@
 //                "LDS-staged hot rows").  A row that spans chunks is accumulated into its
 //                output row by the owning workgroup.  If the next chunk could overflow the
 //                table it is cleared first; a row seen again afterwards gets a second
-//                IndexedSlices entry (sum semantics preserved).  That needs ~1000 distinct rows
-//                in one bucket: adversarial hashing, or more than ~14 M ids in one column
-//                (16384 buckets x ~900).
+//                IndexedSlices entry (sum semantics preserved).  That needs a bucket of several
+//                FULL chunks with more than ~500 distinct rows in the earlier ones: adversarial
+//                hashing, or more than ~7 M ids in one column (16384 buckets x 448) -- buckets
+//                that are long because of a hot row hold few distinct rows.
 //   5 split      a bucket far above the average size holds a hot row (Zipf heads: one row can
 //                own 20% of a column).  One workgroup has ~32 KB of loads in flight, so it would
 //                sum such a row at ~15 GB/s while the rest of the chip idles.  The scan kernel
@@ -80,7 +81,7 @@ constexpr int kBatch = kPerThread < 8 ? kPerThread : 8;   // loads in flight per
 constexpr int kMaxBuckets = 16384;   // 64 KB of LDS counters in hist / scatter
 constexpr int kCP = HBK_BWD_CP;       // pairs per chunk in the reduce kernel
 constexpr int kSlots = 2 * kCP;       // LDS hash-table slots
-constexpr int kTableRoom = kSlots - 32;   // clear the table when occupied + next chunk could pass this
+constexpr int kTableRoom = kSlots - 8;    // clear the table when occupied + next chunk could pass this
 constexpr int kUA = HBK_BWD_UA;       // slots a lane group reduces concurrently (rows in flight)
 constexpr int kHeavy = 64;            // pairs of one row in a chunk that make it a "hot row"
 constexpr int kHotTries = 4;           // ballot rounds that look for a hot row inside a wave
@@ -97,6 +98,7 @@ struct GCol {
   float* grad_rows;
   int32_t* n_unique;
   float* table;
+  float* accum;              // Adagrad accumulator [rows, dim] (apply kind 2)
   int32_t* hist;             // [P * tiles] -> exclusive offsets after the scan
   int32_t* bstart;           // [P + 1]
   int64_t* pair_row[1];      // [n_ids] rows of the pairs, grouped by bucket
@@ -131,6 +133,8 @@ struct GCol {
 struct GArgs {
   int32_t n_cols;
   float lr;
+  int32_t apply;             // 0 none / SGD by lr, 2 Adagrad
+  int32_t pad_;
   GCol col[kMaxCols];
 };
 static_assert(sizeof(GArgs) <= 24576, "kernarg budget");
@@ -381,7 +385,8 @@ struct ReduceJob {
   float* out_vals;
   int32_t* out_counter;      // claimed with one atomic per chunk
   int32_t out_base;          // added to the claimed index
-  float lr;                  // != 0: fused SGD step on the table row
+  float lr;                  // != 0: fused optimizer step on the table row
+  int32_t apply;             // HBK_APPLY_SGD | HBK_APPLY_ADAGRAD
 };
 
 template <typename V>
@@ -397,7 +402,35 @@ __device__ inline V load_grad(const GCol& c, const ReduceJob& job, int32_t seg, 
   return g;
 }
 
-// out row u += (or =) v, and the fused SGD step on the table row
+// The sparse optimizer step of one row chunk (this workgroup owns the row):
+//   SGD      var -= lr * g                                        (GradientDescentOptimizer)
+//   Adagrad  accum += g * g;  var -= lr * g * (1 / sqrt(accum))   (AdagradOptimizer's sparse apply,
+//            docs/tutorial/ranking/taobao/train.py:115; g = the row's deduplicated gradient)
+template <typename V>
+__device__ inline V rsqrt_v(V a);
+template <>
+__device__ inline float rsqrt_v<float>(float a) { return 1.0f / sqrtf(a); }
+template <>
+__device__ inline f32x4 rsqrt_v<f32x4>(f32x4 a) {
+  return f32x4{1.0f / sqrtf(a.x), 1.0f / sqrtf(a.y), 1.0f / sqrtf(a.z), 1.0f / sqrtf(a.w)};
+}
+
+template <typename V>
+__device__ inline void apply_row(const GCol& c, int32_t apply, float lr, int64_t row, int sub, V v) {
+  constexpr int VE = sizeof(V) / 4;
+  const int64_t off = row * c.dim + (int64_t)sub * VE;
+  V* t = reinterpret_cast<V*>(c.table + off);
+  if (apply == HBK_APPLY_ADAGRAD) {
+    V* ap = reinterpret_cast<V*>(c.accum + off);
+    const V a = __builtin_nontemporal_load(ap) + v * v;
+    *ap = a;
+    *t = __builtin_nontemporal_load(t) - (lr * v) * rsqrt_v<V>(a);
+  } else {
+    *t = __builtin_nontemporal_load(t) - lr * v;
+  }
+}
+
+// out row u += (or =) v, and the fused optimizer step on the table row
 template <typename V>
 __device__ inline void emit_row(const GCol& c, const ReduceJob& job, float lr, int32_t u,
                                 bool is_new, int64_t row, int sub, V v) {
@@ -405,10 +438,7 @@ __device__ inline void emit_row(const GCol& c, const ReduceJob& job, float lr, i
   V* o = reinterpret_cast<V*>(job.out_vals + (int64_t)u * c.dim + (int64_t)sub * VE);
   // rows are owned by this workgroup; bypass L1 when re-reading what an earlier chunk wrote
   *o = is_new ? v : __builtin_nontemporal_load(o) + v;
-  if (lr != 0.0f) {
-    V* t = reinterpret_cast<V*>(c.table + row * c.dim + (int64_t)sub * VE);
-    *t = __builtin_nontemporal_load(t) - lr * v;
-  }
+  if (lr != 0.0f) apply_row<V>(c, job.apply, lr, row, sub, v);
 }
 
 template <typename V>
@@ -439,6 +469,8 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
   // (rare: buckets aim at 7/8 of a chunk) therefore only emit, remember the output ranges they
   // claimed, and apply the step once per row at the end.
   const bool defer = job.lr != 0.0f && n_pairs > kCP && n_pairs <= kCP * kMaxRanges;
+  // (beyond kMaxRanges chunks -- adversarial hashing -- the step is applied chunk by chunk: SGD
+  // then only rounds differently, Adagrad sees partial gradients)
   const float lr_chunk = defer ? 0.0f : job.lr;
   for (int32_t cb = 0; cb < n_pairs; cb += kCP) {
     const int32_t n_chunk = n_pairs - cb < kCP ? n_pairs - cb : kCP;
@@ -671,8 +703,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         const int64_t row = job.out_rows[u];
         const V v = __builtin_nontemporal_load(
             reinterpret_cast<const V*>(job.out_vals + (int64_t)u * c.dim + (int64_t)sub * VE));
-        V* t = reinterpret_cast<V*>(c.table + row * c.dim + (int64_t)sub * VE);
-        *t = __builtin_nontemporal_load(t) - job.lr * v;
+        apply_row<V>(c, job.apply, job.lr, row, sub, v);
       }
       __syncthreads();  // rows are distinct inside a range, not across ranges (table clears)
     }
@@ -713,6 +744,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
     job.out_counter = c.pcount + bucket;
     job.out_base = start;
     job.lr = 0.0f;
+    job.apply = HBK_APPLY_SGD;
   } else {
     job.prow = c.pair_row[0] + start;
     job.pseg = c.pair_seg[0] + start;
@@ -722,6 +754,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
     job.out_counter = c.n_unique;
     job.out_base = 0;
     job.lr = a.lr;
+    job.apply = a.apply;
   }
   bucket_reduce<V>(c, job, lds);
 }
@@ -750,6 +783,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const 
   job.out_counter = c.n_unique;
   job.out_base = 0;
   job.lr = a.lr;
+  job.apply = a.apply;
   bucket_reduce<V>(c, job, lds);
 }
 
@@ -909,7 +943,16 @@ extern "C" size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
 extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
                                     float apply_lr, void* workspace, size_t workspace_bytes,
                                     hbk_stream_t stream_) {
+  return hbk_group_lookup_bwd_apply(n_cols, cols, HBK_APPLY_SGD, apply_lr, workspace,
+                                    workspace_bytes, stream_);
+}
+
+extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
+                                          int32_t apply, float apply_lr, void* workspace,
+                                          size_t workspace_bytes, hbk_stream_t stream_) {
   using namespace hbk;
+  HBK_REQUIRE(apply == HBK_APPLY_SGD || apply == HBK_APPLY_ADAGRAD,
+              "group_lookup_bwd: apply must be HBK_APPLY_SGD or HBK_APPLY_ADAGRAD, got %d", apply);
   hipStream_t stream = as_stream(stream_);
   HBK_REQUIRE(n_cols >= 0, "group_lookup_bwd: n_cols must be >= 0, got %d", n_cols);
   if (n_cols == 0) return HBK_OK;
@@ -934,6 +977,9 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
                 "group_lookup_bwd: column %d: NULL buffer", c);
     HBK_REQUIRE(apply_lr == 0.0f || h.table != nullptr || h.n_ids == 0,
                 "group_lookup_bwd: column %d: table is NULL but apply_lr != 0", c);
+    HBK_REQUIRE(apply_lr == 0.0f || apply != HBK_APPLY_ADAGRAD || h.accum != nullptr ||
+                    h.n_ids == 0,
+                "group_lookup_bwd: column %d: Adagrad needs the accumulator table", c);
     HBK_REQUIRE(h.n_runs >= 0, "group_lookup_bwd: column %d: n_runs must be >= 0", c);
     HBK_REQUIRE(h.n_runs == 0 || (h.row_splits == nullptr && h.run_start && h.run_ids &&
                                   h.run_grads),
@@ -970,6 +1016,7 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       d.grad_rows = h.grad_rows;
       d.n_unique = h.n_unique;
       d.table = h.table;
+      d.accum = h.accum;
       d.hist = reinterpret_cast<int32_t*>(wp);
       wp += align8(((size_t)p.tiles * p.n_buckets) * 4);
       d.bstart = reinterpret_cast<int32_t*>(wp);
@@ -1014,7 +1061,7 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
       HBK_REQUIRE(make_rowshape(h.dim,
                                 (uintptr_t)h.grad_out | (uintptr_t)h.grad_rows |
                                     ((uintptr_t)(uint32_t)h.grad_stride * 4) |
-                                    (apply_lr != 0.0f ? (uintptr_t)h.table : 0),
+                                    (apply_lr != 0.0f ? (uintptr_t)h.table | (uintptr_t)h.accum : 0),
                                 &shape),
                   "group_lookup_bwd: dim %d needs more than 64 lanes per row", h.dim);
       d.chunks = shape.chunks;
@@ -1043,6 +1090,8 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
     if (k == 0) continue;
     args.n_cols = k;
     args.lr = apply_lr;
+    args.apply = apply;
+    args.pad_ = 0;
     if (ks > 0) {
       seg_args.n_cols = ks;
       seg_args.lr = 0.f;

@@ -672,7 +672,15 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
 
 extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads,
                                       const int32_t* grad_strides, float apply_lr,
-                                      int64_t* const* unique_rows,
+                                      int64_t* const* unique_rows, float* const* grad_rows,
+                                      int32_t* const* n_unique, hbk_stream_t stream_) {
+  return hbk_sharded_lookup_bwd_apply(p, grads, grad_strides, HBK_APPLY_SGD, apply_lr,
+                                      unique_rows, grad_rows, n_unique, stream_);
+}
+
+extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const* grads,
+                                            const int32_t* grad_strides, int32_t apply,
+                                            float apply_lr, int64_t* const* unique_rows,
                                       float* const* grad_rows, int32_t* const* n_unique,
                                       hbk_stream_t stream_) {
   using namespace hbk;
@@ -739,6 +747,7 @@ extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads
     hbk_lookup_grad_column_t& h = v[c];
     memset(&h, 0, sizeof(h));
     h.table = const_cast<float*>(p->cols[c].shard);
+    h.accum = p->cols[c].accum;
     h.rows = p->cols[c].rows_local;
     h.dim = p->cols[c].dim;
     h.ids_dtype = p->id32 ? HBK_INT32 : HBK_INT64;
@@ -766,8 +775,8 @@ extern "C" int hbk_sharded_lookup_bwd(hbk_sharded_t p, const float* const* grads
   for (int g = 0; g < G; ++g) {
     const Group& gr = p->groups[g];
     HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
-    rc = hbk_group_lookup_bwd(gr.c1 - gr.c0, v.data() + gr.c0, apply_lr, p->bwd_ws.ptr,
-                              p->bwd_ws.bytes, stream_);
+    rc = hbk_group_lookup_bwd_apply(gr.c1 - gr.c0, v.data() + gr.c0, apply, apply_lr,
+                                    p->bwd_ws.ptr, p->bwd_ws.bytes, stream_);
     if (rc != HBK_OK) return rc;
   }
   return HBK_OK;

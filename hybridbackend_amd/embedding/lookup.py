@@ -145,13 +145,23 @@ class GroupLookupGrad:
   hybridbackend/tensorflow/training/gradient.py:193-217).
   """
 
-  def __init__(self, lookup):
+  def __init__(self, lookup, accums=None):
+    """accums: per column the Adagrad accumulator table (fp32, same shape as the weights,
+    filled with ``initial_accumulator_value``), needed for ``optimizer='adagrad'``."""
     self._lib = _lib.lib()
     self.lookup = lookup
     n = len(lookup)
+    self.accums = list(accums) if accums is not None else None
     self._cols = (_lib.LookupGradColumn * n)()
     for c, t in enumerate(lookup.tables):
       col = self._cols[c]
+      if self.accums is not None:
+        a = self.accums[c]
+        _lib.require_device_tensor(a, 'accumulator')
+        if a.dtype != torch.float32 or a.shape != t.shape:
+          raise _lib.InvalidArgumentError(
+            _lib.INVALID_ARGUMENT, f'accumulator {c} must be fp32 {tuple(t.shape)}')
+        col.accum = a.data_ptr()
       col.table = t.data_ptr()
       col.rows = t.shape[0]
       col.dim = t.shape[1]
@@ -160,7 +170,7 @@ class GroupLookupGrad:
       col.combiner = lookup.combiners[c]
     self._ws = None
 
-  def __call__(self, ids, grads, row_splits=None, apply_lr=0.0):
+  def __call__(self, ids, grads, row_splits=None, apply_lr=0.0, optimizer='sgd'):
     """Returns per column ``(unique_rows int64[n_ids], grad_rows f32[n_ids, dim],
     n_unique int32[1])``; only the first ``n_unique`` rows are meaningful, in unspecified
     order (device-side count: no host sync here).  The result buffers belong to this object
@@ -215,7 +225,13 @@ class GroupLookupGrad:
     if self._ws is None or self._ws.numel() < need:
       self._ws = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
     self._keep = (ids, grads, row_splits)
-    _lib.check(self._lib.hbk_group_lookup_bwd(
-      n, self._cols, C.c_float(apply_lr), C.c_void_p(self._ws.data_ptr()),
+    if optimizer not in ('sgd', 'adagrad'):
+      raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, "optimizer must be 'sgd' or 'adagrad'")
+    if optimizer == 'adagrad' and apply_lr != 0.0 and self.accums is None:
+      raise _lib.InvalidArgumentError(
+        _lib.INVALID_ARGUMENT, "optimizer='adagrad' needs GroupLookupGrad(lookup, accums=...)")
+    _lib.check(self._lib.hbk_group_lookup_bwd_apply(
+      n, self._cols, _lib.APPLY_ADAGRAD if optimizer == 'adagrad' else _lib.APPLY_SGD,
+      C.c_float(apply_lr), C.c_void_p(self._ws.data_ptr()),
       C.c_size_t(self._ws.numel()), _lib.current_stream(dev)))
     return list(self._views)

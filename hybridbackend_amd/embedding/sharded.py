@@ -64,8 +64,10 @@ class ShardedGroupLookup:
   """
 
   def __init__(self, shards, coll, buckets=None, combiners='sum', wire_dtype=None,
-               world_size=None):
+               world_size=None, accums=None):
     self.shards = list(shards)
+    # Adagrad accumulators of the shards (same shapes), for backward(optimizer='adagrad')
+    self.accums = list(accums) if accums is not None else None
     self.coll = coll
     self.world_size = int(world_size if world_size is not None else coll.world_size)
     n = len(self.shards)
@@ -136,6 +138,8 @@ class ShardedGroupLookup:
         cols[c].dim = t.shape[1]
         cols[c].combiner = _combiner_code(combs[c])
         cols[c].bucket = self.buckets[c]
+        if self.accums is not None:
+          cols[c].accum = self.accums[c].data_ptr()
       self._plan_handle = C.c_void_p()
       wire = _lib.HALF if self.wire_dtype == torch.float16 else _lib.FLOAT
       _lib.check(self._lib.hbk_sharded_create(
@@ -231,7 +235,7 @@ class ShardedGroupLookup:
   def owner_bwd(self, st, recv_grads, apply_lr=0.0):
     return self._owner_grad(st.recv_ids, recv_grads, None, apply_lr=apply_lr)
 
-  def backward(self, grads, apply_lr=0.0, outs=None):
+  def backward(self, grads, apply_lr=0.0, outs=None, optimizer='sgd'):
     """Backward of the LAST forward step (hbk_sharded_lookup_bwd).  grads[c]: gradient of
     column c's output [segments, dim].  Returns per column the IndexedSlices of the LOCAL
     shard ``(unique_rows, grad_rows, n_unique)``; with ``apply_lr`` the SGD update is applied
@@ -258,8 +262,12 @@ class ShardedGroupLookup:
                   torch.zeros(1, dtype=torch.int32, device=self.device)))
     self._keep_bwd = (grads, res)
     strides = (C.c_int32 * n)(*[0 if g.is_contiguous() else int(g.stride(0)) for g in grads])
-    _lib.check(self._lib.hbk_sharded_lookup_bwd(
-      plan, _lib.ptr_array([g.data_ptr() for g in grads]), strides, C.c_float(apply_lr),
+    if optimizer == 'adagrad' and apply_lr != 0.0 and self.accums is None:
+      raise _lib.InvalidArgumentError(
+        _lib.INVALID_ARGUMENT, "optimizer='adagrad' needs ShardedGroupLookup(..., accums=...)")
+    _lib.check(self._lib.hbk_sharded_lookup_bwd_apply(
+      plan, _lib.ptr_array([g.data_ptr() for g in grads]), strides,
+      _lib.APPLY_ADAGRAD if optimizer == 'adagrad' else _lib.APPLY_SGD, C.c_float(apply_lr),
       _lib.ptr_array([r[0].data_ptr() for r in res]),
       _lib.ptr_array([r[1].data_ptr() for r in res]),
       _lib.ptr_array([r[2].data_ptr() for r in res]), _lib.current_stream(self.device)))

@@ -46,7 +46,8 @@ class DenseFeatures:
       (docs/tutorial/ranking/criteo/train.py:84,91).
   """
 
-  def __init__(self, columns, device, coll=None, batch_size=0, init=None):
+  def __init__(self, columns, device, coll=None, batch_size=0, init=None,
+               initial_accumulator_value=None):
     self.columns = list(columns)
     self.device = torch.device(device)
     self.coll = coll
@@ -61,6 +62,10 @@ class DenseFeatures:
       is_sharded = is_sharded and world > 1
       self.sharded.append(is_sharded)
       self.weights.append(init(col, rows if is_sharded else col.num_buckets, self.device))
+    # Adagrad accumulators (tf.train.AdagradOptimizer: initial_accumulator_value = 0.1)
+    self.accums = None
+    if initial_accumulator_value is not None:
+      self.accums = [torch.full_like(w, float(initial_accumulator_value)) for w in self.weights]
     self.offsets, off = [], 0
     for col in self.columns:
       self.offsets.append(off)
@@ -74,11 +79,14 @@ class DenseFeatures:
       self._lookup = GroupLookup(pick(self._rep, self.weights),
                                  [self.columns[c].num_buckets for c in self._rep],
                                  [self.columns[c].combiner for c in self._rep])
-      self._grad = GroupLookupGrad(self._lookup)
+      self._grad = GroupLookupGrad(
+        self._lookup, pick(self._rep, self.accums) if self.accums is not None else None)
     if self._shd:
       self._sharded = ShardedGroupLookup(pick(self._shd, self.weights), coll,
                                          buckets=[self.columns[c].num_buckets for c in self._shd],
-                                         combiners=[self.columns[c].combiner for c in self._shd])
+                                         combiners=[self.columns[c].combiner for c in self._shd],
+                                         accums=(pick(self._shd, self.accums)
+                                                 if self.accums is not None else None))
 
   def _split(self, features):
     ids, splits, batch = [], [], None
@@ -116,11 +124,12 @@ class DenseFeatures:
         cols_to_output_tensors[col] = views[c]
     return out
 
-  def backward(self, grad, apply_lr=0.0):
+  def backward(self, grad, apply_lr=0.0, optimizer='sgd'):
     """grad: ``[batch, sum of dims]`` gradient of the last forward's output.  Returns per column
     the ``IndexedSlices`` ``(unique_rows, grad_rows, n_unique)`` of this rank's rows (local row
-    numbers for sharded tables); with ``apply_lr`` the sparse SGD step is applied in the same
-    pass.  Gradients of replicated tables still need the cross-rank aggregation of
+    numbers for sharded tables); with ``apply_lr`` the sparse optimizer step (``'sgd'``, or
+    ``'adagrad'`` when the layer was built with ``initial_accumulator_value``) is applied in the
+    same pass.  Gradients of replicated tables still need the cross-rank aggregation of
     hybridbackend/tensorflow/training/gradient.py:119-177 before they are applied at W > 1."""
     ids, splits = self._last
     if grad.dim() != 2 or grad.shape[1] != self.width or grad.dtype != torch.float32:
@@ -139,11 +148,11 @@ class DenseFeatures:
     res = [None] * len(self.columns)
     if self._rep:
       r = self._grad(pick(self._rep, ids), pick(self._rep, views), pick(self._rep, splits),
-                     apply_lr=apply_lr)
+                     apply_lr=apply_lr, optimizer=optimizer)
       for k, c in enumerate(self._rep):
         res[c] = r[k]
     if self._shd:
-      r = self._sharded.backward(pick(self._shd, views), apply_lr=apply_lr)
+      r = self._sharded.backward(pick(self._shd, views), apply_lr=apply_lr, optimizer=optimizer)
       for k, c in enumerate(self._shd):
         res[c] = r[k]
     return res

@@ -182,8 +182,8 @@ int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
  *   each group is reduced by one workgroup (LDS hash table of the distinct rows, sums in
  *   registers; a group holding a hot row is split over several workgroups and merged), so the
  *   summation order is not fixed: tolerance 1e-5 relative.  Rows are distinct unless one group
- *   holds more distinct rows than its LDS table (~1000: adversarial hashing, or more than
- *   ~14 M ids in one column): then a row may appear in more than one entry, sum semantics preserved
+ *   spans several full 512-pair chunks with more than ~500 distinct rows (adversarial hashing,
+ *   or more than ~7 M ids in one column): then a row may appear in more than one entry, sum semantics preserved
  *   (IndexedSlices allow repeated indices; the fused SGD apply stays exact).
  *   apply_lr != 0 additionally performs the sparse SGD update on the shard in the same
  *   pass: table[unique_rows[u],:] -= apply_lr * grad_rows[u,:] (sharded variables skip
@@ -213,6 +213,7 @@ typedef struct {
   const int64_t* run_grads;
   int32_t n_runs;
   int32_t grad_stride;       /* row stride of grad_out in floats; 0 = dim (see out_stride) */
+  float* accum;              /* Adagrad accumulator [rows, dim] (HBK_APPLY_ADAGRAD), else NULL */
 } hbk_lookup_grad_column_t;
 
 size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
@@ -220,6 +221,17 @@ size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
 int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
                          float apply_lr, void* workspace, size_t workspace_bytes,
                          hbk_stream_t stream);
+/* The same with the optimizer named: HBK_APPLY_SGD (above), or HBK_APPLY_ADAGRAD =
+ *   accum[row,:] += g * g;  table[row,:] -= apply_lr * g * (1 / sqrt(accum[row,:]))
+ * on the deduplicated gradient g of every touched row -- tf.train.AdagradOptimizer's sparse
+ * apply, the optimizer of the reference's Taobao tutorials (docs/tutorial/ranking/taobao/
+ * train.py:115); cols[c].accum holds the accumulator (initial_accumulator_value filled in by
+ * the caller). */
+#define HBK_APPLY_SGD 0
+#define HBK_APPLY_ADAGRAD 2
+int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
+                               int32_t apply, float apply_lr, void* workspace,
+                               size_t workspace_bytes, hbk_stream_t stream);
 
 /* R10 (sharded form)  d(stitch + combiner): the transpose of the requester-side
  *   `gather(embeddings, shard_index)` + combiner (hbtf/embedding/sharding.py:200; TF emits
@@ -380,6 +392,7 @@ typedef struct {
   int32_t dim;
   int32_t combiner;
   int64_t bucket;       /* >0: ids are taken modulo this before the partition (R1) */
+  float* accum;         /* Adagrad accumulator of the shard [rows_local, dim], or NULL */
 } hbk_sharded_column_t;
 
 /* Host arithmetic of the peer-major exchange buffers (pure host code, no device work): S is
@@ -405,6 +418,12 @@ int hbk_sharded_lookup_bwd(hbk_sharded_t plan, const float* const* grads,
                            const int32_t* grad_strides, float apply_lr,
                            int64_t* const* unique_rows, float* const* grad_rows,
                            int32_t* const* n_unique, hbk_stream_t stream);
+/* the same with the optimizer named (HBK_APPLY_SGD | HBK_APPLY_ADAGRAD, see
+ * hbk_group_lookup_bwd_apply); Adagrad uses the columns' `accum` shards */
+int hbk_sharded_lookup_bwd_apply(hbk_sharded_t plan, const float* const* grads,
+                                 const int32_t* grad_strides, int32_t apply, float apply_lr,
+                                 int64_t* const* unique_rows, float* const* grad_rows,
+                                 int32_t* const* n_unique, hbk_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -241,6 +241,20 @@ def sparse_sgd_apply(table, rows, g_u, lr):
   return table
 
 
+def sparse_adagrad_apply(table, accum, rows, g_u, lr):
+  """In place, TF1.15 AdagradOptimizer sparse apply on deduplicated slices (third-party TF:
+  training_ops SparseApplyAdagrad; call site docs/tutorial/ranking/taobao/train.py:115):
+  accum[r] += g * g; table[r] -= lr * g * (1 / sqrt(accum[r])), all in fp32, entries in order."""
+  assert table.dtype == np.float32 and accum.dtype == np.float32
+  g_u = np.ascontiguousarray(g_u, np.float32)
+  lr = np.float32(lr)
+  for u, r in enumerate(np.asarray(rows, np.int64)):
+    a = accum[r] + g_u[u] * g_u[u]
+    accum[r] = a
+    table[r] = table[r] - (lr * g_u[u]) * (np.float32(1.0) / np.sqrt(a))
+  return table, accum
+
+
 # R11 -- hybridbackend/common/murmur3.cu.h:32-77
 def murmur3_hash32(keys):
   keys = np.ascontiguousarray(keys, np.int64)

@@ -523,6 +523,42 @@ def test_group_lookup_backward_segmented_inputs():
       st += ln
 
 
+@pytest.mark.parametrize('hook', [None, 'one_bucket'])
+def test_group_lookup_backward_fused_adagrad_apply(monkeypatch, hook):
+  """tf.train.AdagradOptimizer's sparse apply fused into the backward: accum += g^2,
+  var -= lr * g / sqrt(accum) on the deduplicated gradient of every touched row -- bit-equal to
+  the oracle applied to the emitted IndexedSlices (also when rows span chunks: the step is
+  deferred to one apply per row), untouched rows stay untouched."""
+  if hook:
+    monkeypatch.setenv('HBK_BWD_LOG2P', '0')     # one bucket: many chunks per workgroup
+  rng = np.random.RandomState(91)
+  # (one forced bucket spans many full chunks: it must stay below ~500 distinct rows, see hbk.h)
+  for d, rows, n in ((16, 300, 6000), (128, 50, 2000), (6, 450 if hook else 10000, 3000)):
+    table = rng.uniform(-1, 1, size=(rows, d)).astype(np.float32)
+    accum = np.full((rows, d), 0.1, np.float32)
+    ids = rng.randint(0, 2**40, size=n).astype(np.int64)
+    grads = rng.randn(n, d).astype(np.float32)
+    t_dev, a_dev = dev(table.copy()), dev(accum.copy())
+    lookup = hb.embedding.GroupLookup([t_dev], [rows], 'sum')
+    grad = hb.embedding.GroupLookupGrad(lookup, accums=[a_dev])
+    urows, grows, nu = grad([dev(ids)], [dev(grads)], apply_lr=0.05, optimizer='adagrad')[0]
+    k = int(nu.item())
+    assert k == np.unique(ids % rows).size
+    want_t, want_a = table.copy(), accum.copy()
+    oracle.sparse_adagrad_apply(want_t, want_a, host(urows)[:k], host(grows)[:k], 0.05)
+    np.testing.assert_equal(host(a_dev), want_a)
+    np.testing.assert_equal(host(t_dev), want_t)
+    # against float64 from the raw ids: same rows touched, values within fp32 accuracy
+    g64 = np.zeros((rows, d), np.float64)
+    np.add.at(g64, ids % rows, grads.astype(np.float64))
+    a64 = accum.astype(np.float64) + g64 * g64
+    ref = table.astype(np.float64) - 0.05 * g64 / np.sqrt(a64)
+    np.testing.assert_allclose(host(t_dev), ref, rtol=1e-5, atol=1e-5)
+  with pytest.raises(hb.InvalidArgumentError):
+    hb.embedding.GroupLookupGrad(lookup)([dev(ids)], [dev(grads)], apply_lr=0.1,
+                                         optimizer='adagrad')
+
+
 def test_group_lookup_backward_fused_sgd_apply():
   rng = np.random.RandomState(11)
   table = rng.uniform(-1, 1, size=(5000, 16)).astype(np.float32)

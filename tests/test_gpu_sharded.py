@@ -563,3 +563,67 @@ def test_parquet_to_dense_features(tmp_path):
     np.testing.assert_equal(out, np.concatenate(want, axis=1))
     seen += k
   assert seen == n
+
+
+def test_dense_features_adagrad_sharded_in_process_world():
+  """A training step's embedding side at W = 2: forward, backward and the fused Adagrad apply on
+  sharded + replicated tables equal a single-process float64 Adagrad step on the full tables
+  (replicated tables: every rank applies its local gradient; summed over ranks it is the full
+  step only for the rows' gradient sum, so they are checked per rank)."""
+  import threading
+  world = 2
+  rng = np.random.RandomState(93)
+  cols, tables, feats, grads, batch = _dense_case(rng, world)
+  comms = hb.distribute.Collective.local_world(world)
+  results, errors = [None] * world, []
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        def init(c, rows, d):
+          t = tables[cols.index(c)]
+          return dev((t[r::world] if rows != c.num_buckets else t).copy())
+        layer = hb.feature_column.DenseFeatures(cols, DEV, coll=comms[r], batch_size=batch,
+                                                init=init, initial_accumulator_value=0.1)
+        layer(_dev_feats(feats[r]))
+        layer.backward(dev(grads[r]), apply_lr=0.05, optimizer='adagrad')
+        torch.cuda.current_stream().synchronize()
+        results[r] = ([w.cpu().numpy() for w in layer.weights],
+                      [a.cpu().numpy() for a in layer.accums])
+        layer.close()
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((r, repr(e)))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=120)
+  for cm in comms:
+    cm.close()
+  assert not errors, errors
+  off = 0
+  for k, c in enumerate(cols):
+    per_rank = []
+    for r in range(world):
+      _, ids, sps = _want_dense(cols, tables, feats[r])
+      g = np.ascontiguousarray(grads[r][:, off:off + c.dimension])
+      sp = sps[k] if sps[k] is not None else np.arange(batch + 1, dtype=np.int32)
+      g_id = oracle.segment_combine_grad(g, sp, c.combiner).astype(np.float64)
+      dense = np.zeros((c.num_buckets, c.dimension), np.float64)
+      np.add.at(dense, ids[k] % c.num_buckets, g_id)
+      per_rank.append(dense)
+    t64 = tables[k].astype(np.float64)
+    if k != 1:        # sharded: the owner applies the sum of both ranks' gradients once
+      g = per_rank[0] + per_rank[1]
+      a = 0.1 + g * g
+      want = t64 - 0.05 * g / np.sqrt(a)
+      for r in range(world):
+        np.testing.assert_allclose(results[r][0][k], want[r::world], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(results[r][1][k], a[r::world], rtol=1e-5, atol=1e-6)
+    else:             # replicated: each rank stepped with its own gradient
+      for r in range(world):
+        a = 0.1 + per_rank[r] * per_rank[r]
+        np.testing.assert_allclose(results[r][0][k], t64 - 0.05 * per_rank[r] / np.sqrt(a),
+                                   rtol=1e-5, atol=1e-6)
+    off += c.dimension

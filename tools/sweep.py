@@ -230,6 +230,11 @@ def case_cfg5():
   gouts = [torch.randn_like(o) for o in outs]
   us = timed(lambda i: grad(ids, gouts, splits, apply_lr=0.01), iters=5, warmup=2)
   report(f'cfg5 bwd + SGD apply 200 cols mixed dims B={B}', us, n_ids, n_bytes, ids=n_ids)
+  accums = [torch.full_like(t, 0.1) for t in tables]
+  grad_a = hb.embedding.GroupLookupGrad(lookup, accums=accums)
+  us = timed(lambda i: grad_a(ids, gouts, splits, apply_lr=0.01, optimizer='adagrad'), iters=5,
+             warmup=2)
+  report(f'cfg5 bwd + Adagrad apply 200 cols mixed dims B={B}', us, n_ids, n_bytes, ids=n_ids)
 
 
 def case_dense_block():

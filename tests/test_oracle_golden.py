@@ -240,3 +240,23 @@ def test_sharded_backward_equals_dense_scatter():
     assert len(set(rows.tolist())) == len(rows)      # deduplicated
     got[rows * W + r] += g_u
   np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-6)
+
+
+def test_sparse_adagrad_apply_matches_float64():
+  """accum += g^2; var -= lr * g / sqrt(accum), fp32, entries in order (TF AdagradOptimizer's
+  sparse apply; third-party TF, parity unpinned: restated from its documented update rule)."""
+  rng = np.random.RandomState(3)
+  table = rng.uniform(-1, 1, size=(50, 8)).astype(np.float32)
+  accum = np.full((50, 8), 0.1, np.float32)
+  rows = rng.permutation(50)[:20].astype(np.int64)
+  g = rng.randn(20, 8).astype(np.float32)
+  t, a = table.copy(), accum.copy()
+  oracle.sparse_adagrad_apply(t, a, rows, g, 0.05)
+  a64 = accum.astype(np.float64)
+  t64 = table.astype(np.float64)
+  a64[rows] += g.astype(np.float64) ** 2
+  t64[rows] -= 0.05 * g / np.sqrt(a64[rows])
+  np.testing.assert_allclose(a, a64, rtol=1e-6)
+  np.testing.assert_allclose(t, t64, rtol=1e-6, atol=1e-7)
+  untouched = np.setdiff1d(np.arange(50), rows)
+  np.testing.assert_equal(t[untouched], table[untouched])

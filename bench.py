@@ -47,6 +47,8 @@ def parse_args():
                  help='budget of the host-CPU baseline (0 disables it)')
   p.add_argument('--sharded', action='store_true',
                  help='run the sharded pipeline even at N = 1 (validation of the N > 1 code path)')
+  p.add_argument('--watchdog', type=float, default=900.0,
+                 help='N > 1: seconds after which a rank exits instead of waiting for its peers')
   p.add_argument('--id-batches', type=int, default=0,
                  help='distinct id batches kept in HBM (default: steps + warmup, max 64)')
   return p.parse_args()
@@ -159,6 +161,17 @@ def main():
 
   use_dist = world > 1 or ('RANK' in os.environ and args.sharded)
   if use_dist:
+    # a rank that dies leaves its peers waiting inside a collective: never hang the node
+    import threading
+
+    def _abort():
+      sys.stderr.write(f'bench.py: rank {rank} gave up after {args.watchdog} s (a peer is gone '
+                       'or a collective hangs)\n')
+      sys.stderr.flush()
+      os._exit(3)
+    watchdog = threading.Timer(args.watchdog, _abort)
+    watchdog.daemon = True
+    watchdog.start()
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     dist.init_process_group('nccl', device_id=device)
@@ -279,6 +292,7 @@ def main():
     coll.close()
   if use_dist:
     import torch.distributed as dist
+    watchdog.cancel()
     dist.destroy_process_group()
 
 

@@ -47,6 +47,8 @@ def parse_args():
                  help='budget of the host-CPU baseline (0 disables it)')
   p.add_argument('--sharded', action='store_true',
                  help='run the sharded pipeline even at N = 1 (validation of the N > 1 code path)')
+  p.add_argument('--no-prefetch', action='store_true',
+                 help='N > 1: do not partition the next batch during the current step')
   p.add_argument('--watchdog', type=float, default=900.0,
                  help='N > 1: seconds after which a rank exits instead of waiting for its peers')
   p.add_argument('--id-batches', type=int, default=0,
@@ -208,6 +210,9 @@ def main():
 
     def step(i):
       sharded.launch(bound[i % n_batches])
+      if not args.no_prefetch:
+        # the next batch is resident: partition it while this step's exchanges are on the wire
+        sharded.prefetch(bound[(i + 1) % n_batches])
     parallelism = f'row-sharded id-mod-{world} (alltoallv ids + rows over RCCL/xGMI)'
 
   def barrier():
@@ -259,6 +264,7 @@ def main():
       'config': {'workload': workload, 'global_batch': args.batch * world,
                  'parallelism': parallelism,
                  'wire': args.wire if world > 1 else None,
+                 'prefetch_next_partition': (world > 1 or args.sharded) and not args.no_prefetch,
                  'id_batches_resident': n_batches},
       'roofline': {
         'bound': 'hbm',

@@ -278,9 +278,23 @@ struct hbk_sharded {
   hipEvent_t ev[4][4];                   // [stage][group]: packed, ids in, gathered, rows in
   bool have_step;
   // device buffers owned by the plan
-  hbk::Buffer ids_bucketized, part_out, shard_index, sizes_dev, part_ws, send_ids, recv_ids,
-      send_rows, recv_rows, wire_ws, bwd_ws, runs_dev;
-  int32_t* host_sizes;  // pinned [3][N*W]: S, S^T, R as they sit on the device
+  hbk::Buffer part_ws, send_ids, recv_ids, send_rows, recv_rows, wire_ws, bwd_ws, runs_dev;
+  // Stage 1-2 state (partitioned ids, shard index, size matrices), double buffered so that
+  // hbk_sharded_prefetch can partition step i+1 while step i's exchanges are on the wire; the
+  // set of the last forward stays untouched for its backward.
+  struct PartSet {
+    hbk::Buffer part_out, shard_index, sizes_dev;
+    int32_t* host_sizes = nullptr;     // pinned [3][N*W]: S, S^T, R as they sit on the device
+    hipEvent_t done = nullptr;         // partition + size exchange + D2H copy finished
+    std::vector<const int64_t*> ids;   // what was partitioned (match key of a prefetch)
+    std::vector<int64_t> n_ids;
+    bool pending = false;              // prefetched, not consumed yet
+  } ps[2];
+  int cur;                             // set of the last forward
+  hipStream_t pre_stream;              // prefetch work runs here
+  hipEvent_t step_begin;               // caller's stream at the entry of the last forward: all
+                                       // readers of the OTHER set (previous step) are before it
+  bool prefetch_used;                  // a prefetch was issued at some point
   int64_t* host_runs;   // pinned [5][N*W], column-major: run starts / bases of the stitch, then
                         // run starts / id offsets / gradient offsets of the owner-side backward
 };
@@ -315,7 +329,10 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
     if (cols[c].bucket <= 0 || cols[c].bucket > 0x7fffffffll) p->id32 = false;
   }
   p->have_step = false;
-  p->host_sizes = nullptr;
+  p->cur = 0;
+  p->pre_stream = nullptr;
+  p->step_begin = nullptr;
+  p->prefetch_used = false;
   p->host_runs = nullptr;
   for (auto& st : p->ev) {
     for (auto& e : st) {
@@ -325,14 +342,20 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
       }
     }
   }
-  if (hipHostMalloc(reinterpret_cast<void**>(&p->host_sizes),
-                    sizeof(int32_t) * 3 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
-          hipSuccess ||
+  bool ok = hipStreamCreateWithFlags(&p->pre_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&p->step_begin, hipEventDisableTiming) == hipSuccess;
+  for (auto& set : p->ps) {
+    ok = ok && hipEventCreateWithFlags(&set.done, hipEventDisableTiming) == hipSuccess &&
+         hipHostMalloc(reinterpret_cast<void**>(&set.host_sizes),
+                       sizeof(int32_t) * 3 * (size_t)n_cols * p->W,
+                       hipHostMallocDefault) == hipSuccess;
+  }
+  if (!ok ||
       hipHostMalloc(reinterpret_cast<void**>(&p->host_runs),
                     sizeof(int64_t) * 5 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
           hipSuccess) {
-    delete p;
-    return fail(HBK_INTERNAL, "sharded_create: hipHostMalloc failed");
+    hbk_sharded_destroy(p);
+    return fail(HBK_INTERNAL, "sharded_create: could not create streams / events / pinned memory");
   }
   *plan = p;
   return HBK_OK;
@@ -340,12 +363,20 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
 
 extern "C" int hbk_sharded_destroy(hbk_sharded_t p) {
   if (p == nullptr) return HBK_OK;
-  for (hbk::Buffer* b : {&p->ids_bucketized, &p->part_out, &p->shard_index, &p->sizes_dev,
-                         &p->part_ws, &p->send_ids, &p->recv_ids, &p->send_rows, &p->recv_rows,
+  if (p->pre_stream) (void)hipStreamSynchronize(p->pre_stream);
+  for (hbk::Buffer* b : {&p->part_ws, &p->send_ids, &p->recv_ids, &p->send_rows, &p->recv_rows,
                          &p->wire_ws, &p->bwd_ws, &p->runs_dev}) {
     b->release();
   }
-  if (p->host_sizes) (void)hipHostFree(p->host_sizes);
+  for (auto& set : p->ps) {
+    set.part_out.release();
+    set.shard_index.release();
+    set.sizes_dev.release();
+    if (set.host_sizes) (void)hipHostFree(set.host_sizes);
+    if (set.done) (void)hipEventDestroy(set.done);
+  }
+  if (p->step_begin) (void)hipEventDestroy(p->step_begin);
+  if (p->pre_stream) (void)hipStreamDestroy(p->pre_stream);
   if (p->host_runs) (void)hipHostFree(p->host_runs);
   for (auto& st : p->ev) {
     for (auto& e : st) (void)hipEventDestroy(e);
@@ -386,6 +417,54 @@ int exchange(hbk_sharded* p, int32_t dtype, int32_t wire, const void* in, const 
                           wire_ws, wire_ws_bytes, stream, before, after);
 }
 
+// Stages 1-2 of a step into `set`: bucketize + stable partition of all columns, ONE [N x W] size
+// exchange, sizes to the host (asynchronously: set.done fires when they have arrived).
+int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* const* ids,
+                  const int64_t* n_ids, hipStream_t stream) {
+  const int N = p->N, W = p->W;
+  int64_t total = 0;
+  for (int c = 0; c < N; ++c) {
+    HBK_REQUIRE(n_ids[c] >= 0 && n_ids[c] < (1ll << 31), "sharded lookup: bad n_ids[%d]", c);
+    total += n_ids[c];
+  }
+  int rc;
+  if ((rc = set.part_out.ensure((size_t)total * 8 + 8)) != HBK_OK) return rc;
+  if ((rc = set.shard_index.ensure((size_t)total * 4 + 8)) != HBK_OK) return rc;
+  if ((rc = set.sizes_dev.ensure((size_t)N * W * 4 * 3)) != HBK_OK) return rc;
+  std::vector<int64_t*> pout(N);
+  std::vector<int32_t*> sizes(N), idx(N);
+  std::vector<int64_t> buckets(N);
+  int32_t* sizes_dev = reinterpret_cast<int32_t*>(set.sizes_dev.ptr);       // S [N][W]
+  int32_t* sizes_t = sizes_dev + (size_t)N * W;                            // S^T [W][N]
+  int32_t* recv_t = sizes_t + (size_t)N * W;                               // R [W][N]
+  int64_t off = 0;
+  for (int c = 0; c < N; ++c) {
+    pout[c] = reinterpret_cast<int64_t*>(set.part_out.ptr) + off;
+    idx[c] = reinterpret_cast<int32_t*>(set.shard_index.ptr) + off;
+    sizes[c] = sizes_dev + (size_t)c * W;
+    buckets[c] = p->cols[c].bucket;
+    off += n_ids[c];
+  }
+  const size_t ws = hbk_partition_workspace_bytes(N, n_ids, W);
+  if ((rc = p->part_ws.ensure(ws + 8)) != HBK_OK) return rc;
+  rc = partition_by_modulo_fused(N, W, ids, n_ids, buckets.data(), pout.data(), sizes.data(),
+                                 idx.data(), sizes_t, p->part_ws.ptr, p->part_ws.bytes, stream);
+  if (rc != HBK_OK) return rc;
+  const void* sin[1] = {sizes_t};
+  void* sout[1] = {recv_t};
+  const int64_t cnt[1] = {(int64_t)N * W};
+  rc = hbk_alltoall_n(p->comm, 1, HBK_INT32, HBK_TOPOLOGY_ALL, sin, cnt, sout,
+                      reinterpret_cast<hbk_stream_t>(stream));
+  if (rc != HBK_OK) return rc;
+  // S, S^T and R sit back to back: one copy brings S and R to the host
+  HBK_HIP_OK(hipMemcpyAsync(set.host_sizes, sizes_dev, sizeof(int32_t) * 3 * N * W,
+                            hipMemcpyDeviceToHost, stream));
+  HBK_HIP_OK(hipEventRecord(set.done, stream));
+  set.ids.assign(ids, ids + N);
+  set.n_ids.assign(n_ids, n_ids + N);
+  return HBK_OK;
+}
+
 // Number of column groups the step pipelines.  More groups hide more of the gather / stitch
 // behind the exchanges (exposed compute ~ 1/G of it) at the price of G x more launches and
 // smaller kernels: measured on one rank 298 us (G = 1), 318 us (G = 2), 455 us (G = 4) per
@@ -411,7 +490,6 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   HBK_REQUIRE(ids && n_ids && outs, "sharded_lookup_fwd: NULL argument array");
   hipStream_t stream = as_stream(stream_);
   const int N = p->N, W = p->W;
-  int64_t total = 0;
   p->n_ids.assign(n_ids, n_ids + N);
   p->n_seg.resize(N);
   p->row_splits.resize(N);
@@ -421,7 +499,6 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     HBK_REQUIRE(p->row_splits[c] == nullptr || n_segments != nullptr,
                 "sharded_lookup_fwd: n_segments is NULL");
     p->n_seg[c] = p->row_splits[c] ? n_segments[c] : n_ids[c];
-    total += n_ids[c];
   }
   int rc;
   // HBK_SHARDED_TRACE=1: host-side time of the step's phases on stderr (us)
@@ -431,47 +508,49 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   };
   const auto t_begin = now();
-  // ---- 1 bucketize + stable partition (one kernel chain; S and S^T come out of the scan) ------
-  if ((rc = p->part_out.ensure((size_t)total * 8 + 8)) != HBK_OK) return rc;
-  if ((rc = p->shard_index.ensure((size_t)total * 4 + 8)) != HBK_OK) return rc;
-  if ((rc = p->sizes_dev.ensure((size_t)N * W * 4 * 3)) != HBK_OK) return rc;
+  // ---- 1-2 partition + size exchange: taken from a matching prefetch, else done now -----------
+  int use = -1;
+  for (int k = 0; k < 2; ++k) {
+    hbk_sharded::PartSet& cand = p->ps[k];
+    if (!cand.pending) continue;
+    bool same = true;
+    for (int c = 0; c < N && same; ++c) same = cand.ids[c] == ids[c] && cand.n_ids[c] == n_ids[c];
+    if (same) {
+      use = k;
+    }
+    cand.pending = false;   // a prefetch that is not consumed by the next forward is dropped
+  }
+  const bool prefetched = use >= 0;
+  if (!prefetched) {
+    use = p->cur ^ 1;       // never the set the last forward (and its backward) lives in
+    if (p->prefetch_used) {
+      // a dropped prefetch may still be writing that set / the partition workspace on pre_stream
+      HBK_HIP_OK(hipStreamWaitEvent(stream, p->ps[0].done, 0));
+      HBK_HIP_OK(hipStreamWaitEvent(stream, p->ps[1].done, 0));
+    }
+    HBK_HIP_OK(hipEventRecord(p->step_begin, stream));
+    if ((rc = run_partition(p, p->ps[use], ids, n_ids, stream)) != HBK_OK) return rc;
+  } else {
+    HBK_HIP_OK(hipEventRecord(p->step_begin, stream));
+  }
+  hbk_sharded::PartSet& set = p->ps[use];
+  p->cur = use;
+  const double t_enq1 = us_since(t_begin);
+  HBK_HIP_OK(hipEventSynchronize(set.done));   // the step's one host wait: sizes are on the host
+  if (prefetched) HBK_HIP_OK(hipStreamWaitEvent(stream, set.done, 0));
+  const double t_sync = us_since(t_begin);
+  p->send_sizes.assign(set.host_sizes, set.host_sizes + (size_t)N * W);
+  p->recv_sizes.assign(set.host_sizes + 2 * (size_t)N * W, set.host_sizes + 3 * (size_t)N * W);
   std::vector<int64_t*> pout(N);
-  std::vector<int32_t*> sizes(N), idx(N);
-  int32_t* sizes_dev = reinterpret_cast<int32_t*>(p->sizes_dev.ptr);       // S [N][W]
-  int32_t* sizes_t = sizes_dev + (size_t)N * W;                            // S^T [W][N]
-  int32_t* recv_t = sizes_t + (size_t)N * W;                               // R [W][N]
+  std::vector<int32_t*> idx(N);
   {
-    std::vector<int64_t> buckets(N);
     int64_t off = 0;
     for (int c = 0; c < N; ++c) {
-      pout[c] = reinterpret_cast<int64_t*>(p->part_out.ptr) + off;
-      idx[c] = reinterpret_cast<int32_t*>(p->shard_index.ptr) + off;
-      sizes[c] = sizes_dev + (size_t)c * W;
-      buckets[c] = p->cols[c].bucket;
+      pout[c] = reinterpret_cast<int64_t*>(set.part_out.ptr) + off;
+      idx[c] = reinterpret_cast<int32_t*>(set.shard_index.ptr) + off;
       off += n_ids[c];
     }
-    const size_t ws = hbk_partition_workspace_bytes(N, n_ids, W);
-    if ((rc = p->part_ws.ensure(ws + 8)) != HBK_OK) return rc;
-    rc = partition_by_modulo_fused(N, W, ids, n_ids, buckets.data(), pout.data(), sizes.data(),
-                                   idx.data(), sizes_t, p->part_ws.ptr, p->part_ws.bytes, stream);
-    if (rc != HBK_OK) return rc;
   }
-  // ---- 2 one size exchange for all columns, one host sync -----------------------------------
-  {
-    const void* sin[1] = {sizes_t};
-    void* sout[1] = {recv_t};
-    const int64_t cnt[1] = {(int64_t)N * W};
-    rc = hbk_alltoall_n(p->comm, 1, HBK_INT32, HBK_TOPOLOGY_ALL, sin, cnt, sout, stream_);
-    if (rc != HBK_OK) return rc;
-  }
-  // S, S^T and R sit back to back: one copy brings S and R to the host
-  HBK_HIP_OK(hipMemcpyAsync(p->host_sizes, sizes_dev, sizeof(int32_t) * 3 * N * W,
-                            hipMemcpyDeviceToHost, stream));
-  const double t_enq1 = us_since(t_begin);
-  HBK_HIP_OK(hipStreamSynchronize(stream));
-  const double t_sync = us_since(t_begin);
-  p->send_sizes.assign(p->host_sizes, p->host_sizes + (size_t)N * W);
-  p->recv_sizes.assign(p->host_sizes + 2 * (size_t)N * W, p->host_sizes + 3 * (size_t)N * W);
   const int32_t* S = p->send_sizes.data();
   const int32_t* R = p->recv_sizes.data();
   // ---- 3..6 pipelined over column groups ------------------------------------------------------
@@ -664,9 +743,38 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   p->have_step = true;
   if (trace) {
     fprintf(stderr, "hbk_sharded_lookup_fwd host us: enqueue partition+sizes %.1f, sync wait %.1f, "
-                    "enqueue rest %.1f (G = %d, W = %d)\n",
-            t_enq1, t_sync - t_enq1, us_since(t_begin) - t_sync, G, W);
+                    "enqueue rest %.1f (G = %d, W = %d%s)\n",
+            t_enq1, t_sync - t_enq1, us_since(t_begin) - t_sync, G, W,
+            prefetched ? ", partition prefetched" : "");
   }
+  return HBK_OK;
+}
+
+// Partition (stages 1-2) of a FUTURE step on the plan's own stream, so that it overlaps whatever
+// the caller's stream still has in flight (the exchanges of the step just launched).  The next
+// hbk_sharded_lookup_fwd with the same id pointers and counts picks the result up; any other
+// forward drops it.  Every rank must prefetch the same steps (the size exchange is a collective).
+extern "C" int hbk_sharded_prefetch(hbk_sharded_t p, const int64_t* const* ids,
+                                    const int64_t* n_ids, void* ids_ready_event) {
+  using namespace hbk;
+  HBK_REQUIRE(p != nullptr && ids && n_ids, "sharded_prefetch: NULL argument");
+  hbk_sharded::PartSet& set = p->ps[p->cur ^ 1];
+  p->ps[0].pending = p->ps[1].pending = false;
+  p->prefetch_used = true;
+  // pre_stream may start once (a) the ids exist, (b) everything of the step BEFORE the last
+  // forward has drained (it read the set that is overwritten now) and (c) the last forward's own
+  // partition is through with the shared partition workspace -- not after the last forward's
+  // exchanges, gather and stitch: those are what this overlaps.
+  if (ids_ready_event != nullptr) {
+    HBK_HIP_OK(hipStreamWaitEvent(p->pre_stream, reinterpret_cast<hipEvent_t>(ids_ready_event), 0));
+  }
+  if (p->have_step) {
+    HBK_HIP_OK(hipStreamWaitEvent(p->pre_stream, p->step_begin, 0));
+    HBK_HIP_OK(hipStreamWaitEvent(p->pre_stream, p->ps[p->cur].done, 0));
+  }
+  int rc = run_partition(p, set, ids, n_ids, p->pre_stream);
+  if (rc != HBK_OK) return rc;
+  set.pending = true;
   return HBK_OK;
 }
 
@@ -717,7 +825,7 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
       h.dim = p->cols[cc].dim;
       h.combiner = p->cols[cc].combiner;
       h.n_ids = p->n_ids[cc];
-      h.index = reinterpret_cast<const int32_t*>(p->shard_index.ptr) + ioff[cc];
+      h.index = reinterpret_cast<const int32_t*>(p->ps[p->cur].shard_index.ptr) + ioff[cc];
       h.row_splits = p->row_splits[cc];
       h.n_segments = p->n_seg[cc];
       h.grad_out = grads[cc];

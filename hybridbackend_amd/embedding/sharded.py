@@ -193,6 +193,16 @@ class ShardedGroupLookup:
       self._plan(), *bound.args, _lib.current_stream(self.device)))
     return bound.outs
 
+  def prefetch(self, bound, ids_ready=None):
+    """Pipelining hint: run bucketize + partition + size exchange of a FUTURE step (a
+    ``bind()`` result) on the plan's own stream now, overlapping the exchanges of the step that
+    was just launched; the next ``launch(bound)`` picks the result up.  ``ids_ready``: a
+    ``torch.cuda.Event`` recorded after the ids were produced (None: they are complete).  All
+    ranks must prefetch the same steps."""
+    ev = C.c_void_p(ids_ready.cuda_event) if ids_ready is not None else None
+    _lib.check(self._lib.hbk_sharded_prefetch(self._plan(), bound.args[0], bound.args[1], ev))
+    self._keep_prefetch = bound.keep
+
   def __call__(self, ids, row_splits=None, outs=None):
     """One forward step through the communicator.  ``ids[c]``: int64 device vector;
     ``row_splits[c]``: int32 device vector or None.  Returns the per-column outputs."""

@@ -413,6 +413,14 @@ int hbk_sharded_destroy(hbk_sharded_t plan);
 int hbk_sharded_lookup_fwd(hbk_sharded_t plan, const int64_t* const* ids, const int64_t* n_ids,
                            const int32_t* const* row_splits, const int64_t* n_segments,
                            float* const* outs, const int32_t* out_strides, hbk_stream_t stream);
+/* Optional pipelining hint: partition + size exchange (stages 1-2) of a FUTURE step on the plan's
+ * own stream, overlapping what the last forward still has in flight (its exchanges, gather and
+ * stitch).  The next hbk_sharded_lookup_fwd with the same id pointers and counts uses it and
+ * skips its own stages 1-2; any other forward drops it.  All ranks must prefetch the same steps;
+ * the ids must stay valid and unchanged until that forward. */
+int hbk_sharded_prefetch(hbk_sharded_t plan, const int64_t* const* ids, const int64_t* n_ids,
+                         void* ids_ready_event /* hipEvent_t recorded after the ids were written,
+                                                  or NULL when they are complete already */);
 int64_t hbk_sharded_owned_ids(hbk_sharded_t plan, int32_t column);
 int hbk_sharded_lookup_bwd(hbk_sharded_t plan, const float* const* grads,
                            const int32_t* grad_strides, float apply_lr,

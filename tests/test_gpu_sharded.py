@@ -627,3 +627,68 @@ def test_dense_features_adagrad_sharded_in_process_world():
         np.testing.assert_allclose(results[r][0][k], t64 - 0.05 * per_rank[r] / np.sqrt(a),
                                    rtol=1e-5, atol=1e-6)
     off += c.dimension
+
+
+@pytest.mark.parametrize('world', [1, 3])
+def test_sharded_prefetch_next_step(world):
+  """hbk_sharded_prefetch: step i + 1 is partitioned on the plan's own stream while step i is in
+  flight; a matching forward consumes it, a non-matching one drops it; the backward of step i
+  still sees step i's shard index.  Results equal the unprefetched driver (= the oracle)."""
+  import threading
+  rng = np.random.RandomState(95)
+  dims, rows = [16, 8], [50021, 300]
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(2)]
+  steps = 4
+  ids = [[[rng.randint(0, 2**40, size=rng.randint(1, 3000)).astype(np.int64) for _ in range(2)]
+          for _ in range(steps)] for _ in range(world)]
+  grads = [[[rng.randn(ids[r][s][c].size, dims[c]).astype(np.float32) for c in range(2)]
+            for s in range(steps)] for r in range(world)]
+  if world == 1:
+    comms = [hb.distribute.Collective(world_size=1, rank=0)]       # real RCCL communicator
+  else:
+    comms = hb.distribute.Collective.local_world(world)
+  results, errors = [None] * world, []
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        drv = ShardedGroupLookup([dev(t[r::world].copy()) for t in tables], comms[r],
+                                 buckets=rows, combiners='sum')
+        bound = [drv.bind([dev(i) for i in ids[r][s]]) for s in range(steps)]
+        got = []
+        for s in range(steps):
+          outs = drv.launch(bound[s])
+          if s + 1 < steps:
+            # step 2's prefetch names the wrong batch (step 0 again): it must be dropped
+            drv.prefetch(bound[0] if s == 1 else bound[s + 1])
+          sl = drv.backward([dev(g) for g in grads[r][s]])
+          torch.cuda.current_stream().synchronize()
+          got.append(([o.cpu().numpy() for o in outs],
+                      [(u.cpu().numpy()[:int(k.item())], g.cpu().numpy()[:int(k.item())])
+                       for u, g, k in sl]))
+        results[r] = got
+        drv.close()
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((r, repr(e)))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=120)
+  for cm in comms:
+    cm.close()
+  assert not errors, errors
+  for s in range(steps):
+    for r in range(world):
+      want = oracle.group_lookup_fwd(tables, ids[r][s], [None, None], rows, ['sum', 'sum'])
+      for c in range(2):
+        np.testing.assert_equal(results[r][s][0][c], want[c])
+    for c in range(2):
+      dense = np.zeros((rows[c], dims[c]), np.float64)
+      got = np.zeros_like(dense)
+      for r in range(world):
+        np.add.at(dense, ids[r][s][c] % rows[c], grads[r][s][c].astype(np.float64))
+        lr_, g_ = results[r][s][1][c]
+        got[lr_ * world + r] += g_
+      np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5)

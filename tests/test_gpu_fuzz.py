@@ -103,6 +103,23 @@ def test_group_lookup_forward_backward_random(cols, seed):
     mag = np.zeros_like(dense)
     np.add.at(mag, rows, np.abs(g_id))
     assert np.all(np.abs(got - dense) <= 1e-5 * np.maximum(mag, 1e-30) + 1e-12)
+  # the fused optimizer step equals the oracle's step applied to the emitted slices, bit for bit
+  opt = 'adagrad' if seed % 2 else 'sgd'
+  t2 = [dev(t.copy()) for t in tables]
+  a2 = [torch.full_like(t, 0.1) for t in t2]
+  lookup2 = hb.embedding.GroupLookup(t2, buckets, combs)
+  res2 = hb.embedding.GroupLookupGrad(lookup2, accums=a2)(
+    d_ids, [dev(g) for g in grads], d_sp, apply_lr=0.03, optimizer=opt)
+  for k in range(len(cols)):
+    u, g, nu = res2[k]
+    n = int(nu.item())
+    want_t, want_a = tables[k].copy(), np.full(tables[k].shape, 0.1, np.float32)
+    if opt == 'adagrad':
+      oracle.sparse_adagrad_apply(want_t, want_a, u.cpu().numpy()[:n], g.cpu().numpy()[:n], 0.03)
+      np.testing.assert_equal(a2[k].cpu().numpy(), want_a)
+    else:
+      oracle.sparse_sgd_apply(want_t, u.cpu().numpy()[:n], g.cpu().numpy()[:n], 0.03)
+    np.testing.assert_equal(t2[k].cpu().numpy(), want_t)
 
 
 @_cfg(80)

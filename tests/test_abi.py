@@ -113,3 +113,74 @@ def test_shard_sizing_rule_matches_oracle():
     [hb.embedding.sharded_bucket_size(10, 4, r)[1] for r in range(4)]
   with pytest.raises(ValueError):
     hb.embedding.sharded_bucket_size(10, 4, 4)
+
+
+def test_argument_checks_of_every_entry_family():
+  """Each entry validates its arguments before any device work and answers with the reference's
+  InvalidArgument code and a message naming the problem (partition_by_modulo_ops.cc:81-83 style),
+  so the checks are testable without a GPU."""
+  lib = _lib.lib()
+  bad = _lib.INVALID_ARGUMENT
+
+  def msg():
+    return lib.hbk_last_error().decode()
+
+  one_i64 = _lib.i64_array([4])
+  null1 = _lib.ptr_array([None])
+  # R1 / R6
+  assert lib.hbk_floormod_n(1, _lib.FLOAT, null1, one_i64, one_i64, null1, None) == bad
+  assert lib.hbk_floormod_n(1, _lib.INT64, null1, one_i64, None, null1, None) == bad
+  assert lib.hbk_cast_n(1, _lib.INT32, _lib.HALF, null1, one_i64, null1, None) == bad
+  assert 'float->half' in msg()
+  # R7
+  assert lib.hbk_unique_n(-1, None, None, None, None, None, None, C.c_size_t(0), None) == bad
+  # R8-R10: one column with a bad field each
+  col = (_lib.LookupColumn * 1)()
+  col[0].dim, col[0].divisor = 0, 1
+  assert lib.hbk_group_lookup_fwd(1, col, None) == bad and 'dim' in msg()
+  col[0].dim, col[0].ids_dtype = 16, _lib.FLOAT
+  assert lib.hbk_group_lookup_fwd(1, col, None) == bad and 'int32 or int64' in msg()
+  col[0].ids_dtype, col[0].divisor = _lib.INT64, 0
+  assert lib.hbk_group_lookup_fwd(1, col, None) == bad and 'divisor' in msg()
+  col[0].divisor, col[0].combiner = 1, 7
+  assert lib.hbk_group_lookup_fwd(1, col, None) == bad and 'combiner' in msg()
+  gcol = (_lib.LookupGradColumn * 1)()
+  gcol[0].dim, gcol[0].divisor, gcol[0].ids_dtype = 16, 1, _lib.INT64
+  gcol[0].n_ids, gcol[0].n_segments = 4, 5        # no row_splits: segments must equal ids
+  assert lib.hbk_group_lookup_bwd(1, gcol, C.c_float(0.0), None, C.c_size_t(0), None) == bad
+  assert 'n_segments' in msg()
+  assert lib.hbk_group_lookup_bwd_apply(1, gcol, 5, C.c_float(0.1), None, C.c_size_t(0),
+                                        None) == bad and 'HBK_APPLY' in msg()
+  # R11
+  assert lib.hbk_cache_probe(None, 4, 0, None, 0, None, None, None) == bad
+  assert 'cache_slab_size' in msg()
+  assert lib.hbk_cache_probe(None, 0, 32, None, 0, None, None, None) == bad
+  assert lib.hbk_cache_lookup(None, 4, 32, None, 0, None, None, None, None, None, None,
+                              C.c_size_t(0), None) == bad and 'counts' in msg()
+  # R4 / R5 / aggregation: no communicator
+  assert lib.hbk_alltoall_n(None, 1, _lib.INT32, 0, null1, one_i64, null1, None) == bad
+  assert lib.hbk_alltoallv_n(None, 1, _lib.FLOAT, _lib.FLOAT, 0, one_i64, null1, None, null1,
+                             None, None, C.c_size_t(0), None) == bad
+  assert lib.hbk_allreduce_n(None, 1, _lib.FLOAT, 0, null1, one_i64, null1, C.c_float(1.0),
+                             None, C.c_size_t(0), None) == bad
+  assert lib.hbk_allgatherv(None, _lib.FLOAT, None, None, None, None) == bad
+  handle = C.c_void_p()
+  ident = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+  assert lib.hbk_comm_create(C.byref(handle), ident, 0, 1, 0) == bad and 'world_size' in msg()
+  assert lib.hbk_comm_create(C.byref(handle), ident, 8, 3, 0) == bad and 'local_size' in msg()
+  assert lib.hbk_comm_create(C.byref(handle), ident, 8, 8, 8) == bad and 'rank' in msg()
+  # R12: plan creation and the host layout
+  plan = C.c_void_p()
+  assert lib.hbk_sharded_create(C.byref(plan), None, 1, None, _lib.FLOAT) == bad
+  assert lib.hbk_sharded_lookup_fwd(None, None, None, None, None, None, None, None) == bad
+  assert lib.hbk_sharded_prefetch(None, None, None, None) == bad
+  assert lib.hbk_sharded_owned_ids(None, 0) == -1
+  dims = np.array([16, 0], np.int32)
+  sz = np.zeros(4, np.int32)
+  p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+  assert lib.hbk_sharded_layout(2, 2, p(dims), p(sz), p(sz), *([None] * 9)) == bad
+  # workspace queries answer 0 for nonsense instead of failing
+  assert lib.hbk_unique_workspace_bytes(0, None) == 0
+  assert lib.hbk_group_lookup_bwd_workspace_bytes(0, None) == 0
+  assert lib.hbk_allreduce_workspace_bytes(1, one_i64, _lib.FLOAT) == 0   # one tensor: in place
+  assert lib.hbk_cache_lookup_workspace_bytes(0) == 0

@@ -1,6 +1,7 @@
 """Embedding ops of the sharded lookup path
 (host mirror of ``hybridbackend/tensorflow/embedding``)."""
 from hybridbackend_amd.embedding import cache
+from hybridbackend_amd.embedding.hierarchical import HierarchicalGroupLookup
 from hybridbackend_amd.embedding.lookup import GroupLookup
 from hybridbackend_amd.embedding.lookup import GroupLookupGrad
 from hybridbackend_amd.embedding.lookup import group_lookup

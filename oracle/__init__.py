@@ -369,6 +369,56 @@ def sharded_lookup_fwd(shards, ids_per_rank, wire_f16=False, keep=False):
   return outs
 
 
+def _group_alltoallv(values, sizes, groups):
+  """alltoallv inside disjoint rank groups (Topology.INTRA_NODE / INTER_NODE: active ranks of
+  hbtf/distribute/collective.h:80-112): groups = list of rank lists; values[r] holds the chunks
+  for the members of r's group in group order.  Returns (recv_values, recv_sizes) indexed by
+  global rank."""
+  world = len(values)
+  recv_v, recv_s = [None] * world, [None] * world
+  for g in groups:
+    rv, rs = alltoallv_sim([values[r] for r in g], [sizes[r] for r in g])
+    for k, r in enumerate(g):
+      recv_v[r], recv_s[r] = rv[k], rs[k]
+  return recv_v, recv_s
+
+
+def hierarchical_lookup_fwd(shards, ids_per_rank, local_size):
+  """One column through the two-staged lookup of multi-node jobs,
+  hbtf/embedding/sharding.py:210-276: ids first travel inside the node to the GPU whose LOCAL
+  index owns them (dual-modulo stage 1, intra-node alltoallv, unique), then across nodes to the
+  owning rank (stage 2, inter-node alltoallv, unique), rows come back the same way.
+  shards[r]: rank r's rows (id mod W == r, local row = id // W); W = len(shards),
+  nodes = W // local_size.  Returns per-rank embeddings in requester order."""
+  world = len(shards)
+  L = int(local_size)
+  assert world % L == 0
+  M = world // L
+  intra = [list(range(n * L, (n + 1) * L)) for n in range(M)]           # same node
+  inter = [[m * L + l for m in range(M)] for l in range(L)]             # same local index
+  # stage one: shard = (id mod (L*M)) mod L  (:224-228), intra-node exchange (:229-232)
+  p0 = [partition_by_dual_modulo(np.asarray(ids_per_rank[r], np.int64), L, M, 1)
+        for r in range(world)]
+  s0_ids, s0_sizes = _group_alltoallv([p[0] for p in p0], [p[1] for p in p0], intra)
+  u0 = [unique(s0_ids[r]) for r in range(world)]                        # :234-236
+  # stage two: shard = (id mod (M*L)) div L = the node (:237-240), inter-node exchange (:241-244)
+  p1 = [partition_by_dual_modulo(u0[r][0], M, L, 2) for r in range(world)]
+  s1_ids, s1_sizes = _group_alltoallv([p[0] for p in p1], [p[1] for p in p1], inter)
+  send = []
+  for r in range(world):
+    uniq, uidx = unique(s1_ids[r])                                      # :245-247
+    assert np.all(uniq % world == r)                                    # this rank owns them
+    emb = gather(shards[r], uniq // world)                              # :249-254
+    send.append(np.ascontiguousarray(emb[uidx] if uidx.size else emb[:0]))   # :256-258
+  back1, _ = _group_alltoallv(send, s1_sizes, inter)                    # :260-264
+  send0 = []
+  for r in range(world):
+    e = back1[r][p1[r][2]] if p1[r][2].size else back1[r][:0]           # :265-267 s1 stitch
+    send0.append(np.ascontiguousarray(e[u0[r][1]] if u0[r][1].size else e[:0]))  # :268-270
+  back0, _ = _group_alltoallv(send0, s0_sizes, intra)                   # :272-276
+  return [back0[r][p0[r][2]] if p0[r][2].size else back0[r][:0] for r in range(world)]
+
+
 def sharded_lookup_bwd(kept, grads_per_rank, world):
   """Reverse of sharded_lookup_fwd for one column.  grads_per_rank[r]:
   [n_r, D] grads w.r.t. the stitched embeddings.  Returns per-rank

@@ -692,3 +692,80 @@ def test_sharded_prefetch_next_step(world):
         lr_, g_ = results[r][s][1][c]
         got[lr_ * world + r] += g_
       np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------
+# multi-node shape: the two-staged lookup (sharding.py:210-276) with virtual ranks
+def _group_exchange(values, sizes, groups):
+  """values[r][c]: tensor whose rows are chunked by sizes[r][c] (host lists) over r's group, in
+  group order.  Returns (recv_values[r][c], recv_sizes[r][c])."""
+  world, n = len(values), len(values[0])
+  rv = [[None] * n for _ in range(world)]
+  rs = [[None] * n for _ in range(world)]
+  for g in groups:
+    for c in range(n):
+      chunks = {}
+      for q in g:
+        offs = np.concatenate([[0], np.cumsum(sizes[q][c])]).astype(int)
+        for k, r in enumerate(g):
+          chunks[(q, r)] = values[q][c][offs[k]:offs[k + 1]]
+      for r in g:
+        rv[r][c] = torch.cat([chunks[(q, r)] for q in g])
+        rs[r][c] = [int(chunks[(q, r)].shape[0]) for q in g]
+  return rv, rs
+
+
+@pytest.mark.parametrize('local_size,nodes', [(2, 2), (3, 2), (2, 3)])
+def test_hierarchical_lookup_virtual_ranks(local_size, nodes):
+  """Every compute phase of the two-staged lookup on the GPU (dual-modulo partitions, unique,
+  owner gather with `// W`, restores and stitches as fused N-column launches), the exchanges
+  simulated by slicing: the result equals the oracle's restatement of sharding.py:210-276 and the
+  unsharded lookup."""
+  from hybridbackend_amd.embedding import HierarchicalGroupLookup
+  world = local_size * nodes
+  rng = np.random.RandomState(200 + world)
+  dims, rows = [16, 6, 128], [5003, 64, 977]
+  n = len(dims)
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(n)]
+  ids = [[rng.randint(0, 2**40, size=rng.randint(0, 900)).astype(np.int64) for _ in range(n)]
+         for _ in range(world)]
+  drv = [HierarchicalGroupLookup([dev(t[r::world].copy()) for t in tables], world, local_size,
+                                 buckets=rows) for r in range(world)]
+  intra = [list(range(m * local_size, (m + 1) * local_size)) for m in range(nodes)]
+  inter = [[m * local_size + l for m in range(nodes)] for l in range(local_size)]
+  st1 = [drv[r].stage_one([dev(i) for i in ids[r]]) for r in range(world)]
+  h = lambda sizes: [[s.tolist() for s in sizes[r]] for r in range(world)]   # noqa: E731
+  s0_sizes = h([st1[r][1] for r in range(world)])
+  r0, r0_sizes = _group_exchange([st1[r][0] for r in range(world)], s0_sizes, intra)
+  st2 = [drv[r].stage_two(r0[r]) for r in range(world)]
+  s1_sizes = h([st2[r][1] for r in range(world)])
+  r1, r1_sizes = _group_exchange([st2[r][0] for r in range(world)], s1_sizes, inter)
+  emb = [drv[r].owner_gather(r1[r]) for r in range(world)]
+  b1, _ = _group_exchange(emb, r1_sizes, inter)
+  rows0 = [drv[r].unstage_two(b1[r], st2[r][2], st2[r][3]) for r in range(world)]
+  b0, _ = _group_exchange(rows0, r0_sizes, intra)
+  outs = [drv[r].unstage_one(b0[r], st1[r][2]) for r in range(world)]
+  for c in range(n):
+    want = oracle.hierarchical_lookup_fwd(oracle.make_shards(tables[c], world),
+                                          [ids[r][c] % rows[c] for r in range(world)],
+                                          local_size)
+    for r in range(world):
+      np.testing.assert_equal(outs[r][c].cpu().numpy(), want[r])
+      np.testing.assert_equal(want[r], tables[c][ids[r][c] % rows[c]])
+
+
+def test_hierarchical_call_through_rccl_world1():
+  """The whole two-staged forward through a real communicator (world 1: both topologies have
+  one active rank), i.e. the plumbing of the four topology-aware exchanges."""
+  from hybridbackend_amd.embedding import HierarchicalGroupLookup
+  rng = np.random.RandomState(210)
+  tables = [rng.uniform(-1, 1, size=(r, d)).astype(np.float32) for r, d in ((3001, 16), (50, 8))]
+  ids = [rng.randint(0, 2**40, size=k).astype(np.int64) for k in (2000, 0)]
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+  try:
+    drv = HierarchicalGroupLookup([dev(t) for t in tables], 1, 1, buckets=[3001, 50], coll=coll)
+    outs = drv([dev(i) for i in ids])
+    for c in range(2):
+      np.testing.assert_equal(outs[c].cpu().numpy(), tables[c][ids[c] % tables[c].shape[0]])
+  finally:
+    coll.close()

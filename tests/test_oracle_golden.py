@@ -260,3 +260,21 @@ def test_sparse_adagrad_apply_matches_float64():
   np.testing.assert_allclose(t, t64, rtol=1e-6, atol=1e-7)
   untouched = np.setdiff1d(np.arange(50), rows)
   np.testing.assert_equal(t[untouched], table[untouched])
+
+
+@pytest.mark.parametrize('local_size,nodes', [(2, 2), (4, 2), (3, 2), (2, 3), (1, 4), (4, 1)])
+def test_hierarchical_lookup_equals_unsharded(local_size, nodes):
+  """The two-staged lookup of multi-node jobs (sharding.py:210-276: dual-modulo stage 1 +
+  intra-node alltoallv, stage 2 + inter-node alltoallv, and back) returns exactly the rows of the
+  unsharded table, whatever the node shape."""
+  world = local_size * nodes
+  rng = np.random.RandomState(100 + world)
+  table = rng.uniform(-1, 1, size=(1009, 8)).astype(np.float32)
+  shards = oracle.make_shards(table, world)
+  ids = [rng.randint(0, 1009, size=rng.randint(0, 400)).astype(np.int64) for _ in range(world)]
+  ids[0] = np.zeros(0, np.int64) if world > 1 else ids[0]
+  got = oracle.hierarchical_lookup_fwd(shards, ids, local_size)
+  flat = oracle.sharded_lookup_fwd(shards, ids)
+  for r in range(world):
+    np.testing.assert_equal(got[r], table[ids[r]])
+    np.testing.assert_equal(got[r], flat[r])

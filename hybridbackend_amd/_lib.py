@@ -116,6 +116,7 @@ def _declare(l):
     'hbk_local_world_create': (C.c_int, [vp, i32]),
     'hbk_local_world_destroy': (C.c_int, [vp]),
     'hbk_comm_create_local': (C.c_int, [vp, vp, i32]),
+    'hbk_comm_set_local_size': (C.c_int, [vp, i32]),
     'hbk_sharded_layout': (C.c_int, [i32, i32] + [vp] * 12),
     'hbk_sharded_create': (C.c_int, [vp, vp, i32, vp, i32]),
     'hbk_sharded_destroy': (C.c_int, [vp]),

@@ -119,32 +119,42 @@ int fence_out(hbk_comm* c, hipStream_t compute) {
   return HBK_OK;
 }
 
-// One exchange of the in-process world: every rank publishes (pointer, per-peer offsets and
-// lengths in elements), then copies its chunk out of every peer's buffer on its own stream.
-int local_exchange(hbk_comm* c, const void* sendbuf, const std::vector<int64_t>& send_off,
-                   const std::vector<int64_t>& send_len, void* recvbuf,
-                   const std::vector<int64_t>& recv_off, size_t esize, hipStream_t stream) {
+// One exchange of the in-process world inside `ranks` (the active ranks of the topology; every
+// member of a group has the same list): every rank publishes (pointer, per-peer offsets and
+// lengths in elements, indexed by position in the list), then copies its chunk out of every
+// peer's buffer on its own stream.  All world ranks take part in the barriers (a collective is
+// called by every rank, whatever its group).
+int local_exchange(hbk_comm* c, const std::vector<int>& ranks, const void* sendbuf,
+                   const std::vector<int64_t>& send_off, const std::vector<int64_t>& send_len,
+                   void* recvbuf, const std::vector<int64_t>& recv_off, size_t esize,
+                   hipStream_t stream) {
   LocalWorld* w = c->local;
   const int me = c->rank;
+  int k_me = -1;
+  for (size_t k = 0; k < ranks.size(); ++k) {
+    if (ranks[k] == me) k_me = (int)k;
+  }
+  if (k_me < 0) return fail(HBK_INTERNAL, "local_exchange: rank %d not in its own group", me);
   w->ptr[me] = sendbuf;
   w->off[me] = send_off;
   w->len[me] = send_len;
   HBK_HIP_OK(hipEventRecord(w->ready[me], stream));
   w->barrier();
-  for (int i = 0; i < w->world; ++i) {
-    HBK_HIP_OK(hipStreamWaitEvent(stream, w->ready[i], 0));
-    const int64_t n = w->len[i][me];
+  for (size_t k = 0; k < ranks.size(); ++k) {
+    const int peer = ranks[k];
+    HBK_HIP_OK(hipStreamWaitEvent(stream, w->ready[peer], 0));
+    const int64_t n = w->len[peer][k_me];
     if (n > 0) {
-      HBK_HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(recvbuf) + (size_t)recv_off[i] * esize,
-                                reinterpret_cast<const char*>(w->ptr[i]) +
-                                    (size_t)w->off[i][me] * esize,
+      HBK_HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(recvbuf) + (size_t)recv_off[k] * esize,
+                                reinterpret_cast<const char*>(w->ptr[peer]) +
+                                    (size_t)w->off[peer][k_me] * esize,
                                 (size_t)n * esize, hipMemcpyDeviceToDevice, stream));
     }
   }
   HBK_HIP_OK(hipEventRecord(w->done[me], stream));
   w->barrier();
   // nobody may reuse its send buffer before every peer has copied out of it
-  for (int i = 0; i < w->world; ++i) HBK_HIP_OK(hipStreamWaitEvent(stream, w->done[i], 0));
+  for (int peer : ranks) HBK_HIP_OK(hipStreamWaitEvent(stream, w->done[peer], 0));
   w->barrier();
   return HBK_OK;
 }
@@ -199,6 +209,19 @@ extern "C" int hbk_comm_create_local(hbk_comm_t* comm, void* world, int32_t rank
   c->comm_done = nullptr;
   (void)hipGetDevice(&c->device);
   *comm = c;
+  return HBK_OK;
+}
+
+// test hook: the node shape of an in-process world (local_size GPUs per "node"), so that the
+// INTRA_NODE / INTER_NODE topologies can be exercised with in-process ranks
+extern "C" int hbk_comm_set_local_size(hbk_comm_t comm, int32_t local_size) {
+  using namespace hbk;
+  HBK_REQUIRE(comm != nullptr && comm->local != nullptr,
+              "comm_set_local_size: only for in-process communicators");
+  HBK_REQUIRE(local_size >= 1 && comm->world_size % local_size == 0,
+              "comm_set_local_size: local_size (%d) must divide world_size (%d)", local_size,
+              comm->world_size);
+  comm->local_size = local_size;
   return HBK_OK;
 }
 
@@ -324,7 +347,6 @@ extern "C" int hbk_alltoall_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t
     HBK_REQUIRE(counts[c] == 0 || (inputs[c] && outputs[c]), "alltoall_n: NULL buffer %d", c);
   }
   if (comm->local != nullptr) {
-    HBK_REQUIRE(topology == HBK_TOPOLOGY_ALL, "alltoall_n: local world supports topology ALL");
     for (int32_t c = 0; c < n; ++c) {
       const int64_t part = counts[c] / active;
       std::vector<int64_t> off(active), len(active);
@@ -332,7 +354,7 @@ extern "C" int hbk_alltoall_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t
         off[i] = i * part;
         len[i] = part;
       }
-      int lrc = local_exchange(comm, inputs[c], off, len, outputs[c], off, esize,
+      int lrc = local_exchange(comm, ranks, inputs[c], off, len, outputs[c], off, esize,
                                as_stream(compute_stream));
       if (lrc != HBK_OK) return lrc;
     }
@@ -455,7 +477,6 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
   }
 
   if (comm->local != nullptr) {
-    HBK_REQUIRE(topology == HBK_TOPOLOGY_ALL, "alltoallv_n: local world supports topology ALL");
     hipStream_t cs = as_stream(compute_stream);
     int lrc;
     if (before != nullptr) HBK_HIP_OK(hipStreamWaitEvent(cs, before, 0));
@@ -481,7 +502,8 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
         so += slen[i];
         ro += (int64_t)recv_sizes[(size_t)c * active + i] * common_sizes[c];
       }
-      if ((lrc = local_exchange(comm, wire_in[c], soff, slen, wire_out[c], roff, esize, cs)) !=
+      if ((lrc = local_exchange(comm, ranks, wire_in[c], soff, slen, wire_out[c], roff, esize,
+                                cs)) !=
           HBK_OK) {
         return lrc;
       }
@@ -856,7 +878,9 @@ extern "C" int hbk_allgatherv(hbk_comm_t comm, int32_t dtype, const void* input,
   char* out = reinterpret_cast<char*>(output);
   if (comm->local != nullptr) {
     std::vector<int64_t> soff(W, 0), slen(W, counts[me]), roff(off.begin(), off.end() - 1);
-    return local_exchange(comm, input, soff, slen, output, roff, esize, cs);
+    std::vector<int> all(W);
+    for (int r = 0; r < W; ++r) all[r] = r;
+    return local_exchange(comm, all, input, soff, slen, output, roff, esize, cs);
   }
   std::unique_lock<std::mutex> lock(comm->mu);
   HBK_REQUIRE(!comm->aborted, "allgatherv: communicator was aborted");

@@ -69,10 +69,11 @@ class Collective:
     self._wire_ws = None
 
   @classmethod
-  def local_world(cls, world_size):
+  def local_world(cls, world_size, local_size=None):
     """Test transport: ``world_size`` communicators of one in-process world (one host thread
-    and one stream per rank, all on the current GPU).  Returns the list of communicators;
-    keep a reference to the first one's ``_world`` until all are closed."""
+    and one stream per rank, all on the current GPU); ``local_size`` ranks per "node" for the
+    INTRA_NODE / INTER_NODE topologies.  Returns the list of communicators; keep a reference to
+    the first one's ``_world`` until all are closed."""
     lib = _lib.lib()
     world = C.c_void_p()
     _lib.check(lib.hbk_local_world_create(C.byref(world), world_size))
@@ -85,6 +86,9 @@ class Collective:
       c._wire_ws = None
       c._world = world
       _lib.check(lib.hbk_comm_create_local(C.byref(c._handle), world, r))
+      if local_size is not None:
+        _lib.check(lib.hbk_comm_set_local_size(c._handle, int(local_size)))
+        c.local_size = int(local_size)
       comms.append(c)
     return comms
 

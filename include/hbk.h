@@ -370,6 +370,9 @@ int hbk_allgatherv(hbk_comm_t comm, int32_t dtype, const void* input, const int6
 int hbk_local_world_create(void** world, int32_t world_size);
 int hbk_local_world_destroy(void* world);
 int hbk_comm_create_local(hbk_comm_t* comm, void* world, int32_t rank);
+/* node shape of an in-process communicator (local_size GPUs per "node"): lets INTRA_NODE /
+ * INTER_NODE exchanges run between in-process ranks */
+int hbk_comm_set_local_size(hbk_comm_t comm, int32_t local_size);
 
 /* ------------------------------------------------------------------------------------
  * R12  The whole sharded pipeline of hbtf/embedding/sharding.py:171-205 for N columns in one

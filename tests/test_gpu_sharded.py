@@ -769,3 +769,43 @@ def test_hierarchical_call_through_rccl_world1():
       np.testing.assert_equal(outs[c].cpu().numpy(), tables[c][ids[c] % tables[c].shape[0]])
   finally:
     coll.close()
+
+
+@pytest.mark.parametrize('local_size,nodes', [(2, 2), (3, 2)])
+def test_hierarchical_call_in_process_world(local_size, nodes):
+  """The two-staged forward through the communicator API with INTRA_NODE / INTER_NODE topologies:
+  in-process ranks arranged as `nodes` x `local_size` (active ranks and offsets of
+  hbtf/distribute/collective.h:80-112 inside hbk_alltoall_n / hbk_alltoallv_n)."""
+  import threading
+  from hybridbackend_amd.embedding import HierarchicalGroupLookup
+  world = local_size * nodes
+  rng = np.random.RandomState(220 + world)
+  dims, rows = [16, 4], [5003, 97]
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(2)]
+  ids = [[rng.randint(0, 2**40, size=rng.randint(0, 1200)).astype(np.int64) for _ in range(2)]
+         for _ in range(world)]
+  comms = hb.distribute.Collective.local_world(world, local_size=local_size)
+  results, errors = [None] * world, []
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        drv = HierarchicalGroupLookup([dev(t[r::world].copy()) for t in tables], world,
+                                      local_size, buckets=rows, coll=comms[r])
+        outs = drv([dev(i) for i in ids[r]])
+        torch.cuda.current_stream().synchronize()
+        results[r] = [o.cpu().numpy() for o in outs]
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((r, repr(e)))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=120)
+  for cm in comms:
+    cm.close()
+  assert not errors, errors
+  for r in range(world):
+    for c in range(2):
+      np.testing.assert_equal(results[r][c], tables[c][ids[r][c] % rows[c]])

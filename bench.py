@@ -15,11 +15,23 @@ so nothing is served from L2/MALL by repetition (1.66 GB of tables >> 256 MB).
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM-bound
 gather: algorithmic 136 B/lookup = 8 id + 64 row read + 64 output write) and
 `cpu_baseline` (the oracle's C pipeline timed on the host cores, rank 0, N = 1).
+
+Launching.  `python bench.py --gpus N` is enough: without WORLD_SIZE in the environment and
+N > 1 the script starts N ranks of itself on a free port (one process per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would) and relays rank 0's
+JSON line; launched under `python -m torch.distributed.run --nproc-per-node N ...` it uses the
+environment it is given.  The ranks rendezvous over gloo (host TCP): the barrier, the max over
+ranks and the broadcast of the 128-byte RCCL id need no second RCCL communicator next to the
+library's own.  If fewer than N GPUs are visible a JSON line with an "error" key is printed and
+the exit code is 2.  `--dry-run` exercises launcher + rendezvous without touching a GPU.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,6 +42,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # same guide: 6.29 TB/s measured with a float4 copy (79 % of spec)
 
 
 def parse_args():
@@ -53,7 +66,108 @@ def parse_args():
                  help='N > 1: seconds after which a rank exits instead of waiting for its peers')
   p.add_argument('--id-batches', type=int, default=0,
                  help='distinct id batches kept in HBM (default: steps + warmup, max 64)')
+  p.add_argument('--dry-run', action='store_true',
+                 help='launcher + rendezvous + barrier + reduction only (no GPU, no kernels)')
+  p.add_argument('--link-probe-mb', type=float, default=16.0,
+                 help='N > 1: MB per peer of the equal-split alltoallv that measures the links '
+                      'before the timed steps (0 disables it)')
   return p.parse_args()
+
+
+def _free_port():
+  sock = socket.socket()
+  sock.bind(('127.0.0.1', 0))
+  port = sock.getsockname()[1]
+  sock.close()
+  return port
+
+
+def error_line(args, message):
+  """The one JSON line of a run that could not be measured."""
+  return json.dumps({
+    'metric': 'M-lookups/sec, 26-col Criteo-shape dim16, 1/2/4/8 GPUs; % HBM roofline',
+    'value': None, 'unit': 'M-lookups/sec', 'n_gpus': args.gpus, 'steps': args.steps,
+    'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak',
+    'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'error': message})
+
+
+def launch_ranks(args):
+  """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process
+  per GPU), relay rank 0's JSON line, never leave a rank behind."""
+  n = args.gpus
+  if not args.dry_run:
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < n:
+      print(error_line(args, f'--gpus {n} but only {visible} GPU(s) are visible on this node'),
+            flush=True)
+      return 2
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL across processes needs it
+  env['MASTER_ADDR'] = '127.0.0.1'
+  env['MASTER_PORT'] = str(_free_port())
+  env['WORLD_SIZE'] = env['LOCAL_WORLD_SIZE'] = str(n)
+  procs = []
+  for r in range(n):
+    e = dict(env)
+    e['RANK'] = e['LOCAL_RANK'] = str(r)
+    procs.append(subprocess.Popen(
+      [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+  deadline = time.time() + args.watchdog + 60
+  out0 = ''
+  rc = 0
+  try:
+    out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+    rc = procs[0].returncode
+    for pr in procs[1:]:
+      pr.wait(timeout=max(1.0, deadline - time.time()))
+      rc = rc or pr.returncode
+  except subprocess.TimeoutExpired:
+    rc = 3
+  finally:
+    for pr in procs:       # exact PIDs only
+      if pr.poll() is None:
+        pr.kill()
+  line = None
+  for ln in out0.splitlines():
+    if ln.startswith('{'):
+      line = ln
+  if line is None or rc != 0:
+    if line is None:
+      line = error_line(args, f'rank processes failed (exit code {rc}) before a result was printed')
+    print(line, flush=True)
+    return rc or 1
+  print(line, flush=True)
+  return 0
+
+
+def link_probe(coll, device, world, mb_per_peer, dist):
+  """SURVEY 8e pre-measurement (the equal-split mode of the reference's
+  hybridbackend/tensorflow/benchmarks/collective_benchmark.py:74-102): every rank sends
+  `mb_per_peer` MB to every peer through hbk_alltoallv_n; returns the achieved GB/s per link and
+  direction (slowest rank)."""
+  n = int(mb_per_peer * 1e6 / 4)
+  if n <= 0 or world < 2:
+    return None
+  src = torch.ones(n * world, device=device, dtype=torch.float32)
+  dst = torch.empty_like(src)
+  sizes = [[n] * world]
+  for _ in range(2):
+    coll.alltoallv_n([src], sizes, sizes, common_sizes=[1], outs=[dst])
+  torch.cuda.synchronize()
+  dist.barrier()
+  iters = 5
+  t0 = time.perf_counter()
+  for _ in range(iters):
+    coll.alltoallv_n([src], sizes, sizes, common_sizes=[1], outs=[dst])
+  torch.cuda.synchronize()
+  el = time.perf_counter() - t0
+  t = torch.tensor([el], dtype=torch.float64)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  per = float(t.item()) / iters
+  return {'bytes_per_peer': n * 4, 'us_per_exchange': round(per * 1e6, 1),
+          'GBps_per_link_each_way': round(n * 4 / per / 1e9, 2),
+          'GBps_out_per_rank': round(n * 4 * (world - 1) / per / 1e9, 2)}
 
 
 def make_tables(args, device, rank, world):
@@ -142,30 +256,18 @@ def load_traffic(config_key):
 
 def main():
   args = parse_args()
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    sys.exit(launch_ranks(args))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit(
-        f'--gpus {args.gpus} needs one process per GPU: launch with '
-        f'python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} '
-        '--master-addr 127.0.0.1 --master-port <P> bench.py ...')
     raise SystemExit(f'WORLD_SIZE={world} does not match --gpus {args.gpus}')
-  if not torch.cuda.is_available():
-    raise SystemExit('bench.py needs a GPU (the HIP path is the only path)')
-  torch.cuda.set_device(local_rank)
-  device = torch.device('cuda', local_rank)
-
-  import hybridbackend_amd as hb
-  from hybridbackend_amd import _lib
-  _lib.lib()
-
   use_dist = world > 1 or ('RANK' in os.environ and args.sharded)
+  dist = None
+  watchdog = None
   if use_dist:
     # a rank that dies leaves its peers waiting inside a collective: never hang the node
-    import threading
-
     def _abort():
       sys.stderr.write(f'bench.py: rank {rank} gave up after {args.watchdog} s (a peer is gone '
                        'or a collective hangs)\n')
@@ -174,9 +276,47 @@ def main():
     watchdog = threading.Timer(args.watchdog, _abort)
     watchdog.daemon = True
     watchdog.start()
-    import torch.distributed as dist
+    import torch.distributed as dist   # pylint: disable=redefined-outer-name
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', device_id=device)
+    # host-side rendezvous only (barrier, max over ranks, RCCL-id broadcast): gloo, so that the
+    # library's RCCL communicator is the only one in the process
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+  if args.dry_run:
+    # launcher / rendezvous check without a GPU: the same barrier-bracketed timing skeleton
+    if use_dist:
+      obj = [os.urandom(128) if rank == 0 else None]
+      dist.broadcast_object_list(obj, src=0)
+      assert len(obj[0]) == 128
+      dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    el = time.perf_counter() - t0
+    if use_dist:
+      dist.barrier()
+      t = torch.tensor([el], dtype=torch.float64)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      el = float(t.item())
+    if rank == 0:
+      line = json.loads(error_line(args, 'dry run: launcher and rendezvous only, nothing measured'))
+      line['dry_run'] = True
+      line['ranks'] = world
+      line['max_rank_sleep_ms'] = round(el * 1e3, 2)
+      print(json.dumps(line), flush=True)
+    if use_dist:
+      watchdog.cancel()
+      dist.destroy_process_group()
+    return
+  if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+    if rank == 0:
+      print(error_line(args, 'no GPU visible for this rank: the HIP path is the only path'),
+            flush=True)
+    sys.exit(2)
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+
+  import hybridbackend_amd as hb
+  from hybridbackend_amd import _lib
+  _lib.lib()
 
   n_batches = args.id_batches or min(args.steps + args.warmup, 64)
   n_batches = max(1, n_batches)
@@ -217,8 +357,11 @@ def main():
 
   def barrier():
     if use_dist:
-      import torch.distributed as dist
       dist.barrier()
+
+  probe = None
+  if world > 1 and args.link_probe_mb > 0:
+    probe = link_probe(coll, device, world, args.link_probe_mb, dist)
 
   for i in range(args.warmup):
     step(i)
@@ -239,8 +382,7 @@ def main():
   gpu_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream)
 
   if use_dist:
-    import torch.distributed as dist
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    t = torch.tensor([elapsed], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -255,6 +397,7 @@ def main():
     workload = (f'{args.columns} cols x {args.rows} rows x dim{args.dim} fp32, batch '
                 f'{args.batch}/GPU, 1 id/sample, fused bucketize+gather+combiner')
     key = f'c{args.columns}_r{args.rows}_d{args.dim}_b{args.batch}_n{world}'
+    traffic = load_traffic(key)
     result = {
       'metric': 'M-lookups/sec, 26-col Criteo-shape dim16, 1/2/4/8 GPUs; % HBM roofline',
       'value': round(value, 3), 'unit': 'M-lookups/sec', 'n_gpus': world,
@@ -272,7 +415,13 @@ def main():
                    else 'sharded step (all kernels + exchanges)'),
         'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4),
-        'traffic': load_traffic(key),
+        'traffic': traffic,
+        # what the memory system moved per second (PMC bytes / launch time) and how that stands
+        # against the measured-achievable 6.29 TB/s of the guide: the dim-16 gather is bound by
+        # the rate of random 64-byte row requests, not by bytes
+        'memory_side_GBps': (round(traffic / launch_s / 1e9, 1) if traffic else None),
+        'achievable_frac': (round(traffic / launch_s / 1e9 / HBM_ACHIEVABLE_GBS, 4)
+                            if traffic else None),
         'algorithmic_bytes_per_lookup': bytes_per_lookup,
         'avg_launch_us': round(launch_s * 1e6, 3)},
     }
@@ -286,6 +435,7 @@ def main():
       result['xgmi'] = {
         'bytes_out_per_rank_per_step': int(link_bytes), 'links_per_rank': world - 1,
         'achieved_GBps_per_rank_each_way': round(link_bytes / (elapsed / args.steps) / 1e9, 2),
+        'link_probe': probe,
         'note': 'the sharded step is link-bound (DESIGN.md 5): one xGMI link per peer pair'}
     if world == 1 and not args.sharded and args.cpu_seconds > 0:
       result['cpu_baseline'] = cpu_baseline(args, tables, batches[0], args.cpu_seconds)
@@ -297,7 +447,6 @@ def main():
     sharded.close()
     coll.close()
   if use_dist:
-    import torch.distributed as dist
     watchdog.cancel()
     dist.destroy_process_group()
 

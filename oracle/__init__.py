@@ -248,7 +248,14 @@ def sparse_adagrad_apply(table, accum, rows, g_u, lr):
   assert table.dtype == np.float32 and accum.dtype == np.float32
   g_u = np.ascontiguousarray(g_u, np.float32)
   lr = np.float32(lr)
-  for u, r in enumerate(np.asarray(rows, np.int64)):
+  rows = np.asarray(rows, np.int64)
+  if np.unique(rows).size == rows.size:
+    # distinct rows: the entries do not interact, the same fp32 operations element by element
+    a = accum[rows] + g_u * g_u
+    accum[rows] = a
+    table[rows] = table[rows] - (lr * g_u) * (np.float32(1.0) / np.sqrt(a))
+    return table, accum
+  for u, r in enumerate(rows):
     a = accum[r] + g_u[u] * g_u[u]
     accum[r] = a
     table[r] = table[r] - (lr * g_u[u]) * (np.float32(1.0) / np.sqrt(a))

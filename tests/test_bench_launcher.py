@@ -1,0 +1,53 @@
+"""bench.py's launch paths on CPU: `python bench.py --gpus N` must start its own ranks (the driver
+runs exactly that form), the torch.distributed.run form must work too, and a node without enough
+GPUs must answer with one JSON line carrying "error" and a non-zero exit code -- quickly."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _last_json(out):
+  lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+  assert len(lines) == 1, out
+  return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks_dry_run():
+  r = subprocess.run([sys.executable, BENCH, '--gpus', '2', '--steps', '3', '--warmup', '1',
+                      '--dry-run'], capture_output=True, text=True, timeout=300, cwd=ROOT)
+  assert r.returncode == 0, r.stderr
+  line = _last_json(r.stdout)
+  assert line['dry_run'] is True and line['ranks'] == 2 and line['n_gpus'] == 2
+  assert line['max_rank_sleep_ms'] >= 19.0          # the MAX over ranks (rank 1 sleeps 20 ms)
+  assert line['value'] is None and 'error' in line   # nothing measured, and it says so
+
+
+def test_torchrun_form_two_ranks_dry_run():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                      '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+                      str(port), BENCH, '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run'],
+                     capture_output=True, text=True, timeout=300, cwd=ROOT)
+  assert r.returncode == 0, r.stderr
+  line = _last_json(r.stdout)
+  assert line['dry_run'] is True and line['ranks'] == 2
+
+
+def test_not_enough_gpus_is_a_fast_json_error():
+  import torch
+  if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+    import pytest
+    pytest.skip('this node has 8 GPUs')
+  r = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--steps', '3', '--warmup', '1'],
+                     capture_output=True, text=True, timeout=120, cwd=ROOT)
+  assert r.returncode != 0
+  line = _last_json(r.stdout)
+  assert line['value'] is None and 'only' in line['error'] and line['n_gpus'] == 8

@@ -1,0 +1,314 @@
+"""BASELINE.json configs 3, 4 and 5 at their stated workload shape on one MI355X.
+
+Config 3 (26 columns, 1M x 16 tables row-sharded 8 ways, batch 65536 per rank) and config 5
+(200 columns, dims 4..128, lookup + grad apply, 8 ranks) run the code that runs at 8 GPUs --
+hbk_sharded_lookup_fwd/_bwd -- with the ranks as host threads on one GPU (device copies stand in
+for RCCL; 8-GPU hardware is not available to a test).  Config 4 (25 x 1M + 1 x 100M rows, dim
+128, Zipf(1.2) ids) runs at full size: the big table is 51.2 GB, so row offsets pass 2^32 floats.
+Checks at these sizes: on-device properties against torch's own indexing ops, and the oracle on
+sub-samples it finishes in seconds.
+"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import hybridbackend_amd as hb
+from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+  return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+  return t.detach().cpu().numpy()
+
+
+def _zipf_ranks(n, n_rows, alpha, gen):
+  """Zipf(alpha) ranks in [1, n_rows] by the inverse CDF of the continuous power law."""
+  u = torch.rand(n, device=DEV, dtype=torch.float64, generator=gen)
+  a = 1.0 - alpha
+  x = ((float(n_rows) ** a - 1.0) * u + 1.0) ** (1.0 / a)
+  return x.floor().clamp_(1, n_rows).to(torch.int64)
+
+
+def _run_ranks(world, fn):
+  comms = hb.distribute.Collective.local_world(world)
+  results, errors = [None] * world, []
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        results[r] = fn(r, comms[r])
+        torch.cuda.current_stream().synchronize()
+    except Exception as e:  # pylint: disable=broad-except
+      import traceback
+      errors.append((r, repr(e), traceback.format_exc()))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=600)
+  for c in comms:
+    c.close()
+  assert not errors, errors
+  return results
+
+
+# ----------------------------------------------------------------------------------------------
+def test_config4_full_size_zipf_forward_backward():
+  """25 x 1M + 1 x 100M rows, dim 128, Zipf(1.2), batch 65536: forward == table[ids % R] and
+  backward == index_add_ on device; oracle on the sub-sample of ids whose rows lie beyond float
+  offset 2^32 of the big table."""
+  free, _ = torch.cuda.mem_get_info()
+  if free < 100 * 2**30:
+    pytest.skip('needs ~75 GB of HBM')
+  dim, batch, n_cols = 128, 65536, 26
+  rows = [1_000_000] * 25 + [100_000_000]
+  gen = torch.Generator(device=DEV)
+  gen.manual_seed(7)
+  tables = []
+  for c in range(n_cols):
+    t = torch.empty(rows[c], dim, device=DEV)
+    t.uniform_(-1e-3, 1e-3, generator=gen)
+    tables.append(t)
+  far0 = (1 << 32) // dim + 1000           # first row whose float offset is >= 2^32 (+ margin)
+  ids = []
+  for c in range(n_cols):
+    rank = _zipf_ranks(batch, rows[c], 1.2, gen)
+    if rows[c] > far0:
+      # fixed permutation of the big table: a rotation that puts the Zipf head beyond float
+      # offset 2^32 (rank 1 -> row far0), the tail wraps around the whole table
+      row = (rank - 1 + far0) % rows[c]
+    else:
+      row = (rank * 2654435761 + 12345) % rows[c]   # multiplicative permutation (odd, coprime)
+    # ids arrive un-bucketized: add a multiple of the bucket so the fused floor-mod has work to do
+    k = torch.randint(0, 1 << 12, (batch,), device=DEV, dtype=torch.int64, generator=gen)
+    ids.append(row + k * rows[c])
+  lookup = hb.embedding.GroupLookup(tables, buckets=rows, combiners='sum')
+  outs = lookup(ids)
+  grads = [torch.randn(batch, dim, device=DEV, generator=gen) for _ in range(n_cols)]
+  res = hb.embedding.GroupLookupGrad(lookup)(ids, grads)
+  torch.cuda.synchronize()
+  for c in range(n_cols):
+    r = torch.remainder(ids[c], rows[c])
+    assert torch.equal(outs[c], tables[c][r]), f'forward column {c}'
+    urows, grows, nu = res[c]
+    k = int(nu.item())
+    uniq, inv = torch.unique(r, return_inverse=True)
+    assert k == uniq.numel(), f'column {c}: {k} rows emitted, {uniq.numel()} distinct'
+    order = torch.argsort(urows[:k])
+    assert torch.equal(urows[:k][order], uniq), f'backward rows of column {c}'
+    dense = torch.zeros(uniq.numel(), dim, device=DEV, dtype=torch.float64)
+    dense.index_add_(0, inv, grads[c].double())
+    got = grows[:k][order].double()
+    # hot rows sum thousands of N(0,1) terms: fp32 error ~ 1e-5 relative to the summed magnitude
+    mag = torch.zeros(uniq.numel(), dim, device=DEV, dtype=torch.float64)
+    mag.index_add_(0, inv, grads[c].double().abs())
+    assert bool(((got - dense).abs() <= 1e-5 * mag + 1e-6).all()), f'backward values of column {c}'
+  # the oracle on the sub-sample beyond float offset 2^32 (big table)
+  c = n_cols - 1
+  r = torch.remainder(ids[c], rows[c])
+  slab_rows = 1 << 21
+  sel = torch.nonzero((r >= far0) & (r < far0 + slab_rows)).flatten()
+  assert sel.numel() > 20000, 'the Zipf head must lie beyond offset 2^32'
+  assert int(r.max().item()) * dim >= (1 << 32)
+  sel = sel[:20000]
+  h_ids = host(ids[c][sel])
+  slab = host(tables[c][far0:far0 + slab_rows])
+  o_rows = oracle.floormod(h_ids, rows[c])                # integer part: bit-exact
+  np.testing.assert_equal(o_rows, host(r[sel]))
+  want = oracle.gather(slab, o_rows - far0)
+  np.testing.assert_equal(host(outs[c][sel]), want)
+  # backward + fused SGD apply on the sub-sample alone, against the oracle's reduction and apply
+  sub_ids = ids[c][sel].contiguous()
+  sub_g = grads[c][sel].contiguous()
+  one = hb.embedding.GroupLookup([tables[c]], buckets=[rows[c]], combiners='sum')
+  urows, grows, nu = hb.embedding.GroupLookupGrad(one)([sub_ids], [sub_g], apply_lr=0.5)[0]
+  torch.cuda.synchronize()
+  k = int(nu.item())
+  ou, oinv = oracle.unique(o_rows)
+  assert k == ou.size
+  want64 = oracle.unsorted_segment_sum(host(sub_g), oinv, ou.size, f64=True)
+  pos = {int(v): i for i, v in enumerate(ou.tolist())}
+  perm = [pos[int(v)] for v in host(urows)[:k]]
+  absum = oracle.unsorted_segment_sum(np.abs(host(sub_g)), oinv, ou.size, f64=True)
+  assert (np.abs(host(grows)[:k] - want64[perm]) <= 1e-5 * absum[perm] + 1e-6).all()
+  # the step touched exactly the looked-up rows of the 51 GB table, each once
+  after = host(tables[c][far0:far0 + slab_rows])
+  ref = slab.copy()
+  oracle.sparse_sgd_apply(ref, host(urows)[:k] - far0, host(grows)[:k], 0.5)
+  np.testing.assert_equal(after, ref)
+
+
+# ----------------------------------------------------------------------------------------------
+def test_config3_workload_eight_ranks_in_process():
+  """26 columns, 1M x 16 tables sharded 8 ways, batch 65536 per rank, through
+  hbk_sharded_lookup_fwd/_bwd with 8 in-process ranks: forward == the unsharded oracle lookup
+  (bit-exact), backward + fused SGD == dense scatter-add of all ranks' gradients."""
+  world, n_cols, n_rows, dim, batch = 8, 26, 1_000_000, 16, 65536
+  gen = torch.Generator(device=DEV)
+  tables = []
+  for c in range(n_cols):
+    gen.manual_seed(1234 + c)
+    tables.append(torch.empty(n_rows, dim, device=DEV).uniform_(-1e-3, 1e-3, generator=gen))
+  h_tables = [host(t) for t in tables]
+  ids = [[None] * n_cols for _ in range(world)]
+  grads = [[None] * n_cols for _ in range(world)]
+  for r in range(world):
+    for c in range(n_cols):
+      gen.manual_seed(42 + c + 100000 * r)
+      ids[r][c] = torch.randint(0, 1 << 40, (batch,), device=DEV, dtype=torch.int64, generator=gen)
+      grads[r][c] = torch.randn(batch, dim, device=DEV, generator=gen)
+  shards = [[t[r::world].contiguous() for t in tables] for r in range(world)]
+  lr = 0.25
+
+  def fn(r, coll):
+    drv = ShardedGroupLookup(shards[r], coll, buckets=[n_rows] * n_cols, combiners='sum')
+    outs = drv(ids[r])
+    drv.backward(grads[r], apply_lr=lr)
+    torch.cuda.current_stream().synchronize()
+    outs = [o.clone() for o in outs]
+    drv.close()
+    return outs
+
+  res = _run_ranks(world, fn)
+  for r in range(world):
+    want = oracle.group_lookup_fwd(h_tables, [host(i) for i in ids[r]], [None] * n_cols,
+                                   [n_rows] * n_cols, ['sum'] * n_cols, n_threads=8)
+    for c in range(n_cols):
+      np.testing.assert_equal(host(res[r][c]), want[c])
+  # the shards after the fused SGD step == table - lr * (dense scatter-add over all ranks)
+  for c in range(n_cols):
+    dense = torch.zeros(n_rows, dim, device=DEV, dtype=torch.float64)
+    for r in range(world):
+      dense.index_add_(0, torch.remainder(ids[r][c], n_rows), grads[r][c].double())
+    ref = tables[c].double() - lr * dense
+    for r in range(world):
+      torch.testing.assert_close(shards[r][c].double(), ref[r::world], rtol=1e-5, atol=1e-7)
+      untouched = dense[r::world].abs().sum(1) == 0
+      assert torch.equal(shards[r][c][untouched], tables[c][r::world][untouched])
+
+
+# ----------------------------------------------------------------------------------------------
+_DIMS = [4, 8, 12, 16, 24, 32, 36, 48, 64, 80, 128]
+
+
+def _config5_columns(rng, n_cols):
+  dims = [_DIMS[c % len(_DIMS)] for c in range(n_cols)]
+  rows = [int(10 ** rng.uniform(3, 5)) for _ in range(n_cols)]   # log-uniform
+  ragged = [c % 3 == 2 for c in range(n_cols)]
+  combiners = [['sum', 'mean', 'sqrtn'][c % 3] for c in range(n_cols)]
+  return dims, rows, ragged, combiners
+
+
+def test_config5_200_columns_lookup_and_grad_apply_single_gpu():
+  """200 columns, dims cycling 4..128, one third ragged: forward bit-equal to the oracle,
+  backward IndexedSlices within 1e-5, fused SGD and Adagrad apply bit-equal to the oracle's apply
+  of the emitted slices."""
+  rng = np.random.RandomState(5)
+  n_cols, batch = 200, 2048
+  dims, rows, ragged, combiners = _config5_columns(rng, n_cols)
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(n_cols)]
+  ids, splits, grads = [], [], []
+  for c in range(n_cols):
+    if ragged[c]:
+      lens = rng.poisson(4, size=batch).clip(0, 16)
+      sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    else:
+      sp = None
+    n = batch if sp is None else int(sp[-1])
+    splits.append(sp)
+    ids.append(rng.randint(0, 2**40, size=n).astype(np.int64))
+    grads.append(rng.randn(batch, dims[c]).astype(np.float32))
+  d_ids = [dev(i) for i in ids]
+  d_sp = [None if s is None else dev(s) for s in splits]
+  d_g = [dev(g) for g in grads]
+  for opt in ('sgd', 'adagrad'):
+    d_tab = [dev(t.copy()) for t in tables]
+    d_acc = [torch.full_like(t, 0.1) for t in d_tab]
+    lookup = hb.embedding.GroupLookup(d_tab, rows, combiners)
+    outs = lookup(d_ids, d_sp)
+    want = oracle.group_lookup_fwd(tables, ids, splits, rows, combiners, n_threads=8)
+    for c in range(n_cols):
+      np.testing.assert_equal(host(outs[c]), want[c])
+    res = hb.embedding.GroupLookupGrad(lookup, accums=d_acc)(d_ids, d_g, d_sp, apply_lr=0.05,
+                                                               optimizer=opt)
+    torch.cuda.synchronize()
+    for c in range(n_cols):
+      urows, grows, nu = res[c]
+      k = int(nu.item())
+      r = ids[c] % rows[c]
+      ou, oinv = oracle.unique(r)
+      assert k == ou.size and set(host(urows)[:k].tolist()) == set(ou.tolist())
+      sp = splits[c] if splits[c] is not None else np.arange(r.size + 1, dtype=np.int32)
+      g_id = oracle.segment_combine_grad(grads[c], sp, combiners[c])
+      want64 = oracle.unsorted_segment_sum(g_id, oinv, ou.size, f64=True)
+      pos = {int(v): i for i, v in enumerate(ou.tolist())}
+      perm = [pos[int(v)] for v in host(urows)[:k]]
+      np.testing.assert_allclose(host(grows)[:k], want64[perm], rtol=1e-5, atol=1e-5)
+      t_ref, a_ref = tables[c].copy(), np.full_like(tables[c], 0.1)
+      if opt == 'sgd':
+        oracle.sparse_sgd_apply(t_ref, host(urows)[:k], host(grows)[:k], 0.05)
+      else:
+        oracle.sparse_adagrad_apply(t_ref, a_ref, host(urows)[:k], host(grows)[:k], 0.05)
+        np.testing.assert_equal(host(d_acc[c]), a_ref)
+      np.testing.assert_equal(host(d_tab[c]), t_ref)
+
+
+def test_config5_200_columns_eight_ranks_end_to_end_step():
+  """The 8-GPU step of config 5 with in-process ranks: 200 columns, mixed dims, one third ragged,
+  forward + backward + fused SGD through hbk_sharded_lookup_fwd/_bwd."""
+  world, n_cols, batch = 8, 200, 512
+  rng = np.random.RandomState(55)
+  dims, rows, ragged, combiners = _config5_columns(rng, n_cols)
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(n_cols)]
+  ids, splits, grads = [], [], []
+  for r in range(world):
+    rid, rsp, rg = [], [], []
+    for c in range(n_cols):
+      if ragged[c]:
+        lens = rng.poisson(3, size=batch).clip(0, 12)
+        sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+      else:
+        sp = None
+      n = batch if sp is None else int(sp[-1])
+      rsp.append(sp)
+      rid.append(rng.randint(0, 2**40, size=n).astype(np.int64))
+      rg.append(rng.randn(batch, dims[c]).astype(np.float32))
+    ids.append(rid)
+    splits.append(rsp)
+    grads.append(rg)
+  shards = [[dev(t[r::world].copy()) for t in tables] for r in range(world)]
+  lr = 0.1
+
+  def fn(r, coll):
+    drv = ShardedGroupLookup(shards[r], coll, buckets=rows, combiners=combiners)
+    outs = drv([dev(i) for i in ids[r]], [None if s is None else dev(s) for s in splits[r]])
+    drv.backward([dev(g) for g in grads[r]], apply_lr=lr)
+    torch.cuda.current_stream().synchronize()
+    outs = [host(o) for o in outs]
+    drv.close()
+    return outs
+
+  res = _run_ranks(world, fn)
+  for r in range(world):
+    want = oracle.group_lookup_fwd(tables, ids[r], splits[r], rows, combiners, n_threads=8)
+    for c in range(n_cols):
+      np.testing.assert_equal(res[r][c], want[c])
+  for c in range(n_cols):
+    dense = np.zeros((rows[c], dims[c]), np.float64)
+    for r in range(world):
+      sp = splits[r][c] if splits[r][c] is not None else np.arange(ids[r][c].size + 1, dtype=np.int32)
+      g_id = oracle.segment_combine_grad(grads[r][c], sp, combiners[c]).astype(np.float64)
+      np.add.at(dense, ids[r][c] % rows[c], g_id)
+    ref = tables[c].astype(np.float64) - lr * dense
+    for r in range(world):
+      np.testing.assert_allclose(host(shards[r][c]), ref[r::world], rtol=1e-5, atol=1e-5)

@@ -278,3 +278,110 @@ def test_hierarchical_lookup_equals_unsharded(local_size, nodes):
   for r in range(world):
     np.testing.assert_equal(got[r], table[ids[r]])
     np.testing.assert_equal(got[r], flat[r])
+
+
+# ----------------------------------------------------------------------------------------------
+# External pin of the fp32 rows R1, R7-R10: the examples PUBLISHED in the TensorFlow 1.15 API
+# documentation (the third-party dependency those rows live in; tests/golden/tf115_semantics.json)
+# and an independent second implementation (torch's embedding_bag on the CPU).
+def csr_of(segment_ids, num_segments=None):
+  """sorted segment ids -> row_splits (rows = num_segments or last id + 1; missing ids = empty)"""
+  seg = np.asarray(segment_ids, np.int64)
+  n_seg = int(num_segments) if num_segments is not None else (int(seg[-1]) + 1 if seg.size else 0)
+  return np.concatenate([[0], np.cumsum(np.bincount(seg, minlength=n_seg))]).astype(np.int32)
+
+
+def test_tf115_unique_example(golden_dir):
+  for k in _load(golden_dir, 'tf115_semantics.json')['unique']:
+    y, idx = oracle.unique(np.array(k['x'], np.int64))
+    assert y.tolist() == k['y'] and idx.tolist() == k['idx']
+
+
+def test_tf115_floormod_examples(golden_dir):
+  for k in _load(golden_dir, 'tf115_semantics.json')['floormod']:
+    assert oracle.floormod(np.array([k['x']], np.int64), k['y']).tolist() == [k['out']]
+
+
+def test_tf115_sparse_segment_examples(golden_dir):
+  g = _load(golden_dir, 'tf115_semantics.json')
+  for k in g['sparse_segment_sum']:
+    splits = csr_of(k['segment_ids'], k['num_segments'])
+    got = oracle.segment_combine(np.array(k['data'], np.float32), np.array(k['indices'], np.int32),
+                                 splits, 'sum')
+    np.testing.assert_equal(got, np.array(k['out'], np.float32))
+  for k in g['segment_mean']:
+    got = oracle.segment_combine(np.array(k['data'], np.float32), np.array(k['indices'], np.int32),
+                                 csr_of(k['segment_ids']), 'mean')
+    np.testing.assert_equal(got, np.array(k['out'], np.float32))
+  for k in g['segment_sqrt_n']:
+    got = oracle.segment_combine(np.array(k['data'], np.float32), np.array(k['indices'], np.int32),
+                                 csr_of(k['segment_ids']), 'sqrtn')
+    want = np.array(k['out_times_sqrt_n'], np.float32) / np.sqrt(np.array(k['n'], np.float32))[:, None]
+    np.testing.assert_equal(got, want)
+  for k in g['unsorted_segment_sum']:
+    got = oracle.unsorted_segment_sum(np.array(k['data'], np.float32),
+                                      np.array(k['segment_ids'], np.int32), k['num_segments'])
+    np.testing.assert_equal(got, np.array(k['out'], np.float32))
+
+
+def test_tf115_embedding_lookup_sparse_example(golden_dir):
+  for k in _load(golden_dir, 'tf115_semantics.json')['embedding_lookup_sparse']:
+    rng = np.random.RandomState(4)
+    params = rng.randn(5, 20).astype(np.float32)
+    ids = np.array(k['sp_ids'], np.int64)
+    splits = np.array(k['row_splits'], np.int32)
+    assert csr_of([i[0] for i in k['sp_indices']], k['dense_shape'][0]).tolist() == splits.tolist()
+    for comb in ('sum', 'mean', 'sqrtn'):
+      got = oracle.group_lookup_fwd([params], [ids], [splits], [0], [comb])[0]
+      for s, rows in enumerate(k['rows_of_output']):
+        ref = params[rows].astype(np.float64).sum(axis=0)
+        ref = ref / len(rows) if comb == 'mean' else ref / np.sqrt(len(rows)) if comb == 'sqrtn' else ref
+        np.testing.assert_allclose(got[s], ref, rtol=1e-6)
+
+
+def test_tf115_sparse_apply_rules(golden_dir):
+  for k in _load(golden_dir, 'tf115_semantics.json')['sparse_apply']:
+    var, accum = np.array(k['var'], np.float32), np.array(k['accum'], np.float32)
+    rows, g, lr = np.array(k['indices'], np.int64), np.array(k['grad'], np.float32), k['lr']
+    v = oracle.sparse_sgd_apply(var.copy(), rows, g, lr)
+    want = var.copy()
+    want[rows] -= np.float32(lr) * g          # "var -= alpha * delta"
+    np.testing.assert_equal(v, want)
+    v, a = oracle.sparse_adagrad_apply(var.copy(), accum.copy(), rows, g, lr)
+    wa = accum.astype(np.float64)
+    wv = var.astype(np.float64)
+    wa[rows] += g.astype(np.float64) ** 2     # "accum += grad * grad"
+    wv[rows] -= lr * g * (1 / np.sqrt(wa[rows]))   # "var -= lr * grad * (1 / sqrt(accum))"
+    np.testing.assert_allclose(a, wa, rtol=1e-6)
+    np.testing.assert_allclose(v, wv, rtol=1e-6)
+    np.testing.assert_equal(v[1], var[1])     # rows without a gradient are untouched
+
+
+def test_lookup_against_torch_embedding_bag():
+  """A second, independent implementation of gather + segment combiner and of its gradient
+  (duplicate-row reduction): torch.nn.functional.embedding_bag on the CPU."""
+  import torch
+  import torch.nn.functional as F
+  rng = np.random.RandomState(21)
+  for dim, rows, n_seg in ((16, 1000, 300), (5, 37, 64), (128, 4000, 50)):
+    table = rng.uniform(-1, 1, size=(rows, dim)).astype(np.float32)
+    lens = rng.poisson(4, size=n_seg).clip(0, 12)
+    lens[0] = 0
+    splits = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ids = rng.randint(0, rows, size=int(splits[-1])).astype(np.int64)
+    w = torch.tensor(table, requires_grad=True)
+    for comb, mode in (('sum', 'sum'), ('mean', 'mean')):
+      got = oracle.group_lookup_fwd([table], [ids], [splits], [0], [comb])[0]
+      ref = F.embedding_bag(torch.from_numpy(ids), w, torch.from_numpy(splits[:-1].astype(np.int64)),
+                            mode=mode)
+      np.testing.assert_allclose(got, ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+      # backward: IndexedSlices of the oracle scattered densely == autograd's dense gradient
+      g_out = rng.randn(n_seg, dim).astype(np.float32)
+      w.grad = None
+      ref.backward(torch.from_numpy(g_out))
+      g_rows = oracle.segment_combine_grad(g_out, splits, comb)     # d(combiner): one row per id
+      uniq, inv = oracle.unique(ids)
+      g_u = oracle.unsorted_segment_sum(g_rows, inv, uniq.size)     # duplicate-row reduction
+      dense = np.zeros_like(table)
+      dense[uniq] = g_u
+      np.testing.assert_allclose(dense, w.grad.numpy(), rtol=1e-5, atol=1e-6)

@@ -10,28 +10,29 @@
 // Zipf).  The design below has NO global atomics on the data path:
 //
 //   0 seg_of     (ragged columns) segment of every id
-//   1 hist       row(j) = bucketize/`// W`; bucket = top bits of a 64-bit mix of the row;
+//   1 hist       row(j) = bucketize/`// W`; bucket = high bits of a 32-bit mix of the row;
 //                per-1024-id-tile LDS histogram, all columns in one launch
 //   2 scan       hist[tile][bucket]: prefix over tiles per bucket, then bucket starts
 //   3 scatter    (row, segment) pairs grouped by bucket (LDS ticket per bucket and tile)
 //   4 reduce     ONE workgroup owns a bucket, hence every table row that hashes to it.  Per
-//                chunk of <= 512 pairs: (a) LDS hash table of the distinct rows (64-bit CAS),
-//                per-slot pair counts; (b) one packed block scan gives, per slot, the start of
-//                its pairs, its rank among the active slots and its rank among the NEW rows
-//                (ballot-free prefix sums; one global atomic per workgroup claims the output
-//                range); (c) counting sort of the pairs by slot; (d) a lane group walks one
-//                slot's pairs and sums their gradient rows IN REGISTERS, four rows in flight,
-//                then writes unique_rows / grad_rows with plain 16-byte stores (and applies
-//                the SGD update when apply_lr != 0: exclusive ownership makes the
-//                read-modify-write race free); (e) hot rows (>= 64 pairs in the chunk) are
-//                summed by the whole workgroup and folded through a 4 KB LDS buffer (the
-//                "LDS-staged hot rows").  A row that spans chunks is accumulated into its
-//                output row by the owning workgroup.  If the next chunk could overflow the
-//                table it is cleared first; a row seen again afterwards gets a second
-//                IndexedSlices entry (sum semantics preserved).  That needs a bucket of several
-//                FULL chunks with more than ~500 distinct rows in the earlier ones: adversarial
-//                hashing, or more than ~7 M ids in one column (16384 buckets x 448) -- buckets
-//                that are long because of a hot row hold few distinct rows.
+//                chunk of <= 512 pairs: every lane group first ISSUES the loads of its pairs'
+//                gradient rows (<= 8 rows in flight per lane) -- they travel while (a) the rows are
+//                entered into an LDS hash table (64-bit CAS) with one ticket per pair and slot, and
+//                (b) one packed block scan over the PAIRS (new rows | rows with several pairs |
+//                their pair counts) hands every new row its output position (one global atomic per
+//                workgroup claims the range); (c) a row with ONE pair in the chunk -- the common
+//                case -- is written straight from the registers the gradient arrived in, plain
+//                16-byte stores, with the optimizer step when apply_lr != 0 (exclusive ownership
+//                makes the read-modify-write race free); (d) rows with several pairs are counting-
+//                sorted by slot and a lane group walks one slot's pairs, summing IN REGISTERS;
+//                (e) hot rows (>= 64 pairs in the chunk) are summed by the whole workgroup and
+//                folded through a 4 KB LDS buffer (the "LDS-staged hot rows").  A row that spans
+//                chunks is accumulated into its output row by the owning workgroup.  The table
+//                takes new rows only while it has room; pairs whose row found no room are left for
+//                another PASS over the bucket with an emptied table (handled pairs are struck out
+//                of the pair buffer), so every row is emitted exactly once whatever the bucket
+//                holds -- adversarial hashing or 100 M ids in one column cost passes, never
+//                correctness (the fused Adagrad step depends on that).
 //   5 split      a bucket far above the average size holds a hot row (Zipf heads: one row can
 //                own 20% of a column).  One workgroup has ~32 KB of loads in flight, so it would
 //                sum such a row at ~15 GB/s while the rest of the chip idles.  The scan kernel
@@ -81,14 +82,50 @@ constexpr int kBatch = kPerThread < 8 ? kPerThread : 8;   // loads in flight per
 constexpr int kMaxBuckets = 16384;   // 64 KB of LDS counters in hist / scatter
 constexpr int kCP = HBK_BWD_CP;       // pairs per chunk in the reduce kernel
 constexpr int kSlots = 2 * kCP;       // LDS hash-table slots
-constexpr int kTableRoom = kSlots - 8;    // clear the table when occupied + next chunk could pass this
+constexpr int kRoom = kSlots - kBlock - 8;  // rows enter the table while it holds fewer (a
+                                           // block's concurrent inserts overshoot by < kBlock)
+#ifndef HBK_BWD_PRE
+#define HBK_BWD_PRE 4
+#endif
+constexpr int kPre = HBK_BWD_PRE;     // gradient rows a lane keeps in flight (single-pair rows)
 constexpr int kUA = HBK_BWD_UA;       // slots a lane group reduces concurrently (rows in flight)
 constexpr int kHeavy = 64;            // pairs of one row in a chunk that make it a "hot row"
-constexpr int kHotTries = 4;           // ballot rounds that look for a hot row inside a wave
+constexpr int kLdsRowPairs = 64;      // multi-pair slots are summed in LDS rows when they hold at
+                                      // most this many pairs together
+#ifndef HBK_BWD_HOT
+#define HBK_BWD_HOT 4
+#endif
+constexpr int kHotTries = HBK_BWD_HOT; // ballot rounds that look for a hot row inside a wave
 constexpr int kHotMin = 8;             // lanes sharing a row that make the wave reduce it first
 constexpr int kUH = HBK_BWD_UH;       // rows in flight per lane group while summing a hot row
-constexpr int kMaxRanges = 64;         // chunks of one job whose SGD apply can be deferred
 constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr int64_t kDonePair = -1;      // a pair struck out of the pair buffer (rows are >= 0)
+constexpr uint16_t kNoSlot = 0xffff;
+
+// Phase timing of the reduce kernel (probe builds only: tools/Makefile builds a second library with
+// -DHBK_BWD_STAMPS; never defined in the product build): thread 0 of every workgroup adds the
+// shader-clock cycles of each phase into a global table read back by hbk_debug_bwd_stamps().
+#ifdef HBK_BWD_STAMPS
+constexpr int kTraceBlocks = 8192, kTraceSlots = 8;
+__device__ unsigned long long g_bwd_trace[kTraceBlocks * kTraceSlots];
+#define HBK_STAMP_BEGIN()                                                                  \
+  if (threadIdx.x == 0 && blockIdx.x < kTraceBlocks) {                                     \
+    g_bwd_trace[blockIdx.x * kTraceSlots] = __builtin_amdgcn_s_memrealtime();                  \
+  }
+#define HBK_STAMP(i)                                                                       \
+  do {                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < kTraceBlocks) {                                   \
+      g_bwd_trace[blockIdx.x * kTraceSlots + (i)] = __builtin_amdgcn_s_memrealtime();          \
+    }                                                                                      \
+  } while (0)
+#define HBK_STAMP_ARG
+#define HBK_STAMP_PASS
+#else
+#define HBK_STAMP_BEGIN()
+#define HBK_STAMP(i)
+#define HBK_STAMP_ARG
+#define HBK_STAMP_PASS
+#endif
 
 struct GCol {
   const void* ids;
@@ -104,6 +141,8 @@ struct GCol {
   int64_t* pair_row[1];      // [n_ids] rows of the pairs, grouped by bucket
   int32_t* pair_seg[1];      // [n_ids] their segments
   int32_t* seg_of;           // [n_ids], ragged columns only
+  int4* desc;                // [n_buckets + e_max] job of every reduce workgroup slot of the column:
+                             // {first pair, pairs of the bucket, bucket or -1, range index}
   int32_t* work;             // [2 * e_max] (bucket, range index >= 1) of the spare workgroups
   int32_t* n_extra;          // -> entries of `work` (written by the scan kernel)
   int32_t* pcount;           // [P] partial entries of a split bucket
@@ -135,34 +174,47 @@ struct GArgs {
   float lr;
   int32_t apply;             // 0 none / SGD by lr, 2 Adagrad
   int32_t pad_;
+  // first block of every column in the grids below (copies of the GCol fields, kept together so
+  // that a block finds its column with ONE wave-wide load + ballot instead of a binary search of
+  // dependent scalar loads -- each a cold miss at kernel start)
+  int32_t tile0[kMaxCols];
+  int32_t bucket0[kMaxCols];
+  int32_t merge0[kMaxCols];
+  int32_t scan0[kMaxCols];
+  int32_t segtile0[kMaxCols];
   GCol col[kMaxCols];
 };
 static_assert(sizeof(GArgs) <= 24576, "kernarg budget");
+static_assert(kMaxCols <= kWave, "one lane per column in HBK_FIND_COL");
 static_assert(kSlots <= 65536 && kCP <= 65536, "16-bit LDS indices");
 
 #define HBK_FIND_COL(ARGS, FIELD)                                                  \
-  int ci = 0, hi__ = (ARGS).n_cols;                                                \
-  while (hi__ - ci > 1) {                                                          \
-    const int mid__ = (ci + hi__) >> 1;                                            \
-    if ((ARGS).col[mid__].FIELD <= (int)blockIdx.x) {                              \
-      ci = mid__;                                                                  \
-    } else {                                                                       \
-      hi__ = mid__;                                                                \
-    }                                                                              \
+  int ci;                                                                          \
+  {                                                                                \
+    const int l__ = (int)threadIdx.x & (kWave - 1);                                \
+    const int v__ = l__ < (ARGS).n_cols ? (ARGS).FIELD[l__] : 0x7fffffff;          \
+    ci = (int)__builtin_popcountll(__ballot(v__ <= (int)blockIdx.x)) - 1;          \
+    ci = __builtin_amdgcn_readfirstlane(ci);                                       \
   }                                                                                \
   const auto& c = (ARGS).col[ci];
 
-__device__ inline uint64_t mix64(uint64_t k) {
-  k ^= k >> 33;
-  k *= 0xff51afd7ed558ccdull;
-  k ^= k >> 33;
-  k *= 0xc4ceb9fe1a85ec53ull;
-  k ^= k >> 33;
+// 32-bit avalanche of a row number (murmur3's finalizer on the folded halves): every bit of the
+// result depends on every bit of the row.  The grouping kernels hash every id twice (histogram and
+// scatter) and the reduce kernel once more for its LDS table; a 64-bit mixer costs two 64x64
+// multiplies = ~10 quarter-rate 32-bit multiplies per id, this one two.
+__device__ inline uint32_t mix32(uint64_t row) {
+  uint32_t k = (uint32_t)row ^ ((uint32_t)(row >> 32) * 0x9e3779b1u);
+  k ^= k >> 16;
+  k *= 0x85ebca6bu;
+  k ^= k >> 13;
+  k *= 0xc2b2ae35u;
+  k ^= k >> 16;
   return k;
 }
 
+// bucket = high bits of the mix scaled to any bucket count; the LDS table uses the LOW bits
 __device__ inline int bucket_of(uint64_t row, int n_buckets) {
-  return (int)__umul64hi(mix64(row), (uint64_t)n_buckets);
+  return (int)__umulhi(mix32(row), (uint32_t)n_buckets);
 }
 
 // Segmented inputs: position j of the column -> where its id and its gradient row live.  A
@@ -200,12 +252,10 @@ __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
   const int P = c.n_buckets;
   const int tid = (int)threadIdx.x;
   const int ctile = (int)blockIdx.x - c.tile0;
-  for (int p = tid; p < P; p += kBlock) counters[p] = 0;
-  __syncthreads();
   const int64_t base = (int64_t)ctile * kTile;
   RunCursor rc;
-  for (int k0 = 0; k0 < kPerThread; k0 += kBatch) {
-    int64_t id[kBatch];
+  int64_t id[kBatch];
+  auto load_batch = [&](int k0) {
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       const int64_t j = base + (int64_t)(k0 + k) * kBlock + tid;
@@ -215,6 +265,12 @@ __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
         id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
       }
     }
+  };
+  load_batch(0);   // the ids travel while the counters are cleared
+  for (int p = tid; p < P; p += kBlock) counters[p] = 0;
+  __syncthreads();
+  for (int k0 = 0; k0 < kPerThread; k0 += kBatch) {
+    if (k0 > 0) load_batch(k0);
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       const int64_t j = base + (int64_t)(k0 + k) * kBlock + tid;
@@ -235,11 +291,9 @@ __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
 // column scans the <= 16384 bucket totals into bucket starts, clears the counters and lists the
 // extra ranges of every bucket above split_t pairs (step 5).  Replaces a one-block serial walk
 // over all P x tiles entries (0.4 ms per launch on the 200-column config).
-__global__ __launch_bounds__(kBlock) void bwd_scan_tiles_kernel(const GArgs a) {
-  HBK_FIND_COL(a, scan0)
+// prefix over the tiles of bucket p (in place), bucket total -> bstart[p]
+__device__ inline void scan_tiles_of_bucket(const GCol& c, int p) {
   const int P = c.n_buckets;
-  const int p = ((int)blockIdx.x - c.scan0) * kBlock + (int)threadIdx.x;
-  if (p >= P) return;
   const int n_tiles = (int)((c.n_ids + kTile - 1) / kTile);
   int32_t* h = c.hist + p;
   int32_t run = 0;
@@ -262,10 +316,16 @@ __global__ __launch_bounds__(kBlock) void bwd_scan_tiles_kernel(const GArgs a) {
   c.bstart[p] = run;
 }
 
-__global__ __launch_bounds__(kBlock) void bwd_scan_kernel(const GArgs a) {
-  __shared__ int32_t wave_tot[kWavesPerBlock];
-  __shared__ int32_t n_extra;
-  const GCol& c = a.col[blockIdx.x];
+__global__ __launch_bounds__(kBlock) void bwd_scan_tiles_kernel(const GArgs a) {
+  HBK_FIND_COL(a, scan0)
+  const int p = ((int)blockIdx.x - c.scan0) * kBlock + (int)threadIdx.x;
+  if (p < c.n_buckets) scan_tiles_of_bucket(c, p);
+}
+
+// bucket totals (bstart[0..P)) -> bucket starts, job descriptors, list of extra ranges; one
+// workgroup per column
+__device__ inline void scan_buckets_of_column(const GCol& c, int32_t* wave_tot, int32_t* n_extra_lds) {
+  int32_t& n_extra = *n_extra_lds;
   const int P = c.n_buckets;
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int per = (P + kBlock - 1) / kBlock;   // contiguous buckets per thread (<= 64)
@@ -287,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void bwd_scan_kernel(const GArgs a) {
   for (int p = beg; p < end; ++p) {
     const int32_t n_b = c.bstart[p];
     c.bstart[p] = run;
-    run += n_b;
+    c.desc[p] = make_int4(run, n_b, p, 0);
     c.pcount[p] = 0;
     if (n_b > c.split_t) {
       const int32_t extras = (n_b - 1) / c.split_t;
@@ -295,15 +355,35 @@ __global__ __launch_bounds__(kBlock) void bwd_scan_kernel(const GArgs a) {
       for (int32_t e = 0; e < extras; ++e) {
         c.work[2 * (base + e)] = p;
         c.work[2 * (base + e) + 1] = e + 1;
+        c.desc[P + base + e] = make_int4(run, n_b, p, e + 1);
       }
     }
+    run += n_b;
   }
   __syncthreads();
+  for (int e = n_extra + tid; e < c.e_max; e += kBlock) c.desc[P + e] = make_int4(0, 0, -1, 0);
   if (tid == kBlock - 1) {
     c.bstart[P] = run;   // the last thread's running sum is the column total
     *c.n_unique = 0;
     *c.n_extra = n_extra;
   }
+}
+
+__global__ __launch_bounds__(kBlock) void bwd_scan_kernel(const GArgs a) {
+  __shared__ int32_t wave_tot[kWavesPerBlock];
+  __shared__ int32_t n_extra;
+  scan_buckets_of_column(a.col[blockIdx.x], wave_tot, &n_extra);
+}
+
+// both steps in one launch when every column of the call is small (<= kBlock buckets, few tiles:
+// one thread walks a bucket's tiles): one workgroup per column
+__global__ __launch_bounds__(kBlock) void bwd_scan_fused_kernel(const GArgs a) {
+  __shared__ int32_t wave_tot[kWavesPerBlock];
+  __shared__ int32_t n_extra;
+  const GCol& c = a.col[blockIdx.x];
+  if ((int)threadIdx.x < c.n_buckets) scan_tiles_of_bucket(c, (int)threadIdx.x);
+  __syncthreads();   // bstart[] written above is read below by other threads of this workgroup
+  scan_buckets_of_column(c, wave_tot, &n_extra);
 }
 
 // ---- 3: (row, segment) pairs grouped by bucket ---------------------------------------------
@@ -313,13 +393,11 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
   const int P = c.n_buckets;
   const int tid = (int)threadIdx.x;
   const int ctile = (int)blockIdx.x - c.tile0;
-  for (int p = tid; p < P; p += kBlock) run[p] = c.bstart[p] + c.hist[(int64_t)ctile * P + p];
-  __syncthreads();
   const int64_t base = (int64_t)ctile * kTile;
   RunCursor rc;
-  for (int k0 = 0; k0 < kPerThread; k0 += kBatch) {
-    int64_t id[kBatch];
-    int32_t seg[kBatch];
+  int64_t id[kBatch];
+  int32_t seg[kBatch];
+  auto load_batch = [&](int k0) {
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       const int64_t j = base + (int64_t)(k0 + k) * kBlock + tid;
@@ -335,6 +413,12 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
         if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
       }
     }
+  };
+  load_batch(0);   // the ids travel beside the bucket offsets
+  for (int p = tid; p < P; p += kBlock) run[p] = c.bstart[p] + c.hist[(int64_t)ctile * P + p];
+  __syncthreads();
+  for (int k0 = 0; k0 < kPerThread; k0 += kBatch) {
+    if (k0 > 0) load_batch(k0);
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       const int64_t j = base + (int64_t)(k0 + k) * kBlock + tid;
@@ -353,18 +437,17 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
 // ---- 4: one workgroup per bucket ---------------------------------------------------------------
 struct ReduceLds {
   unsigned long long keys[kSlots];
-  int32_t cnt[kSlots];       // pairs of the slot in this chunk; bit 30: row is new in this chunk
-  int32_t off[kSlots];       // start of the slot's pairs in `order` (turned into the end by (c))
+  int32_t cnt[kSlots];       // tickets = pairs of the slot in this chunk; bit 30: row is new in it
+  int32_t off[kSlots];       // multi-pair slots: start of the slot's pairs in `order` (-> end by (d))
   int32_t slot_out[kSlots];  // output row of the slot, -1 = none yet
   int32_t segs[kCP];         // segment (= row of grad_out) of every pair of the chunk
-  uint16_t active[kCP];      // slots with pairs in this chunk
-  uint16_t order[kCP];       // pair indices grouped by slot
-  uint16_t pslot[kCP];       // 16-bit: 30.5 KB per workgroup = five workgroups per CU
+  uint16_t active[kCP];      // slots with several pairs in this chunk
+  uint16_t order[kCP];       // their pair indices grouped by slot
+  uint16_t pslot[kCP];       // slot of every pair; kNoSlot: struck out earlier / left for a later pass
+  uint16_t emitted[kSlots];  // slots of the rows this pass has emitted (jobs of several chunks)
   int32_t heavy[kCP / kHeavy + 1];
   int32_t wave_tot[kWavesPerBlock];
-  int32_t n_active, n_heavy, base_u, occupied;
-  int32_t rng_base[kMaxRanges];  // output ranges claimed per chunk (deferred SGD apply)
-  int32_t rng_n[kMaxRanges];
+  int32_t n_active, n_new, n_heavy, n_single, base_u, occupied, n_left, lds_rows, n_emitted, emit0;
   float red[kBlock * 4];     // hot-row partial sums, one 16-byte chunk per thread
 };
 
@@ -374,7 +457,8 @@ constexpr int32_t kNewBit = 1 << 30;
 // IndexedSlices, a range of a split bucket into its partial entries, or those entries into the
 // final IndexedSlices (merge).
 struct ReduceJob {
-  const int64_t* prow;       // rows of the pairs
+  int64_t* prow;             // rows of the pairs (handled pairs are struck out when a bucket needs
+                             // more than one pass)
   const int32_t* pseg;       // their gradient rows; NULL: pair i reads gradient row i
   const float* grad;         // [*, dim]
   int32_t n_pairs;
@@ -415,33 +499,74 @@ __device__ inline f32x4 rsqrt_v<f32x4>(f32x4 a) {
   return f32x4{1.0f / sqrtf(a.x), 1.0f / sqrtf(a.y), 1.0f / sqrtf(a.z), 1.0f / sqrtf(a.w)};
 }
 
+// out row u += (or =) v
 template <typename V>
-__device__ inline void apply_row(const GCol& c, int32_t apply, float lr, int64_t row, int sub, V v) {
-  constexpr int VE = sizeof(V) / 4;
-  const int64_t off = row * c.dim + (int64_t)sub * VE;
-  V* t = reinterpret_cast<V*>(c.table + off);
-  if (apply == HBK_APPLY_ADAGRAD) {
-    V* ap = reinterpret_cast<V*>(c.accum + off);
-    const V a = __builtin_nontemporal_load(ap) + v * v;
-    *ap = a;
-    *t = __builtin_nontemporal_load(t) - (lr * v) * rsqrt_v<V>(a);
-  } else {
-    *t = __builtin_nontemporal_load(t) - lr * v;
-  }
-}
-
-// out row u += (or =) v, and the fused optimizer step on the table row
-template <typename V>
-__device__ inline void emit_row(const GCol& c, const ReduceJob& job, float lr, int32_t u,
-                                bool is_new, int64_t row, int sub, V v) {
+__device__ inline void emit_row(const GCol& c, const ReduceJob& job, int32_t u, bool is_new,
+                                int sub, V v) {
   constexpr int VE = sizeof(V) / 4;
   V* o = reinterpret_cast<V*>(job.out_vals + (int64_t)u * c.dim + (int64_t)sub * VE);
   // rows are owned by this workgroup; bypass L1 when re-reading what an earlier chunk wrote
   *o = is_new ? v : __builtin_nontemporal_load(o) + v;
-  if (lr != 0.0f) apply_row<V>(c, job.apply, lr, row, sub, v);
 }
 
+// The sparse optimizer step of one row chunk (this workgroup owns the row), from values already
+// in registers: g = the row's deduplicated gradient, tv / av = table / accumulator row
+//   SGD      var -= lr * g                                        (GradientDescentOptimizer)
+//   Adagrad  accum += g * g;  var -= lr * g * (1 / sqrt(accum))   (AdagradOptimizer's sparse apply,
+//            docs/tutorial/ranking/taobao/train.py:115)
 template <typename V>
+__device__ inline void step_row(const GCol& c, bool adagrad, float lr, int64_t toff, V g, V tv, V av) {
+  if (adagrad) {
+    const V acc = av + g * g;
+    *reinterpret_cast<V*>(c.accum + toff) = acc;
+    *reinterpret_cast<V*>(c.table + toff) = tv - (lr * g) * rsqrt_v<V>(acc);
+  } else {
+    *reinterpret_cast<V*>(c.table + toff) = tv - lr * g;
+  }
+}
+
+// emit + (lr != 0) the optimizer step with the loads it needs: the rows of (d), (e) and of the
+// LDS-row path -- few, or long to sum, so the extra round trip is not on the critical path
+template <typename V, int STEP>
+__device__ inline void emit_step_row(const GCol& c, const ReduceJob& job, float lr, int32_t u,
+                                     bool is_new, int64_t row, int sub, V v) {
+  constexpr int VE = sizeof(V) / 4;
+  emit_row<V>(c, job, u, is_new, sub, v);
+  if (STEP && lr != 0.0f) {
+    constexpr bool adagrad = STEP == 2;
+    const int64_t toff = row * c.dim + (int64_t)sub * VE;
+    const V tv = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+    V av = zero_v<V>();
+    if (adagrad) av = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
+    step_row<V>(c, adagrad, lr, toff, v, tv, av);
+  }
+}
+
+// Find `row` in the LDS table or enter it while the table has room.  Returns the slot, or -1 when
+// the row is absent and the table takes no more rows (the pair waits for the next pass).
+__device__ inline int table_slot(ReduceLds& L, unsigned long long row) {
+  int h = (int)(mix32(row) & (kSlots - 1));
+  for (;;) {
+    const unsigned long long k = L.keys[h];
+    if (k == row) return h;
+    if (k == kEmptyKey) {
+      // racy read of the fill level: concurrent inserts overshoot kRoom by < kBlock rows, the
+      // table keeps >= 8 empty slots, so every probe sequence ends
+      if (*(volatile int32_t*)&L.occupied >= kRoom) return -1;
+      const unsigned long long prev = atomicCAS(&L.keys[h], kEmptyKey, row);
+      if (prev == kEmptyKey) {
+        atomicAdd(&L.occupied, 1);
+        return h;
+      }
+      if (prev == row) return h;
+    }
+    h = (h + 1) & (kSlots - 1);
+  }
+}
+
+// STEP: 0 = no fused optimizer step (none of its loads, registers and branches), 1 = SGD,
+// 2 = Adagrad (accumulator rows as well).
+template <typename V, int STEP>
 __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, ReduceLds& L) {
   constexpr int VE = sizeof(V) / 4;
   const int tid = (int)threadIdx.x;
@@ -454,337 +579,531 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
 
   const int32_t n_pairs = job.n_pairs;
   if (n_pairs <= 0) return;
-  const int64_t* prow = job.prow;
+  int64_t* prow = job.prow;
   const int32_t* pseg = job.pseg;
 
+  __syncthreads();   // a workgroup may run several jobs: the previous one is done with the table
   for (int i = tid; i < kSlots; i += kBlock) {
     L.keys[i] = kEmptyKey;
     L.slot_out[i] = -1;
+    L.cnt[i] = 0;
   }
-  if (tid == 0) L.occupied = 0;
+  if (tid == 0) {
+    L.occupied = 0;
+    L.n_left = 0;
+  }
   __syncthreads();
+  HBK_STAMP(2);
 
-  // A row that spans chunks is summed across them in its output row; applying the SGD step chunk
-  // by chunk would round differently from table -= lr * grad_row.  Jobs with several chunks
-  // (rare: buckets aim at 7/8 of a chunk) therefore only emit, remember the output ranges they
-  // claimed, and apply the step once per row at the end.
-  const bool defer = job.lr != 0.0f && n_pairs > kCP && n_pairs <= kCP * kMaxRanges;
-  // (beyond kMaxRanges chunks -- adversarial hashing -- the step is applied chunk by chunk: SGD
-  // then only rounds differently, Adagrad sees partial gradients)
-  const float lr_chunk = defer ? 0.0f : job.lr;
-  for (int32_t cb = 0; cb < n_pairs; cb += kCP) {
-    const int32_t n_chunk = n_pairs - cb < kCP ? n_pairs - cb : kCP;
-    if (L.occupied + n_chunk > kTableRoom) {  // uniform: read after a barrier
-      __syncthreads();
-      for (int i = tid; i < kSlots; i += kBlock) {
-        L.keys[i] = kEmptyKey;
-        L.slot_out[i] = -1;
+  // The optimizer step is taken once per row.  A job of one chunk (almost all: buckets aim at 7/8
+  // of a chunk) steps a row right where its sum sits in registers.  In a job of several chunks a
+  // row may span chunks and is summed across them in its output row; stepping chunk by chunk
+  // would round differently from table -= lr * grad_row and is wrong for Adagrad, so such a job
+  // only emits, lists the rows a pass emitted, and steps them after the pass.
+  const bool defer = STEP && job.lr != 0.0f && n_pairs > kCP;
+  const float lr_now = !STEP || defer ? 0.0f : job.lr;
+  constexpr bool adagrad = STEP == 2;
+  if (tid == 0) L.n_emitted = 0;
+  int32_t first_cb = 0;        // first chunk that may still hold unhandled pairs
+  bool striking = false;       // this pass left pairs behind: handled pairs are struck out
+  for (;;) {                   // passes; one unless the bucket holds more rows than the table
+    int32_t first_left = -1;
+    for (int32_t cb = first_cb; cb < n_pairs; cb += kCP) {
+      const int32_t n_chunk = n_pairs - cb < kCP ? n_pairs - cb : kCP;
+      if (tid == 0) {
+        L.n_heavy = 0;
+        L.n_single = 0;
       }
-      if (tid == 0) L.occupied = 0;
-    }
-    for (int i = tid; i < kSlots; i += kBlock) L.cnt[i] = 0;
-    if (tid == 0) L.n_heavy = 0;
-    __syncthreads();
 
-    // (a) distinct rows of the chunk -> slots, pairs per slot.  Same-address LDS atomics
-    // serialise, so a hot row is first reduced inside the wave: up to kHotTries times the first
-    // pending lane's row is matched with a ballot; a group of >= kHotMin lanes lets its leader
-    // probe once and add the whole count, the other lanes take the slot by broadcast.
+      // the LDS rows that take the sums of multi-pair slots in (c)
+      *reinterpret_cast<f32x4*>(&L.red[(size_t)tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+      // (a) rows of the chunk -> slots; one ticket per pair and slot.  Same-address LDS atomics
+      // serialise, so a hot row is first reduced inside the wave: up to kHotTries times the first
+      // pending lane's row is matched with a ballot; a group of >= kHotMin lanes lets its leader
+      // probe once and take all tickets, the other lanes get slot and ticket by broadcast.
+      int hs_[kCP / kBlock], tk_[kCP / kBlock], rk_[kCP / kBlock];
+      unsigned long long row_[kCP / kBlock];
 #pragma unroll
-    for (int k = 0; k < kCP / kBlock; ++k) {
-      const int e = k * kBlock + tid;
-      const bool valid = e < n_chunk;
-      unsigned long long row = 0;
-      if (valid) {
-        row = (unsigned long long)prow[cb + e];
-        L.segs[e] = pseg != nullptr ? pseg[cb + e] : cb + e;
-      }
-      int h = -1;
-      unsigned long long todo = __ballot(valid);
-      for (int t = 0; t < kHotTries && todo != 0ull; ++t) {
-        const int leader = __builtin_ctzll(todo);
-        const unsigned long long r =
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(row >> 32), leader) << 32) |
-            (unsigned)__builtin_amdgcn_readlane((int)row, leader);
-        const unsigned long long same = __ballot(valid && row == r) & todo;
-        todo &= ~same;
-        const int n_same = (int)__builtin_popcountll(same);
-        if (n_same < kHotMin) continue;  // wave-uniform
-        int hs = 0;
-        if (lane == leader) {
-          hs = (int)(mix64(r) & (kSlots - 1));
-          for (;;) {
-            const unsigned long long prev = atomicCAS(&L.keys[hs], kEmptyKey, r);
-            if (prev == kEmptyKey || prev == r) break;
-            hs = (hs + 1) & (kSlots - 1);
+      for (int k = 0; k < kCP / kBlock; ++k) {
+        const int e = k * kBlock + tid;
+        bool valid = e < n_chunk;
+        unsigned long long row = 0;
+        if (valid) {
+          const int64_t r = prow[cb + e];
+          L.segs[e] = pseg != nullptr ? pseg[cb + e] : cb + e;
+          valid = r != kDonePair;
+          row = (unsigned long long)r;
+        }
+        int h = -2, ticket = 0;    // -2: not looked up yet, -1: no room in this pass
+        unsigned long long todo = __ballot(valid);
+        for (int t = 0; t < kHotTries && todo != 0ull; ++t) {
+          const int leader = __builtin_ctzll(todo);
+          const unsigned long long r =
+              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(row >> 32), leader) << 32) |
+              (unsigned)__builtin_amdgcn_readlane((int)row, leader);
+          const unsigned long long same = __ballot(valid && row == r) & todo;
+          todo &= ~same;
+          const int n_same = (int)__builtin_popcountll(same);
+          // wave-uniform.  Uniform ids: the first lane's row is shared with nobody and the search
+          // ends after one round (it would cost 5 % of the backward otherwise); skewed ids: the
+          // first lane most likely holds a repeated row and the search goes on
+#ifndef HBK_BWD_HOT_NOEARLY
+          if (n_same == 1 && t == 0) break;
+#endif
+          if (n_same < kHotMin) continue;
+          int hs = -1, base = 0;
+          if (lane == leader) {
+            hs = table_slot(L, r);
+            if (hs >= 0) base = atomicAdd(&L.cnt[hs], n_same);
           }
-          atomicAdd(&L.cnt[hs], n_same);
-        }
-        hs = __builtin_amdgcn_readlane(hs, leader);
-        if ((same >> lane) & 1ull) h = hs;
-      }
-      if (valid && h < 0) {
-        h = (int)(mix64(row) & (kSlots - 1));
-        for (;;) {  // the table never fills: cleared before a chunk that could pass kTableRoom
-          const unsigned long long prev = atomicCAS(&L.keys[h], kEmptyKey, row);
-          if (prev == kEmptyKey || prev == row) break;
-          h = (h + 1) & (kSlots - 1);
-        }
-        atomicAdd(&L.cnt[h], 1);
-      }
-      if (valid) L.pslot[e] = (uint16_t)h;
-    }
-    __syncthreads();
-
-    // (b) one packed exclusive scan over the slots: pairs | active slots << 10 | new rows << 20
-    {
-      int32_t local[kSlots / kBlock], sum = 0;
-#pragma unroll
-      for (int k = 0; k < kSlots / kBlock; ++k) {
-        const int s = tid * (kSlots / kBlock) + k;
-        const int32_t n = L.cnt[s];
-        local[k] = n > 0 ? n | (1 << 10) | (L.slot_out[s] < 0 ? (1 << 20) : 0) : 0;  // kCP <= 512
-        sum += local[k];
-      }
-      int32_t incl = sum;
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const int32_t y = __shfl_up(incl, o, kWave);
-        if (lane >= o) incl += y;
-      }
-      if (lane == kWave - 1) L.wave_tot[wave] = incl;
-      __syncthreads();
-      int32_t run = incl - sum;
-      for (int w = 0; w < wave; ++w) run += L.wave_tot[w];
-      if (tid == kBlock - 1) {
-        const int32_t tot = run + sum;
-        const int32_t n_new = tot >> 20;
-        L.n_active = (tot >> 10) & 1023;
-        L.base_u = job.out_base + (n_new > 0 ? atomicAdd(job.out_counter, n_new) : 0);
-        L.occupied += n_new;
-        if (defer) {
-          L.rng_base[cb / kCP] = L.base_u;
-          L.rng_n[cb / kCP] = n_new;
-        }
-      }
-      __syncthreads();
-      const int32_t base_u = L.base_u;
-#pragma unroll
-      for (int k = 0; k < kSlots / kBlock; ++k) {
-        const int s = tid * (kSlots / kBlock) + k;
-        if (local[k] != 0) {
-          L.off[s] = run & 1023;
-          L.active[(run >> 10) & 1023] = (uint16_t)s;
-          if (local[k] >> 20) {
-            const int32_t u = base_u + (run >> 20);
-            L.slot_out[s] = u;
-            L.cnt[s] |= kNewBit;
-            job.out_rows[u] = (int64_t)L.keys[s];
+          hs = __builtin_amdgcn_readlane(hs, leader);
+          base = __builtin_amdgcn_readlane(base, leader);
+          if ((same >> lane) & 1ull) {
+            h = hs;
+            ticket = base + rank_below(same);
           }
         }
-        run += local[k];
+        if (valid && h == -2) {
+          h = table_slot(L, row);
+          if (h >= 0) ticket = atomicAdd(&L.cnt[h], 1);
+        }
+        if (e < n_chunk) L.pslot[e] = valid && h >= 0 ? (uint16_t)h : kNoSlot;
+        if (valid && h < 0) atomicAdd(&L.n_left, 1);
+        hs_[k] = valid && h >= 0 ? h : -1;
+        tk_[k] = ticket;
+        row_[k] = row;
       }
-    }
-    __syncthreads();
+      __syncthreads();
+      HBK_STAMP(3);
 
-    // (c) counting sort of the pairs by slot (off[] ends up as the end of every slot's run);
-    // tickets of a hot slot are taken once per wave and split by ballot rank
+      // (b) one packed exclusive scan over the PAIRS that hold ticket 0 (one per slot of the
+      // chunk): new rows | slots with several pairs << 10 | their pairs << 20
+      {
+        int32_t pk[kCP / kBlock], sum = 0;
 #pragma unroll
-    for (int k = 0; k < kCP / kBlock; ++k) {
-      const int e = k * kBlock + tid;
-      const bool valid = e < n_chunk;
-      const int h = valid ? L.pslot[e] : -1;
-      int pos = -1;
-      unsigned long long todo = __ballot(valid);
-      for (int t = 0; t < kHotTries && todo != 0ull; ++t) {
-        const int leader = __builtin_ctzll(todo);
-        const int hs = __builtin_amdgcn_readlane(h, leader);
-        const unsigned long long same = __ballot(valid && h == hs) & todo;
-        todo &= ~same;
-        const int n_same = (int)__builtin_popcountll(same);
-        if (n_same < kHotMin) continue;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&L.off[hs], n_same);
-        base = __builtin_amdgcn_readlane(base, leader);
-        if ((same >> lane) & 1ull) pos = base + rank_below(same);
+        for (int k = 0; k < kCP / kBlock; ++k) {
+          pk[k] = 0;
+          if (hs_[k] >= 0 && tk_[k] == 0) {
+            const int32_t n = L.cnt[hs_[k]];
+            const bool is_new = L.slot_out[hs_[k]] < 0;
+            // a new row with one pair is stored straight from registers in (c); rows with
+            // several pairs, and rows an earlier chunk already emitted (read-modify-write), go
+            // through the sorted walk of (d)
+            pk[k] = (is_new ? 1 : 0) | (n > 1 || !is_new ? (1 << 10) | (n << 20) : 0);
+          }
+          sum += pk[k];
+        }
+        int32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+          const int32_t y = __shfl_up(incl, o, kWave);
+          if (lane >= o) incl += y;
+        }
+        if (lane == kWave - 1) L.wave_tot[wave] = incl;
+        __syncthreads();
+        int32_t run = incl - sum;
+        for (int w = 0; w < wave; ++w) run += L.wave_tot[w];
+        if (tid == kBlock - 1) {
+          const int32_t tot = run + sum;
+          L.n_new = tot & 1023;
+          L.n_active = (tot >> 10) & 1023;
+          // few multi-pair slots holding few pairs (the usual case): their pairs are summed in LDS
+          // rows by ds_add_f32; many, or a slot with many pairs (skewed ids: same-address LDS
+          // atomics serialise): they are sorted by slot and walked / summed by the whole
+          // workgroup, see (d), (e)
+          L.lds_rows = ((tot >> 10) & 1023) * c.dim <= kBlock * 4 && (tot >> 20) <= kLdsRowPairs;
+        }
+        __syncthreads();
+        const bool lds_rows_b = L.lds_rows != 0;
+#pragma unroll
+        for (int k = 0; k < kCP / kBlock; ++k) {
+          rk_[k] = -1;
+          if (!lds_rows_b) {
+            // skewed ids: most pairs belong to multi-pair slots and go through (d); (c) then walks
+            // the LIST of single-pair new rows (kept in order[], which (d) only fills later), one
+            // LDS ticket per wave
+            const unsigned long long single = __ballot(pk[k] == 1);
+            if (single != 0ull) {
+              int base = 0;
+              const int first = __builtin_ctzll(single);
+              if (lane == first) base = atomicAdd(&L.n_single, (int)__builtin_popcountll(single));
+              base = __builtin_amdgcn_readlane(base, first);
+              if (pk[k] == 1) L.order[base + rank_below(single)] = (uint16_t)(k * kBlock + tid);
+            }
+          }
+          if (pk[k] != 0) {
+            const int s = hs_[k];
+            if (pk[k] & 1) {
+              // the output position is base_u + rank; base_u comes from the claiming atomic, whose
+              // round trip runs beside the gradient loads of (c): until then the slot holds the rank
+              rk_[k] = run & 1023;
+              L.slot_out[s] = -2 - rk_[k];
+              L.cnt[s] |= kNewBit;
+            }
+            if (pk[k] >> 10) {
+              const int m = (run >> 10) & 1023;
+              L.active[m] = (uint16_t)s;
+              L.off[s] = lds_rows_b ? m : run >> 20;
+            }
+          }
+          run += pk[k];
+        }
       }
-      if (valid) {
-        if (pos < 0) pos = atomicAdd(&L.off[h], 1);
-        L.order[pos] = (uint16_t)e;
-      }
-    }
-    __syncthreads();
+      __syncthreads();
+      HBK_STAMP(4);
 
-    // (d) a lane group sums the rows of kUA slots at a time, in registers
-    const int n_active = L.n_active;
-    for (int k0 = 0; k0 < n_active; k0 += groups * kUA) {
-      int32_t slot[kUA], beg[kUA], len[kUA];
-      V acc[kUA];
-      int32_t longest = 0;
+      // (c) one round of gradient loads, kPre rows in flight per lane.  A NEW row with ONE pair in
+      // the chunk -- the common case -- is stored straight from the registers its gradient
+      // arrived in; the pairs of multi-pair slots are added into the slot's LDS row (ds_add_f32)
+      // when there are few such slots, else left to (d).
+      const int n_active = L.n_active;   // uniform
+      const bool lds_rows = L.lds_rows != 0;
+      // one global atomic per workgroup and chunk claims the output range of the new rows; its
+      // round trip runs beside the gradient loads (the barrier below waits for both)
+      int32_t claimed = 0;
+      if (tid == kBlock - 1 && L.n_new > 0) claimed = atomicAdd(job.out_counter, L.n_new);
+      int32_t base_u = 0;
+      // lds_rows: every pair of the chunk is fetched here; else only the listed single-pair rows
+      const int n_fetch = lds_rows ? n_chunk : L.n_single;
+      for (int e0 = 0; e0 == 0 || e0 < n_fetch; e0 += kPre * groups) {
+        V pre[kPre], tv[kPre], av[kPre];
+        int32_t cv[kPre], sl[kPre];
+        int64_t toff[kPre];
 #pragma unroll
-      for (int u = 0; u < kUA; ++u) {
-        const int idx = k0 + u * groups + my_group;
-        slot[u] = -1;
-        len[u] = 0;
-        beg[u] = 0;
-        acc[u] = zero_v<V>();
-        if (idx < n_active) {
-          slot[u] = L.active[idx];
-          const int32_t n = L.cnt[slot[u]] & (kNewBit - 1);
-          if (n >= kHeavy) {
-            if (sub == 0) L.heavy[atomicAdd(&L.n_heavy, 1)] = slot[u];
+        for (int k = 0; k < kPre; ++k) {
+          const int i = e0 + k * groups + my_group;
+          pre[k] = tv[k] = av[k] = zero_v<V>();
+          cv[k] = 0;
+          toff[k] = 0;
+          sl[k] = (int)kNoSlot;
+          if (i < n_fetch && live) {
+            const int e = lds_rows ? i : (int)L.order[i];
+            sl[k] = (int)L.pslot[e];
+            if (sl[k] != (int)kNoSlot) {
+              cv[k] = L.cnt[sl[k]];
+              if (cv[k] == (kNewBit | 1) || lds_rows) pre[k] = load_grad<V>(c, job, L.segs[e], sub);
+              if (STEP && cv[k] == (kNewBit | 1) && lr_now != 0.0f) {
+                // the table (and accumulator) row of the step travels with the gradient
+                toff[k] = (int64_t)L.keys[sl[k]] * c.dim + (int64_t)sub * VE;
+                tv[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff[k]));
+                if (adagrad) {
+                  av[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff[k]));
+                }
+              }
+            }
+          }
+        }
+        if (e0 == 0) {
+          if (tid == kBlock - 1) {
+            L.base_u = job.out_base + claimed;
+            L.emit0 = L.n_emitted;
+            L.n_emitted += L.n_new;
+          }
+          __syncthreads();
+          base_u = L.base_u;
+        }
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+          if (sl[k] == (int)kNoSlot) continue;
+          if (cv[k] == (kNewBit | 1)) {
+            emit_row<V>(c, job, base_u + (-2 - L.slot_out[sl[k]]), true, sub, pre[k]);
+            if (STEP && lr_now != 0.0f) step_row<V>(c, adagrad, lr_now, toff[k], pre[k], tv[k], av[k]);
+          } else if (lds_rows) {
+            float* r = &L.red[(size_t)L.off[sl[k]] * c.dim + (size_t)sub * VE];
+#pragma unroll
+            for (int i = 0; i < VE; ++i) atomicAdd(r + i, reinterpret_cast<const float*>(&pre[k])[i]);
+          }
+        }
+      }
+      // the new rows' slots get their absolute output position (later chunks, (d), the optimizer
+      // step read it), and the row numbers go out
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < kCP / kBlock; ++k) {
+        if (rk_[k] >= 0) {
+          const int32_t u = base_u + rk_[k];
+          L.slot_out[hs_[k]] = u;
+          job.out_rows[u] = (int64_t)row_[k];
+          if (defer) L.emitted[L.emit0 + rk_[k]] = (uint16_t)hs_[k];
+        }
+      }
+      if (lds_rows && n_active > 0) {
+        __syncthreads();
+        for (int m = my_group; m < n_active; m += groups) {
+          if (!live) continue;
+          const int sidx = L.active[m];
+          emit_step_row<V, STEP>(c, job, lr_now, L.slot_out[sidx], (L.cnt[sidx] & kNewBit) != 0,
+                           (int64_t)L.keys[sidx], sub,
+                           *reinterpret_cast<const V*>(&L.red[(size_t)m * c.dim + (size_t)sub * VE]));
+        }
+      }
+      HBK_STAMP(5);
+      if (n_active > 0 && !lds_rows) {
+        // (d) counting sort of the pairs of multi-pair slots (off[] ends up as the end of every
+        // slot's run); tickets of a hot slot are taken once per wave and split by ballot rank
+#pragma unroll
+        for (int k = 0; k < kCP / kBlock; ++k) {
+          const int e = k * kBlock + tid;
+          const int h = hs_[k];
+          const bool valid = h >= 0 && L.cnt[h] != (kNewBit | 1);
+          int pos = -1;
+          unsigned long long todo = __ballot(valid);
+          for (int t = 0; t < kHotTries && todo != 0ull; ++t) {
+            const int leader = __builtin_ctzll(todo);
+            const int hs = __builtin_amdgcn_readlane(h, leader);
+            const unsigned long long same = __ballot(valid && h == hs) & todo;
+            todo &= ~same;
+            const int n_same = (int)__builtin_popcountll(same);
+            if (n_same < kHotMin) continue;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&L.off[hs], n_same);
+            base = __builtin_amdgcn_readlane(base, leader);
+            if ((same >> lane) & 1ull) pos = base + rank_below(same);
+          }
+          if (valid) {
+            if (pos < 0) pos = atomicAdd(&L.off[h], 1);
+            L.order[pos] = (uint16_t)e;
+          }
+        }
+        __syncthreads();
+
+        // a lane group sums the rows of kUA slots at a time, in registers
+        for (int k0 = 0; k0 < n_active; k0 += groups * kUA) {
+          int32_t slot[kUA], beg[kUA], len[kUA];
+          V acc[kUA];
+          int32_t longest = 0;
+#pragma unroll
+          for (int u = 0; u < kUA; ++u) {
+            const int idx = k0 + u * groups + my_group;
             slot[u] = -1;
-          } else {
-            len[u] = n;
-            beg[u] = L.off[slot[u]] - n;
-            longest = n > longest ? n : longest;
+            len[u] = 0;
+            beg[u] = 0;
+            acc[u] = zero_v<V>();
+            if (idx < n_active) {
+              slot[u] = L.active[idx];
+              const int32_t n = L.cnt[slot[u]] & (kNewBit - 1);
+              if (n >= kHeavy) {
+                if (sub == 0) L.heavy[atomicAdd(&L.n_heavy, 1)] = slot[u];
+                slot[u] = -1;
+              } else {
+                len[u] = n;
+                beg[u] = L.off[slot[u]] - n;
+                longest = n > longest ? n : longest;
+              }
+            }
+          }
+          for (int r = 0; r < longest; ++r) {
+            V g[kUA];
+#pragma unroll
+            for (int u = 0; u < kUA; ++u) {
+              g[u] = zero_v<V>();
+              if (r < len[u] && live) g[u] = load_grad<V>(c, job, L.segs[L.order[beg[u] + r]], sub);
+            }
+#pragma unroll
+            for (int u = 0; u < kUA; ++u) acc[u] = acc[u] + g[u];
+          }
+#pragma unroll
+          for (int u = 0; u < kUA; ++u) {
+            if (slot[u] >= 0 && live) {
+              emit_step_row<V, STEP>(c, job, lr_now, L.slot_out[slot[u]],
+                               (L.cnt[slot[u]] & kNewBit) != 0, (int64_t)L.keys[slot[u]], sub, acc[u]);
+            }
           }
         }
-      }
-      for (int r = 0; r < longest; ++r) {
-        V g[kUA];
-#pragma unroll
-        for (int u = 0; u < kUA; ++u) {
-          g[u] = zero_v<V>();
-          if (r < len[u] && live) g[u] = load_grad<V>(c, job, L.segs[L.order[beg[u] + r]], sub);
-        }
-#pragma unroll
-        for (int u = 0; u < kUA; ++u) acc[u] = acc[u] + g[u];
-      }
-#pragma unroll
-      for (int u = 0; u < kUA; ++u) {
-        if (slot[u] >= 0 && live) {
-          emit_row<V>(c, job, lr_chunk, L.slot_out[slot[u]], (L.cnt[slot[u]] & kNewBit) != 0,
-                      (int64_t)L.keys[slot[u]], sub, acc[u]);
-        }
-      }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // (e) hot rows: the whole workgroup sums one row, partial sums folded through LDS
-    const int n_heavy = L.n_heavy;
-    for (int hidx = 0; hidx < n_heavy; ++hidx) {
-      const int s = L.heavy[hidx];
-      const int32_t n = L.cnt[s] & (kNewBit - 1);
-      const int32_t b0 = L.off[s] - n;
-      V acc = zero_v<V>();
-      for (int32_t p0 = 0; p0 < n; p0 += groups * kUH) {
-        V g[kUH];
+        // (e) hot rows: the whole workgroup sums one row, partial sums folded through LDS
+        const int n_heavy = L.n_heavy;
+        for (int hidx = 0; hidx < n_heavy; ++hidx) {
+          const int s = L.heavy[hidx];
+          const int32_t n = L.cnt[s] & (kNewBit - 1);
+          const int32_t b0 = L.off[s] - n;
+          V acc = zero_v<V>();
+          for (int32_t p0 = 0; p0 < n; p0 += groups * kUH) {
+            V g[kUH];
 #pragma unroll
-        for (int u = 0; u < kUH; ++u) {
-          const int32_t p = p0 + u * groups + my_group;
-          g[u] = zero_v<V>();
-          if (p < n && live) g[u] = load_grad<V>(c, job, L.segs[L.order[b0 + p]], sub);
-        }
+            for (int u = 0; u < kUH; ++u) {
+              const int32_t p = p0 + u * groups + my_group;
+              g[u] = zero_v<V>();
+              if (p < n && live) g[u] = load_grad<V>(c, job, L.segs[L.order[b0 + p]], sub);
+            }
 #pragma unroll
-        for (int u = 0; u < kUH; ++u) acc = acc + g[u];
-      }
-      *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = acc;
-      __syncthreads();
-      if (my_group == 0 && live) {
-        V tot = zero_v<V>();
-        for (int gi = 0; gi < groups; ++gi) {
-          tot = tot + *reinterpret_cast<const V*>(&L.red[((size_t)(gi << lpr_log2) + sub) * VE]);
+            for (int u = 0; u < kUH; ++u) acc = acc + g[u];
+          }
+          *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = acc;
+          __syncthreads();
+          if (my_group == 0 && live) {
+            V tot = zero_v<V>();
+            for (int gi = 0; gi < groups; ++gi) {
+              tot = tot + *reinterpret_cast<const V*>(&L.red[((size_t)(gi << lpr_log2) + sub) * VE]);
+            }
+            emit_step_row<V, STEP>(c, job, lr_now, L.slot_out[s], (L.cnt[s] & kNewBit) != 0,
+                             (int64_t)L.keys[s], sub, tot);
+          }
+          __syncthreads();
         }
-        emit_row<V>(c, job, lr_chunk, L.slot_out[s], (L.cnt[s] & kNewBit) != 0,
-                    (int64_t)L.keys[s], sub, tot);
       }
       __syncthreads();
+
+      // chunk done: the tickets go back to zero; once a pass has left pairs behind, the pairs it
+      // did handle are struck out of the pair buffer so that the next pass skips them
+      const bool left = L.n_left > 0;   // uniform: written before the barriers above
+      if (left && first_left < 0) first_left = cb;
+      striking = striking || left;
+#pragma unroll
+      for (int k = 0; k < kCP / kBlock; ++k) {
+        if (hs_[k] >= 0) {
+          L.cnt[hs_[k]] = 0;
+          if (striking) prow[cb + k * kBlock + tid] = kDonePair;
+        }
+      }
+      __syncthreads();
+      HBK_STAMP(6);
     }
+    // the pass is over (job of several chunks): one optimizer step per row the pass emitted.  All
+    // loads of a round first (gradient sums, table rows, accumulator rows of kAp rows per lane
+    // group), then the stores: a load behind a store to a possibly aliasing row would serialise
+    // the round into one memory round trip per row.
+    if (STEP && defer) {
+      constexpr int kAp = 4;
+      const int n_emitted = L.n_emitted;   // written before the last barrier
+      for (int i0 = 0; i0 < n_emitted; i0 += kAp * groups) {
+        int64_t toff[kAp];
+        V g[kAp], tv[kAp], av[kAp];
+#pragma unroll
+        for (int k = 0; k < kAp; ++k) {
+          const int i = i0 + k * groups + my_group;
+          toff[k] = -1;
+          g[k] = tv[k] = av[k] = zero_v<V>();
+          if (i < n_emitted && live) {
+            const int s = L.emitted[i];
+            toff[k] = (int64_t)L.keys[s] * c.dim + (int64_t)sub * VE;
+            g[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(
+                job.out_vals + (int64_t)L.slot_out[s] * c.dim + (int64_t)sub * VE));
+            tv[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff[k]));
+            if (adagrad) {
+              av[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff[k]));
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kAp; ++k) {
+          if (toff[k] >= 0) step_row<V>(c, adagrad, job.lr, toff[k], g[k], tv[k], av[k]);
+        }
+      }
+    }
+    if (first_left < 0) break;     // uniform
+    // another pass for the rows that found no room, with an emptied table
     __syncthreads();
-  }
-  if (defer) {
-    const int n_rng = (n_pairs + kCP - 1) / kCP;
-    for (int r = 0; r < n_rng; ++r) {
-      const int32_t base = L.rng_base[r], n = L.rng_n[r];
-      for (int32_t i = my_group; i < n; i += groups) {
-        if (!live) continue;
-        const int32_t u = base + i;
-        const int64_t row = job.out_rows[u];
-        const V v = __builtin_nontemporal_load(
-            reinterpret_cast<const V*>(job.out_vals + (int64_t)u * c.dim + (int64_t)sub * VE));
-        apply_row<V>(c, job.apply, job.lr, row, sub, v);
-      }
-      __syncthreads();  // rows are distinct inside a range, not across ranges (table clears)
+    for (int i = tid; i < kSlots; i += kBlock) {
+      L.keys[i] = kEmptyKey;
+      L.slot_out[i] = -1;
     }
+    if (tid == 0) {
+      L.occupied = 0;
+      L.n_left = 0;
+      L.n_emitted = 0;
+    }
+    first_cb = first_left;
+    __syncthreads();
   }
 }
 
-// Two instantiations (16-byte / 4-byte chunks) so the common one keeps its registers low; a
-// block whose column is of the other kind exits at once.  Blocks [0, P) of a column take the
-// buckets (range 0 of a split bucket), the e_max spare blocks take the listed extra ranges.
+// Two instantiations (16-byte / 4-byte chunks) so the common one keeps its registers low; a job
+// whose column is of the other kind is skipped.  Every workgroup's job is one 16-byte descriptor
+// written by the scan kernel (slots [0, P) of a column are its buckets = range 0 of a split
+// bucket, the e_max spare slots take the listed extra ranges): one scalar load instead of a chain
+// of dependent loads (column, list of extras, bucket start, bucket end) at the head of every
+// workgroup's critical path.  (Persistent workgroups that fetch the next job's pairs while the
+// current one runs were tried: the state carried around the loop spills, 224 us vs 143.)
 template <typename V>
-__global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const GArgs a) {
-  __shared__ ReduceLds lds;
-  HBK_FIND_COL(a, bucket0)
-  if ((c.vec4 != 0) != (sizeof(V) == 16)) return;
-  const int bi = (int)blockIdx.x - c.bucket0;
-  const int P = c.n_buckets;
-  int bucket = bi, range = 0;
-  if (bi >= P) {
-    const int e = bi - P;
-    if (e >= *c.n_extra) return;
-    bucket = c.work[2 * e];
-    range = c.work[2 * e + 1];
-  }
-  const int32_t start = c.bstart[bucket];
-  const int32_t n_b = c.bstart[bucket + 1] - start;
-  ReduceJob job;
-  job.grad = c.grad_out;
-  job.scale = true;
-  job.seg_is_offset = c.n_runs > 0;
-  job.stride = c.grad_stride;
+__device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4& d, float lr,
+                                  int* ci_out, ReduceJob* job) {
+  if (d.z < 0 || d.y <= 0) return false;   // wave-uniform
+  int ci = (int)__builtin_popcountll(__ballot(my_b0 <= vb)) - 1;
+  ci = __builtin_amdgcn_readfirstlane(ci);
+  const GCol& c = a.col[ci];
+  if ((c.vec4 != 0) != (sizeof(V) == 16)) return false;
+  *ci_out = ci;
+  const int32_t start = d.x, n_b = d.y, bucket = d.z, range = d.w;
+  job->grad = c.grad_out;
+  job->scale = true;
+  job->seg_is_offset = c.n_runs > 0;
+  job->stride = c.grad_stride;
   if (n_b > c.split_t) {
     const int32_t lo = range * c.split_t;
-    job.prow = c.pair_row[0] + start + lo;
-    job.pseg = c.pair_seg[0] + start + lo;
-    job.n_pairs = n_b - lo < c.split_t ? n_b - lo : c.split_t;
-    job.out_rows = c.part_rows;
-    job.out_vals = c.part_vals;
-    job.out_counter = c.pcount + bucket;
-    job.out_base = start;
-    job.lr = 0.0f;
-    job.apply = HBK_APPLY_SGD;
+    job->prow = c.pair_row[0] + start + lo;
+    job->pseg = c.pair_seg[0] + start + lo;
+    job->n_pairs = n_b - lo < c.split_t ? n_b - lo : c.split_t;
+    job->out_rows = c.part_rows;
+    job->out_vals = c.part_vals;
+    job->out_counter = c.pcount + bucket;
+    job->out_base = start;
+    job->lr = 0.0f;
+    job->apply = HBK_APPLY_SGD;
   } else {
-    job.prow = c.pair_row[0] + start;
-    job.pseg = c.pair_seg[0] + start;
-    job.n_pairs = n_b;
+    job->prow = c.pair_row[0] + start;
+    job->pseg = c.pair_seg[0] + start;
+    job->n_pairs = n_b;
+    job->out_rows = c.unique_rows;
+    job->out_vals = c.grad_rows;
+    job->out_counter = c.n_unique;
+    job->out_base = 0;
+    job->lr = lr;
+    job->apply = a.apply;
+  }
+  return true;
+}
+
+template <typename V, int STEP>
+__global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const GArgs a,
+                                                                          const int4* desc) {
+  __shared__ ReduceLds lds;
+  HBK_STAMP_BEGIN()
+  const int lane = (int)threadIdx.x & (kWave - 1);
+  // two independent loads (the job, the columns' first slots): one round trip
+  const int4 d = desc[blockIdx.x];
+  const int my_b0 = lane < a.n_cols ? a.bucket0[lane] : 0x7fffffff;
+  ReduceJob job;
+  int ci;
+  if (!decode_job<V>(a, my_b0, (int)blockIdx.x, d, a.lr, &ci, &job)) return;
+  HBK_STAMP(1);
+  bucket_reduce<V, STEP>(a.col[ci], job, lds);
+  HBK_STAMP(7);
+}
+
+// The partial entries of a split bucket -> final rows.  Every split bucket has exactly one entry
+// with range index 1 in the column's list of extra ranges; the column's merge blocks (at most
+// kMergeBlocks) share that list round robin.
+constexpr int kMergeBlocks = 8;
+template <typename V, int STEP>
+__global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const GArgs a) {
+  __shared__ ReduceLds lds;
+  HBK_FIND_COL(a, merge0)
+  if ((c.vec4 != 0) != (sizeof(V) == 16)) return;
+  const int n_extra = *c.n_extra;
+  const int blocks = c.e_max < kMergeBlocks ? c.e_max : kMergeBlocks;
+  for (int e = (int)blockIdx.x - c.merge0; e < n_extra; e += blocks) {
+    if (c.work[2 * e + 1] != 1) continue;
+    const int bucket = c.work[2 * e];
+    const int32_t start = c.bstart[bucket];
+    ReduceJob job;
+    job.prow = c.part_rows + start;
+    job.pseg = nullptr;
+    job.grad = c.part_vals + (int64_t)start * c.dim;
+    job.n_pairs = c.pcount[bucket];
+    job.scale = false;
+    job.seg_is_offset = false;
+    job.stride = c.dim;
     job.out_rows = c.unique_rows;
     job.out_vals = c.grad_rows;
     job.out_counter = c.n_unique;
     job.out_base = 0;
     job.lr = a.lr;
     job.apply = a.apply;
+    bucket_reduce<V, STEP>(c, job, lds);
   }
-  bucket_reduce<V>(c, job, lds);
-}
-
-// The partial entries of a split bucket -> final rows; spare block e of a column does it when
-// it is the bucket's first extra range (every split bucket has exactly one).
-template <typename V>
-__global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const GArgs a) {
-  __shared__ ReduceLds lds;
-  HBK_FIND_COL(a, merge0)
-  if ((c.vec4 != 0) != (sizeof(V) == 16)) return;
-  const int e = (int)blockIdx.x - c.merge0;
-  if (e >= *c.n_extra || c.work[2 * e + 1] != 1) return;
-  const int bucket = c.work[2 * e];
-  const int32_t start = c.bstart[bucket];
-  ReduceJob job;
-  job.prow = c.part_rows + start;
-  job.pseg = nullptr;
-  job.grad = c.part_vals + (int64_t)start * c.dim;
-  job.n_pairs = c.pcount[bucket];
-  job.scale = false;
-  job.seg_is_offset = false;
-  job.stride = c.dim;
-  job.out_rows = c.unique_rows;
-  job.out_vals = c.grad_rows;
-  job.out_counter = c.n_unique;
-  job.out_base = 0;
-  job.lr = a.lr;
-  job.apply = a.apply;
-  bucket_reduce<V>(c, job, lds);
 }
 
 // ---- d(stitch + combiner): permutation scatter (hbk_group_stitch_bwd) ----------------------
@@ -810,9 +1129,11 @@ struct SCol {
 struct SArgs {
   int32_t n_cols;
   int32_t pad_;
+  int32_t tile0[kMaxStitchCols];   // first block of every column (see GArgs)
   SCol col[kMaxStitchCols];
 };
 static_assert(sizeof(SArgs) <= 20480, "kernarg budget");
+static_assert(kMaxStitchCols <= 2 * kWave, "two lanes-worth of columns in the stitch search");
 
 template <typename V>
 __device__ inline void stitch_segments(const SCol& c, int64_t seg0) {
@@ -856,7 +1177,16 @@ __device__ inline void stitch_segments(const SCol& c, int64_t seg0) {
 }
 
 __global__ __launch_bounds__(kBlock) void stitch_bwd_kernel(const SArgs a) {
-  HBK_FIND_COL(a, tile0)
+  int ci;
+  {
+    const int l = (int)threadIdx.x & (kWave - 1);
+    const int t0 = l < a.n_cols ? a.tile0[l] : 0x7fffffff;
+    const int t1 = l + kWave < a.n_cols ? a.tile0[l + kWave] : 0x7fffffff;
+    ci = (int)__builtin_popcountll(__ballot(t0 <= (int)blockIdx.x)) +
+         (int)__builtin_popcountll(__ballot(t1 <= (int)blockIdx.x)) - 1;
+    ci = __builtin_amdgcn_readfirstlane(ci);
+  }
+  const SCol& c = a.col[ci];
   const int64_t tile = (int)blockIdx.x - c.tile0;
   const int rpi = kWave >> c.lpr_log2;
   const int64_t seg0 = (tile * kWavesPerBlock + (threadIdx.x >> 6)) * (int64_t)(kIters * rpi);
@@ -922,6 +1252,7 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
   b += (size_t)h.n_ids * 8;                                // pair_row
   b += align8((size_t)h.n_ids * 4);                        // pair_seg
   if (h.row_splits != nullptr) b += align8((size_t)h.n_ids * 4);
+  b += ((size_t)p.n_buckets + p.e_max) * sizeof(int4);     // desc (carved from the call's head)
   b += align8((size_t)p.e_max * 8) + 8;                    // work, n_extra
   b += align8(((size_t)p.n_buckets) * 4);                 // pcount
   b += (size_t)h.n_ids * 8;                                // part_rows
@@ -932,12 +1263,28 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
 }  // namespace
 }  // namespace hbk
 
+#ifdef HBK_BWD_STAMPS
+// probe builds: constant-clock (100 MHz) stamps of the first 8192 reduce workgroups, 8 each
+extern "C" int hbk_debug_bwd_trace(unsigned long long* out, int reset) {
+  using namespace hbk;
+  HBK_HIP_OK(hipDeviceSynchronize());
+  if (out != nullptr) {
+    HBK_HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_trace), sizeof(g_bwd_trace)));
+  }
+  if (reset) {
+    static unsigned long long z[kTraceBlocks * kTraceSlots];
+    HBK_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_trace), z, sizeof(z)));
+  }
+  return HBK_OK;
+}
+#endif
+
 extern "C" size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
                                                        const hbk_lookup_grad_column_t* cols) {
   if (n_cols <= 0 || cols == nullptr) return 0;
   size_t total = 0;
   for (int32_t c = 0; c < n_cols; ++c) total += hbk::col_workspace(cols[c]);
-  return total;
+  return total == 0 ? 0 : total + 16;   // the descriptor table is aligned to 16 bytes inside
 }
 
 extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
@@ -992,14 +1339,24 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
               workspace_bytes);
   HBK_REQUIRE(((uintptr_t)workspace & 7) == 0,
               "group_lookup_bwd: workspace must be 8-byte aligned");
-  char* wp = reinterpret_cast<char*>(workspace);
+  // head of the workspace: the job descriptors of all columns (16-byte aligned), then the
+  // per-column buffers
+  char* dp = reinterpret_cast<char*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  char* wp = dp;
+  for (int32_t c = 0; c < n_cols; ++c) {
+    if (cols[c].n_ids <= 0) continue;
+    const ColPlan p = plan_of(cols[c].n_ids, cols[c].dim);
+    wp += ((size_t)p.n_buckets + p.e_max) * sizeof(int4);
+  }
 
   int32_t c0 = 0;
   while (c0 < n_cols) {
     GArgs args, seg_args;
+    int4* const desc_group = reinterpret_cast<int4*>(dp);
     int32_t k = 0, ks = 0;
     int64_t tiles = 0, buckets = 0, segtiles = 0, merges = 0, scans = 0;
     size_t lds_hist = 0;
+    bool small_scan = true;
     while (c0 < n_cols && k < kMaxCols) {
       const hbk_lookup_grad_column_t& h = cols[c0++];
       if (h.n_ids == 0) {
@@ -1030,6 +1387,8 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
         d.seg_of = reinterpret_cast<int32_t*>(wp);
         wp += align8((size_t)h.n_ids * 4);
       }
+      d.desc = reinterpret_cast<int4*>(dp);
+      dp += ((size_t)p.n_buckets + p.e_max) * sizeof(int4);
       d.work = reinterpret_cast<int32_t*>(wp);
       wp += align8((size_t)p.e_max * 8);
       d.n_extra = reinterpret_cast<int32_t*>(wp);
@@ -1043,9 +1402,10 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       d.split_t = p.split_t;
       d.e_max = p.e_max;
       d.merge0 = (int32_t)merges;
-      merges += p.e_max;
+      merges += p.e_max < kMergeBlocks ? p.e_max : kMergeBlocks;
       d.scan0 = (int32_t)scans;
       scans += ((int64_t)p.n_buckets + kBlock - 1) / kBlock;
+      small_scan = small_scan && p.n_buckets <= kBlock && p.tiles <= 64;
       d.run_start = h.run_start;
       d.run_ids = h.run_ids;
       d.run_grads = h.run_grads;
@@ -1078,10 +1438,16 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       HBK_REQUIRE(tiles < (1ll << 31) && buckets < (1ll << 31),
                   "group_lookup_bwd: grid too large");
       if ((size_t)4 * p.n_buckets > lds_hist) lds_hist = (size_t)4 * p.n_buckets;
+      args.tile0[k] = d.tile0;
+      args.bucket0[k] = d.bucket0;
+      args.merge0[k] = d.merge0;
+      args.scan0[k] = d.scan0;
+      args.segtile0[k] = 0;
       if (h.row_splits != nullptr && h.n_segments > 0) {
         GCol& sdesc = seg_args.col[ks];
         sdesc = d;
         sdesc.segtile0 = (int32_t)segtiles;
+        seg_args.segtile0[ks] = (int32_t)segtiles;
         segtiles += (h.n_segments + kBlock - 1) / kBlock;
         ++ks;
       }
@@ -1100,9 +1466,13 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     }
     hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist, stream,
                        args);
-    hipLaunchKernelGGL(bwd_scan_tiles_kernel, dim3((unsigned)scans), dim3(kBlock), 0, stream,
-                       args);
-    hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)k), dim3(kBlock), 0, stream, args);
+    if (small_scan) {
+      hipLaunchKernelGGL(bwd_scan_fused_kernel, dim3((unsigned)k), dim3(kBlock), 0, stream, args);
+    } else {
+      hipLaunchKernelGGL(bwd_scan_tiles_kernel, dim3((unsigned)scans), dim3(kBlock), 0, stream,
+                         args);
+      hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)k), dim3(kBlock), 0, stream, args);
+    }
     hipLaunchKernelGGL(bwd_scatter_pairs_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist,
                        stream, args);
     bool any_vec4 = false, any_scalar = false;
@@ -1110,22 +1480,28 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       any_vec4 |= args.col[q].vec4 != 0;
       any_scalar |= args.col[q].vec4 == 0;
     }
+    // one instantiation per optimizer (none / SGD / Adagrad)
+    const int step = apply_lr == 0.0f ? 0 : apply == HBK_APPLY_ADAGRAD ? 2 : 1;
+    typedef void (*reduce_fn)(const GArgs, const int4*);
+    typedef void (*merge_fn)(const GArgs);
+    static const reduce_fn kReduce4[3] = {&bwd_reduce_kernel<f32x4, 0>, &bwd_reduce_kernel<f32x4, 1>,
+                                          &bwd_reduce_kernel<f32x4, 2>};
+    static const reduce_fn kReduce1[3] = {&bwd_reduce_kernel<float, 0>, &bwd_reduce_kernel<float, 1>,
+                                          &bwd_reduce_kernel<float, 2>};
+    static const merge_fn kMerge4[3] = {&bwd_merge_kernel<f32x4, 0>, &bwd_merge_kernel<f32x4, 1>,
+                                        &bwd_merge_kernel<f32x4, 2>};
+    static const merge_fn kMerge1[3] = {&bwd_merge_kernel<float, 0>, &bwd_merge_kernel<float, 1>,
+                                        &bwd_merge_kernel<float, 2>};
+    const reduce_fn reduce4 = kReduce4[step], reduce1 = kReduce1[step];
+    const merge_fn merge4 = kMerge4[step], merge1 = kMerge1[step];
     if (any_vec4) {
-      hipLaunchKernelGGL(bwd_reduce_kernel<f32x4>, dim3((unsigned)buckets), dim3(kBlock), 0,
-                         stream, args);
+      hipLaunchKernelGGL(reduce4, dim3((unsigned)buckets), dim3(kBlock), 0, stream, args, desc_group);
     }
     if (any_scalar) {
-      hipLaunchKernelGGL(bwd_reduce_kernel<float>, dim3((unsigned)buckets), dim3(kBlock), 0,
-                         stream, args);
+      hipLaunchKernelGGL(reduce1, dim3((unsigned)buckets), dim3(kBlock), 0, stream, args, desc_group);
     }
-    if (any_vec4) {
-      hipLaunchKernelGGL(bwd_merge_kernel<f32x4>, dim3((unsigned)merges), dim3(kBlock), 0,
-                         stream, args);
-    }
-    if (any_scalar) {
-      hipLaunchKernelGGL(bwd_merge_kernel<float>, dim3((unsigned)merges), dim3(kBlock), 0,
-                         stream, args);
-    }
+    if (any_vec4) hipLaunchKernelGGL(merge4, dim3((unsigned)merges), dim3(kBlock), 0, stream, args);
+    if (any_scalar) hipLaunchKernelGGL(merge1, dim3((unsigned)merges), dim3(kBlock), 0, stream, args);
     HBK_HIP_OK(hipGetLastError());
   }
   return HBK_OK;
@@ -1190,6 +1566,7 @@ extern "C" int hbk_group_stitch_bwd(int32_t n_cols, const hbk_stitch_grad_column
       const int64_t rpi = kWave >> d.lpr_log2;
       const int64_t per_block = kWavesPerBlock * kIters * rpi;
       d.tile0 = (int32_t)t_seg;
+      args.tile0[k] = (int32_t)t_seg;
       t_seg += (h.n_segments + per_block - 1) / per_block;
       HBK_REQUIRE(t_seg < (1ll << 31), "group_stitch_bwd: grid too large");
       ++k;

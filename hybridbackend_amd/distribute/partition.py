@@ -14,17 +14,22 @@ from hybridbackend_amd import _lib
 
 
 class _Workspace:
-  """Grow-only device scratch, one per (device, stream-agnostic) caller."""
+  """Grow-only device scratch, ONE PER STREAM: the partition kernels of two streams (prefetch
+  thread and training thread, or the in-process ranks of a test) run concurrently and must not
+  share their histograms."""
 
   def __init__(self):
-    self._buf = None
+    self._bufs = {}
 
   def get(self, nbytes, device):
     if nbytes == 0:
       return None, 0
-    if self._buf is None or self._buf.numel() < nbytes or self._buf.device != device:
-      self._buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-    return self._buf, self._buf.numel()
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    buf = self._bufs.get(key)
+    if buf is None or buf.numel() < nbytes:
+      buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+      self._bufs[key] = buf
+    return buf, buf.numel()
 
 
 _ws = _Workspace()

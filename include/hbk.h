@@ -181,10 +181,10 @@ int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
  *   nothing.  No global atomics on the data path: ids are grouped by a hash of their row and
  *   each group is reduced by one workgroup (LDS hash table of the distinct rows, sums in
  *   registers; a group holding a hot row is split over several workgroups and merged), so the
- *   summation order is not fixed: tolerance 1e-5 relative.  Rows are distinct unless one group
- *   spans several full 512-pair chunks with more than ~500 distinct rows (adversarial hashing,
- *   or more than ~7 M ids in one column): then a row may appear in more than one entry, sum semantics preserved
- *   (IndexedSlices allow repeated indices; the fused SGD apply stays exact).
+ *   summation order is not fixed: tolerance 1e-5 relative.  unique_rows[c][0..u) are DISTINCT
+ *   whatever the column holds: a group with more distinct rows than the workgroup's LDS table
+ *   takes further passes over its pairs (rows handled in one pass are struck out), so every row
+ *   is emitted -- and stepped by the fused optimizer -- exactly once.
  *   apply_lr != 0 additionally performs the sparse SGD update on the shard in the same
  *   pass: table[unique_rows[u],:] -= apply_lr * grad_rows[u,:] (sharded variables skip
  *   cross-rank aggregation, hbtf/training/gradient.py:193-217).                        */

@@ -55,7 +55,7 @@ def _run_ranks(world, fn):
   for t in threads:
     t.start()
   for t in threads:
-    t.join(timeout=600)
+    t.join(timeout=90)
   for c in comms:
     c.close()
   assert not errors, errors

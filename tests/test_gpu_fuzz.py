@@ -208,7 +208,7 @@ def test_sharded_driver_random_in_process_world(world, cols, wire16, seed):
   for t in threads:
     t.start()
   for t in threads:
-    t.join(timeout=120)
+    t.join(timeout=45)
   for cm in comms:
     cm.close()
   assert not errors, errors

@@ -189,7 +189,7 @@ def _run_ranks(world, fn):
   for t in threads:
     t.start()
   for t in threads:
-    t.join(timeout=120)
+    t.join(timeout=45)
   for c in comms:
     c.close()
   assert not errors, errors

@@ -387,9 +387,10 @@ def test_group_lookup_backward(combiner):
     _check_slices(res[c], ids[c] % buckets[c], grads[c], splits[c], combiner)
 
 
-def test_group_lookup_backward_multi_chunk_and_table_clear_path(monkeypatch):
+def test_group_lookup_backward_multi_chunk_and_multi_pass_path(monkeypatch):
   # one bucket per column: many 512-pair chunks per workgroup, rows spanning chunks are
-  # accumulated into their output row, and > 768 distinct rows force table clears
+  # accumulated into their output row, and more distinct rows than the LDS table holds force
+  # further passes over the bucket -- every row is still emitted exactly once
   monkeypatch.setenv('HBK_BWD_LOG2P', '0')
   rng = np.random.RandomState(21)
   for d, rows, n in ((16, 97, 5000), (128, 3000, 9000), (6, 10, 2000), (32, 100000, 4000)):
@@ -399,7 +400,7 @@ def test_group_lookup_backward_multi_chunk_and_table_clear_path(monkeypatch):
     t_dev = dev(table.copy())
     lookup = hb.embedding.GroupLookup([t_dev], [rows], 'sum')
     res = hb.embedding.GroupLookupGrad(lookup)([dev(ids)], [dev(grads)], apply_lr=0.5)[0]
-    _check_slices(res, ids % rows, grads, None, 'sum', distinct=False,
+    _check_slices(res, ids % rows, grads, None, 'sum', distinct=True,
                   atol=RTOL * 30)   # hundreds of N(0,1) terms per row: error ~ 1e-5 * sqrt(n)
     ref = table.astype(np.float64)
     np.subtract.at(ref, ids % rows, 0.5 * grads.astype(np.float64))
@@ -532,8 +533,9 @@ def test_group_lookup_backward_fused_adagrad_apply(monkeypatch, hook):
   if hook:
     monkeypatch.setenv('HBK_BWD_LOG2P', '0')     # one bucket: many chunks per workgroup
   rng = np.random.RandomState(91)
-  # (one forced bucket spans many full chunks: it must stay below ~500 distinct rows, see hbk.h)
-  for d, rows, n in ((16, 300, 6000), (128, 50, 2000), (6, 450 if hook else 10000, 3000)):
+  # (the forced single bucket holds far more distinct rows than the 1024-slot LDS table: several
+  # passes over the bucket, and still one entry and ONE step per row)
+  for d, rows, n in ((16, 300, 6000), (128, 50, 2000), (6, 10000, 3000), (16, 4000, 20000)):
     table = rng.uniform(-1, 1, size=(rows, d)).astype(np.float32)
     accum = np.full((rows, d), 0.1, np.float32)
     ids = rng.randint(0, 2**40, size=n).astype(np.int64)
@@ -688,3 +690,36 @@ def test_large_single_column_properties():
   dense = torch.zeros(rows, d, device=DEV, dtype=torch.float64)
   dense.index_add_(0, r, g.double())
   torch.testing.assert_close(grows[:k].double(), dense[urows[:k]], rtol=1e-5, atol=1e-5)
+
+
+def test_partition_from_concurrent_streams():
+  """Two host threads, each on its own stream, partition different ids at the same time (what
+  in-process ranks, or a prefetch thread beside the training thread, do): the scratch of the
+  partition kernels is per stream, the results stay bit-exact."""
+  import threading
+  rng = np.random.RandomState(31)
+  n_threads, rounds = 4, 20
+  xs = [[rng.randint(0, 2**40, size=rng.randint(20000, 70000)).astype(np.int64) for _ in range(3)]
+        for _ in range(n_threads)]
+  want = [[oracle.partition_by_modulo(x, 8) for x in xs[t]] for t in range(n_threads)]
+  errors = []
+
+  def run(t):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        d = [dev(x) for x in xs[t]]
+        for _ in range(rounds):
+          ys, sizes, idxs = hb.distribute.partition_by_modulo_n(d, 8)
+          for c in range(3):
+            np.testing.assert_equal(host(ys[c]), want[t][c][0])
+            np.testing.assert_equal(host(sizes[c]), want[t][c][1])
+            np.testing.assert_equal(host(idxs[c]), want[t][c][2])
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((t, repr(e)[:300]))
+
+  threads = [threading.Thread(target=run, args=(t,)) for t in range(n_threads)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=45)
+  assert not errors, errors

@@ -247,7 +247,7 @@ def test_cxx_driver_multi_rank_in_process_world(monkeypatch, world, wire16, id64
   for t in threads:
     t.start()
   for t in threads:
-    t.join(timeout=120)
+    t.join(timeout=45)
   assert not errors, errors
   assert all(x is not None for x in results)
   eff = tables
@@ -372,7 +372,7 @@ def test_dense_features_sharded_and_replicated_columns_in_process_world():
   for t in threads:
     t.start()
   for t in threads:
-    t.join(timeout=120)
+    t.join(timeout=45)
   assert not errors, errors
   wants = [_want_dense(cols, tables, feats[r]) for r in range(world)]
   for r in range(world):
@@ -432,7 +432,7 @@ def test_gradient_aggregation_in_process_world(world):
   for t in threads:
     t.start()
   for t in threads:
-    t.join(timeout=120)
+    t.join(timeout=45)
   assert not errors, errors
   want_max = np.max(np.stack(ints), axis=0)
   for r in range(world):
@@ -510,7 +510,7 @@ def test_cxx_driver_empty_ranks_and_columns_in_process_world():
   for t in threads:
     t.start()
   for t in threads:
-    t.join(timeout=120)
+    t.join(timeout=45)
   assert not errors, errors
   for r in range(world):
     want = oracle.group_lookup_fwd(tables, ids[r], splits[r], rows, combiners)
@@ -598,7 +598,7 @@ def test_dense_features_adagrad_sharded_in_process_world():
   for t in threads:
     t.start()
   for t in threads:
-    t.join(timeout=120)
+    t.join(timeout=45)
   for cm in comms:
     cm.close()
   assert not errors, errors
@@ -675,7 +675,7 @@ def test_sharded_prefetch_next_step(world):
   for t in threads:
     t.start()
   for t in threads:
-    t.join(timeout=120)
+    t.join(timeout=45)
   for cm in comms:
     cm.close()
   assert not errors, errors
@@ -802,7 +802,7 @@ def test_hierarchical_call_in_process_world(local_size, nodes):
   for t in threads:
     t.start()
   for t in threads:
-    t.join(timeout=120)
+    t.join(timeout=45)
   for cm in comms:
     cm.close()
   assert not errors, errors

@@ -2,6 +2,7 @@
 // unique (R7), backward duplicate-row reduction (R10).  HIP events around `iters` back-to-back
 // calls on the null stream; inputs regenerated per call from a pool of resident id batches.
 //   build: make -C tools        run: tools/bin/bench_ops
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -176,6 +177,54 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
   snprintf(what, sizeof(what), "group_lookup_bwd %d x %lld ids, dim %d, %lld rows%s", n_cols,
            (long long)B, dim, (long long)rows, lr != 0.f ? " + SGD apply" : "");
   printf("%-66s %9.2f us  %8.1f M lookups/s\n", what, us, n / us);
+  {  // probe build of the library (-DHBK_BWD_STAMPS): shader-clock stamps of the reduce workgroups
+    typedef int (*trace_fn)(unsigned long long*, int);
+    trace_fn fn = (trace_fn)dlsym(RTLD_DEFAULT, "hbk_debug_bwd_trace");
+    if (fn != nullptr) {
+      std::vector<unsigned long long> tr(8192 * 8);
+      fn(nullptr, 1);
+      fill(0);
+      HB(hbk_group_lookup_bwd(n_cols, cols.data(), lr, ws, ws_bytes, nullptr));
+      fn(tr.data(), 0);
+      static const char* names[7] = {"setup (column, bstart)", "table init", "(a) pairs + insert",
+                                     "(b) scan", "(c) gradient round", "(d,e) + chunk end", "exit"};
+      // stamps are ticks of the 100 MHz constant clock (10 ns), the same clock on every CU
+      double sum[7] = {0}, life = 0;
+      unsigned long long t_min = ~0ull, t_max = 0;
+      int n_blocks = 0;
+      for (int b = 0; b < 8192; ++b) {
+        const unsigned long long* t = &tr[(size_t)b * 8];
+        if (t[0] == 0 || t[7] == 0) continue;
+        bool ok = true;
+        for (int i = 1; i < 8; ++i) ok = ok && t[i] >= t[i - 1];
+        if (!ok) continue;
+        ++n_blocks;
+        for (int i = 0; i < 7; ++i) sum[i] += (double)(t[i + 1] - t[i]);
+        life += (double)(t[7] - t[0]);
+        t_min = t[0] < t_min ? t[0] : t_min;
+        t_max = t[7] > t_max ? t[7] : t_max;
+      }
+      const double nb = n_blocks ? n_blocks : 1;
+      printf("   reduce kernel: %d traced workgroups over %.1f us, mean life %.2f us (=> %.0f alive on "
+             "average); per phase (us):", n_blocks, (t_max - t_min) * 0.01, life / nb * 0.01,
+             life * 0.01 / ((t_max - t_min) * 0.01 + 1e-9));
+      for (int i = 0; i < 7; ++i) printf("  %s %.2f", names[i], sum[i] / nb * 0.01);
+      printf("\n");
+      // how many workgroups are alive / past their setup at a few instants
+      for (int q = 1; q <= 9; q += 2) {
+        const unsigned long long at = t_min + (t_max - t_min) * q / 10;
+        int alive = 0, working = 0, started = 0;
+        for (int b = 0; b < 8192; ++b) {
+          const unsigned long long* t = &tr[(size_t)b * 8];
+          if (t[0] == 0 || t[7] == 0) continue;
+          started += t[0] <= at;
+          alive += t[0] <= at && at < t[7];
+          working += t[1] <= at && at < t[7];
+        }
+        printf("     at %d0%% of the span: %d started, %d alive, %d past setup\n", q, started, alive, working);
+      }
+    }
+  }
   for (auto& t : tables) CK(hipFree(t));
 }
 

@@ -37,11 +37,21 @@ for st in $STAGES; do
       timeout 300 python bench.py --gpus 1 --sharded --steps 20 --warmup 5 --cpu-seconds 0 > $O/bench_sharded1.log 2>&1; echo "bench rc=$?" >> $O/bench_sharded1.log; tail -3 $O/bench_sharded1.log;;
     ops)
       timeout 300 tools/bin/bench_ops > $O/bench_ops.log 2>&1; echo "ops rc=$?" >> $O/bench_ops.log; cat $O/bench_ops.log;;
+    ceilpmc)
+      prof pmc_ceil_rd "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" -- $R/tools/bin/ceiling_probe --quick
+      prof pmc_ceil_hit "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/ceiling_probe --quick
+      for f in pmc_ceil_rd pmc_ceil_hit; do echo "== $f"; tail -2 $O/$f.log; python - $O/$f.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k,v in sorted(d.items()):
+  print(k[:60].ljust(60), {c:round(x['mean']) for c,x in v.items()})
+PY
+      done;;
     ceil)
       timeout 600 tools/bin/ceiling_probe > $O/ceiling.log 2>&1; echo "rc=$?" >> $O/ceiling.log; cat $O/ceiling.log
-      prof pmc_ceil_rd "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" -- tools/bin/ceiling_probe --quick
-      prof pmc_ceil_hit "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- tools/bin/ceiling_probe --quick
-      prof pmc_ceil_req "TCC_REQ_sum TCC_READ_sum TCC_EA0_RD_UNCACHED_32B_sum TCC_BUBBLE_sum" -- tools/bin/ceiling_probe --quick
+      prof pmc_ceil_rd "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" -- $R/tools/bin/ceiling_probe --quick
+      prof pmc_ceil_hit "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/ceiling_probe --quick
+      prof pmc_ceil_req "TCC_REQ_sum TCC_READ_sum TCC_EA0_RD_UNCACHED_32B_sum TCC_BUBBLE_sum" -- $R/tools/bin/ceiling_probe --quick
       prof pmc_bench_rd "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" -- python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0
       prof pmc_bench_hit "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0
       prof pmc_bench_fetch "FETCH_SIZE" -- python $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0
@@ -51,7 +61,7 @@ for st in $STAGES; do
       prof prof_bench "" -- python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0
       cat $O/prof_bench.txt;;
     profops)
-      prof prof_ops "" -- tools/bin/bench_ops ${OPS_ARGS:-}
+      prof prof_ops "" -- $R/tools/bin/bench_ops ${OPS_ARGS:-}
       cat $O/prof_ops.txt;;
     sweep)
       timeout 1200 python tools/sweep.py --big --cases ${SWEEP_CASES:-a,b,c,d,e,f,g,h,i} > $O/sweep.log 2>&1; echo "sweep rc=$?" >> $O/sweep.log; cut -c1-400 $O/sweep.log;;

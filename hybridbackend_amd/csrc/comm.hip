@@ -75,6 +75,14 @@ namespace {
     }                                                                                \
   } while (0)
 
+// inside ncclGroupStart .. ncclGroupEnd: a failing call must not leave the group open (the
+// communicator would be unusable): remember the first error, keep going to the ncclGroupEnd
+#define HBK_NCCL_IN_GROUP(first_err, expr)                                           \
+  do {                                                                               \
+    ncclResult_t r__ = (expr);                                                       \
+    if (r__ != ncclSuccess && (first_err) == ncclSuccess) (first_err) = r__;         \
+  } while (0)
+
 bool to_nccl(int32_t dtype, ncclDataType_t* out) {
   switch (dtype) {
     case HBK_INT8: *out = ncclInt8; return true;
@@ -364,6 +372,7 @@ extern "C" int hbk_alltoall_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t
   HBK_REQUIRE(!comm->aborted, "alltoall_n: communicator was aborted");
   int rc = fence_in(comm, as_stream(compute_stream));
   if (rc != HBK_OK) return rc;
+  ncclResult_t in_group = ncclSuccess;
   HBK_NCCL_OK(ncclGroupStart());
   for (int32_t c = 0; c < n; ++c) {
     if (counts[c] == 0) continue;
@@ -373,11 +382,12 @@ extern "C" int hbk_alltoall_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t
     for (int64_t i = 0; i < active; ++i) {
       const size_t off = (size_t)i * part * esize;
       if (ranks[i] == comm->rank) continue;  // own slice: copied below, never through RCCL
-      HBK_NCCL_OK(ncclSend(sendbuf + off, part, nt, ranks[i], comm->comm, comm->stream));
-      HBK_NCCL_OK(ncclRecv(recvbuf + off, part, nt, ranks[i], comm->comm, comm->stream));
+      HBK_NCCL_IN_GROUP(in_group, ncclSend(sendbuf + off, part, nt, ranks[i], comm->comm, comm->stream));
+      HBK_NCCL_IN_GROUP(in_group, ncclRecv(recvbuf + off, part, nt, ranks[i], comm->comm, comm->stream));
     }
   }
   HBK_NCCL_OK(ncclGroupEnd());
+  HBK_NCCL_OK(in_group);
   for (int32_t c = 0; c < n; ++c) {
     const size_t part = (size_t)(counts[c] / active);
     for (int64_t i = 0; i < active && part > 0; ++i) {
@@ -523,6 +533,14 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
     if (after != nullptr) HBK_HIP_OK(hipEventRecord(after, cs));
     return HBK_OK;
   }
+  for (int32_t c = 0; c < n; ++c) {     // checked before any RCCL group is opened
+    for (int32_t i = 0; i < active; ++i) {
+      HBK_REQUIRE(ranks[i] != comm->rank || send_sizes[(size_t)c * active + i] ==
+                                                recv_sizes[(size_t)c * active + i],
+                  "alltoallv_n: self send/recv sizes differ for input %d (%d, %d)", c,
+                  send_sizes[(size_t)c * active + i], recv_sizes[(size_t)c * active + i]);
+    }
+  }
   std::unique_lock<std::mutex> lock(comm->mu);
   HBK_REQUIRE(!comm->aborted, "alltoallv_n: communicator was aborted");
   int rc = HBK_OK;
@@ -542,6 +560,8 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
     rc = cast_n_impl(n, HBK_FLOAT, HBK_HALF, inputs, lens.data(), dst.data(), comm->stream);
     if (rc != HBK_OK) return rc;
   }
+  ncclResult_t in_group = ncclSuccess;
+  hipError_t copy_err = hipSuccess;
   HBK_NCCL_OK(ncclGroupStart());
   for (int32_t c = 0; c < n; ++c) {
     const char* sendbuf = reinterpret_cast<const char*>(wire_in[c]);
@@ -553,20 +573,18 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
       if (ranks[i] == comm->rank) {
         // own slice: a device copy on the comm stream (RCCL's self send/recv moves it through
         // one channel's copy loop: 54 MB took 111 us, the blit engine path ~25 us)
-        HBK_REQUIRE(sendsize == recvsize, "alltoallv_n: self send/recv sizes differ (%zu, %zu)",
-                    sendsize, recvsize);
-        if (sendsize > 0) {
-          HBK_HIP_OK(hipMemcpyAsync(recvbuf + recvoffset, sendbuf + sendoffset,
-                                    sendsize * esize, hipMemcpyDeviceToDevice, comm->stream));
+        if (sendsize > 0 && copy_err == hipSuccess) {
+          copy_err = hipMemcpyAsync(recvbuf + recvoffset, sendbuf + sendoffset, sendsize * esize,
+                                    hipMemcpyDeviceToDevice, comm->stream);
         }
       } else {
         if (sendsize > 0) {
-          HBK_NCCL_OK(ncclSend(sendbuf + sendoffset, sendsize, nt, ranks[i], comm->comm,
-                               comm->stream));
+          HBK_NCCL_IN_GROUP(in_group, ncclSend(sendbuf + sendoffset, sendsize, nt, ranks[i],
+                                               comm->comm, comm->stream));
         }
         if (recvsize > 0) {
-          HBK_NCCL_OK(ncclRecv(recvbuf + recvoffset, recvsize, nt, ranks[i], comm->comm,
-                               comm->stream));
+          HBK_NCCL_IN_GROUP(in_group, ncclRecv(recvbuf + recvoffset, recvsize, nt, ranks[i],
+                                               comm->comm, comm->stream));
         }
       }
       sendoffset += sendsize * esize;
@@ -574,6 +592,8 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
     }
   }
   HBK_NCCL_OK(ncclGroupEnd());
+  HBK_NCCL_OK(in_group);
+  HBK_HIP_OK(copy_err);
   if (half_wire) {
     std::vector<int64_t> lens(n);
     std::vector<const void*> src(n);
@@ -781,7 +801,11 @@ extern "C" int hbk_allreduce_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
     red_in = red_out = workspace;
   }
   hipStream_t rs = comm->local != nullptr ? cs : comm->stream;   // stream of pack/reduce/unpack
+  // one communicator = one ordered queue: everything enqueued on its stream is under its mutex
+  std::unique_lock<std::mutex> lock(comm->mu, std::defer_lock);
   if (comm->local == nullptr) {
+    lock.lock();
+    HBK_REQUIRE(!comm->aborted, "allreduce_n: communicator was aborted");
     int rc = fence_in(comm, cs);
     if (rc != HBK_OK) return rc;
   }
@@ -839,8 +863,6 @@ extern "C" int hbk_allreduce_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
     (void)hipFree(tmp);
     w->barrier();
   } else {
-    std::unique_lock<std::mutex> lock(comm->mu);
-    HBK_REQUIRE(!comm->aborted, "allreduce_n: communicator was aborted");
     HBK_NCCL_OK(ncclAllReduce(red_in, red_out, (size_t)total, nt, op, comm->comm, comm->stream));
   }
   if (n > 1) {
@@ -886,18 +908,20 @@ extern "C" int hbk_allgatherv(hbk_comm_t comm, int32_t dtype, const void* input,
   HBK_REQUIRE(!comm->aborted, "allgatherv: communicator was aborted");
   int rc = fence_in(comm, cs);
   if (rc != HBK_OK) return rc;
+  ncclResult_t in_group = ncclSuccess;
   HBK_NCCL_OK(ncclGroupStart());
   for (int r = 0; r < W; ++r) {
     if (r == me) continue;
     if (counts[me] > 0) {
-      HBK_NCCL_OK(ncclSend(input, (size_t)counts[me], nt, r, comm->comm, comm->stream));
+      HBK_NCCL_IN_GROUP(in_group, ncclSend(input, (size_t)counts[me], nt, r, comm->comm, comm->stream));
     }
     if (counts[r] > 0) {
-      HBK_NCCL_OK(ncclRecv(out + (size_t)off[r] * esize, (size_t)counts[r], nt, r, comm->comm,
-                           comm->stream));
+      HBK_NCCL_IN_GROUP(in_group, ncclRecv(out + (size_t)off[r] * esize, (size_t)counts[r], nt, r,
+                                           comm->comm, comm->stream));
     }
   }
   HBK_NCCL_OK(ncclGroupEnd());
+  HBK_NCCL_OK(in_group);
   if (counts[me] > 0) {
     HBK_HIP_OK(hipMemcpyAsync(out + (size_t)off[me] * esize, input, (size_t)counts[me] * esize,
                               hipMemcpyDeviceToDevice, comm->stream));

@@ -159,7 +159,15 @@ class ParquetDataset:
           raise item
         batch, ready = item
         if ready is not None:
-          torch.cuda.current_stream(self.device).wait_event(ready)
+          cur = torch.cuda.current_stream(self.device)
+          cur.wait_event(ready)
+          # the tensors were allocated on the copy stream: tell the caching allocator that the
+          # consumer's stream uses them too, or their blocks could be handed to a later batch's
+          # H2D copy while lookup kernels of this batch are still queued on the consumer's stream
+          for v in batch.values():
+            for t in (v if isinstance(v, tuple) else (v,)):
+              if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)
         yield batch
     finally:
       stop.set()

@@ -202,6 +202,13 @@ class GroupLookupGrad:
       i, g, s = ids[c], grads[c], row_splits[c]
       _lib.require_device_tensor(i, 'ids')
       _lib.require_device_tensor(g, 'grads', row_strided=True)
+      if i.dtype not in (torch.int32, torch.int64) or i.dim() != 1:
+        raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, 'ids must be an int32/int64 vector')
+      if s is not None:
+        _lib.require_device_tensor(s, 'row_splits')
+        if s.dtype != torch.int32 or s.dim() != 1 or s.numel() < 1:
+          raise _lib.InvalidArgumentError(
+            _lib.INVALID_ARGUMENT, 'row_splits must be an int32 vector [segments+1]')
       n_seg = i.numel() if s is None else s.numel() - 1
       if g.dtype != torch.float32 or tuple(g.shape) != (n_seg, dims[c]):
         raise _lib.InvalidArgumentError(

@@ -45,7 +45,7 @@ class _Step:
 
 class _BoundStep:
   """One step's tensors marshalled for hbk_sharded_lookup_fwd (ShardedGroupLookup.bind)."""
-  __slots__ = ('keep', 'outs', 'args')
+  __slots__ = ('keep', 'outs', 'args', 'shapes')
 
 
 class ShardedGroupLookup:
@@ -166,6 +166,9 @@ class ShardedGroupLookup:
       s = row_splits[c]
       if s is not None:
         _lib.require_device_tensor(s, 'row_splits')
+        if s.dtype != torch.int32 or s.dim() != 1 or s.numel() < 1:
+          raise _lib.InvalidArgumentError(
+            _lib.INVALID_ARGUMENT, 'row_splits must be an int32 vector [segments+1]')
       n_seg.append(ids[c].numel() if s is None else s.numel() - 1)
     if outs is None:
       outs = [torch.empty((n_seg[c], self.dims[c]), dtype=torch.float32, device=self.device)
@@ -176,6 +179,7 @@ class ShardedGroupLookup:
         raise _lib.InvalidArgumentError(
           _lib.INVALID_ARGUMENT, f'output {c} must be fp32 [{n_seg[c]}, {self.dims[c]}]')
     bound = _BoundStep()
+    bound.shapes = [(n_seg[c], self.dims[c]) for c in range(n)]
     bound.keep = (ids, row_splits, outs)
     bound.outs = outs
     # column blocks of one wider tensor are written in place (row stride != dim)
@@ -189,6 +193,7 @@ class ShardedGroupLookup:
   def launch(self, bound):
     """Enqueue a bound step on the current stream; returns its outputs."""
     self._keep = bound.keep
+    self._last_shapes = bound.shapes   # what backward() differentiates
     _lib.check(self._lib.hbk_sharded_lookup_fwd(
       self._plan(), *bound.args, _lib.current_stream(self.device)))
     return bound.outs
@@ -254,9 +259,18 @@ class ShardedGroupLookup:
     (collective.py:334-347): no new size exchange, no host sync."""
     n = len(self.shards)
     plan = self._plan()
+    if optimizer not in ('sgd', 'adagrad'):
+      raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, "optimizer must be 'sgd' or 'adagrad'")
     res = []
+    shapes = getattr(self, '_last_shapes', None)
     for c in range(n):
       _lib.require_device_tensor(grads[c], 'grads', row_strided=True)
+      if grads[c].dtype != torch.float32 or (
+          shapes is not None and tuple(grads[c].shape) != shapes[c]):
+        raise _lib.InvalidArgumentError(
+          _lib.INVALID_ARGUMENT,
+          f'grad {c} must be fp32 {shapes[c] if shapes else "[segments, dim]"} '
+          '(the shape of the last forward\'s output)')
       k = int(self._lib.hbk_sharded_owned_ids(plan, c))
       if k < 0:
         raise _lib.HbkError(_lib.INTERNAL, 'backward() needs a forward step first')

@@ -129,8 +129,11 @@ class DenseFeatures:
     the ``IndexedSlices`` ``(unique_rows, grad_rows, n_unique)`` of this rank's rows (local row
     numbers for sharded tables); with ``apply_lr`` the sparse optimizer step (``'sgd'``, or
     ``'adagrad'`` when the layer was built with ``initial_accumulator_value``) is applied in the
-    same pass.  Gradients of replicated tables still need the cross-rank aggregation of
-    hybridbackend/tensorflow/training/gradient.py:119-177 before they are applied at W > 1."""
+    same pass -- for the SHARDED tables.  Small tables are replicated on every rank: at W > 1
+    their gradients must first be aggregated across ranks (``hb.distribute.aggregate_gradients``,
+    hybridbackend/tensorflow/training/gradient.py:119-177) or the replicas diverge, so for them
+    this method never applies the step at W > 1: it returns their IndexedSlices and the caller
+    applies the aggregated gradient."""
     ids, splits = self._last
     if grad.dim() != 2 or grad.shape[1] != self.width or grad.dtype != torch.float32:
       raise _lib.InvalidArgumentError(
@@ -147,8 +150,9 @@ class DenseFeatures:
     pick = lambda idx, xs: [xs[c] for c in idx]   # noqa: E731
     res = [None] * len(self.columns)
     if self._rep:
+      rep_lr = apply_lr if (self.coll.world_size if self.coll is not None else 1) <= 1 else 0.0
       r = self._grad(pick(self._rep, ids), pick(self._rep, views), pick(self._rep, splits),
-                     apply_lr=apply_lr, optimizer=optimizer)
+                     apply_lr=rep_lr, optimizer=optimizer)
       for k, c in enumerate(self._rep):
         res[c] = r[k]
     if self._shd:

@@ -568,8 +568,8 @@ def test_parquet_to_dense_features(tmp_path):
 def test_dense_features_adagrad_sharded_in_process_world():
   """A training step's embedding side at W = 2: forward, backward and the fused Adagrad apply on
   sharded + replicated tables equal a single-process float64 Adagrad step on the full tables
-  (replicated tables: every rank applies its local gradient; summed over ranks it is the full
-  step only for the rows' gradient sum, so they are checked per rank)."""
+  (replicated tables are NOT stepped at W > 1: their gradients need the cross-rank aggregation of
+  training/gradient.py:119-177 first, so backward() only returns their IndexedSlices)."""
   import threading
   world = 2
   rng = np.random.RandomState(93)
@@ -586,10 +586,12 @@ def test_dense_features_adagrad_sharded_in_process_world():
         layer = hb.feature_column.DenseFeatures(cols, DEV, coll=comms[r], batch_size=batch,
                                                 init=init, initial_accumulator_value=0.1)
         layer(_dev_feats(feats[r]))
-        layer.backward(dev(grads[r]), apply_lr=0.05, optimizer='adagrad')
+        res = layer.backward(dev(grads[r]), apply_lr=0.05, optimizer='adagrad')
         torch.cuda.current_stream().synchronize()
+        n1 = int(res[1][2].item())
         results[r] = ([w.cpu().numpy() for w in layer.weights],
-                      [a.cpu().numpy() for a in layer.accums])
+                      [a.cpu().numpy() for a in layer.accums],
+                      (res[1][0].cpu().numpy()[:n1], res[1][1].cpu().numpy()[:n1]))
         layer.close()
     except Exception as e:  # pylint: disable=broad-except
       errors.append((r, repr(e)))
@@ -621,11 +623,14 @@ def test_dense_features_adagrad_sharded_in_process_world():
       for r in range(world):
         np.testing.assert_allclose(results[r][0][k], want[r::world], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(results[r][1][k], a[r::world], rtol=1e-5, atol=1e-6)
-    else:             # replicated: each rank stepped with its own gradient
+    else:             # replicated: untouched (the replicas would diverge), slices handed back
       for r in range(world):
-        a = 0.1 + per_rank[r] * per_rank[r]
-        np.testing.assert_allclose(results[r][0][k], t64 - 0.05 * per_rank[r] / np.sqrt(a),
-                                   rtol=1e-5, atol=1e-6)
+        np.testing.assert_equal(results[r][0][k], tables[k])
+        np.testing.assert_equal(results[r][1][k], np.full_like(tables[k], 0.1))
+        rows_r, g_r = results[r][2]
+        got = np.zeros_like(per_rank[r])
+        got[rows_r] = g_r
+        np.testing.assert_allclose(got, per_rank[r], rtol=1e-5, atol=1e-6)
     off += c.dimension
 
 

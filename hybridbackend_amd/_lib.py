@@ -79,6 +79,8 @@ def _declare(l):
   protos = {
     'hbk_last_error': (C.c_char_p, []),
     'hbk_version': (C.c_char_p, []),
+    'hbk_set_option': (C.c_int, [C.c_char_p, i32]),
+    'hbk_get_option': (C.c_int, [C.c_char_p, vp]),
     'hbk_host_floormod_i64': (i64, [i64, i64]),
     'hbk_host_fastdiv_u64': (C.c_uint64, [C.c_uint64, C.c_uint64]),
     'hbk_floormod_n': (C.c_int, [i32, i32, vp, vp, vp, vp, vp]),
@@ -113,10 +115,7 @@ def _declare(l):
     'hbk_allreduce_workspace_bytes': (sz, [i32, vp, i32]),
     'hbk_allreduce_n': (C.c_int, [vp, i32, i32, i32, vp, vp, vp, C.c_float, vp, sz, vp]),
     'hbk_allgatherv': (C.c_int, [vp, i32, vp, vp, vp, vp]),
-    'hbk_local_world_create': (C.c_int, [vp, i32]),
-    'hbk_local_world_destroy': (C.c_int, [vp]),
-    'hbk_comm_create_local': (C.c_int, [vp, vp, i32]),
-    'hbk_comm_set_local_size': (C.c_int, [vp, i32]),
+    'hbk_comm_create_custom': (C.c_int, [vp, vp, i32, i32, i32]),
     'hbk_sharded_layout': (C.c_int, [i32, i32] + [vp] * 12),
     'hbk_sharded_create': (C.c_int, [vp, vp, i32, vp, i32]),
     'hbk_sharded_destroy': (C.c_int, [vp]),
@@ -149,6 +148,39 @@ def lib():
   _declare(l)
   _lib = l
   return l
+
+
+_testing = None
+TESTING_LIB_PATH = os.path.join(_HERE, 'lib', 'libhbk_testing.so')
+
+
+def testing_lib():
+  """tests/support's libhbk_testing.so (in-process world over hbk_comm_create_custom): test
+  support, NOT part of the product; only ``Collective.local_world`` loads it."""
+  global _testing
+  if _testing is None:
+    lib()
+    if not os.path.exists(TESTING_LIB_PATH):
+      raise ImportError(f'{TESTING_LIB_PATH} not found: run `make -C tests/support` '
+                        '(__graft_entry__.build() does)')
+    t = C.CDLL(TESTING_LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i32 = C.c_void_p, C.c_int32
+    t.hbk_testing_local_world_create.restype = C.c_int
+    t.hbk_testing_local_world_create.argtypes = [vp, i32]
+    t.hbk_testing_local_world_destroy.restype = C.c_int
+    t.hbk_testing_local_world_destroy.argtypes = [vp]
+    t.hbk_testing_comm_create.restype = C.c_int
+    t.hbk_testing_comm_create.argtypes = [vp, vp, i32, i32]
+    _testing = t
+  return _testing
+
+
+def set_option(name, value):
+  """hbk_set_option: process-wide tuning / diagnostic knob; returns the previous value."""
+  old = C.c_int32()
+  check(lib().hbk_get_option(name.encode(), C.byref(old)))
+  check(lib().hbk_set_option(name.encode(), int(value)))
+  return old.value
 
 
 def check(status):

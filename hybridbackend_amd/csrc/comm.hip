@@ -14,7 +14,6 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
-#include <condition_variable>
 #include <mutex>
 #include <vector>
 
@@ -25,32 +24,9 @@ int cast_n_impl(int32_t n, int32_t src_dtype, int32_t dst_dtype, const void* con
                 const int64_t* lens, void* const* outputs, hipStream_t stream);
 }
 
-// In-process world (tests): ranks = host threads sharing one GPU.
-struct LocalWorld {
-  int world;
-  std::mutex mu;
-  std::condition_variable cv;
-  int arrived = 0;
-  long generation = 0;
-  std::vector<const void*> ptr;          // [world] published send pointer
-  std::vector<std::vector<int64_t>> off; // [world][world] element offset of the chunk for peer j
-  std::vector<std::vector<int64_t>> len; // [world][world] elements for peer j
-  std::vector<hipEvent_t> ready, done;   // [world]
-  void barrier() {
-    std::unique_lock<std::mutex> lk(mu);
-    const long gen = generation;
-    if (++arrived == world) {
-      arrived = 0;
-      ++generation;
-      cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return generation != gen; });
-    }
-  }
-};
-
 struct hbk_comm {
-  LocalWorld* local = nullptr;
+  bool custom = false;         // exchanges go through `transport` instead of RCCL
+  hbk_transport_t transport;
   ncclComm_t comm;
   hipStream_t stream;
   hipEvent_t compute_done;
@@ -127,89 +103,43 @@ int fence_out(hbk_comm* c, hipStream_t compute) {
   return HBK_OK;
 }
 
-// One exchange of the in-process world inside `ranks` (the active ranks of the topology; every
-// member of a group has the same list): every rank publishes (pointer, per-peer offsets and
-// lengths in elements, indexed by position in the list), then copies its chunk out of every
-// peer's buffer on its own stream.  All world ranks take part in the barriers (a collective is
-// called by every rank, whatever its group).
-int local_exchange(hbk_comm* c, const std::vector<int>& ranks, const void* sendbuf,
-                   const std::vector<int64_t>& send_off, const std::vector<int64_t>& send_len,
-                   void* recvbuf, const std::vector<int64_t>& recv_off, size_t esize,
-                   hipStream_t stream) {
-  LocalWorld* w = c->local;
-  const int me = c->rank;
-  int k_me = -1;
-  for (size_t k = 0; k < ranks.size(); ++k) {
-    if (ranks[k] == me) k_me = (int)k;
-  }
-  if (k_me < 0) return fail(HBK_INTERNAL, "local_exchange: rank %d not in its own group", me);
-  w->ptr[me] = sendbuf;
-  w->off[me] = send_off;
-  w->len[me] = send_len;
-  HBK_HIP_OK(hipEventRecord(w->ready[me], stream));
-  w->barrier();
-  for (size_t k = 0; k < ranks.size(); ++k) {
-    const int peer = ranks[k];
-    HBK_HIP_OK(hipStreamWaitEvent(stream, w->ready[peer], 0));
-    const int64_t n = w->len[peer][k_me];
-    if (n > 0) {
-      HBK_HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(recvbuf) + (size_t)recv_off[k] * esize,
-                                reinterpret_cast<const char*>(w->ptr[peer]) +
-                                    (size_t)w->off[peer][k_me] * esize,
-                                (size_t)n * esize, hipMemcpyDeviceToDevice, stream));
-    }
-  }
-  HBK_HIP_OK(hipEventRecord(w->done[me], stream));
-  w->barrier();
-  // nobody may reuse its send buffer before every peer has copied out of it
-  for (int peer : ranks) HBK_HIP_OK(hipStreamWaitEvent(stream, w->done[peer], 0));
-  w->barrier();
+// One exchange through a custom transport inside `ranks` (the active ranks of the topology):
+// chunk k (send_off[k], send_len[k] elements) goes to ranks[k], the chunk from ranks[k] lands at
+// recv_off[k].
+int custom_exchange(hbk_comm* c, const std::vector<int>& ranks, const void* sendbuf,
+                    const std::vector<int64_t>& send_off, const std::vector<int64_t>& send_len,
+                    void* recvbuf, const std::vector<int64_t>& recv_off, size_t esize,
+                    hipStream_t stream, bool skip_self = false) {
+  std::vector<int32_t> r32(ranks.begin(), ranks.end());
+  const int rc = c->transport.exchange(c->transport.ctx, c->rank, r32.data(), (int32_t)r32.size(),
+                                       sendbuf, send_off.data(), send_len.data(), recvbuf,
+                                       recv_off.data(), esize, skip_self ? 1 : 0,
+                                       reinterpret_cast<hbk_stream_t>(stream));
+  if (rc != HBK_OK) return fail(rc, "custom transport: exchange failed (%d)", rc);
   return HBK_OK;
 }
 
 }  // namespace
 }  // namespace hbk
 
-extern "C" int hbk_local_world_create(void** world, int32_t world_size) {
+// A communicator over a caller-provided transport (the reference's Collective is an abstract
+// class with NCCL as one implementation, hbtf/distribute/collective.h:70-201).
+extern "C" int hbk_comm_create_custom(hbk_comm_t* comm, const hbk_transport_t* transport,
+                                      int32_t world_size, int32_t local_size, int32_t rank) {
   using namespace hbk;
-  HBK_REQUIRE(world != nullptr && world_size >= 1, "local_world_create: bad argument");
-  LocalWorld* w = new LocalWorld();
-  w->world = world_size;
-  w->ptr.resize(world_size);
-  w->off.resize(world_size);
-  w->len.resize(world_size);
-  w->ready.resize(world_size);
-  w->done.resize(world_size);
-  for (int i = 0; i < world_size; ++i) {
-    HBK_HIP_OK(hipEventCreateWithFlags(&w->ready[i], hipEventDisableTiming));
-    HBK_HIP_OK(hipEventCreateWithFlags(&w->done[i], hipEventDisableTiming));
-  }
-  *world = w;
-  return HBK_OK;
-}
-
-extern "C" int hbk_local_world_destroy(void* world) {
-  LocalWorld* w = reinterpret_cast<LocalWorld*>(world);
-  if (w == nullptr) return HBK_OK;
-  for (int i = 0; i < w->world; ++i) {
-    (void)hipEventDestroy(w->ready[i]);
-    (void)hipEventDestroy(w->done[i]);
-  }
-  delete w;
-  return HBK_OK;
-}
-
-extern "C" int hbk_comm_create_local(hbk_comm_t* comm, void* world, int32_t rank) {
-  using namespace hbk;
-  LocalWorld* w = reinterpret_cast<LocalWorld*>(world);
-  HBK_REQUIRE(comm != nullptr && w != nullptr, "comm_create_local: NULL argument");
-  HBK_REQUIRE(rank >= 0 && rank < w->world, "comm_create_local: rank %d out of [0, %d)", rank,
-              w->world);
+  HBK_REQUIRE(comm != nullptr && transport != nullptr && transport->exchange != nullptr,
+              "comm_create_custom: NULL argument");
+  HBK_REQUIRE(world_size >= 1 && local_size >= 1 && world_size % local_size == 0,
+              "comm_create_custom: local_size (%d) must divide world_size (%d)", local_size,
+              world_size);
+  HBK_REQUIRE(rank >= 0 && rank < world_size, "comm_create_custom: rank %d out of [0, %d)", rank,
+              world_size);
   hbk_comm* c = new hbk_comm();
-  c->local = w;
+  c->custom = true;
+  c->transport = *transport;
   c->comm = nullptr;
-  c->world_size = w->world;
-  c->local_size = w->world;
+  c->world_size = world_size;
+  c->local_size = local_size;
   c->rank = rank;
   c->aborted = false;
   c->stream = nullptr;
@@ -217,19 +147,6 @@ extern "C" int hbk_comm_create_local(hbk_comm_t* comm, void* world, int32_t rank
   c->comm_done = nullptr;
   (void)hipGetDevice(&c->device);
   *comm = c;
-  return HBK_OK;
-}
-
-// test hook: the node shape of an in-process world (local_size GPUs per "node"), so that the
-// INTRA_NODE / INTER_NODE topologies can be exercised with in-process ranks
-extern "C" int hbk_comm_set_local_size(hbk_comm_t comm, int32_t local_size) {
-  using namespace hbk;
-  HBK_REQUIRE(comm != nullptr && comm->local != nullptr,
-              "comm_set_local_size: only for in-process communicators");
-  HBK_REQUIRE(local_size >= 1 && comm->world_size % local_size == 0,
-              "comm_set_local_size: local_size (%d) must divide world_size (%d)", local_size,
-              comm->world_size);
-  comm->local_size = local_size;
   return HBK_OK;
 }
 
@@ -287,7 +204,8 @@ extern "C" int hbk_comm_create(hbk_comm_t* comm, const uint8_t id[HBK_COMM_ID_BY
 extern "C" int hbk_comm_destroy(hbk_comm_t comm) {
   using namespace hbk;
   if (comm == nullptr) return HBK_OK;
-  if (comm->local != nullptr) {
+  if (comm->custom) {
+    if (comm->transport.destroy != nullptr) comm->transport.destroy(comm->transport.ctx);
     delete comm;
     return HBK_OK;
   }
@@ -304,7 +222,7 @@ extern "C" int hbk_comm_destroy(hbk_comm_t comm) {
 extern "C" int hbk_comm_check_async(hbk_comm_t comm) {
   using namespace hbk;
   HBK_REQUIRE(comm != nullptr, "comm_check_async: comm is NULL");
-  if (comm->local != nullptr) return HBK_OK;
+  if (comm->custom) return HBK_OK;
   std::unique_lock<std::mutex> lock(comm->mu);
   if (comm->aborted) return fail(HBK_INTERNAL, "communicator was aborted");
   ncclResult_t async = ncclSuccess;
@@ -354,7 +272,7 @@ extern "C" int hbk_alltoall_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t
                 (long long)counts[c], (long long)active);  // nccl_collective.cc:119-123
     HBK_REQUIRE(counts[c] == 0 || (inputs[c] && outputs[c]), "alltoall_n: NULL buffer %d", c);
   }
-  if (comm->local != nullptr) {
+  if (comm->custom) {
     for (int32_t c = 0; c < n; ++c) {
       const int64_t part = counts[c] / active;
       std::vector<int64_t> off(active), len(active);
@@ -362,8 +280,8 @@ extern "C" int hbk_alltoall_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t
         off[i] = i * part;
         len[i] = part;
       }
-      int lrc = local_exchange(comm, ranks, inputs[c], off, len, outputs[c], off, esize,
-                               as_stream(compute_stream));
+      int lrc = custom_exchange(comm, ranks, inputs[c], off, len, outputs[c], off, esize,
+                                as_stream(compute_stream));
       if (lrc != HBK_OK) return lrc;
     }
     return HBK_OK;
@@ -425,11 +343,15 @@ namespace hbk {
 // is done -- the compute stream is NOT fenced, so the caller can overlap other work with the
 // exchange (sharded.hip pipelines column groups this way).  With both NULL it fences against
 // `compute_stream` on both sides like the reference (hbtf/common/stream.cc:83-142).
+// `skip_self`: the caller has placed this rank's own chunk itself (the sharded driver's owner
+// gather writes it where the exchange would have copied it); not with the fp16 wire, whose casts
+// also round the own chunk (as the reference's do).
 int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dtype,
                      int32_t topology, const int64_t* common_sizes, const void* const* inputs,
                      const int32_t* send_sizes, void* const* outputs,
                      const int32_t* recv_sizes, void* wire_ws, size_t wire_ws_bytes,
-                     hbk_stream_t compute_stream, hipEvent_t before, hipEvent_t after) {
+                     hbk_stream_t compute_stream, hipEvent_t before, hipEvent_t after,
+                     bool skip_self) {
   HBK_REQUIRE(comm != nullptr, "alltoallv_n: comm is NULL");
   HBK_REQUIRE(n >= 0, "alltoallv_n: n must be >= 0");
   if (n == 0) return HBK_OK;
@@ -438,6 +360,7 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
   const bool half_wire = (dtype == HBK_FLOAT && wire_dtype == HBK_HALF);
   HBK_REQUIRE(half_wire || wire_dtype == dtype || wire_dtype == HBK_FLOAT,
               "alltoallv_n: wire_dtype must be float or half (half only for float data)");
+  HBK_REQUIRE(!(skip_self && half_wire), "alltoallv_n: skip_self is not available with the fp16 wire");
   ncclDataType_t nt;
   HBK_REQUIRE(to_nccl(half_wire ? HBK_HALF : dtype, &nt), "alltoallv_n: unsupported dtype %d",
               dtype);
@@ -486,7 +409,7 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
     }
   }
 
-  if (comm->local != nullptr) {
+  if (comm->custom) {
     hipStream_t cs = as_stream(compute_stream);
     int lrc;
     if (before != nullptr) HBK_HIP_OK(hipStreamWaitEvent(cs, before, 0));
@@ -512,8 +435,8 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
         so += slen[i];
         ro += (int64_t)recv_sizes[(size_t)c * active + i] * common_sizes[c];
       }
-      if ((lrc = local_exchange(comm, ranks, wire_in[c], soff, slen, wire_out[c], roff, esize,
-                                cs)) !=
+      if ((lrc = custom_exchange(comm, ranks, wire_in[c], soff, slen, wire_out[c], roff, esize,
+                                 cs, skip_self)) !=
           HBK_OK) {
         return lrc;
       }
@@ -573,7 +496,7 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
       if (ranks[i] == comm->rank) {
         // own slice: a device copy on the comm stream (RCCL's self send/recv moves it through
         // one channel's copy loop: 54 MB took 111 us, the blit engine path ~25 us)
-        if (sendsize > 0 && copy_err == hipSuccess) {
+        if (sendsize > 0 && copy_err == hipSuccess && !skip_self) {
           copy_err = hipMemcpyAsync(recvbuf + recvoffset, sendbuf + sendoffset, sendsize * esize,
                                     hipMemcpyDeviceToDevice, comm->stream);
         }
@@ -619,7 +542,7 @@ extern "C" int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
                                size_t wire_ws_bytes, hbk_stream_t compute_stream) {
   return hbk::alltoallv_events(comm, n, dtype, wire_dtype, topology, common_sizes, inputs,
                                send_sizes, outputs, recv_sizes, wire_ws, wire_ws_bytes,
-                               compute_stream, nullptr, nullptr);
+                               compute_stream, nullptr, nullptr, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -711,35 +634,6 @@ int bucket_copy(int32_t n, const void* const* src, void* const* dst, const int64
   return HBK_OK;
 }
 
-// in-process world: out[i] = op over ranks (rank order) of the published buffers
-struct PeerPtrs {
-  const void* p[64];
-  int32_t world;
-  int32_t op;
-  int32_t dtype;
-  int32_t pad_;
-};
-
-template <typename T>
-__device__ inline T red_op(T a, T b, int op) {
-  switch (op) {
-    case 1: return a * b;
-    case 2: return a > b ? a : b;
-    case 3: return a < b ? a : b;
-    default: return a + b;
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(kRedBlock) void local_reduce_kernel(const PeerPtrs pp, int64_t n,
-                                                                 T* out) {
-  const int64_t i = (int64_t)blockIdx.x * kRedBlock + threadIdx.x;
-  if (i >= n) return;
-  T acc = reinterpret_cast<const T*>(pp.p[0])[i];
-  for (int r = 1; r < pp.world; ++r) acc = red_op<T>(acc, reinterpret_cast<const T*>(pp.p[r])[i], pp.op);
-  out[i] = acc;
-}
-
 bool to_nccl_op(int32_t op, ncclRedOp_t* out) {
   switch (op) {
     case 0: *out = ncclSum; return true;
@@ -800,10 +694,10 @@ extern "C" int hbk_allreduce_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
     }
     red_in = red_out = workspace;
   }
-  hipStream_t rs = comm->local != nullptr ? cs : comm->stream;   // stream of pack/reduce/unpack
+  hipStream_t rs = comm->custom ? cs : comm->stream;   // stream of pack/reduce/unpack
   // one communicator = one ordered queue: everything enqueued on its stream is under its mutex
   std::unique_lock<std::mutex> lock(comm->mu, std::defer_lock);
-  if (comm->local == nullptr) {
+  if (!comm->custom) {
     lock.lock();
     HBK_REQUIRE(!comm->aborted, "allreduce_n: communicator was aborted");
     int rc = fence_in(comm, cs);
@@ -813,55 +707,13 @@ extern "C" int hbk_allreduce_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
     int rc = bucket_copy(n, inputs, slots.data(), counts, esize, false, 1.0f, rs);
     if (rc != HBK_OK) return rc;
   }
-  if (comm->local != nullptr) {
-    LocalWorld* w = comm->local;
-    const int me = comm->rank;
-    HBK_REQUIRE(w->world <= 64, "allreduce_n: local world larger than 64");
-    // partial results go to a private buffer so that peers still read this rank's INPUT
-    void* tmp = nullptr;
-    HBK_HIP_OK(hipMalloc(&tmp, (size_t)total * esize + 16));
-    w->ptr[me] = red_in;
-    HBK_HIP_OK(hipEventRecord(w->ready[me], rs));
-    w->barrier();
-    PeerPtrs pp;
-    pp.world = w->world;
-    pp.op = reduce_op;
-    pp.dtype = dtype;
-    pp.pad_ = 0;
-    for (int i = 0; i < w->world; ++i) {
-      HBK_HIP_OK(hipStreamWaitEvent(rs, w->ready[i], 0));
-      pp.p[i] = w->ptr[i];
-    }
-    const unsigned blocks = (unsigned)((total + kRedBlock - 1) / kRedBlock);
-    switch (dtype) {
-      case HBK_FLOAT:
-        hipLaunchKernelGGL(local_reduce_kernel<float>, dim3(blocks), dim3(kRedBlock), 0, rs, pp,
-                           total, reinterpret_cast<float*>(tmp));
-        break;
-      case HBK_INT32:
-        hipLaunchKernelGGL(local_reduce_kernel<int32_t>, dim3(blocks), dim3(kRedBlock), 0, rs, pp,
-                           total, reinterpret_cast<int32_t*>(tmp));
-        break;
-      case HBK_INT64:
-        hipLaunchKernelGGL(local_reduce_kernel<int64_t>, dim3(blocks), dim3(kRedBlock), 0, rs, pp,
-                           total, reinterpret_cast<int64_t*>(tmp));
-        break;
-      case HBK_DOUBLE:
-        hipLaunchKernelGGL(local_reduce_kernel<double>, dim3(blocks), dim3(kRedBlock), 0, rs, pp,
-                           total, reinterpret_cast<double*>(tmp));
-        break;
-      default:
-        (void)hipFree(tmp);
-        return fail(HBK_INVALID_ARGUMENT, "allreduce_n: the in-process world reduces float, "
-                                          "double, int32, int64");
-    }
-    HBK_HIP_OK(hipEventRecord(w->done[me], rs));
-    w->barrier();
-    for (int i = 0; i < w->world; ++i) HBK_HIP_OK(hipStreamWaitEvent(rs, w->done[i], 0));
-    HBK_HIP_OK(hipMemcpyAsync(red_out, tmp, (size_t)total * esize, hipMemcpyDeviceToDevice, rs));
-    HBK_HIP_OK(hipStreamSynchronize(rs));   // test transport: tmp is freed right away
-    (void)hipFree(tmp);
-    w->barrier();
+  if (comm->custom) {
+    HBK_REQUIRE(comm->transport.allreduce != nullptr,
+                "allreduce_n: the custom transport has no allreduce");
+    const int trc = comm->transport.allreduce(comm->transport.ctx, comm->rank, comm->world_size,
+                                              dtype, reduce_op, red_in, red_out, total,
+                                              reinterpret_cast<hbk_stream_t>(rs));
+    if (trc != HBK_OK) return fail(trc, "custom transport: allreduce failed (%d)", trc);
   } else {
     HBK_NCCL_OK(ncclAllReduce(red_in, red_out, (size_t)total, nt, op, comm->comm, comm->stream));
   }
@@ -874,7 +726,7 @@ extern "C" int hbk_allreduce_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
     int rc = bucket_copy(1, src, outputs, counts, esize, true, scale, rs);
     if (rc != HBK_OK) return rc;
   }
-  if (comm->local == nullptr) return fence_out(comm, cs);
+  if (!comm->custom) return fence_out(comm, cs);
   return HBK_OK;
 }
 
@@ -898,11 +750,11 @@ extern "C" int hbk_allgatherv(hbk_comm_t comm, int32_t dtype, const void* input,
   HBK_REQUIRE(output != nullptr && (counts[me] == 0 || input != nullptr), "allgatherv: NULL buffer");
   hipStream_t cs = as_stream(compute_stream);
   char* out = reinterpret_cast<char*>(output);
-  if (comm->local != nullptr) {
+  if (comm->custom) {
     std::vector<int64_t> soff(W, 0), slen(W, counts[me]), roff(off.begin(), off.end() - 1);
     std::vector<int> all(W);
     for (int r = 0; r < W; ++r) all[r] = r;
-    return local_exchange(comm, all, input, soff, slen, output, roff, esize, cs);
+    return custom_exchange(comm, all, input, soff, slen, output, roff, esize, cs);
   }
   std::unique_lock<std::mutex> lock(comm->mu);
   HBK_REQUIRE(!comm->aborted, "allgatherv: communicator was aborted");

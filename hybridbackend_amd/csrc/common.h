@@ -116,6 +116,22 @@ __host__ __device__ inline uint64_t floormod_i64(int64_t v, const FastDiv& f) {
   return v < 0 ? f.d - 1 - r : r;
 }
 
+// Tuning / diagnostic options (hbk_set_option, include/hbk.h).  Read from the environment ONCE,
+// when the library is loaded; the entry points read plain ints, never getenv.
+struct Options {
+  int bwd_buckets_log2 = -1;   // HBK_BWD_LOG2P: force 2^v buckets per column in the backward
+  int bwd_bucket_pairs = 0;    // HBK_BWD_TARGET: aimed pairs per bucket (0: default)
+  int bwd_split_pairs = 0;     // HBK_BWD_SPLIT: pairs per workgroup of a split bucket (0: default)
+  int unique_buckets_log2 = -1;  // HBK_UNIQUE_LOG2P
+  int partition_sub_tiles = 1;   // HBK_PART_SUB
+  int partition_fixed_max = 8;   // HBK_PART_FIXED
+  int sharded_groups = 2;        // HBK_SHARDED_GROUPS: column groups a sharded step pipelines
+  int sharded_id64 = 0;          // HBK_SHARDED_ID64: keep int64 ids on the wire
+  int sharded_copy_self = 0;     // HBK_SHARDED_COPY_SELF: own slice through a device copy
+  int sharded_trace = 0;         // HBK_SHARDED_TRACE: host-side phase times on stderr
+};
+Options& options();
+
 constexpr int kWave = 64;  // gfx950 wavefront
 
 __device__ inline int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }

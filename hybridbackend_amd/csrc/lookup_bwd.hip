@@ -1208,13 +1208,10 @@ struct ColPlan {
   int32_t e_max;
 };
 
-// test hooks: HBK_BWD_LOG2P forces the bucket count to 1 << value (0 = one bucket per column) so
-// that multi-chunk buckets, rows spanning chunks and the table-clear path are exercised;
-// HBK_BWD_TARGET sets the aimed pairs per bucket (tuning)
-int forced_log2p() {
-  const char* e = getenv("HBK_BWD_LOG2P");
-  return e ? atoi(e) : -1;
-}
+// options (hbk_set_option): bwd_buckets_log2 forces the bucket count to 1 << value (0 = one
+// bucket per column) so that multi-chunk buckets, rows spanning chunks and the multi-pass path
+// can be exercised; bwd_bucket_pairs sets the aimed pairs per bucket (tuning)
+int forced_log2p() { return options().bwd_buckets_log2; }
 
 ColPlan plan_of(int64_t n_ids, int32_t dim) {
   (void)dim;
@@ -1224,8 +1221,7 @@ ColPlan plan_of(int64_t n_ids, int32_t dim) {
   // 1024-slot scan) is spread over as many pairs as possible.  Measured, config 2 backward:
   // aim 256 171 us, 320 165, 384 157, 448 147, 512 149.
   int64_t target = kCP * 7 / 8;
-  const char* te = getenv("HBK_BWD_TARGET");
-  if (te != nullptr && atoi(te) > 0) target = atoi(te);
+  if (options().bwd_bucket_pairs > 0) target = options().bwd_bucket_pairs;
   int64_t nb = (n_ids + target - 1) / target;
   if (nb < 1) nb = 1;
   if (nb > kMaxBuckets) nb = kMaxBuckets;
@@ -1237,8 +1233,7 @@ ColPlan plan_of(int64_t n_ids, int32_t dim) {
   // (measured, config 4 backward: ranges of 1024 pairs 391 us, 2048 417 us, 4096 466 us)
   int64_t t = 2 * ((n_ids + nb - 1) / nb) + 128;
   if (t < 2 * kCP) t = 2 * kCP;
-  const char* e = getenv("HBK_BWD_SPLIT");   // test hook
-  if (e != nullptr && atoi(e) > 0) t = atoi(e);
+  if (options().bwd_split_pairs > 0) t = options().bwd_split_pairs;
   p.split_t = (int32_t)t;
   p.e_max = (int32_t)(n_ids / t + 1);
   return p;

@@ -1,4 +1,7 @@
-// Error channel and version string of libhbk_core.so.
+// Error channel, version string and options of libhbk_core.so.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace hbk {
@@ -15,7 +18,67 @@ int fail(int code, const char* fmt, ...) {
 }
 }  // namespace hbk
 
+namespace hbk {
+namespace {
+struct OptionEntry {
+  const char* name;
+  const char* env;
+  int Options::*field;
+};
+const OptionEntry kOptions[] = {
+    {"bwd_buckets_log2", "HBK_BWD_LOG2P", &Options::bwd_buckets_log2},
+    {"bwd_bucket_pairs", "HBK_BWD_TARGET", &Options::bwd_bucket_pairs},
+    {"bwd_split_pairs", "HBK_BWD_SPLIT", &Options::bwd_split_pairs},
+    {"unique_buckets_log2", "HBK_UNIQUE_LOG2P", &Options::unique_buckets_log2},
+    {"partition_sub_tiles", "HBK_PART_SUB", &Options::partition_sub_tiles},
+    {"partition_fixed_max", "HBK_PART_FIXED", &Options::partition_fixed_max},
+    {"sharded_groups", "HBK_SHARDED_GROUPS", &Options::sharded_groups},
+    {"sharded_id64", "HBK_SHARDED_ID64", &Options::sharded_id64},
+    {"sharded_copy_self", "HBK_SHARDED_COPY_SELF", &Options::sharded_copy_self},
+    {"sharded_trace", "HBK_SHARDED_TRACE", &Options::sharded_trace},
+};
+
+Options from_environment() {
+  Options o;
+  for (const OptionEntry& e : kOptions) {
+    const char* v = getenv(e.env);
+    if (v != nullptr && *v != 0) o.*(e.field) = atoi(v);
+  }
+  return o;
+}
+}  // namespace
+
+Options& options() {
+  static Options o = from_environment();   // once, at first use
+  return o;
+}
+}  // namespace hbk
+
 extern "C" const char* hbk_last_error(void) { return hbk::g_last_error; }
+
+extern "C" int hbk_set_option(const char* name, int32_t value) {
+  using namespace hbk;
+  HBK_REQUIRE(name != nullptr, "set_option: name is NULL");
+  for (const OptionEntry& e : kOptions) {
+    if (strcmp(e.name, name) == 0) {
+      options().*(e.field) = value;
+      return HBK_OK;
+    }
+  }
+  return fail(HBK_INVALID_ARGUMENT, "set_option: unknown option '%s'", name);
+}
+
+extern "C" int hbk_get_option(const char* name, int32_t* value) {
+  using namespace hbk;
+  HBK_REQUIRE(name != nullptr && value != nullptr, "get_option: NULL argument");
+  for (const OptionEntry& e : kOptions) {
+    if (strcmp(e.name, name) == 0) {
+      *value = options().*(e.field);
+      return HBK_OK;
+    }
+  }
+  return fail(HBK_INVALID_ARGUMENT, "get_option: unknown option '%s'", name);
+}
 
 extern "C" const char* hbk_version(void) { return "hbk 0.1.0 gfx950"; }
 

@@ -459,13 +459,12 @@ int launch_group(const PartArgs& args, int P, hipStream_t stream) {
 
 // A wave may take several 1024-id passes (sub_tiles); measured slower than one pass per wave at
 // every size (10 M ids: 69 us with 1 pass, 89 us with 4; 1.7 M ids: 33 vs 73 us), so the default
-// is 1 and HBK_PART_SUB is only a tuning hook.
+// is 1 and the option partition_sub_tiles is only a tuning knob.
 int sub_tiles_of(int32_t n_cols, const int64_t* lens) {
   (void)n_cols;
   (void)lens;
   int64_t sub = 1;
-  const char* e = getenv("HBK_PART_SUB");
-  if (e != nullptr && atoi(e) >= 1) sub = atoi(e);
+  if (options().partition_sub_tiles >= 1) sub = options().partition_sub_tiles;
   return sub > 8 ? 8 : (int)sub;
 }
 
@@ -524,7 +523,7 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
     args.sizes_t = sizes_t;
     args.n_total_cols = n_cols;
     args.pad_ = 0;
-    args.fixed_max = getenv("HBK_PART_FIXED") ? atoi(getenv("HBK_PART_FIXED")) : 8;
+    args.fixed_max = options().partition_fixed_max;
     args.sub_tiles = sub;
     int32_t k = 0;
     int64_t tiles = 0;

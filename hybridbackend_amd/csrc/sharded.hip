@@ -33,7 +33,8 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
                      int32_t topology, const int64_t* common_sizes, const void* const* inputs,
                      const int32_t* send_sizes, void* const* outputs,
                      const int32_t* recv_sizes, void* wire_ws, size_t wire_ws_bytes,
-                     hbk_stream_t compute_stream, hipEvent_t before, hipEvent_t after);
+                     hbk_stream_t compute_stream, hipEvent_t before, hipEvent_t after,
+                     bool skip_self);
 int partition_by_modulo_fused(int32_t n_cols, int32_t num_partitions, const int64_t* const* inputs,
                               const int64_t* lens, const int64_t* buckets,
                               int64_t* const* outputs, int32_t* const* sizes,
@@ -267,6 +268,8 @@ struct hbk_sharded {
   int W, rank, N;
   int32_t wire_dtype;
   bool id32;   // ids travel (and stay on the owner) as int32: every column is bucketized below 2^31
+  bool trace;  // option sharded_trace: host-side phase times on stderr
+  int n_groups;  // option sharded_groups
   std::vector<hbk_sharded_column_t> cols;
   // per-step state (kept for the backward)
   std::vector<int64_t> n_ids, n_seg;
@@ -278,7 +281,17 @@ struct hbk_sharded {
   hipEvent_t ev[4][4];                   // [stage][group]: packed, ids in, gathered, rows in
   bool have_step;
   // device buffers owned by the plan
-  hbk::Buffer part_ws, send_ids, recv_ids, send_rows, recv_rows, wire_ws, bwd_ws, runs_dev;
+  // ids_buf = [ids going out | ids coming in], rows_buf = [rows going out | rows coming in]: one
+  // allocation each, so that a run of this rank's OWN slice can be addressed from either side
+  // (zero_copy_self) with a known, positive offset
+  hbk::Buffer part_ws, ids_buf, rows_buf, wire_ws, bwd_ws, runs_dev;
+  char* send_ids_p;     // views into ids_buf / rows_buf, set by every forward
+  char* recv_ids_p;
+  float* send_rows_p;
+  float* recv_rows_p;
+  bool zero_copy_self;  // fp32 wire: the own slice never travels, not even as a device copy: the
+                        // owner gather reads its ids where the pack left them and writes the rows
+                        // where the stitch reads them (and the backward the other way round)
   // Stage 1-2 state (partitioned ids, shard index, size matrices), double buffered so that
   // hbk_sharded_prefetch can partition step i+1 while step i's exchanges are on the wire; the
   // set of the last forward stays untouched for its backward.
@@ -323,12 +336,18 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
   p->cols.assign(cols, cols + n_cols);
   // After the bucketize ids are < bucket, so when every bucket fits int32 the id exchange moves
   // half the bytes (the reference always sends the tensor's own dtype, nccl_collective.cc:257-259;
-  // SURVEY 8e).  HBK_SHARDED_ID64=1 keeps int64 on the wire.
-  p->id32 = getenv("HBK_SHARDED_ID64") == nullptr;
+  // SURVEY 8e).  Option sharded_id64 keeps int64 on the wire.  (All options are read here, at
+  // plan creation, not per step.)
+  p->id32 = options().sharded_id64 == 0;
+  p->trace = options().sharded_trace != 0;
+  p->n_groups = options().sharded_groups;
   for (int32_t c = 0; c < n_cols; ++c) {
     if (cols[c].bucket <= 0 || cols[c].bucket > 0x7fffffffll) p->id32 = false;
   }
   p->have_step = false;
+  p->zero_copy_self = wire_dtype == HBK_FLOAT && options().sharded_copy_self == 0;
+  p->send_ids_p = p->recv_ids_p = nullptr;
+  p->send_rows_p = p->recv_rows_p = nullptr;
   p->cur = 0;
   p->pre_stream = nullptr;
   p->step_begin = nullptr;
@@ -364,8 +383,8 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
 extern "C" int hbk_sharded_destroy(hbk_sharded_t p) {
   if (p == nullptr) return HBK_OK;
   if (p->pre_stream) (void)hipStreamSynchronize(p->pre_stream);
-  for (hbk::Buffer* b : {&p->part_ws, &p->send_ids, &p->recv_ids, &p->send_rows, &p->recv_rows,
-                         &p->wire_ws, &p->bwd_ws, &p->runs_dev}) {
+  for (hbk::Buffer* b : {&p->part_ws, &p->ids_buf, &p->rows_buf, &p->wire_ws, &p->bwd_ws,
+                         &p->runs_dev}) {
     b->release();
   }
   for (auto& set : p->ps) {
@@ -402,7 +421,8 @@ inline Seg make_seg(const void* src, void* dst, int64_t bytes, int narrow = 0) {
 // the communicator's stream behind `before` and records `after`; the compute stream goes on.
 int exchange(hbk_sharded* p, int32_t dtype, int32_t wire, const void* in, const int32_t* send,
              void* out, const int32_t* recv, hbk_stream_t stream, hipEvent_t before = nullptr,
-             hipEvent_t after = nullptr, void* wire_ws = nullptr, size_t wire_ws_bytes = 0) {
+             hipEvent_t after = nullptr, void* wire_ws = nullptr, size_t wire_ws_bytes = 0,
+             bool skip_self = false) {
   const int64_t cs[1] = {1};
   const void* vin[1] = {in};
   void* vout[1] = {out};
@@ -414,7 +434,7 @@ int exchange(hbk_sharded* p, int32_t dtype, int32_t wire, const void* in, const 
     wire_ws_bytes = p->wire_ws.bytes;
   }
   return alltoallv_events(p->comm, 1, dtype, wire, HBK_TOPOLOGY_ALL, cs, vin, send, vout, recv,
-                          wire_ws, wire_ws_bytes, stream, before, after);
+                          wire_ws, wire_ws_bytes, stream, before, after, skip_self);
 }
 
 // Stages 1-2 of a step into `set`: bucketize + stable partition of all columns, ONE [N x W] size
@@ -468,12 +488,9 @@ int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* cons
 // Number of column groups the step pipelines.  More groups hide more of the gather / stitch
 // behind the exchanges (exposed compute ~ 1/G of it) at the price of G x more launches and
 // smaller kernels: measured on one rank 298 us (G = 1), 318 us (G = 2), 455 us (G = 4) per
-// forward step.  2 until an 8-GPU measurement says otherwise; HBK_SHARDED_GROUPS overrides (1..4).
-int pipeline_groups(int n_cols, int world) {
-  (void)world;
-  int g = 2;
-  const char* e = getenv("HBK_SHARDED_GROUPS");
-  if (e != nullptr && atoi(e) >= 1 && atoi(e) <= 4) g = atoi(e);
+// forward step.  2 until an 8-GPU measurement says otherwise; option sharded_groups overrides (1..4).
+int pipeline_groups(int n_cols, int requested) {
+  int g = requested >= 1 && requested <= 4 ? requested : 2;
   return g < n_cols ? g : n_cols;
 }
 
@@ -501,8 +518,8 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     p->n_seg[c] = p->row_splits[c] ? n_segments[c] : n_ids[c];
   }
   int rc;
-  // HBK_SHARDED_TRACE=1: host-side time of the step's phases on stderr (us)
-  const bool trace = getenv("HBK_SHARDED_TRACE") != nullptr;
+  // option sharded_trace: host-side time of the step's phases on stderr (us)
+  const bool trace = p->trace;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto us_since = [](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -559,7 +576,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   // ids of group g+1 are on the wire, and stitches group g while the rows of group g+1 travel:
   //   comm    : ids(0) ids(1) ...            rows(0)      rows(1) ...
   //   compute : pack(0..G-1)      gather(0)  gather(1) ..      stitch(0)   stitch(1)
-  const int G = pipeline_groups(N, W);
+  const int G = pipeline_groups(N, p->n_groups);
   std::vector<Group>& groups = p->groups;
   groups.assign(G, Group());
   int64_t tot_req_ids = 0, tot_own_ids = 0, tot_own_floats = 0, tot_req_floats = 0;
@@ -591,10 +608,19 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   }
   const size_t id_bytes = p->id32 ? 4 : 8;
   const int32_t id_dtype = p->id32 ? HBK_INT32 : HBK_INT64;
-  if ((rc = p->send_ids.ensure((size_t)tot_req_ids * id_bytes + 16)) != HBK_OK) return rc;
-  if ((rc = p->recv_ids.ensure((size_t)tot_own_ids * id_bytes + 16)) != HBK_OK) return rc;
-  if ((rc = p->send_rows.ensure((size_t)tot_own_floats * 4 + 16)) != HBK_OK) return rc;
-  if ((rc = p->recv_rows.ensure((size_t)tot_req_floats * 4 + 16)) != HBK_OK) return rc;
+  auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t ids_send_bytes = up256((size_t)tot_req_ids * id_bytes + 16);
+  const size_t rows_send_bytes = up256((size_t)tot_own_floats * 4 + 16);
+  if ((rc = p->ids_buf.ensure(ids_send_bytes + (size_t)tot_own_ids * id_bytes + 16)) != HBK_OK) {
+    return rc;
+  }
+  if ((rc = p->rows_buf.ensure(rows_send_bytes + (size_t)tot_req_floats * 4 + 16)) != HBK_OK) {
+    return rc;
+  }
+  p->send_ids_p = reinterpret_cast<char*>(p->ids_buf.ptr);
+  p->recv_ids_p = p->send_ids_p + ids_send_bytes;
+  p->send_rows_p = reinterpret_cast<float*>(p->rows_buf.ptr);
+  p->recv_rows_p = p->send_rows_p + rows_send_bytes / 4;
   if (p->wire_dtype == HBK_HALF) {  // staging for the largest group (exchanges are serial)
     size_t wws = 0;
     const int64_t cs1[1] = {1};
@@ -605,13 +631,18 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     }
     if ((rc = p->wire_ws.ensure(wws + 16)) != HBK_OK) return rc;
   }
-  HBK_REQUIRE(tot_own_floats < (1ll << 32) && tot_req_floats < (1ll << 32),
+  HBK_REQUIRE((int64_t)(rows_send_bytes / 4) + tot_req_floats < (1ll << 32),
               "sharded_lookup_fwd: more than 2^32 floats (16 GB) of rows per step on one rank");
   if ((rc = p->runs_dev.ensure(sizeof(int64_t) * 5 * (size_t)N * W)) != HBK_OK) return rc;
-  char* ids_send_base = reinterpret_cast<char*>(p->send_ids.ptr);
-  char* ids_recv_base = reinterpret_cast<char*>(p->recv_ids.ptr);
-  float* rows_send_base = reinterpret_cast<float*>(p->send_rows.ptr);
-  float* rows_recv_base = reinterpret_cast<float*>(p->recv_rows.ptr);
+  char* ids_send_base = p->send_ids_p;
+  char* ids_recv_base = p->recv_ids_p;
+  float* rows_send_base = p->send_rows_p;
+  float* rows_recv_base = p->recv_rows_p;
+  const bool zc = p->zero_copy_self;
+  const int me = p->rank;
+  // element offsets of the "other side" buffers seen from the owner-side bases of the backward
+  const int64_t ids_send_from_recv = -(int64_t)(ids_send_bytes / id_bytes);
+  const int64_t rows_recv_from_send = (int64_t)(rows_send_bytes / 4);
   // run tables of the in-place stitch (column c = W runs over the group's received rows)
   {
     int64_t* h_start = p->host_runs;
@@ -639,6 +670,12 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
           h_ostart[at] = o;
           h_oids[at] = gr.id_recv + gr.lay.own_id_off[(size_t)q * ng + c];
           h_ograds[at] = gr.row_send + gr.lay.own_row_off[(size_t)q * ng + c];
+          if (zc && q == me) {
+            // the own slice stays where the requester side put it: ids in the outgoing id buffer,
+            // gradient rows in the buffer the rows came back in
+            h_oids[at] = ids_send_from_recv + gr.id_send + gr.lay.req_id_off[(size_t)q * ng + c];
+            h_ograds[at] = rows_recv_from_send + gr.row_recv + gr.lay.req_row_off[(size_t)q * ng + c];
+          }
           o += gr.R[(size_t)q * ng + c];
         }
       }
@@ -668,7 +705,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     const Group& gr = groups[g];
     rc = exchange(p, id_dtype, id_dtype, ids_send_base + gr.id_send * id_bytes,
                   gr.lay.ids_send_peer.data(), ids_recv_base + gr.id_recv * id_bytes,
-                  gr.lay.ids_recv_peer.data(), stream_, p->ev[0][0], p->ev[1][g]);
+                  gr.lay.ids_recv_peer.data(), stream_, p->ev[0][0], p->ev[1][g], nullptr, 0, zc);
     if (rc != HBK_OK) return rc;
   }
   // stage C: owner gather of group g as soon as its ids are in (N_g * W virtual columns, straight
@@ -696,6 +733,10 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
         h.divisor = W;
         h.combiner = HBK_COMBINER_SUM;
         h.out = rows_send_base + gr.row_send + gr.lay.own_row_off[(size_t)q * ng + c];
+        if (zc && q == me) {
+          h.ids = ids_send_base + (gr.id_send + gr.lay.req_id_off[(size_t)q * ng + c]) * id_bytes;
+          h.out = rows_recv_base + gr.row_recv + gr.lay.req_row_off[(size_t)q * ng + c];
+        }
         v.push_back(h);
       }
     }
@@ -705,7 +746,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     rc = exchange(p, HBK_FLOAT, p->wire_dtype, rows_send_base + gr.row_send,
                   gr.lay.rows_send_peer.data(), rows_recv_base + gr.row_recv,
                   gr.lay.rows_recv_peer.data(), stream_, p->ev[2][g], p->ev[3][g],
-                  p->wire_ws.ptr, p->wire_ws.bytes);
+                  p->wire_ws.ptr, p->wire_ws.bytes, zc);
     if (rc != HBK_OK) return rc;
   }
   // stage D: stitch + combiner of group g when its rows are in; the received rows stay
@@ -800,8 +841,8 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
   const int N = p->N, W = p->W;
   const int32_t* R = p->recv_sizes.data();
   const int G = (int)p->groups.size();
-  float* rows_send_base = reinterpret_cast<float*>(p->send_rows.ptr);
-  float* rows_recv_base = reinterpret_cast<float*>(p->recv_rows.ptr);
+  float* rows_send_base = p->send_rows_p;
+  float* rows_recv_base = p->recv_rows_p;
   const int64_t* d_start = reinterpret_cast<const int64_t*>(p->runs_dev.ptr);
   const int64_t* d_base = d_start + (size_t)N * W;
   const int64_t* d_ostart = d_start + 2 * (size_t)N * W;
@@ -844,7 +885,8 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
     const Group& gr = p->groups[g];
     rc = exchange(p, HBK_FLOAT, p->wire_dtype, rows_recv_base + gr.row_recv,
                   gr.lay.rows_recv_peer.data(), rows_send_base + gr.row_send,
-                  gr.lay.rows_send_peer.data(), stream_, p->ev[0][g], p->ev[1][g]);
+                  gr.lay.rows_send_peer.data(), stream_, p->ev[0][g], p->ev[1][g], nullptr, 0,
+                  p->zero_copy_self);
     if (rc != HBK_OK) return rc;
   }
   // ---- B3 owner side: duplicate-row reduction (+ SGD) reading ids and gradient rows in place ---
@@ -859,7 +901,7 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
     h.rows = p->cols[c].rows_local;
     h.dim = p->cols[c].dim;
     h.ids_dtype = p->id32 ? HBK_INT32 : HBK_INT64;
-    h.ids = p->recv_ids.ptr;
+    h.ids = p->recv_ids_p;
     h.n_ids = n_own;
     h.n_segments = n_own;
     h.divisor = W;

@@ -382,8 +382,8 @@ inline int log2p_of(int64_t len) {
   int lp = 0;  // aim at 256 keys per bucket: a quarter-full 1024-slot table
   while (lp < 13 && ((int64_t)256 << lp) < len) ++lp;
   while (((int64_t)1 << lp) > kMaxBuckets) --lp;
-  const char* e = getenv("HBK_UNIQUE_LOG2P");  // test hook: force the bucket count
-  if (e != nullptr && atoi(e) >= 0 && atoi(e) <= 13) lp = atoi(e);
+  const int forced = options().unique_buckets_log2;   // option: force the bucket count
+  if (forced >= 0 && forced <= 13) lp = forced;
   return lp;
 }
 

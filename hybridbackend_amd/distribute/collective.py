@@ -70,25 +70,26 @@ class Collective:
 
   @classmethod
   def local_world(cls, world_size, local_size=None):
-    """Test transport: ``world_size`` communicators of one in-process world (one host thread
-    and one stream per rank, all on the current GPU); ``local_size`` ranks per "node" for the
-    INTRA_NODE / INTER_NODE topologies.  Returns the list of communicators; keep a reference to
-    the first one's ``_world`` until all are closed."""
+    """TEST transport (tests/support/libhbk_testing.so, not part of the product library):
+    ``world_size`` communicators of one in-process world -- one host thread and one stream per
+    rank, all on the current GPU -- plugged in through the public custom-transport hook
+    ``hbk_comm_create_custom``; ``local_size`` ranks per "node" for the INTRA_NODE / INTER_NODE
+    topologies.  Returns the list of communicators."""
     lib = _lib.lib()
+    tlib = _lib.testing_lib()
     world = C.c_void_p()
-    _lib.check(lib.hbk_local_world_create(C.byref(world), world_size))
+    if tlib.hbk_testing_local_world_create(C.byref(world), world_size) != 0:
+      raise _lib.HbkError(_lib.INTERNAL, 'could not create the in-process world')
     comms = []
     for r in range(world_size):
       c = cls.__new__(cls)
       c._lib = lib
-      c.world_size, c.rank, c.local_size = world_size, r, world_size
+      c.world_size, c.rank = world_size, r
+      c.local_size = int(local_size) if local_size is not None else world_size
       c._handle = C.c_void_p()
       c._wire_ws = None
       c._world = world
-      _lib.check(lib.hbk_comm_create_local(C.byref(c._handle), world, r))
-      if local_size is not None:
-        _lib.check(lib.hbk_comm_set_local_size(c._handle, int(local_size)))
-        c.local_size = int(local_size)
+      _lib.check(tlib.hbk_testing_comm_create(C.byref(c._handle), world, r, c.local_size))
       comms.append(c)
     return comms
 

@@ -68,7 +68,16 @@ typedef void* hbk_stream_t;
 const char* hbk_last_error(void);
 /* "hbk <version> gfx950" */
 const char* hbk_version(void);
-/* test hooks: the kernels' divide-free floor-mod / floor-div (multiply-high by a
+/* Tuning / diagnostic options of the library, process wide.  Defaults come from the environment
+ * once, when the library is first used (HBK_BWD_LOG2P, HBK_BWD_TARGET, HBK_BWD_SPLIT,
+ * HBK_UNIQUE_LOG2P, HBK_PART_SUB, HBK_PART_FIXED, HBK_SHARDED_GROUPS, HBK_SHARDED_ID64,
+ * HBK_SHARDED_COPY_SELF, HBK_SHARDED_TRACE); no entry point reads the environment per call.
+ * Names: bwd_buckets_log2, bwd_bucket_pairs, bwd_split_pairs, unique_buckets_log2,
+ * partition_sub_tiles, partition_fixed_max, sharded_groups, sharded_id64, sharded_copy_self,
+ * sharded_trace (the sharded_* ones are taken by hbk_sharded_create). */
+int hbk_set_option(const char* name, int32_t value);
+int hbk_get_option(const char* name, int32_t* value);
+/* the kernels' divide-free floor-mod / floor-div (multiply-high by a
  * host-computed magic) evaluated on the host, so the integer arithmetic can be checked
  * against Python's % and // without a GPU.  d > 0. */
 int64_t hbk_host_floormod_i64(int64_t v, int64_t d);
@@ -363,16 +372,29 @@ int hbk_allreduce_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t reduce_op
 int hbk_allgatherv(hbk_comm_t comm, int32_t dtype, const void* input, const int64_t* counts,
                    void* output, hbk_stream_t compute_stream);
 
-/* In-process "world" for tests: `world_size` ranks living in ONE process (one host thread and
- * one stream each, all on the current GPU) exchange through device copies with the same
- * chunk/offset arithmetic as the RCCL path.  It exists so that the multi-rank driver below can
- * be exercised on a single-GPU machine; it is not a production transport. */
-int hbk_local_world_create(void** world, int32_t world_size);
-int hbk_local_world_destroy(void* world);
-int hbk_comm_create_local(hbk_comm_t* comm, void* world, int32_t rank);
-/* node shape of an in-process communicator (local_size GPUs per "node"): lets INTRA_NODE /
- * INTER_NODE exchanges run between in-process ranks */
-int hbk_comm_set_local_size(hbk_comm_t comm, int32_t local_size);
+/* A communicator over a caller-provided transport instead of RCCL (the reference's Collective is
+ * an abstract class with NCCL as one implementation, hbtf/distribute/collective.h:70-201).  Every
+ * collective above, and the sharded pipeline below, then moves its data through these callbacks
+ * with the same chunk / offset arithmetic as over RCCL:
+ *   exchange   chunk k of sendbuf (send_off[k], send_len[k] elements of esize bytes) goes to
+ *              ranks[k], the chunk from ranks[k] lands at recv_off[k] elements of recvbuf; all on
+ *              `stream`; with skip_self the chunk for `rank` itself is left alone
+ *   allreduce  out[i] = reduce over the world's ranks of in[i]  (may be NULL: no allreduce)
+ *   destroy    called by hbk_comm_destroy (may be NULL)
+ * tests/support builds an in-process world on it (host threads sharing one GPU, device copies);
+ * that code is not part of this library. */
+typedef struct {
+  void* ctx;
+  int (*exchange)(void* ctx, int32_t rank, const int32_t* ranks, int32_t n_ranks,
+                  const void* sendbuf, const int64_t* send_off, const int64_t* send_len,
+                  void* recvbuf, const int64_t* recv_off, size_t esize, int32_t skip_self,
+                  hbk_stream_t stream);
+  int (*allreduce)(void* ctx, int32_t rank, int32_t world_size, int32_t dtype, int32_t reduce_op,
+                   const void* in, void* out, int64_t count, hbk_stream_t stream);
+  void (*destroy)(void* ctx);
+} hbk_transport_t;
+int hbk_comm_create_custom(hbk_comm_t* comm, const hbk_transport_t* transport,
+                           int32_t world_size, int32_t local_size, int32_t rank);
 
 /* ------------------------------------------------------------------------------------
  * R12  The whole sharded pipeline of hbtf/embedding/sharding.py:171-205 for N columns in one

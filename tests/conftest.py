@@ -23,6 +23,20 @@ def _built():
   import oracle
   oracle.build()
   lib_path = os.path.join(ROOT, 'hybridbackend_amd', 'lib', 'libhbk_core.so')
-  if not os.path.exists(lib_path):
+  test_lib = os.path.join(ROOT, 'hybridbackend_amd', 'lib', 'libhbk_testing.so')
+  if not os.path.exists(lib_path) or not os.path.exists(test_lib):
     import __graft_entry__
     __graft_entry__.build()
+
+
+@pytest.fixture
+def hbk_option():
+  """Set library options (hbk_set_option) for one test; restored afterwards."""
+  from hybridbackend_amd import _lib
+  saved = []
+
+  def set_(name, value):
+    saved.append((name, _lib.set_option(name, value)))
+  yield set_
+  for name, old in reversed(saved):
+    _lib.set_option(name, old)

@@ -184,3 +184,51 @@ def test_argument_checks_of_every_entry_family():
   assert lib.hbk_group_lookup_bwd_workspace_bytes(0, None) == 0
   assert lib.hbk_allreduce_workspace_bytes(1, one_i64, _lib.FLOAT) == 0   # one tensor: in place
   assert lib.hbk_cache_lookup_workspace_bytes(0) == 0
+
+
+def test_product_library_carries_no_test_scaffolding():
+  """The in-process test world lives in tests/support (libhbk_testing.so, over the public
+  custom-transport hook); the product library exports nothing of it and reads the environment
+  only once, for its option defaults."""
+  import subprocess
+  out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True,
+                       text=True, check=True).stdout
+  exported = set(re.findall(r'\b(hbk_[a-z0-9_]+)\b', out))
+  assert not [s for s in exported if 'local_world' in s or 'testing' in s or 'debug' in s]
+  assert exported == set(_declared_symbols()), exported ^ set(_declared_symbols())
+  undefined = subprocess.run(['nm', '-D', '--undefined-only', _lib.LIB_PATH], capture_output=True,
+                             text=True, check=True).stdout
+  assert 'getenv' in undefined                      # misc.cpp: option defaults, once
+  src = os.path.join(ROOT, 'hybridbackend_amd', 'csrc')
+  users = [f for f in sorted(os.listdir(src)) if os.path.isfile(os.path.join(src, f)) and
+           'getenv(' in open(os.path.join(src, f)).read()]
+  assert users == ['misc.cpp'], users
+
+
+def test_options_roundtrip_and_unknown_names():
+  lib = _lib.lib()
+  old = _lib.set_option('bwd_buckets_log2', 3)
+  try:
+    v = C.c_int32()
+    assert lib.hbk_get_option(b'bwd_buckets_log2', C.byref(v)) == 0 and v.value == 3
+  finally:
+    _lib.set_option('bwd_buckets_log2', old)
+  assert lib.hbk_set_option(b'no_such_option', 1) == _lib.INVALID_ARGUMENT
+  assert 'no_such_option' in lib.hbk_last_error().decode()
+  assert lib.hbk_get_option(None, None) == _lib.INVALID_ARGUMENT
+
+
+def test_custom_transport_argument_checks():
+  lib = _lib.lib()
+  comm = C.c_void_p()
+  assert lib.hbk_comm_create_custom(C.byref(comm), None, 2, 2, 0) == _lib.INVALID_ARGUMENT
+
+  class Transport(C.Structure):
+    _fields_ = [('ctx', C.c_void_p), ('exchange', C.c_void_p), ('allreduce', C.c_void_p),
+                ('destroy', C.c_void_p)]
+  t = Transport()
+  assert lib.hbk_comm_create_custom(C.byref(comm), C.byref(t), 2, 2, 0) == _lib.INVALID_ARGUMENT
+  t.exchange = 1   # any non-NULL pointer: only the shape of the world is checked here
+  assert lib.hbk_comm_create_custom(C.byref(comm), C.byref(t), 4, 3, 0) == _lib.INVALID_ARGUMENT
+  assert 'local_size' in lib.hbk_last_error().decode()
+  assert lib.hbk_comm_create_custom(C.byref(comm), C.byref(t), 4, 2, 7) == _lib.INVALID_ARGUMENT

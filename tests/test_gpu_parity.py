@@ -288,10 +288,10 @@ def test_unique_first_occurrence_order():
     np.testing.assert_equal(host(idx), oidx)
 
 
-def test_unique_table_overflow_is_still_exact(monkeypatch):
+def test_unique_table_overflow_is_still_exact(hbk_option):
   # one bucket per column: > 1024 distinct keys overflow the LDS table and are resolved by the
   # exact bucket scan
-  monkeypatch.setenv('HBK_UNIQUE_LOG2P', '0')
+  hbk_option('unique_buckets_log2', 0)
   rng = np.random.RandomState(16)
   cases = [rng.randint(0, 3000, size=6000).astype(np.int64),
            rng.randint(-5, 5, size=3000).astype(np.int64),
@@ -387,11 +387,11 @@ def test_group_lookup_backward(combiner):
     _check_slices(res[c], ids[c] % buckets[c], grads[c], splits[c], combiner)
 
 
-def test_group_lookup_backward_multi_chunk_and_multi_pass_path(monkeypatch):
+def test_group_lookup_backward_multi_chunk_and_multi_pass_path(hbk_option):
   # one bucket per column: many 512-pair chunks per workgroup, rows spanning chunks are
   # accumulated into their output row, and more distinct rows than the LDS table holds force
   # further passes over the bucket -- every row is still emitted exactly once
-  monkeypatch.setenv('HBK_BWD_LOG2P', '0')
+  hbk_option('bwd_buckets_log2', 0)
   rng = np.random.RandomState(21)
   for d, rows, n in ((16, 97, 5000), (128, 3000, 9000), (6, 10, 2000), (32, 100000, 4000)):
     table = rng.uniform(-1, 1, size=(rows, d)).astype(np.float32)
@@ -425,13 +425,13 @@ def test_group_lookup_backward_zipf_hot_rows():
 
 
 @pytest.mark.parametrize('split,log2p', [(None, None), ('96', '2'), ('700', '0')])
-def test_group_lookup_backward_split_buckets(monkeypatch, split, log2p):
+def test_group_lookup_backward_split_buckets(hbk_option, split, log2p):
   """Hot rows: a bucket far above the average is reduced by several workgroups (partial sums
   per range, then a merge), rows stay unique and the fused SGD apply stays exact.  The env hooks
   force tiny ranges so that ordinary buckets split too (many partial entries per bucket)."""
   if split is not None:
-    monkeypatch.setenv('HBK_BWD_SPLIT', split)
-    monkeypatch.setenv('HBK_BWD_LOG2P', log2p)
+    hbk_option('bwd_split_pairs', int(split))
+    hbk_option('bwd_buckets_log2', int(log2p))
   rng = np.random.RandomState(23)
   cases = []
   for d, rows, n in ((128, 1000, 40000), (16, 300, 30000), (6, 50, 9000)):
@@ -525,13 +525,13 @@ def test_group_lookup_backward_segmented_inputs():
 
 
 @pytest.mark.parametrize('hook', [None, 'one_bucket'])
-def test_group_lookup_backward_fused_adagrad_apply(monkeypatch, hook):
+def test_group_lookup_backward_fused_adagrad_apply(hbk_option, hook):
   """tf.train.AdagradOptimizer's sparse apply fused into the backward: accum += g^2,
   var -= lr * g / sqrt(accum) on the deduplicated gradient of every touched row -- bit-equal to
   the oracle applied to the emitted IndexedSlices (also when rows span chunks: the step is
   deferred to one apply per row), untouched rows stay untouched."""
   if hook:
-    monkeypatch.setenv('HBK_BWD_LOG2P', '0')     # one bucket: many chunks per workgroup
+    hbk_option('bwd_buckets_log2', 0)     # one bucket: many chunks per workgroup
   rng = np.random.RandomState(91)
   # (the forced single bucket holds far more distinct rows than the 1024-slot LDS table: several
   # passes over the bucket, and still one entry and ONE step per row)

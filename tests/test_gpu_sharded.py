@@ -192,13 +192,13 @@ def test_sharded_backward_through_rccl_world1_with_apply():
 
 @pytest.mark.parametrize('world,wire16,id64', [(2, False, False), (4, True, False),
                                                (8, False, False), (4, False, True)])
-def test_cxx_driver_multi_rank_in_process_world(monkeypatch, world, wire16, id64):
+def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64):
   """hbk_sharded_lookup_fwd/_bwd (the code that runs at 8 GPUs) with W ranks as host threads
   of one process on one GPU; only the transport differs from production (device copies
   instead of RCCL).  Forward == unsharded oracle lookup, backward == dense scatter-add."""
   import threading
   if id64:   # ids travel as int32 by default (all buckets < 2^31); this keeps int64 on the wire
-    monkeypatch.setenv('HBK_SHARDED_ID64', '1')
+    hbk_option('sharded_id64', 1)
   rng = np.random.RandomState(300 + world)
   # world 4 includes a dim that is not a multiple of 4 floats: unpack path instead of the
   # in-place segmented stitch

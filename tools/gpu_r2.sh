@@ -60,6 +60,10 @@ PY
     profbench)
       prof prof_bench "" -- python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0
       cat $O/prof_bench.txt;;
+    profsharded)
+      prof prof_sharded "" -- python $R/bench.py --gpus 1 --sharded --steps 30 --warmup 5 --cpu-seconds 0 ${SHARDED_ARGS:-}
+      cat $O/prof_sharded.txt
+      HBK_SHARDED_TRACE=1 timeout 120 python bench.py --gpus 1 --sharded --steps 8 --warmup 2 --cpu-seconds 0 ${SHARDED_ARGS:-} 2>&1 | tail -6;;
     profops)
       prof prof_ops "" -- $R/tools/bin/bench_ops ${OPS_ARGS:-}
       cat $O/prof_ops.txt;;

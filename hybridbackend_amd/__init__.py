@@ -6,6 +6,7 @@ from hybridbackend_amd import data
 from hybridbackend_amd import distribute
 from hybridbackend_amd import embedding
 from hybridbackend_amd import feature_column
+from hybridbackend_amd import training
 from hybridbackend_amd._lib import HbkError
 from hybridbackend_amd._lib import InvalidArgumentError
 

@@ -161,6 +161,49 @@ class DenseFeatures:
         res[c] = r[k]
     return res
 
+  # ---- checkpoints (hybridbackend/tensorflow/training/saver.py:97-185) ----------------------------
+  def variables(self):
+    """``{name: tensor | ShardedSlice}`` of this rank: the embedding weights (TF naming:
+    ``<key>_embedding/embedding_weights``; a sharded table is the slice ``part_<rank>`` of it,
+    variables.py:112-141) and, when the layer keeps them, the Adagrad slots (``.../Adagrad``)."""
+    from hybridbackend_amd.training.saver import ShardedSlice
+    world = self.coll.world_size if self.coll is not None else 1
+    rank = self.coll.rank if self.coll is not None else 0
+    out = {}
+    for c, col in enumerate(self.columns):
+      name = f'{col.key}_embedding/embedding_weights'
+      for suffix, tensors in (('', self.weights), ('/Adagrad', self.accums)):
+        if tensors is None:
+          continue
+        t = tensors[c]
+        out[name + suffix] = (ShardedSlice(t, col.num_buckets, world, rank)
+                              if self.sharded[c] else t)
+    return out
+
+  def _saver(self, barrier):
+    from hybridbackend_amd.training.saver import Saver
+    world = self.coll.world_size if self.coll is not None else 1
+    rank = self.coll.rank if self.coll is not None else 0
+    if barrier is None and world > 1:
+      import torch.distributed as dist   # pylint: disable=import-outside-toplevel
+      if not dist.is_initialized():
+        raise _lib.HbkError(_lib.INTERNAL, 'save/restore at W > 1 needs a barrier '
+                                           '(torch.distributed is not initialized)')
+      barrier = dist.barrier
+    return Saver(rank, world, barrier)
+
+  def save(self, prefix, barrier=None):
+    """Every rank writes its shards, rank 0 also the replicated tables and the index; all ranks
+    call this together.  The device work of the current stream is waited for first."""
+    if self.device.type == 'cuda':
+      torch.cuda.current_stream(self.device).synchronize()
+    return self._saver(barrier).save(prefix, self.variables())
+
+  def restore(self, prefix, barrier=None, layout='logical'):
+    """Loads this rank's rows from a checkpoint written at ANY world size (``layout='reference'``:
+    the reference's contiguous slicing instead, see training/saver.py)."""
+    self._saver(barrier).restore(prefix, self.variables(), layout=layout)
+
   def close(self):
     if self._sharded is not None:
       self._sharded.close()

@@ -1,0 +1,5 @@
+"""Checkpoints of sharded embedding tables
+(host mirror of ``hybridbackend/tensorflow/training/saver.py``)."""
+from hybridbackend_amd.training.saver import Saver
+from hybridbackend_amd.training.saver import ShardedSlice
+from hybridbackend_amd.training.saver import load_full

@@ -814,3 +814,84 @@ def test_hierarchical_call_in_process_world(local_size, nodes):
   for r in range(world):
     for c in range(2):
       np.testing.assert_equal(results[r][c], tables[c][ids[r][c] % rows[c]])
+
+
+# ----------------------------------------------------------------------------------
+# sharded checkpoints of the feature layer (training/saver.py), re-sharding included
+def test_dense_features_checkpoint_reshard_in_process_world(tmp_path):
+  """Two ranks train one step (forward, backward, fused Adagrad), save; four ranks restore the
+  checkpoint (every rank gathers the rows it now owns) and their forward equals the oracle lookup
+  on the updated tables -- weights AND optimizer slots survive the change of world size."""
+  import threading
+  from hybridbackend_amd.training import load_full
+  rng = np.random.RandomState(97)
+  cols, tables, feats2, grads2, batch = _dense_case(rng, 2)
+  prefix = str(tmp_path / 'model.ckpt-1')
+
+  def world_run(world, fn):
+    comms = hb.distribute.Collective.local_world(world)
+    barrier = threading.Barrier(world)
+    results, errors = [None] * world, []
+
+    def run(r):
+      try:
+        with torch.cuda.stream(torch.cuda.Stream()):
+          results[r] = fn(r, comms[r], barrier.wait)
+          torch.cuda.current_stream().synchronize()
+      except Exception as e:  # pylint: disable=broad-except
+        import traceback
+        errors.append((r, repr(e), traceback.format_exc()))
+        barrier.abort()
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+      t.start()
+    for t in threads:
+      t.join(timeout=45)
+    for cm in comms:
+      cm.close()
+    assert not errors, errors
+    return results
+
+  def train_and_save(r, coll, barrier):
+    def init(c, rows, d):
+      t = tables[cols.index(c)]
+      return dev((t[r::2] if rows != c.num_buckets else t).copy())
+    layer = hb.feature_column.DenseFeatures(cols, DEV, coll=coll, batch_size=batch, init=init,
+                                            initial_accumulator_value=0.1)
+    layer(_dev_feats(feats2[r]))
+    layer.backward(dev(grads2[r]), apply_lr=0.05, optimizer='adagrad')
+    layer.save(prefix, barrier=barrier)
+    layer.close()
+    return True
+
+  world_run(2, train_and_save)
+  # the logical tables after the step, read back from the checkpoint
+  updated = [load_full(prefix, f'{c.key}_embedding/embedding_weights') for c in cols]
+  slots = [load_full(prefix, f'{c.key}_embedding/embedding_weights/Adagrad') for c in cols]
+  for k, c in enumerate(cols):
+    assert updated[k].shape == tables[k].shape
+    if k != 1:
+      assert not np.array_equal(updated[k], tables[k])       # the step happened
+      assert (slots[k] >= 0.1).all() and (slots[k] > 0.1).any()
+
+  _, _, feats4, _, _ = _dense_case(np.random.RandomState(98), 4)
+
+  def restore_and_lookup(r, coll, barrier):
+    layer = hb.feature_column.DenseFeatures(cols, DEV, coll=coll, batch_size=batch,
+                                            initial_accumulator_value=0.1)
+    layer.restore(prefix, barrier=barrier)
+    out = layer(_dev_feats(feats4[r]))
+    torch.cuda.current_stream().synchronize()
+    res = (out.cpu().numpy(), [w.cpu().numpy() for w in layer.weights],
+           [a.cpu().numpy() for a in layer.accums], list(layer.sharded))
+    layer.close()
+    return res
+
+  res = world_run(4, restore_and_lookup)
+  for r in range(4):
+    want, _, _ = _want_dense(cols, updated, feats4[r])
+    np.testing.assert_equal(res[r][0], want)
+    for k in range(len(cols)):
+      sharded = res[r][3][k]
+      np.testing.assert_equal(res[r][1][k], updated[k][r::4] if sharded else updated[k])
+      np.testing.assert_equal(res[r][2][k], slots[k][r::4] if sharded else slots[k])

@@ -447,7 +447,8 @@ struct ReduceLds {
   uint16_t emitted[kSlots];  // slots of the rows this pass has emitted (jobs of several chunks)
   int32_t heavy[kCP / kHeavy + 1];
   int32_t wave_tot[kWavesPerBlock];
-  int32_t n_active, n_new, n_heavy, n_single, base_u, occupied, n_left, lds_rows, n_emitted, emit0;
+  int32_t n_active, n_new, n_heavy, n_single, base_u, occupied, occupied_before, n_left, lds_rows,
+      n_emitted, emit0;
   float red[kBlock * 4];     // hot-row partial sums, one 16-byte chunk per thread
 };
 
@@ -590,6 +591,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
   }
   if (tid == 0) {
     L.occupied = 0;
+    L.occupied_before = 0;
     L.n_left = 0;
   }
   __syncthreads();
@@ -677,6 +679,17 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       __syncthreads();
       HBK_STAMP(3);
 
+      // One global atomic per workgroup and chunk claims the output range of the new rows.  A
+      // returning device-scope atomic under this load takes several microseconds: it is issued
+      // as soon as the count is known -- the rows the table has gained in this chunk -- and its
+      // round trip runs beside the scan of (b) and the gradient loads of (c).
+      int32_t claimed = 0;
+      if (tid == kBlock - 1) {
+        const int32_t n_new = L.occupied - L.occupied_before;
+        L.occupied_before = L.occupied;
+        if (n_new > 0) claimed = atomicAdd(job.out_counter, n_new);
+      }
+
       // (b) one packed exclusive scan over the PAIRS that hold ticket 0 (one per slot of the
       // chunk): new rows | slots with several pairs << 10 | their pairs << 20
       {
@@ -759,36 +772,39 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       // when there are few such slots, else left to (d).
       const int n_active = L.n_active;   // uniform
       const bool lds_rows = L.lds_rows != 0;
-      // one global atomic per workgroup and chunk claims the output range of the new rows; its
-      // round trip runs beside the gradient loads (the barrier below waits for both)
-      int32_t claimed = 0;
-      if (tid == kBlock - 1 && L.n_new > 0) claimed = atomicAdd(job.out_counter, L.n_new);
       int32_t base_u = 0;
-      // lds_rows: every pair of the chunk is fetched here; else only the listed single-pair rows
+      // lds_rows: every pair of the chunk is fetched here; else only the listed single-pair rows.
+      // kDepth rows in flight per lane; between the loads and the stores a lane keeps nothing but
+      // the rows and one flag word (slot, ticket count and output position are read again from
+      // LDS), so that the deep variant fits the register budget without spilling.
+      constexpr int kDepth = STEP ? kPre : 2 * kPre;
       const int n_fetch = lds_rows ? n_chunk : L.n_single;
-      for (int e0 = 0; e0 == 0 || e0 < n_fetch; e0 += kPre * groups) {
-        V pre[kPre], tv[kPre], av[kPre];
-        int32_t cv[kPre], sl[kPre];
-        int64_t toff[kPre];
+      for (int e0 = 0; e0 == 0 || e0 < n_fetch; e0 += kDepth * groups) {
+        V pre[kDepth], tv[STEP ? kDepth : 1], av[STEP == 2 ? kDepth : 1];
+        uint32_t single = 0, multi = 0;     // bit k: row k of this round is a single new row / an
+                                            // LDS-summed pair
 #pragma unroll
-        for (int k = 0; k < kPre; ++k) {
+        for (int k = 0; k < kDepth; ++k) {
           const int i = e0 + k * groups + my_group;
-          pre[k] = tv[k] = av[k] = zero_v<V>();
-          cv[k] = 0;
-          toff[k] = 0;
-          sl[k] = (int)kNoSlot;
+          pre[k] = zero_v<V>();
           if (i < n_fetch && live) {
             const int e = lds_rows ? i : (int)L.order[i];
-            sl[k] = (int)L.pslot[e];
-            if (sl[k] != (int)kNoSlot) {
-              cv[k] = L.cnt[sl[k]];
-              if (cv[k] == (kNewBit | 1) || lds_rows) pre[k] = load_grad<V>(c, job, L.segs[e], sub);
-              if (STEP && cv[k] == (kNewBit | 1) && lr_now != 0.0f) {
+            const int sidx = (int)L.pslot[e];
+            if (sidx != (int)kNoSlot) {
+              const bool is_single = L.cnt[sidx] == (kNewBit | 1);
+              if (is_single || lds_rows) {
+                pre[k] = load_grad<V>(c, job, L.segs[e], sub);
+                single |= is_single ? 1u << k : 0u;
+                multi |= is_single ? 0u : 1u << k;
+              }
+              if (STEP && is_single && lr_now != 0.0f) {
                 // the table (and accumulator) row of the step travels with the gradient
-                toff[k] = (int64_t)L.keys[sl[k]] * c.dim + (int64_t)sub * VE;
-                tv[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff[k]));
-                if (adagrad) {
-                  av[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff[k]));
+                const int64_t toff = (int64_t)L.keys[sidx] * c.dim + (int64_t)sub * VE;
+                tv[STEP ? k : 0] =
+                    __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+                if (STEP == 2) {
+                  av[STEP == 2 ? k : 0] =
+                      __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
                 }
               }
             }
@@ -804,15 +820,21 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
           base_u = L.base_u;
         }
 #pragma unroll
-        for (int k = 0; k < kPre; ++k) {
-          if (sl[k] == (int)kNoSlot) continue;
-          if (cv[k] == (kNewBit | 1)) {
-            emit_row<V>(c, job, base_u + (-2 - L.slot_out[sl[k]]), true, sub, pre[k]);
-            if (STEP && lr_now != 0.0f) step_row<V>(c, adagrad, lr_now, toff[k], pre[k], tv[k], av[k]);
-          } else if (lds_rows) {
-            float* r = &L.red[(size_t)L.off[sl[k]] * c.dim + (size_t)sub * VE];
+        for (int k = 0; k < kDepth; ++k) {
+          if (((single | multi) >> k & 1u) == 0) continue;
+          const int i = e0 + k * groups + my_group;
+          const int sidx = (int)L.pslot[lds_rows ? i : (int)L.order[i]];
+          if (single >> k & 1u) {
+            emit_row<V>(c, job, base_u + (-2 - L.slot_out[sidx]), true, sub, pre[k]);
+            if (STEP && lr_now != 0.0f) {
+              const int64_t toff = (int64_t)L.keys[sidx] * c.dim + (int64_t)sub * VE;
+              step_row<V>(c, adagrad, lr_now, toff, pre[k], tv[STEP ? k : 0],
+                          STEP == 2 ? av[STEP == 2 ? k : 0] : zero_v<V>());
+            }
+          } else {
+            float* r = &L.red[(size_t)L.off[sidx] * c.dim + (size_t)sub * VE];
 #pragma unroll
-            for (int i = 0; i < VE; ++i) atomicAdd(r + i, reinterpret_cast<const float*>(&pre[k])[i]);
+            for (int q = 0; q < VE; ++q) atomicAdd(r + q, reinterpret_cast<const float*>(&pre[k])[q]);
           }
         }
       }
@@ -1002,6 +1024,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
     }
     if (tid == 0) {
       L.occupied = 0;
+      L.occupied_before = 0;
       L.n_left = 0;
       L.n_emitted = 0;
     }

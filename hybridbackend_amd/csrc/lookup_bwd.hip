@@ -53,9 +53,6 @@
 
 #include "lookup_common.h"
 
-#ifndef HBK_BWD_CP
-#define HBK_BWD_CP 512
-#endif
 #ifndef HBK_BWD_UA
 #define HBK_BWD_UA 4
 #endif
@@ -80,17 +77,46 @@ constexpr int kTile = HBK_BWD_TILE;  // ids per 256-thread block in hist / scatt
 constexpr int kPerThread = kTile / kBlock;
 constexpr int kBatch = kPerThread < 8 ? kPerThread : 8;   // loads in flight per thread
 constexpr int kMaxBuckets = 16384;   // 64 KB of LDS counters in hist / scatter
-constexpr int kCP = HBK_BWD_CP;       // pairs per chunk in the reduce kernel
+// The reduce stage works in TEAMS: kTeam threads own one bucket.  kTeam = 256 (shipped): a team
+// is the workgroup.  kTeam = 64 (-DHBK_BWD_TEAM=64): a team is ONE WAVE, a workgroup holds four
+// independent teams with their own LDS tables and there is no workgroup barrier anywhere in the
+// reduce kernel (lanes of a wave execute LDS instructions in lockstep: a fence that keeps the
+// compiler from reordering them is all the synchronisation a team needs), so a CU runs 16
+// independent chains of dependent memory round trips instead of 4.  Measured on the config-2
+// backward (profiles/r02_bwd_reduce_trace.txt): a wave-team job lives 17 us instead of 21 and the
+// reduce kernel takes the same ~95 us either way (jobs x life / resident teams + one life of
+// tail), while four times as many buckets cost the grouping kernels 19 us (scatter 26 -> 39, scan
+// 6 -> 12): 164 vs 142 us in total.
+#ifndef HBK_BWD_TEAM
+#define HBK_BWD_TEAM 256
+#endif
+constexpr int kTeam = HBK_BWD_TEAM;
+constexpr int kTeams = kBlock / kTeam;  // teams per workgroup
+constexpr int kCP = 2 * kTeam;        // pairs per chunk in the reduce kernel
 constexpr int kSlots = 2 * kCP;       // LDS hash-table slots
-constexpr int kRoom = kSlots - kBlock - 8;  // rows enter the table while it holds fewer (a
-                                           // block's concurrent inserts overshoot by < kBlock)
+constexpr int kRoom = kSlots - kTeam - 8;   // rows enter the table while it holds fewer (a
+                                           // team's concurrent inserts overshoot by < kTeam)
+static_assert(kTeam == 64 || kTeam == kBlock, "a team is one wave or the whole workgroup");
+
+// all threads of a team have finished their LDS accesses before anyone goes on
+__device__ inline void team_sync() {
+  if (kTeam == kBlock) {
+    __syncthreads();
+  } else {
+    // one wave: the hardware runs its LDS instructions in order; keep the compiler from moving
+    // LDS accesses across this point and wait for the ones issued
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
 #ifndef HBK_BWD_PRE
 #define HBK_BWD_PRE 4
 #endif
 constexpr int kPre = HBK_BWD_PRE;     // gradient rows a lane keeps in flight (single-pair rows)
 constexpr int kUA = HBK_BWD_UA;       // slots a lane group reduces concurrently (rows in flight)
 constexpr int kHeavy = 64;            // pairs of one row in a chunk that make it a "hot row"
-constexpr int kLdsRowPairs = 64;      // multi-pair slots are summed in LDS rows when they hold at
+constexpr int kLdsRowPairs = kCP / 8; // multi-pair slots are summed in LDS rows when they hold at
                                       // most this many pairs together
 #ifndef HBK_BWD_HOT
 #define HBK_BWD_HOT 4
@@ -134,6 +160,11 @@ struct GCol {
   int64_t* unique_rows;
   float* grad_rows;
   int32_t* n_unique;
+  int32_t* counter;          // the column's claim counter, ALONE on its 256-byte line of the workspace:
+                             // every reduce job claims its output range with one atomic on it, and
+                             // atomics on one line are served by one memory channel at ~80 per us --
+                             // 26 caller-side counters side by side in one line made the whole reduce
+                             // kernel wait for that channel (3822 claims = its ~95 us)
   float* table;
   float* accum;              // Adagrad accumulator [rows, dim] (apply kind 2)
   int32_t* hist;             // [P * tiles] -> exclusive offsets after the scan
@@ -364,7 +395,7 @@ __device__ inline void scan_buckets_of_column(const GCol& c, int32_t* wave_tot, 
   for (int e = n_extra + tid; e < c.e_max; e += kBlock) c.desc[P + e] = make_int4(0, 0, -1, 0);
   if (tid == kBlock - 1) {
     c.bstart[P] = run;   // the last thread's running sum is the column total
-    *c.n_unique = 0;
+    *c.counter = 0;
     *c.n_extra = n_extra;
   }
 }
@@ -375,13 +406,13 @@ __global__ __launch_bounds__(kBlock) void bwd_scan_kernel(const GArgs a) {
   scan_buckets_of_column(a.col[blockIdx.x], wave_tot, &n_extra);
 }
 
-// both steps in one launch when every column of the call is small (<= kBlock buckets, few tiles:
-// one thread walks a bucket's tiles): one workgroup per column
+// both steps in one launch when every column of the call is small (<= 1024 buckets, few tiles:
+// a thread walks the tiles of up to four buckets): one workgroup per column
 __global__ __launch_bounds__(kBlock) void bwd_scan_fused_kernel(const GArgs a) {
   __shared__ int32_t wave_tot[kWavesPerBlock];
   __shared__ int32_t n_extra;
   const GCol& c = a.col[blockIdx.x];
-  if ((int)threadIdx.x < c.n_buckets) scan_tiles_of_bucket(c, (int)threadIdx.x);
+  for (int p = (int)threadIdx.x; p < c.n_buckets; p += kBlock) scan_tiles_of_bucket(c, p);
   __syncthreads();   // bstart[] written above is read below by other threads of this workgroup
   scan_buckets_of_column(c, wave_tot, &n_extra);
 }
@@ -446,10 +477,10 @@ struct ReduceLds {
   uint16_t pslot[kCP];       // slot of every pair; kNoSlot: struck out earlier / left for a later pass
   uint16_t emitted[kSlots];  // slots of the rows this pass has emitted (jobs of several chunks)
   int32_t heavy[kCP / kHeavy + 1];
-  int32_t wave_tot[kWavesPerBlock];
+  int32_t wave_tot[kTeam / kWave];
   int32_t n_active, n_new, n_heavy, n_single, base_u, occupied, occupied_before, n_left, lds_rows,
       n_emitted, emit0;
-  float red[kBlock * 4];     // hot-row partial sums, one 16-byte chunk per thread
+  float red[kTeam * 4];      // hot-row partial sums, one 16-byte chunk per thread
 };
 
 constexpr int32_t kNewBit = 1 << 30;
@@ -551,7 +582,7 @@ __device__ inline int table_slot(ReduceLds& L, unsigned long long row) {
     const unsigned long long k = L.keys[h];
     if (k == row) return h;
     if (k == kEmptyKey) {
-      // racy read of the fill level: concurrent inserts overshoot kRoom by < kBlock rows, the
+      // racy read of the fill level: concurrent inserts overshoot kRoom by < kTeam rows, the
       // table keeps >= 8 empty slots, so every probe sequence ends
       if (*(volatile int32_t*)&L.occupied >= kRoom) return -1;
       const unsigned long long prev = atomicCAS(&L.keys[h], kEmptyKey, row);
@@ -570,12 +601,12 @@ __device__ inline int table_slot(ReduceLds& L, unsigned long long row) {
 template <typename V, int STEP>
 __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, ReduceLds& L) {
   constexpr int VE = sizeof(V) / 4;
-  const int tid = (int)threadIdx.x;
+  const int tid = (int)threadIdx.x & (kTeam - 1);   // inside the team
   const int lane = tid & (kWave - 1), wave = tid >> 6;
   const int lpr_log2 = c.lpr_log2;
   const int sub = lane & ((1 << lpr_log2) - 1);
   const bool live = sub < c.chunks;
-  const int groups = kBlock >> lpr_log2;
+  const int groups = kTeam >> lpr_log2 > 0 ? kTeam >> lpr_log2 : 1;
   const int my_group = tid >> lpr_log2;
 
   const int32_t n_pairs = job.n_pairs;
@@ -583,8 +614,8 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
   int64_t* prow = job.prow;
   const int32_t* pseg = job.pseg;
 
-  __syncthreads();   // a workgroup may run several jobs: the previous one is done with the table
-  for (int i = tid; i < kSlots; i += kBlock) {
+  team_sync();   // a workgroup may run several jobs: the previous one is done with the table
+  for (int i = tid; i < kSlots; i += kTeam) {
     L.keys[i] = kEmptyKey;
     L.slot_out[i] = -1;
     L.cnt[i] = 0;
@@ -594,7 +625,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
     L.occupied_before = 0;
     L.n_left = 0;
   }
-  __syncthreads();
+  team_sync();
   HBK_STAMP(2);
 
   // The optimizer step is taken once per row.  A job of one chunk (almost all: buckets aim at 7/8
@@ -624,11 +655,11 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       // serialise, so a hot row is first reduced inside the wave: up to kHotTries times the first
       // pending lane's row is matched with a ballot; a group of >= kHotMin lanes lets its leader
       // probe once and take all tickets, the other lanes get slot and ticket by broadcast.
-      int hs_[kCP / kBlock], tk_[kCP / kBlock], rk_[kCP / kBlock];
-      unsigned long long row_[kCP / kBlock];
+      int hs_[kCP / kTeam], tk_[kCP / kTeam], rk_[kCP / kTeam];
+      unsigned long long row_[kCP / kTeam];
 #pragma unroll
-      for (int k = 0; k < kCP / kBlock; ++k) {
-        const int e = k * kBlock + tid;
+      for (int k = 0; k < kCP / kTeam; ++k) {
+        const int e = k * kTeam + tid;
         bool valid = e < n_chunk;
         unsigned long long row = 0;
         if (valid) {
@@ -676,7 +707,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         tk_[k] = ticket;
         row_[k] = row;
       }
-      __syncthreads();
+      team_sync();
       HBK_STAMP(3);
 
       // One global atomic per workgroup and chunk claims the output range of the new rows.  A
@@ -684,7 +715,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       // as soon as the count is known -- the rows the table has gained in this chunk -- and its
       // round trip runs beside the scan of (b) and the gradient loads of (c).
       int32_t claimed = 0;
-      if (tid == kBlock - 1) {
+      if (tid == kTeam - 1) {
         const int32_t n_new = L.occupied - L.occupied_before;
         L.occupied_before = L.occupied;
         if (n_new > 0) claimed = atomicAdd(job.out_counter, n_new);
@@ -693,9 +724,9 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       // (b) one packed exclusive scan over the PAIRS that hold ticket 0 (one per slot of the
       // chunk): new rows | slots with several pairs << 10 | their pairs << 20
       {
-        int32_t pk[kCP / kBlock], sum = 0;
+        int32_t pk[kCP / kTeam], sum = 0;
 #pragma unroll
-        for (int k = 0; k < kCP / kBlock; ++k) {
+        for (int k = 0; k < kCP / kTeam; ++k) {
           pk[k] = 0;
           if (hs_[k] >= 0 && tk_[k] == 0) {
             const int32_t n = L.cnt[hs_[k]];
@@ -714,10 +745,10 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
           if (lane >= o) incl += y;
         }
         if (lane == kWave - 1) L.wave_tot[wave] = incl;
-        __syncthreads();
+        team_sync();
         int32_t run = incl - sum;
         for (int w = 0; w < wave; ++w) run += L.wave_tot[w];
-        if (tid == kBlock - 1) {
+        if (tid == kTeam - 1) {
           const int32_t tot = run + sum;
           L.n_new = tot & 1023;
           L.n_active = (tot >> 10) & 1023;
@@ -725,12 +756,12 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
           // rows by ds_add_f32; many, or a slot with many pairs (skewed ids: same-address LDS
           // atomics serialise): they are sorted by slot and walked / summed by the whole
           // workgroup, see (d), (e)
-          L.lds_rows = ((tot >> 10) & 1023) * c.dim <= kBlock * 4 && (tot >> 20) <= kLdsRowPairs;
+          L.lds_rows = ((tot >> 10) & 1023) * c.dim <= kTeam * 4 && (tot >> 20) <= kLdsRowPairs;
         }
-        __syncthreads();
+        team_sync();
         const bool lds_rows_b = L.lds_rows != 0;
 #pragma unroll
-        for (int k = 0; k < kCP / kBlock; ++k) {
+        for (int k = 0; k < kCP / kTeam; ++k) {
           rk_[k] = -1;
           if (!lds_rows_b) {
             // skewed ids: most pairs belong to multi-pair slots and go through (d); (c) then walks
@@ -742,7 +773,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
               const int first = __builtin_ctzll(single);
               if (lane == first) base = atomicAdd(&L.n_single, (int)__builtin_popcountll(single));
               base = __builtin_amdgcn_readlane(base, first);
-              if (pk[k] == 1) L.order[base + rank_below(single)] = (uint16_t)(k * kBlock + tid);
+              if (pk[k] == 1) L.order[base + rank_below(single)] = (uint16_t)(k * kTeam + tid);
             }
           }
           if (pk[k] != 0) {
@@ -763,7 +794,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
           run += pk[k];
         }
       }
-      __syncthreads();
+      team_sync();
       HBK_STAMP(4);
 
       // (c) one round of gradient loads, kPre rows in flight per lane.  A NEW row with ONE pair in
@@ -811,12 +842,12 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
           }
         }
         if (e0 == 0) {
-          if (tid == kBlock - 1) {
+          if (tid == kTeam - 1) {
             L.base_u = job.out_base + claimed;
             L.emit0 = L.n_emitted;
             L.n_emitted += L.n_new;
           }
-          __syncthreads();
+          team_sync();
           base_u = L.base_u;
         }
 #pragma unroll
@@ -840,9 +871,9 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       }
       // the new rows' slots get their absolute output position (later chunks, (d), the optimizer
       // step read it), and the row numbers go out
-      __syncthreads();
+      team_sync();
 #pragma unroll
-      for (int k = 0; k < kCP / kBlock; ++k) {
+      for (int k = 0; k < kCP / kTeam; ++k) {
         if (rk_[k] >= 0) {
           const int32_t u = base_u + rk_[k];
           L.slot_out[hs_[k]] = u;
@@ -851,7 +882,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         }
       }
       if (lds_rows && n_active > 0) {
-        __syncthreads();
+        team_sync();
         for (int m = my_group; m < n_active; m += groups) {
           if (!live) continue;
           const int sidx = L.active[m];
@@ -865,8 +896,8 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         // (d) counting sort of the pairs of multi-pair slots (off[] ends up as the end of every
         // slot's run); tickets of a hot slot are taken once per wave and split by ballot rank
 #pragma unroll
-        for (int k = 0; k < kCP / kBlock; ++k) {
-          const int e = k * kBlock + tid;
+        for (int k = 0; k < kCP / kTeam; ++k) {
+          const int e = k * kTeam + tid;
           const int h = hs_[k];
           const bool valid = h >= 0 && L.cnt[h] != (kNewBit | 1);
           int pos = -1;
@@ -888,7 +919,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
             L.order[pos] = (uint16_t)e;
           }
         }
-        __syncthreads();
+        team_sync();
 
         // a lane group sums the rows of kUA slots at a time, in registers
         for (int k0 = 0; k0 < n_active; k0 += groups * kUA) {
@@ -933,7 +964,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
             }
           }
         }
-        __syncthreads();
+        team_sync();
 
         // (e) hot rows: the whole workgroup sums one row, partial sums folded through LDS
         const int n_heavy = L.n_heavy;
@@ -954,7 +985,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
             for (int u = 0; u < kUH; ++u) acc = acc + g[u];
           }
           *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = acc;
-          __syncthreads();
+          team_sync();
           if (my_group == 0 && live) {
             V tot = zero_v<V>();
             for (int gi = 0; gi < groups; ++gi) {
@@ -963,10 +994,10 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
             emit_step_row<V, STEP>(c, job, lr_now, L.slot_out[s], (L.cnt[s] & kNewBit) != 0,
                              (int64_t)L.keys[s], sub, tot);
           }
-          __syncthreads();
+          team_sync();
         }
       }
-      __syncthreads();
+      team_sync();
 
       // chunk done: the tickets go back to zero; once a pass has left pairs behind, the pairs it
       // did handle are struck out of the pair buffer so that the next pass skips them
@@ -974,13 +1005,13 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       if (left && first_left < 0) first_left = cb;
       striking = striking || left;
 #pragma unroll
-      for (int k = 0; k < kCP / kBlock; ++k) {
+      for (int k = 0; k < kCP / kTeam; ++k) {
         if (hs_[k] >= 0) {
           L.cnt[hs_[k]] = 0;
-          if (striking) prow[cb + k * kBlock + tid] = kDonePair;
+          if (striking) prow[cb + k * kTeam + tid] = kDonePair;
         }
       }
-      __syncthreads();
+      team_sync();
       HBK_STAMP(6);
     }
     // the pass is over (job of several chunks): one optimizer step per row the pass emitted.  All
@@ -1017,8 +1048,8 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
     }
     if (first_left < 0) break;     // uniform
     // another pass for the rows that found no room, with an emptied table
-    __syncthreads();
-    for (int i = tid; i < kSlots; i += kBlock) {
+    team_sync();
+    for (int i = tid; i < kSlots; i += kTeam) {
       L.keys[i] = kEmptyKey;
       L.slot_out[i] = -1;
     }
@@ -1029,7 +1060,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       L.n_emitted = 0;
     }
     first_cb = first_left;
-    __syncthreads();
+    team_sync();
   }
 }
 
@@ -1071,7 +1102,7 @@ __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4&
     job->n_pairs = n_b;
     job->out_rows = c.unique_rows;
     job->out_vals = c.grad_rows;
-    job->out_counter = c.n_unique;
+    job->out_counter = c.counter;
     job->out_base = 0;
     job->lr = lr;
     job->apply = a.apply;
@@ -1081,18 +1112,22 @@ __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4&
 
 template <typename V, int STEP>
 __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const GArgs a,
-                                                                          const int4* desc) {
-  __shared__ ReduceLds lds;
+                                                                          const int4* desc,
+                                                                          int total) {
+  __shared__ ReduceLds lds[kTeams];
   HBK_STAMP_BEGIN()
   const int lane = (int)threadIdx.x & (kWave - 1);
+  const int team = (int)threadIdx.x / kTeam;
+  const int vb = (int)blockIdx.x * kTeams + team;   // the team's job slot
+  if (vb >= total) return;                          // team-uniform; no workgroup barrier follows
   // two independent loads (the job, the columns' first slots): one round trip
-  const int4 d = desc[blockIdx.x];
+  const int4 d = desc[vb];
   const int my_b0 = lane < a.n_cols ? a.bucket0[lane] : 0x7fffffff;
   ReduceJob job;
   int ci;
-  if (!decode_job<V>(a, my_b0, (int)blockIdx.x, d, a.lr, &ci, &job)) return;
+  if (!decode_job<V>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
   HBK_STAMP(1);
-  bucket_reduce<V, STEP>(a.col[ci], job, lds);
+  bucket_reduce<V, STEP>(a.col[ci], job, lds[team]);
   HBK_STAMP(7);
 }
 
@@ -1102,12 +1137,13 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
 constexpr int kMergeBlocks = 8;
 template <typename V, int STEP>
 __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const GArgs a) {
-  __shared__ ReduceLds lds;
+  __shared__ ReduceLds lds[kTeams];
   HBK_FIND_COL(a, merge0)
   if ((c.vec4 != 0) != (sizeof(V) == 16)) return;
+  const int team = (int)threadIdx.x / kTeam;
   const int n_extra = *c.n_extra;
   const int blocks = c.e_max < kMergeBlocks ? c.e_max : kMergeBlocks;
-  for (int e = (int)blockIdx.x - c.merge0; e < n_extra; e += blocks) {
+  for (int e = ((int)blockIdx.x - c.merge0) * kTeams + team; e < n_extra; e += blocks * kTeams) {
     if (c.work[2 * e + 1] != 1) continue;
     const int bucket = c.work[2 * e];
     const int32_t start = c.bstart[bucket];
@@ -1121,12 +1157,18 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const 
     job.stride = c.dim;
     job.out_rows = c.unique_rows;
     job.out_vals = c.grad_rows;
-    job.out_counter = c.n_unique;
+    job.out_counter = c.counter;
     job.out_base = 0;
     job.lr = a.lr;
     job.apply = a.apply;
-    bucket_reduce<V, STEP>(c, job, lds);
+    bucket_reduce<V, STEP>(c, job, lds[team]);
   }
+}
+
+// the columns' row counts go from the workspace counters to the caller's n_unique
+__global__ __launch_bounds__(kWave) void bwd_finish_kernel(const GArgs a) {
+  const int ci = (int)threadIdx.x;
+  if (ci < a.n_cols) *a.col[ci].n_unique = *a.col[ci].counter;
 }
 
 // ---- d(stitch + combiner): permutation scatter (hbk_group_stitch_bwd) ----------------------
@@ -1271,6 +1313,7 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
   b += align8((size_t)h.n_ids * 4);                        // pair_seg
   if (h.row_splits != nullptr) b += align8((size_t)h.n_ids * 4);
   b += ((size_t)p.n_buckets + p.e_max) * sizeof(int4);     // desc (carved from the call's head)
+  b += 256;                                                // the claim counter's own line
   b += align8((size_t)p.e_max * 8) + 8;                    // work, n_extra
   b += align8(((size_t)p.n_buckets) * 4);                 // pcount
   b += (size_t)h.n_ids * 8;                                // part_rows
@@ -1302,7 +1345,7 @@ extern "C" size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
   if (n_cols <= 0 || cols == nullptr) return 0;
   size_t total = 0;
   for (int32_t c = 0; c < n_cols; ++c) total += hbk::col_workspace(cols[c]);
-  return total == 0 ? 0 : total + 16;   // the descriptor table is aligned to 16 bytes inside
+  return total == 0 ? 0 : total + 256;  // the head (counters, descriptors) is aligned inside
 }
 
 extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
@@ -1359,7 +1402,11 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
               "group_lookup_bwd: workspace must be 8-byte aligned");
   // head of the workspace: the job descriptors of all columns (16-byte aligned), then the
   // per-column buffers
-  char* dp = reinterpret_cast<char*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  char* cp = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  char* dp = cp;
+  for (int32_t c = 0; c < n_cols; ++c) {
+    if (cols[c].n_ids > 0) dp += 256;       // one claim counter per column, one per line
+  }
   char* wp = dp;
   for (int32_t c = 0; c < n_cols; ++c) {
     if (cols[c].n_ids <= 0) continue;
@@ -1390,6 +1437,8 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       d.unique_rows = h.unique_rows;
       d.grad_rows = h.grad_rows;
       d.n_unique = h.n_unique;
+      d.counter = reinterpret_cast<int32_t*>(cp);
+      cp += 256;
       d.table = h.table;
       d.accum = h.accum;
       d.hist = reinterpret_cast<int32_t*>(wp);
@@ -1423,7 +1472,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       merges += p.e_max < kMergeBlocks ? p.e_max : kMergeBlocks;
       d.scan0 = (int32_t)scans;
       scans += ((int64_t)p.n_buckets + kBlock - 1) / kBlock;
-      small_scan = small_scan && p.n_buckets <= kBlock && p.tiles <= 64;
+      small_scan = small_scan && p.n_buckets <= 4 * kBlock && p.tiles <= 64;
       d.run_start = h.run_start;
       d.run_ids = h.run_ids;
       d.run_grads = h.run_grads;
@@ -1500,7 +1549,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     }
     // one instantiation per optimizer (none / SGD / Adagrad)
     const int step = apply_lr == 0.0f ? 0 : apply == HBK_APPLY_ADAGRAD ? 2 : 1;
-    typedef void (*reduce_fn)(const GArgs, const int4*);
+    typedef void (*reduce_fn)(const GArgs, const int4*, int);
     typedef void (*merge_fn)(const GArgs);
     static const reduce_fn kReduce4[3] = {&bwd_reduce_kernel<f32x4, 0>, &bwd_reduce_kernel<f32x4, 1>,
                                           &bwd_reduce_kernel<f32x4, 2>};
@@ -1513,13 +1562,16 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     const reduce_fn reduce4 = kReduce4[step], reduce1 = kReduce1[step];
     const merge_fn merge4 = kMerge4[step], merge1 = kMerge1[step];
     if (any_vec4) {
-      hipLaunchKernelGGL(reduce4, dim3((unsigned)buckets), dim3(kBlock), 0, stream, args, desc_group);
+      hipLaunchKernelGGL(reduce4, dim3((unsigned)((buckets + kTeams - 1) / kTeams)), dim3(kBlock), 0,
+                         stream, args, desc_group, (int)buckets);
     }
     if (any_scalar) {
-      hipLaunchKernelGGL(reduce1, dim3((unsigned)buckets), dim3(kBlock), 0, stream, args, desc_group);
+      hipLaunchKernelGGL(reduce1, dim3((unsigned)((buckets + kTeams - 1) / kTeams)), dim3(kBlock), 0,
+                         stream, args, desc_group, (int)buckets);
     }
     if (any_vec4) hipLaunchKernelGGL(merge4, dim3((unsigned)merges), dim3(kBlock), 0, stream, args);
     if (any_scalar) hipLaunchKernelGGL(merge1, dim3((unsigned)merges), dim3(kBlock), 0, stream, args);
+    hipLaunchKernelGGL(bwd_finish_kernel, dim3(1), dim3(kWave), 0, stream, args);
     HBK_HIP_OK(hipGetLastError());
   }
   return HBK_OK;

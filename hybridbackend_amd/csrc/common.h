@@ -125,6 +125,7 @@ struct Options {
   int unique_buckets_log2 = -1;  // HBK_UNIQUE_LOG2P
   int partition_sub_tiles = 1;   // HBK_PART_SUB
   int partition_fixed_max = 8;   // HBK_PART_FIXED
+  int partition_onepass = 1;     // HBK_PART_ONEPASS: 0 = always the three-launch path
   int sharded_groups = 2;        // HBK_SHARDED_GROUPS: column groups a sharded step pipelines
   int sharded_id64 = 0;          // HBK_SHARDED_ID64: keep int64 ids on the wire
   int sharded_copy_self = 0;     // HBK_SHARDED_COPY_SELF: own slice through a device copy

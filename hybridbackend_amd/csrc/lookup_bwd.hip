@@ -160,6 +160,8 @@ struct GCol {
   int64_t* unique_rows;
   float* grad_rows;
   int32_t* n_unique;
+  int32_t no_emit;           // unique_rows / grad_rows are scratch: the caller passed none (step only)
+  int32_t pad2_;
   int32_t* counter;          // the column's claim counter, ALONE on its 256-byte line of the workspace:
                              // every reduce job claims its output range with one atomic on it, and
                              // atomics on one line are served by one memory channel at ~80 per us --
@@ -503,6 +505,9 @@ struct ReduceJob {
   int32_t out_base;          // added to the claimed index
   float lr;                  // != 0: fused optimizer step on the table row
   int32_t apply;             // HBK_APPLY_SGD | HBK_APPLY_ADAGRAD
+  bool no_emit;              // "step only" (the caller wants no IndexedSlices) and the job is one
+                             // chunk: rows are stepped where their sums sit in registers, nothing
+                             // is written out and no output range is claimed
 };
 
 template <typename V>
@@ -563,7 +568,7 @@ template <typename V, int STEP>
 __device__ inline void emit_step_row(const GCol& c, const ReduceJob& job, float lr, int32_t u,
                                      bool is_new, int64_t row, int sub, V v) {
   constexpr int VE = sizeof(V) / 4;
-  emit_row<V>(c, job, u, is_new, sub, v);
+  if (!(STEP && job.no_emit)) emit_row<V>(c, job, u, is_new, sub, v);
   if (STEP && lr != 0.0f) {
     constexpr bool adagrad = STEP == 2;
     const int64_t toff = row * c.dim + (int64_t)sub * VE;
@@ -718,7 +723,12 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       if (tid == kTeam - 1) {
         const int32_t n_new = L.occupied - L.occupied_before;
         L.occupied_before = L.occupied;
-        if (n_new > 0) claimed = atomicAdd(job.out_counter, n_new);
+        if (STEP && job.no_emit) {
+          // only the count is wanted: fire and forget, nobody waits for this atomic
+          if (n_new > 0) __hip_atomic_fetch_add(job.out_counter, n_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (n_new > 0) {
+          claimed = atomicAdd(job.out_counter, n_new);
+        }
       }
 
       // (b) one packed exclusive scan over the PAIRS that hold ticket 0 (one per slot of the
@@ -856,7 +866,9 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
           const int i = e0 + k * groups + my_group;
           const int sidx = (int)L.pslot[lds_rows ? i : (int)L.order[i]];
           if (single >> k & 1u) {
-            emit_row<V>(c, job, base_u + (-2 - L.slot_out[sidx]), true, sub, pre[k]);
+            if (!(STEP && job.no_emit)) {
+              emit_row<V>(c, job, base_u + (-2 - L.slot_out[sidx]), true, sub, pre[k]);
+            }
             if (STEP && lr_now != 0.0f) {
               const int64_t toff = (int64_t)L.keys[sidx] * c.dim + (int64_t)sub * VE;
               step_row<V>(c, adagrad, lr_now, toff, pre[k], tv[STEP ? k : 0],
@@ -877,7 +889,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         if (rk_[k] >= 0) {
           const int32_t u = base_u + rk_[k];
           L.slot_out[hs_[k]] = u;
-          job.out_rows[u] = (int64_t)row_[k];
+          if (!(STEP && job.no_emit)) job.out_rows[u] = (int64_t)row_[k];
           if (defer) L.emitted[L.emit0 + rk_[k]] = (uint16_t)hs_[k];
         }
       }
@@ -1081,6 +1093,7 @@ __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4&
   if ((c.vec4 != 0) != (sizeof(V) == 16)) return false;
   *ci_out = ci;
   const int32_t start = d.x, n_b = d.y, bucket = d.z, range = d.w;
+  job->no_emit = false;
   job->grad = c.grad_out;
   job->scale = true;
   job->seg_is_offset = c.n_runs > 0;
@@ -1106,6 +1119,7 @@ __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4&
     job->out_base = 0;
     job->lr = lr;
     job->apply = a.apply;
+    job->no_emit = c.no_emit != 0 && lr != 0.0f && n_b <= kCP;
   }
   return true;
 }
@@ -1161,6 +1175,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const 
     job.out_base = 0;
     job.lr = a.lr;
     job.apply = a.apply;
+    job.no_emit = false;
     bucket_reduce<V, STEP>(c, job, lds[team]);
   }
 }
@@ -1318,6 +1333,10 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
   b += align8(((size_t)p.n_buckets) * 4);                 // pcount
   b += (size_t)h.n_ids * 8;                                // part_rows
   b += align8((size_t)h.n_ids * h.dim * 4) + 16;           // part_vals (16-byte aligned)
+  if (h.grad_rows == nullptr) {                            // step only: scratch for the rows of the
+    b += (size_t)h.n_ids * 8;                              // few jobs that must emit (several
+    b += align8((size_t)h.n_ids * h.dim * 4) + 16;         // chunks, split buckets)
+  }
   return b;
 }
 
@@ -1381,8 +1400,12 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
                 "group_lookup_bwd: column %d: n_segments must equal n_ids when row_splits "
                 "is NULL", c);
     HBK_REQUIRE(h.n_unique != nullptr, "group_lookup_bwd: column %d: n_unique is NULL", c);
-    HBK_REQUIRE(h.n_ids == 0 || (h.ids && h.grad_out && h.unique_rows && h.grad_rows),
-                "group_lookup_bwd: column %d: NULL buffer", c);
+    HBK_REQUIRE(h.n_ids == 0 || (h.ids && h.grad_out), "group_lookup_bwd: column %d: NULL buffer", c);
+    HBK_REQUIRE(h.n_ids == 0 || (h.unique_rows != nullptr) == (h.grad_rows != nullptr),
+                "group_lookup_bwd: column %d: unique_rows and grad_rows go together", c);
+    HBK_REQUIRE(h.n_ids == 0 || h.grad_rows != nullptr || apply_lr != 0.0f,
+                "group_lookup_bwd: column %d: no output buffers and no optimizer step: nothing "
+                "to do (unique_rows / grad_rows may only be NULL with apply_lr != 0)", c);
     HBK_REQUIRE(apply_lr == 0.0f || h.table != nullptr || h.n_ids == 0,
                 "group_lookup_bwd: column %d: table is NULL but apply_lr != 0", c);
     HBK_REQUIRE(apply_lr == 0.0f || apply != HBK_APPLY_ADAGRAD || h.accum != nullptr ||
@@ -1466,6 +1489,15 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       wp += (size_t)h.n_ids * 8;
       d.part_vals = reinterpret_cast<float*>(((uintptr_t)wp + 15) & ~(uintptr_t)15);
       wp += align8((size_t)h.n_ids * h.dim * 4) + 16;
+      d.no_emit = 0;
+      d.pad2_ = 0;
+      if (h.grad_rows == nullptr) {
+        d.no_emit = 1;
+        d.unique_rows = reinterpret_cast<int64_t*>(wp);
+        wp += (size_t)h.n_ids * 8;
+        d.grad_rows = reinterpret_cast<float*>(((uintptr_t)wp + 15) & ~(uintptr_t)15);
+        wp += align8((size_t)h.n_ids * h.dim * 4) + 16;
+      }
       d.split_t = p.split_t;
       d.e_max = p.e_max;
       d.merge0 = (int32_t)merges;

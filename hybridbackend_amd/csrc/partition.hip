@@ -16,12 +16,22 @@
 //                       running counter gives the base; chunks are taken in order, so
 //                       input order is preserved inside every shard
 //
+// P <= 8 and columns of <= 256 tiles (the single-node step: 26 x 65536 ids over 8 ranks) take
+// ONE launch instead of the three: a wave keeps its 1024 ids and their ranks inside the tile in
+// registers, publishes the tile's counts, waits for the other tiles of its column to publish
+// theirs (every wave of a column is resident: see partition_onepass_kernel), derives its bases
+// from all of them and scatters from registers -- the ids are read once.
+//
 // Column descriptors travel in the kernel-argument segment: no pinned pointer tables and
 // no H2D copies per call (cu.cc:283-306).  `%` never reaches the 64-bit software divide:
 // shards come from a multiply-high with a host-computed magic (common.h).
 #include <stdlib.h>
+#include <string.h>
 
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -62,8 +72,9 @@ struct PartArgs {
   int32_t* hist;  // [sum over columns of P * tiles_c]; column c starts at P * tile_start[c]
   int32_t* sizes_t;      // optional [P][n_total_cols] transposed copy of the sizes
   int32_t n_total_cols;
-  int32_t pad_;
+  int32_t uniform_tiles;  // > 0: every column of the launch has this many tiles (col = tile / it)
   ShardFn fn;
+  int32_t tile0[kMaxColsPerLaunch];   // first tile of every column, packed (find_col reads 4 lines)
   PartCol col[kMaxColsPerLaunch];
 };
 static_assert(sizeof(PartArgs) <= 16384, "kernarg budget");
@@ -102,10 +113,11 @@ __device__ inline int find_col(const PartArgs& a, int tile) {
   // every lane reads one descriptor's first tile (two independent loads cover 128 columns) and a
   // ballot counts those <= tile: one memory round trip instead of a binary search's 7 dependent
   // scalar loads, each a cold miss at the start of these short kernels
+  if (a.uniform_tiles > 0) return tile / a.uniform_tiles;   // no memory round trip at all
   const int lane = lane_id();
   const int n = a.n_cols;
-  const int t0 = lane < n ? a.col[lane].tile_start : 0x7fffffff;
-  const int t1 = lane + kWave < n ? a.col[lane + kWave].tile_start : 0x7fffffff;
+  const int t0 = lane < n ? a.tile0[lane] : 0x7fffffff;
+  const int t1 = lane + kWave < n ? a.tile0[lane + kWave] : 0x7fffffff;
   const int ci = (int)__builtin_popcountll(__ballot(t0 <= tile)) +
                  (int)__builtin_popcountll(__ballot(t1 <= tile)) - 1;
   return __builtin_amdgcn_readfirstlane(ci);
@@ -186,6 +198,65 @@ __device__ inline int32_t place(uint32_t shard, int P, int lane, int32_t& my_run
   return pos;
 }
 
+// Rank of a lane's id among the ids of its shard, P <= 8, from one ballot per BIT of the shard
+// (<= 3) instead of one per shard: the lane builds the mask of its shard's lanes from the bit
+// ballots taken plain or inverted; the counts of the chunks before live in four uniform words of
+// two 16-bit fields each (scalar registers, advanced with scalar popcounts of the eight
+// shard masks), so the vector unit sees ~25 instructions per chunk and no VALU -> SALU -> VALU
+// round trip sits on its critical path.  (The one-ballot-per-shard form above measured 8.3 us of
+// a wave's 16 us in the one-pass kernel.)
+struct Run8 {
+  uint32_t w[4];   // w[s >> 1] >> 16 (s & 1): ids of shard s in the chunks so far
+};
+
+__device__ inline int32_t place_bits(uint32_t shard, bool valid, Run8& run) {
+  const unsigned long long all = __ballot(valid);
+  const unsigned long long b0 = __ballot(valid && (shard & 1u) != 0);
+  const unsigned long long b1 = __ballot(valid && (shard & 2u) != 0);
+  const unsigned long long b2 = __ballot(valid && (shard & 4u) != 0);
+  // lanes of my shard = lanes whose three bits all equal mine: per 32-bit half,
+  // all & ~((b0 ^ m0) | (b1 ^ m1) | (b2 ^ m2)) with m_i = bit i of my shard spread over the word
+  const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)shard, 0, 1);
+  const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)shard, 1, 1);
+  const uint32_t m2 = (uint32_t)__builtin_amdgcn_sbfe((int)shard, 2, 1);
+  const uint32_t lo = (uint32_t)all & ~(((uint32_t)b0 ^ m0) | ((uint32_t)b1 ^ m1) | ((uint32_t)b2 ^ m2));
+  const uint32_t hi = (uint32_t)(all >> 32) &
+                      ~(((uint32_t)(b0 >> 32) ^ m0) | ((uint32_t)(b1 >> 32) ^ m1) | ((uint32_t)(b2 >> 32) ^ m2));
+  const int32_t below = (int32_t)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+  uint32_t w = (shard & 2u) ? run.w[1] : run.w[0];
+  w = (shard & 4u) ? ((shard & 2u) ? run.w[3] : run.w[2]) : w;
+  const int32_t before = (int32_t)((w >> ((shard & 1u) * 16u)) & 0xffffu);
+  // advance the uniform counts: popcounts of the shard masks (all scalar)
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const unsigned long long m = all & ((h & 1) ? b1 : ~b1) & ((h & 2) ? b2 : ~b2);
+    run.w[h] += (uint32_t)__builtin_popcountll(m & ~b0) |
+                ((uint32_t)__builtin_popcountll(m & b0) << 16);
+  }
+  return before + below;
+}
+
+// the counts alone (histogram kernel): four ballots and scalar popcounts per chunk
+__device__ inline void count_bits(uint32_t shard, bool valid, Run8& run) {
+  const unsigned long long all = __ballot(valid);
+  const unsigned long long b0 = __ballot(valid && (shard & 1u) != 0);
+  const unsigned long long b1 = __ballot(valid && (shard & 2u) != 0);
+  const unsigned long long b2 = __ballot(valid && (shard & 4u) != 0);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const unsigned long long m = all & ((h & 1) ? b1 : ~b1) & ((h & 2) ? b2 : ~b2);
+    run.w[h] += (uint32_t)__builtin_popcountll(m & ~b0) |
+                ((uint32_t)__builtin_popcountll(m & b0) << 16);
+  }
+}
+
+// lane p's view of the uniform counts: the count of shard p (lanes >= 8: 0)
+__device__ inline int32_t run_of_lane(const Run8& run, int lane) {
+  uint32_t w = (lane & 2) ? run.w[1] : run.w[0];
+  w = (lane & 4) ? ((lane & 2) ? run.w[3] : run.w[2]) : w;
+  return lane < 8 ? (int32_t)((w >> ((lane & 1) * 16)) & 0xffffu) : 0;
+}
+
 // 8 < P <= 64: the lanes holding the same shard are found from one ballot per BIT of the shard
 // (<= 6) instead of one loop iteration per distinct shard in the chunk (up to 64, each waiting
 // for the previous one): every lane ANDs the ballots, taken plain or inverted by its own bits,
@@ -216,10 +287,17 @@ __device__ inline void shard_masks_n(uint32_t shard, int nbits, int lane, unsign
 }
 
 // ---- A: per-tile histogram ------------------------------------------------------
+// (hist and scatter: kTileWaves independent waves per workgroup while the counters fit registers,
+// P <= 64 -- the dispatcher starts ~300 workgroups per us whatever their size, and 26 x 1 M ids
+// are 26 624 tiles; one wave per workgroup when the counters need LDS)
+constexpr int kTileWaves = 4;
+
 template <typename T>
-__global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a) {
+__global__ __launch_bounds__(kTileWaves* kWave) void partition_hist_kernel(const PartArgs a) {
   extern __shared__ int32_t counters[];
-  const int tile = (int)blockIdx.x;
+  const int tile = (int)blockIdx.x * (int)(blockDim.x >> 6) +
+                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (tile >= a.total_tiles) return;
   const int ci = find_col(a, tile);
   const PartCol& c = a.col[ci];
   const int P = a.fn.num_partitions;
@@ -238,6 +316,9 @@ __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a)
   while ((1 << nbits) < P) ++nbits;
   const int fixed_max = a.fixed_max;
   int32_t cnt = 0;  // P <= 64: lane p counts the ids of shard p in this tile
+  Run8 run8;        // P <= 8: the counts as uniform words
+  run8.w[0] = run8.w[1] = run8.w[2] = run8.w[3] = 0u;
+  const bool bits8 = P <= 8;
   if (!small_p) {
     for (int p = lane; p < P; p += kWave) counters[p] = 0;
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): zeroing done before the atomics
@@ -256,7 +337,9 @@ __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a)
       const int64_t i = base + k * kWave + lane;
       const uint32_t shard =
           i < len ? shard_of<T>(bucketize<T>(v[k], bk), fn) : 0xffffffffu;
-      if (P <= fixed_max) {
+      if (bits8) {
+        count_bits(shard, i < len, run8);
+      } else if (P <= fixed_max) {
         cnt += count_shards(shard, P, lane);
       } else if (small_p) {
         unsigned long long mine, for_lane;
@@ -268,6 +351,7 @@ __global__ __launch_bounds__(kWave) void partition_hist_kernel(const PartArgs a)
     }
   }
   int32_t* hist = a.hist + (int64_t)P * c.tile_start;
+  if (bits8) cnt = run_of_lane(run8, lane);
   if (small_p) {
     if (lane < P) hist[(int64_t)lane * n_tiles + ctile] = cnt;
     return;
@@ -343,10 +427,12 @@ __global__ __launch_bounds__(kScanBlock) void partition_scan_kernel(const PartAr
 
 // ---- C: stable scatter --------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs a) {
+__global__ __launch_bounds__(kTileWaves* kWave) void partition_scatter_kernel(const PartArgs a) {
   extern __shared__ int32_t run_lds[];
   volatile int32_t* run = run_lds;  // cross-lane hand-off inside one wave: keep every access
-  const int tile = (int)blockIdx.x;
+  const int tile = (int)blockIdx.x * (int)(blockDim.x >> 6) +
+                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (tile >= a.total_tiles) return;
   const int ci = find_col(a, tile);
   const PartCol& c = a.col[ci];
   const int P = a.fn.num_partitions;
@@ -364,6 +450,8 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
   // running position of every shard: lane p's register for P <= 64, LDS beyond; it carries over
   // the 1024-id passes of the tile, which are taken in order (stability)
   int32_t my_run = 0;
+  Run8 run8;   // P <= 8: ids of every shard in the chunks of this tile so far (uniform)
+  run8.w[0] = run8.w[1] = run8.w[2] = run8.w[3] = 0u;
   int nbits = 1;
   while ((1 << nbits) < P) ++nbits;
   const int fixed_max = a.fixed_max;
@@ -382,8 +470,21 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
       const int64_t i = base + k * kWave + lane;
       v[k] = i < len ? bucketize<T>(in[i], bk) : T(0);
     }
-    if (P <= fixed_max) {
-      // the single-node case: one ballot per shard, all compares of a chunk independent
+    if (P <= 8) {
+      // the single-node case: one ballot per bit of the shard, counts in scalar registers
+#pragma unroll
+      for (int k = 0; k < kChunks; ++k) {
+        const int64_t i = base + k * kWave + lane;
+        const bool valid = i < len;
+        const uint32_t shard = valid ? shard_of<T>(v[k], fn) : 0u;
+        const int32_t pos = __shfl(my_run, (int)shard, kWave) + place_bits(shard, valid, run8);
+        if (valid) {
+          out[pos] = v[k];
+          indices[i] = pos;
+        }
+      }
+    } else if (P <= fixed_max) {
+      // one ballot per shard, all compares of a chunk independent
 #pragma unroll
       for (int k = 0; k < kChunks; ++k) {
         const int64_t i = base + k * kWave + lane;
@@ -438,20 +539,251 @@ __global__ __launch_bounds__(kWave) void partition_scatter_kernel(const PartArgs
   }
 }
 
+
+// ---- A+B+C in one launch (P <= 8, <= kOneMaxTiles tiles per column) ----------------------------
+// Every wave publishes hist[p][tile] = count + 1 (0 = not there yet; the words are zero when the
+// kernel starts) and polls the words of ITS COLUMN until all are there: lane t reads tile t's
+// word of every shard, the totals and the prefix over the earlier tiles are two sums per shard.
+// A wave waits for tiles launched AFTER it, so those must find a slot while it spins: workgroups
+// are dispatched in index order, hence when the dispatcher is stalled all resident waves of this
+// kernel belong to the one column that is not fully dispatched -- at most kOneMaxTiles of the
+// ~5000 one-wave slots of the chip (8 such kernels side by side still fit).  The wait is bounded
+// all the same: after kOneWaitTicks of the 100 MHz clock a wave raises *status (host memory),
+// skips its stores, and the next entry call reports HBK_INTERNAL instead of the box hanging.
+// Probe builds only (-DHBK_PART_STAMPS, tools/Makefile): constant-clock stamps of the one-pass
+// kernel's waves, read back by hbk_debug_part_trace().
+#ifdef HBK_PART_STAMPS
+constexpr int kPTraceBlocks = 8192, kPTraceSlots = 8;
+__device__ unsigned long long g_part_trace[kPTraceBlocks * kPTraceSlots];
+#define HBK_PSTAMP(i)                                                                          \
+  do {                                                                                         \
+    const unsigned tr_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                  \
+    if ((threadIdx.x & 63) == 0 && tr_ < kPTraceBlocks) {                                      \
+      g_part_trace[tr_ * kPTraceSlots + (i)] = __builtin_amdgcn_s_memrealtime();               \
+    }                                                                                          \
+  } while (0)
+#else
+#define HBK_PSTAMP(i)
+#endif
+constexpr int kOneMaxTiles = 256;
+constexpr int kOneMaxP = 8;
+constexpr unsigned long long kOneWaitTicks = 20000000ull;   // 200 ms
+
+struct OnePass {
+  int32_t* zero;        // words the call before this one left set (the other half), or NULL
+  int64_t zero_words;
+  int32_t* status;      // host-visible, raised on a timed-out wait
+};
+
+constexpr int kOneWaves = 4;   // waves per workgroup, each on a tile of its own (nothing shared:
+                               // the dispatcher starts ~350 workgroups per us whatever their size)
+
+// one wave: its LDS instructions run in order; keep the compiler from moving them across
+__device__ inline void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <typename T>
+__global__ __launch_bounds__(kOneWaves* kWave) void partition_onepass_kernel(const PartArgs a,
+                                                                             const OnePass o) {
+  __shared__ int32_t xs_all[kOneWaves][kOneMaxP * kWave];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int32_t* xs = xs_all[wave];
+  const int tile = (int)blockIdx.x * kOneWaves + wave;
+  const int lane = lane_id();
+  HBK_PSTAMP(0);
+  if (tile >= a.total_tiles) return;
+  for (int64_t j = (int64_t)tile * kWave + lane; j < o.zero_words; j += (int64_t)a.total_tiles * kWave) {
+    o.zero[j] = 0;
+  }
+  const int ci = find_col(a, tile);
+  const PartCol& c = a.col[ci];
+  const int P = a.fn.num_partitions;
+  const int ctile = tile - c.tile_start;
+  const int n_tiles = (c.len + kTile - 1) / kTile;
+  const T* in = reinterpret_cast<const T*>(c.in);
+  const int64_t len = c.len;
+  const ShardFn fn = a.fn;
+  const FastDiv bk = c.bucket;
+  int32_t* hist = a.hist + (int64_t)P * c.tile_start;
+  const int64_t base = (int64_t)ctile * kTile;
+
+  T v[kChunks];
+#pragma unroll
+  for (int k = 0; k < kChunks; ++k) {
+    const int64_t i = base + k * kWave + lane;
+    v[k] = i < len ? in[i] : T(0);
+  }
+  if (tile == 0) {
+    // columns without ids have no tile: their sizes are written here
+    for (int e = 0; e < a.n_cols; ++e) {
+      const PartCol& z = a.col[e];
+      if (z.len == 0 && lane < P) {
+        z.sizes[lane] = 0;
+        if (a.sizes_t != nullptr) a.sizes_t[(int64_t)lane * a.n_total_cols + z.global_col] = 0;
+      }
+    }
+  }
+  HBK_PSTAMP(1);   // descriptor known, loads issued
+#ifdef HBK_PART_STAMPS
+  __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0)
+#endif
+  HBK_PSTAMP(2);   // ids here
+  // rank of every id among the ids of its shard inside the tile; lane p counts shard p
+  int32_t pk[kChunks];
+  // (1) shards: the single-node case -- plain modulo by a power of two, nothing to bucketize --
+  // is a mask; the general case takes the multiply-high forms
+  if (fn.stage == 0 && fn.part.kind == 1 && bk.d == 0) {
+    const uint32_t mask = (uint32_t)fn.part.d - 1u;
+#pragma unroll
+    for (int k = 0; k < kChunks; ++k) pk[k] = (int32_t)((uint32_t)v[k] & mask);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kChunks; ++k) {
+      v[k] = bucketize<T>(v[k], bk);
+      pk[k] = (int32_t)shard_of<T>(v[k], fn);
+    }
+  }
+  // (2) ranks inside the tile
+  Run8 run;
+  run.w[0] = run.w[1] = run.w[2] = run.w[3] = 0u;
+#pragma unroll
+  for (int k = 0; k < kChunks; ++k) {
+    const bool valid = base + k * kWave + lane < len;
+    const uint32_t shard = valid ? (uint32_t)pk[k] : 0u;
+    const int32_t r = place_bits(shard, valid, run);
+    pk[k] = valid ? (r | (int32_t)(shard << 16)) : -1;
+  }
+  // lane p holds the tile's count of shard p
+  const int32_t my_run = run_of_lane(run, lane);
+  HBK_PSTAMP(3);   // ranks done
+  if (lane < P) {
+    __hip_atomic_store(hist + (int64_t)lane * n_tiles + ctile, my_run + 1, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // wait for the column, 64 tiles at a time: lane p ends with the total of shard p and its count
+  // in the tiles before this one
+  int32_t tot = 0, pre = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  for (int g0 = 0; g0 < n_tiles; g0 += kWave) {
+    const int t = g0 + lane;
+    int32_t x[kOneMaxP];
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int p = 0; p < kOneMaxP; ++p) {
+        x[p] = 1;
+        if (p < P && t < n_tiles) {
+          x[p] = __hip_atomic_load(hist + (int64_t)p * n_tiles + t, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ok = ok && x[p] != 0;
+      }
+      if (__ballot(!ok) == 0ull) break;
+      if (__builtin_amdgcn_s_memrealtime() - t_begin > kOneWaitTicks) {
+        if (lane == 0) {
+          __hip_atomic_store(o.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    wave_sync();
+#pragma unroll
+    for (int p = 0; p < kOneMaxP; ++p) xs[p * kWave + lane] = x[p] - 1;
+    wave_sync();
+    // lane (p, j) = 8 p + j adds tiles 8 j .. 8 j + 7 of shard p, three butterfly steps finish
+    const int sp = lane >> 3, sj = lane & 7;
+    int32_t s = 0, q = 0;
+#pragma unroll
+    for (int i2 = 0; i2 < 8; ++i2) {
+      const int tt = sj * 8 + i2;
+      const int32_t y = xs[sp * kWave + tt];
+      s += y;
+      q += g0 + tt < ctile ? y : 0;
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+      s += __shfl_xor(s, off, kWave);
+      q += __shfl_xor(q, off, kWave);
+    }
+    const int32_t s_p = __shfl(s, (lane & 7) * 8, kWave);
+    const int32_t q_p = __shfl(q, (lane & 7) * 8, kWave);
+    if (lane < kOneMaxP) {
+      tot += s_p;
+      pre += q_p;
+    }
+  }
+  HBK_PSTAMP(4);   // the column's counts are in
+  // start of shard p = total of the shards below it
+  int32_t inc = tot;
+#pragma unroll
+  for (int off = 1; off < kOneMaxP; off <<= 1) {
+    const int32_t y = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += y;
+  }
+  const int32_t my_base = inc - tot + pre;
+  if (ctile == 0 && lane < P) {
+    c.sizes[lane] = tot;
+    if (a.sizes_t != nullptr) a.sizes_t[(int64_t)lane * a.n_total_cols + c.global_col] = tot;
+  }
+  T* out = reinterpret_cast<T*>(c.out);
+  int32_t* indices = c.indices;
+#pragma unroll
+  for (int k = 0; k < kChunks; ++k) {
+    const int64_t i = base + k * kWave + lane;
+    const bool valid = pk[k] >= 0;
+    const int32_t pos = __shfl(my_base, valid ? pk[k] >> 16 : 0, kWave) + (pk[k] & 0xffff);
+    if (valid) {
+      out[pos] = v[k];
+      indices[i] = pos;
+    }
+  }
+  HBK_PSTAMP(5);   // stores issued
+#ifdef HBK_PART_STAMPS
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  HBK_PSTAMP(6);   // stores done
+  HBK_PSTAMP(7);
+#endif
+}
+
+// host-visible word the one-pass kernel raises when a wait runs out (one per process)
+int32_t* onepass_status() {
+  static int32_t* word = [] {
+    void* q = nullptr;
+    if (hipHostMalloc(&q, 64, hipHostMallocDefault) != hipSuccess) return (int32_t*)nullptr;
+    memset(q, 0, 64);
+    return reinterpret_cast<int32_t*>(q);
+  }();
+  return word;
+}
+
+template <typename T>
+int launch_onepass(const PartArgs& args, const OnePass& o, hipStream_t stream) {
+  hipLaunchKernelGGL(partition_onepass_kernel<T>,
+                     dim3((unsigned)((args.total_tiles + kOneWaves - 1) / kOneWaves)),
+                     dim3(kOneWaves * kWave), 0, stream, args, o);
+  HBK_HIP_OK(hipGetLastError());
+  return HBK_OK;
+}
+
 template <typename T>
 int launch_group(const PartArgs& args, int P, hipStream_t stream) {
-  const size_t lds = (size_t)P * sizeof(int32_t);
+  const size_t lds = P > kWave ? (size_t)P * sizeof(int32_t) : 0;
+  const int wpb = P > kWave ? 1 : kTileWaves;   // LDS counters belong to one wave
+  const unsigned blocks = (unsigned)((args.total_tiles + wpb - 1) / wpb);
   if (args.total_tiles > 0) {
-    hipLaunchKernelGGL(partition_hist_kernel<T>, dim3((unsigned)args.total_tiles),
-                       dim3(kWave), lds, stream, args);
+    hipLaunchKernelGGL(partition_hist_kernel<T>, dim3(blocks), dim3(wpb * kWave), lds, stream, args);
     HBK_HIP_OK(hipGetLastError());
   }
   hipLaunchKernelGGL(partition_scan_kernel, dim3((unsigned)args.n_cols), dim3(kScanBlock), 0,
                      stream, args);
   HBK_HIP_OK(hipGetLastError());
   if (args.total_tiles > 0) {
-    hipLaunchKernelGGL(partition_scatter_kernel<T>, dim3((unsigned)args.total_tiles),
-                       dim3(kWave), lds, stream, args);
+    hipLaunchKernelGGL(partition_scatter_kernel<T>, dim3(blocks), dim3(wpb * kWave), lds, stream,
+                       args);
     HBK_HIP_OK(hipGetLastError());
   }
   return HBK_OK;
@@ -467,6 +799,40 @@ int sub_tiles_of(int32_t n_cols, const int64_t* lens) {
   if (options().partition_sub_tiles >= 1) sub = options().partition_sub_tiles;
   return sub > 8 ? 8 : (int)sub;
 }
+
+// The words the one-pass kernel polls must read zero when it starts.  They live in buffers of the
+// library, one per (device, stream): launches on one stream are ordered, so a call takes one half
+// of its stream's buffer and clears what the call before it left in the other -- no launch is
+// spent on a memset.  (Buffers are a few hundred KB and are kept for the life of the process; a
+// buffer that has become too small is replaced and the old one kept, work on the stream may still
+// be reading it.)
+struct SyncSlot {
+  int32_t* buf = nullptr;
+  size_t half_words = 0;
+  int half = 0;                    // half the next call uses
+  size_t dirty_words[2] = {0, 0};  // words a call has left set
+};
+
+SyncSlot* sync_slot(hipStream_t stream, size_t words) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SyncSlot> slots;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  SyncSlot& s = slots[std::make_pair(dev, stream)];
+  if (s.half_words < words) {
+    const size_t half = (words + words / 2 + 16384 + 63) / 64 * 64;
+    void* q = nullptr;
+    if (hipMalloc(&q, 2 * half * sizeof(int32_t)) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(q, 0, 2 * half * sizeof(int32_t), stream) != hipSuccess) return nullptr;
+    s.buf = reinterpret_cast<int32_t*>(q);
+    s.half_words = half;
+    s.half = 0;
+    s.dirty_words[0] = s.dirty_words[1] = 0;
+  }
+  return &s;
+}
+
 
 int64_t tiles_of(int64_t len, int sub) {
   const int64_t tile_ids = (int64_t)kTile * sub;
@@ -506,6 +872,13 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
                 "%s: NULL buffer for input %d", what, c);
   }
 
+  if (int32_t* st = onepass_status()) {
+    if (*reinterpret_cast<volatile int32_t*>(st) != 0) {
+      return fail(HBK_INTERNAL,
+                  "%s: an earlier one-pass partition launch gave up waiting for the tiles of its "
+                  "column (its outputs are not valid); set option partition_onepass = 0", what);
+    }
+  }
   ShardFn fn;
   fn.stage = stage;
   fn.num_partitions = P;
@@ -515,6 +888,39 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
 
   int32_t* hist = reinterpret_cast<int32_t*>(workspace);
   const int sub = sub_tiles_of(n_cols, lens);
+  // one launch when every column fits the one-pass kernel (see there); its words must read zero
+  int64_t all_tiles = 0;
+  bool onepass = options().partition_onepass != 0 && sub == 1 && P <= kOneMaxP &&
+                 P <= options().partition_fixed_max && onepass_status() != nullptr;
+  for (int32_t c = 0; c < n_cols; ++c) {
+    const int64_t t = tiles_of(lens[c], sub);
+    onepass = onepass && t <= kOneMaxTiles;
+    all_tiles += t;
+  }
+  onepass = onepass && all_tiles > 0;
+  OnePass one;
+  one.zero = nullptr;
+  one.zero_words = 0;
+  one.status = onepass_status();
+  if (onepass) {
+    const size_t words = (size_t)all_tiles * (size_t)P;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &capturing);
+    SyncSlot* slot = capturing == hipStreamCaptureStatusNone ? sync_slot(stream, words) : nullptr;
+    if (slot == nullptr) {
+      // (a graph replays the same launch: no state may alternate between calls) the caller's
+      // workspace, cleared by one memset node in front of the kernel
+      HBK_HIP_OK(hipMemsetAsync(hist, 0, words * sizeof(int32_t), stream));
+    } else {
+      const int h = slot->half;
+      hist = slot->buf + (size_t)h * slot->half_words;
+      one.zero = slot->buf + (size_t)(1 - h) * slot->half_words;
+      one.zero_words = (int64_t)slot->dirty_words[1 - h];
+      slot->dirty_words[h] = words;
+      slot->dirty_words[1 - h] = 0;
+      slot->half = 1 - h;
+    }
+  }
   int32_t c0 = 0;
   while (c0 < n_cols) {
     PartArgs args;
@@ -522,7 +928,7 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
     args.hist = hist;
     args.sizes_t = sizes_t;
     args.n_total_cols = n_cols;
-    args.pad_ = 0;
+    args.uniform_tiles = 0;
     args.fixed_max = options().partition_fixed_max;
     args.sub_tiles = sub;
     int32_t k = 0;
@@ -539,6 +945,12 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
       d.global_col = c0;
       d.pad_ = 0;
       d.tile_start = (int32_t)tiles;
+      args.tile0[k] = (int32_t)tiles;
+      {
+        const int64_t t = tiles_of(lens[c0], sub);
+        if (k == 0) args.uniform_tiles = (int32_t)t;
+        if (t != args.uniform_tiles) args.uniform_tiles = 0;
+      }
       tiles += tiles_of(lens[c0], sub);
       HBK_REQUIRE(tiles < (1ll << 31), "%s: too many tiles", what);
       ++k;
@@ -547,11 +959,21 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
     args.n_cols = k;
     args.total_tiles = (int32_t)tiles;
     int rc;
-    switch (dtype) {
-      case HBK_INT32: rc = launch_group<int32_t>(args, P, stream); break;
-      case HBK_INT64: rc = launch_group<int64_t>(args, P, stream); break;
-      case HBK_UINT32: rc = launch_group<uint32_t>(args, P, stream); break;
-      default: rc = launch_group<uint64_t>(args, P, stream); break;
+    if (onepass && tiles > 0) {
+      switch (dtype) {
+        case HBK_INT32: rc = launch_onepass<int32_t>(args, one, stream); break;
+        case HBK_INT64: rc = launch_onepass<int64_t>(args, one, stream); break;
+        case HBK_UINT32: rc = launch_onepass<uint32_t>(args, one, stream); break;
+        default: rc = launch_onepass<uint64_t>(args, one, stream); break;
+      }
+      one.zero_words = 0;   // the first launch of the call clears the other half
+    } else {
+      switch (dtype) {
+        case HBK_INT32: rc = launch_group<int32_t>(args, P, stream); break;
+        case HBK_INT64: rc = launch_group<int64_t>(args, P, stream); break;
+        case HBK_UINT32: rc = launch_group<uint32_t>(args, P, stream); break;
+        default: rc = launch_group<uint64_t>(args, P, stream); break;
+      }
     }
     if (rc != HBK_OK) return rc;
     hist += tiles * P;
@@ -618,3 +1040,18 @@ extern "C" int hbk_partition_by_dual_modulo_n(int32_t n_cols, int32_t dtype,
                              modulus, stage, inputs, lens, outputs, sizes, indices, workspace,
                              workspace_bytes, hbk::as_stream(stream));
 }
+
+#ifdef HBK_PART_STAMPS
+extern "C" int hbk_debug_part_trace(unsigned long long* out, int reset) {
+  using namespace hbk;
+  HBK_HIP_OK(hipDeviceSynchronize());
+  if (out != nullptr) {
+    HBK_HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_part_trace), sizeof(g_part_trace)));
+  }
+  if (reset) {
+    static unsigned long long z[kPTraceBlocks * kPTraceSlots];
+    HBK_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_part_trace), z, sizeof(z)));
+  }
+  return HBK_OK;
+}
+#endif

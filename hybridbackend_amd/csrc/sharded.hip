@@ -835,8 +835,11 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
   using namespace hbk;
   HBK_REQUIRE(p != nullptr, "sharded_lookup_bwd: plan is NULL");
   HBK_REQUIRE(p->have_step, "sharded_lookup_bwd: no forward step to differentiate");
-  HBK_REQUIRE(grads && unique_rows && grad_rows && n_unique,
-              "sharded_lookup_bwd: NULL argument array");
+  HBK_REQUIRE(grads && n_unique, "sharded_lookup_bwd: NULL argument array");
+  HBK_REQUIRE((unique_rows != nullptr) == (grad_rows != nullptr),
+              "sharded_lookup_bwd: unique_rows and grad_rows go together");
+  HBK_REQUIRE(unique_rows != nullptr || apply_lr != 0.0f,
+              "sharded_lookup_bwd: no output buffers and no optimizer step: nothing to do");
   hipStream_t stream = as_stream(stream_);
   const int N = p->N, W = p->W;
   const int32_t* R = p->recv_sizes.data();
@@ -907,8 +910,8 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
     h.divisor = W;
     h.combiner = HBK_COMBINER_SUM;
     h.grad_out = rows_send_base;
-    h.unique_rows = unique_rows[c];
-    h.grad_rows = grad_rows[c];
+    h.unique_rows = unique_rows != nullptr ? unique_rows[c] : nullptr;   // NULL: step only
+    h.grad_rows = grad_rows != nullptr ? grad_rows[c] : nullptr;
     h.n_unique = n_unique[c];
     h.run_start = d_ostart + (size_t)c * W;
     h.run_ids = d_oids + (size_t)c * W;

@@ -170,17 +170,26 @@ class GroupLookupGrad:
       col.combiner = lookup.combiners[c]
     self._ws = None
 
-  def __call__(self, ids, grads, row_splits=None, apply_lr=0.0, optimizer='sgd'):
+  def __call__(self, ids, grads, row_splits=None, apply_lr=0.0, optimizer='sgd', emit=True):
     """Returns per column ``(unique_rows int64[n_ids], grad_rows f32[n_ids, dim],
     n_unique int32[1])``; only the first ``n_unique`` rows are meaningful, in unspecified
     order (device-side count: no host sync here).  The result buffers belong to this object
-    and are reused by the next call with the same id counts."""
+    and are reused by the next call with the same id counts.  ``emit=False`` (with ``apply_lr``):
+    step only -- the rows are stepped, no IndexedSlices are written; only ``n_unique`` of each
+    returned triple is meaningful."""
+    if not emit and apply_lr == 0.0:
+      raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, 'emit=False needs apply_lr != 0')
     n = len(self.lookup)
     if row_splits is None:
       row_splits = [None] * n
     dev = self.lookup.tables[0].device if n else None
     dims = [int(t.shape[1]) for t in self.lookup.tables]
-    counts = tuple(int(i.numel()) for i in ids)
+    counts = tuple(int(i.numel()) for i in ids) if emit else ('step only',)
+    if getattr(self, '_out_key', None) != counts and not emit:
+      self._nu = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+      self._urows = self._grows = None
+      self._views = [(None, None, self._nu[c:c + 1]) for c in range(n)]
+      self._out_key = counts
     if getattr(self, '_out_key', None) != counts:
       # three allocations for all columns, carved into per-column views
       self._urows = torch.empty(sum(counts), dtype=torch.int64, device=dev)
@@ -225,8 +234,8 @@ class GroupLookupGrad:
         raise _lib.InvalidArgumentError(
           _lib.INVALID_ARGUMENT, f'grad {c} must be contiguous along its last dimension')
       col.grad_stride = 0 if g.is_contiguous() else int(g.stride(0))
-      col.unique_rows = urows.data_ptr()
-      col.grad_rows = grows.data_ptr()
+      col.unique_rows = urows.data_ptr() if emit else None
+      col.grad_rows = grows.data_ptr() if emit else None
       col.n_unique = nu.data_ptr()
     need = self._lib.hbk_group_lookup_bwd_workspace_bytes(n, self._cols)
     if self._ws is None or self._ws.numel() < need:

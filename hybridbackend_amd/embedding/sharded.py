@@ -250,13 +250,16 @@ class ShardedGroupLookup:
   def owner_bwd(self, st, recv_grads, apply_lr=0.0):
     return self._owner_grad(st.recv_ids, recv_grads, None, apply_lr=apply_lr)
 
-  def backward(self, grads, apply_lr=0.0, outs=None, optimizer='sgd'):
+  def backward(self, grads, apply_lr=0.0, outs=None, optimizer='sgd', emit=True):
     """Backward of the LAST forward step (hbk_sharded_lookup_bwd).  grads[c]: gradient of
     column c's output [segments, dim].  Returns per column the IndexedSlices of the LOCAL
     shard ``(unique_rows, grad_rows, n_unique)``; with ``apply_lr`` the SGD update is applied
     to the shard in the same pass (sharded variables are not aggregated across ranks,
     training/gradient.py:193-217).  The exchange reuses the forward's sizes reversed
-    (collective.py:334-347): no new size exchange, no host sync."""
+    (collective.py:334-347): no new size exchange, no host sync.  ``emit=False`` (with
+    ``apply_lr``): step only, no IndexedSlices are written (only the ``n_unique`` counts)."""
+    if not emit and apply_lr == 0.0:
+      raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, 'emit=False needs apply_lr != 0')
     n = len(self.shards)
     plan = self._plan()
     if optimizer not in ('sgd', 'adagrad'):
@@ -281,6 +284,9 @@ class ShardedGroupLookup:
             _lib.INVALID_ARGUMENT, f'backward outs[{c}] too small for {k} owned ids')
         res.append(tuple(outs[c]))
         continue
+      if not emit:
+        res.append((None, None, torch.zeros(1, dtype=torch.int32, device=self.device)))
+        continue
       res.append((torch.empty(k, dtype=torch.int64, device=self.device),
                   torch.empty((k, self.dims[c]), dtype=torch.float32, device=self.device),
                   torch.zeros(1, dtype=torch.int32, device=self.device)))
@@ -292,7 +298,7 @@ class ShardedGroupLookup:
     _lib.check(self._lib.hbk_sharded_lookup_bwd_apply(
       plan, _lib.ptr_array([g.data_ptr() for g in grads]), strides,
       _lib.APPLY_ADAGRAD if optimizer == 'adagrad' else _lib.APPLY_SGD, C.c_float(apply_lr),
-      _lib.ptr_array([r[0].data_ptr() for r in res]),
-      _lib.ptr_array([r[1].data_ptr() for r in res]),
+      _lib.ptr_array([r[0].data_ptr() for r in res]) if emit else None,
+      _lib.ptr_array([r[1].data_ptr() for r in res]) if emit else None,
       _lib.ptr_array([r[2].data_ptr() for r in res]), _lib.current_stream(self.device)))
     return res

@@ -124,7 +124,7 @@ class DenseFeatures:
         cols_to_output_tensors[col] = views[c]
     return out
 
-  def backward(self, grad, apply_lr=0.0, optimizer='sgd'):
+  def backward(self, grad, apply_lr=0.0, optimizer='sgd', emit=True):
     """grad: ``[batch, sum of dims]`` gradient of the last forward's output.  Returns per column
     the ``IndexedSlices`` ``(unique_rows, grad_rows, n_unique)`` of this rank's rows (local row
     numbers for sharded tables); with ``apply_lr`` the sparse optimizer step (``'sgd'``, or
@@ -133,7 +133,8 @@ class DenseFeatures:
     their gradients must first be aggregated across ranks (``hb.distribute.aggregate_gradients``,
     hybridbackend/tensorflow/training/gradient.py:119-177) or the replicas diverge, so for them
     this method never applies the step at W > 1: it returns their IndexedSlices and the caller
-    applies the aggregated gradient."""
+    applies the aggregated gradient.  ``emit=False`` (with ``apply_lr``): the stepped tables
+    write no IndexedSlices (step only; their entries are ``(None, None, n_unique)``)."""
     ids, splits = self._last
     if grad.dim() != 2 or grad.shape[1] != self.width or grad.dtype != torch.float32:
       raise _lib.InvalidArgumentError(
@@ -152,11 +153,12 @@ class DenseFeatures:
     if self._rep:
       rep_lr = apply_lr if (self.coll.world_size if self.coll is not None else 1) <= 1 else 0.0
       r = self._grad(pick(self._rep, ids), pick(self._rep, views), pick(self._rep, splits),
-                     apply_lr=rep_lr, optimizer=optimizer)
+                     apply_lr=rep_lr, optimizer=optimizer, emit=emit or rep_lr == 0.0)
       for k, c in enumerate(self._rep):
         res[c] = r[k]
     if self._shd:
-      r = self._sharded.backward(pick(self._shd, views), apply_lr=apply_lr, optimizer=optimizer)
+      r = self._sharded.backward(pick(self._shd, views), apply_lr=apply_lr, optimizer=optimizer,
+                                 emit=emit)
       for k, c in enumerate(self._shd):
         res[c] = r[k]
     return res

@@ -196,7 +196,11 @@ int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
  *   is emitted -- and stepped by the fused optimizer -- exactly once.
  *   apply_lr != 0 additionally performs the sparse SGD update on the shard in the same
  *   pass: table[unique_rows[u],:] -= apply_lr * grad_rows[u,:] (sharded variables skip
- *   cross-rank aggregation, hbtf/training/gradient.py:193-217).                        */
+ *   cross-rank aggregation, hbtf/training/gradient.py:193-217).  With apply_lr != 0 a column
+ *   may pass unique_rows = grad_rows = NULL ("step only"): the rows are stepped where their sums
+ *   sit in registers and no IndexedSlices are written (a third of the traffic, and no output range
+ *   to claim); n_unique still receives the number of distinct rows.  The workspace query must be
+ *   made with the same NULL / non-NULL pointers as the call.                            */
 typedef struct {
   float* table;              /* device [rows, dim]; only touched when apply_lr != 0 */
   int64_t rows;
@@ -452,7 +456,8 @@ int hbk_sharded_lookup_bwd(hbk_sharded_t plan, const float* const* grads,
                            int64_t* const* unique_rows, float* const* grad_rows,
                            int32_t* const* n_unique, hbk_stream_t stream);
 /* the same with the optimizer named (HBK_APPLY_SGD | HBK_APPLY_ADAGRAD, see
- * hbk_group_lookup_bwd_apply); Adagrad uses the columns' `accum` shards */
+ * hbk_group_lookup_bwd_apply); Adagrad uses the columns' `accum` shards.  unique_rows and grad_rows
+ * may both be NULL when apply_lr != 0 (step only: no IndexedSlices are written). */
 int hbk_sharded_lookup_bwd_apply(hbk_sharded_t plan, const float* const* grads,
                                  const int32_t* grad_strides, int32_t apply, float apply_lr,
                                  int64_t* const* unique_rows, float* const* grad_rows,

@@ -52,6 +52,7 @@ def test_partition_argument_checks():
                                           null, None, C.c_size_t(0), None)
   assert rc == _lib.INVALID_ARGUMENT and 'stage' in lib.hbk_last_error().decode()
   assert lib.hbk_partition_workspace_bytes(2, _lib.i64_array([1024, 1025]), 8) == 3 * 8 * 4
+  assert lib.hbk_partition_workspace_bytes(2, _lib.i64_array([0, 0]), 8) == 0
 
 
 def test_host_floormod_matches_python():
@@ -151,6 +152,15 @@ def test_argument_checks_of_every_entry_family():
   assert 'n_segments' in msg()
   assert lib.hbk_group_lookup_bwd_apply(1, gcol, 5, C.c_float(0.1), None, C.c_size_t(0),
                                         None) == bad and 'HBK_APPLY' in msg()
+  # step only (no IndexedSlices buffers) needs a learning rate; the two buffers go together
+  gcol[0].n_segments, gcol[0].rows = 4, 10
+  gcol[0].n_unique = gcol[0].ids = gcol[0].grad_out = 64    # checked for NULL only, never read
+  assert lib.hbk_group_lookup_bwd(1, gcol, C.c_float(0.0), None, C.c_size_t(0), None) == bad
+  assert 'nothing to do' in msg() or 'apply_lr' in msg(), msg()
+  gcol[0].unique_rows = 64
+  assert lib.hbk_group_lookup_bwd(1, gcol, C.c_float(0.1), None, C.c_size_t(0), None) == bad
+  assert 'together' in msg(), msg()
+  gcol[0].unique_rows = None
   # R11
   assert lib.hbk_cache_probe(None, 4, 0, None, 0, None, None, None) == bad
   assert 'cache_slab_size' in msg()

@@ -139,6 +139,36 @@ def test_partition_many_columns_and_large():
       assert bool((seg[1:] > seg[:-1]).all())
 
 
+@pytest.mark.parametrize('onepass', [1, 0])
+def test_partition_one_launch_and_three_launch_paths(hbk_option, onepass):
+  """P <= 8 with columns of <= 256 tiles takes the one-launch kernel (tiles wait for their
+  column's counts), anything else the histogram / scan / scatter launches; both are the
+  reference's stable counting sort, bit for bit.  Repeated calls reuse one workspace."""
+  hbk_option('partition_onepass', onepass)
+  rng = np.random.RandomState(70)
+  for rep in range(3):
+    for P in (1, 2, 3, 7, 8):
+      lens = [0, 1, 1023, 1024, 1025, 65536, 0, 200000, 262144, int(rng.randint(1, 70000))]
+      if rep == 2:
+        lens.append(262145)           # one column too long for one launch: the whole call falls back
+      xs = [rng.randint(-2**40, 2**40, size=n).astype(np.int64) for n in lens]
+      xs[5] = np.full(65536, 5, np.int64)                          # everything in one shard
+      ys, sizes, idxs = hb.distribute.partition_by_modulo_n([dev(x) for x in xs], P)
+      for c, x in enumerate(xs):
+        oy, os_, oi = oracle.partition_by_modulo(x, P)
+        np.testing.assert_equal(host(sizes[c]), os_)
+        np.testing.assert_equal(host(ys[c]), oy)
+        np.testing.assert_equal(host(idxs[c]), oi)
+  x32 = [rng.randint(-2**31, 2**31 - 1, size=n).astype(np.int32) for n in (5000, 70000, 0)]
+  for stage in (1, 2):
+    ys, sizes, idxs = hb.distribute.partition_by_dual_modulo_n([dev(x) for x in x32], 4, 2, stage)
+    for c, x in enumerate(x32):
+      oy, os_, oi = oracle.partition_by_dual_modulo(x, 4, 2, stage)
+      np.testing.assert_equal(host(ys[c]), oy)
+      np.testing.assert_equal(host(sizes[c]), os_)
+      np.testing.assert_equal(host(idxs[c]), oi)
+
+
 # ----------------------------------------------------------------------------------
 # R1 bucketize
 def test_floormod_n():
@@ -577,6 +607,64 @@ def test_group_lookup_backward_fused_sgd_apply():
   ref = table.astype(np.float64)
   np.subtract.at(ref, ids % 5000, 0.05 * grads.astype(np.float64))
   np.testing.assert_allclose(host(t_dev), ref, rtol=RTOL, atol=1e-6)
+
+
+@pytest.mark.parametrize('optimizer', ['sgd', 'adagrad'])
+@pytest.mark.parametrize('hook', [None, 'one_bucket', 'split'])
+def test_group_lookup_backward_step_only(hbk_option, optimizer, hook):
+  """Step only (unique_rows = grad_rows = NULL with a learning rate): no IndexedSlices are
+  written, the shards (and accumulators) end as the emitting call leaves them on the same inputs
+  (which the tests above pin to the oracle) and as float64 from the raw ids says, and n_unique
+  still counts the distinct rows.
+  Jobs that cannot step from registers (rows spanning chunks, split buckets) fall back to
+  scratch rows in the workspace."""
+  if hook == 'one_bucket':
+    hbk_option('bwd_buckets_log2', 0)
+  if hook == 'split':
+    hbk_option('bwd_split_pairs', 96)
+    hbk_option('bwd_buckets_log2', 2)
+  rng = np.random.RandomState(77)
+  shapes = ((16, 5000, 20000), (128, 700, 6000), (6, 90, 3000), (32, 100000, 4000), (16, 50, 0))
+  tables = [rng.uniform(-1, 1, size=(r, d)).astype(np.float32) for d, r, _ in shapes]
+  accums = [np.full(t.shape, 0.1, np.float32) for t in tables]
+  ids = [rng.randint(0, 2**40, size=n).astype(np.int64) for _, _, n in shapes]
+  ids[1] = (rng.zipf(1.3, size=shapes[1][2])).astype(np.int64)     # hot rows
+  grads = [rng.randn(n, d).astype(np.float32) for d, _, n in shapes]
+  rows = [r for _, r, _ in shapes]
+  ends = []
+  for emit in (True, False):
+    t_dev = [dev(t.copy()) for t in tables]
+    a_dev = [dev(a.copy()) for a in accums]
+    lookup = hb.embedding.GroupLookup(t_dev, rows, 'sum')
+    grad = hb.embedding.GroupLookupGrad(lookup, accums=a_dev if optimizer == 'adagrad' else None)
+    res = grad([dev(i) for i in ids], [dev(g) for g in grads], apply_lr=0.05,
+               optimizer=optimizer, emit=emit)
+    ends.append(([host(t) for t in t_dev], [host(a) for a in a_dev],
+                 [int(r[2].item()) for r in res]))
+  for c in range(len(shapes)):
+    local = ids[c] % rows[c]
+    assert ends[1][2][c] == np.unique(local).size == ends[0][2][c]
+    # rows with one id in the batch: the same fp32 operations in both modes, bit for bit; rows
+    # summed from several gradient rows: the order of the LDS float adds is not fixed from run to
+    # run, so two runs of EITHER mode agree to rounding only
+    once = np.bincount(local, minlength=rows[c]) <= 1
+    for got, want in ((ends[1][0][c], ends[0][0][c]), (ends[1][1][c], ends[0][1][c])):
+      np.testing.assert_equal(got[once], want[once])
+      np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+    if optimizer == 'sgd':
+      ref = tables[c].astype(np.float64)
+      np.subtract.at(ref, local, 0.05 * grads[c].astype(np.float64))
+      np.testing.assert_allclose(ends[1][0][c], ref, rtol=RTOL, atol=1e-4)
+    else:
+      g64 = np.zeros(tables[c].shape, np.float64)
+      np.add.at(g64, local, grads[c].astype(np.float64))
+      a64 = accums[c].astype(np.float64) + g64 * g64
+      np.testing.assert_allclose(ends[1][1][c], a64, rtol=1e-4, atol=1e-4)
+      np.testing.assert_allclose(ends[1][0][c],
+                                 tables[c].astype(np.float64) - 0.05 * g64 / np.sqrt(a64),
+                                 rtol=1e-4, atol=1e-4)
+  with pytest.raises(hb.InvalidArgumentError):
+    grad([dev(i) for i in ids], [dev(g) for g in grads], emit=False)
 
 
 # ----------------------------------------------------------------------------------

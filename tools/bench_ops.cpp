@@ -98,6 +98,42 @@ static void bench_partition(const char* what, int n_cols, int64_t len, int P, in
   const double bytes = ids * (3.0 * sizeof(T) + 4);
   printf("%-66s %9.2f us  %8.1f M ids/s  %7.1f GB/s (%.3f of 8 TB/s)\n", what, us, ids / us,
          bytes / us / 1e3, bytes / us / 1e3 / 8000.0);
+  {  // probe build of the library (-DHBK_PART_STAMPS): constant-clock stamps of the one-pass waves
+    typedef int (*trace_fn)(unsigned long long*, int);
+    trace_fn fn = (trace_fn)dlsym(RTLD_DEFAULT, "hbk_debug_part_trace");
+    if (fn != nullptr) {
+      std::vector<unsigned long long> tr(8192 * 8);
+      fn(nullptr, 1);
+      HB(hbk_partition_by_modulo_n(n_cols, dtype, P, in.data(), lens.data(), o.data(), s.data(),
+                                   ix.data(), ws, ws_bytes, nullptr));
+      fn(tr.data(), 0);
+      static const char* names[7] = {"descriptor", "ids arrive", "ranks", "publish + wait",
+                                     "bases + stores issued", "stores land", "-"};
+      double sum[7] = {0}, life = 0;
+      unsigned long long t_min = ~0ull, t_max = 0, first_pub = ~0ull, last_pub = 0, last_start = 0;
+      int nb = 0;
+      for (int b = 0; b < 8192; ++b) {
+        const unsigned long long* t = &tr[(size_t)b * 8];
+        if (t[0] == 0 || t[7] == 0) continue;
+        ++nb;
+        for (int i = 0; i < 7; ++i) sum[i] += (double)(t[i + 1] - t[i]);
+        life += (double)(t[7] - t[0]);
+        t_min = t[0] < t_min ? t[0] : t_min;
+        t_max = t[7] > t_max ? t[7] : t_max;
+        last_start = t[0] > last_start ? t[0] : last_start;
+        first_pub = t[3] < first_pub ? t[3] : first_pub;
+        last_pub = t[3] > last_pub ? t[3] : last_pub;
+      }
+      if (nb > 0) {
+        printf("   one-pass kernel: %d traced waves over %.2f us, mean life %.2f us; last wave starts at "
+               "%.2f us, publishes from %.2f to %.2f us; per phase (us):", nb, (t_max - t_min) * 0.01,
+               life / nb * 0.01, (last_start - t_min) * 0.01, (first_pub - t_min) * 0.01,
+               (last_pub - t_min) * 0.01);
+        for (int i = 0; i < 6; ++i) printf("  %s %.2f", names[i], sum[i] / nb * 0.01);
+        printf("\n");
+      }
+    }
+  }
 }
 
 static void bench_unique(int n_cols, int64_t len, uint64_t mod) {
@@ -130,7 +166,8 @@ static void bench_unique(int n_cols, int64_t len, uint64_t mod) {
   printf("%-66s %9.2f us  %8.1f M ids/s\n", what, us, ids / us);
 }
 
-static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float lr) {
+static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float lr,
+                           bool step_only = false) {
   const int kPool = 4;
   std::vector<int64_t*> pool(kPool);
   for (auto& p : pool) p = dev_random<int64_t>((size_t)n_cols * B, (uint64_t)1 << 40);
@@ -160,8 +197,8 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
       h.divisor = 1;
       h.combiner = HBK_COMBINER_SUM;
       h.grad_out = gout + (size_t)c * B * dim;
-      h.unique_rows = urows + (size_t)c * B;
-      h.grad_rows = grows + (size_t)c * B * dim;
+      h.unique_rows = step_only ? nullptr : urows + (size_t)c * B;
+      h.grad_rows = step_only ? nullptr : grows + (size_t)c * B * dim;
       h.n_unique = nu + c;
     }
   };
@@ -175,7 +212,8 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
   const double n = (double)n_cols * B;
   char what[128];
   snprintf(what, sizeof(what), "group_lookup_bwd %d x %lld ids, dim %d, %lld rows%s", n_cols,
-           (long long)B, dim, (long long)rows, lr != 0.f ? " + SGD apply" : "");
+           (long long)B, dim, (long long)rows,
+           step_only ? ", SGD step only" : lr != 0.f ? " + SGD apply" : "");
   printf("%-66s %9.2f us  %8.1f M lookups/s\n", what, us, n / us);
   {  // probe build of the library (-DHBK_BWD_STAMPS): shader-clock stamps of the reduce workgroups
     typedef int (*trace_fn)(unsigned long long*, int);
@@ -302,6 +340,20 @@ int main(int argc, char** argv) {
     bench_backward(26, 65536, 16, 1000000, 0.f);
     return 0;
   }
+  if (argc > 1 && argv[1][0] == 'p') {  // "part": the single-node partition only
+    bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 8", 26, 65536, 8, HBK_INT64);
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'q') {  // the reference benchmark's shape only
+    bench_partition<int32_t>("partition_by_modulo_n 100 x 100000 int32, P = 8 (reference benchmark)", 100,
+                             100000, 8, HBK_INT32);
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 's') {  // "step": config-2 backward with the step, both modes
+    bench_backward(26, 65536, 16, 1000000, 0.01f);
+    bench_backward(26, 65536, 16, 1000000, 0.01f, true);
+    return 0;
+  }
   bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 8", 26, 65536, 8, HBK_INT64);
   bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 2", 26, 65536, 2, HBK_INT64);
   bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 64", 26, 65536, 64, HBK_INT64);
@@ -312,7 +364,10 @@ int main(int argc, char** argv) {
   bench_unique(26, 65536, 4096);
   bench_backward(26, 65536, 16, 1000000, 0.f);
   bench_backward(26, 65536, 16, 1000000, 0.01f);
+  bench_backward(26, 65536, 16, 1000000, 0.01f, true);
   bench_backward(26, 65536, 128, 1000000, 0.f);
+  bench_backward(26, 65536, 128, 1000000, 0.01f);
+  bench_backward(26, 65536, 128, 1000000, 0.01f, true);
   bench_streaming(26, 65536);
   bench_streaming(26, 1048576);
   bench_probe(26 * 65536, 1 << 16, 32);

@@ -116,9 +116,10 @@ def case_backward_cfg2():
   gouts = [torch.randn(B, 16, device=DEV) for _ in range(26)]
   res = grad(batches[0], gouts)
   u = sum(int(r[2].item()) for r in res)
-  for lr, tag in ((0.0, 'IndexedSlices only'), (0.01, 'fused SGD apply')):
-    us = timed(lambda i: grad(batches[i % nb], gouts, apply_lr=lr), iters=10)
-    nbytes = 26 * B * 8 + 26 * B * 64 + u * (2 * 64 if lr else 64)
+  for lr, emit, tag in ((0.0, True, 'IndexedSlices only'), (0.01, True, 'fused SGD apply'),
+                        (0.01, False, 'SGD step only, no IndexedSlices')):
+    us = timed(lambda i: grad(batches[i % nb], gouts, apply_lr=lr, emit=emit), iters=10)
+    nbytes = 26 * B * 8 + 26 * B * 64 + u * ((2 * 64 if lr else 0) + (72 if emit else 0))
     report(f'cfg2 bwd H=1 dim16 B={B} ({tag})', us, 26 * B, nbytes, unique_rows=u)
 
 
@@ -152,9 +153,10 @@ def case_cfg4(big):
          26 * B * (8 + 512))
   grad = hb.embedding.GroupLookupGrad(lookup)
   gouts = [torch.randn(B, dim, device=DEV) for _ in range(26)]
-  for lr, tag in ((0.0, 'IndexedSlices only'), (0.01, 'fused SGD apply')):
-    us = timed(lambda i: grad(batches[i % nb], gouts, apply_lr=lr), iters=10)
-    nbytes = 26 * B * 8 + 26 * B * 512 + uniq * (2 * 512 if lr else 512)
+  for lr, emit, tag in ((0.0, True, 'IndexedSlices only'), (0.01, True, 'fused SGD apply'),
+                        (0.01, False, 'SGD step only, no IndexedSlices')):
+    us = timed(lambda i: grad(batches[i % nb], gouts, apply_lr=lr, emit=emit), iters=10)
+    nbytes = 26 * B * 8 + 26 * B * 512 + uniq * ((2 * 512 if lr else 0) + (520 if emit else 0))
     report(f'cfg4 bwd Zipf(1.2) dim128 B={B} ({tag})', us, 26 * B, nbytes, unique_rows=uniq)
 
 
@@ -230,6 +232,8 @@ def case_cfg5():
   gouts = [torch.randn_like(o) for o in outs]
   us = timed(lambda i: grad(ids, gouts, splits, apply_lr=0.01), iters=5, warmup=2)
   report(f'cfg5 bwd + SGD apply 200 cols mixed dims B={B}', us, n_ids, n_bytes, ids=n_ids)
+  us = timed(lambda i: grad(ids, gouts, splits, apply_lr=0.01, emit=False), iters=5, warmup=2)
+  report(f'cfg5 bwd SGD step only 200 cols mixed dims B={B}', us, n_ids, n_bytes, ids=n_ids)
   accums = [torch.full_like(t, 0.1) for t in tables]
   grad_a = hb.embedding.GroupLookupGrad(lookup, accums=accums)
   us = timed(lambda i: grad_a(ids, gouts, splits, apply_lr=0.01, optimizer='adagrad'), iters=5,
@@ -293,6 +297,13 @@ def case_sharded_world1():
     drv.backward(gouts, apply_lr=0.01, outs=bouts)
   us_fb = timed(fwd_bwd, iters=20)
   report(f'sharded pipeline W=1 fwd + bwd + SGD dim16 B={B} wire=fp32', us_fb, 26 * B,
+         26 * B * (136 + 8 + 64 + 128))
+
+  def fwd_step(i):
+    drv.launch(bound[i % nb])
+    drv.backward(gouts, apply_lr=0.01, emit=False)
+  us_fb = timed(fwd_step, iters=20)
+  report(f'sharded pipeline W=1 fwd + SGD step only dim16 B={B} wire=fp32', us_fb, 26 * B,
          26 * B * (136 + 8 + 64 + 128))
   coll.close()
 

@@ -126,12 +126,28 @@ struct Options {
   int partition_sub_tiles = 1;   // HBK_PART_SUB
   int partition_fixed_max = 8;   // HBK_PART_FIXED
   int partition_onepass = 1;     // HBK_PART_ONEPASS: 0 = always the three-launch path
+  int unique_onepass = 1;        // HBK_UNIQUE_ONEPASS: 0 = always the nine-launch path
   int sharded_groups = 2;        // HBK_SHARDED_GROUPS: column groups a sharded step pipelines
   int sharded_id64 = 0;          // HBK_SHARDED_ID64: keep int64 ids on the wire
   int sharded_copy_self = 0;     // HBK_SHARDED_COPY_SELF: own slice through a device copy
   int sharded_trace = 0;         // HBK_SHARDED_TRACE: host-side phase times on stderr
 };
 Options& options();
+
+// Zeroed words for kernels whose tiles wait for each other (sync.hip).  sync_take: `words` zeroed
+// int32 of the stream's buffer for this call; the call's FIRST kernel must clear zero[0,
+// zero_words) (what the call before left set).  false while the stream is being captured into a
+// graph (or without memory): the caller clears its own words with a memset node instead.
+struct SyncTake {
+  int32_t* words;
+  int32_t* zero;
+  int64_t zero_words;
+  int32_t* status;    // host-visible, raised by a wait that ran out
+};
+bool sync_take(hipStream_t stream, size_t words, SyncTake* out);
+int32_t* sync_status();
+bool sync_raised();
+constexpr unsigned long long kSyncWaitTicks = 20000000ull;   // 200 ms of the 100 MHz clock
 
 constexpr int kWave = 64;  // gfx950 wavefront
 

@@ -33,6 +33,7 @@ const OptionEntry kOptions[] = {
     {"partition_sub_tiles", "HBK_PART_SUB", &Options::partition_sub_tiles},
     {"partition_fixed_max", "HBK_PART_FIXED", &Options::partition_fixed_max},
     {"partition_onepass", "HBK_PART_ONEPASS", &Options::partition_onepass},
+    {"unique_onepass", "HBK_UNIQUE_ONEPASS", &Options::unique_onepass},
     {"sharded_groups", "HBK_SHARDED_GROUPS", &Options::sharded_groups},
     {"sharded_id64", "HBK_SHARDED_ID64", &Options::sharded_id64},
     {"sharded_copy_self", "HBK_SHARDED_COPY_SELF", &Options::sharded_copy_self},

@@ -28,10 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <map>
-#include <mutex>
 #include <type_traits>
-#include <utility>
 
 #include "common.h"
 
@@ -548,7 +545,7 @@ __global__ __launch_bounds__(kTileWaves* kWave) void partition_scatter_kernel(co
 // are dispatched in index order, hence when the dispatcher is stalled all resident waves of this
 // kernel belong to the one column that is not fully dispatched -- at most kOneMaxTiles of the
 // ~5000 one-wave slots of the chip (8 such kernels side by side still fit).  The wait is bounded
-// all the same: after kOneWaitTicks of the 100 MHz clock a wave raises *status (host memory),
+// all the same: after kSyncWaitTicks of the 100 MHz clock a wave raises *status (host memory),
 // skips its stores, and the next entry call reports HBK_INTERNAL instead of the box hanging.
 // Probe builds only (-DHBK_PART_STAMPS, tools/Makefile): constant-clock stamps of the one-pass
 // kernel's waves, read back by hbk_debug_part_trace().
@@ -567,7 +564,6 @@ __device__ unsigned long long g_part_trace[kPTraceBlocks * kPTraceSlots];
 #endif
 constexpr int kOneMaxTiles = 256;
 constexpr int kOneMaxP = 8;
-constexpr unsigned long long kOneWaitTicks = 20000000ull;   // 200 ms
 
 struct OnePass {
   int32_t* zero;        // words the call before this one left set (the other half), or NULL
@@ -682,7 +678,7 @@ __global__ __launch_bounds__(kOneWaves* kWave) void partition_onepass_kernel(con
         ok = ok && x[p] != 0;
       }
       if (__ballot(!ok) == 0ull) break;
-      if (__builtin_amdgcn_s_memrealtime() - t_begin > kOneWaitTicks) {
+      if (__builtin_amdgcn_s_memrealtime() - t_begin > kSyncWaitTicks) {
         if (lane == 0) {
           __hip_atomic_store(o.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -749,17 +745,6 @@ __global__ __launch_bounds__(kOneWaves* kWave) void partition_onepass_kernel(con
 #endif
 }
 
-// host-visible word the one-pass kernel raises when a wait runs out (one per process)
-int32_t* onepass_status() {
-  static int32_t* word = [] {
-    void* q = nullptr;
-    if (hipHostMalloc(&q, 64, hipHostMallocDefault) != hipSuccess) return (int32_t*)nullptr;
-    memset(q, 0, 64);
-    return reinterpret_cast<int32_t*>(q);
-  }();
-  return word;
-}
-
 template <typename T>
 int launch_onepass(const PartArgs& args, const OnePass& o, hipStream_t stream) {
   hipLaunchKernelGGL(partition_onepass_kernel<T>,
@@ -800,40 +785,6 @@ int sub_tiles_of(int32_t n_cols, const int64_t* lens) {
   return sub > 8 ? 8 : (int)sub;
 }
 
-// The words the one-pass kernel polls must read zero when it starts.  They live in buffers of the
-// library, one per (device, stream): launches on one stream are ordered, so a call takes one half
-// of its stream's buffer and clears what the call before it left in the other -- no launch is
-// spent on a memset.  (Buffers are a few hundred KB and are kept for the life of the process; a
-// buffer that has become too small is replaced and the old one kept, work on the stream may still
-// be reading it.)
-struct SyncSlot {
-  int32_t* buf = nullptr;
-  size_t half_words = 0;
-  int half = 0;                    // half the next call uses
-  size_t dirty_words[2] = {0, 0};  // words a call has left set
-};
-
-SyncSlot* sync_slot(hipStream_t stream, size_t words) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, SyncSlot> slots;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  SyncSlot& s = slots[std::make_pair(dev, stream)];
-  if (s.half_words < words) {
-    const size_t half = (words + words / 2 + 16384 + 63) / 64 * 64;
-    void* q = nullptr;
-    if (hipMalloc(&q, 2 * half * sizeof(int32_t)) != hipSuccess) return nullptr;
-    if (hipMemsetAsync(q, 0, 2 * half * sizeof(int32_t), stream) != hipSuccess) return nullptr;
-    s.buf = reinterpret_cast<int32_t*>(q);
-    s.half_words = half;
-    s.half = 0;
-    s.dirty_words[0] = s.dirty_words[1] = 0;
-  }
-  return &s;
-}
-
-
 int64_t tiles_of(int64_t len, int sub) {
   const int64_t tile_ids = (int64_t)kTile * sub;
   return (len + tile_ids - 1) / tile_ids;
@@ -872,12 +823,10 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
                 "%s: NULL buffer for input %d", what, c);
   }
 
-  if (int32_t* st = onepass_status()) {
-    if (*reinterpret_cast<volatile int32_t*>(st) != 0) {
-      return fail(HBK_INTERNAL,
-                  "%s: an earlier one-pass partition launch gave up waiting for the tiles of its "
-                  "column (its outputs are not valid); set option partition_onepass = 0", what);
-    }
+  if (sync_raised()) {
+    return fail(HBK_INTERNAL,
+                "%s: an earlier one-pass launch gave up waiting for the tiles of its column (its "
+                "outputs are not valid); set options partition_onepass / unique_onepass = 0", what);
   }
   ShardFn fn;
   fn.stage = stage;
@@ -891,7 +840,7 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
   // one launch when every column fits the one-pass kernel (see there); its words must read zero
   int64_t all_tiles = 0;
   bool onepass = options().partition_onepass != 0 && sub == 1 && P <= kOneMaxP &&
-                 P <= options().partition_fixed_max && onepass_status() != nullptr;
+                 P <= options().partition_fixed_max && sync_status() != nullptr;
   for (int32_t c = 0; c < n_cols; ++c) {
     const int64_t t = tiles_of(lens[c], sub);
     onepass = onepass && t <= kOneMaxTiles;
@@ -901,24 +850,18 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
   OnePass one;
   one.zero = nullptr;
   one.zero_words = 0;
-  one.status = onepass_status();
+  one.status = sync_status();
   if (onepass) {
     const size_t words = (size_t)all_tiles * (size_t)P;
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(stream, &capturing);
-    SyncSlot* slot = capturing == hipStreamCaptureStatusNone ? sync_slot(stream, words) : nullptr;
-    if (slot == nullptr) {
+    SyncTake take;
+    if (!sync_take(stream, words, &take)) {
       // (a graph replays the same launch: no state may alternate between calls) the caller's
       // workspace, cleared by one memset node in front of the kernel
       HBK_HIP_OK(hipMemsetAsync(hist, 0, words * sizeof(int32_t), stream));
     } else {
-      const int h = slot->half;
-      hist = slot->buf + (size_t)h * slot->half_words;
-      one.zero = slot->buf + (size_t)(1 - h) * slot->half_words;
-      one.zero_words = (int64_t)slot->dirty_words[1 - h];
-      slot->dirty_words[h] = words;
-      slot->dirty_words[1 - h] = 0;
-      slot->half = 1 - h;
+      hist = take.words;
+      one.zero = take.zero;
+      one.zero_words = take.zero_words;
     }
   }
   int32_t c0 = 0;

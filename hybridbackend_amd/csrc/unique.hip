@@ -11,11 +11,20 @@
 //   4 first      ONE workgroup owns a bucket, hence every key that hashes to it: LDS hash
 //                table key -> minimum position (64-bit LDS CAS + ds_min_u32); every pair then
 //                learns the position of its key's first occurrence.  A key that finds the
-//                table full (needs > 1024 distinct keys in one bucket: adversarial hashing)
+//                table full (needs > 2048 distinct keys in one bucket: adversarial hashing)
 //                is resolved exactly by scanning its bucket.
 //   5 count / 6 scan / 7 emit / 8 index   an id is a "first occurrence" iff first[i] == i;
 //                per-1024-id-tile ballot + popcount ranks and a scan give its place in the
 //                unique list -- order of first occurrence, exactly as TF's CPU kernel emits.
+// Columns of <= 262144 ids (the owner side of a step) take FOUR launches instead of the nine:
+//   group   1-3 in one: a 4096-id tile keeps its keys and their ranks inside the tile (the value
+//           the LDS atomic returns) in registers, publishes its bucket counts and waits for the
+//           other tiles of its column (all resident: <= 64 workgroups; sync.hip), derives the
+//           bucket starts and its own offsets from all of them and scatters from registers
+//   first   4, unchanged
+//   order   5-7 in one: a 1024-id tile publishes its count of first occurrences and sums the
+//           counts of the tiles BEFORE it (decoupled look-back: aggregate / inclusive-prefix words)
+//   index   8, unchanged
 // All N columns share each launch (descriptors by value in the kernel-argument segment).
 #include <alloca.h>
 #include <stdlib.h>
@@ -34,7 +43,8 @@ constexpr int kBigTile = 4096;               // hist / scatter tiles
 constexpr int kBigPerThread = kBigTile / kBlock;
 constexpr int kBatch = 8;
 constexpr int kMaxCols = 96;
-constexpr int kSlots = 1024;
+constexpr int kSlots = 2048;
+constexpr int kFirstBlock = kBlock;   // threads of the per-bucket kernel
 constexpr int kMaxBuckets = 8192;
 constexpr unsigned long long kEmpty = ~0ull;  // key -1 never enters the table (own counter)
 
@@ -56,25 +66,34 @@ struct UCol {
   int32_t big_start;   // first 4096-id tile
   int32_t bucket0;     // first block of the per-bucket kernel
   int32_t scan0;       // first block of the scan-over-tiles kernel
+  int32_t sync0;       // group kernel: first of this column's [tiles][P] words
+  int32_t pad_;
 };
 
 struct UArgs {
   int32_t n_cols;
   int32_t pad_;
+  int32_t tile_start_v[kMaxCols];   // the columns' first blocks, packed (HBK_FIND_UCOL)
+  int32_t big_start_v[kMaxCols];
+  int32_t bucket0_v[kMaxCols];
+  int32_t scan0_v[kMaxCols];
   UCol col[kMaxCols];
 };
 static_assert(sizeof(UArgs) <= 16384, "kernarg budget");
 
-#define HBK_FIND_UCOL(FIELD)                                                       \
-  int ci = 0, hi__ = a.n_cols;                                                     \
-  while (hi__ - ci > 1) {                                                          \
-    const int mid__ = (ci + hi__) >> 1;                                            \
-    if (a.col[mid__].FIELD <= (int)blockIdx.x) {                                   \
-      ci = mid__;                                                                  \
-    } else {                                                                       \
-      hi__ = mid__;                                                                \
-    }                                                                              \
-  }                                                                                \
+// column of this workgroup: every lane reads one column's first block (two loads cover the 96
+// columns) and a ballot counts those <= blockIdx.x -- one memory round trip where a binary search
+// over the descriptors takes five dependent scalar loads, cold at the start of these short kernels
+#define HBK_FIND_UCOL(FIELD)                                                                   \
+  int ci;                                                                                      \
+  {                                                                                            \
+    const int ln__ = (int)(threadIdx.x & (kWave - 1)), blk__ = (int)blockIdx.x;                \
+    const int t0__ = ln__ < a.n_cols ? a.FIELD##_v[ln__] : 0x7fffffff;                         \
+    const int t1__ = ln__ + kWave < a.n_cols ? a.FIELD##_v[ln__ + kWave] : 0x7fffffff;         \
+    ci = (int)__builtin_popcountll(__ballot(t0__ <= blk__)) +                                  \
+         (int)__builtin_popcountll(__ballot(t1__ <= blk__)) - 1;                               \
+    ci = __builtin_amdgcn_readfirstlane(ci);                                                   \
+  }                                                                                            \
   const UCol& c = a.col[ci];
 
 __device__ inline uint64_t mix64(uint64_t k) {
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void unique_scatter_kernel(const UArgs a) {
 }
 
 // ---- 4: one workgroup per bucket: first occurrence of every key ------------------------------
-__global__ __launch_bounds__(kBlock) void unique_first_kernel(const UArgs a) {
+__global__ __launch_bounds__(kFirstBlock) void unique_first_kernel(const UArgs a) {
   __shared__ unsigned long long keys[kSlots];
   __shared__ uint32_t first[kSlots];
   __shared__ uint32_t first_m1;  // key -1 (the table's empty marker) has its own cell
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void unique_first_kernel(const UArgs a) {
   const int32_t start = c.bstart[bucket];
   const int32_t n = c.bstart[bucket + 1] - start;
   if (n == 0) return;
-  for (int i = tid; i < kSlots; i += kBlock) {
+  for (int i = tid; i < kSlots; i += kFirstBlock) {
     keys[i] = kEmpty;
     first[i] = 0xffffffffu;
   }
@@ -224,48 +243,75 @@ __global__ __launch_bounds__(kBlock) void unique_first_kernel(const UArgs a) {
   __syncthreads();
   const int64_t* pkey = c.pair_key + start;
   const int32_t* pidx = c.pair_idx + start;
-  for (int32_t e = tid; e < n; e += kBlock) {
-    const unsigned long long key = (unsigned long long)pkey[e];
-    const uint32_t idx = (uint32_t)pidx[e];
-    if (key == kEmpty) {
-      atomicMin(&first_m1, idx);
-      continue;
+  // A round = kFirstKeys pairs per thread, all loads in flight at once; buckets aim at 512 pairs,
+  // so one round is the rule and its registers serve both phases.  (Measured for 26 x 65536 ids:
+  // 256 threads per 512-pair bucket 21 us, 128 threads 32 us: the kernel is bound by what one
+  // thread does in sequence, not by the rate waves start at.)
+  constexpr int kFirstKeys = 6;
+  constexpr int kRound = kFirstBlock * kFirstKeys;
+  unsigned long long key[kFirstKeys];
+  uint32_t idx[kFirstKeys];
+  for (int32_t r0 = 0; r0 < n; r0 += kRound) {
+#pragma unroll
+    for (int k = 0; k < kFirstKeys; ++k) {
+      const int32_t e = r0 + k * kFirstBlock + tid;
+      key[k] = e < n ? (unsigned long long)pkey[e] : 0ull;
+      idx[k] = e < n ? (uint32_t)pidx[e] : 0u;
     }
-    int h = (int)(mix64(key) & (kSlots - 1));
-    for (int probe = 0; probe < kSlots; ++probe) {
-      const unsigned long long prev = atomicCAS(&keys[h], kEmpty, key);
-      if (prev == kEmpty || prev == key) {
-        atomicMin(&first[h], idx);
-        break;
+#pragma unroll
+    for (int k = 0; k < kFirstKeys; ++k) {
+      if (r0 + k * kFirstBlock + tid >= n) continue;
+      if (key[k] == kEmpty) {
+        atomicMin(&first_m1, idx[k]);
+        continue;
       }
-      h = (h + 1) & (kSlots - 1);
+      int h = (int)(mix64(key[k]) & (kSlots - 1));
+      for (int probe = 0; probe < kSlots; ++probe) {
+        const unsigned long long prev = atomicCAS(&keys[h], kEmpty, key[k]);
+        if (prev == kEmpty || prev == key[k]) {
+          atomicMin(&first[h], idx[k]);
+          break;
+        }
+        h = (h + 1) & (kSlots - 1);
+      }
     }
   }
   __syncthreads();
-  for (int32_t e = tid; e < n; e += kBlock) {
-    const unsigned long long key = (unsigned long long)pkey[e];
-    const int32_t idx = pidx[e];
-    uint32_t f = 0xffffffffu;
-    if (key == kEmpty) {
-      f = first_m1;
-    } else {
-      int h = (int)(mix64(key) & (kSlots - 1));
-      for (int probe = 0; probe < kSlots; ++probe) {
-        const unsigned long long k = keys[h];
-        if (k == key) {
-          f = first[h];
-          break;
-        }
-        if (k == kEmpty) break;
-        h = (h + 1) & (kSlots - 1);
-      }
-      if (f == 0xffffffffu) {  // table was full for this key: exact answer by scanning the bucket
-        for (int32_t q = 0; q < n; ++q) {
-          if ((unsigned long long)pkey[q] == key && (uint32_t)pidx[q] < f) f = (uint32_t)pidx[q];
-        }
+  const bool one_round = n <= kRound;
+  for (int32_t r0 = 0; r0 < n; r0 += kRound) {
+    if (!one_round) {
+#pragma unroll
+      for (int k = 0; k < kFirstKeys; ++k) {
+        const int32_t e = r0 + k * kFirstBlock + tid;
+        key[k] = e < n ? (unsigned long long)pkey[e] : 0ull;
+        idx[k] = e < n ? (uint32_t)pidx[e] : 0u;
       }
     }
-    c.first[idx] = (int32_t)f;
+#pragma unroll
+    for (int k = 0; k < kFirstKeys; ++k) {
+      if (r0 + k * kFirstBlock + tid >= n) continue;
+      uint32_t f = 0xffffffffu;
+      if (key[k] == kEmpty) {
+        f = first_m1;
+      } else {
+        int h = (int)(mix64(key[k]) & (kSlots - 1));
+        for (int probe = 0; probe < kSlots; ++probe) {
+          const unsigned long long q = keys[h];
+          if (q == key[k]) {
+            f = first[h];
+            break;
+          }
+          if (q == kEmpty) break;
+          h = (h + 1) & (kSlots - 1);
+        }
+        if (f == 0xffffffffu) {  // table was full for this key: exact answer by scanning the bucket
+          for (int32_t q = 0; q < n; ++q) {
+            if ((unsigned long long)pkey[q] == key[k] && (uint32_t)pidx[q] < f) f = (uint32_t)pidx[q];
+          }
+        }
+      }
+      c.first[idx[k]] = (int32_t)f;
+    }
   }
 }
 
@@ -365,6 +411,232 @@ __global__ __launch_bounds__(kBlock) void unique_emit_kernel(const UArgs a) {
   }
 }
 
+// ---- 1-3 in one launch ---------------------------------------------------------------------------
+constexpr int kGroupMaxTiles = 64;     // 4096-id tiles per column
+constexpr int kGroupMaxLog2P = 10;     // buckets per column: LDS counters
+
+struct USync {
+  int32_t* hist;        // group: per column [tiles][P] words, 0 = not published, else count + 1
+  uint32_t* order;      // order: per 1024-id tile, 0 = nothing, v << 2 | 1 aggregate, | 2 inclusive
+  int32_t* zero;        // words the call before left set (cleared by the group kernel)
+  int64_t zero_words;
+  int32_t* status;      // raised by a wait that ran out
+};
+
+__global__ __launch_bounds__(kBlock) void unique_group_kernel(const UArgs a, const USync y) {
+  __shared__ int32_t counters[1 << kGroupMaxLog2P];   // counts, then bases
+  __shared__ int32_t wave_tot[kWavesPerBlock];
+  __shared__ int32_t gave_up;
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + tid; j < y.zero_words;
+       j += (int64_t)gridDim.x * kBlock) {
+    y.zero[j] = 0;
+  }
+  HBK_FIND_UCOL(big_start)
+  const int P = 1 << c.log2p;
+  const int ctile = (int)blockIdx.x - c.big_start;
+  const int n_tiles = (c.len + kBigTile - 1) / kBigTile;
+  int32_t* hist = y.hist + c.sync0;
+  for (int p = tid; p < P; p += kBlock) counters[p] = 0;
+  if (tid == 0) gave_up = 0;
+  const int64_t base = (int64_t)ctile * kBigTile;
+  int64_t key[kBigPerThread];
+#pragma unroll
+  for (int k = 0; k < kBigPerThread; ++k) {
+    const int64_t j = base + (int64_t)k * kBlock + tid;
+    key[k] = j < c.len ? c.in[j] : 0;
+  }
+  __syncthreads();
+  // bucket and rank inside the tile's share of the bucket (what the LDS atomic returns)
+  int32_t br[kBigPerThread];
+#pragma unroll
+  for (int k = 0; k < kBigPerThread; ++k) {
+    const int64_t j = base + (int64_t)k * kBlock + tid;
+    br[k] = -1;
+    if (j < c.len) {
+      const int b = bucket_of((uint64_t)key[k], c.log2p);
+      br[k] = b | (atomicAdd(&counters[b], 1) << kGroupMaxLog2P);
+    }
+  }
+  __syncthreads();
+  for (int p = tid; p < P; p += kBlock) {
+    __hip_atomic_store(hist + (int64_t)ctile * P + p, counters[p] + 1, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // thread t owns buckets [t * per, t * per + per): their totals over the column's tiles and the
+  // part of the tiles before this one
+  const int per = P >= kBlock ? P / kBlock : 1;
+  const int p0 = tid * per;
+  int32_t tot[4] = {0, 0, 0, 0}, pre[4] = {0, 0, 0, 0};
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  bool lost = false;
+  if (p0 < P) {
+    // up to 16 tiles per poll (the 16 tiles of a 65536-id column: one wait, not two)
+    for (int t0 = 0; t0 < n_tiles && !lost; t0 += 16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q >= per) break;
+        int32_t x[16];
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            x[e] = 1;
+            if (t0 + e < n_tiles) {
+              x[e] = __hip_atomic_load(hist + (int64_t)(t0 + e) * P + p0 + q, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ok = ok && x[e] != 0;
+          }
+          if (ok) break;
+          if (__builtin_amdgcn_s_memrealtime() - t_begin > kSyncWaitTicks) {
+            lost = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (lost) break;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          tot[q] += x[e] - 1;
+          pre[q] += t0 + e < ctile ? x[e] - 1 : 0;
+        }
+      }
+    }
+  }
+  if (lost) gave_up = 1;
+  // bucket starts: exclusive scan of the totals in bucket order
+  int32_t mine = tot[0] + tot[1] + tot[2] + tot[3];
+  int32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int32_t v = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += v;
+  }
+  if (lane == kWave - 1) wave_tot[wave] = incl;
+  __syncthreads();
+  if (gave_up != 0) {
+    if (tid == 0) __hip_atomic_store(y.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  int32_t run = incl - mine;
+  for (int w = 0; w < wave; ++w) run += wave_tot[w];
+  if (p0 < P) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q >= per) break;
+      counters[p0 + q] = run + pre[q];
+      if (ctile == 0) c.bstart[p0 + q] = run;
+      run += tot[q];
+    }
+  }
+  if (ctile == 0 && tid == 0) c.bstart[P] = c.len;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kBigPerThread; ++k) {
+    if (br[k] >= 0) {
+      const int32_t pos = counters[br[k] & ((1 << kGroupMaxLog2P) - 1)] + (br[k] >> kGroupMaxLog2P);
+      c.pair_key[pos] = key[k];
+      c.pair_idx[pos] = (int32_t)(base + (int64_t)k * kBlock + tid);
+    }
+  }
+}
+
+// ---- 5-7 in one launch ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void unique_order_kernel(const UArgs a, const USync y) {
+  __shared__ int32_t wave_cnt[kWavesPerBlock];
+  __shared__ int32_t prefix_s;   // first occurrences in the tiles before this one; -1: gave up
+  // (1024-id tiles, 4 consecutive ids per thread; 4096-id tiles with 16 per thread measured 35 us
+  // instead of 20 for 26 x 65536 ids: what one thread does in sequence is what counts)
+  HBK_FIND_UCOL(tile_start)
+  const int ctile = (int)blockIdx.x - c.tile_start;
+  const int n_tiles = (c.len + kTile - 1) / kTile;
+  const int64_t i0 = (int64_t)ctile * kTile + (int64_t)threadIdx.x * kPerThread;
+  int64_t val[kPerThread];   // the ids travel beside the flags: no load after the look-back
+#pragma unroll
+  for (int e = 0; e < kPerThread; ++e) val[e] = i0 + e < c.len ? c.in[i0 + e] : 0;
+  const int flags = first_flags(c, i0);
+  const int n = __builtin_popcount(flags);
+  int below = 0, total = 0;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const unsigned long long m = __ballot((n >> b) & 1);
+    below += rank_below(m) << b;
+    total += (int)__builtin_popcountll(m) << b;
+  }
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  if (lane == 0) wave_cnt[wave] = total;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t block_total = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) block_total += (uint32_t)wave_cnt[w];
+    uint32_t* words = y.order + c.tile_start;
+    if (lane == 0) {
+      __hip_atomic_store(words + ctile, (block_total << 2) | (ctile == 0 ? 2u : 1u),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // look back over the tiles before this one, nearest first, 64 at a time, up to the nearest
+    // one that knows its inclusive prefix
+    uint32_t excl = 0;
+    bool lost = false;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    for (int look = ctile - 1; look >= 0; look -= kWave) {
+      const int t = look - lane;
+      uint32_t x;
+      unsigned long long incl_mask;
+      for (;;) {
+        x = 2u;   // before the column's first tile: an inclusive prefix of nothing
+        if (t >= 0) x = __hip_atomic_load(words + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        incl_mask = __ballot((x & 3u) == 2u);
+        unsigned long long need = ~0ull;   // lanes whose word is needed: up to the nearest inclusive
+        if (incl_mask != 0ull) {
+          const int f = __builtin_ctzll(incl_mask);
+          need = f == 63 ? ~0ull : ((1ull << (f + 1)) - 1ull);
+        }
+        if ((__ballot(x == 0u) & need) == 0ull) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_begin > kSyncWaitTicks) {
+          lost = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (lost) break;
+      const int f = incl_mask != 0ull ? __builtin_ctzll(incl_mask) : kWave;
+      uint32_t part = lane <= f ? x >> 2 : 0u;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) part += (uint32_t)__shfl_xor((int)part, off, kWave);
+      excl += part;
+      if (incl_mask != 0ull) break;
+    }
+    if (lane == 0) {
+      prefix_s = lost ? -1 : (int32_t)excl;
+      if (lost) {
+        __hip_atomic_store(y.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        if (ctile > 0) {
+          __hip_atomic_store(words + ctile, ((excl + block_total) << 2) | 2u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (ctile == n_tiles - 1) *c.n_unique = (int32_t)(excl + block_total);
+      }
+    }
+  }
+  __syncthreads();
+  if (prefix_s < 0) return;
+  int pos = prefix_s + below;
+  for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+#pragma unroll
+  for (int e = 0; e < kPerThread; ++e) {
+    if (flags & (1 << e)) {
+      const int64_t i = i0 + e;
+      c.uniq[pos] = val[e];
+      c.upos[i] = pos;
+      ++pos;
+    }
+  }
+}
+
 // ---- 8: index[i] = place of the first occurrence of in[i] --------------------------------------
 __global__ __launch_bounds__(kBlock) void unique_index_kernel(const UArgs a) {
   HBK_FIND_UCOL(tile_start)
@@ -379,8 +651,11 @@ __global__ __launch_bounds__(kBlock) void unique_index_kernel(const UArgs a) {
 inline size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 
 inline int log2p_of(int64_t len) {
-  int lp = 0;  // aim at 256 keys per bucket: a quarter-full 1024-slot table
-  while (lp < 13 && ((int64_t)256 << lp) < len) ++lp;
+  // aim at 512 keys per bucket, a quarter-full 2048-slot table (measured for 26 x 65536 ids: 256
+  // keys 76 us, 512 keys 71 us, 1024 keys 80 us for the whole unique; a half-full 1024-slot table
+  // costs the per-bucket kernel 29 us instead of 21: probe sequences are what it waits for)
+  int lp = 0;
+  while (lp < 13 && ((int64_t)512 << lp) < len) ++lp;
   while (((int64_t)1 << lp) > kMaxBuckets) --lp;
   const int forced = options().unique_buckets_log2;   // option: force the bucket count
   if (forced >= 0 && forced <= 13) lp = forced;
@@ -424,12 +699,42 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
               "unique_n: workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
   HBK_REQUIRE(((uintptr_t)workspace & 7) == 0, "unique_n: workspace must be 8-byte aligned");
   char* wp = reinterpret_cast<char*>(workspace);
+  if (sync_raised()) {
+    return fail(HBK_INTERNAL, "unique_n: an earlier one-pass launch gave up waiting for the tiles "
+                              "of its column (its outputs are not valid); set options "
+                              "partition_onepass / unique_onepass = 0");
+  }
+  // four launches when every column fits the group kernel (see there)
+  bool onepass = options().unique_onepass != 0 && n_cols <= kMaxCols;
+  size_t group_words = 0, order_words = 0;
+  for (int32_t c = 0; c < n_cols && onepass; ++c) {
+    if (cols[c].len == 0) continue;
+    const int64_t cbig = (cols[c].len + kBigTile - 1) / kBigTile;
+    const int lp = log2p_of(cols[c].len);
+    onepass = cbig <= kGroupMaxTiles && lp <= kGroupMaxLog2P;
+    group_words += (size_t)cbig << lp;
+    order_words += (size_t)((cols[c].len + kTile - 1) / kTile);
+  }
+  USync sync;
+  memset(&sync, 0, sizeof(sync));
+  if (onepass && group_words > 0) {
+    SyncTake take;
+    onepass = group_words + order_words < (1u << 30) &&
+              sync_take(stream, group_words + order_words, &take);
+    if (onepass) {
+      sync.hist = take.words;
+      sync.order = reinterpret_cast<uint32_t*>(take.words + group_words);
+      sync.zero = take.zero;
+      sync.zero_words = take.zero_words;
+      sync.status = take.status;
+    }
+  }
 
   int32_t c0 = 0;
   while (c0 < n_cols) {
     UArgs args;
     int32_t k = 0;
-    int64_t tiles = 0, big = 0, buckets = 0, scans = 0;
+    int64_t tiles = 0, big = 0, buckets = 0, scans = 0, sync0 = 0;
     size_t lds = 0;
     while (c0 < n_cols && k < kMaxCols) {
       const UniqueColumn& h = cols[c0++];
@@ -466,6 +771,12 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
       d.big_start = (int32_t)big;
       d.bucket0 = (int32_t)buckets;
       d.scan0 = (int32_t)scans;
+      args.tile_start_v[k] = d.tile_start;
+      args.big_start_v[k] = d.big_start;
+      args.bucket0_v[k] = d.bucket0;
+      args.scan0_v[k] = d.scan0;
+      d.sync0 = (int32_t)sync0;
+      sync0 += cbig << lp;
       scans += (((int64_t)1 << lp) + kBlock - 1) / kBlock;
       tiles += ctiles;
       big += cbig;
@@ -478,11 +789,19 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
     args.n_cols = k;
     args.pad_ = 0;
     const dim3 block(kBlock);
+    if (onepass) {
+      hipLaunchKernelGGL(unique_group_kernel, dim3((unsigned)big), block, 0, stream, args, sync);
+      hipLaunchKernelGGL(unique_first_kernel, dim3((unsigned)buckets), dim3(kFirstBlock), 0, stream, args);
+      hipLaunchKernelGGL(unique_order_kernel, dim3((unsigned)tiles), block, 0, stream, args, sync);
+      hipLaunchKernelGGL(unique_index_kernel, dim3((unsigned)tiles), block, 0, stream, args);
+      HBK_HIP_OK(hipGetLastError());
+      continue;
+    }
     hipLaunchKernelGGL(unique_hist_kernel, dim3((unsigned)big), block, lds, stream, args);
     hipLaunchKernelGGL(unique_scan_tiles_kernel, dim3((unsigned)scans), block, 0, stream, args);
     hipLaunchKernelGGL(unique_bucket_scan_kernel, dim3((unsigned)k), block, 0, stream, args);
     hipLaunchKernelGGL(unique_scatter_kernel, dim3((unsigned)big), block, lds, stream, args);
-    hipLaunchKernelGGL(unique_first_kernel, dim3((unsigned)buckets), block, 0, stream, args);
+    hipLaunchKernelGGL(unique_first_kernel, dim3((unsigned)buckets), dim3(kFirstBlock), 0, stream, args);
     hipLaunchKernelGGL(unique_count_kernel, dim3((unsigned)tiles), block, 0, stream, args);
     hipLaunchKernelGGL(unique_scan_kernel, dim3((unsigned)k), block, 0, stream, args);
     hipLaunchKernelGGL(unique_emit_kernel, dim3((unsigned)tiles), block, 0, stream, args);

@@ -301,26 +301,37 @@ def test_group_lookup_baseline_full_size_properties():
 
 # ----------------------------------------------------------------------------------
 # R7 unique
-def test_unique_first_occurrence_order():
+@pytest.mark.parametrize('onepass', [1, 0])
+def test_unique_first_occurrence_order(hbk_option, onepass):
+  # four launches (tiles wait for each other) and the nine-launch form: both TF's Unique
+  hbk_option('unique_onepass', onepass)
   rng = np.random.RandomState(6)
   cases = [np.array([], np.int64), np.array([5, 3, 5, 7, 3, 3, 9], np.int64),
            np.array([-1, -1, 0, -2**63, 2**63 - 1, -1, -2**63], np.int64),
            rng.randint(0, 50, size=1000).astype(np.int64),
            rng.randint(0, 2**40, size=70000).astype(np.int64),
            rng.randint(0, 1000, size=70000).astype(np.int64),
-           (rng.zipf(1.2, size=50000) % 100000).astype(np.int64)]
-  res = hb.embedding.unique_n([dev(x) for x in cases])
-  for x, (u, idx, nu) in zip(cases, res):
-    ou, oidx = oracle.unique(x)
-    k = int(nu.item())
-    assert k == ou.size
-    np.testing.assert_equal(host(u)[:k], ou)
-    np.testing.assert_equal(host(idx), oidx)
+           (rng.zipf(1.2, size=50000) % 100000).astype(np.int64),
+           rng.randint(0, 2**40, size=262144).astype(np.int64),      # 64 tiles: the limit
+           np.arange(4097, dtype=np.int64), np.zeros(9000, np.int64)]
+  for rep in range(3):                     # repeated calls: the sync words alternate halves
+    if rep == 2:
+      cases.append(rng.randint(0, 10**6, size=262145).astype(np.int64))   # the whole call falls back
+    res = hb.embedding.unique_n([dev(x) for x in cases])
+    for x, (u, idx, nu) in zip(cases, res):
+      ou, oidx = oracle.unique(x)
+      k = int(nu.item())
+      assert k == ou.size
+      np.testing.assert_equal(host(u)[:k], ou)
+      np.testing.assert_equal(host(idx), oidx)
+    cases = cases[::-1]
 
 
-def test_unique_table_overflow_is_still_exact(hbk_option):
-  # one bucket per column: > 1024 distinct keys overflow the LDS table and are resolved by the
+@pytest.mark.parametrize('onepass', [1, 0])
+def test_unique_table_overflow_is_still_exact(hbk_option, onepass):
+  # one bucket per column: > 2048 distinct keys overflow the LDS table and are resolved by the
   # exact bucket scan
+  hbk_option('unique_onepass', onepass)
   hbk_option('unique_buckets_log2', 0)
   rng = np.random.RandomState(16)
   cases = [rng.randint(0, 3000, size=6000).astype(np.int64),

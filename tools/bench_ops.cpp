@@ -344,6 +344,10 @@ int main(int argc, char** argv) {
     bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 8", 26, 65536, 8, HBK_INT64);
     return 0;
   }
+  if (argc > 1 && argv[1][0] == 'u') {  // "unique": the owner-side unique only
+    bench_unique(26, 65536, 1000000);
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'q') {  // the reference benchmark's shape only
     bench_partition<int32_t>("partition_by_modulo_n 100 x 100000 int32, P = 8 (reference benchmark)", 100,
                              100000, 8, HBK_INT32);

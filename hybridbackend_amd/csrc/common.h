@@ -122,6 +122,7 @@ struct Options {
   int bwd_buckets_log2 = -1;   // HBK_BWD_LOG2P: force 2^v buckets per column in the backward
   int bwd_bucket_pairs = 0;    // HBK_BWD_TARGET: aimed pairs per bucket (0: default)
   int bwd_split_pairs = 0;     // HBK_BWD_SPLIT: pairs per workgroup of a split bucket (0: default)
+  int bwd_onepass = 1;         // HBK_BWD_ONEPASS: 0 = histogram, scan and scatter as three launches
   int unique_buckets_log2 = -1;  // HBK_UNIQUE_LOG2P
   int partition_sub_tiles = 1;   // HBK_PART_SUB
   int partition_fixed_max = 8;   // HBK_PART_FIXED

@@ -161,7 +161,7 @@ struct GCol {
   float* grad_rows;
   int32_t* n_unique;
   int32_t no_emit;           // unique_rows / grad_rows are scratch: the caller passed none (step only)
-  int32_t pad2_;
+  int32_t sync0;             // group kernel: first of the column's [tiles][n_buckets] sync words
   int32_t* counter;          // the column's claim counter, ALONE on its 256-byte line of the workspace:
                              // every reduce job claims its output range with one atomic on it, and
                              // atomics on one line are served by one memory channel at ~80 per us --
@@ -397,7 +397,8 @@ __device__ inline void scan_buckets_of_column(const GCol& c, int32_t* wave_tot, 
   for (int e = n_extra + tid; e < c.e_max; e += kBlock) c.desc[P + e] = make_int4(0, 0, -1, 0);
   if (tid == kBlock - 1) {
     c.bstart[P] = run;   // the last thread's running sum is the column total
-    *c.counter = 0;
+    c.counter[0] = 0;
+    c.counter[1] = 0;      // merge blocks of the column that are done (bwd_merge_kernel)
     *c.n_extra = n_extra;
   }
 }
@@ -465,6 +466,207 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
       }
     }
   }
+}
+
+// ---- 1-3 in one launch ---------------------------------------------------------------------------
+// Columns of <= 1024 buckets and <= 64 tiles (every column of a 65536-id step): a tile keeps its
+// rows, their buckets and their ranks inside the tile's share of the bucket (what the LDS atomic
+// returns) in registers, publishes its bucket counts (count + 1 into words that read zero when
+// the kernel starts, sync.hip) and waits for the other tiles of its column -- all resident:
+// workgroups start in index order, so when the dispatcher stalls every waiting workgroup belongs
+// to the one column that is not fully started, <= 64 of the chip's > 1000 slots -- then derives
+// the bucket starts and its own offsets from all of them and scatters from registers.  Tile 0 of a
+// column also writes what the scan kernel wrote: bucket starts, job descriptors, extra ranges of
+// split buckets, the cleared counters.  The ids are read once and two launches disappear
+// (hist 9 us + scan 6 us + scatter 26 us -> measured in profiles/).
+#ifdef HBK_BWD_STAMPS
+__device__ unsigned long long g_grp_trace[kTraceBlocks * kTraceSlots];
+#define HBK_GSTAMP(i)                                                                       \
+  do {                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < kTraceBlocks) {                                    \
+      g_grp_trace[blockIdx.x * kTraceSlots + (i)] = __builtin_amdgcn_s_memrealtime();       \
+    }                                                                                       \
+  } while (0)
+#else
+#define HBK_GSTAMP(i)
+#endif
+
+struct GSync {
+  int32_t* hist;        // per column [tiles][n_buckets] words: 0 = not published, else count + 1
+  int32_t* zero;        // words the call before left set
+  int64_t zero_words;
+  int32_t* status;      // raised by a wait that ran out
+};
+
+// (5 waves per SIMD: all 832 workgroups of a 26 x 65536 call resident at once; at 145 VGPRs the
+// last 64 started 21 us late and the kernel took as long as the three launches it replaces)
+__global__ __launch_bounds__(kBlock, 5) void bwd_group_kernel(const GArgs a, const GSync y) {
+  __shared__ int32_t counters[4 * kBlock];   // counts of the tile, then its offsets
+  __shared__ int32_t tot_s[4 * kBlock], pre_s[4 * kBlock];   // bucket totals / before this tile
+  __shared__ int32_t wave_tot[kWavesPerBlock];
+  __shared__ int32_t n_extra, gave_up;
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  HBK_GSTAMP(0);
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + tid; j < y.zero_words;
+       j += (int64_t)gridDim.x * kBlock) {
+    y.zero[j] = 0;
+  }
+  HBK_FIND_COL(a, tile0)
+  const int P = c.n_buckets;
+  const int ctile = (int)blockIdx.x - c.tile0;
+  const int n_tiles = (int)((c.n_ids + kTile - 1) / kTile);
+  const int64_t base = (int64_t)ctile * kTile;
+  int32_t* hist = y.hist + c.sync0;
+  RunCursor rc;
+  int64_t id[kPerThread];
+  int32_t seg[kPerThread];
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int64_t j = base + (int64_t)k * kBlock + tid;
+    id[k] = 0;
+    seg[k] = (int32_t)j;
+    if (j < c.n_ids) {
+      if (c.n_runs > 0) {
+        run_seek(c, j, rc);
+        seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);
+      }
+      id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
+      if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
+    }
+  }
+  for (int p = tid; p < P; p += kBlock) counters[p] = 0;
+  if (tid == 0) {
+    n_extra = 0;
+    gave_up = 0;
+  }
+  __syncthreads();
+  HBK_GSTAMP(1);            // counters cleared, loads issued
+  int32_t br[kPerThread];   // bucket | rank << 10, -1: no row
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int64_t j = base + (int64_t)k * kBlock + tid;
+    br[k] = -1;
+    if (j < c.n_ids) {
+      const uint64_t r = id_to_row(c.map, id[k]);
+      id[k] = (int64_t)r;
+      if (r != kNoRow) {
+        const int b = bucket_of(r, P);
+        br[k] = b | (atomicAdd(&counters[b], 1) << 10);
+      }
+    }
+  }
+  __syncthreads();
+  HBK_GSTAMP(2);            // ids arrived, ranks taken
+  for (int p = tid; p < P; p += kBlock) {
+    __hip_atomic_store(hist + (int64_t)ctile * P + p, counters[p] + 1, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  HBK_GSTAMP(3);            // published
+  // totals of every bucket over the column's tiles and the part of the tiles before this one
+  // (a thread per bucket, 16 tiles per poll), left in LDS for the scan
+  const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+  bool lost = false;
+#pragma unroll 1
+  for (int p = tid; p < P && !lost; p += kBlock) {
+    int32_t t_all = 0, t_pre = 0;
+#pragma unroll 1
+    for (int t0 = 0; t0 < n_tiles && !lost; t0 += 16) {
+      int32_t x[16];
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          x[e] = 1;
+          if (t0 + e < n_tiles) {
+            x[e] = __hip_atomic_load(hist + (int64_t)(t0 + e) * P + p, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+          }
+          ok = ok && x[e] != 0;
+        }
+        if (ok) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_begin > kSyncWaitTicks) {
+          lost = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (lost) break;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        t_all += x[e] - 1;
+        t_pre += t0 + e < ctile ? x[e] - 1 : 0;
+      }
+    }
+    tot_s[p] = t_all;
+    pre_s[p] = t_pre;
+  }
+  if (lost) gave_up = 1;
+  __syncthreads();
+  HBK_GSTAMP(4);            // the column's counts are in
+  if (gave_up != 0) {
+    if (tid == 0) __hip_atomic_store(y.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  // bucket starts: thread t scans buckets [t * per, t * per + per)
+  const int per = (P + kBlock - 1) / kBlock;   // <= 4
+  const int beg = tid * per;
+  const int end = beg + per < P ? beg + per : P;
+  int32_t sum = 0;
+  for (int p = beg; p < end; ++p) sum += tot_s[p];
+  int32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int32_t v = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += v;
+  }
+  if (lane == kWave - 1) wave_tot[wave] = incl;
+  __syncthreads();
+  int32_t run = incl - sum;
+  for (int w = 0; w < wave; ++w) run += wave_tot[w];
+  const bool first_tile = ctile == 0;
+  for (int p = beg; p < end; ++p) {
+    const int32_t n_b = tot_s[p];
+    counters[p] = run + pre_s[p];
+    if (first_tile) {
+      c.bstart[p] = run;
+      c.desc[p] = make_int4(run, n_b, p, 0);
+      c.pcount[p] = 0;
+      if (n_b > c.split_t) {
+        const int32_t extras = (n_b - 1) / c.split_t;
+        const int32_t e0 = atomicAdd(&n_extra, extras);
+        for (int32_t e = 0; e < extras; ++e) {
+          c.work[2 * (e0 + e)] = p;
+          c.work[2 * (e0 + e) + 1] = e + 1;
+          c.desc[P + e0 + e] = make_int4(run, n_b, p, e + 1);
+        }
+      }
+    }
+    run += n_b;
+  }
+  __syncthreads();
+  if (first_tile) {
+    for (int e = n_extra + tid; e < c.e_max; e += kBlock) c.desc[P + e] = make_int4(0, 0, -1, 0);
+    if (tid == kBlock - 1) {
+      c.bstart[P] = run;   // the last thread's running sum is the column total
+      c.counter[0] = 0;
+      c.counter[1] = 0;    // merge blocks of the column that are done (bwd_merge_kernel)
+      *c.n_extra = n_extra;
+    }
+  }
+  HBK_GSTAMP(5);            // offsets known
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    if (br[k] >= 0) {
+      const int32_t pos = counters[br[k] & 1023] + (br[k] >> 10);
+      c.pair_row[0][pos] = id[k];
+      c.pair_seg[0][pos] = seg[k];
+    }
+  }
+  HBK_GSTAMP(6);            // stores issued
+#ifdef HBK_BWD_STAMPS
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  HBK_GSTAMP(7);            // stores landed
+#endif
 }
 
 // ---- 4: one workgroup per bucket ---------------------------------------------------------------
@@ -1178,12 +1380,17 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const 
     job.no_emit = false;
     bucket_reduce<V, STEP>(c, job, lds[team]);
   }
-}
-
-// the columns' row counts go from the workspace counters to the caller's n_unique
-__global__ __launch_bounds__(kWave) void bwd_finish_kernel(const GArgs a) {
-  const int ci = (int)threadIdx.x;
-  if (ci < a.n_cols) *a.col[ci].n_unique = *a.col[ci].counter;
+  // The column's row count goes from its workspace counter to the caller's n_unique: by the last
+  // of the column's merge blocks to get here (no launch of its own).  Every claim of a block has
+  // returned before the block counts itself done, so the last one reads the final count.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int32_t done = __hip_atomic_fetch_add(c.counter + 1, 1, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+    if (done == blocks - 1) {
+      *c.n_unique = __hip_atomic_load(c.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---- d(stitch + combiner): permutation scatter (hbk_group_stitch_bwd) ----------------------
@@ -1344,6 +1551,18 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
 }  // namespace hbk
 
 #ifdef HBK_BWD_STAMPS
+extern "C" int hbk_debug_grp_trace(unsigned long long* out, int reset) {
+  using namespace hbk;
+  HBK_HIP_OK(hipDeviceSynchronize());
+  if (out != nullptr) {
+    HBK_HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grp_trace), sizeof(g_grp_trace)));
+  }
+  if (reset) {
+    static unsigned long long z[kTraceBlocks * kTraceSlots];
+    HBK_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_grp_trace), z, sizeof(z)));
+  }
+  return HBK_OK;
+}
 // probe builds: constant-clock (100 MHz) stamps of the first 8192 reduce workgroups, 8 each
 extern "C" int hbk_debug_bwd_trace(unsigned long long* out, int reset) {
   using namespace hbk;
@@ -1423,6 +1642,11 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
               workspace_bytes);
   HBK_REQUIRE(((uintptr_t)workspace & 7) == 0,
               "group_lookup_bwd: workspace must be 8-byte aligned");
+  if (sync_raised()) {
+    return fail(HBK_INTERNAL, "group_lookup_bwd: an earlier one-pass launch gave up waiting for "
+                              "the tiles of its column (its outputs are not valid); set option "
+                              "bwd_onepass = 0");
+  }
   // head of the workspace: the job descriptors of all columns (16-byte aligned), then the
   // per-column buffers
   char* cp = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -1442,7 +1666,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     GArgs args, seg_args;
     int4* const desc_group = reinterpret_cast<int4*>(dp);
     int32_t k = 0, ks = 0;
-    int64_t tiles = 0, buckets = 0, segtiles = 0, merges = 0, scans = 0;
+    int64_t tiles = 0, buckets = 0, segtiles = 0, merges = 0, scans = 0, sync_words = 0;
     size_t lds_hist = 0;
     bool small_scan = true;
     while (c0 < n_cols && k < kMaxCols) {
@@ -1490,7 +1714,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       d.part_vals = reinterpret_cast<float*>(((uintptr_t)wp + 15) & ~(uintptr_t)15);
       wp += align8((size_t)h.n_ids * h.dim * 4) + 16;
       d.no_emit = 0;
-      d.pad2_ = 0;
+      d.sync0 = 0;
       if (h.grad_rows == nullptr) {
         d.no_emit = 1;
         d.unique_rows = reinterpret_cast<int64_t*>(wp);
@@ -1505,6 +1729,8 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       d.scan0 = (int32_t)scans;
       scans += ((int64_t)p.n_buckets + kBlock - 1) / kBlock;
       small_scan = small_scan && p.n_buckets <= 4 * kBlock && p.tiles <= 64;
+      d.sync0 = (int32_t)sync_words;
+      sync_words += (int64_t)p.tiles * p.n_buckets;
       d.run_start = h.run_start;
       d.run_ids = h.run_ids;
       d.run_grads = h.run_grads;
@@ -1563,17 +1789,39 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       hipLaunchKernelGGL(bwd_segof_kernel, dim3((unsigned)segtiles), dim3(kBlock), 0, stream,
                          seg_args);
     }
-    hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist, stream,
-                       args);
-    if (small_scan) {
+    GSync sync;
+    memset(&sync, 0, sizeof(sync));
+    bool onepass = small_scan && options().bwd_onepass != 0 && sync_words < (1ll << 30);
+    if (onepass) {
+      SyncTake take;
+      onepass = sync_take(stream, (size_t)sync_words, &take);
+      if (onepass) {
+        sync.hist = take.words;
+        sync.zero = take.zero;
+        sync.zero_words = take.zero_words;
+        sync.status = take.status;
+      }
+    }
+    if (onepass) {
+      hipLaunchKernelGGL(bwd_group_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, stream, args,
+                         sync);
+    } else {
+      hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist, stream,
+                         args);
+    }
+    if (onepass) {
+      // (hist, scan and scatter were that one launch)
+    } else if (small_scan) {
       hipLaunchKernelGGL(bwd_scan_fused_kernel, dim3((unsigned)k), dim3(kBlock), 0, stream, args);
     } else {
       hipLaunchKernelGGL(bwd_scan_tiles_kernel, dim3((unsigned)scans), dim3(kBlock), 0, stream,
                          args);
       hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)k), dim3(kBlock), 0, stream, args);
     }
-    hipLaunchKernelGGL(bwd_scatter_pairs_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist,
-                       stream, args);
+    if (!onepass) {
+      hipLaunchKernelGGL(bwd_scatter_pairs_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist,
+                         stream, args);
+    }
     bool any_vec4 = false, any_scalar = false;
     for (int32_t q = 0; q < k; ++q) {
       any_vec4 |= args.col[q].vec4 != 0;
@@ -1603,7 +1851,6 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     }
     if (any_vec4) hipLaunchKernelGGL(merge4, dim3((unsigned)merges), dim3(kBlock), 0, stream, args);
     if (any_scalar) hipLaunchKernelGGL(merge1, dim3((unsigned)merges), dim3(kBlock), 0, stream, args);
-    hipLaunchKernelGGL(bwd_finish_kernel, dim3(1), dim3(kWave), 0, stream, args);
     HBK_HIP_OK(hipGetLastError());
   }
   return HBK_OK;

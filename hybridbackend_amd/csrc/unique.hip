@@ -423,8 +423,9 @@ struct USync {
   int32_t* status;      // raised by a wait that ran out
 };
 
-__global__ __launch_bounds__(kBlock) void unique_group_kernel(const UArgs a, const USync y) {
+__global__ __launch_bounds__(kBlock, 4) void unique_group_kernel(const UArgs a, const USync y) {
   __shared__ int32_t counters[1 << kGroupMaxLog2P];   // counts, then bases
+  __shared__ int32_t tot_s[1 << kGroupMaxLog2P], pre_s[1 << kGroupMaxLog2P];
   __shared__ int32_t wave_tot[kWavesPerBlock];
   __shared__ int32_t gave_up;
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
@@ -463,50 +464,55 @@ __global__ __launch_bounds__(kBlock) void unique_group_kernel(const UArgs a, con
     __hip_atomic_store(hist + (int64_t)ctile * P + p, counters[p] + 1, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   }
-  // thread t owns buckets [t * per, t * per + per): their totals over the column's tiles and the
-  // part of the tiles before this one
-  const int per = P >= kBlock ? P / kBlock : 1;
-  const int p0 = tid * per;
-  int32_t tot[4] = {0, 0, 0, 0}, pre[4] = {0, 0, 0, 0};
+  // totals of every bucket over the column's tiles and the part of the tiles before this one
+  // (a thread per bucket, 16 tiles per poll), left in LDS for the scan
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
   bool lost = false;
-  if (p0 < P) {
-    // up to 16 tiles per poll (the 16 tiles of a 65536-id column: one wait, not two)
+#pragma unroll 1
+  for (int p = tid; p < P && !lost; p += kBlock) {
+    int32_t t_all = 0, t_pre = 0;
+#pragma unroll 1
     for (int t0 = 0; t0 < n_tiles && !lost; t0 += 16) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q >= per) break;
-        int32_t x[16];
-        for (;;) {
-          bool ok = true;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            x[e] = 1;
-            if (t0 + e < n_tiles) {
-              x[e] = __hip_atomic_load(hist + (int64_t)(t0 + e) * P + p0 + q, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            }
-            ok = ok && x[e] != 0;
-          }
-          if (ok) break;
-          if (__builtin_amdgcn_s_memrealtime() - t_begin > kSyncWaitTicks) {
-            lost = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (lost) break;
+      int32_t x[16];
+      for (;;) {
+        bool ok = true;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          tot[q] += x[e] - 1;
-          pre[q] += t0 + e < ctile ? x[e] - 1 : 0;
+          x[e] = 1;
+          if (t0 + e < n_tiles) {
+            x[e] = __hip_atomic_load(hist + (int64_t)(t0 + e) * P + p, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+          }
+          ok = ok && x[e] != 0;
         }
+        if (ok) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_begin > kSyncWaitTicks) {
+          lost = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (lost) break;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        t_all += x[e] - 1;
+        t_pre += t0 + e < ctile ? x[e] - 1 : 0;
       }
     }
+    tot_s[p] = t_all;
+    pre_s[p] = t_pre;
   }
   if (lost) gave_up = 1;
-  // bucket starts: exclusive scan of the totals in bucket order
-  int32_t mine = tot[0] + tot[1] + tot[2] + tot[3];
+  __syncthreads();
+  if (gave_up != 0) {
+    if (tid == 0) __hip_atomic_store(y.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  // bucket starts: thread t scans buckets [t * per, t * per + per)
+  const int per = P >= kBlock ? P / kBlock : 1;
+  const int p0 = tid * per;
+  int32_t mine = 0;
+  for (int q = 0; q < per; ++q) mine += p0 + q < P ? tot_s[p0 + q] : 0;
   int32_t incl = mine;
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
@@ -515,20 +521,14 @@ __global__ __launch_bounds__(kBlock) void unique_group_kernel(const UArgs a, con
   }
   if (lane == kWave - 1) wave_tot[wave] = incl;
   __syncthreads();
-  if (gave_up != 0) {
-    if (tid == 0) __hip_atomic_store(y.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return;
-  }
   int32_t run = incl - mine;
   for (int w = 0; w < wave; ++w) run += wave_tot[w];
-  if (p0 < P) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q >= per) break;
-      counters[p0 + q] = run + pre[q];
-      if (ctile == 0) c.bstart[p0 + q] = run;
-      run += tot[q];
-    }
+  for (int q = 0; q < per; ++q) {
+    const int pp = p0 + q;
+    if (pp >= P) break;
+    counters[pp] = run + pre_s[pp];
+    if (ctile == 0) c.bstart[pp] = run;
+    run += tot_s[pp];
   }
   if (ctile == 0 && tid == 0) c.bstart[P] = c.len;
   __syncthreads();

@@ -215,6 +215,40 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
            (long long)B, dim, (long long)rows,
            step_only ? ", SGD step only" : lr != 0.f ? " + SGD apply" : "");
   printf("%-66s %9.2f us  %8.1f M lookups/s\n", what, us, n / us);
+  {  // probe build: stamps of the grouping kernel's workgroups
+    typedef int (*trace_fn)(unsigned long long*, int);
+    trace_fn fn = (trace_fn)dlsym(RTLD_DEFAULT, "hbk_debug_grp_trace");
+    if (fn != nullptr) {
+      std::vector<unsigned long long> tr(8192 * 8);
+      fn(nullptr, 1);
+      fill(0);
+      HB(hbk_group_lookup_bwd(n_cols, cols.data(), lr, ws, ws_bytes, nullptr));
+      fn(tr.data(), 0);
+      static const char* names[7] = {"column + clear + issue loads", "ids arrive + ranks", "publish",
+                                     "wait + sums", "scan + offsets", "issue stores", "stores land"};
+      double sum[7] = {0}, life = 0;
+      unsigned long long t_min = ~0ull, t_max = 0, last_start = 0, last_pub = 0;
+      int nb = 0;
+      for (int b = 0; b < 8192; ++b) {
+        const unsigned long long* t = &tr[(size_t)b * 8];
+        if (t[0] == 0 || t[7] == 0) continue;
+        ++nb;
+        for (int i = 0; i < 7; ++i) sum[i] += (double)(t[i + 1] - t[i]);
+        life += (double)(t[7] - t[0]);
+        t_min = t[0] < t_min ? t[0] : t_min;
+        t_max = t[7] > t_max ? t[7] : t_max;
+        last_start = t[0] > last_start ? t[0] : last_start;
+        last_pub = t[3] > last_pub ? t[3] : last_pub;
+      }
+      if (nb > 0) {
+        printf("   group kernel: %d traced workgroups over %.2f us, mean life %.2f us; last starts at %.2f us, "
+               "last publish at %.2f us; per phase (us):", nb, (t_max - t_min) * 0.01, life / nb * 0.01,
+               (last_start - t_min) * 0.01, (last_pub - t_min) * 0.01);
+        for (int i = 0; i < 7; ++i) printf("  %s %.2f", names[i], sum[i] / nb * 0.01);
+        printf("\n");
+      }
+    }
+  }
   {  // probe build of the library (-DHBK_BWD_STAMPS): shader-clock stamps of the reduce workgroups
     typedef int (*trace_fn)(unsigned long long*, int);
     trace_fn fn = (trace_fn)dlsym(RTLD_DEFAULT, "hbk_debug_bwd_trace");

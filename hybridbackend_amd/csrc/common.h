@@ -128,7 +128,7 @@ struct Options {
   int partition_fixed_max = 8;   // HBK_PART_FIXED
   int partition_onepass = 1;     // HBK_PART_ONEPASS: 0 = always the three-launch path
   int unique_onepass = 1;        // HBK_UNIQUE_ONEPASS: 0 = always the nine-launch path
-  int sharded_groups = 2;        // HBK_SHARDED_GROUPS: column groups a sharded step pipelines
+  int sharded_groups = 0;        // HBK_SHARDED_GROUPS: column groups a sharded step pipelines (0: 2, or 1 on one rank)
   int sharded_id64 = 0;          // HBK_SHARDED_ID64: keep int64 ids on the wire
   int sharded_copy_self = 0;     // HBK_SHARDED_COPY_SELF: own slice through a device copy
   int sharded_trace = 0;         // HBK_SHARDED_TRACE: host-side phase times on stderr

@@ -489,8 +489,9 @@ int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* cons
 // behind the exchanges (exposed compute ~ 1/G of it) at the price of G x more launches and
 // smaller kernels: measured on one rank 298 us (G = 1), 318 us (G = 2), 455 us (G = 4) per
 // forward step.  2 until an 8-GPU measurement says otherwise; option sharded_groups overrides (1..4).
-int pipeline_groups(int n_cols, int requested) {
+int pipeline_groups(int n_cols, int world, int requested) {
   int g = requested >= 1 && requested <= 4 ? requested : 2;
+  if (world == 1 && !(requested >= 1 && requested <= 4)) g = 1;   // nothing on the wire to hide
   return g < n_cols ? g : n_cols;
 }
 
@@ -576,7 +577,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   // ids of group g+1 are on the wire, and stitches group g while the rows of group g+1 travel:
   //   comm    : ids(0) ids(1) ...            rows(0)      rows(1) ...
   //   compute : pack(0..G-1)      gather(0)  gather(1) ..      stitch(0)   stitch(1)
-  const int G = pipeline_groups(N, p->n_groups);
+  const int G = pipeline_groups(N, W, p->n_groups);
   std::vector<Group>& groups = p->groups;
   groups.assign(G, Group());
   int64_t tot_req_ids = 0, tot_own_ids = 0, tot_own_floats = 0, tot_req_floats = 0;
@@ -699,9 +700,12 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     }
   }
   if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
-  HBK_HIP_OK(hipEventRecord(p->ev[0][0], stream));
+  // one rank with its own slice left in place: nothing goes on the wire, the step stays on the
+  // compute stream (no hops to the communicator's stream and back)
+  const bool wire = !(W == 1 && zc);
+  if (wire) HBK_HIP_OK(hipEventRecord(p->ev[0][0], stream));
   // stage B: ids exchanges, back to back on the communicator's stream
-  for (int g = 0; g < G; ++g) {
+  for (int g = 0; g < G && wire; ++g) {
     const Group& gr = groups[g];
     rc = exchange(p, id_dtype, id_dtype, ids_send_base + gr.id_send * id_bytes,
                   gr.lay.ids_send_peer.data(), ids_recv_base + gr.id_recv * id_bytes,
@@ -713,7 +717,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   for (int g = 0; g < G; ++g) {
     const Group& gr = groups[g];
     const int ng = gr.c1 - gr.c0;
-    HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
+    if (wire) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
     std::vector<hbk_lookup_column_t> v;
     v.reserve((size_t)ng * W);
     for (int q = 0; q < W; ++q) {
@@ -742,6 +746,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     }
     rc = hbk_group_lookup_fwd((int32_t)v.size(), v.data(), stream_);
     if (rc != HBK_OK) return rc;
+    if (!wire) continue;
     HBK_HIP_OK(hipEventRecord(p->ev[2][g], stream));
     rc = exchange(p, HBK_FLOAT, p->wire_dtype, rows_send_base + gr.row_send,
                   gr.lay.rows_send_peer.data(), rows_recv_base + gr.row_recv,
@@ -756,7 +761,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   for (int g = 0; g < G; ++g) {
     const Group& gr = groups[g];
     const int ng = gr.c1 - gr.c0;
-    HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[3][g], 0));
+    if (wire) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[3][g], 0));
     std::vector<hbk_lookup_column_t> v(ng);
     for (int c = 0; c < ng; ++c) {
       const int cc = gr.c0 + c;
@@ -844,6 +849,7 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
   const int N = p->N, W = p->W;
   const int32_t* R = p->recv_sizes.data();
   const int G = (int)p->groups.size();
+  const bool wire = !(W == 1 && p->zero_copy_self);   // (see the forward)
   float* rows_send_base = p->send_rows_p;
   float* rows_recv_base = p->recv_rows_p;
   const int64_t* d_start = reinterpret_cast<const int64_t*>(p->runs_dev.ptr);
@@ -881,10 +887,10 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
     }
     rc = hbk_group_stitch_bwd(ng, v.data(), stream_);
     if (rc != HBK_OK) return rc;
-    HBK_HIP_OK(hipEventRecord(p->ev[0][g], stream));
+    if (wire) HBK_HIP_OK(hipEventRecord(p->ev[0][g], stream));
   }
   // ---- B2 reverse exchanges (the forward's sizes, swapped: collective.py:334-347) -------------
-  for (int g = 0; g < G; ++g) {
+  for (int g = 0; g < G && wire; ++g) {
     const Group& gr = p->groups[g];
     rc = exchange(p, HBK_FLOAT, p->wire_dtype, rows_recv_base + gr.row_recv,
                   gr.lay.rows_recv_peer.data(), rows_send_base + gr.row_send,
@@ -927,7 +933,7 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
   if ((rc = p->bwd_ws.ensure(ws + 8)) != HBK_OK) return rc;
   for (int g = 0; g < G; ++g) {
     const Group& gr = p->groups[g];
-    HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
+    if (wire) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
     rc = hbk_group_lookup_bwd_apply(gr.c1 - gr.c0, v.data() + gr.c0, apply, apply_lr,
                                     p->bwd_ws.ptr, p->bwd_ws.bytes, stream_);
     if (rc != HBK_OK) return rc;

@@ -285,7 +285,10 @@ class ShardedGroupLookup:
         res.append(tuple(outs[c]))
         continue
       if not emit:
-        res.append((None, None, torch.zeros(1, dtype=torch.int32, device=self.device)))
+        # the counts live in one buffer of the driver, written by every call
+        if getattr(self, '_nu_step', None) is None:
+          self._nu_step = torch.zeros(n, dtype=torch.int32, device=self.device)
+        res.append((None, None, self._nu_step[c:c + 1]))
         continue
       res.append((torch.empty(k, dtype=torch.int64, device=self.device),
                   torch.empty((k, self.dims[c]), dtype=torch.float32, device=self.device),

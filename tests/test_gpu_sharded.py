@@ -98,7 +98,11 @@ def test_sharded_forward_equals_unsharded(world, wire16):
       np.testing.assert_equal(outs[c].cpu().numpy(), want[c])
 
 
-def test_sharded_call_through_rccl_world1():
+@pytest.mark.parametrize('groups', [0, 2, 3])
+def test_sharded_call_through_rccl_world1(hbk_option, groups):
+  # one rank pipelines ONE column group by default (nothing on the wire to hide); the option
+  # forces the multi-group pipeline of W > 1 through the same calls
+  hbk_option('sharded_groups', groups)
   rng = np.random.RandomState(7)
   coll = hb.distribute.Collective(world_size=1, rank=0)
   try:

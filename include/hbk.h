@@ -70,11 +70,18 @@ const char* hbk_last_error(void);
 const char* hbk_version(void);
 /* Tuning / diagnostic options of the library, process wide.  Defaults come from the environment
  * once, when the library is first used (HBK_BWD_LOG2P, HBK_BWD_TARGET, HBK_BWD_SPLIT,
- * HBK_UNIQUE_LOG2P, HBK_PART_SUB, HBK_PART_FIXED, HBK_SHARDED_GROUPS, HBK_SHARDED_ID64,
- * HBK_SHARDED_COPY_SELF, HBK_SHARDED_TRACE); no entry point reads the environment per call.
- * Names: bwd_buckets_log2, bwd_bucket_pairs, bwd_split_pairs, unique_buckets_log2,
- * partition_sub_tiles, partition_fixed_max, sharded_groups, sharded_id64, sharded_copy_self,
- * sharded_trace (the sharded_* ones are taken by hbk_sharded_create). */
+ * HBK_BWD_ONEPASS, HBK_UNIQUE_LOG2P, HBK_UNIQUE_ONEPASS, HBK_PART_SUB, HBK_PART_FIXED,
+ * HBK_PART_ONEPASS, HBK_SHARDED_GROUPS, HBK_SHARDED_ID64, HBK_SHARDED_COPY_SELF,
+ * HBK_SHARDED_TRACE); no entry point reads the environment per call.
+ * Names: bwd_buckets_log2, bwd_bucket_pairs, bwd_split_pairs, bwd_onepass, unique_buckets_log2,
+ * unique_onepass, partition_sub_tiles, partition_fixed_max, partition_onepass, sharded_groups,
+ * sharded_id64, sharded_copy_self, sharded_trace (the sharded_* ones are taken by
+ * hbk_sharded_create).
+ * *_onepass (default 1): small calls of partition / unique / the backward group their ids in ONE
+ * launch whose tiles wait for each other; 0 keeps the multi-launch forms.  The
+ * waits are bounded: a launch that gave up (never seen) makes the NEXT call of these entries
+ * return HBK_INTERNAL.  The words the tiles poll live in buffers the library keeps per (device,
+ * stream): calls that share a stream are ordered, which is all these entries ask of the caller. */
 int hbk_set_option(const char* name, int32_t value);
 int hbk_get_option(const char* name, int32_t* value);
 /* the kernels' divide-free floor-mod / floor-div (multiply-high by a

@@ -21,19 +21,43 @@ def unique_n(ids_list):
     _lib.require_device_tensor(t, 'ids')
     if t.dtype != torch.int64 or t.dim() != 1:
       raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, 'ids must be an int64 vector')
-  lens = _lib.i64_array([t.numel() for t in ids_list])
-  uniq = [torch.empty_like(t) for t in ids_list]
-  idx = [torch.empty(t.numel(), dtype=torch.int32, device=dev) for t in ids_list]
-  nu = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in ids_list]
+  counts = [int(t.numel()) for t in ids_list]
+  lens = _lib.i64_array(counts)
+  # three allocations for all columns; views from one split call each, addresses by arithmetic
+  # (every count is written by the call: no zero fill)
+  total = sum(counts)
+  flat_u = torch.empty(total, dtype=torch.int64, device=dev)
+  flat_i = torch.empty(total, dtype=torch.int32, device=dev)
+  flat_n = torch.empty(n, dtype=torch.int32, device=dev)
+  uniq = torch.split(flat_u, counts)
+  idx = torch.split(flat_i, counts)
+  nu = torch.split(flat_n, 1)
+  offs = [0] * n
+  for c in range(1, n):
+    offs[c] = offs[c - 1] + counts[c - 1]
+  pu, pi, pn = flat_u.data_ptr(), flat_i.data_ptr(), flat_n.data_ptr()
   need = lib.hbk_unique_workspace_bytes(n, lens)
-  ws = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
+  ws = _workspace(max(need, 8), dev)
   _lib.check(lib.hbk_unique_n(
     n, _lib.ptr_array([t.data_ptr() for t in ids_list]), lens,
-    _lib.ptr_array([t.data_ptr() for t in uniq]),
-    _lib.ptr_array([t.data_ptr() for t in idx]),
-    _lib.ptr_array([t.data_ptr() for t in nu]),
+    _lib.ptr_array([pu + 8 * o for o in offs]),
+    _lib.ptr_array([pi + 4 * o for o in offs]),
+    _lib.ptr_array([pn + 4 * c for c in range(n)]),
     C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), _lib.current_stream(dev)))
   return list(zip(uniq, idx, nu))
+
+
+_ws = {}
+
+
+def _workspace(nbytes, dev):
+  """Grow-only scratch, one per (device, stream) like the partition op's."""
+  key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+  buf = _ws.get(key)
+  if buf is None or buf.numel() < nbytes:
+    buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+    _ws[key] = buf
+  return buf
 
 
 def unique(ids):

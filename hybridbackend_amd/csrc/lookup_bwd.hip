@@ -803,6 +803,17 @@ __device__ inline int table_slot(ReduceLds& L, unsigned long long row) {
   }
 }
 
+// Look `row` up without entering it (the table is still: no insert runs beside this).
+__device__ inline int table_find(const ReduceLds& L, unsigned long long row) {
+  int h = (int)(mix32(row) & (kSlots - 1));
+  for (;;) {
+    const unsigned long long k = L.keys[h];
+    if (k == row) return h;
+    if (k == kEmptyKey) return -1;
+    h = (h + 1) & (kSlots - 1);
+  }
+}
+
 // STEP: 0 = no fused optimizer step (none of its loads, registers and branches), 1 = SGD,
 // 2 = Adagrad (accumulator rows as well).
 template <typename V, int STEP>
@@ -910,11 +921,28 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         }
         if (e < n_chunk) L.pslot[e] = valid && h >= 0 ? (uint16_t)h : kNoSlot;
         if (valid && h < 0) atomicAdd(&L.n_left, 1);
-        hs_[k] = valid && h >= 0 ? h : -1;
+        hs_[k] = valid && h >= 0 ? h : (valid ? -2 : -1);   // -2: found no room
         tk_[k] = ticket;
         row_[k] = row;
       }
       team_sync();
+      if (L.n_left > 0) {   // uniform: nobody changes it before the next pass
+        // A pair that found no room may belong to a row another lane entered in the same instant
+        // (it read the slot before that lane's CAS and the fill level after it): the next pass
+        // would enter the row a second time and emit it twice.  The table is still now: look again.
+#pragma unroll
+        for (int k = 0; k < kCP / kTeam; ++k) {
+          if (hs_[k] == -2) {
+            const int h = table_find(L, row_[k]);
+            if (h >= 0) {
+              tk_[k] = atomicAdd(&L.cnt[h], 1);
+              L.pslot[k * kTeam + tid] = (uint16_t)h;
+            }
+            hs_[k] = h >= 0 ? h : -1;
+          }
+        }
+        team_sync();
+      }
       HBK_STAMP(3);
 
       // One global atomic per workgroup and chunk claims the output range of the new rows.  A

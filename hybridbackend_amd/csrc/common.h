@@ -138,7 +138,7 @@ Options& options();
 // Zeroed words for kernels whose tiles wait for each other (sync.hip).  sync_take: `words` zeroed
 // int32 of the stream's buffer for this call; the call's FIRST kernel must clear zero[0,
 // zero_words) (what the call before left set).  false while the stream is being captured into a
-// graph (or without memory): the caller clears its own words with a memset node instead.
+// graph (or without memory): the caller takes its multi-launch form instead.
 struct SyncTake {
   int32_t* words;
   int32_t* zero;

@@ -855,9 +855,9 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
     const size_t words = (size_t)all_tiles * (size_t)P;
     SyncTake take;
     if (!sync_take(stream, words, &take)) {
-      // (a graph replays the same launch: no state may alternate between calls) the caller's
-      // workspace, cleared by one memset node in front of the kernel
-      HBK_HIP_OK(hipMemsetAsync(hist, 0, words * sizeof(int32_t), stream));
+      // the stream is being captured into a graph (a graph replays ONE recorded launch: no state
+      // may alternate between calls), or there is no memory for the words: three launches
+      onepass = false;
     } else {
       hist = take.words;
       one.zero = take.zero;

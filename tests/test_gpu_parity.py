@@ -831,3 +831,51 @@ def test_partition_from_concurrent_streams():
   for t in threads:
     t.join(timeout=45)
   assert not errors, errors
+
+
+@pytest.mark.parametrize('which', ['partition', 'unique', 'backward'])
+def test_ops_inside_a_captured_graph(which):
+  """hipGraph capture of the id-grouping ops: a graph replays ONE recorded launch, so the
+  one-launch kernels cannot alternate the halves of their sync words between calls -- under
+  capture partition, unique and the backward record their multi-launch forms.  Replays with new ids in the same buffers stay equal to the oracle."""
+  rng = np.random.RandomState(99)
+  n, P, rows, d = 30000, 8, 5000, 16
+  ids_dev = torch.zeros(n, dtype=torch.int64, device=DEV)
+  g_dev = torch.zeros(n, d, device=DEV)
+  table = torch.zeros(rows, d, device=DEV)
+  lookup = hb.embedding.GroupLookup([table], [rows], 'sum')
+  grad = hb.embedding.GroupLookupGrad(lookup)
+
+  def step():
+    part = hb.distribute.partition_by_modulo_n([ids_dev], P) if which == 'partition' else None
+    uniq = hb.embedding.unique_n([ids_dev]) if which == 'unique' else None
+    slices = grad([ids_dev], [g_dev]) if which == 'backward' else None
+    return part, uniq, slices
+
+  side = torch.cuda.Stream()
+  with torch.cuda.stream(side):       # warm-up on the capture stream (allocations, lazy set-up)
+    step()
+  torch.cuda.synchronize()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph, stream=side):
+    part, uniq, slices = step()
+  for rep in range(3):
+    ids = rng.randint(0, 2**40, size=n).astype(np.int64)
+    grads = rng.randn(n, d).astype(np.float32)
+    ids_dev.copy_(dev(ids))
+    g_dev.copy_(dev(grads))
+    graph.replay()
+    torch.cuda.synchronize()
+    if which == 'partition':
+      oy, os_, oi = oracle.partition_by_modulo(ids, P)
+      np.testing.assert_equal(host(part[0][0]), oy)
+      np.testing.assert_equal(host(part[1][0]), os_)
+      np.testing.assert_equal(host(part[2][0]), oi)
+    elif which == 'unique':
+      ou, oidx = oracle.unique(ids)
+      k = int(uniq[0][2].item())
+      assert k == ou.size
+      np.testing.assert_equal(host(uniq[0][0])[:k], ou)
+      np.testing.assert_equal(host(uniq[0][1]), oidx)
+    else:
+      _check_slices(slices[0], ids % rows, grads, None, 'sum', atol=RTOL * 30)

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
 }
 
 // ---- 1-3 in one launch ---------------------------------------------------------------------------
-// Columns of <= 1024 buckets and <= 64 tiles (every column of a 65536-id step): a tile keeps its
+// Columns of <= 512 buckets and <= 64 tiles (every column of a 65536-id step): a tile keeps its
 // rows, their buckets and their ranks inside the tile's share of the bucket (what the LDS atomic
 // returns) in registers, publishes its bucket counts (count + 1 into words that read zero when
 // the kernel starts, sync.hip) and waits for the other tiles of its column -- all resident:
@@ -491,6 +491,8 @@ __device__ unsigned long long g_grp_trace[kTraceBlocks * kTraceSlots];
 #define HBK_GSTAMP(i)
 #endif
 
+constexpr int kGroupMaxBuckets = 2 * kBlock;   // (64 tiles of 2048 ids at ~448 per bucket: 293)
+
 struct GSync {
   int32_t* hist;        // per column [tiles][n_buckets] words: 0 = not published, else count + 1
   int32_t* zero;        // words the call before left set
@@ -499,12 +501,17 @@ struct GSync {
 };
 
 // (5 waves per SIMD: all 832 workgroups of a 26 x 65536 call resident at once; at 145 VGPRs the
-// last 64 started 21 us late and the kernel took as long as the three launches it replaces)
-__global__ __launch_bounds__(kBlock, 5) void bwd_group_kernel(const GArgs a, const GSync y) {
-  __shared__ int32_t counters[4 * kBlock];   // counts of the tile, then its offsets
-  __shared__ int32_t tot_s[4 * kBlock], pre_s[4 * kBlock];   // bucket totals / before this tile
-  __shared__ int32_t wave_tot[kWavesPerBlock];
-  __shared__ int32_t n_extra, gave_up;
+// last 64 started 21 us late and the kernel took as long as the three launches it replaces;
+// with the staged scatter's 28 KB of LDS four workgroups fit a CU: 1024 slots)
+__global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, const GSync y) {
+  __shared__ int32_t counters[kGroupMaxBuckets];   // pairs of the tile per bucket
+  __shared__ int32_t tot_s[kGroupMaxBuckets], pre_s[kGroupMaxBuckets];   // bucket totals / before
+                                                   // this tile; then position deltas / first slots
+  __shared__ int64_t st_row[kTile];                          // the tile's pairs, sorted by bucket
+  __shared__ int32_t st_seg[kTile];
+  __shared__ uint16_t st_b[kTile];
+  __shared__ int32_t wave_tot[kWavesPerBlock], wave_cnt[kWavesPerBlock];
+  __shared__ int32_t n_extra, gave_up, n_staged;
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   HBK_GSTAMP(0);
   for (int64_t j = (int64_t)blockIdx.x * kBlock + tid; j < y.zero_words;
@@ -607,26 +614,42 @@ __global__ __launch_bounds__(kBlock, 5) void bwd_group_kernel(const GArgs a, con
     if (tid == 0) __hip_atomic_store(y.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
-  // bucket starts: thread t scans buckets [t * per, t * per + per)
+  // bucket starts (scan of the column's totals) and, for the staged scatter, the tile's own
+  // bucket offsets (scan of its counts): thread t scans buckets [t * per, t * per + per)
   const int per = (P + kBlock - 1) / kBlock;   // <= 4
   const int beg = tid * per;
   const int end = beg + per < P ? beg + per : P;
-  int32_t sum = 0;
-  for (int p = beg; p < end; ++p) sum += tot_s[p];
-  int32_t incl = sum;
+  int32_t sum = 0, sum_c = 0;
+  for (int p = beg; p < end; ++p) {
+    sum += tot_s[p];
+    sum_c += counters[p];
+  }
+  int32_t incl = sum, incl_c = sum_c;
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
     const int32_t v = __shfl_up(incl, off, kWave);
-    if (lane >= off) incl += v;
+    const int32_t w = __shfl_up(incl_c, off, kWave);
+    if (lane >= off) {
+      incl += v;
+      incl_c += w;
+    }
   }
-  if (lane == kWave - 1) wave_tot[wave] = incl;
+  if (lane == kWave - 1) {
+    wave_tot[wave] = incl;
+    wave_cnt[wave] = incl_c;
+  }
   __syncthreads();
-  int32_t run = incl - sum;
-  for (int w = 0; w < wave; ++w) run += wave_tot[w];
+  int32_t run = incl - sum, run_c = incl_c - sum_c;
+  for (int w = 0; w < wave; ++w) {
+    run += wave_tot[w];
+    run_c += wave_cnt[w];
+  }
   const bool first_tile = ctile == 0;
   for (int p = beg; p < end; ++p) {
     const int32_t n_b = tot_s[p];
-    counters[p] = run + pre_s[p];
+    const int32_t n_c = counters[p];
+    tot_s[p] = run + pre_s[p] - run_c;   // global position of the tile's pair at staged slot L: + L
+    pre_s[p] = run_c;                    // first staged slot of the bucket
     if (first_tile) {
       c.bstart[p] = run;
       c.desc[p] = make_int4(run, n_b, p, 0);
@@ -642,7 +665,9 @@ __global__ __launch_bounds__(kBlock, 5) void bwd_group_kernel(const GArgs a, con
       }
     }
     run += n_b;
+    run_c += n_c;
   }
+  if (tid == kBlock - 1) n_staged = run_c;   // the last thread's running count: pairs of the tile
   __syncthreads();
   if (first_tile) {
     for (int e = n_extra + tid; e < c.e_max; e += kBlock) c.desc[P + e] = make_int4(0, 0, -1, 0);
@@ -654,12 +679,29 @@ __global__ __launch_bounds__(kBlock, 5) void bwd_group_kernel(const GArgs a, con
     }
   }
   HBK_GSTAMP(5);            // offsets known
+  // The tile's pairs go through LDS sorted by bucket and leave in that order: consecutive lanes
+  // store consecutive positions of a bucket's run (~14 pairs = 112 + 56 bytes) instead of 64
+  // different buckets, i.e. 64 different lines, per store instruction (the direct scatter spent
+  // 6.3 us of the tile's 22 us issuing its 16 store instructions).
 #pragma unroll
   for (int k = 0; k < kPerThread; ++k) {
     if (br[k] >= 0) {
-      const int32_t pos = counters[br[k] & 1023] + (br[k] >> 10);
-      c.pair_row[0][pos] = id[k];
-      c.pair_seg[0][pos] = seg[k];
+      const int b = br[k] & 1023;
+      const int L = pre_s[b] + (br[k] >> 10);
+      st_row[L] = id[k];
+      st_seg[L] = seg[k];
+      st_b[L] = (uint16_t)b;
+    }
+  }
+  __syncthreads();
+  const int n_st = n_staged;
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int L = k * kBlock + tid;
+    if (L < n_st) {
+      const int32_t pos = tot_s[st_b[L]] + L;
+      c.pair_row[0][pos] = st_row[L];
+      c.pair_seg[0][pos] = st_seg[L];
     }
   }
   HBK_GSTAMP(6);            // stores issued
@@ -1696,7 +1738,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     int32_t k = 0, ks = 0;
     int64_t tiles = 0, buckets = 0, segtiles = 0, merges = 0, scans = 0, sync_words = 0;
     size_t lds_hist = 0;
-    bool small_scan = true;
+    bool small_scan = true, group_ok = true;
     while (c0 < n_cols && k < kMaxCols) {
       const hbk_lookup_grad_column_t& h = cols[c0++];
       if (h.n_ids == 0) {
@@ -1757,6 +1799,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       d.scan0 = (int32_t)scans;
       scans += ((int64_t)p.n_buckets + kBlock - 1) / kBlock;
       small_scan = small_scan && p.n_buckets <= 4 * kBlock && p.tiles <= 64;
+      group_ok = group_ok && p.n_buckets <= kGroupMaxBuckets;
       d.sync0 = (int32_t)sync_words;
       sync_words += (int64_t)p.tiles * p.n_buckets;
       d.run_start = h.run_start;
@@ -1819,7 +1862,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     }
     GSync sync;
     memset(&sync, 0, sizeof(sync));
-    bool onepass = small_scan && options().bwd_onepass != 0 && sync_words < (1ll << 30);
+    bool onepass = small_scan && group_ok && options().bwd_onepass != 0 && sync_words < (1ll << 30);
     if (onepass) {
       SyncTake take;
       onepass = sync_take(stream, (size_t)sync_words, &take);

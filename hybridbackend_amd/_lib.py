@@ -183,6 +183,13 @@ def set_option(name, value):
   return old.value
 
 
+def get_option(name):
+  """hbk_get_option: current value of a process-wide option."""
+  v = C.c_int32()
+  check(lib().hbk_get_option(name.encode(), C.byref(v)))
+  return v.value
+
+
 def check(status):
   if status != OK:
     msg = lib().hbk_last_error().decode('utf-8', 'replace')

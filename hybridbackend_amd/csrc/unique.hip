@@ -17,10 +17,11 @@
 //                per-1024-id-tile ballot + popcount ranks and a scan give its place in the
 //                unique list -- order of first occurrence, exactly as TF's CPU kernel emits.
 // Columns of <= 262144 ids (the owner side of a step) take FOUR launches instead of the nine:
-//   group   1-3 in one: a 4096-id tile keeps its keys and their ranks inside the tile (the value
+//   group   1-3 in one: a 2048-id tile keeps its keys and their ranks inside the tile (the value
 //           the LDS atomic returns) in registers, publishes its bucket counts and waits for the
-//           other tiles of its column (all resident: <= 64 workgroups; sync.hip), derives the
-//           bucket starts and its own offsets from all of them and scatters from registers
+//           other tiles of its column (all resident: <= 128 workgroups; sync.hip), derives the
+//           bucket starts and its own offsets from all of them and stores its pairs staged
+//           through LDS sorted by bucket (coalesced runs)
 //   first   4, unchanged
 //   order   5-7 in one: a 1024-id tile publishes its count of first occurrences and sums the
 //           counts of the tiles BEFORE it (decoupled look-back: aggregate / inclusive-prefix words)
@@ -39,7 +40,7 @@ constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kPerThread = 4;
 constexpr int kTile = kBlock * kPerThread;   // 1024 ids: count / emit / index tiles
-constexpr int kBigTile = 4096;               // hist / scatter tiles
+constexpr int kBigTile = 2048;               // hist / scatter / group tiles
 constexpr int kBigPerThread = kBigTile / kBlock;
 constexpr int kBatch = 8;
 constexpr int kMaxCols = 96;
@@ -47,6 +48,22 @@ constexpr int kSlots = 2048;
 constexpr int kFirstBlock = kBlock;   // threads of the per-bucket kernel
 constexpr int kMaxBuckets = 8192;
 constexpr unsigned long long kEmpty = ~0ull;  // key -1 never enters the table (own counter)
+
+// Probe builds only (-DHBK_PART_STAMPS, tools/Makefile): constant-clock stamps of the first
+// workgroups of one kernel (picked by g_uni_which: 0 group, 1 first, 2 order).
+#ifdef HBK_PART_STAMPS
+constexpr int kUTraceBlocks = 8192, kUTraceSlots = 8;
+__device__ unsigned long long g_uni_trace[kUTraceBlocks * kUTraceSlots];
+__device__ int g_uni_which;
+#define HBK_USTAMP(w, i)                                                                       \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < kUTraceBlocks && g_uni_which == (w)) {                \
+      g_uni_trace[blockIdx.x * kUTraceSlots + (i)] = __builtin_amdgcn_s_memrealtime();         \
+    }                                                                                          \
+  } while (0)
+#else
+#define HBK_USTAMP(w, i)
+#endif
 
 struct UCol {
   const int64_t* in;
@@ -232,15 +249,18 @@ __global__ __launch_bounds__(kFirstBlock) void unique_first_kernel(const UArgs a
   HBK_FIND_UCOL(bucket0)
   const int bucket = (int)blockIdx.x - c.bucket0;
   const int tid = (int)threadIdx.x;
+  HBK_USTAMP(1, 0);
   const int32_t start = c.bstart[bucket];
   const int32_t n = c.bstart[bucket + 1] - start;
   if (n == 0) return;
+  HBK_USTAMP(1, 1);
   for (int i = tid; i < kSlots; i += kFirstBlock) {
     keys[i] = kEmpty;
     first[i] = 0xffffffffu;
   }
   if (tid == 0) first_m1 = 0xffffffffu;
   __syncthreads();
+  HBK_USTAMP(1, 2);
   const int64_t* pkey = c.pair_key + start;
   const int32_t* pidx = c.pair_idx + start;
   // A round = kFirstKeys pairs per thread, all loads in flight at once; buckets aim at 512 pairs,
@@ -277,6 +297,7 @@ __global__ __launch_bounds__(kFirstBlock) void unique_first_kernel(const UArgs a
     }
   }
   __syncthreads();
+  HBK_USTAMP(1, 3);
   const bool one_round = n <= kRound;
   for (int32_t r0 = 0; r0 < n; r0 += kRound) {
     if (!one_round) {
@@ -313,6 +334,13 @@ __global__ __launch_bounds__(kFirstBlock) void unique_first_kernel(const UArgs a
       c.first[idx[k]] = (int32_t)f;
     }
   }
+  HBK_USTAMP(1, 4);
+#ifdef HBK_PART_STAMPS
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  HBK_USTAMP(1, 5);
+  HBK_USTAMP(1, 6);
+  HBK_USTAMP(1, 7);
+#endif
 }
 
 // flags of the 4 consecutive ids owned by this thread: bit e set iff id i0+e is the first
@@ -412,8 +440,8 @@ __global__ __launch_bounds__(kBlock) void unique_emit_kernel(const UArgs a) {
 }
 
 // ---- 1-3 in one launch ---------------------------------------------------------------------------
-constexpr int kGroupMaxTiles = 64;     // 4096-id tiles per column
-constexpr int kGroupMaxLog2P = 10;     // buckets per column: LDS counters
+constexpr int kGroupMaxTiles = 128;    // 2048-id tiles per column
+constexpr int kGroupMaxLog2P = 9;      // buckets per column: LDS counters
 
 struct USync {
   int32_t* hist;        // group: per column [tiles][P] words, 0 = not published, else count + 1
@@ -426,9 +454,14 @@ struct USync {
 __global__ __launch_bounds__(kBlock, 4) void unique_group_kernel(const UArgs a, const USync y) {
   __shared__ int32_t counters[1 << kGroupMaxLog2P];   // counts, then bases
   __shared__ int32_t tot_s[1 << kGroupMaxLog2P], pre_s[1 << kGroupMaxLog2P];
+  __shared__ int64_t st_key[kBigTile];     // the tile's pairs, sorted by bucket (staged scatter)
+  __shared__ int32_t st_idx[kBigTile];
+  __shared__ uint16_t st_b[kBigTile];
+  __shared__ int32_t wave_cnt[kWavesPerBlock], n_staged;
   __shared__ int32_t wave_tot[kWavesPerBlock];
   __shared__ int32_t gave_up;
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  HBK_USTAMP(0, 0);
   for (int64_t j = (int64_t)blockIdx.x * kBlock + tid; j < y.zero_words;
        j += (int64_t)gridDim.x * kBlock) {
     y.zero[j] = 0;
@@ -448,6 +481,7 @@ __global__ __launch_bounds__(kBlock, 4) void unique_group_kernel(const UArgs a, 
     key[k] = j < c.len ? c.in[j] : 0;
   }
   __syncthreads();
+  HBK_USTAMP(0, 1);
   // bucket and rank inside the tile's share of the bucket (what the LDS atomic returns)
   int32_t br[kBigPerThread];
 #pragma unroll
@@ -460,10 +494,12 @@ __global__ __launch_bounds__(kBlock, 4) void unique_group_kernel(const UArgs a, 
     }
   }
   __syncthreads();
+  HBK_USTAMP(0, 2);
   for (int p = tid; p < P; p += kBlock) {
     __hip_atomic_store(hist + (int64_t)ctile * P + p, counters[p] + 1, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   }
+  HBK_USTAMP(0, 3);
   // totals of every bucket over the column's tiles and the part of the tiles before this one
   // (a thread per bucket, 16 tiles per poll), left in LDS for the scan
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
@@ -504,42 +540,83 @@ __global__ __launch_bounds__(kBlock, 4) void unique_group_kernel(const UArgs a, 
   }
   if (lost) gave_up = 1;
   __syncthreads();
+  HBK_USTAMP(0, 4);
   if (gave_up != 0) {
     if (tid == 0) __hip_atomic_store(y.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
-  // bucket starts: thread t scans buckets [t * per, t * per + per)
+  // bucket starts (scan of the column's totals) and the tile's own bucket offsets (scan of its
+  // counts, for the staged scatter): thread t scans buckets [t * per, t * per + per)
   const int per = P >= kBlock ? P / kBlock : 1;
   const int p0 = tid * per;
-  int32_t mine = 0;
-  for (int q = 0; q < per; ++q) mine += p0 + q < P ? tot_s[p0 + q] : 0;
-  int32_t incl = mine;
+  int32_t mine = 0, mine_c = 0;
+  for (int q = 0; q < per; ++q) {
+    mine += p0 + q < P ? tot_s[p0 + q] : 0;
+    mine_c += p0 + q < P ? counters[p0 + q] : 0;
+  }
+  int32_t incl = mine, incl_c = mine_c;
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
     const int32_t v = __shfl_up(incl, off, kWave);
-    if (lane >= off) incl += v;
+    const int32_t w = __shfl_up(incl_c, off, kWave);
+    if (lane >= off) {
+      incl += v;
+      incl_c += w;
+    }
   }
-  if (lane == kWave - 1) wave_tot[wave] = incl;
+  if (lane == kWave - 1) {
+    wave_tot[wave] = incl;
+    wave_cnt[wave] = incl_c;
+  }
   __syncthreads();
-  int32_t run = incl - mine;
-  for (int w = 0; w < wave; ++w) run += wave_tot[w];
+  int32_t run = incl - mine, run_c = incl_c - mine_c;
+  for (int w = 0; w < wave; ++w) {
+    run += wave_tot[w];
+    run_c += wave_cnt[w];
+  }
   for (int q = 0; q < per; ++q) {
     const int pp = p0 + q;
     if (pp >= P) break;
-    counters[pp] = run + pre_s[pp];
+    const int32_t n_b = tot_s[pp], n_c = counters[pp];
     if (ctile == 0) c.bstart[pp] = run;
-    run += tot_s[pp];
+    tot_s[pp] = run + pre_s[pp] - run_c;   // global position of the pair at staged slot L: + L
+    pre_s[pp] = run_c;                     // first staged slot of the bucket
+    run += n_b;
+    run_c += n_c;
   }
+  if (tid == kBlock - 1) n_staged = run_c;
   if (ctile == 0 && tid == 0) c.bstart[P] = c.len;
   __syncthreads();
+  HBK_USTAMP(0, 5);
+  // The tile's pairs go through LDS sorted by bucket and leave in that order: consecutive lanes
+  // store consecutive positions of a bucket's run instead of 64 different buckets (= lines) per
+  // store instruction -- the direct scatter spent 11 of the tile's 19 us issuing its stores.
 #pragma unroll
   for (int k = 0; k < kBigPerThread; ++k) {
     if (br[k] >= 0) {
-      const int32_t pos = counters[br[k] & ((1 << kGroupMaxLog2P) - 1)] + (br[k] >> kGroupMaxLog2P);
-      c.pair_key[pos] = key[k];
-      c.pair_idx[pos] = (int32_t)(base + (int64_t)k * kBlock + tid);
+      const int b = br[k] & ((1 << kGroupMaxLog2P) - 1);
+      const int L = pre_s[b] + (br[k] >> kGroupMaxLog2P);
+      st_key[L] = key[k];
+      st_idx[L] = (int32_t)(base + (int64_t)k * kBlock + tid);
+      st_b[L] = (uint16_t)b;
     }
   }
+  __syncthreads();
+  const int n_st = n_staged;
+#pragma unroll
+  for (int k = 0; k < kBigPerThread; ++k) {
+    const int L = k * kBlock + tid;
+    if (L < n_st) {
+      const int32_t pos = tot_s[st_b[L]] + L;
+      c.pair_key[pos] = st_key[L];
+      c.pair_idx[pos] = st_idx[L];
+    }
+  }
+  HBK_USTAMP(0, 6);
+#ifdef HBK_PART_STAMPS
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  HBK_USTAMP(0, 7);
+#endif
 }
 
 // ---- 5-7 in one launch ---------------------------------------------------------------------------
@@ -837,3 +914,18 @@ extern "C" int hbk_unique_n(int32_t n_cols, const int64_t* const* inputs, const 
   }
   return unique_n_impl(n_cols, cols, workspace, workspace_bytes, as_stream(stream));
 }
+
+#ifdef HBK_PART_STAMPS
+extern "C" int hbk_debug_uni_trace(unsigned long long* out, int which) {
+  using namespace hbk;
+  HBK_HIP_OK(hipDeviceSynchronize());
+  if (out != nullptr) {
+    HBK_HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_uni_trace), sizeof(g_uni_trace)));
+  } else {
+    static unsigned long long z[kUTraceBlocks * kUTraceSlots];
+    HBK_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_uni_trace), z, sizeof(z)));
+    HBK_HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_uni_which), &which, sizeof(int)));
+  }
+  return HBK_OK;
+}
+#endif

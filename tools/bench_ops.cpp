@@ -159,6 +159,35 @@ static void bench_unique(int n_cols, int64_t len, uint64_t mod) {
     HB(hbk_unique_n(n_cols, in.data(), lens.data(), u.data(), ix.data(), n.data(), ws, ws_bytes,
                     nullptr));
   });
+  {  // probe build: per-workgroup stamps of the group / first kernels
+    typedef int (*trace_fn)(unsigned long long*, int);
+    trace_fn fn = (trace_fn)dlsym(RTLD_DEFAULT, "hbk_debug_uni_trace");
+    for (int which = 0; fn != nullptr && which < 2; ++which) {
+      std::vector<unsigned long long> tr(8192 * 8);
+      fn(nullptr, which);
+      HB(hbk_unique_n(n_cols, in.data(), lens.data(), u.data(), ix.data(), n.data(), ws, ws_bytes, nullptr));
+      fn(tr.data(), which);
+      double sum[7] = {0}, life = 0;
+      unsigned long long t_min = ~0ull, t_max = 0, last_start = 0;
+      int nb = 0;
+      for (int b = 0; b < 8192; ++b) {
+        const unsigned long long* t = &tr[(size_t)b * 8];
+        if (t[0] == 0 || t[7] == 0) continue;
+        ++nb;
+        for (int i = 0; i < 7; ++i) sum[i] += (double)(t[i + 1] - t[i]);
+        life += (double)(t[7] - t[0]);
+        t_min = t[0] < t_min ? t[0] : t_min;
+        t_max = t[7] > t_max ? t[7] : t_max;
+        last_start = t[0] > last_start ? t[0] : last_start;
+      }
+      if (nb > 0) {
+        printf("   unique %s kernel: %d traced workgroups over %.2f us, mean life %.2f us, last starts at %.2f us; phases (us):",
+               which == 0 ? "group" : "first", nb, (t_max - t_min) * 0.01, life / nb * 0.01, (last_start - t_min) * 0.01);
+        for (int i = 0; i < 7; ++i) printf(" %.2f", sum[i] / nb * 0.01);
+        printf("\n");
+      }
+    }
+  }
   const double ids = (double)n_cols * len;
   char what[128];
   snprintf(what, sizeof(what), "unique_n %d x %lld int64 (ids uniform in [0, %llu))", n_cols,

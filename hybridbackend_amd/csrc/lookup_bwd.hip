@@ -114,7 +114,6 @@ __device__ inline void team_sync() {
 #define HBK_BWD_PRE 4
 #endif
 constexpr int kPre = HBK_BWD_PRE;     // gradient rows a lane keeps in flight (single-pair rows)
-constexpr int kUA = HBK_BWD_UA;       // slots a lane group reduces concurrently (rows in flight)
 constexpr int kHeavy = 64;            // pairs of one row in a chunk that make it a "hot row"
 constexpr int kLdsRowPairs = kCP / 8; // multi-pair slots are summed in LDS rows when they hold at
                                       // most this many pairs together
@@ -123,7 +122,6 @@ constexpr int kLdsRowPairs = kCP / 8; // multi-pair slots are summed in LDS rows
 #endif
 constexpr int kHotTries = HBK_BWD_HOT; // ballot rounds that look for a hot row inside a wave
 constexpr int kHotMin = 8;             // lanes sharing a row that make the wave reduce it first
-constexpr int kUH = HBK_BWD_UH;       // rows in flight per lane group while summing a hot row
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr int64_t kDonePair = -1;      // a pair struck out of the pair buffer (rows are >= 0)
 constexpr uint16_t kNoSlot = 0xffff;
@@ -725,8 +723,9 @@ struct ReduceLds {
   int32_t heavy[kCP / kHeavy + 1];
   int32_t wave_tot[kTeam / kWave];
   int32_t n_active, n_new, n_heavy, n_single, base_u, occupied, occupied_before, n_left, lds_rows,
-      n_emitted, emit0;
-  float red[kTeam * 4];      // hot-row partial sums, one 16-byte chunk per thread
+      n_emitted, emit0, n_multi;
+  float red[kTeam * 4];      // partial sums handed between lane groups, one 16-byte chunk per thread
+  float carry[2][kWave * 4]; // sum of the slot that runs on into the next round of the sorted walk
 };
 
 constexpr int32_t kNewBit = 1 << 30;
@@ -1034,6 +1033,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
           const int32_t tot = run + sum;
           L.n_new = tot & 1023;
           L.n_active = (tot >> 10) & 1023;
+          L.n_multi = tot >> 20;
           // few multi-pair slots holding few pairs (the usual case): their pairs are summed in LDS
           // rows by ds_add_f32; many, or a slot with many pairs (skewed ids: same-address LDS
           // atomics serialise): they are sorted by slot and walked / summed by the whole
@@ -1205,78 +1205,124 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         }
         team_sync();
 
-        // a lane group sums the rows of kUA slots at a time, in registers
-        for (int k0 = 0; k0 < n_active; k0 += groups * kUA) {
-          int32_t slot[kUA], beg[kUA], len[kUA];
-          V acc[kUA];
-          int32_t longest = 0;
+        // The sorted pairs are walked FLAT: per round a lane group takes kW consecutive positions
+        // of the sorted order, all their gradient rows in flight at once, and sums runs of one slot
+        // in registers.  A slot's pairs span neighbouring lane groups (and rounds): the group where
+        // a run starts owns it and adds the head partials its successors leave in LDS; a slot that
+        // runs past the round's end is carried in an LDS row into the next round.  One emit per
+        // slot whatever its length -- 3 pairs or a hot row's 400 -- and no lane group walks a
+        // slot's pairs one memory round trip at a time (with 33 pairs per row that walk was 20 of
+        // a workgroup's 37 us; it also replaces the whole-workgroup sum of hot rows).
+        constexpr int kW = STEP == 2 ? kPre / 2 : STEP ? kPre : 2 * kPre;   // (register budget)
+        const int n_multi = L.n_multi;
+        const int per_round = groups * kW;
+        int par = 0;
+        for (int r0 = 0; r0 < n_multi; r0 += per_round, par ^= 1) {
+          const int q0 = r0 + my_group * kW;   // my first position
+          V g[kW];
+          int32_t sl[kW];                       // slot of every position, -1 beyond the end
 #pragma unroll
-          for (int u = 0; u < kUA; ++u) {
-            const int idx = k0 + u * groups + my_group;
-            slot[u] = -1;
-            len[u] = 0;
-            beg[u] = 0;
-            acc[u] = zero_v<V>();
-            if (idx < n_active) {
-              slot[u] = L.active[idx];
-              const int32_t n = L.cnt[slot[u]] & (kNewBit - 1);
-              if (n >= kHeavy) {
-                if (sub == 0) L.heavy[atomicAdd(&L.n_heavy, 1)] = slot[u];
-                slot[u] = -1;
-              } else {
-                len[u] = n;
-                beg[u] = L.off[slot[u]] - n;
-                longest = n > longest ? n : longest;
+          for (int w = 0; w < kW; ++w) {
+            const int q = q0 + w;
+            sl[w] = -1;
+            g[w] = zero_v<V>();
+            if (q < n_multi) {
+              const int e = (int)L.order[q];
+              sl[w] = (int)L.pslot[e];
+              if (live) g[w] = load_grad<V>(c, job, L.segs[e], sub);
+            }
+          }
+          // head: the run at my first position (it may have started in a group before me)
+          {
+            V head = zero_v<V>();
+            bool in_head = sl[0] >= 0;
+#pragma unroll
+            for (int w = 0; w < kW; ++w) {
+              in_head = in_head && sl[w] == sl[0];
+              if (in_head) head = head + g[w];
+            }
+            *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = head;
+          }
+          team_sync();
+          const int round_end = r0 + per_round;
+          V acc = zero_v<V>();
+          int cur = -1;
+          bool owned = false;
+          uint32_t fin = 0;   // bit w: a run I own ends at my position w and is complete: its sum is
+                              // left in g[w] (the registers its last gradient row arrived in)
+#pragma unroll
+          for (int w = 0; w <= kW; ++w) {
+            const int sw = w < kW ? sl[w] : -1;
+            if (sw != cur) {
+              if (w > 0 && cur >= 0 && owned) {
+                // the run of `cur` ends at my position w - 1
+                const int32_t s_end = L.off[cur];
+                const int32_t s_beg = s_end - (L.cnt[cur] & (kNewBit - 1));
+                V total = acc;
+                if (w == kW) {
+                  // it reached the end of my range: the heads of the groups it goes on in
+                  const int lim = s_end < round_end ? s_end : round_end;
+                  for (int q = q0 + kW; q < lim; q += kW) {
+                    const int gp = (q - r0) / kW;
+                    total = total + *reinterpret_cast<const V*>(
+                                        &L.red[(((size_t)gp << lpr_log2) + sub) * VE]);
+                  }
+                }
+                if (s_beg < r0) {   // it began in an earlier round (only the round's first run can)
+                  total = total + *reinterpret_cast<const V*>(&L.carry[par ^ 1][(size_t)sub * VE]);
+                }
+                if (s_end > round_end) {
+                  *reinterpret_cast<V*>(&L.carry[par][(size_t)sub * VE]) = total;   // goes on
+                } else {
+                  g[w > 0 ? w - 1 : 0] = total;
+                  fin |= 1u << (w > 0 ? w - 1 : 0);
+                }
+              }
+              cur = sw;
+              acc = zero_v<V>();
+              // a run that starts inside my range is mine; the one at my first position is mine
+              // when the slot starts there or when I am the round's first group (it is carried in)
+              owned = w > 0 || my_group == 0 ||
+                      (sw >= 0 && L.off[sw] - (L.cnt[sw] & (kNewBit - 1)) >= q0);
+            }
+            if (w < kW && sw >= 0) acc = acc + g[w];
+          }
+          // the finished rows leave together: the table (and accumulator) rows of the optimizer
+          // step are requested for all of them before the first is used
+          if (STEP && lr_now != 0.0f) {
+            V tv[kW], av[STEP == 2 ? kW : 1];
+#pragma unroll
+            for (int w = 0; w < kW; ++w) {
+              tv[w] = zero_v<V>();
+              if ((fin >> w & 1u) && live) {
+                const int64_t toff = (int64_t)L.keys[sl[w]] * c.dim + (int64_t)sub * VE;
+                tv[w] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+                if (STEP == 2) {
+                  av[STEP == 2 ? w : 0] =
+                      __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
+                }
               }
             }
-          }
-          for (int r = 0; r < longest; ++r) {
-            V g[kUA];
 #pragma unroll
-            for (int u = 0; u < kUA; ++u) {
-              g[u] = zero_v<V>();
-              if (r < len[u] && live) g[u] = load_grad<V>(c, job, L.segs[L.order[beg[u] + r]], sub);
+            for (int w = 0; w < kW; ++w) {
+              if ((fin >> w & 1u) && live) {
+                const int s = sl[w];
+                if (!job.no_emit) {
+                  emit_row<V>(c, job, L.slot_out[s], (L.cnt[s] & kNewBit) != 0, sub, g[w]);
+                }
+                const int64_t toff = (int64_t)L.keys[s] * c.dim + (int64_t)sub * VE;
+                step_row<V>(c, adagrad, lr_now, toff, g[w], tv[w],
+                            STEP == 2 ? av[STEP == 2 ? w : 0] : zero_v<V>());
+              }
             }
+          } else {
 #pragma unroll
-            for (int u = 0; u < kUA; ++u) acc[u] = acc[u] + g[u];
-          }
-#pragma unroll
-          for (int u = 0; u < kUA; ++u) {
-            if (slot[u] >= 0 && live) {
-              emit_step_row<V, STEP>(c, job, lr_now, L.slot_out[slot[u]],
-                               (L.cnt[slot[u]] & kNewBit) != 0, (int64_t)L.keys[slot[u]], sub, acc[u]);
+            for (int w = 0; w < kW; ++w) {
+              if ((fin >> w & 1u) && live) {
+                const int s = sl[w];
+                emit_row<V>(c, job, L.slot_out[s], (L.cnt[s] & kNewBit) != 0, sub, g[w]);
+              }
             }
-          }
-        }
-        team_sync();
-
-        // (e) hot rows: the whole workgroup sums one row, partial sums folded through LDS
-        const int n_heavy = L.n_heavy;
-        for (int hidx = 0; hidx < n_heavy; ++hidx) {
-          const int s = L.heavy[hidx];
-          const int32_t n = L.cnt[s] & (kNewBit - 1);
-          const int32_t b0 = L.off[s] - n;
-          V acc = zero_v<V>();
-          for (int32_t p0 = 0; p0 < n; p0 += groups * kUH) {
-            V g[kUH];
-#pragma unroll
-            for (int u = 0; u < kUH; ++u) {
-              const int32_t p = p0 + u * groups + my_group;
-              g[u] = zero_v<V>();
-              if (p < n && live) g[u] = load_grad<V>(c, job, L.segs[L.order[b0 + p]], sub);
-            }
-#pragma unroll
-            for (int u = 0; u < kUH; ++u) acc = acc + g[u];
-          }
-          *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = acc;
-          team_sync();
-          if (my_group == 0 && live) {
-            V tot = zero_v<V>();
-            for (int gi = 0; gi < groups; ++gi) {
-              tot = tot + *reinterpret_cast<const V*>(&L.red[((size_t)(gi << lpr_log2) + sub) * VE]);
-            }
-            emit_step_row<V, STEP>(c, job, lr_now, L.slot_out[s], (L.cnt[s] & kNewBit) != 0,
-                             (int64_t)L.keys[s], sub, tot);
           }
           team_sync();
         }

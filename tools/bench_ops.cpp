@@ -407,6 +407,13 @@ int main(int argc, char** argv) {
     bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 8", 26, 65536, 8, HBK_INT64);
     return 0;
   }
+  if (argc > 1 && argv[1][0] == 'd') {  // "dup": duplicated ids (3, 33 and 330 pairs per row)
+    bench_backward(26, 65536, 16, 20000, 0.f);
+    bench_backward(26, 65536, 16, 2000, 0.f);
+    bench_backward(26, 65536, 16, 200, 0.f);
+    bench_backward(26, 65536, 64, 20000, 0.f);
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'u') {  // "unique": the owner-side unique only
     bench_unique(26, 65536, 1000000);
     return 0;

@@ -93,7 +93,10 @@ constexpr int kMaxBuckets = 16384;   // 64 KB of LDS counters in hist / scatter
 constexpr int kTeam = HBK_BWD_TEAM;
 constexpr int kTeams = kBlock / kTeam;  // teams per workgroup
 constexpr int kCP = 2 * kTeam;        // pairs per chunk in the reduce kernel
-constexpr int kSlots = 2 * kCP;       // LDS hash-table slots
+#ifndef HBK_BWD_SLOTX
+#define HBK_BWD_SLOTX 2
+#endif
+constexpr int kSlots = HBK_BWD_SLOTX * kCP;   // LDS hash-table slots
 constexpr int kRoom = kSlots - kTeam - 8;   // rows enter the table while it holds fewer (a
                                            // team's concurrent inserts overshoot by < kTeam)
 static_assert(kTeam == 64 || kTeam == kBlock, "a team is one wave or the whole workgroup");
@@ -132,6 +135,13 @@ constexpr uint16_t kNoSlot = 0xffff;
 #ifdef HBK_BWD_STAMPS
 constexpr int kTraceBlocks = 8192, kTraceSlots = 8;
 __device__ unsigned long long g_bwd_trace[kTraceBlocks * kTraceSlots];
+__device__ unsigned long long g_bwd_sub[kTraceBlocks * 4];   // sub-stamps inside phase (a)
+#define HBK_SUBSTAMP(i)                                                                    \
+  do {                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < kTraceBlocks) {                                   \
+      g_bwd_sub[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime();                  \
+    }                                                                                      \
+  } while (0)
 #define HBK_STAMP_BEGIN()                                                                  \
   if (threadIdx.x == 0 && blockIdx.x < kTraceBlocks) {                                     \
     g_bwd_trace[blockIdx.x * kTraceSlots] = __builtin_amdgcn_s_memrealtime();                  \
@@ -145,6 +155,7 @@ __device__ unsigned long long g_bwd_trace[kTraceBlocks * kTraceSlots];
 #define HBK_STAMP_ARG
 #define HBK_STAMP_PASS
 #else
+#define HBK_SUBSTAMP(i)
 #define HBK_STAMP_BEGIN()
 #define HBK_STAMP(i)
 #define HBK_STAMP_ARG
@@ -757,8 +768,12 @@ template <typename V>
 __device__ inline V load_grad(const GCol& c, const ReduceJob& job, int32_t seg, int sub) {
   constexpr int VE = sizeof(V) / 4;
   const int64_t off = job.seg_is_offset ? (int64_t)(uint32_t)seg : (int64_t)seg * job.stride;
+#ifdef HBK_BWD_ABLATE_LOADS   // probe builds: what the kernel costs without its gradient traffic
+  V g = zero_v<V>() + (float)(off & 7);
+#else
   V g = __builtin_nontemporal_load(
       reinterpret_cast<const V*>(job.grad + off + (int64_t)sub * VE));
+#endif
   if (job.scale && c.combiner != HBK_COMBINER_SUM && c.splits != nullptr) {
     const int32_t n = c.splits[seg + 1] - c.splits[seg];
     g = c.combiner == HBK_COMBINER_MEAN ? g / (float)n : g / sqrtf((float)n);
@@ -785,8 +800,13 @@ __device__ inline void emit_row(const GCol& c, const ReduceJob& job, int32_t u, 
                                 int sub, V v) {
   constexpr int VE = sizeof(V) / 4;
   V* o = reinterpret_cast<V*>(job.out_vals + (int64_t)u * c.dim + (int64_t)sub * VE);
+#ifdef HBK_BWD_ABLATE_STORES   // probe builds: what the kernel costs without its output traffic
+  if (u == 0x7fffffff) *o = v;
+  (void)is_new;
+#else
   // rows are owned by this workgroup; bypass L1 when re-reading what an earlier chunk wrote
   *o = is_new ? v : __builtin_nontemporal_load(o) + v;
+#endif
 }
 
 // The sparse optimizer step of one row chunk (this workgroup owns the row), from values already
@@ -824,18 +844,22 @@ __device__ inline void emit_step_row(const GCol& c, const ReduceJob& job, float 
 
 // Find `row` in the LDS table or enter it while the table has room.  Returns the slot, or -1 when
 // the row is absent and the table takes no more rows (the pair waits for the next pass).
-__device__ inline int table_slot(ReduceLds& L, unsigned long long row) {
+// `entered` is set when the row is new in the table: the CALLER adds the new rows of a wave to
+// L.occupied with one atomic (every lane adding its own 1 to that one LDS word serialised 512
+// same-address atomics per chunk: 4.4 of a workgroup's 20 us).
+__device__ inline int table_slot(ReduceLds& L, unsigned long long row, bool* entered) {
   int h = (int)(mix32(row) & (kSlots - 1));
   for (;;) {
     const unsigned long long k = L.keys[h];
     if (k == row) return h;
     if (k == kEmptyKey) {
-      // racy read of the fill level: concurrent inserts overshoot kRoom by < kTeam rows, the
-      // table keeps >= 8 empty slots, so every probe sequence ends
+      // racy read of the fill level (the waves add their new rows after every pair of the chunk
+      // loop): concurrent inserts overshoot kRoom by < kTeam rows, the table keeps >= 8 empty
+      // slots, so every probe sequence ends
       if (*(volatile int32_t*)&L.occupied >= kRoom) return -1;
       const unsigned long long prev = atomicCAS(&L.keys[h], kEmptyKey, row);
       if (prev == kEmptyKey) {
-        atomicAdd(&L.occupied, 1);
+        *entered = true;
         return h;
       }
       if (prev == row) return h;
@@ -916,18 +940,38 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       // probe once and take all tickets, the other lanes get slot and ticket by broadcast.
       int hs_[kCP / kTeam], tk_[kCP / kTeam], rk_[kCP / kTeam];
       unsigned long long row_[kCP / kTeam];
+      HBK_SUBSTAMP(0);
+      // all pairs of the chunk are requested before the first is worked on (inside the loop below
+      // the second pair's loads waited behind the LDS work of the first: two memory round trips)
+      int64_t r_in[kCP / kTeam];
+      int32_t seg_in[kCP / kTeam];
+#pragma unroll
+      for (int k = 0; k < kCP / kTeam; ++k) {
+        const int e = k * kTeam + tid;
+        r_in[k] = kDonePair;
+        seg_in[k] = cb + e;
+        if (e < n_chunk) {
+          r_in[k] = prow[cb + e];
+          if (pseg != nullptr) seg_in[k] = pseg[cb + e];
+        }
+      }
+#ifdef HBK_BWD_STAMPS
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      HBK_SUBSTAMP(1);
+#endif
 #pragma unroll
       for (int k = 0; k < kCP / kTeam; ++k) {
         const int e = k * kTeam + tid;
         bool valid = e < n_chunk;
         unsigned long long row = 0;
         if (valid) {
-          const int64_t r = prow[cb + e];
-          L.segs[e] = pseg != nullptr ? pseg[cb + e] : cb + e;
+          const int64_t r = r_in[k];
+          L.segs[e] = seg_in[k];
           valid = r != kDonePair;
           row = (unsigned long long)r;
         }
         int h = -2, ticket = 0;    // -2: not looked up yet, -1: no room in this pass
+        bool entered = false;      // this lane entered a new row into the table
         unsigned long long todo = __ballot(valid);
         for (int t = 0; t < kHotTries && todo != 0ull; ++t) {
           const int leader = __builtin_ctzll(todo);
@@ -946,7 +990,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
           if (n_same < kHotMin) continue;
           int hs = -1, base = 0;
           if (lane == leader) {
-            hs = table_slot(L, r);
+            hs = table_slot(L, r, &entered);
             if (hs >= 0) base = atomicAdd(&L.cnt[hs], n_same);
           }
           hs = __builtin_amdgcn_readlane(hs, leader);
@@ -957,8 +1001,15 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
           }
         }
         if (valid && h == -2) {
-          h = table_slot(L, row);
+          h = table_slot(L, row, &entered);
           if (h >= 0) ticket = atomicAdd(&L.cnt[h], 1);
+        }
+        {
+          // the wave's new rows enter the fill level with one atomic
+          const unsigned long long fresh = __ballot(entered);
+          if (fresh != 0ull && lane == (int)__builtin_ctzll(fresh)) {
+            atomicAdd(&L.occupied, (int32_t)__builtin_popcountll(fresh));
+          }
         }
         if (e < n_chunk) L.pslot[e] = valid && h >= 0 ? (uint16_t)h : kNoSlot;
         if (valid && h < 0) atomicAdd(&L.n_left, 1);
@@ -966,7 +1017,9 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         tk_[k] = ticket;
         row_[k] = row;
       }
+      HBK_SUBSTAMP(2);
       team_sync();
+      HBK_SUBSTAMP(3);
       if (L.n_left > 0) {   // uniform: nobody changes it before the next pass
         // A pair that found no room may belong to a row another lane entered in the same instant
         // (it read the slot before that lane's CAS and the fill level after it): the next pass
@@ -1680,6 +1733,12 @@ extern "C" int hbk_debug_grp_trace(unsigned long long* out, int reset) {
   return HBK_OK;
 }
 // probe builds: constant-clock (100 MHz) stamps of the first 8192 reduce workgroups, 8 each
+extern "C" int hbk_debug_bwd_sub(unsigned long long* out) {
+  using namespace hbk;
+  HBK_HIP_OK(hipDeviceSynchronize());
+  HBK_HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_sub), sizeof(g_bwd_sub)));
+  return HBK_OK;
+}
 extern "C" int hbk_debug_bwd_trace(unsigned long long* out, int reset) {
   using namespace hbk;
   HBK_HIP_OK(hipDeviceSynchronize());

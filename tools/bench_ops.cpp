@@ -305,6 +305,26 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
         t_min = t[0] < t_min ? t[0] : t_min;
         t_max = t[7] > t_max ? t[7] : t_max;
       }
+      {
+        typedef int (*sub_fn)(unsigned long long*);
+        sub_fn sf = (sub_fn)dlsym(RTLD_DEFAULT, "hbk_debug_bwd_sub");
+        if (sf != nullptr) {
+          std::vector<unsigned long long> sb(8192 * 4);
+          sf(sb.data());
+          double d[3] = {0, 0, 0};
+          int m = 0;
+          for (int b = 0; b < 8192; ++b) {
+            const unsigned long long* q = &sb[(size_t)b * 4];
+            if (q[0] == 0 || q[3] < q[0]) continue;
+            ++m;
+            for (int i = 0; i < 3; ++i) d[i] += (double)(q[i + 1] - q[i]);
+          }
+          if (m > 0) {
+            printf("   inside (a), first chunk: pairs arrive %.2f us, search + insert (both pairs) %.2f, barrier %.2f\n",
+                   d[0] / m * 0.01, d[1] / m * 0.01, d[2] / m * 0.01);
+          }
+        }
+      }
       const double nb = n_blocks ? n_blocks : 1;
       printf("   reduce kernel: %d traced workgroups over %.1f us, mean life %.2f us (=> %.0f alive on "
              "average); per phase (us):", n_blocks, (t_max - t_min) * 0.01, life / nb * 0.01,

@@ -195,9 +195,18 @@ static void bench_unique(int n_cols, int64_t len, uint64_t mod) {
   printf("%-66s %9.2f us  %8.1f M ids/s\n", what, us, ids / us);
 }
 
+// H > 0: every sample holds H ids (row_splits 0, H, 2H, ...), combiner mean; n_ids = B
 static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float lr,
-                           bool step_only = false) {
+                           bool step_only = false, int H = 0) {
   const int kPool = 4;
+  const int64_t n_seg = H > 0 ? B / H : B;
+  int32_t* splits = nullptr;
+  if (H > 0) {
+    std::vector<int32_t> hs((size_t)n_seg + 1);
+    for (int64_t i = 0; i <= n_seg; ++i) hs[(size_t)i] = (int32_t)(i * H);
+    splits = dev_alloc<int32_t>((size_t)n_seg + 1);
+    CK(hipMemcpy(splits, hs.data(), ((size_t)n_seg + 1) * 4, hipMemcpyHostToDevice));
+  }
   std::vector<int64_t*> pool(kPool);
   for (auto& p : pool) p = dev_random<int64_t>((size_t)n_cols * B, (uint64_t)1 << 40);
   std::vector<float*> tables(n_cols);
@@ -221,11 +230,12 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
       h.ids_dtype = HBK_INT64;
       h.ids = pool[i % kPool] + (size_t)c * B;
       h.n_ids = B;
-      h.n_segments = B;
+      h.n_segments = n_seg;
+      h.row_splits = splits;
       h.bucket = rows;
       h.divisor = 1;
-      h.combiner = HBK_COMBINER_SUM;
-      h.grad_out = gout + (size_t)c * B * dim;
+      h.combiner = H > 0 ? HBK_COMBINER_MEAN : HBK_COMBINER_SUM;
+      h.grad_out = gout + (size_t)c * n_seg * dim;
       h.unique_rows = step_only ? nullptr : urows + (size_t)c * B;
       h.grad_rows = step_only ? nullptr : grows + (size_t)c * B * dim;
       h.n_unique = nu + c;
@@ -240,8 +250,8 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
   });
   const double n = (double)n_cols * B;
   char what[128];
-  snprintf(what, sizeof(what), "group_lookup_bwd %d x %lld ids, dim %d, %lld rows%s", n_cols,
-           (long long)B, dim, (long long)rows,
+  snprintf(what, sizeof(what), "group_lookup_bwd %d x %lld ids%s, dim %d, %lld rows%s", n_cols,
+           (long long)B, H > 0 ? " (ragged mean)" : "", dim, (long long)rows,
            step_only ? ", SGD step only" : lr != 0.f ? " + SGD apply" : "");
   printf("%-66s %9.2f us  %8.1f M lookups/s\n", what, us, n / us);
   {  // probe build: stamps of the grouping kernel's workgroups
@@ -425,6 +435,13 @@ int main(int argc, char** argv) {
   }
   if (argc > 1 && argv[1][0] == 'p') {  // "part": the single-node partition only
     bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 8", 26, 65536, 8, HBK_INT64);
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'r') {  // "ragged": config-5-like columns (8 ids per sample, mean)
+    bench_backward(16, 524288, 16, 100000, 0.01f, false, 8);
+    bench_backward(16, 524288, 64, 100000, 0.01f, false, 8);
+    bench_backward(16, 524288, 16, 10000000, 0.01f, false, 8);
+    bench_backward(16, 524288, 4, 3000, 0.01f, false, 8);
     return 0;
   }
   if (argc > 1 && argv[1][0] == 'd') {  // "dup": duplicated ids (3, 33 and 330 pairs per row)

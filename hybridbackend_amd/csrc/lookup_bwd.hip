@@ -114,9 +114,13 @@ __device__ inline void team_sync() {
   }
 }
 #ifndef HBK_BWD_PRE
-#define HBK_BWD_PRE 4
+#define HBK_BWD_PRE 3
 #endif
-constexpr int kPre = HBK_BWD_PRE;     // gradient rows a lane keeps in flight (single-pair rows)
+// gradient rows a lane keeps in flight: 2 x kPre without the optimizer step, kPre with it.  Four
+// (8 / 4 rows) made the kernels spill 64-188 bytes per lane of loop-invariant state: 63 MB of
+// scratch writes per config-2 launch (TCC_EA0_WRREQ_64B 2.85 M where the rows account for 1.86 M),
+// 117 us instead of 110.
+constexpr int kPre = HBK_BWD_PRE;
 constexpr int kHeavy = 64;            // pairs of one row in a chunk that make it a "hot row"
 constexpr int kLdsRowPairs = kCP / 8; // multi-pair slots are summed in LDS rows when they hold at
                                       // most this many pairs together
@@ -1266,7 +1270,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         // slot whatever its length -- 3 pairs or a hot row's 400 -- and no lane group walks a
         // slot's pairs one memory round trip at a time (with 33 pairs per row that walk was 20 of
         // a workgroup's 37 us; it also replaces the whole-workgroup sum of hot rows).
-        constexpr int kW = STEP == 2 ? kPre / 2 : STEP ? kPre : 2 * kPre;   // (register budget)
+        constexpr int kW = STEP == 2 ? 2 : STEP ? kPre : 2 * kPre;   // (register budget)
         const int n_multi = L.n_multi;
         const int per_round = groups * kW;
         int par = 0;

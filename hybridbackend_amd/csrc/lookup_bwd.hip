@@ -1147,7 +1147,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       // kDepth rows in flight per lane; between the loads and the stores a lane keeps nothing but
       // the rows and one flag word (slot, ticket count and output position are read again from
       // LDS), so that the deep variant fits the register budget without spilling.
-      constexpr int kDepth = STEP ? kPre : 2 * kPre;
+      constexpr int kDepth = STEP == 2 ? kPre - 1 : STEP ? kPre : 2 * kPre;   // (Adagrad: a third row spills 136 B/lane)
       const int n_fetch = lds_rows ? n_chunk : L.n_single;
       for (int e0 = 0; e0 == 0 || e0 < n_fetch; e0 += kDepth * groups) {
         V pre[kDepth], tv[STEP ? kDepth : 1], av[STEP == 2 ? kDepth : 1];
@@ -1406,7 +1406,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
     // group), then the stores: a load behind a store to a possibly aliasing row would serialise
     // the round into one memory round trip per row.
     if (STEP && defer) {
-      constexpr int kAp = 4;
+      constexpr int kAp = STEP == 2 ? 2 : 4;   // (Adagrad: four rows of three vectors spill)
       const int n_emitted = L.n_emitted;   // written before the last barrier
       for (int i0 = 0; i0 < n_emitted; i0 += kAp * groups) {
         int64_t toff[kAp];

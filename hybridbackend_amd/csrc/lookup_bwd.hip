@@ -14,20 +14,22 @@
 //                per-1024-id-tile LDS histogram, all columns in one launch
 //   2 scan       hist[tile][bucket]: prefix over tiles per bucket, then bucket starts
 //   3 scatter    (row, segment) pairs grouped by bucket (LDS ticket per bucket and tile)
+//                (1-3 are ONE launch for columns of <= 512 buckets and <= 64 tiles: bwd_group_kernel)
 //   4 reduce     ONE workgroup owns a bucket, hence every table row that hashes to it.  Per
-//                chunk of <= 512 pairs: every lane group first ISSUES the loads of its pairs'
-//                gradient rows (<= 8 rows in flight per lane) -- they travel while (a) the rows are
-//                entered into an LDS hash table (64-bit CAS) with one ticket per pair and slot, and
-//                (b) one packed block scan over the PAIRS (new rows | rows with several pairs |
-//                their pair counts) hands every new row its output position (one global atomic per
-//                workgroup claims the range); (c) a row with ONE pair in the chunk -- the common
-//                case -- is written straight from the registers the gradient arrived in, plain
-//                16-byte stores, with the optimizer step when apply_lr != 0 (exclusive ownership
-//                makes the read-modify-write race free); (d) rows with several pairs are counting-
-//                sorted by slot and a lane group walks one slot's pairs, summing IN REGISTERS;
-//                (e) hot rows (>= 64 pairs in the chunk) are summed by the whole workgroup and
-//                folded through a 4 KB LDS buffer (the "LDS-staged hot rows").  A row that spans
-//                chunks is accumulated into its output row by the owning workgroup.  The table
+//                chunk of <= 512 pairs: (a) the rows are entered into an LDS hash table (64-bit
+//                CAS) with one ticket per pair and slot; (b) one packed block scan over the PAIRS
+//                (new rows | rows with several pairs | their pair counts) hands every new row its
+//                output position (one global atomic per workgroup claims the range, issued right
+//                after (a)); (c) one round of gradient loads, 6 rows in flight per lane (3 with the
+//                optimizer step): a row with ONE pair in the chunk -- the common case -- is written
+//                straight from the registers the gradient arrived in, plain 16-byte stores, with
+//                the optimizer step when apply_lr != 0 (exclusive ownership makes the
+//                read-modify-write race free); (d) rows with several pairs are counting-sorted by
+//                slot and the sorted pairs are walked FLAT: a lane group takes consecutive
+//                positions, all rows in flight, sums runs of one slot in registers, and the group
+//                where a run starts adds the head partials of its successors (LDS) -- the
+//                "LDS-staged hot rows": a row of 400 pairs is 50 lane groups' partials.  A row
+//                that spans chunks is accumulated into its output row by the owning workgroup.  The table
 //                takes new rows only while it has room; pairs whose row found no room are left for
 //                another PASS over the bucket with an emptied table (handled pairs are struck out
 //                of the pair buffer), so every row is emitted exactly once whatever the bucket
@@ -38,7 +40,7 @@
 //                sum such a row at ~15 GB/s while the rest of the chip idles.  The scan kernel
 //                therefore lists every bucket with more than split_t pairs; the reduce grid has
 //                spare workgroups that take the 2nd, 3rd.. range of split_t pairs of a listed
-//                bucket.  The workgroups of a split bucket run steps (a)-(e) on their range but
+//                bucket.  The workgroups of a split bucket run steps (a)-(d) on their range but
 //                emit (row, partial sum) entries into the bucket's own slice of a partials
 //                buffer; a merge launch then runs the same steps over those entries (one
 //                workgroup per split bucket) and emits the final rows.  A table row still has
@@ -53,14 +55,8 @@
 
 #include "lookup_common.h"
 
-#ifndef HBK_BWD_UA
-#define HBK_BWD_UA 4
-#endif
 #ifndef HBK_BWD_WAVES
 #define HBK_BWD_WAVES 4
-#endif
-#ifndef HBK_BWD_UH
-#define HBK_BWD_UH 8
 #endif
 
 namespace hbk {
@@ -121,7 +117,6 @@ __device__ inline void team_sync() {
 // scratch writes per config-2 launch (TCC_EA0_WRREQ_64B 2.85 M where the rows account for 1.86 M),
 // 117 us instead of 110.
 constexpr int kPre = HBK_BWD_PRE;
-constexpr int kHeavy = 64;            // pairs of one row in a chunk that make it a "hot row"
 constexpr int kLdsRowPairs = kCP / 8; // multi-pair slots are summed in LDS rows when they hold at
                                       // most this many pairs together
 #ifndef HBK_BWD_HOT
@@ -735,9 +730,8 @@ struct ReduceLds {
   uint16_t order[kCP];       // their pair indices grouped by slot
   uint16_t pslot[kCP];       // slot of every pair; kNoSlot: struck out earlier / left for a later pass
   uint16_t emitted[kSlots];  // slots of the rows this pass has emitted (jobs of several chunks)
-  int32_t heavy[kCP / kHeavy + 1];
   int32_t wave_tot[kTeam / kWave];
-  int32_t n_active, n_new, n_heavy, n_single, base_u, occupied, occupied_before, n_left, lds_rows,
+  int32_t n_active, n_new, n_single, base_u, occupied, occupied_before, n_left, lds_rows,
       n_emitted, emit0, n_multi;
   float red[kTeam * 4];      // partial sums handed between lane groups, one 16-byte chunk per thread
   float carry[2][kWave * 4]; // sum of the slot that runs on into the next round of the sorted walk
@@ -829,7 +823,7 @@ __device__ inline void step_row(const GCol& c, bool adagrad, float lr, int64_t t
   }
 }
 
-// emit + (lr != 0) the optimizer step with the loads it needs: the rows of (d), (e) and of the
+// emit + (lr != 0) the optimizer step with the loads it needs: the rows of the
 // LDS-row path -- few, or long to sum, so the extra round trip is not on the critical path
 template <typename V, int STEP>
 __device__ inline void emit_step_row(const GCol& c, const ReduceJob& job, float lr, int32_t u,
@@ -931,7 +925,6 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
     for (int32_t cb = first_cb; cb < n_pairs; cb += kCP) {
       const int32_t n_chunk = n_pairs - cb < kCP ? n_pairs - cb : kCP;
       if (tid == 0) {
-        L.n_heavy = 0;
         L.n_single = 0;
       }
 
@@ -1094,7 +1087,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
           // few multi-pair slots holding few pairs (the usual case): their pairs are summed in LDS
           // rows by ds_add_f32; many, or a slot with many pairs (skewed ids: same-address LDS
           // atomics serialise): they are sorted by slot and walked / summed by the whole
-          // workgroup, see (d), (e)
+          // workgroup, see (d)
           L.lds_rows = ((tot >> 10) & 1023) * c.dim <= kTeam * 4 && (tot >> 20) <= kLdsRowPairs;
         }
         team_sync();

@@ -623,8 +623,11 @@ __global__ __launch_bounds__(kBlock, 4) void unique_group_kernel(const UArgs a, 
 __global__ __launch_bounds__(kBlock) void unique_order_kernel(const UArgs a, const USync y) {
   __shared__ int32_t wave_cnt[kWavesPerBlock];
   __shared__ int32_t prefix_s;   // first occurrences in the tiles before this one; -1: gave up
+  __shared__ int64_t st_val[kTile];   // the tile's first occurrences in list order
+  static_assert(kPerThread == 4, "the dense upos stores below write four places per thread");
   // (1024-id tiles, 4 consecutive ids per thread; 4096-id tiles with 16 per thread measured 35 us
   // instead of 20 for 26 x 65536 ids: what one thread does in sequence is what counts)
+  HBK_USTAMP(2, 0);
   HBK_FIND_UCOL(tile_start)
   const int ctile = (int)blockIdx.x - c.tile_start;
   const int n_tiles = (c.len + kTile - 1) / kTile;
@@ -643,7 +646,9 @@ __global__ __launch_bounds__(kBlock) void unique_order_kernel(const UArgs a, con
   }
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   if (lane == 0) wave_cnt[wave] = total;
+  HBK_USTAMP(2, 1);   // (thread 0: loads arrived, flags counted)
   __syncthreads();
+  HBK_USTAMP(2, 2);
   if (wave == 0) {
     uint32_t block_total = 0;
 #pragma unroll
@@ -699,19 +704,50 @@ __global__ __launch_bounds__(kBlock) void unique_order_kernel(const UArgs a, con
       }
     }
   }
+  HBK_USTAMP(2, 3);   // (wave 0: look-back done)
   __syncthreads();
+  HBK_USTAMP(2, 4);
   if (prefix_s < 0) return;
-  int pos = prefix_s + below;
-  for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+  // The first occurrences leave through LDS in the order of the unique list, and the places go
+  // out densely (-1 for the other ids): predicated 8- and 4-byte stores of every fourth element
+  // touched four times the lines (4.4 of the tile's 15.6 us went into issuing them).
+  int local = below;
+  for (int w = 0; w < wave; ++w) local += wave_cnt[w];
+  int tile_total = 0;
 #pragma unroll
-  for (int e = 0; e < kPerThread; ++e) {
-    if (flags & (1 << e)) {
-      const int64_t i = i0 + e;
-      c.uniq[pos] = val[e];
-      c.upos[i] = pos;
-      ++pos;
+  for (int w = 0; w < kWavesPerBlock; ++w) tile_total += wave_cnt[w];
+  const int32_t base_pos = prefix_s;
+  int32_t up[kPerThread];
+  {
+    int r = 0;
+#pragma unroll
+    for (int e = 0; e < kPerThread; ++e) {
+      up[e] = -1;
+      if (flags & (1 << e)) {
+        st_val[local + r] = val[e];
+        up[e] = base_pos + local + r;
+        ++r;
+      }
     }
   }
+  if (i0 + kPerThread <= c.len) {
+    // (the workspace slices are 8-byte aligned and i0 is a multiple of 4)
+    *reinterpret_cast<int2*>(c.upos + i0) = make_int2(up[0], up[1]);
+    *reinterpret_cast<int2*>(c.upos + i0 + 2) = make_int2(up[2], up[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < kPerThread; ++e) {
+      if (i0 + e < c.len) c.upos[i0 + e] = up[e];
+    }
+  }
+  __syncthreads();
+  for (int r = (int)threadIdx.x; r < tile_total; r += kBlock) c.uniq[base_pos + r] = st_val[r];
+  HBK_USTAMP(2, 5);
+#ifdef HBK_PART_STAMPS
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  HBK_USTAMP(2, 6);
+  HBK_USTAMP(2, 7);
+#endif
 }
 
 // ---- 8: index[i] = place of the first occurrence of in[i] --------------------------------------

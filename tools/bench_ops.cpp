@@ -162,7 +162,7 @@ static void bench_unique(int n_cols, int64_t len, uint64_t mod) {
   {  // probe build: per-workgroup stamps of the group / first kernels
     typedef int (*trace_fn)(unsigned long long*, int);
     trace_fn fn = (trace_fn)dlsym(RTLD_DEFAULT, "hbk_debug_uni_trace");
-    for (int which = 0; fn != nullptr && which < 2; ++which) {
+    for (int which = 0; fn != nullptr && which < 3; ++which) {
       std::vector<unsigned long long> tr(8192 * 8);
       fn(nullptr, which);
       HB(hbk_unique_n(n_cols, in.data(), lens.data(), u.data(), ix.data(), n.data(), ws, ws_bytes, nullptr));
@@ -182,7 +182,7 @@ static void bench_unique(int n_cols, int64_t len, uint64_t mod) {
       }
       if (nb > 0) {
         printf("   unique %s kernel: %d traced workgroups over %.2f us, mean life %.2f us, last starts at %.2f us; phases (us):",
-               which == 0 ? "group" : "first", nb, (t_max - t_min) * 0.01, life / nb * 0.01, (last_start - t_min) * 0.01);
+               which == 0 ? "group" : which == 1 ? "first" : "order", nb, (t_max - t_min) * 0.01, life / nb * 0.01, (last_start - t_min) * 0.01);
         for (int i = 0; i < 7; ++i) printf(" %.2f", sum[i] / nb * 0.01);
         printf("\n");
       }

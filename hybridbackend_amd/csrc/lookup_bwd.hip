@@ -51,6 +51,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "lookup_common.h"
@@ -1765,6 +1767,51 @@ extern "C" int hbk_group_lookup_bwd(int32_t n_cols, const hbk_lookup_grad_column
                                     workspace_bytes, stream_);
 }
 
+namespace hbk {
+namespace {
+// Four streams and their fork / join events per device, kept for the life of the process.  The
+// mutex is held while a call enqueues on them (host side only: microseconds).
+constexpr int kHelperStreams = 4;
+struct BwdHelpers {
+  hipStream_t s[kHelperStreams];
+  hipEvent_t fork, join[kHelperStreams];
+  std::mutex mu;
+};
+
+BwdHelpers* bwd_helpers(hipStream_t caller) {
+  static std::mutex table_mu;
+  static std::map<int, BwdHelpers*> table;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(caller, &capturing);
+  if (capturing != hipStreamCaptureStatusNone) return nullptr;   // a captured call stays on its stream
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  BwdHelpers* h = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(table_mu);
+    auto it = table.find(dev);
+    if (it == table.end()) {
+      h = new BwdHelpers();
+      bool ok = true;
+      for (int i = 0; i < kHelperStreams; ++i) {
+        ok = ok && hipStreamCreateWithFlags(&h->s[i], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&h->join[i], hipEventDisableTiming) == hipSuccess;
+      }
+      ok = ok && hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) == hipSuccess;
+      if (!ok) {
+        delete h;
+        h = nullptr;
+      }
+      table[dev] = h;
+    } else {
+      h = it->second;
+    }
+  }
+  return h;
+}
+}  // namespace
+}  // namespace hbk
+
 extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
                                           int32_t apply, float apply_lr, void* workspace,
                                           size_t workspace_bytes, hbk_stream_t stream_) {
@@ -1833,18 +1880,37 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     wp += ((size_t)p.n_buckets + p.e_max) * sizeof(int4);
   }
 
+  // More than kMaxCols columns make several launch groups (config 5: 200 columns = 4).  They are
+  // independent (own workspace slices), so they rotate over four streams of the library:
+  // the tail of one group's reduce kernel -- a few long-lived workgroups on an idle chip -- runs
+  // beside the next group's grouping launches instead of in front of them.
+  int32_t live_cols = 0;
+  for (int32_t c = 0; c < n_cols; ++c) live_cols += cols[c].n_ids > 0;
+  int group_cols = options().bwd_group_cols;   // columns per launch group (tuning; 0: kMaxCols)
+  if (group_cols <= 0 || group_cols > kMaxCols) group_cols = kMaxCols;
+  BwdHelpers* helpers = live_cols > group_cols ? bwd_helpers(stream) : nullptr;
+  std::unique_lock<std::mutex> hold;   // (released on every return path)
+  if (helpers != nullptr) {
+    hold = std::unique_lock<std::mutex>(helpers->mu);
+    HBK_HIP_OK(hipEventRecord(helpers->fork, stream));
+    for (int i = 0; i < kHelperStreams; ++i) {
+      HBK_HIP_OK(hipStreamWaitEvent(helpers->s[i], helpers->fork, 0));
+    }
+  }
+  int group_no = 0;
   int32_t c0 = 0;
   while (c0 < n_cols) {
+    hipStream_t ls = helpers != nullptr ? helpers->s[group_no++ % kHelperStreams] : stream;
     GArgs args, seg_args;
     int4* const desc_group = reinterpret_cast<int4*>(dp);
     int32_t k = 0, ks = 0;
     int64_t tiles = 0, buckets = 0, segtiles = 0, merges = 0, scans = 0, sync_words = 0;
     size_t lds_hist = 0;
     bool small_scan = true, group_ok = true;
-    while (c0 < n_cols && k < kMaxCols) {
+    while (c0 < n_cols && k < group_cols) {
       const hbk_lookup_grad_column_t& h = cols[c0++];
       if (h.n_ids == 0) {
-        HBK_HIP_OK(hipMemsetAsync(h.n_unique, 0, sizeof(int32_t), stream));
+        HBK_HIP_OK(hipMemsetAsync(h.n_unique, 0, sizeof(int32_t), ls));
         continue;
       }
       const ColPlan p = plan_of(h.n_ids, h.dim);
@@ -1959,7 +2025,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     if (ks > 0) {
       seg_args.n_cols = ks;
       seg_args.lr = 0.f;
-      hipLaunchKernelGGL(bwd_segof_kernel, dim3((unsigned)segtiles), dim3(kBlock), 0, stream,
+      hipLaunchKernelGGL(bwd_segof_kernel, dim3((unsigned)segtiles), dim3(kBlock), 0, ls,
                          seg_args);
     }
     GSync sync;
@@ -1967,7 +2033,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     bool onepass = small_scan && group_ok && options().bwd_onepass != 0 && sync_words < (1ll << 30);
     if (onepass) {
       SyncTake take;
-      onepass = sync_take(stream, (size_t)sync_words, &take);
+      onepass = sync_take(ls, (size_t)sync_words, &take);
       if (onepass) {
         sync.hist = take.words;
         sync.zero = take.zero;
@@ -1976,24 +2042,24 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       }
     }
     if (onepass) {
-      hipLaunchKernelGGL(bwd_group_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, stream, args,
+      hipLaunchKernelGGL(bwd_group_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ls, args,
                          sync);
     } else {
-      hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist, stream,
+      hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist, ls,
                          args);
     }
     if (onepass) {
       // (hist, scan and scatter were that one launch)
     } else if (small_scan) {
-      hipLaunchKernelGGL(bwd_scan_fused_kernel, dim3((unsigned)k), dim3(kBlock), 0, stream, args);
+      hipLaunchKernelGGL(bwd_scan_fused_kernel, dim3((unsigned)k), dim3(kBlock), 0, ls, args);
     } else {
-      hipLaunchKernelGGL(bwd_scan_tiles_kernel, dim3((unsigned)scans), dim3(kBlock), 0, stream,
+      hipLaunchKernelGGL(bwd_scan_tiles_kernel, dim3((unsigned)scans), dim3(kBlock), 0, ls,
                          args);
-      hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)k), dim3(kBlock), 0, stream, args);
+      hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)k), dim3(kBlock), 0, ls, args);
     }
     if (!onepass) {
       hipLaunchKernelGGL(bwd_scatter_pairs_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist,
-                         stream, args);
+                         ls, args);
     }
     bool any_vec4 = false, any_scalar = false;
     for (int32_t q = 0; q < k; ++q) {
@@ -2016,15 +2082,21 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     const merge_fn merge4 = kMerge4[step], merge1 = kMerge1[step];
     if (any_vec4) {
       hipLaunchKernelGGL(reduce4, dim3((unsigned)((buckets + kTeams - 1) / kTeams)), dim3(kBlock), 0,
-                         stream, args, desc_group, (int)buckets);
+                         ls, args, desc_group, (int)buckets);
     }
     if (any_scalar) {
       hipLaunchKernelGGL(reduce1, dim3((unsigned)((buckets + kTeams - 1) / kTeams)), dim3(kBlock), 0,
-                         stream, args, desc_group, (int)buckets);
+                         ls, args, desc_group, (int)buckets);
     }
-    if (any_vec4) hipLaunchKernelGGL(merge4, dim3((unsigned)merges), dim3(kBlock), 0, stream, args);
-    if (any_scalar) hipLaunchKernelGGL(merge1, dim3((unsigned)merges), dim3(kBlock), 0, stream, args);
+    if (any_vec4) hipLaunchKernelGGL(merge4, dim3((unsigned)merges), dim3(kBlock), 0, ls, args);
+    if (any_scalar) hipLaunchKernelGGL(merge1, dim3((unsigned)merges), dim3(kBlock), 0, ls, args);
     HBK_HIP_OK(hipGetLastError());
+  }
+  if (helpers != nullptr) {
+    for (int i = 0; i < kHelperStreams; ++i) {
+      HBK_HIP_OK(hipEventRecord(helpers->join[i], helpers->s[i]));
+      HBK_HIP_OK(hipStreamWaitEvent(stream, helpers->join[i], 0));
+    }
   }
   return HBK_OK;
 }

@@ -313,9 +313,10 @@ __global__ __launch_bounds__(kTileWaves* kWave) void partition_hist_kernel(const
   while ((1 << nbits) < P) ++nbits;
   const int fixed_max = a.fixed_max;
   int32_t cnt = 0;  // P <= 64: lane p counts the ids of shard p in this tile
-  Run8 run8;        // P <= 8: the counts as uniform words
-  run8.w[0] = run8.w[1] = run8.w[2] = run8.w[3] = 0u;
+  unsigned long long lane_cnt = 0;   // P <= 8: this lane's ids per shard, eight 8-bit fields
   const bool bits8 = P <= 8;
+  const bool pow2_plain = fn.stage == 0 && fn.part.kind == 1 && bk.d == 0;
+  const uint32_t pow2_mask = (uint32_t)fn.part.d - 1u;
   if (!small_p) {
     for (int p = lane; p < P; p += kWave) counters[p] = 0;
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): zeroing done before the atomics
@@ -333,9 +334,14 @@ __global__ __launch_bounds__(kTileWaves* kWave) void partition_hist_kernel(const
     for (int k = 0; k < kChunks; ++k) {
       const int64_t i = base + k * kWave + lane;
       const uint32_t shard =
-          i < len ? shard_of<T>(bucketize<T>(v[k], bk), fn) : 0xffffffffu;
+          !(i < len) ? 0xffffffffu
+                     : pow2_plain ? (uint32_t)v[k] & pow2_mask   // floor-mod by a power of two
+                                  : shard_of<T>(bucketize<T>(v[k], bk), fn);
       if (bits8) {
-        count_bits(shard, i < len, run8);
+        // every lane counts ITS ids in eight 8-bit fields of one 64-bit word: no cross-lane work
+        // per id (the ballots + scalar popcounts per chunk were most of this kernel: 25 us for the
+        // 10 M ids of the reference's benchmark shape, whose 40 MB stream in 8)
+        if (i < len) lane_cnt += 1ull << (shard * 8u);
       } else if (P <= fixed_max) {
         cnt += count_shards(shard, P, lane);
       } else if (small_p) {
@@ -348,7 +354,24 @@ __global__ __launch_bounds__(kTileWaves* kWave) void partition_hist_kernel(const
     }
   }
   int32_t* hist = a.hist + (int64_t)P * c.tile_start;
-  if (bits8) cnt = run_of_lane(run8, lane);
+  if (bits8) {
+    // wave sum of the lanes' counters: bytes spread to 16-bit fields (<= 64 lanes x 128 ids), one
+    // butterfly over four dwords, lane p keeps the field of shard p
+    auto spread = [](uint32_t x) -> unsigned long long {
+      return (unsigned long long)(x & 0xffu) | ((unsigned long long)(x & 0xff00u) << 8) |
+             ((unsigned long long)(x & 0xff0000u) << 16) | ((unsigned long long)(x & 0xff000000u) << 24);
+    };
+    unsigned long long lo = spread((uint32_t)lane_cnt), hi = spread((uint32_t)(lane_cnt >> 32));
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      lo += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(lo >> 32), off, kWave) << 32) |
+            (uint32_t)__shfl_xor((int)(uint32_t)lo, off, kWave);
+      hi += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(hi >> 32), off, kWave) << 32) |
+            (uint32_t)__shfl_xor((int)(uint32_t)hi, off, kWave);
+    }
+    const unsigned long long w = (lane & 4) ? hi : lo;
+    cnt = lane < 8 ? (int32_t)((w >> ((lane & 3) * 16)) & 0xffffu) : 0;
+  }
   if (small_p) {
     if (lane < P) hist[(int64_t)lane * n_tiles + ctile] = cnt;
     return;
@@ -563,6 +586,7 @@ __device__ unsigned long long g_part_trace[kPTraceBlocks * kPTraceSlots];
 #define HBK_PSTAMP(i)
 #endif
 constexpr int kOneMaxTiles = 256;
+constexpr int kOneMaxGrid = 3072;   // tiles of one call
 constexpr int kOneMaxP = 8;
 
 struct OnePass {
@@ -846,7 +870,9 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
     onepass = onepass && t <= kOneMaxTiles;
     all_tiles += t;
   }
-  onepass = onepass && all_tiles > 0;
+  // (beyond what is resident at once the waves wait for slots as much as for counts: the
+  // reference's benchmark shape, 9766 tiles, takes 68 us in one launch and 56 us in three)
+  onepass = onepass && all_tiles > 0 && all_tiles <= kOneMaxGrid;
   OnePass one;
   one.zero = nullptr;
   one.zero_words = 0;

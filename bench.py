@@ -68,6 +68,11 @@ def parse_args():
                  help='distinct id batches kept in HBM (default: steps + warmup, max 64)')
   p.add_argument('--dry-run', action='store_true',
                  help='launcher + rendezvous + barrier + reduction only (no GPU, no kernels)')
+  p.add_argument('--tune-steps', type=int, default=8,
+                 help='N > 1 (or --sharded): untimed steps per candidate of the pipeline group '
+                      'count (option sharded_groups: 2 = exchanges of one column group overlap the '
+                      'gather / stitch of the other, 1 = no pipelining, half the cross-stream '
+                      'hops); the faster one runs the timed steps.  0: keep the default')
   p.add_argument('--link-probe-mb', type=float, default=16.0,
                  help='N > 1: MB per peer of the equal-split alltoallv that measures the links '
                       'before the timed steps (0 disables it)')
@@ -363,6 +368,35 @@ def main():
   if world > 1 and args.link_probe_mb > 0:
     probe = link_probe(coll, device, world, args.link_probe_mb, dist)
 
+  # The pipeline group count of the sharded step is a hardware question (a cross-stream hop costs
+  # ~11 us on this chip, an owner gather ~33 us: profiles/r02_hop_probe.txt): both forms run a few
+  # untimed steps on the machine at hand, every rank takes the one whose slowest rank was faster.
+  groups_probe = None
+  if (world > 1 or args.sharded) and args.tune_steps > 0:
+    from hybridbackend_amd import _lib as _hbk
+    groups_probe = {}
+    for g in (2, 1):
+      _hbk.set_option('sharded_groups', g)
+      sharded.close()                 # the option is read when the plan is (re)created
+      for i in range(3):
+        step(i)
+      torch.cuda.synchronize()
+      barrier()
+      t_probe = time.perf_counter()
+      for i in range(args.tune_steps):
+        step(3 + i)
+      torch.cuda.synchronize()
+      barrier()
+      dt = time.perf_counter() - t_probe
+      if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+      groups_probe[g] = round(dt / args.tune_steps * 1e3, 5)
+    best_groups = min(groups_probe, key=groups_probe.get)
+    _hbk.set_option('sharded_groups', best_groups)
+    sharded.close()
+
   for i in range(args.warmup):
     step(i)
   torch.cuda.synchronize()
@@ -408,7 +442,9 @@ def main():
                  'parallelism': parallelism,
                  'wire': args.wire if world > 1 else None,
                  'prefetch_next_partition': (world > 1 or args.sharded) and not args.no_prefetch,
-                 'id_batches_resident': n_batches},
+                 'id_batches_resident': n_batches,
+                 'sharded_groups': (best_groups if groups_probe else None),
+                 'sharded_groups_probe_ms_per_step': groups_probe},
       'roofline': {
         'bound': 'hbm',
         'kernel': ('group_lookup_fwd_kernel' if world == 1 and not args.sharded

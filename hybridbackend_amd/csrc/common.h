@@ -124,6 +124,7 @@ struct Options {
   int bwd_split_pairs = 0;     // HBK_BWD_SPLIT: pairs per workgroup of a split bucket (0: default)
   int bwd_onepass = 1;         // HBK_BWD_ONEPASS: 0 = histogram, scan and scatter as three launches
   int bwd_group_cols = 0;      // HBK_BWD_GROUP_COLS: columns per launch group of the backward (0: 64)
+  int bwd_dense = 1;           // HBK_BWD_DENSE: 0 = hashed buckets for every column (no row-range buckets)
   int unique_buckets_log2 = -1;  // HBK_UNIQUE_LOG2P
   int partition_sub_tiles = 1;   // HBK_PART_SUB
   int partition_fixed_max = 8;   // HBK_PART_FIXED

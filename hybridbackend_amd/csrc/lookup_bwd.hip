@@ -210,6 +210,10 @@ struct GCol {
   int32_t scan0;             // first block (scan-over-tiles grid)
   int32_t n_runs;
   int32_t grad_stride;       // floats between rows of grad_out (>= dim)
+  uint32_t dense_mul;        // != 0: DENSE column -- a bucket is a row RANGE, bucket =
+                             // mulhi(row, dense_mul), and the reduce stage indexes its LDS tables
+                             // directly with row - first row of the range (4b); 0: hashed buckets
+  int32_t pad_;
 };
 
 struct GArgs {
@@ -255,9 +259,13 @@ __device__ inline uint32_t mix32(uint64_t row) {
   return k;
 }
 
-// bucket = high bits of the mix scaled to any bucket count; the LDS table uses the LOW bits
-__device__ inline int bucket_of(uint64_t row, int n_buckets) {
-  return (int)__umulhi(mix32(row), (uint32_t)n_buckets);
+// bucket = high bits of the mix scaled to any bucket count; the LDS table uses the LOW bits.
+// Dense columns (rows / ids small enough that a bucket's row range fits the LDS bitmaps of 4b):
+// bucket = floor(row * M / 2^32), M = floor(2^32 * P / rows) -- monotone in the row, so a bucket
+// is the row range [ceil(b 2^32 / M), ceil((b + 1) 2^32 / M)).
+__device__ inline int bucket_of(const GCol& c, uint64_t row) {
+  if (c.dense_mul != 0) return (int)__umulhi((uint32_t)row, c.dense_mul);
+  return (int)__umulhi(mix32(row), (uint32_t)c.n_buckets);
 }
 
 // Segmented inputs: position j of the column -> where its id and its gradient row live.  A
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
       const int64_t j = base + (int64_t)(k0 + k) * kBlock + tid;
       if (j < c.n_ids) {
         const uint64_t r = id_to_row(c.map, id[k]);
-        if (r != kNoRow) atomicAdd(&counters[bucket_of(r, c.n_buckets)], 1);
+        if (r != kNoRow) atomicAdd(&counters[bucket_of(c, r)], 1);
       }
     }
   }
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
       if (j < c.n_ids) {
         const uint64_t r = id_to_row(c.map, id[k]);
         if (r != kNoRow) {
-          const int32_t pos = atomicAdd(&run[bucket_of(r, c.n_buckets)], 1);
+          const int32_t pos = atomicAdd(&run[bucket_of(c, r)], 1);
           c.pair_row[0][pos] = (int64_t)r;
           c.pair_seg[0][pos] = seg[k];
         }
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
       const uint64_t r = id_to_row(c.map, id[k]);
       id[k] = (int64_t)r;
       if (r != kNoRow) {
-        const int b = bucket_of(r, P);
+        const int b = bucket_of(c, r);
         br[k] = b | (atomicAdd(&counters[b], 1) << 10);
       }
     }
@@ -1446,6 +1454,341 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
   }
 }
 
+// ---- 4b: dense columns -- one workgroup per ROW RANGE, LDS tables indexed by the row ---------------
+// When a column's batch covers its table densely enough (rows / ids <~ 36: all of config 2, most
+// of config 5) a bucket is a contiguous range of <= kDenseSpan rows and the reduce stage needs no
+// hash table, no CAS, no probe chains and no tickets:
+//   A  every pair sets its row's bit in a PRESENT bitmap (ds_or with return); a pair that finds
+//      the bit set also sets it in a DUP bitmap (rows with several pairs);
+//   B  one packed scan over the bitmap words (popcounts): rows before every word.  The rank of a
+//      row among the bucket's rows = prefix + popcount of the lower bits of its word -- its output
+//      position once the workgroup's ONE global atomic has claimed the range; the rows leave
+//      SORTED, and their numbers are written straight from the bitmap (consecutive lanes store
+//      consecutive entries);
+//   C  a pair whose row has no other pair (the common case) moves its gradient row from the
+//      registers it arrived in to its output row, with the optimizer step when there is one (the
+//      table / accumulator row travels in the same round);
+//   D  the pairs of DUP rows are summed in LDS rows (ds_add_f32; a lane group first adds up what it
+//      holds for one row in registers), kRedFloats / dim rows per round, and every such row is
+//      emitted -- and stepped -- once, from the finished sum.
+// Every row is complete when it is emitted whatever the number of chunks: no rows spanning chunks,
+// no deferred step, no second pass.  Jobs of several chunks (a bucket above kCP pairs, the ranges
+// of a split bucket, the merge of their partial entries) read their pairs once per stage.
+constexpr int kDenseSpan = 16384;                 // rows of a bucket's range (bits per bitmap)
+constexpr int kDenseWords = kDenseSpan / 32;
+constexpr int kDenseWPT = kDenseWords / kBlock;   // bitmap words per thread in the scan
+constexpr int kRedFloats = 4096;                  // LDS floats that take the sums of dup rows
+constexpr int32_t kDupBit = 1 << 30;
+static_assert(kDenseWords % kBlock == 0, "whole words per thread");
+
+struct DenseLds {
+  uint32_t present[kDenseWords];
+  uint32_t dup[kDenseWords];
+  uint32_t pre[kDenseWords];     // rows before word w: present (low 16 bits) | dup (high 16 bits)
+  int32_t seg[kCP];              // gradient row of every pair of the chunk
+  int32_t code[kCP];             // rank of the pair's row among the bucket's rows, or kDupBit | its
+                                 // rank among the dup rows
+  uint16_t off[kCP];             // row - first row of the range
+  uint16_t dlist[kCP];           // pairs of the chunk whose dup row is summed in this round
+  uint16_t doff[kCP];            // row - first row of the range, of every dup row of the round
+  float red[kRedFloats];
+  int32_t wave_tot[kWavesPerBlock];
+  int32_t n_rows, n_dup, base_u;
+  int32_t n_dlist[2];
+};
+
+// first row of bucket b of a dense column: the smallest r with mulhi(r, M) >= b
+__device__ inline uint64_t dense_first_row(uint32_t M, int b) {
+  return (((uint64_t)(uint32_t)b << 32) + M - 1) / M;
+}
+
+template <typename V, int STEP>
+__device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLds& L, int bucket) {
+  constexpr int VE = sizeof(V) / 4;
+  constexpr int PT = kCP / kBlock;   // pairs per thread and chunk
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
+  const int lpr_log2 = c.lpr_log2;
+  const int sub = lane & ((1 << lpr_log2) - 1);
+  const bool live = sub < c.chunks;
+  const int groups = kBlock >> lpr_log2;
+  const int my_group = tid >> lpr_log2;
+  const int32_t n_pairs = job.n_pairs;
+  if (n_pairs <= 0) return;
+  const int64_t* prow = job.prow;
+  const int32_t* pseg = job.pseg;
+  const bool one_chunk = n_pairs <= kCP;   // the pairs stay in registers between the stages
+  const float lr = STEP ? job.lr : 0.0f;
+  constexpr bool adagrad = STEP == 2;
+  const bool emit = !(STEP && job.no_emit);
+
+  int64_t r_in[PT];
+  int32_t seg_in[PT];
+  auto load_pairs = [&](int32_t cb) {
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      const int32_t e = cb + k * kBlock + tid;
+      r_in[k] = -1;
+      seg_in[k] = e;
+      if (e < n_pairs) {
+        r_in[k] = prow[e];
+        if (pseg != nullptr) seg_in[k] = pseg[e];
+      }
+    }
+  };
+  load_pairs(0);   // they travel while the bitmaps are cleared
+  const uint32_t M = c.dense_mul;
+  const uint32_t base = (uint32_t)dense_first_row(M, bucket);
+  uint64_t lim = dense_first_row(M, bucket + 1);
+  if (lim > c.map.rows) lim = c.map.rows;
+  const int words = (int)((lim - base + 31) >> 5);   // <= kDenseWords (host: plan_of)
+
+  __syncthreads();   // a workgroup may run several jobs (merge): the previous one is done with L
+  for (int w = tid; w < words; w += kBlock) {
+    L.present[w] = 0u;
+    L.dup[w] = 0u;
+  }
+  if (tid == 0) {
+    L.n_dlist[0] = 0;
+    L.n_dlist[1] = 0;
+  }
+  __syncthreads();
+  HBK_STAMP(2);
+
+  // A: rows -> bitmaps.  A bit that is already set is not set again: the pairs of a hot row
+  // would serialise on its word (64 same-address LDS atomics per instruction).
+  for (int32_t cb = 0; cb < n_pairs; cb += kCP) {
+    if (cb > 0) load_pairs(cb);
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      if (r_in[k] >= 0) {
+        const uint32_t off = (uint32_t)r_in[k] - base;
+        const int w = (int)(off >> 5);
+        const uint32_t bit = 1u << (off & 31u);
+        uint32_t old = L.present[w];
+        if ((old & bit) == 0u) old = atomicOr(&L.present[w], bit);
+        if ((old & bit) != 0u && (L.dup[w] & bit) == 0u) atomicOr(&L.dup[w], bit);
+      }
+    }
+  }
+  __syncthreads();
+  HBK_STAMP(3);
+
+  // B: rows before every word, present and dup counts packed in one scan (both <= kDenseSpan < 2^16)
+  int32_t claimed = 0;
+  {
+    uint32_t cnt[kDenseWPT], sum = 0;
+#pragma unroll
+    for (int q = 0; q < kDenseWPT; ++q) {
+      const int w = tid * kDenseWPT + q;
+      cnt[q] = 0;
+      if (w < words) {
+        cnt[q] = (uint32_t)__builtin_popcount(L.present[w]) |
+                 ((uint32_t)__builtin_popcount(L.dup[w]) << 16);
+      }
+      sum += cnt[q];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)incl, o, kWave);
+      if (lane >= o) incl += y;
+    }
+    if (lane == kWave - 1) L.wave_tot[wave] = (int32_t)incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += (uint32_t)L.wave_tot[w];
+#pragma unroll
+    for (int q = 0; q < kDenseWPT; ++q) {
+      const int w = tid * kDenseWPT + q;
+      if (w < words) L.pre[w] = run;
+      run += cnt[q];
+    }
+    if (tid == kBlock - 1) {
+      const int32_t n_rows = (int32_t)(run & 0xffffu);
+      L.n_rows = n_rows;
+      L.n_dup = (int32_t)(run >> 16);
+      // One global atomic per workgroup claims the output range of the bucket's rows; a returning
+      // device-scope atomic takes microseconds under load: its round trip runs beside the gradient
+      // loads of C.  Step only: just the count is wanted, nobody waits for it.
+      if (!emit) {
+        __hip_atomic_fetch_add(job.out_counter, n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        claimed = atomicAdd(job.out_counter, n_rows);
+      }
+    }
+  }
+  __syncthreads();
+  HBK_STAMP(4);
+
+  const int n_dup = L.n_dup;
+  int cap = kRedFloats / c.dim;   // dup rows summed per round
+  if (cap > kCP) cap = kCP;
+  const int n_rounds = n_dup > 0 ? (n_dup + cap - 1) / cap : 1;
+  // gradient rows a lane keeps in flight (register budget: the step's table / accumulator rows
+  // travel with them)
+  constexpr int kDepth = STEP == 2 ? 3 : STEP ? 4 : 8;
+  int32_t base_u = 0;
+  bool have_base = !emit;   // step only: no output positions
+  int par = 0;
+  for (int round = 0; round < n_rounds; ++round) {
+    const int d0 = round * cap;
+    const int d1 = n_dup < d0 + cap ? n_dup : d0 + cap;
+    for (int i = tid; i < (d1 - d0) * c.dim; i += kBlock) L.red[i] = 0.0f;
+    for (int32_t cb = 0; cb < n_pairs; cb += kCP, par ^= 1) {
+      const int32_t n_chunk = n_pairs - cb < kCP ? n_pairs - cb : kCP;
+      if (!one_chunk) {
+        load_pairs(cb);
+        __syncthreads();   // the walks of the chunk before are over: seg / code / dlist are free
+      }
+      // per pair: output rank of its row; dup pairs of this round go on the chunk's list
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const int e = k * kBlock + tid;
+        bool listed = false;
+        if (r_in[k] >= 0) {
+          const uint32_t off = (uint32_t)r_in[k] - base;
+          const int w = (int)(off >> 5);
+          const uint32_t below = (1u << (off & 31u)) - 1u;
+          const uint32_t pw = L.present[w], dw = L.dup[w], pr = L.pre[w];
+          int32_t code = (int32_t)(pr & 0xffffu) + __builtin_popcount(pw & below);
+          if ((dw >> (off & 31u)) & 1u) {
+            const int32_t dr = (int32_t)(pr >> 16) + __builtin_popcount(dw & below);
+            code = kDupBit | dr;
+            if (dr >= d0 && dr < d1) {
+              listed = true;
+              L.doff[dr - d0] = (uint16_t)off;   // (every pair of the row writes the same value)
+            }
+          }
+          L.seg[e] = seg_in[k];
+          L.code[e] = code;
+          L.off[e] = (uint16_t)off;
+        }
+        const unsigned long long m = __ballot(listed);
+        if (m != 0ull) {
+          const int first = __builtin_ctzll(m);
+          int at = 0;
+          if (lane == first) at = atomicAdd(&L.n_dlist[par], (int)__builtin_popcountll(m));
+          at = __builtin_amdgcn_readlane(at, first);
+          if (listed) L.dlist[at + rank_below(m)] = (uint16_t)e;
+        }
+      }
+      if (tid == 0) L.n_dlist[par ^ 1] = 0;   // the next chunk's list (its last users are past the
+                                              // barrier above, or there is no chunk before)
+      __syncthreads();
+      HBK_STAMP(5);
+
+      // C: the pairs that are alone on their row (first round only)
+      if (round == 0) {
+        for (int e0 = 0; e0 < n_chunk; e0 += kDepth * groups) {
+          V g[kDepth], tv[STEP ? kDepth : 1], av[STEP == 2 ? kDepth : 1];
+          uint32_t mask = 0;
+#pragma unroll
+          for (int k = 0; k < kDepth; ++k) {
+            const int i = e0 + k * groups + my_group;
+            g[k] = zero_v<V>();
+            if (i < n_chunk && live) {
+              const int32_t code = L.code[i];
+              if ((code & kDupBit) == 0) {
+                mask |= 1u << k;
+                g[k] = load_grad<V>(c, job, L.seg[i], sub);
+                if (STEP && lr != 0.0f) {
+                  const int64_t toff = (int64_t)(base + L.off[i]) * c.dim + (int64_t)sub * VE;
+                  tv[STEP ? k : 0] =
+                      __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+                  if (STEP == 2) {
+                    av[STEP == 2 ? k : 0] =
+                        __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
+                  }
+                }
+              }
+            }
+          }
+          if (!have_base) {   // uniform
+            if (tid == kBlock - 1) L.base_u = job.out_base + claimed;
+            __syncthreads();
+            base_u = L.base_u;
+            have_base = true;
+          }
+#pragma unroll
+          for (int k = 0; k < kDepth; ++k) {
+            if ((mask >> k & 1u) == 0) continue;
+            const int i = e0 + k * groups + my_group;
+            if (emit) emit_row<V>(c, job, base_u + L.code[i], true, sub, g[k]);
+            if (STEP && lr != 0.0f) {
+              const int64_t toff = (int64_t)(base + L.off[i]) * c.dim + (int64_t)sub * VE;
+              step_row<V>(c, adagrad, lr, toff, g[k], tv[STEP ? k : 0],
+                          STEP == 2 ? av[STEP == 2 ? k : 0] : zero_v<V>());
+            }
+          }
+        }
+      }
+
+      // D: this round's dup pairs -> LDS sums.  What a lane group holds for one row in
+      // consecutive registers is added up first: a hot row's pairs cost one LDS add per group
+      // and round instead of one each.
+      const int n_dl = L.n_dlist[par];
+      for (int i0 = 0; i0 < n_dl; i0 += kDepth * groups) {
+        V g[kDepth];
+        int dr[kDepth];
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) {
+          const int i = i0 + k * groups + my_group;
+          dr[k] = -1;
+          g[k] = zero_v<V>();
+          if (i < n_dl && live) {
+            const int e = (int)L.dlist[i];
+            dr[k] = (L.code[e] & (kDupBit - 1)) - d0;
+            g[k] = load_grad<V>(c, job, L.seg[e], sub);
+          }
+        }
+#pragma unroll
+        for (int k = 1; k < kDepth; ++k) {
+          if (dr[k] >= 0 && dr[k] == dr[k - 1]) {
+            g[k] = g[k] + g[k - 1];
+            dr[k - 1] = -1;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) {
+          if (dr[k] >= 0) {
+            float* r = &L.red[(size_t)dr[k] * c.dim + (size_t)sub * VE];
+#pragma unroll
+            for (int q = 0; q < VE; ++q) atomicAdd(r + q, reinterpret_cast<const float*>(&g[k])[q]);
+          }
+        }
+      }
+    }
+    if (n_dup > 0) {
+      __syncthreads();   // the round's sums are complete
+      for (int m = d0 + my_group; m < d1; m += groups) {
+        if (!live) continue;
+        const uint32_t off = L.doff[m - d0];
+        const int w = (int)(off >> 5);
+        const int32_t rank = (int32_t)(L.pre[w] & 0xffffu) +
+                             __builtin_popcount(L.present[w] & ((1u << (off & 31u)) - 1u));
+        emit_step_row<V, STEP>(c, job, lr, base_u + rank, true, (int64_t)(base + off), sub,
+                               *reinterpret_cast<const V*>(&L.red[(size_t)(m - d0) * c.dim +
+                                                                  (size_t)sub * VE]));
+      }
+      if (round + 1 < n_rounds) __syncthreads();   // the next round clears the sums
+    }
+  }
+  HBK_STAMP(6);
+  // the row numbers, sorted, straight from the bitmap
+  if (emit) {
+    for (int w = tid; w < words; w += kBlock) {
+      uint32_t m = L.present[w];
+      int64_t* o = job.out_rows + base_u + (int32_t)(L.pre[w] & 0xffffu);
+      const int64_t r0 = (int64_t)base + 32 * (int64_t)w;
+      while (m != 0u) {
+        *o++ = r0 + __builtin_ctz(m);
+        m &= m - 1u;
+      }
+    }
+  }
+}
+
 // Two instantiations (16-byte / 4-byte chunks) so the common one keeps its registers low; a job
 // whose column is of the other kind is skipped.  Every workgroup's job is one 16-byte descriptor
 // written by the scan kernel (slots [0, P) of a column are its buckets = range 0 of a split
@@ -1453,14 +1796,14 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
 // of dependent loads (column, list of extras, bucket start, bucket end) at the head of every
 // workgroup's critical path.  (Persistent workgroups that fetch the next job's pairs while the
 // current one runs were tried: the state carried around the loop spills, 224 us vs 143.)
-template <typename V>
+template <typename V, bool DENSE>
 __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4& d, float lr,
                                   int* ci_out, ReduceJob* job) {
   if (d.z < 0 || d.y <= 0) return false;   // wave-uniform
   int ci = (int)__builtin_popcountll(__ballot(my_b0 <= vb)) - 1;
   ci = __builtin_amdgcn_readfirstlane(ci);
   const GCol& c = a.col[ci];
-  if ((c.vec4 != 0) != (sizeof(V) == 16)) return false;
+  if ((c.vec4 != 0) != (sizeof(V) == 16) || (c.dense_mul != 0) != DENSE) return false;
   *ci_out = ci;
   const int32_t start = d.x, n_b = d.y, bucket = d.z, range = d.w;
   job->no_emit = false;
@@ -1489,29 +1832,57 @@ __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4&
     job->out_base = 0;
     job->lr = lr;
     job->apply = a.apply;
-    job->no_emit = c.no_emit != 0 && lr != 0.0f && n_b <= kCP;
+    // step only: a dense job emits every row complete whatever its chunk count; a hashed one may
+    // see a row span chunks (deferred step from the emitted rows)
+    job->no_emit = c.no_emit != 0 && lr != 0.0f && (DENSE || n_b <= kCP);
   }
   return true;
 }
 
+// The kernels are instantiated per row kind (16-byte / 4-byte chunks), optimizer (none / SGD /
+// Adagrad) and bucket kind (hashed / dense); the host sorts a launch group's columns by kind, so
+// the job slots of one kind are one range [slot0, slot0 + grid) and no workgroup starts for
+// nothing.
 template <typename V, int STEP>
 __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const GArgs a,
                                                                           const int4* desc,
-                                                                          int total) {
+                                                                          int slot0, int total) {
   __shared__ ReduceLds lds[kTeams];
   HBK_STAMP_BEGIN()
   const int lane = (int)threadIdx.x & (kWave - 1);
   const int team = (int)threadIdx.x / kTeam;
-  const int vb = (int)blockIdx.x * kTeams + team;   // the team's job slot
+  const int vb = slot0 + (int)blockIdx.x * kTeams + team;   // the team's job slot
   if (vb >= total) return;                          // team-uniform; no workgroup barrier follows
   // two independent loads (the job, the columns' first slots): one round trip
   const int4 d = desc[vb];
   const int my_b0 = lane < a.n_cols ? a.bucket0[lane] : 0x7fffffff;
   ReduceJob job;
   int ci;
-  if (!decode_job<V>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
+  if (!decode_job<V, false>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
   HBK_STAMP(1);
   bucket_reduce<V, STEP>(a.col[ci], job, lds[team]);
+  HBK_STAMP(7);
+}
+
+#ifndef HBK_BWD_DENSE_WAVES
+#define HBK_BWD_DENSE_WAVES 5
+#endif
+template <typename V, int STEP>
+__global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES) void bwd_dense_kernel(const GArgs a,
+                                                                               const int4* desc,
+                                                                               int slot0, int total) {
+  __shared__ DenseLds lds;
+  HBK_STAMP_BEGIN()
+  const int lane = (int)threadIdx.x & (kWave - 1);
+  const int vb = slot0 + (int)blockIdx.x;
+  if (vb >= total) return;
+  const int4 d = desc[vb];
+  const int my_b0 = lane < a.n_cols ? a.bucket0[lane] : 0x7fffffff;
+  ReduceJob job;
+  int ci;
+  if (!decode_job<V, true>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
+  HBK_STAMP(1);
+  dense_reduce<V, STEP>(a.col[ci], job, lds, d.z);
   HBK_STAMP(7);
 }
 
@@ -1519,38 +1890,21 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
 // with range index 1 in the column's list of extra ranges; the column's merge blocks (at most
 // kMergeBlocks) share that list round robin.
 constexpr int kMergeBlocks = 8;
-template <typename V, int STEP>
-__global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const GArgs a) {
-  __shared__ ReduceLds lds[kTeams];
-  HBK_FIND_COL(a, merge0)
-  if ((c.vec4 != 0) != (sizeof(V) == 16)) return;
-  const int team = (int)threadIdx.x / kTeam;
-  const int n_extra = *c.n_extra;
-  const int blocks = c.e_max < kMergeBlocks ? c.e_max : kMergeBlocks;
-  for (int e = ((int)blockIdx.x - c.merge0) * kTeams + team; e < n_extra; e += blocks * kTeams) {
-    if (c.work[2 * e + 1] != 1) continue;
-    const int bucket = c.work[2 * e];
-    const int32_t start = c.bstart[bucket];
-    ReduceJob job;
-    job.prow = c.part_rows + start;
-    job.pseg = nullptr;
-    job.grad = c.part_vals + (int64_t)start * c.dim;
-    job.n_pairs = c.pcount[bucket];
-    job.scale = false;
-    job.seg_is_offset = false;
-    job.stride = c.dim;
-    job.out_rows = c.unique_rows;
-    job.out_vals = c.grad_rows;
-    job.out_counter = c.counter;
-    job.out_base = 0;
-    job.lr = a.lr;
-    job.apply = a.apply;
-    job.no_emit = false;
-    bucket_reduce<V, STEP>(c, job, lds[team]);
-  }
-  // The column's row count goes from its workspace counter to the caller's n_unique: by the last
-  // of the column's merge blocks to get here (no launch of its own).  Every claim of a block has
-  // returned before the block counts itself done, so the last one reads the final count.
+
+#define HBK_FIND_COL_AT(ARGS, FIELD, BLOCK)                                        \
+  int ci;                                                                          \
+  {                                                                                \
+    const int l__ = (int)threadIdx.x & (kWave - 1);                                \
+    const int v__ = l__ < (ARGS).n_cols ? (ARGS).FIELD[l__] : 0x7fffffff;          \
+    ci = (int)__builtin_popcountll(__ballot(v__ <= (BLOCK))) - 1;                  \
+    ci = __builtin_amdgcn_readfirstlane(ci);                                       \
+  }                                                                                \
+  const auto& c = (ARGS).col[ci];
+
+// the column's row count goes from its workspace counter to the caller's n_unique: by the last of
+// the column's merge blocks to get here (no launch of its own).  Every claim of a block has
+// returned before the block counts itself done, so the last one reads the final count.
+__device__ inline void merge_done(const GCol& c, int blocks) {
   __syncthreads();
   if (threadIdx.x == 0) {
     const int32_t done = __hip_atomic_fetch_add(c.counter + 1, 1, __ATOMIC_RELAXED,
@@ -1559,6 +1913,58 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const 
       *c.n_unique = __hip_atomic_load(c.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+__device__ inline void merge_job(const GArgs& a, const GCol& c, int bucket, ReduceJob* job) {
+  const int32_t start = c.bstart[bucket];
+  job->prow = c.part_rows + start;
+  job->pseg = nullptr;
+  job->grad = c.part_vals + (int64_t)start * c.dim;
+  job->n_pairs = c.pcount[bucket];
+  job->scale = false;
+  job->seg_is_offset = false;
+  job->stride = c.dim;
+  job->out_rows = c.unique_rows;
+  job->out_vals = c.grad_rows;
+  job->out_counter = c.counter;
+  job->out_base = 0;
+  job->lr = a.lr;
+  job->apply = a.apply;
+  job->no_emit = false;
+}
+
+template <typename V, int STEP>
+__global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const GArgs a, int block0) {
+  __shared__ ReduceLds lds[kTeams];
+  const int block = block0 + (int)blockIdx.x;
+  HBK_FIND_COL_AT(a, merge0, block)
+  const int team = (int)threadIdx.x / kTeam;
+  const int n_extra = *c.n_extra;
+  const int blocks = c.e_max < kMergeBlocks ? c.e_max : kMergeBlocks;
+  for (int e = (block - c.merge0) * kTeams + team; e < n_extra; e += blocks * kTeams) {
+    if (c.work[2 * e + 1] != 1) continue;
+    ReduceJob job;
+    merge_job(a, c, c.work[2 * e], &job);
+    bucket_reduce<V, STEP>(c, job, lds[team]);
+  }
+  merge_done(c, blocks);
+}
+
+template <typename V, int STEP>
+__global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES) void bwd_dense_merge_kernel(const GArgs a,
+                                                                                     int block0) {
+  __shared__ DenseLds lds;
+  const int block = block0 + (int)blockIdx.x;
+  HBK_FIND_COL_AT(a, merge0, block)
+  const int n_extra = *c.n_extra;
+  const int blocks = c.e_max < kMergeBlocks ? c.e_max : kMergeBlocks;
+  for (int e = block - c.merge0; e < n_extra; e += blocks) {
+    if (c.work[2 * e + 1] != 1) continue;   // uniform
+    ReduceJob job;
+    merge_job(a, c, c.work[2 * e], &job);
+    dense_reduce<V, STEP>(c, job, lds, c.work[2 * e]);
+  }
+  merge_done(c, blocks);
 }
 
 // ---- d(stitch + combiner): permutation scatter (hbk_group_stitch_bwd) ----------------------
@@ -1661,14 +2067,16 @@ struct ColPlan {
   int64_t tiles;
   int32_t split_t;   // a bucket above this many pairs is reduced by several workgroups
   int32_t e_max;
+  uint32_t dense_mul;   // != 0: row-range buckets (4b)
 };
 
 // options (hbk_set_option): bwd_buckets_log2 forces the bucket count to 1 << value (0 = one
 // bucket per column) so that multi-chunk buckets, rows spanning chunks and the multi-pass path
-// can be exercised; bwd_bucket_pairs sets the aimed pairs per bucket (tuning)
+// can be exercised; bwd_bucket_pairs sets the aimed pairs per bucket (tuning); bwd_dense = 0
+// keeps hashed buckets for every column
 int forced_log2p() { return options().bwd_buckets_log2; }
 
-ColPlan plan_of(int64_t n_ids, int32_t dim) {
+ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows) {
   (void)dim;
   ColPlan p;
   // Aim at 7/8 of a chunk per bucket: bucket sizes are Poisson around the aim, so ~0.1 % of the
@@ -1682,6 +2090,19 @@ ColPlan plan_of(int64_t n_ids, int32_t dim) {
   if (nb > kMaxBuckets) nb = kMaxBuckets;
   const int forced = forced_log2p();
   if (forced >= 0 && forced <= 14) nb = (int64_t)1 << forced;
+  // Dense: bucket = floor(row * M / 2^32) with M = floor(2^32 P / rows) (< 2^32: P <= rows; any
+  // smaller M is still a monotone map into [0, P)); a bucket then spans at most ceil(2^32 / M)
+  // rows, which must fit the reduce stage's LDS bitmaps.
+  p.dense_mul = 0;
+  if (kTeam == kBlock && options().bwd_dense != 0 && rows >= 1 && rows < (1ll << 32)) {
+    const int64_t P = nb < rows ? nb : rows;
+    uint64_t M = ((uint64_t)P << 32) / (uint64_t)rows;
+    if (M > 0xffffffffull) M = 0xffffffffull;
+    if (M >= 1 && (((uint64_t)1 << 32) + M - 1) / M <= (uint64_t)kDenseSpan) {
+      p.dense_mul = (uint32_t)M;
+      nb = P;
+    }
+  }
   p.n_buckets = (int)nb;
   p.tiles = (n_ids + kTile - 1) / kTile;
   // hashing keeps ordinary buckets near n / P pairs; twice that (and >= 2 chunks) means a hot row
@@ -1696,7 +2117,7 @@ ColPlan plan_of(int64_t n_ids, int32_t dim) {
 
 size_t col_workspace(const hbk_lookup_grad_column_t& h) {
   if (h.n_ids <= 0) return 0;
-  const ColPlan p = plan_of(h.n_ids, h.dim);
+  const ColPlan p = plan_of(h.n_ids, h.dim, h.rows);
   size_t b = align8(((size_t)p.tiles * p.n_buckets) * 4);   // hist
   b += align8(((size_t)p.n_buckets + 1) * 4);          // bstart
   b += (size_t)h.n_ids * 8;                                // pair_row
@@ -1876,19 +2297,61 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
   char* wp = dp;
   for (int32_t c = 0; c < n_cols; ++c) {
     if (cols[c].n_ids <= 0) continue;
-    const ColPlan p = plan_of(cols[c].n_ids, cols[c].dim);
+    const ColPlan p = plan_of(cols[c].n_ids, cols[c].dim, cols[c].rows);
     wp += ((size_t)p.n_buckets + p.e_max) * sizeof(int4);
+  }
+
+  // Per column: plan, row shape, kind.  Everything that can fail is checked here, before any
+  // helper stream is forked.
+  struct ColInfo {
+    ColPlan p;
+    RowShape shape;
+    int kind;       // (dense ? 0 : 2) + (16-byte chunks ? 0 : 1): columns of a launch group are
+                    // sorted by it, so every kernel instantiation runs on ONE range of job slots
+    bool onepass;   // small enough for the one-launch grouping (bwd_group_kernel)
+  };
+  std::vector<ColInfo> info((size_t)n_cols);
+  std::vector<int32_t> order;   // live columns: the one-launch ones first, then the large ones
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int32_t c = 0; c < n_cols; ++c) {
+      const hbk_lookup_grad_column_t& h = cols[c];
+      if (h.n_ids <= 0) continue;
+      ColInfo& ci = info[(size_t)c];
+      if (pass == 0) {
+        ci.p = plan_of(h.n_ids, h.dim, h.rows);
+        HBK_REQUIRE(h.grad_stride == 0 || (h.grad_stride >= h.dim && h.n_runs == 0),
+                    "group_lookup_bwd: column %d: bad grad_stride %d", c, h.grad_stride);
+        HBK_REQUIRE(make_rowshape(h.dim,
+                                  (uintptr_t)h.grad_out | (uintptr_t)h.grad_rows |
+                                      ((uintptr_t)(uint32_t)h.grad_stride * 4) |
+                                      (apply_lr != 0.0f ? (uintptr_t)h.table | (uintptr_t)h.accum : 0),
+                                  &ci.shape),
+                    "group_lookup_bwd: dim %d needs more than 64 lanes per row", h.dim);
+        ci.kind = (ci.p.dense_mul != 0 ? 0 : 2) + (ci.shape.vec4 ? 0 : 1);
+        ci.onepass = options().bwd_onepass != 0 && ci.p.n_buckets <= kGroupMaxBuckets &&
+                     ci.p.tiles <= 64;
+      }
+      if ((pass == 0) == ci.onepass) order.push_back(c);
+    }
+  }
+  for (int32_t c = 0; c < n_cols; ++c) {
+    if (cols[c].n_ids == 0) HBK_HIP_OK(hipMemsetAsync(cols[c].n_unique, 0, sizeof(int32_t), stream));
   }
 
   // More than kMaxCols columns make several launch groups (config 5: 200 columns = 4).  They are
   // independent (own workspace slices), so they rotate over four streams of the library:
   // the tail of one group's reduce kernel -- a few long-lived workgroups on an idle chip -- runs
-  // beside the next group's grouping launches instead of in front of them.
-  int32_t live_cols = 0;
-  for (int32_t c = 0; c < n_cols; ++c) live_cols += cols[c].n_ids > 0;
+  // beside the next group's grouping launches instead of in front of them.  A group holds either
+  // one-launch columns or large ones (a single large column would otherwise put its whole group
+  // on the three grouping launches).
+  const int32_t live_cols = (int32_t)order.size();
   int group_cols = options().bwd_group_cols;   // columns per launch group (tuning; 0: kMaxCols)
   if (group_cols <= 0 || group_cols > kMaxCols) group_cols = kMaxCols;
-  BwdHelpers* helpers = live_cols > group_cols ? bwd_helpers(stream) : nullptr;
+  bool mixed = false;
+  for (int32_t q = 1; q < live_cols; ++q) {
+    mixed = mixed || info[(size_t)order[q]].onepass != info[(size_t)order[0]].onepass;
+  }
+  BwdHelpers* helpers = live_cols > group_cols || mixed ? bwd_helpers(stream) : nullptr;
   std::unique_lock<std::mutex> hold;   // (released on every return path)
   if (helpers != nullptr) {
     hold = std::unique_lock<std::mutex>(helpers->mu);
@@ -1897,23 +2360,43 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       HBK_HIP_OK(hipStreamWaitEvent(helpers->s[i], helpers->fork, 0));
     }
   }
+  // after the fork every path joins the helper streams before it returns: work queued on them
+  // uses the caller's workspace and outputs
+  int status = HBK_OK;
   int group_no = 0;
-  int32_t c0 = 0;
-  while (c0 < n_cols) {
+  int32_t q0 = 0;
+  while (q0 < live_cols && status == HBK_OK) {
     hipStream_t ls = helpers != nullptr ? helpers->s[group_no++ % kHelperStreams] : stream;
     GArgs args, seg_args;
     int4* const desc_group = reinterpret_cast<int4*>(dp);
+    // the group's columns: up to group_cols of one grouping form, sorted by kind (stable)
+    const bool group_onepass = info[(size_t)order[q0]].onepass;
+    int32_t members[kMaxCols];
+    int32_t k_n = 0;
+    while (q0 < live_cols && k_n < group_cols && info[(size_t)order[q0]].onepass == group_onepass) {
+      members[k_n++] = order[q0++];
+    }
+    for (int32_t i = 1; i < k_n; ++i) {   // insertion sort: <= 64 entries
+      const int32_t m = members[i];
+      int32_t j = i;
+      while (j > 0 && info[(size_t)members[j - 1]].kind > info[(size_t)m].kind) {
+        members[j] = members[j - 1];
+        --j;
+      }
+      members[j] = m;
+    }
     int32_t k = 0, ks = 0;
     int64_t tiles = 0, buckets = 0, segtiles = 0, merges = 0, scans = 0, sync_words = 0;
     size_t lds_hist = 0;
-    bool small_scan = true, group_ok = true;
-    while (c0 < n_cols && k < group_cols) {
-      const hbk_lookup_grad_column_t& h = cols[c0++];
-      if (h.n_ids == 0) {
-        HBK_HIP_OK(hipMemsetAsync(h.n_unique, 0, sizeof(int32_t), ls));
-        continue;
-      }
-      const ColPlan p = plan_of(h.n_ids, h.dim);
+    bool small_scan = true;
+    int64_t slot_lo[4] = {0, 0, 0, 0}, slot_hi[4] = {0, 0, 0, 0};     // job slots of every kind
+    int64_t merge_lo[4] = {0, 0, 0, 0}, merge_hi[4] = {0, 0, 0, 0};   // merge blocks of every kind
+    bool have_kind[4] = {false, false, false, false};
+    for (; k < k_n; ++k) {
+      const int32_t col_index = members[k];
+      const hbk_lookup_grad_column_t& h = cols[col_index];
+      const ColInfo& ci = info[(size_t)col_index];
+      const ColPlan& p = ci.p;
       GCol& d = args.col[k];
       memset(&d, 0, sizeof(d));
       d.ids = h.ids;
@@ -1952,7 +2435,6 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       d.part_vals = reinterpret_cast<float*>(((uintptr_t)wp + 15) & ~(uintptr_t)15);
       wp += align8((size_t)h.n_ids * h.dim * 4) + 16;
       d.no_emit = 0;
-      d.sync0 = 0;
       if (h.grad_rows == nullptr) {
         d.no_emit = 1;
         d.unique_rows = reinterpret_cast<int64_t*>(wp);
@@ -1962,45 +2444,46 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       }
       d.split_t = p.split_t;
       d.e_max = p.e_max;
+      d.dense_mul = p.dense_mul;
       d.merge0 = (int32_t)merges;
-      merges += p.e_max < kMergeBlocks ? p.e_max : kMergeBlocks;
+      const int64_t merge_blocks = p.e_max < kMergeBlocks ? p.e_max : kMergeBlocks;
       d.scan0 = (int32_t)scans;
       scans += ((int64_t)p.n_buckets + kBlock - 1) / kBlock;
       small_scan = small_scan && p.n_buckets <= 4 * kBlock && p.tiles <= 64;
-      group_ok = group_ok && p.n_buckets <= kGroupMaxBuckets;
       d.sync0 = (int32_t)sync_words;
       sync_words += (int64_t)p.tiles * p.n_buckets;
       d.run_start = h.run_start;
       d.run_ids = h.run_ids;
       d.run_grads = h.run_grads;
       d.n_runs = h.n_runs;
-      HBK_REQUIRE(h.grad_stride == 0 || (h.grad_stride >= h.dim && h.n_runs == 0),
-                  "group_lookup_bwd: column %d: bad grad_stride %d", c0 - 1, h.grad_stride);
       d.grad_stride = h.grad_stride > 0 ? h.grad_stride : h.dim;
       d.map = make_idmap(h.bucket, h.divisor, h.rows);
       d.n_ids = h.n_ids;
       d.n_seg = h.n_segments;
       d.dim = h.dim;
-      RowShape shape;
-      HBK_REQUIRE(make_rowshape(h.dim,
-                                (uintptr_t)h.grad_out | (uintptr_t)h.grad_rows |
-                                    ((uintptr_t)(uint32_t)h.grad_stride * 4) |
-                                    (apply_lr != 0.0f ? (uintptr_t)h.table | (uintptr_t)h.accum : 0),
-                                &shape),
-                  "group_lookup_bwd: dim %d needs more than 64 lanes per row", h.dim);
-      d.chunks = shape.chunks;
-      d.lpr_log2 = shape.lpr_log2;
-      d.vec4 = shape.vec4;
+      d.chunks = ci.shape.chunks;
+      d.lpr_log2 = ci.shape.lpr_log2;
+      d.vec4 = ci.shape.vec4;
       d.ids64 = h.ids_dtype == HBK_INT64;
       d.combiner = (uint8_t)h.combiner;
       d.n_buckets = p.n_buckets;
       d.tile0 = (int32_t)tiles;
       d.bucket0 = (int32_t)buckets;
       d.segtile0 = 0;
+      if (!have_kind[ci.kind]) {
+        have_kind[ci.kind] = true;
+        slot_lo[ci.kind] = buckets;
+        merge_lo[ci.kind] = merges;
+      }
       tiles += p.tiles;
       buckets += (int64_t)p.n_buckets + p.e_max;
-      HBK_REQUIRE(tiles < (1ll << 31) && buckets < (1ll << 31),
-                  "group_lookup_bwd: grid too large");
+      merges += merge_blocks;
+      slot_hi[ci.kind] = buckets;
+      merge_hi[ci.kind] = merges;
+      if (tiles >= (1ll << 31) || buckets >= (1ll << 31)) {
+        status = fail(HBK_INVALID_ARGUMENT, "group_lookup_bwd: grid too large");
+        break;
+      }
       if ((size_t)4 * p.n_buckets > lds_hist) lds_hist = (size_t)4 * p.n_buckets;
       args.tile0[k] = d.tile0;
       args.bucket0[k] = d.bucket0;
@@ -2015,8 +2498,8 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
         segtiles += (h.n_segments + kBlock - 1) / kBlock;
         ++ks;
       }
-      ++k;
     }
+    if (status != HBK_OK) break;
     if (k == 0) continue;
     args.n_cols = k;
     args.lr = apply_lr;
@@ -2030,7 +2513,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     }
     GSync sync;
     memset(&sync, 0, sizeof(sync));
-    bool onepass = small_scan && group_ok && options().bwd_onepass != 0 && sync_words < (1ll << 30);
+    bool onepass = group_onepass && sync_words < (1ll << 30);
     if (onepass) {
       SyncTake take;
       onepass = sync_take(ls, (size_t)sync_words, &take);
@@ -2042,63 +2525,68 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       }
     }
     if (onepass) {
+      // (hist, scan and scatter are this one launch)
       hipLaunchKernelGGL(bwd_group_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ls, args,
                          sync);
     } else {
       hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist, ls,
                          args);
-    }
-    if (onepass) {
-      // (hist, scan and scatter were that one launch)
-    } else if (small_scan) {
-      hipLaunchKernelGGL(bwd_scan_fused_kernel, dim3((unsigned)k), dim3(kBlock), 0, ls, args);
-    } else {
-      hipLaunchKernelGGL(bwd_scan_tiles_kernel, dim3((unsigned)scans), dim3(kBlock), 0, ls,
-                         args);
-      hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)k), dim3(kBlock), 0, ls, args);
-    }
-    if (!onepass) {
+      if (small_scan) {
+        hipLaunchKernelGGL(bwd_scan_fused_kernel, dim3((unsigned)k), dim3(kBlock), 0, ls, args);
+      } else {
+        hipLaunchKernelGGL(bwd_scan_tiles_kernel, dim3((unsigned)scans), dim3(kBlock), 0, ls,
+                           args);
+        hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)k), dim3(kBlock), 0, ls, args);
+      }
       hipLaunchKernelGGL(bwd_scatter_pairs_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist,
                          ls, args);
     }
-    bool any_vec4 = false, any_scalar = false;
-    for (int32_t q = 0; q < k; ++q) {
-      any_vec4 |= args.col[q].vec4 != 0;
-      any_scalar |= args.col[q].vec4 == 0;
-    }
-    // one instantiation per optimizer (none / SGD / Adagrad)
+    // one instantiation per kind and optimizer (none / SGD / Adagrad), each on its own job slots
     const int step = apply_lr == 0.0f ? 0 : apply == HBK_APPLY_ADAGRAD ? 2 : 1;
-    typedef void (*reduce_fn)(const GArgs, const int4*, int);
-    typedef void (*merge_fn)(const GArgs);
-    static const reduce_fn kReduce4[3] = {&bwd_reduce_kernel<f32x4, 0>, &bwd_reduce_kernel<f32x4, 1>,
-                                          &bwd_reduce_kernel<f32x4, 2>};
-    static const reduce_fn kReduce1[3] = {&bwd_reduce_kernel<float, 0>, &bwd_reduce_kernel<float, 1>,
-                                          &bwd_reduce_kernel<float, 2>};
-    static const merge_fn kMerge4[3] = {&bwd_merge_kernel<f32x4, 0>, &bwd_merge_kernel<f32x4, 1>,
-                                        &bwd_merge_kernel<f32x4, 2>};
-    static const merge_fn kMerge1[3] = {&bwd_merge_kernel<float, 0>, &bwd_merge_kernel<float, 1>,
-                                        &bwd_merge_kernel<float, 2>};
-    const reduce_fn reduce4 = kReduce4[step], reduce1 = kReduce1[step];
-    const merge_fn merge4 = kMerge4[step], merge1 = kMerge1[step];
-    if (any_vec4) {
-      hipLaunchKernelGGL(reduce4, dim3((unsigned)((buckets + kTeams - 1) / kTeams)), dim3(kBlock), 0,
-                         ls, args, desc_group, (int)buckets);
+    typedef void (*reduce_fn)(const GArgs, const int4*, int, int);
+    typedef void (*merge_fn)(const GArgs, int);
+    static const reduce_fn kReduce[4][3] = {
+        {&bwd_dense_kernel<f32x4, 0>, &bwd_dense_kernel<f32x4, 1>, &bwd_dense_kernel<f32x4, 2>},
+        {&bwd_dense_kernel<float, 0>, &bwd_dense_kernel<float, 1>, &bwd_dense_kernel<float, 2>},
+        {&bwd_reduce_kernel<f32x4, 0>, &bwd_reduce_kernel<f32x4, 1>, &bwd_reduce_kernel<f32x4, 2>},
+        {&bwd_reduce_kernel<float, 0>, &bwd_reduce_kernel<float, 1>, &bwd_reduce_kernel<float, 2>}};
+    static const merge_fn kMerge[4][3] = {
+        {&bwd_dense_merge_kernel<f32x4, 0>, &bwd_dense_merge_kernel<f32x4, 1>,
+         &bwd_dense_merge_kernel<f32x4, 2>},
+        {&bwd_dense_merge_kernel<float, 0>, &bwd_dense_merge_kernel<float, 1>,
+         &bwd_dense_merge_kernel<float, 2>},
+        {&bwd_merge_kernel<f32x4, 0>, &bwd_merge_kernel<f32x4, 1>, &bwd_merge_kernel<f32x4, 2>},
+        {&bwd_merge_kernel<float, 0>, &bwd_merge_kernel<float, 1>, &bwd_merge_kernel<float, 2>}};
+    for (int kind = 0; kind < 4; ++kind) {
+      if (!have_kind[kind]) continue;
+      const int64_t n_slots = slot_hi[kind] - slot_lo[kind];
+      const int64_t per = kind >= 2 ? kTeams : 1;   // job slots per workgroup
+      hipLaunchKernelGGL(kReduce[kind][step], dim3((unsigned)((n_slots + per - 1) / per)),
+                         dim3(kBlock), 0, ls, args, desc_group, (int)slot_lo[kind],
+                         (int)slot_hi[kind]);
     }
-    if (any_scalar) {
-      hipLaunchKernelGGL(reduce1, dim3((unsigned)((buckets + kTeams - 1) / kTeams)), dim3(kBlock), 0,
-                         ls, args, desc_group, (int)buckets);
+    for (int kind = 0; kind < 4; ++kind) {
+      if (!have_kind[kind]) continue;
+      hipLaunchKernelGGL(kMerge[kind][step], dim3((unsigned)(merge_hi[kind] - merge_lo[kind])),
+                         dim3(kBlock), 0, ls, args, (int)merge_lo[kind]);
     }
-    if (any_vec4) hipLaunchKernelGGL(merge4, dim3((unsigned)merges), dim3(kBlock), 0, ls, args);
-    if (any_scalar) hipLaunchKernelGGL(merge1, dim3((unsigned)merges), dim3(kBlock), 0, ls, args);
-    HBK_HIP_OK(hipGetLastError());
+    const hipError_t launch_err = hipGetLastError();
+    if (launch_err != hipSuccess) {
+      status = fail(HBK_INTERNAL, "group_lookup_bwd: launch failed: %s",
+                    hipGetErrorString(launch_err));
+    }
   }
   if (helpers != nullptr) {
     for (int i = 0; i < kHelperStreams; ++i) {
-      HBK_HIP_OK(hipEventRecord(helpers->join[i], helpers->s[i]));
-      HBK_HIP_OK(hipStreamWaitEvent(stream, helpers->join[i], 0));
+      const hipError_t e1 = hipEventRecord(helpers->join[i], helpers->s[i]);
+      const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(stream, helpers->join[i], 0) : e1;
+      if (e2 != hipSuccess && status == HBK_OK) {
+        status = fail(HBK_INTERNAL, "group_lookup_bwd: joining the helper streams failed: %s",
+                      hipGetErrorString(e2));
+      }
     }
   }
-  return HBK_OK;
+  return status;
 }
 
 // d(stitch + combiner) of the sharded pipeline (sharding.py:200 in reverse):

@@ -31,6 +31,7 @@ const OptionEntry kOptions[] = {
     {"bwd_split_pairs", "HBK_BWD_SPLIT", &Options::bwd_split_pairs},
     {"bwd_onepass", "HBK_BWD_ONEPASS", &Options::bwd_onepass},
     {"bwd_group_cols", "HBK_BWD_GROUP_COLS", &Options::bwd_group_cols},
+    {"bwd_dense", "HBK_BWD_DENSE", &Options::bwd_dense},
     {"unique_buckets_log2", "HBK_UNIQUE_LOG2P", &Options::unique_buckets_log2},
     {"partition_sub_tiles", "HBK_PART_SUB", &Options::partition_sub_tiles},
     {"partition_fixed_max", "HBK_PART_FIXED", &Options::partition_fixed_max},

@@ -403,12 +403,15 @@ def _check_slices(res, rows, grads, splits, combiner, distinct=True, atol=1e-6):
   np.testing.assert_allclose(got, want64, rtol=RTOL, atol=atol)
 
 
+@pytest.mark.parametrize('dense', [1, 0])
 @pytest.mark.parametrize('onepass', [1, 0])
 @pytest.mark.parametrize('combiner', ['sum', 'mean', 'sqrtn'])
-def test_group_lookup_backward(hbk_option, combiner, onepass):
+def test_group_lookup_backward(hbk_option, combiner, onepass, dense):
   # onepass: pairs grouped by ONE launch (tiles wait for their column) or by the histogram /
-  # scan / scatter launches
+  # scan / scatter launches; dense: row-range buckets + direct-indexed LDS tables where the batch
+  # covers the table densely (every column here but the 100000-row one), or hashed buckets only
   hbk_option('bwd_onepass', onepass)
+  hbk_option('bwd_dense', dense)
   rng = np.random.RandomState(10)
   tables, ids, splits, buckets, grads = [], [], [], [], []
   for k, d in enumerate([4, 16, 16, 32, 128, 6]):
@@ -432,11 +435,15 @@ def test_group_lookup_backward(hbk_option, combiner, onepass):
     _check_slices(res[c], ids[c] % buckets[c], grads[c], splits[c], combiner)
 
 
-def test_group_lookup_backward_multi_chunk_and_multi_pass_path(hbk_option):
+@pytest.mark.parametrize('dense', [1, 0])
+def test_group_lookup_backward_multi_chunk_and_multi_pass_path(hbk_option, dense):
   # one bucket per column: many 512-pair chunks per workgroup, rows spanning chunks are
   # accumulated into their output row, and more distinct rows than the LDS table holds force
-  # further passes over the bucket -- every row is still emitted exactly once
+  # further passes over the bucket -- every row is still emitted exactly once.  dense: the
+  # tables of <= 16384 rows take the row-range path (one bitmap over the whole table, the pairs
+  # read once per stage, the sums of duplicated rows in rounds of 4096 / dim LDS rows)
   hbk_option('bwd_buckets_log2', 0)
+  hbk_option('bwd_dense', dense)
   rng = np.random.RandomState(21)
   for d, rows, n in ((16, 97, 5000), (128, 3000, 9000), (6, 10, 2000), (32, 100000, 4000)):
     table = rng.uniform(-1, 1, size=(rows, d)).astype(np.float32)
@@ -469,13 +476,67 @@ def test_group_lookup_backward_zipf_hot_rows():
   _check_slices(res, ids, grads, None, 'sum', atol=RTOL * 100)   # ~12k terms on the hot row
 
 
+@pytest.mark.parametrize('aim', [0, 3000, 64])
+def test_group_lookup_backward_dense_row_ranges(hbk_option, aim):
+  """Row-range buckets (dense columns): output rows of a bucket are sorted, distinct and complete
+  whatever the bucket holds -- buckets of one chunk (default aim), of several chunks (aim 3000),
+  tiny ones (aim 64), hot rows next to single ones, duplicated rows that need several rounds of
+  LDS sums (dim 128: 32 rows per round), int32 ids, `// W` row numbers, ids outside the table,
+  the optimizer step fused (SGD) and the step-only form."""
+  if aim:
+    hbk_option('bwd_bucket_pairs', aim)
+  rng = np.random.RandomState(123)
+  shapes = ((16, 40000, 30000, 1), (128, 3000, 9000, 1), (4, 2000, 20000, 1), (6, 1500, 4000, 1),
+            (32, 70000, 20000, 3), (128, 100000, 8000, 1), (16, 1 << 14, 5000, 1),
+            (64, 3, 3000, 1), (12, 1, 700, 1))
+  for d, rows, n, div in shapes:
+    table = rng.uniform(-1, 1, size=(rows, d)).astype(np.float32)
+    ids = rng.randint(0, rows * div, size=n).astype(np.int64)
+    if d == 16:
+      ids[::3] = ids[1]                      # a hot row next to ordinary ones
+      ids[5::7] = rows * div + 5             # outside the table: dropped
+      ids[6::11] = -3
+    local = ids // div
+    ok = (ids >= 0) & (local < rows)
+    grads = rng.randn(n, d).astype(np.float32)
+    want = np.zeros((rows, d), np.float64)
+    np.add.at(want, local[ok], grads[ok].astype(np.float64))
+    for ids_dtype in (np.int64, np.int32):
+      for mode in ('emit', 'sgd', 'step_only'):
+        t_dev = dev(table.copy())
+        lookup = hb.embedding.GroupLookup([t_dev], None, 'sum', divisor=div)
+        lr = 0.0 if mode == 'emit' else 0.25
+        res = hb.embedding.GroupLookupGrad(lookup)([dev(ids.astype(ids_dtype))], [dev(grads)],
+                                                   apply_lr=lr, emit=mode != 'step_only')[0]
+        k = int(res[2].item())
+        assert k == np.unique(local[ok]).size
+        if mode != 'step_only':
+          urows = host(res[0])[:k]
+          assert np.array_equal(np.sort(urows), np.unique(local[ok]))
+          got = np.zeros_like(want)
+          got[urows] = host(res[1])[:k].astype(np.float64)
+          np.testing.assert_allclose(got, want, rtol=RTOL, atol=RTOL * 40)
+        if mode != 'emit':
+          np.testing.assert_allclose(host(t_dev), table.astype(np.float64) - 0.25 * want,
+                                     rtol=RTOL, atol=1e-4)
+          untouched = np.ones(rows, bool)
+          untouched[local[ok]] = False
+          np.testing.assert_equal(host(t_dev)[untouched], table[untouched])
+        if mode == 'sgd':
+          ref = table.copy()
+          oracle.sparse_sgd_apply(ref, host(res[0])[:k], host(res[1])[:k], 0.25)
+          np.testing.assert_equal(host(t_dev), ref)
+
+
+@pytest.mark.parametrize('dense', [1, 0])
 @pytest.mark.parametrize('onepass', [1, 0])
 @pytest.mark.parametrize('split,log2p', [(None, None), ('96', '2'), ('700', '0')])
-def test_group_lookup_backward_split_buckets(hbk_option, split, log2p, onepass):
+def test_group_lookup_backward_split_buckets(hbk_option, split, log2p, onepass, dense):
   """Hot rows: a bucket far above the average is reduced by several workgroups (partial sums
   per range, then a merge), rows stay unique and the fused SGD apply stays exact.  The env hooks
   force tiny ranges so that ordinary buckets split too (many partial entries per bucket)."""
   hbk_option('bwd_onepass', onepass)
+  hbk_option('bwd_dense', dense)
   if split is not None:
     hbk_option('bwd_split_pairs', int(split))
     hbk_option('bwd_buckets_log2', int(log2p))
@@ -572,12 +633,14 @@ def test_group_lookup_backward_segmented_inputs():
       st += ln
 
 
+@pytest.mark.parametrize('dense', [1, 0])
 @pytest.mark.parametrize('hook', [None, 'one_bucket'])
-def test_group_lookup_backward_fused_adagrad_apply(hbk_option, hook):
+def test_group_lookup_backward_fused_adagrad_apply(hbk_option, hook, dense):
   """tf.train.AdagradOptimizer's sparse apply fused into the backward: accum += g^2,
   var -= lr * g / sqrt(accum) on the deduplicated gradient of every touched row -- bit-equal to
   the oracle applied to the emitted IndexedSlices (also when rows span chunks: the step is
   deferred to one apply per row), untouched rows stay untouched."""
+  hbk_option('bwd_dense', dense)
   if hook:
     hbk_option('bwd_buckets_log2', 0)     # one bucket: many chunks per workgroup
   rng = np.random.RandomState(91)
@@ -627,15 +690,17 @@ def test_group_lookup_backward_fused_sgd_apply():
   np.testing.assert_allclose(host(t_dev), ref, rtol=RTOL, atol=1e-6)
 
 
+@pytest.mark.parametrize('dense', [1, 0])
 @pytest.mark.parametrize('optimizer', ['sgd', 'adagrad'])
 @pytest.mark.parametrize('hook', [None, 'one_bucket', 'split'])
-def test_group_lookup_backward_step_only(hbk_option, optimizer, hook):
+def test_group_lookup_backward_step_only(hbk_option, optimizer, hook, dense):
   """Step only (unique_rows = grad_rows = NULL with a learning rate): no IndexedSlices are
   written, the shards (and accumulators) end as the emitting call leaves them on the same inputs
   (which the tests above pin to the oracle) and as float64 from the raw ids says, and n_unique
   still counts the distinct rows.
   Jobs that cannot step from registers (rows spanning chunks, split buckets) fall back to
   scratch rows in the workspace."""
+  hbk_option('bwd_dense', dense)
   if hook == 'one_bucket':
     hbk_option('bwd_buckets_log2', 0)
   if hook == 'split':

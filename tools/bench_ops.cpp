@@ -455,6 +455,12 @@ int main(int argc, char** argv) {
     bench_backward(26, 65536, 64, 20000, 0.f);
     return 0;
   }
+  if (argc > 1 && argv[1][0] == 'w') {  // "wide": dim-128 backward (config 4's 1M-row tables, uniform ids)
+    bench_backward(26, 65536, 128, 1000000, 0.f);
+    bench_backward(26, 65536, 128, 1000000, 0.01f);
+    bench_backward(26, 65536, 128, 1000000, 0.01f, true);
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'u') {  // "unique": the owner-side unique only
     bench_unique(26, 65536, 1000000);
     return 0;

@@ -1,0 +1,63 @@
+#!/bin/bash
+# Round-3 GPU-box visits: stages picked on the command line, everything lands under gpurun_out/.
+#   tools/gpu_r3.sh "bwdtest bwdops"        (see the case labels)
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+STAGES=${1:-"test"}
+prof() {  # prof <name> <pmc counters or ""> -- cmd...   (counters in their own pass, kernel-trace only)
+  local name=$1; shift
+  local ctrs=$1; shift
+  shift
+  rm -rf $O/$name
+  if [ -n "$ctrs" ]; then
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log)
+    python tools/prof_summary.py pmc $O/$name > $O/$name.json 2>> $O/$name.log
+  else
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log)
+    python tools/prof_summary.py stats $O/$name > $O/$name.txt 2>> $O/$name.log
+  fi
+  find $O/$name -name "*.csv" -size +2M -delete
+}
+for st in $STAGES; do
+  case $st in
+    test)
+      timeout 2400 python -m pytest tests -x -q -m gpu --durations=15 > $O/test.log 2>&1; echo "pytest rc=$?" >> $O/test.log; tail -25 $O/test.log;;
+    bwdtest)
+      timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -m gpu -k "backward or bwd or fuzz" --durations=10 > $O/bwdtest.log 2>&1; echo "pytest rc=$?" >> $O/bwdtest.log; tail -40 $O/bwdtest.log;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -3 $O/smoke.log;;
+    bench)
+      timeout 600 python bench.py --steps 50 --warmup 10 > $O/bench.log 2>&1; echo "bench rc=$?" >> $O/bench.log; tail -3 $O/bench.log;;
+    ops)
+      timeout 300 tools/bin/bench_ops > $O/bench_ops.log 2>&1; echo "ops rc=$?" >> $O/bench_ops.log; cat $O/bench_ops.log;;
+    bwdops)   # the backward through the C ABI: dense (row-range) buckets vs hashed ones
+      for dense in 1 0; do
+        for w in b s d r w; do
+          HBK_BWD_DENSE=$dense timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk " | sed "s/^/dense=$dense  /"
+        done
+      done > $O/bwdops.log 2>&1; cat $O/bwdops.log;;
+    bwdstamps)
+      for w in b s; do LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops $w; done > $O/bwdstamps.log 2>&1; cat $O/bwdstamps.log;;
+    profbwd)
+      prof prof_bwd "" -- $R/tools/bin/bench_ops b
+      prof prof_bwd_step "" -- $R/tools/bin/bench_ops s
+      cat $O/prof_bwd.txt $O/prof_bwd_step.txt;;
+    pmcbwd)
+      prof pmc_bwd_sq1 "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES" -- $R/tools/bin/bench_ops b
+      prof pmc_bwd_sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" -- $R/tools/bin/bench_ops b
+      prof pmc_bwd_tcc "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/bench_ops b
+      for f in pmc_bwd_sq1 pmc_bwd_sq2 pmc_bwd_tcc; do echo "== $f"; tail -2 $O/$f.log; python - $O/$f.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k,v in sorted(d.items()):
+  print(k[:70].ljust(70), {c:round(x['mean']) for c,x in v.items()})
+PY
+      done;;
+    sweep)
+      timeout 1200 python tools/sweep.py --big --cases ${SWEEP_CASES:-a,b,c,d,e,f,g,h,i} > $O/sweep.log 2>&1; echo "sweep rc=$?" >> $O/sweep.log; cut -c1-400 $O/sweep.log;;
+    *) echo "unknown stage $st";;
+  esac
+done

@@ -125,6 +125,8 @@ struct Options {
   int bwd_onepass = 1;         // HBK_BWD_ONEPASS: 0 = histogram, scan and scatter as three launches
   int bwd_group_cols = 0;      // HBK_BWD_GROUP_COLS: columns per launch group of the backward (0: 64)
   int bwd_dense = 1;           // HBK_BWD_DENSE: 0 = hashed buckets for every column (no row-range buckets)
+  int fwd_hot_rows = 0;        // HBK_FWD_HOT: forward of wide one-id-per-sample columns: 1 = 256-segment tiles with
+                               // repeated rows staged in LDS, 2 = the large tiles alone (probe), 0 = per-wave gather
   int unique_buckets_log2 = -1;  // HBK_UNIQUE_LOG2P
   int partition_sub_tiles = 1;   // HBK_PART_SUB
   int partition_fixed_max = 8;   // HBK_PART_FIXED
@@ -134,6 +136,9 @@ struct Options {
   int sharded_id64 = 0;          // HBK_SHARDED_ID64: keep int64 ids on the wire
   int sharded_copy_self = 0;     // HBK_SHARDED_COPY_SELF: own slice through a device copy
   int sharded_trace = 0;         // HBK_SHARDED_TRACE: host-side phase times on stderr
+  int sync_wait_ms = 2000;       // HBK_SYNC_WAIT_MS: bound of a wait between the tiles of a one-launch kernel
+  int sync_onepass_off = 0;      // HBK_SYNC_ONEPASS_OFF: 1 = multi-launch forms only (set by a wait that ran out)
+  int sync_test_withhold = -1;   // HBK_SYNC_TEST_WITHHOLD: test hook, the tile that never publishes its counts
 };
 Options& options();
 
@@ -146,11 +151,39 @@ struct SyncTake {
   int32_t* zero;
   int64_t zero_words;
   int32_t* status;    // host-visible, raised by a wait that ran out
+  int32_t* poison;    // device word of THIS call (zero at its start, cleared with the call's words):
+                      // set by a wait that ran out; the later kernels of the call read it first and
+                      // leave without touching anything (their inputs were never written)
+  unsigned long long wait_ticks;   // bound of a wait, 100 MHz ticks (option sync_wait_ms)
+  int32_t withhold;   // test hook (option sync_test_withhold): the tile that never publishes, -1
 };
-bool sync_take(hipStream_t stream, size_t words, SyncTake* out);
+// what the waiting kernels need of a SyncTake, by value in their arguments
+struct SyncWait {
+  int32_t* status;
+  int32_t* poison;
+  unsigned long long ticks;
+  int32_t withhold;
+  int32_t pad_;
+};
+inline SyncWait sync_wait_of(const SyncTake& t) {
+  SyncWait w;
+  w.status = t.status;
+  w.poison = t.poison;
+  w.ticks = t.wait_ticks;
+  w.withhold = t.withhold;
+  w.pad_ = 0;
+  return w;
+}
+// `words` zeroed int32 (+ the call's poison word) of the stream's buffer.  `kernel` / `block` /
+// `max_column_wgs`: the waiting kernel, its workgroup size and the most workgroups of ONE column
+// that wait for each other: false when the device cannot hold them all at once (CU masks,
+// partitioned modes), as when the stream is being captured or a wait has run out before.
+bool sync_take(hipStream_t stream, size_t words, SyncTake* out, const void* kernel = nullptr,
+               int block = 0, int max_column_wgs = 0);
 int32_t* sync_status();
-bool sync_raised();
-constexpr unsigned long long kSyncWaitTicks = 20000000ull;   // 200 ms of the 100 MHz clock
+// HBK_OK, or -- ONCE per timed-out wait -- HBK_INTERNAL with the story in hbk_last_error(); the
+// one-launch forms are then off for the rest of the process (option sync_onepass_off)
+int sync_check(const char* who);
 
 constexpr int kWave = 64;  // gfx950 wavefront
 

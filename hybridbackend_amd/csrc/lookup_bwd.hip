@@ -1474,10 +1474,19 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
 // Every row is complete when it is emitted whatever the number of chunks: no rows spanning chunks,
 // no deferred step, no second pass.  Jobs of several chunks (a bucket above kCP pairs, the ranges
 // of a split bucket, the merge of their partial entries) read their pairs once per stage.
+// workgroups per CU the dense kernels are compiled for: 5 (96 VGPRs) without the optimizer step,
+// 4 (128 VGPRs) with it -- the step's table / accumulator rows spill at 96
+#ifndef HBK_BWD_DENSE_WAVES
+#define HBK_BWD_DENSE_WAVES(STEP) ((STEP) ? 4 : 5)
+#endif
+#ifndef HBK_BWD_DENSE_WALK
+#define HBK_BWD_DENSE_WALK(STEP) ((STEP) == 2 ? 2 : (STEP) ? 3 : 4)
+#endif
 constexpr int kDenseSpan = 16384;                 // rows of a bucket's range (bits per bitmap)
 constexpr int kDenseWords = kDenseSpan / 32;
 constexpr int kDenseWPT = kDenseWords / kBlock;   // bitmap words per thread in the scan
-constexpr int kRedFloats = 4096;                  // LDS floats that take the sums of dup rows
+constexpr int kRedFloats = 2048;                  // LDS floats that take the sums of dup rows
+constexpr int kSortMin = 48;                      // dup pairs of a chunk above which they are sorted by row (D)
 constexpr int32_t kDupBit = 1 << 30;
 static_assert(kDenseWords % kBlock == 0, "whole words per thread");
 
@@ -1489,9 +1498,14 @@ struct DenseLds {
   int32_t code[kCP];             // rank of the pair's row among the bucket's rows, or kDupBit | its
                                  // rank among the dup rows
   uint16_t off[kCP];             // row - first row of the range
-  uint16_t dlist[kCP];           // pairs of the chunk whose dup row is summed in this round
+  uint16_t dlist[kCP];           // pairs of the chunk whose dup row is summed in this round; sorted
+                                 // by row when there are many (D)
   uint16_t doff[kCP];            // row - first row of the range, of every dup row of the round
-  float red[kRedFloats];
+  int32_t dcnt[kCP];             // pairs of dup row m of the round in this chunk (tickets)
+  uint32_t drun[kCP];            // its run in the sorted list: first (low 16 bits) | end (high 16)
+  float red[kRedFloats];         // sums of dup rows across chunks / of the few-pairs case
+  float heads[kBlock * 4];       // sorted walk: what a lane group holds of the run at its first position
+  float carry[2][kWave * 4];     // sorted walk: the run that goes on into the next round
   int32_t wave_tot[kWavesPerBlock];
   int32_t n_rows, n_dup, base_u;
   int32_t n_dlist[2];
@@ -1548,6 +1562,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
     L.present[w] = 0u;
     L.dup[w] = 0u;
   }
+  for (int i = tid; i < kCP; i += kBlock) L.dcnt[i] = 0;
   if (tid == 0) {
     L.n_dlist[0] = 0;
     L.n_dlist[1] = 0;
@@ -1635,6 +1650,8 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
     const int d0 = round * cap;
     const int d1 = n_dup < d0 + cap ? n_dup : d0 + cap;
     for (int i = tid; i < (d1 - d0) * c.dim; i += kBlock) L.red[i] = 0.0f;
+    bool used_red = false;                                      // LDS sums to flush after the round
+    const bool last_use = one_chunk && round + 1 == n_rounds;   // nobody takes tickets after this
     for (int32_t cb = 0; cb < n_pairs; cb += kCP, par ^= 1) {
       const int32_t n_chunk = n_pairs - cb < kCP ? n_pairs - cb : kCP;
       if (!one_chunk) {
@@ -1642,10 +1659,13 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
         __syncthreads();   // the walks of the chunk before are over: seg / code / dlist are free
       }
       // per pair: output rank of its row; dup pairs of this round go on the chunk's list
+      int m_[PT], tk_[PT];   // listed pairs: dup row inside the round, ticket inside the row
 #pragma unroll
       for (int k = 0; k < PT; ++k) {
         const int e = k * kBlock + tid;
         bool listed = false;
+        m_[k] = -1;
+        tk_[k] = 0;
         if (r_in[k] >= 0) {
           const uint32_t off = (uint32_t)r_in[k] - base;
           const int w = (int)(off >> 5);
@@ -1657,6 +1677,8 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
             code = kDupBit | dr;
             if (dr >= d0 && dr < d1) {
               listed = true;
+              m_[k] = dr - d0;
+              tk_[k] = atomicAdd(&L.dcnt[dr - d0], 1);
               L.doff[dr - d0] = (uint16_t)off;   // (every pair of the row writes the same value)
             }
           }
@@ -1677,6 +1699,50 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
                                               // barrier above, or there is no chunk before)
       __syncthreads();
       HBK_STAMP(5);
+
+      // this round's dup pairs of the chunk.  Many: they are counting-sorted by row here (the
+      // tickets taken above) and walked in D; the tickets leave the registers before C needs them
+      const int n_dl = L.n_dlist[par];
+      const int nd = d1 - d0;
+      const bool sorted = n_dl > kSortMin;   // uniform
+      if (sorted) {
+        {
+          int32_t cn[PT], sum = 0;
+#pragma unroll
+          for (int k = 0; k < PT; ++k) {
+            const int i = tid * PT + k;
+            cn[k] = i < nd ? L.dcnt[i] : 0;
+            sum += cn[k];
+          }
+          int32_t incl = sum;
+#pragma unroll
+          for (int o = 1; o < kWave; o <<= 1) {
+            const int32_t y = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += y;
+          }
+          if (lane == kWave - 1) L.wave_tot[wave] = incl;
+          __syncthreads();
+          int32_t run = incl - sum;
+          for (int w = 0; w < wave; ++w) run += L.wave_tot[w];
+#pragma unroll
+          for (int k = 0; k < PT; ++k) {
+            const int i = tid * PT + k;
+            if (i < nd) L.drun[i] = (uint32_t)run | ((uint32_t)(run + cn[k]) << 16);
+            run += cn[k];
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+          if (m_[k] >= 0) L.dlist[(L.drun[m_[k]] & 0xffffu) + tk_[k]] = (uint16_t)(k * kBlock + tid);
+        }
+        __syncthreads();
+        if (!last_use) {
+          for (int i = tid; i < nd; i += kBlock) L.dcnt[i] = 0;   // (next read: behind a barrier)
+        }
+      } else if (!last_use) {
+        for (int i = tid; i < nd; i += kBlock) L.dcnt[i] = 0;   // (next read: behind a barrier)
+      }
 
       // C: the pairs that are alone on their row (first round only)
       if (round == 0) {
@@ -1724,42 +1790,172 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
         }
       }
 
-      // D: this round's dup pairs -> LDS sums.  What a lane group holds for one row in
-      // consecutive registers is added up first: a hot row's pairs cost one LDS add per group
-      // and round instead of one each.
-      const int n_dl = L.n_dlist[par];
-      for (int i0 = 0; i0 < n_dl; i0 += kDepth * groups) {
-        V g[kDepth];
-        int dr[kDepth];
+      // D: this round's dup pairs.
+      if (sorted) {
+        // Many: LDS float atomics are slow (~3 clocks per lane and add on a CU, measured: with 3
+        // pairs per row the whole backward took twice as long as with hashed buckets), so the
+        // pairs are counting-sorted by row (the tickets taken above) and the sorted list is walked
+        // FLAT, sums in registers: per round a lane group takes kDepth consecutive positions, all
+        // gradient rows in flight at once; the group where a run starts owns it and adds what its
+        // successors hold of it (heads, LDS); a run that goes on past the round's end is carried.
+        constexpr int kW = HBK_BWD_DENSE_WALK(STEP);   // (register budget: 96 VGPRs = 5 workgroups per CU)
+        const int per_round = groups * kW;
+        int cpar = 0;
+        for (int r0 = 0; r0 < n_dl; r0 += per_round, cpar ^= 1) {
+          const int q0 = r0 + my_group * kW;   // my first position
+          V g[kW];
+          int sl[kW];                           // dup row of every position, -1 beyond the end
 #pragma unroll
-        for (int k = 0; k < kDepth; ++k) {
-          const int i = i0 + k * groups + my_group;
-          dr[k] = -1;
-          g[k] = zero_v<V>();
-          if (i < n_dl && live) {
-            const int e = (int)L.dlist[i];
-            dr[k] = (L.code[e] & (kDupBit - 1)) - d0;
-            g[k] = load_grad<V>(c, job, L.seg[e], sub);
+          for (int w = 0; w < kW; ++w) {
+            const int q = q0 + w;
+            sl[w] = -1;
+            g[w] = zero_v<V>();
+            if (q < n_dl) {
+              const int e = (int)L.dlist[q];
+              sl[w] = (L.code[e] & (kDupBit - 1)) - d0;
+              if (live) g[w] = load_grad<V>(c, job, L.seg[e], sub);
+            }
           }
-        }
+          {
+            V head = zero_v<V>();
+            bool in_head = sl[0] >= 0;
 #pragma unroll
-        for (int k = 1; k < kDepth; ++k) {
-          if (dr[k] >= 0 && dr[k] == dr[k - 1]) {
-            g[k] = g[k] + g[k - 1];
-            dr[k - 1] = -1;
+            for (int w = 0; w < kW; ++w) {
+              in_head = in_head && sl[w] == sl[0];
+              if (in_head) head = head + g[w];
+            }
+            *reinterpret_cast<V*>(&L.heads[(size_t)tid * VE]) = head;
           }
+          __syncthreads();
+          const int round_end = r0 + per_round;
+          V acc = zero_v<V>();
+          int cur = -1;
+          bool owned = false;
+          uint32_t fin = 0;   // bit w: a run I own ends at my position w, complete: its sum is in g[w]
+#pragma unroll
+          for (int w = 0; w <= kW; ++w) {
+            const int sw = w < kW ? sl[w] : -1;
+            if (sw != cur) {
+              if (w > 0 && cur >= 0 && owned) {
+                const uint32_t rn = L.drun[cur];
+                const int s_beg = (int)(rn & 0xffffu), s_end = (int)(rn >> 16);
+                V total = acc;
+                if (w == kW) {
+                  // it reached the end of my range: the heads of the groups it goes on in
+                  const int lim = s_end < round_end ? s_end : round_end;
+                  for (int q = q0 + kW; q < lim; q += kW) {
+                    const int gp = (q - r0) / kW;
+                    total = total + *reinterpret_cast<const V*>(
+                                        &L.heads[(((size_t)gp << lpr_log2) + sub) * VE]);
+                  }
+                }
+                if (s_beg < r0) {   // it began in an earlier round (only the round's first run can)
+                  total = total + *reinterpret_cast<const V*>(&L.carry[cpar ^ 1][(size_t)sub * VE]);
+                }
+                if (s_end > round_end) {
+                  *reinterpret_cast<V*>(&L.carry[cpar][(size_t)sub * VE]) = total;   // goes on
+                } else {
+                  g[w > 0 ? w - 1 : 0] = total;
+                  fin |= 1u << (w > 0 ? w - 1 : 0);
+                }
+              }
+              cur = sw;
+              acc = zero_v<V>();
+              // a run that starts inside my range is mine; the one at my first position is mine
+              // when the row starts there or when I am the round's first group (it is carried in)
+              owned = w > 0 || my_group == 0 || (sw >= 0 && (int)(L.drun[sw] & 0xffffu) >= q0);
+            }
+            if (w < kW && sw >= 0) acc = acc + g[w];
+          }
+          if (!one_chunk) {
+            // a job of several chunks: the row's pairs in the other chunks are still to come (or
+            // already there): the chunk's sum joins the row's LDS sum; one owner per row and chunk
+#pragma unroll
+            for (int w = 0; w < kW; ++w) {
+              if ((fin >> w & 1u) && live) {
+                V* r = reinterpret_cast<V*>(&L.red[(size_t)sl[w] * c.dim + (size_t)sub * VE]);
+                *r = *r + g[w];
+              }
+            }
+          } else {
+            // the row is complete: it leaves from the registers its sum sits in, with the
+            // optimizer step (table / accumulator rows requested for all finished rows first)
+            int32_t u_[kW];
+            uint32_t off_[kW];
+            V tv[STEP ? kW : 1], av[STEP == 2 ? kW : 1];
+#pragma unroll
+            for (int w = 0; w < kW; ++w) {
+              u_[w] = 0;
+              off_[w] = 0;
+              if ((fin >> w & 1u) && live) {
+                const uint32_t off = L.doff[sl[w]];
+                const int ww = (int)(off >> 5);
+                off_[w] = off;
+                u_[w] = base_u + (int32_t)(L.pre[ww] & 0xffffu) +
+                        __builtin_popcount(L.present[ww] & ((1u << (off & 31u)) - 1u));
+                if (STEP && lr != 0.0f) {
+                  const int64_t toff = (int64_t)(base + off) * c.dim + (int64_t)sub * VE;
+                  tv[STEP ? w : 0] =
+                      __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+                  if (STEP == 2) {
+                    av[STEP == 2 ? w : 0] =
+                        __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
+                  }
+                }
+              }
+            }
+#pragma unroll
+            for (int w = 0; w < kW; ++w) {
+              if ((fin >> w & 1u) && live) {
+                if (emit) emit_row<V>(c, job, u_[w], true, sub, g[w]);
+                if (STEP && lr != 0.0f) {
+                  const int64_t toff = (int64_t)(base + off_[w]) * c.dim + (int64_t)sub * VE;
+                  step_row<V>(c, adagrad, lr, toff, g[w], tv[STEP ? w : 0],
+                              STEP == 2 ? av[STEP == 2 ? w : 0] : zero_v<V>());
+                }
+              }
+            }
+          }
+          __syncthreads();
         }
+      } else {
+        // Few (uniform ids: ~14 of a chunk's 450 pairs): summed into the rows' LDS sums by
+        // ds_add_f32; what a lane group holds for one row in consecutive registers is added up
+        // first.
+        used_red = used_red || n_dl > 0;
+        for (int i0 = 0; i0 < n_dl; i0 += kDepth * groups) {
+          V g[kDepth];
+          int dr[kDepth];
 #pragma unroll
-        for (int k = 0; k < kDepth; ++k) {
-          if (dr[k] >= 0) {
-            float* r = &L.red[(size_t)dr[k] * c.dim + (size_t)sub * VE];
+          for (int k = 0; k < kDepth; ++k) {
+            const int i = i0 + k * groups + my_group;
+            dr[k] = -1;
+            g[k] = zero_v<V>();
+            if (i < n_dl && live) {
+              const int e = (int)L.dlist[i];
+              dr[k] = (L.code[e] & (kDupBit - 1)) - d0;
+              g[k] = load_grad<V>(c, job, L.seg[e], sub);
+            }
+          }
 #pragma unroll
-            for (int q = 0; q < VE; ++q) atomicAdd(r + q, reinterpret_cast<const float*>(&g[k])[q]);
+          for (int k = 1; k < kDepth; ++k) {
+            if (dr[k] >= 0 && dr[k] == dr[k - 1]) {
+              g[k] = g[k] + g[k - 1];
+              dr[k - 1] = -1;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < kDepth; ++k) {
+            if (dr[k] >= 0) {
+              float* r = &L.red[(size_t)dr[k] * c.dim + (size_t)sub * VE];
+#pragma unroll
+              for (int q = 0; q < VE; ++q) atomicAdd(r + q, reinterpret_cast<const float*>(&g[k])[q]);
+            }
           }
         }
       }
     }
-    if (n_dup > 0) {
+    if (!one_chunk || used_red) {   // uniform
       __syncthreads();   // the round's sums are complete
       for (int m = d0 + my_group; m < d1; m += groups) {
         if (!live) continue;
@@ -1771,8 +1967,8 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
                                *reinterpret_cast<const V*>(&L.red[(size_t)(m - d0) * c.dim +
                                                                   (size_t)sub * VE]));
       }
-      if (round + 1 < n_rounds) __syncthreads();   // the next round clears the sums
     }
+    if (round + 1 < n_rounds) __syncthreads();   // the next round clears the sums, takes tickets
   }
   HBK_STAMP(6);
   // the row numbers, sorted, straight from the bitmap
@@ -1864,11 +2060,9 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
   HBK_STAMP(7);
 }
 
-#ifndef HBK_BWD_DENSE_WAVES
-#define HBK_BWD_DENSE_WAVES 5
-#endif
+
 template <typename V, int STEP>
-__global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES) void bwd_dense_kernel(const GArgs a,
+__global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(STEP)) void bwd_dense_kernel(const GArgs a,
                                                                                const int4* desc,
                                                                                int slot0, int total) {
   __shared__ DenseLds lds;
@@ -1951,7 +2145,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const 
 }
 
 template <typename V, int STEP>
-__global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES) void bwd_dense_merge_kernel(const GArgs a,
+__global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(STEP)) void bwd_dense_merge_kernel(const GArgs a,
                                                                                      int block0) {
   __shared__ DenseLds lds;
   const int block = block0 + (int)blockIdx.x;

@@ -60,6 +60,7 @@ __device__ inline uint64_t row_offset(const ColArg& c, uint64_t r) {
 
 struct LookupArgs {
   int32_t n_cols;
+  int32_t hot_mode;   // hot-row kernel only: 1 = stage repeated rows in LDS, 2 = large tiles only
   int32_t tile_start[kMaxColsPerLaunch + 1];
   ColArg col[kMaxColsPerLaunch];
 };
@@ -215,6 +216,154 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupAr
   }
 }
 
+// ---------------------------------------------------------------------------------
+// LDS-staged hot rows (config 4: dim 128, Zipf ids; north_star's "LDS-staged hot rows", the
+// reference's analogue is the slab cache in front of the table, hbtf/embedding/
+// lookup_functors.cu.cc:54-149).  One id per segment, wide rows (dim >= 64, 16-byte chunks).  A
+// workgroup owns a tile of 256 segments: (1) the tile's rows enter an LDS hash table (64-bit CAS)
+// with a count per row; (2) rows that occur more than once get one of S = min(64, 4096 / dim)
+// staging slots; (3) every staged row is fetched ONCE into LDS; (4) a segment whose row is staged
+// is served from LDS, the others gather from the table as before.  With Zipf(1.2) ids about half
+// of a tile's segments name one of its ~13 repeated rows: half of the L2 -> L1 row reads go away;
+// what stays are the stores.
+constexpr int kHotTile = 256;          // segments per workgroup
+constexpr int kHotSlots = 512;         // LDS hash slots (a tile holds <= 256 distinct rows)
+constexpr int kHotStageFloats = 4096;  // 16 KB of staged rows
+constexpr int kHotMaxStage = 64;
+constexpr int kHotU = 4;               // row loads in flight per lane
+constexpr unsigned long long kHotEmpty = ~0ull;   // (= kNoRow: never inserted)
+
+__device__ inline uint32_t hot_mix(uint64_t row) {
+  uint32_t k = (uint32_t)row ^ ((uint32_t)(row >> 32) * 0x9e3779b1u);
+  k ^= k >> 16;
+  k *= 0x85ebca6bu;
+  k ^= k >> 13;
+  return k;
+}
+
+__global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const LookupArgs a) {
+  typedef f32x4 V;
+  __shared__ unsigned long long keys[kHotSlots];
+  __shared__ int32_t cnt[kHotSlots];
+  __shared__ int16_t stage_of[kHotSlots];
+  __shared__ uint16_t slot_of[kHotTile];
+  __shared__ uint16_t stage_slot[kHotMaxStage];
+  __shared__ float stage[kHotStageFloats];
+  __shared__ int32_t n_staged;
+  const int b = (int)blockIdx.x;
+  const int tid = (int)threadIdx.x;
+  int ci;
+  {
+    const int lane = tid & (kWave - 1);
+    const int n = a.n_cols;
+    const int t0 = lane < n ? a.tile_start[lane] : 0x7fffffff;
+    const int t1 = lane + kWave < n ? a.tile_start[lane + kWave] : 0x7fffffff;
+    ci = (int)__builtin_popcountll(__ballot(t0 <= b)) +
+         (int)__builtin_popcountll(__ballot(t1 <= b)) - 1;
+    ci = __builtin_amdgcn_readfirstlane(ci);
+  }
+  const ColArg& c = a.col[ci];
+  const int64_t seg0 = (int64_t)(b - a.tile_start[ci]) * kHotTile;
+  const int64_t n_seg = c.n_seg;
+  const bool staging = a.hot_mode == 1;
+
+  // (0) one id per thread
+  uint64_t row = kNoRow;
+  if (seg0 + tid < n_seg) row = id_to_row(c.map, load_id(c.ids, c.ids64, seg0 + tid));
+  for (int i = tid; i < kHotSlots; i += kBlock) {
+    keys[i] = kHotEmpty;
+    cnt[i] = 0;
+  }
+  if (tid == 0) n_staged = 0;
+  __syncthreads();
+  // (1) rows -> slots, one count per row
+  int slot = 0xffff;
+  if (row != kNoRow) {
+    int h = (int)(hot_mix(row) & (kHotSlots - 1));
+    for (;;) {
+      const unsigned long long k = keys[h];
+      if (k == row) break;
+      if (k == kHotEmpty) {
+        const unsigned long long prev = atomicCAS(&keys[h], kHotEmpty, (unsigned long long)row);
+        if (prev == kHotEmpty || prev == row) break;
+      }
+      h = (h + 1) & (kHotSlots - 1);
+    }
+    slot = h;
+    if (staging) atomicAdd(&cnt[h], 1);
+  }
+  slot_of[tid] = (uint16_t)slot;
+  __syncthreads();
+  // (2) repeated rows take the staging slots, first come first served
+  const int S = kHotStageFloats / c.dim < kHotMaxStage ? kHotStageFloats / c.dim : kHotMaxStage;
+  for (int i = tid; i < kHotSlots; i += kBlock) {
+    int st = -1;
+    if (cnt[i] >= 2) {
+      const int idx = atomicAdd(&n_staged, 1);
+      if (idx < S) {
+        st = idx;
+        stage_slot[idx] = (uint16_t)i;
+      }
+    }
+    stage_of[i] = (int16_t)st;
+  }
+  __syncthreads();
+  const int ns = n_staged < S ? n_staged : S;
+  const int lpr_log2 = c.lpr_log2;
+  const int sub = tid & ((1 << lpr_log2) - 1);
+  const int grp = tid >> lpr_log2;
+  const int groups = kBlock >> lpr_log2;
+  const bool live = sub < c.chunks;
+  // (3) every staged row is fetched once
+  for (int i0 = 0; i0 < ns; i0 += kHotU * groups) {
+    V v[kHotU];
+#pragma unroll
+    for (int u = 0; u < kHotU; ++u) {
+      const int i = i0 + u * groups + grp;
+      v[u] = zero_v<V>();
+      if (i < ns && live) {
+        const uint64_t r = keys[stage_slot[i]];
+        v[u] = *reinterpret_cast<const V*>(c.table + r * (uint64_t)c.dim + (uint64_t)sub * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kHotU; ++u) {
+      const int i = i0 + u * groups + grp;
+      if (i < ns && live) *reinterpret_cast<V*>(&stage[(size_t)i * c.dim + (size_t)sub * 4]) = v[u];
+    }
+  }
+  if (ns > 0) __syncthreads();   // uniform
+  // (4) the tile's segments: staged rows from LDS, the others from the table
+  for (int s0 = 0; s0 < kHotTile; s0 += kHotU * groups) {
+    if (seg0 + s0 >= n_seg) break;   // uniform
+    V v[kHotU];
+#pragma unroll
+    for (int u = 0; u < kHotU; ++u) {
+      const int sl = s0 + u * groups + grp;
+      v[u] = zero_v<V>();
+      if (seg0 + sl < n_seg && live) {
+        const int q = (int)slot_of[sl];
+        if (q != 0xffff) {
+          const int st = (int)stage_of[q];
+          if (st >= 0) {
+            v[u] = *reinterpret_cast<const V*>(&stage[(size_t)st * c.dim + (size_t)sub * 4]);
+          } else {
+            v[u] = *reinterpret_cast<const V*>(c.table + keys[q] * (uint64_t)c.dim + (uint64_t)sub * 4);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kHotU; ++u) {
+      const int64_t s = seg0 + s0 + u * groups + grp;
+      if (s < n_seg && live) {
+        __builtin_nontemporal_store(
+            v[u], reinterpret_cast<V*>(c.out + s * (int64_t)c.out_stride + (int64_t)sub * 4));
+      }
+    }
+  }
+}
+
 template <bool CSR, typename V, bool RUNS>
 void launch_kind(const LookupArgs& args, unsigned tiles, hipStream_t stream) {
   hipLaunchKernelGGL((group_lookup_fwd_kernel<CSR, V, RUNS>), dim3(tiles), dim3(kBlock), 0, stream,
@@ -222,6 +371,10 @@ void launch_kind(const LookupArgs& args, unsigned tiles, hipStream_t stream) {
 }
 
 void launch_by_kind(int kind, const LookupArgs& args, unsigned tiles, hipStream_t stream) {
+  if (kind == 8) {  // wide rows through the hot-row kernel (option fwd_hot_rows)
+    hipLaunchKernelGGL(group_lookup_fwd_hot_kernel, dim3(tiles), dim3(kBlock), 0, stream, args);
+    return;
+  }
   switch (kind) {  // bit 0 ragged, bit 1 scalar chunks, bit 2 segmented table
     case 0: launch_kind<false, f32x4, false>(args, tiles, stream); break;
     case 1: launch_kind<true, f32x4, false>(args, tiles, stream); break;
@@ -268,10 +421,12 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
                 "group_lookup_fwd: column %d: more than 2^31-1 ids/segments", c);
   }
 
-  for (int kind = 0; kind < 8; ++kind) {
+  const int hot_mode = options().fwd_hot_rows;
+  for (int kind = 0; kind < 9; ++kind) {
     int32_t c0 = 0;
     while (c0 < n_cols) {
       LookupArgs args;
+      args.hot_mode = hot_mode;
       int32_t k = 0;
       int64_t tiles = 0;
       args.tile_start[0] = 0;
@@ -289,8 +444,13 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
                                   &shape),
                     "group_lookup_fwd: dim %d needs more than 64 lanes per row "
                     "(unaligned or dim %% 4 != 0 with dim > 64 is unsupported)", h.dim);
-        const int col_kind = (h.row_splits != nullptr ? 1 : 0) | (shape.vec4 ? 0 : 2) |
-                             (h.n_runs > 0 ? 4 : 0);
+        int col_kind = (h.row_splits != nullptr ? 1 : 0) | (shape.vec4 ? 0 : 2) |
+                       (h.n_runs > 0 ? 4 : 0);
+        // one id per segment, plain table, wide 16-byte-chunk rows: the hot-row kernel when asked
+        if (col_kind == 0 && hot_mode > 0 && h.dim >= 64 && h.dim <= 1024 &&
+            shape.lpr_log2 <= 6 && h.dim <= kHotStageFloats) {
+          col_kind = 8;
+        }
         if (col_kind != kind) continue;
         ColArg& d = args.col[k];
         d.table = h.table;
@@ -310,7 +470,8 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
         d.run_start = h.run_start;
         d.run_base = h.run_base;
         const int64_t rpi = kWave >> d.lpr_log2;
-        const int64_t per_block = kWavesPerBlock * rpi * (h.row_splits ? kSegIters : kU);
+        const int64_t per_block =
+            col_kind == 8 ? kHotTile : kWavesPerBlock * rpi * (h.row_splits ? kSegIters : kU);
         tiles += (h.n_segments + per_block - 1) / per_block;
         HBK_REQUIRE(tiles < (1ll << 31), "group_lookup_fwd: grid too large");
         ++k;

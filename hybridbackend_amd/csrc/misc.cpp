@@ -32,6 +32,7 @@ const OptionEntry kOptions[] = {
     {"bwd_onepass", "HBK_BWD_ONEPASS", &Options::bwd_onepass},
     {"bwd_group_cols", "HBK_BWD_GROUP_COLS", &Options::bwd_group_cols},
     {"bwd_dense", "HBK_BWD_DENSE", &Options::bwd_dense},
+    {"fwd_hot_rows", "HBK_FWD_HOT", &Options::fwd_hot_rows},
     {"unique_buckets_log2", "HBK_UNIQUE_LOG2P", &Options::unique_buckets_log2},
     {"partition_sub_tiles", "HBK_PART_SUB", &Options::partition_sub_tiles},
     {"partition_fixed_max", "HBK_PART_FIXED", &Options::partition_fixed_max},
@@ -41,6 +42,9 @@ const OptionEntry kOptions[] = {
     {"sharded_id64", "HBK_SHARDED_ID64", &Options::sharded_id64},
     {"sharded_copy_self", "HBK_SHARDED_COPY_SELF", &Options::sharded_copy_self},
     {"sharded_trace", "HBK_SHARDED_TRACE", &Options::sharded_trace},
+    {"sync_wait_ms", "HBK_SYNC_WAIT_MS", &Options::sync_wait_ms},
+    {"sync_onepass_off", "HBK_SYNC_ONEPASS_OFF", &Options::sync_onepass_off},
+    {"sync_test_withhold", "HBK_SYNC_TEST_WITHHOLD", &Options::sync_test_withhold},
 };
 
 Options from_environment() {
@@ -84,6 +88,8 @@ extern "C" int hbk_get_option(const char* name, int32_t* value) {
   }
   return fail(HBK_INVALID_ARGUMENT, "get_option: unknown option '%s'", name);
 }
+
+extern "C" int hbk_sync_check(void) { return hbk::sync_check("sync_check"); }
 
 extern "C" const char* hbk_version(void) { return "hbk 0.1.0 gfx950"; }
 

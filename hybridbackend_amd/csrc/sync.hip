@@ -7,9 +7,14 @@
 // a memset.  Buffers are a few hundred KB and are kept for the life of the process; a buffer that
 // has become too small is replaced and the old one kept (work on the stream may still read it).
 //
-// Every wait is bounded: a wave that has polled for kSyncWaitTicks of the 100 MHz clock raises the
-// host-visible status word and gives up, and the next entry call reports HBK_INTERNAL instead of
-// the device hanging.
+// Every wait is bounded (option sync_wait_ms, 2 s of the constant 100 MHz clock: far beyond any
+// queue preemption, short of a hang).  A wave that gives up raises the host-visible status word
+// AND the call's poison word in device memory: the later kernels of the same call read the poison
+// first and leave, so nothing is computed from descriptors that were never written.  The host
+// reports the failure once -- at the next entry call, at hbk_sync_check(), or in the SAME call
+// where that call synchronises anyway (the sharded step) -- and from then on takes the
+// multi-launch forms (option sync_onepass_off).  The one-launch forms are also refused when the
+// device could not hold a whole column's workgroups at once (occupancy x CUs, cached).
 #include <map>
 #include <mutex>
 #include <utility>
@@ -38,19 +43,51 @@ int32_t* sync_status() {
   return word;
 }
 
-bool sync_raised() {
+int sync_check(const char* who) {
   int32_t* st = sync_status();
-  return st != nullptr && *reinterpret_cast<volatile int32_t*>(st) != 0;
+  if (st == nullptr || *reinterpret_cast<volatile int32_t*>(st) == 0) return HBK_OK;
+  *reinterpret_cast<volatile int32_t*>(st) = 0;
+  options().sync_onepass_off = 1;
+  return fail(HBK_INTERNAL,
+              "%s: a one-launch kernel (partition / unique / backward grouping) gave up waiting "
+              "for the tiles of its column after %d ms; the outputs of the call it belonged to "
+              "are not valid.  The library has switched to its multi-launch forms "
+              "(option sync_onepass_off = 1)", who, options().sync_wait_ms);
 }
 
-bool sync_take(hipStream_t stream, size_t words, SyncTake* out) {
+namespace {
+// can `max_column_wgs` workgroups of `kernel` be resident at once?  (cached per device and kernel)
+bool fits_device(int dev, const void* kernel, int block, int max_column_wgs) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> capacity;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = capacity.find(std::make_pair(dev, kernel));
+  if (it == capacity.end()) {
+    int per_cu = 0, cus = 0;
+    int cap = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
+      cap = per_cu * cus;
+    }
+    it = capacity.emplace(std::make_pair(dev, kernel), cap).first;
+  }
+  // a column's workgroups wait while OTHER columns' workgroups occupy slots too: ask for twice
+  return it->second >= 2 * max_column_wgs;
+}
+}  // namespace
+
+bool sync_take(hipStream_t stream, size_t words, SyncTake* out, const void* kernel, int block,
+               int max_column_wgs) {
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, SyncSlot> slots;
+  if (options().sync_onepass_off != 0) return false;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(stream, &capturing);
   if (capturing != hipStreamCaptureStatusNone) return false;   // a graph replays ONE launch
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || sync_status() == nullptr) return false;
+  if (kernel != nullptr && !fits_device(dev, kernel, block, max_column_wgs)) return false;
+  words += 1;   // the call's poison word, behind its sync words
   std::lock_guard<std::mutex> lock(mu);
   SyncSlot& s = slots[std::make_pair(dev, stream)];
   if (s.half_words < words) {
@@ -68,6 +105,10 @@ bool sync_take(hipStream_t stream, size_t words, SyncTake* out) {
   out->zero = s.buf + (size_t)(1 - h) * s.half_words;
   out->zero_words = (int64_t)s.dirty_words[1 - h];
   out->status = sync_status();
+  out->poison = out->words + (words - 1);
+  out->wait_ticks = (unsigned long long)(options().sync_wait_ms > 0 ? options().sync_wait_ms : 1) *
+                    100000ull;
+  out->withhold = options().sync_test_withhold;
   s.dirty_words[h] = words;
   s.dirty_words[1 - h] = 0;
   s.half = 1 - h;

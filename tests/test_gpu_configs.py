@@ -63,10 +63,13 @@ def _run_ranks(world, fn):
 
 
 # ----------------------------------------------------------------------------------------------
-def test_config4_full_size_zipf_forward_backward():
+@pytest.mark.parametrize('hot_rows', [0, 1])
+def test_config4_full_size_zipf_forward_backward(hbk_option, hot_rows):
   """25 x 1M + 1 x 100M rows, dim 128, Zipf(1.2), batch 65536: forward == table[ids % R] and
   backward == index_add_ on device; oracle on the sub-sample of ids whose rows lie beyond float
-  offset 2^32 of the big table."""
+  offset 2^32 of the big table.  hot_rows: the forward through the per-wave gather or through the
+  256-segment tiles that stage repeated rows in LDS."""
+  hbk_option('fwd_hot_rows', hot_rows)
   free, _ = torch.cuda.mem_get_info()
   if free < 100 * 2**30:
     pytest.skip('needs ~75 GB of HBM')

@@ -279,6 +279,57 @@ def test_group_lookup_more_columns_than_one_launch():
     np.testing.assert_equal(host(o), w)
 
 
+@pytest.mark.parametrize('mode', [1, 2])
+def test_group_lookup_hot_row_tiles(hbk_option, mode):
+  """Wide one-id-per-sample columns through the 256-segment tiles (option fwd_hot_rows): 1 =
+  repeated rows staged in LDS, 2 = the tiles alone.  Bit-equal to the oracle's gather: skewed ids
+  (more repeated rows than staging slots), all ids one row, all rows distinct, ids outside the
+  table (zero rows), a short last tile, int32 ids, a strided output; dims below 64 and ragged
+  columns in the same call keep their kernels."""
+  hbk_option('fwd_hot_rows', mode)
+  rng = np.random.RandomState(77)
+  cases = []   # (dim, rows, ids, bucket)
+  for dim, rows, n in ((128, 5000, 3000), (64, 300, 1500), (256, 2000, 777), (72, 100000, 2049)):
+    zipf = (rng.zipf(1.2, size=n) * 7919) % rows
+    cases.append((dim, rows, zipf.astype(np.int64), None))
+    cases.append((dim, rows, np.full(n, rows - 1, np.int64), None))
+    cases.append((dim, rows, rng.permutation(max(rows, n))[:n].astype(np.int64) % rows, None))
+    bad = rng.randint(0, rows, size=n).astype(np.int64)
+    bad[::5] = rows + 3
+    bad[1::7] = -2
+    cases.append((dim, rows, bad, None))
+    cases.append((dim, rows, rng.randint(0, 2**40, size=n).astype(np.int64), rows))
+  cases.append((16, 1000, rng.randint(0, 1000, size=5000).astype(np.int64), None))   # narrow: not eligible
+  tables = [rng.uniform(-1, 1, size=(r, d)).astype(np.float32) for d, r, _, _ in cases]
+  for ids_dtype in (np.int64, np.int32):
+    use = [i for i, c in enumerate(cases) if ids_dtype == np.int64 or c[3] is None]
+    t_dev = [dev(tables[i]) for i in use]
+    buckets = [cases[i][3] or 0 for i in use]
+    lookup = hb.embedding.GroupLookup(t_dev, buckets if any(buckets) else None, 'sum')
+    outs = lookup([dev(cases[i][2].astype(ids_dtype)) for i in use])
+    for i, out in zip(use, outs):
+      dim, rows, ids, bucket = cases[i]
+      local = ids % bucket if bucket else ids
+      want = np.zeros((ids.size, dim), np.float32)
+      ok = (local >= 0) & (local < rows)
+      want[ok] = tables[i][local[ok]]
+      np.testing.assert_equal(host(out), want)
+  # strided output (the dense feature block) through the tiles
+  dims = [64, 128, 64]
+  batch = 1000
+  block = torch.full((batch, sum(dims) + 4), float('nan'), device=DEV)
+  tabs = [rng.uniform(-1, 1, size=(50, d)).astype(np.float32) for d in dims]
+  ids = [(rng.zipf(1.3, size=batch) % 50).astype(np.int64) for _ in dims]
+  views, off = [], 0
+  for d in dims:
+    views.append(block[:, off:off + d])
+    off += d
+  hb.embedding.GroupLookup([dev(t) for t in tabs], None, 'sum')([dev(i) for i in ids], None, views)
+  got = host(block)
+  np.testing.assert_equal(got[:, :off], np.concatenate([t[i] for t, i in zip(tabs, ids)], axis=1))
+  assert np.isnan(got[:, off:]).all()
+
+
 def test_group_lookup_baseline_full_size_properties():
   # BASELINE config 2: 26 columns x 1M x 16, batch 65536: size-independent properties
   torch.manual_seed(0)

@@ -35,12 +35,12 @@ for st in $STAGES; do
       timeout 300 tools/bin/bench_ops > $O/bench_ops.log 2>&1; echo "ops rc=$?" >> $O/bench_ops.log; cat $O/bench_ops.log;;
     bwdops)   # the backward through the C ABI: dense (row-range) buckets vs hashed ones
       for dense in 1 0; do
-        for w in b s d r w; do
+        for w in ${BWD_CASES:-b s d r w}; do
           HBK_BWD_DENSE=$dense timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk " | sed "s/^/dense=$dense  /"
         done
       done > $O/bwdops.log 2>&1; cat $O/bwdops.log;;
     bwdstamps)
-      for w in b s; do LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops $w; done > $O/bwdstamps.log 2>&1; cat $O/bwdstamps.log;;
+      for w in b s d; do LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops $w; done > $O/bwdstamps.log 2>&1; cat $O/bwdstamps.log;;
     profbwd)
       prof prof_bwd "" -- $R/tools/bin/bench_ops b
       prof prof_bwd_step "" -- $R/tools/bin/bench_ops s
@@ -56,6 +56,10 @@ for k,v in sorted(d.items()):
   print(k[:70].ljust(70), {c:round(x['mean']) for c,x in v.items()})
 PY
       done;;
+    hottest)
+      timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "hot_row or group_lookup" --durations=5 > $O/hottest.log 2>&1; echo "pytest rc=$?" >> $O/hottest.log; tail -15 $O/hottest.log;;
+    hotsweep)
+      timeout 900 python tools/sweep.py --big --cases j > $O/hotsweep.log 2>&1; echo "rc=$?" >> $O/hotsweep.log; cut -c1-300 $O/hotsweep.log;;
     sweep)
       timeout 1200 python tools/sweep.py --big --cases ${SWEEP_CASES:-a,b,c,d,e,f,g,h,i} > $O/sweep.log 2>&1; echo "sweep rc=$?" >> $O/sweep.log; cut -c1-400 $O/sweep.log;;
     *) echo "unknown stage $st";;

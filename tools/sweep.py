@@ -160,6 +160,42 @@ def case_cfg4(big):
     report(f'cfg4 bwd Zipf(1.2) dim128 B={B} ({tag})', us, 26 * B, nbytes, unique_rows=uniq)
 
 
+def case_cfg4_hot_rows(big):
+  """Config-4 forward under option fwd_hot_rows: 0 per-wave gather, 1 256-segment tiles with
+  repeated rows staged in LDS, 2 the tiles alone; Zipf(1.2), uniform and one-row ids."""
+  from hybridbackend_amd import _lib
+  dim, B = 128, 65536
+  rows = [1000000] * 25 + [100000000 if big else 10000000]
+  tables = [torch.empty(r, dim, device=DEV).uniform_(-1e-3, 1e-3) for r in rows]
+  g = torch.Generator(device=DEV)
+  g.manual_seed(7)
+  nb = 4
+  kinds = {
+      'Zipf(1.2)': [[zipf_ids(B, rows[c], 1.2, g, 2654435761 % rows[c] | 1) for c in range(26)]
+                    for _ in range(nb)],
+      'uniform': [[torch.randint(0, rows[c], (B,), device=DEV, generator=g) for c in range(26)]
+                  for _ in range(nb)],
+      'one row': [[torch.zeros(B, dtype=torch.int64, device=DEV) for c in range(26)]] * nb,
+  }
+  outs = [torch.empty(B, dim, device=DEV) for _ in range(26)]
+  for name, batches in kinds.items():
+    plans = []
+    for b in range(nb):
+      gl = hb.embedding.GroupLookup(tables, None, 'sum')
+      gl.bind(batches[b], None, outs)
+      plans.append(gl)
+    uniq = sum(int(torch.unique(batches[0][c]).numel()) for c in range(26))
+    for mode in (0, 1, 2):
+      old = _lib.set_option('fwd_hot_rows', mode)
+      try:
+        us = timed(lambda i: plans[i % nb].launch(), iters=20)
+      finally:
+        _lib.set_option('fwd_hot_rows', old)
+      report(f'cfg4 fwd {name} dim128 B={B} fwd_hot_rows={mode}', us, 26 * B,
+             26 * B * (8 + 512 + 512), unique_rows=uniq,
+             dedup_aware_GBps=round((26 * B * (8 + 512) + uniq * 512) / us / 1e3, 1))
+
+
 def case_integer():
   B = 65536
   ids = [torch.randint(0, 1 << 40, (B,), device=DEV) for _ in range(26)]
@@ -316,5 +352,6 @@ if __name__ == '__main__':
   torch.manual_seed(0)
   for c in args.cases.split(','):
     {'a': case_batch_sweep, 'b': case_ragged, 'c': case_backward_cfg2,
-     'd': lambda: case_cfg4(args.big), 'e': case_integer, 'f': case_bwd_probe, 'g': case_sharded_world1, 'h': case_cfg5, 'i': case_dense_block}[c]()
+     'd': lambda: case_cfg4(args.big), 'e': case_integer, 'f': case_bwd_probe, 'g': case_sharded_world1, 'h': case_cfg5, 'i': case_dense_block,
+     'j': lambda: case_cfg4_hot_rows(args.big)}[c]()
     torch.cuda.empty_cache()

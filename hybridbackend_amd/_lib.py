@@ -81,6 +81,7 @@ def _declare(l):
     'hbk_version': (C.c_char_p, []),
     'hbk_set_option': (C.c_int, [C.c_char_p, i32]),
     'hbk_get_option': (C.c_int, [C.c_char_p, vp]),
+    'hbk_sync_check': (C.c_int, []),
     'hbk_host_floormod_i64': (i64, [i64, i64]),
     'hbk_host_fastdiv_u64': (C.c_uint64, [C.c_uint64, C.c_uint64]),
     'hbk_floormod_n': (C.c_int, [i32, i32, vp, vp, vp, vp, vp]),

@@ -187,6 +187,17 @@ int sync_check(const char* who);
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// a wait of an earlier kernel of this call ran out: what it should have written is not there
+__device__ inline bool poisoned(const int32_t* poison) {
+  return poison != nullptr &&
+         __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+// a wait ran out: poison the call (device word), tell the host (pinned word)
+__device__ inline void give_up(const SyncWait& w) {
+  __hip_atomic_store(w.poison, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(w.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ inline int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }
 
 // number of set bits of `mask` strictly below this lane

@@ -515,7 +515,7 @@ struct GSync {
   int32_t* hist;        // per column [tiles][n_buckets] words: 0 = not published, else count + 1
   int32_t* zero;        // words the call before left set
   int64_t zero_words;
-  int32_t* status;      // raised by a wait that ran out
+  SyncWait wait;        // bound of the waits, status / poison words, test hook
 };
 
 // (5 waves per SIMD: all 832 workgroups of a 26 x 65536 call resident at once; at 145 VGPRs the
@@ -582,9 +582,11 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
   }
   __syncthreads();
   HBK_GSTAMP(2);            // ids arrived, ranks taken
-  for (int p = tid; p < P; p += kBlock) {
-    __hip_atomic_store(hist + (int64_t)ctile * P + p, counters[p] + 1, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+  if ((int)blockIdx.x != y.wait.withhold) {
+    for (int p = tid; p < P; p += kBlock) {
+      __hip_atomic_store(hist + (int64_t)ctile * P + p, counters[p] + 1, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   HBK_GSTAMP(3);            // published
   // totals of every bucket over the column's tiles and the part of the tiles before this one
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
           ok = ok && x[e] != 0;
         }
         if (ok) break;
-        if (__builtin_amdgcn_s_memrealtime() - t_begin > kSyncWaitTicks) {
+        if (__builtin_amdgcn_s_memrealtime() - t_begin > y.wait.ticks) {
           lost = true;
           break;
         }
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
   __syncthreads();
   HBK_GSTAMP(4);            // the column's counts are in
   if (gave_up != 0) {
-    if (tid == 0) __hip_atomic_store(y.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) give_up(y.wait);
     return;
   }
   // bucket starts (scan of the column's totals) and, for the staged scatter, the tile's own
@@ -1507,7 +1509,7 @@ struct DenseLds {
   float heads[kBlock * 4];       // sorted walk: what a lane group holds of the run at its first position
   float carry[2][kWave * 4];     // sorted walk: the run that goes on into the next round
   int32_t wave_tot[kWavesPerBlock];
-  int32_t n_rows, n_dup, base_u;
+  int32_t n_again, n_dup, base_u;   // pairs that found their row's bit set; dup rows; output base
   int32_t n_dlist[2];
 };
 
@@ -1566,31 +1568,52 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
   if (tid == 0) {
     L.n_dlist[0] = 0;
     L.n_dlist[1] = 0;
+    L.n_again = 0;
   }
   __syncthreads();
   HBK_STAMP(2);
 
   // A: rows -> bitmaps.  A bit that is already set is not set again: the pairs of a hot row
   // would serialise on its word (64 same-address LDS atomics per instruction).
+  // The pairs that find their bit set are counted: rows of the bucket = pairs - those, known
+  // right behind the barrier, a scan earlier than the ranks.
+  int n_again = 0;   // (wave-uniform)
   for (int32_t cb = 0; cb < n_pairs; cb += kCP) {
     if (cb > 0) load_pairs(cb);
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
+      bool again = false;
       if (r_in[k] >= 0) {
         const uint32_t off = (uint32_t)r_in[k] - base;
         const int w = (int)(off >> 5);
         const uint32_t bit = 1u << (off & 31u);
         uint32_t old = L.present[w];
         if ((old & bit) == 0u) old = atomicOr(&L.present[w], bit);
-        if ((old & bit) != 0u && (L.dup[w] & bit) == 0u) atomicOr(&L.dup[w], bit);
+        again = (old & bit) != 0u;
+        if (again && (L.dup[w] & bit) == 0u) atomicOr(&L.dup[w], bit);
       }
+      n_again += (int)__builtin_popcountll(__ballot(again));
     }
   }
+  if (lane == 0 && n_again > 0) atomicAdd(&L.n_again, n_again);
   __syncthreads();
   HBK_STAMP(3);
 
-  // B: rows before every word, present and dup counts packed in one scan (both <= kDenseSpan < 2^16)
+  // One global atomic per workgroup claims the output range of the bucket's rows; a returning
+  // device-scope atomic takes microseconds under load: it is issued as soon as the count is known
+  // and its round trip runs beside the scan of B and the gradient loads of C.  Step only: just
+  // the count is wanted, nobody waits for it.
   int32_t claimed = 0;
+  if (tid == kBlock - 1) {
+    const int32_t n_rows = n_pairs - L.n_again;
+    if (!emit) {
+      __hip_atomic_fetch_add(job.out_counter, n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      claimed = atomicAdd(job.out_counter, n_rows);
+    }
+  }
+
+  // B: rows before every word, present and dup counts packed in one scan (both <= kDenseSpan < 2^16)
   {
     uint32_t cnt[kDenseWPT], sum = 0;
 #pragma unroll
@@ -1619,19 +1642,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
       if (w < words) L.pre[w] = run;
       run += cnt[q];
     }
-    if (tid == kBlock - 1) {
-      const int32_t n_rows = (int32_t)(run & 0xffffu);
-      L.n_rows = n_rows;
-      L.n_dup = (int32_t)(run >> 16);
-      // One global atomic per workgroup claims the output range of the bucket's rows; a returning
-      // device-scope atomic takes microseconds under load: its round trip runs beside the gradient
-      // loads of C.  Step only: just the count is wanted, nobody waits for it.
-      if (!emit) {
-        __hip_atomic_fetch_add(job.out_counter, n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        claimed = atomicAdd(job.out_counter, n_rows);
-      }
-    }
+    if (tid == kBlock - 1) L.n_dup = (int32_t)(run >> 16);
   }
   __syncthreads();
   HBK_STAMP(4);
@@ -1744,11 +1755,15 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
         for (int i = tid; i < nd; i += kBlock) L.dcnt[i] = 0;   // (next read: behind a barrier)
       }
 
-      // C: the pairs that are alone on their row (first round only)
+      // C: the pairs that are alone on their row (first round only).  When the chunk's dup pairs
+      // are few (not sorted), their gradient rows travel in the same round and go into the rows'
+      // LDS sums (ds_add_f32) when they arrive.
       if (round == 0) {
+        const bool fold = !sorted && n_dl > 0;   // uniform
+        used_red = used_red || fold;
         for (int e0 = 0; e0 < n_chunk; e0 += kDepth * groups) {
           V g[kDepth], tv[STEP ? kDepth : 1], av[STEP == 2 ? kDepth : 1];
-          uint32_t mask = 0;
+          uint32_t mask = 0, dmask = 0;
 #pragma unroll
           for (int k = 0; k < kDepth; ++k) {
             const int i = e0 + k * groups + my_group;
@@ -1767,6 +1782,9 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
                         __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
                   }
                 }
+              } else if (fold && (code & (kDupBit - 1)) < d1) {   // (round 0: d0 = 0)
+                dmask |= 1u << k;
+                g[k] = load_grad<V>(c, job, L.seg[i], sub);
               }
             }
           }
@@ -1778,8 +1796,14 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
           }
 #pragma unroll
           for (int k = 0; k < kDepth; ++k) {
-            if ((mask >> k & 1u) == 0) continue;
+            if (((mask | dmask) >> k & 1u) == 0) continue;
             const int i = e0 + k * groups + my_group;
+            if (dmask >> k & 1u) {
+              float* r = &L.red[(size_t)(L.code[i] & (kDupBit - 1)) * c.dim + (size_t)sub * VE];
+#pragma unroll
+              for (int q = 0; q < VE; ++q) atomicAdd(r + q, reinterpret_cast<const float*>(&g[k])[q]);
+              continue;
+            }
             if (emit) emit_row<V>(c, job, base_u + L.code[i], true, sub, g[k]);
             if (STEP && lr != 0.0f) {
               const int64_t toff = (int64_t)(base + L.off[i]) * c.dim + (int64_t)sub * VE;
@@ -1918,10 +1942,10 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
           }
           __syncthreads();
         }
-      } else {
-        // Few (uniform ids: ~14 of a chunk's 450 pairs): summed into the rows' LDS sums by
-        // ds_add_f32; what a lane group holds for one row in consecutive registers is added up
-        // first.
+      } else if (round > 0) {
+        // Few, and not the first round (wide rows: only 2048 / dim sums fit LDS at a time; the
+        // first round's pairs went with C): summed into the rows' LDS sums by ds_add_f32; what a
+        // lane group holds for one row in consecutive registers is added up first.
         used_red = used_red || n_dl > 0;
         for (int i0 = 0; i0 < n_dl; i0 += kDepth * groups) {
           V g[kDepth];
@@ -2042,8 +2066,10 @@ __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4&
 template <typename V, int STEP>
 __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const GArgs a,
                                                                           const int4* desc,
-                                                                          int slot0, int total) {
+                                                                          int slot0, int total,
+                                                                          const int32_t* poison) {
   __shared__ ReduceLds lds[kTeams];
+  if (poisoned(poison)) return;   // the grouping launch gave up: no descriptors, no pairs
   HBK_STAMP_BEGIN()
   const int lane = (int)threadIdx.x & (kWave - 1);
   const int team = (int)threadIdx.x / kTeam;
@@ -2064,8 +2090,10 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
 template <typename V, int STEP>
 __global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(STEP)) void bwd_dense_kernel(const GArgs a,
                                                                                const int4* desc,
-                                                                               int slot0, int total) {
+                                                                               int slot0, int total,
+                                                                               const int32_t* poison) {
   __shared__ DenseLds lds;
+  if (poisoned(poison)) return;   // the grouping launch gave up: no descriptors, no pairs
   HBK_STAMP_BEGIN()
   const int lane = (int)threadIdx.x & (kWave - 1);
   const int vb = slot0 + (int)blockIdx.x;
@@ -2128,8 +2156,10 @@ __device__ inline void merge_job(const GArgs& a, const GCol& c, int bucket, Redu
 }
 
 template <typename V, int STEP>
-__global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const GArgs a, int block0) {
+__global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const GArgs a, int block0,
+                                                                         const int32_t* poison) {
   __shared__ ReduceLds lds[kTeams];
+  if (poisoned(poison)) return;
   const int block = block0 + (int)blockIdx.x;
   HBK_FIND_COL_AT(a, merge0, block)
   const int team = (int)threadIdx.x / kTeam;
@@ -2146,8 +2176,10 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const 
 
 template <typename V, int STEP>
 __global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(STEP)) void bwd_dense_merge_kernel(const GArgs a,
-                                                                                     int block0) {
+                                                                                     int block0,
+                                                                                     const int32_t* poison) {
   __shared__ DenseLds lds;
+  if (poisoned(poison)) return;
   const int block = block0 + (int)blockIdx.x;
   HBK_FIND_COL_AT(a, merge0, block)
   const int n_extra = *c.n_extra;
@@ -2476,10 +2508,9 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
               workspace_bytes);
   HBK_REQUIRE(((uintptr_t)workspace & 7) == 0,
               "group_lookup_bwd: workspace must be 8-byte aligned");
-  if (sync_raised()) {
-    return fail(HBK_INTERNAL, "group_lookup_bwd: an earlier one-pass launch gave up waiting for "
-                              "the tiles of its column (its outputs are not valid); set option "
-                              "bwd_onepass = 0");
+  {
+    const int rc = sync_check("group_lookup_bwd");
+    if (rc != HBK_OK) return rc;
   }
   // head of the workspace: the job descriptors of all columns (16-byte aligned), then the
   // per-column buffers
@@ -2710,12 +2741,13 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     bool onepass = group_onepass && sync_words < (1ll << 30);
     if (onepass) {
       SyncTake take;
-      onepass = sync_take(ls, (size_t)sync_words, &take);
+      onepass = sync_take(ls, (size_t)sync_words, &take,
+                          reinterpret_cast<const void*>(&bwd_group_kernel), kBlock, 64);
       if (onepass) {
         sync.hist = take.words;
         sync.zero = take.zero;
         sync.zero_words = take.zero_words;
-        sync.status = take.status;
+        sync.wait = sync_wait_of(take);
       }
     }
     if (onepass) {
@@ -2737,8 +2769,9 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     }
     // one instantiation per kind and optimizer (none / SGD / Adagrad), each on its own job slots
     const int step = apply_lr == 0.0f ? 0 : apply == HBK_APPLY_ADAGRAD ? 2 : 1;
-    typedef void (*reduce_fn)(const GArgs, const int4*, int, int);
-    typedef void (*merge_fn)(const GArgs, int);
+    typedef void (*reduce_fn)(const GArgs, const int4*, int, int, const int32_t*);
+    typedef void (*merge_fn)(const GArgs, int, const int32_t*);
+    const int32_t* poison = onepass ? sync.wait.poison : nullptr;
     static const reduce_fn kReduce[4][3] = {
         {&bwd_dense_kernel<f32x4, 0>, &bwd_dense_kernel<f32x4, 1>, &bwd_dense_kernel<f32x4, 2>},
         {&bwd_dense_kernel<float, 0>, &bwd_dense_kernel<float, 1>, &bwd_dense_kernel<float, 2>},
@@ -2757,12 +2790,12 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       const int64_t per = kind >= 2 ? kTeams : 1;   // job slots per workgroup
       hipLaunchKernelGGL(kReduce[kind][step], dim3((unsigned)((n_slots + per - 1) / per)),
                          dim3(kBlock), 0, ls, args, desc_group, (int)slot_lo[kind],
-                         (int)slot_hi[kind]);
+                         (int)slot_hi[kind], poison);
     }
     for (int kind = 0; kind < 4; ++kind) {
       if (!have_kind[kind]) continue;
       hipLaunchKernelGGL(kMerge[kind][step], dim3((unsigned)(merge_hi[kind] - merge_lo[kind])),
-                         dim3(kBlock), 0, ls, args, (int)merge_lo[kind]);
+                         dim3(kBlock), 0, ls, args, (int)merge_lo[kind], poison);
     }
     const hipError_t launch_err = hipGetLastError();
     if (launch_err != hipSuccess) {

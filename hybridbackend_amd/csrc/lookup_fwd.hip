@@ -333,15 +333,17 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const Look
     }
   }
   if (ns > 0) __syncthreads();   // uniform
-  // (4) the tile's segments: staged rows from LDS, the others from the table
-  for (int s0 = 0; s0 < kHotTile; s0 += kHotU * groups) {
-    if (seg0 + s0 >= n_seg) break;   // uniform
-    V v[kHotU];
+  // (4) the tile's segments: staged rows from LDS, the others from the table.  Software
+  // pipelined: the rows of batch i + 1 are requested before batch i is stored, so a lane keeps
+  // 2 x kHotU row chunks in flight and loads and stores of one workgroup overlap (without it the
+  // tiles alone were 15 % slower than the per-wave gather on uniform ids).
+  const int step = kHotU * groups;
+  auto fetch = [&](int s0, V* v) {
 #pragma unroll
     for (int u = 0; u < kHotU; ++u) {
       const int sl = s0 + u * groups + grp;
       v[u] = zero_v<V>();
-      if (seg0 + sl < n_seg && live) {
+      if (sl < kHotTile && seg0 + sl < n_seg && live) {
         const int q = (int)slot_of[sl];
         if (q != 0xffff) {
           const int st = (int)stage_of[q];
@@ -353,14 +355,27 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const Look
         }
       }
     }
+  };
+  auto put = [&](int s0, const V* v) {
 #pragma unroll
     for (int u = 0; u < kHotU; ++u) {
-      const int64_t s = seg0 + s0 + u * groups + grp;
-      if (s < n_seg && live) {
+      const int sl = s0 + u * groups + grp;
+      const int64_t s = seg0 + sl;
+      if (sl < kHotTile && s < n_seg && live) {
         __builtin_nontemporal_store(
             v[u], reinterpret_cast<V*>(c.out + s * (int64_t)c.out_stride + (int64_t)sub * 4));
       }
     }
+  };
+  int64_t left = n_seg - seg0;
+  const int n_here = left < kHotTile ? (int)left : kHotTile;
+  V va[kHotU], vb[kHotU];
+  fetch(0, va);
+  for (int s0 = 0; s0 < n_here; s0 += 2 * step) {
+    if (s0 + step < n_here) fetch(s0 + step, vb);
+    put(s0, va);
+    if (s0 + 2 * step < n_here) fetch(s0 + 2 * step, va);
+    if (s0 + step < n_here) put(s0 + step, vb);
   }
 }
 

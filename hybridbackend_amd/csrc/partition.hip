@@ -592,7 +592,7 @@ constexpr int kOneMaxP = 8;
 struct OnePass {
   int32_t* zero;        // words the call before this one left set (the other half), or NULL
   int64_t zero_words;
-  int32_t* status;      // host-visible, raised on a timed-out wait
+  SyncWait wait;        // bound of the waits, status / poison words, test hook
 };
 
 constexpr int kOneWaves = 4;   // waves per workgroup, each on a tile of its own (nothing shared:
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(kOneWaves* kWave) void partition_onepass_kernel(con
   // lane p holds the tile's count of shard p
   const int32_t my_run = run_of_lane(run, lane);
   HBK_PSTAMP(3);   // ranks done
-  if (lane < P) {
+  if (lane < P && tile != o.wait.withhold) {
     __hip_atomic_store(hist + (int64_t)lane * n_tiles + ctile, my_run + 1, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -702,10 +702,8 @@ __global__ __launch_bounds__(kOneWaves* kWave) void partition_onepass_kernel(con
         ok = ok && x[p] != 0;
       }
       if (__ballot(!ok) == 0ull) break;
-      if (__builtin_amdgcn_s_memrealtime() - t_begin > kSyncWaitTicks) {
-        if (lane == 0) {
-          __hip_atomic_store(o.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+      if (__builtin_amdgcn_s_memrealtime() - t_begin > o.wait.ticks) {
+        if (lane == 0) give_up(o.wait);
         return;
       }
       __builtin_amdgcn_s_sleep(1);
@@ -847,10 +845,9 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
                 "%s: NULL buffer for input %d", what, c);
   }
 
-  if (sync_raised()) {
-    return fail(HBK_INTERNAL,
-                "%s: an earlier one-pass launch gave up waiting for the tiles of its column (its "
-                "outputs are not valid); set options partition_onepass / unique_onepass = 0", what);
+  {
+    const int rc = sync_check(what);
+    if (rc != HBK_OK) return rc;
   }
   ShardFn fn;
   fn.stage = stage;
@@ -876,11 +873,19 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
   OnePass one;
   one.zero = nullptr;
   one.zero_words = 0;
-  one.status = sync_status();
+  memset(&one.wait, 0, sizeof(one.wait));
   if (onepass) {
     const size_t words = (size_t)all_tiles * (size_t)P;
     SyncTake take;
-    if (!sync_take(stream, words, &take)) {
+    const void* fn_ptr = nullptr;
+    switch (dtype) {
+      case HBK_INT32: fn_ptr = reinterpret_cast<const void*>(&partition_onepass_kernel<int32_t>); break;
+      case HBK_UINT32: fn_ptr = reinterpret_cast<const void*>(&partition_onepass_kernel<uint32_t>); break;
+      case HBK_INT64: fn_ptr = reinterpret_cast<const void*>(&partition_onepass_kernel<int64_t>); break;
+      default: fn_ptr = reinterpret_cast<const void*>(&partition_onepass_kernel<uint64_t>); break;
+    }
+    if (!sync_take(stream, words, &take, fn_ptr, kOneWaves * kWave,
+                   (kOneMaxTiles + kOneWaves - 1) / kOneWaves)) {
       // the stream is being captured into a graph (a graph replays ONE recorded launch: no state
       // may alternate between calls), or there is no memory for the words: three launches
       onepass = false;
@@ -888,6 +893,7 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
       hist = take.words;
       one.zero = take.zero;
       one.zero_words = take.zero_words;
+      one.wait = sync_wait_of(take);
     }
   }
   int32_t c0 = 0;

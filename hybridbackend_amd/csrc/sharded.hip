@@ -555,6 +555,9 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   p->cur = use;
   const double t_enq1 = us_since(t_begin);
   HBK_HIP_OK(hipEventSynchronize(set.done));   // the step's one host wait: sizes are on the host
+  // the partition's one-launch form may have given up (bounded waits, sync.hip): then the sizes
+  // just read are not valid -- THIS step fails, before anything is sized from them
+  if ((rc = sync_check("sharded_lookup_fwd")) != HBK_OK) return rc;
   if (prefetched) HBK_HIP_OK(hipStreamWaitEvent(stream, set.done, 0));
   const double t_sync = us_since(t_begin);
   p->send_sizes.assign(set.host_sizes, set.host_sizes + (size_t)N * W);

@@ -242,10 +242,12 @@ __global__ __launch_bounds__(kBlock) void unique_scatter_kernel(const UArgs a) {
 }
 
 // ---- 4: one workgroup per bucket: first occurrence of every key ------------------------------
-__global__ __launch_bounds__(kFirstBlock) void unique_first_kernel(const UArgs a) {
+__global__ __launch_bounds__(kFirstBlock) void unique_first_kernel(const UArgs a,
+                                                                    const int32_t* poison) {
   __shared__ unsigned long long keys[kSlots];
   __shared__ uint32_t first[kSlots];
   __shared__ uint32_t first_m1;  // key -1 (the table's empty marker) has its own cell
+  if (poisoned(poison)) return;   // the grouping launch gave up: bucket starts were never written
   HBK_FIND_UCOL(bucket0)
   const int bucket = (int)blockIdx.x - c.bucket0;
   const int tid = (int)threadIdx.x;
@@ -448,8 +450,9 @@ struct USync {
   uint32_t* order;      // order: per 1024-id tile, 0 = nothing, v << 2 | 1 aggregate, | 2 inclusive
   int32_t* zero;        // words the call before left set (cleared by the group kernel)
   int64_t zero_words;
-  int32_t* status;      // raised by a wait that ran out
+  SyncWait wait;        // bound of the waits, status / poison words, test hook
 };
+
 
 __global__ __launch_bounds__(kBlock, 4) void unique_group_kernel(const UArgs a, const USync y) {
   __shared__ int32_t counters[1 << kGroupMaxLog2P];   // counts, then bases
@@ -495,9 +498,11 @@ __global__ __launch_bounds__(kBlock, 4) void unique_group_kernel(const UArgs a, 
   }
   __syncthreads();
   HBK_USTAMP(0, 2);
-  for (int p = tid; p < P; p += kBlock) {
-    __hip_atomic_store(hist + (int64_t)ctile * P + p, counters[p] + 1, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+  if ((int)blockIdx.x != y.wait.withhold) {
+    for (int p = tid; p < P; p += kBlock) {
+      __hip_atomic_store(hist + (int64_t)ctile * P + p, counters[p] + 1, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   HBK_USTAMP(0, 3);
   // totals of every bucket over the column's tiles and the part of the tiles before this one
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(kBlock, 4) void unique_group_kernel(const UArgs a, 
           ok = ok && x[e] != 0;
         }
         if (ok) break;
-        if (__builtin_amdgcn_s_memrealtime() - t_begin > kSyncWaitTicks) {
+        if (__builtin_amdgcn_s_memrealtime() - t_begin > y.wait.ticks) {
           lost = true;
           break;
         }
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(kBlock, 4) void unique_group_kernel(const UArgs a, 
   __syncthreads();
   HBK_USTAMP(0, 4);
   if (gave_up != 0) {
-    if (tid == 0) __hip_atomic_store(y.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) give_up(y.wait);
     return;
   }
   // bucket starts (scan of the column's totals) and the tile's own bucket offsets (scan of its
@@ -628,6 +633,7 @@ __global__ __launch_bounds__(kBlock) void unique_order_kernel(const UArgs a, con
   // (1024-id tiles, 4 consecutive ids per thread; 4096-id tiles with 16 per thread measured 35 us
   // instead of 20 for 26 x 65536 ids: what one thread does in sequence is what counts)
   HBK_USTAMP(2, 0);
+  if (poisoned(y.wait.poison)) return;   // the group kernel gave up: no pairs, no first[]
   HBK_FIND_UCOL(tile_start)
   const int ctile = (int)blockIdx.x - c.tile_start;
   const int n_tiles = (c.len + kTile - 1) / kTile;
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(kBlock) void unique_order_kernel(const UArgs a, con
           need = f == 63 ? ~0ull : ((1ull << (f + 1)) - 1ull);
         }
         if ((__ballot(x == 0u) & need) == 0ull) break;
-        if (__builtin_amdgcn_s_memrealtime() - t_begin > kSyncWaitTicks) {
+        if (__builtin_amdgcn_s_memrealtime() - t_begin > y.wait.ticks) {
           lost = true;
           break;
         }
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void unique_order_kernel(const UArgs a, con
     if (lane == 0) {
       prefix_s = lost ? -1 : (int32_t)excl;
       if (lost) {
-        __hip_atomic_store(y.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        give_up(y.wait);
       } else {
         if (ctile > 0) {
           __hip_atomic_store(words + ctile, ((excl + block_total) << 2) | 2u, __ATOMIC_RELAXED,
@@ -751,7 +757,9 @@ __global__ __launch_bounds__(kBlock) void unique_order_kernel(const UArgs a, con
 }
 
 // ---- 8: index[i] = place of the first occurrence of in[i] --------------------------------------
-__global__ __launch_bounds__(kBlock) void unique_index_kernel(const UArgs a) {
+__global__ __launch_bounds__(kBlock) void unique_index_kernel(const UArgs a,
+                                                               const int32_t* poison) {
+  if (poisoned(poison)) return;
   HBK_FIND_UCOL(tile_start)
   const int64_t base = (int64_t)((int)blockIdx.x - c.tile_start) * kTile;
 #pragma unroll
@@ -812,10 +820,9 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
               "unique_n: workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
   HBK_REQUIRE(((uintptr_t)workspace & 7) == 0, "unique_n: workspace must be 8-byte aligned");
   char* wp = reinterpret_cast<char*>(workspace);
-  if (sync_raised()) {
-    return fail(HBK_INTERNAL, "unique_n: an earlier one-pass launch gave up waiting for the tiles "
-                              "of its column (its outputs are not valid); set options "
-                              "partition_onepass / unique_onepass = 0");
+  {
+    const int rc = sync_check("unique_n");
+    if (rc != HBK_OK) return rc;
   }
   // four launches when every column fits the group kernel (see there)
   bool onepass = options().unique_onepass != 0 && n_cols <= kMaxCols;
@@ -833,13 +840,14 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
   if (onepass && group_words > 0) {
     SyncTake take;
     onepass = group_words + order_words < (1u << 30) &&
-              sync_take(stream, group_words + order_words, &take);
+              sync_take(stream, group_words + order_words, &take,
+                        reinterpret_cast<const void*>(&unique_group_kernel), kBlock, kGroupMaxTiles);
     if (onepass) {
       sync.hist = take.words;
       sync.order = reinterpret_cast<uint32_t*>(take.words + group_words);
       sync.zero = take.zero;
       sync.zero_words = take.zero_words;
-      sync.status = take.status;
+      sync.wait = sync_wait_of(take);
     }
   }
 
@@ -904,9 +912,11 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
     const dim3 block(kBlock);
     if (onepass) {
       hipLaunchKernelGGL(unique_group_kernel, dim3((unsigned)big), block, 0, stream, args, sync);
-      hipLaunchKernelGGL(unique_first_kernel, dim3((unsigned)buckets), dim3(kFirstBlock), 0, stream, args);
+      hipLaunchKernelGGL(unique_first_kernel, dim3((unsigned)buckets), dim3(kFirstBlock), 0, stream, args,
+                         (const int32_t*)sync.wait.poison);
       hipLaunchKernelGGL(unique_order_kernel, dim3((unsigned)tiles), block, 0, stream, args, sync);
-      hipLaunchKernelGGL(unique_index_kernel, dim3((unsigned)tiles), block, 0, stream, args);
+      hipLaunchKernelGGL(unique_index_kernel, dim3((unsigned)tiles), block, 0, stream, args,
+                         (const int32_t*)sync.wait.poison);
       HBK_HIP_OK(hipGetLastError());
       continue;
     }
@@ -914,11 +924,13 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
     hipLaunchKernelGGL(unique_scan_tiles_kernel, dim3((unsigned)scans), block, 0, stream, args);
     hipLaunchKernelGGL(unique_bucket_scan_kernel, dim3((unsigned)k), block, 0, stream, args);
     hipLaunchKernelGGL(unique_scatter_kernel, dim3((unsigned)big), block, lds, stream, args);
-    hipLaunchKernelGGL(unique_first_kernel, dim3((unsigned)buckets), dim3(kFirstBlock), 0, stream, args);
+    hipLaunchKernelGGL(unique_first_kernel, dim3((unsigned)buckets), dim3(kFirstBlock), 0, stream, args,
+                       (const int32_t*)nullptr);
     hipLaunchKernelGGL(unique_count_kernel, dim3((unsigned)tiles), block, 0, stream, args);
     hipLaunchKernelGGL(unique_scan_kernel, dim3((unsigned)k), block, 0, stream, args);
     hipLaunchKernelGGL(unique_emit_kernel, dim3((unsigned)tiles), block, 0, stream, args);
-    hipLaunchKernelGGL(unique_index_kernel, dim3((unsigned)tiles), block, 0, stream, args);
+    hipLaunchKernelGGL(unique_index_kernel, dim3((unsigned)tiles), block, 0, stream, args,
+                       (const int32_t*)nullptr);
     HBK_HIP_OK(hipGetLastError());
   }
   return HBK_OK;

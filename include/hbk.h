@@ -77,14 +77,24 @@ const char* hbk_version(void);
  * unique_buckets_log2,
  * unique_onepass, partition_sub_tiles, partition_fixed_max, partition_onepass, sharded_groups,
  * sharded_id64, sharded_copy_self, sharded_trace (the sharded_* ones are taken by
- * hbk_sharded_create).
+ * hbk_sharded_create), sync_wait_ms, sync_onepass_off, sync_test_withhold.
  * *_onepass (default 1): small calls of partition / unique / the backward group their ids in ONE
  * launch whose tiles wait for each other; 0 keeps the multi-launch forms.  The
- * waits are bounded: a launch that gave up (never seen) makes the NEXT call of these entries
- * return HBK_INTERNAL.  The words the tiles poll live in buffers the library keeps per (device,
- * stream): calls that share a stream are ordered, which is all these entries ask of the caller. */
+ * waits are bounded (sync_wait_ms, default 2000).  A launch that gave up (never seen outside the
+ * test hook sync_test_withhold) poisons its call: the call's later kernels leave without touching
+ * anything, its outputs are not valid, and the failure is reported ONCE as HBK_INTERNAL -- by the
+ * sharded step in the call that suffered it (it synchronises anyway), else by the next call of
+ * these entries or by hbk_sync_check() -- after which the library takes the multi-launch forms
+ * (sync_onepass_off = 1; writable).  The one-launch forms are also not taken when the device
+ * cannot hold a whole column's workgroups at once (CU masks, partitioned modes).  The words the
+ * tiles poll live in buffers the library keeps per (device, stream): calls that share a stream
+ * are ordered, which is all these entries ask of the caller. */
 int hbk_set_option(const char* name, int32_t value);
 int hbk_get_option(const char* name, int32_t* value);
+/* HBK_OK, or once per timed-out one-launch wait HBK_INTERNAL (see above).  Callers that read
+ * the outputs of hbk_partition_* / hbk_unique_n / hbk_group_lookup_bwd* after their own stream
+ * synchronisation call this behind it to learn of a failed call before using its outputs. */
+int hbk_sync_check(void);
 /* the kernels' divide-free floor-mod / floor-div (multiply-high by a
  * host-computed magic) evaluated on the host, so the integer arithmetic can be checked
  * against Python's % and // without a GPU.  d > 0. */

@@ -1,0 +1,165 @@
+"""The one-launch kernels whose tiles wait for each other (partition, unique, the backward's
+grouping; csrc/sync.hip): a wait that runs out must fail the call it belongs to -- no kernel of
+that call may compute from descriptors that were never written -- be reported ONCE, and leave the
+library working on its multi-launch forms; and the waits must hold while other kernels fill the
+chip from another stream.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import hybridbackend_amd as hb
+from hybridbackend_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+  return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+  return t.detach().cpu().numpy()
+
+
+def _sync_check():
+  return _lib.lib().hbk_sync_check()
+
+
+def _run(which, rng):
+  """One call of the op on fresh inputs; returns a checker to run after synchronising."""
+  if which == 'partition':
+    ids = [rng.randint(-2**40, 2**40, size=n).astype(np.int64) for n in (5000, 70000, 1234)]
+    res = hb.distribute.partition_by_modulo_n([dev(i) for i in ids], 8)
+
+    def check():
+      for i, (o, s, x) in zip(ids, res):
+        wo, ws, wx = oracle.partition_by_modulo(i, 8)
+        np.testing.assert_equal(host(o), wo)
+        np.testing.assert_equal(host(s), ws)
+        np.testing.assert_equal(host(x), wx)
+    return check
+  if which == 'unique':
+    ids = [rng.randint(0, 3000, size=n).astype(np.int64) for n in (40000, 9000)]
+    res = hb.embedding.unique_n([dev(i) for i in ids])
+
+    def check():
+      for i, (u, inv, nu) in zip(ids, res):
+        wu, winv = oracle.unique(i)
+        assert int(nu.item()) == wu.size
+        np.testing.assert_equal(host(u)[:wu.size], wu)
+        np.testing.assert_equal(host(inv), winv)
+    return check
+  rows, d, n = 5000, 16, 30000
+  table = dev(rng.uniform(-1, 1, size=(rows, d)).astype(np.float32))
+  ids = rng.randint(0, rows, size=n).astype(np.int64)
+  grads = rng.randn(n, d).astype(np.float32)
+  lookup = hb.embedding.GroupLookup([table], None, 'sum')
+  res = hb.embedding.GroupLookupGrad(lookup)([dev(ids)], [dev(grads)])[0]
+
+  def check():
+    k = int(res[2].item())
+    assert k == np.unique(ids).size
+    want = np.zeros((rows, d), np.float64)
+    np.add.at(want, ids, grads.astype(np.float64))
+    got = np.zeros_like(want)
+    got[host(res[0])[:k]] = host(res[1])[:k]
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-4)
+  return check
+
+
+@pytest.mark.parametrize('which', ['partition', 'unique', 'bwd'])
+def test_timed_out_wait_fails_its_call_once_and_falls_back(hbk_option, which):
+  """Hook: tile 0 never publishes its counts, so every tile of its column gives up after
+  sync_wait_ms.  The call is poisoned (its later kernels leave at once: no crash, no stray
+  writes), hbk_sync_check() reports the failure exactly once, the one-launch forms are switched
+  off, and the next call -- multi-launch -- is right."""
+  rng = np.random.RandomState(5)
+  assert _sync_check() == 0
+  hbk_option('sync_onepass_off', 0)
+  _run(which, rng)()                      # the one-launch form works
+  torch.cuda.synchronize()
+  hbk_option('sync_wait_ms', 20)
+  hbk_option('sync_test_withhold', 0)
+  _run(which, rng)                        # returns OK: the launches are asynchronous
+  torch.cuda.synchronize()
+  assert _sync_check() == _lib.INTERNAL
+  assert 'gave up waiting' in _lib.lib().hbk_last_error().decode()
+  assert _sync_check() == 0               # reported once
+  assert _lib.get_option('sync_onepass_off') == 1
+  hbk_option('sync_test_withhold', -1)
+  check = _run(which, rng)                # multi-launch forms from now on
+  torch.cuda.synchronize()
+  check()
+  assert _sync_check() == 0
+
+
+def test_failure_surfaces_at_the_next_entry_call(hbk_option):
+  rng = np.random.RandomState(6)
+  hbk_option('sync_onepass_off', 0)
+  hbk_option('sync_wait_ms', 20)
+  hbk_option('sync_test_withhold', 0)
+  _run('partition', rng)
+  torch.cuda.synchronize()
+  hbk_option('sync_test_withhold', -1)
+  with pytest.raises(_lib.HbkError, match='gave up waiting'):
+    _run('unique', rng)
+  check = _run('unique', rng)             # the call after the report goes through
+  torch.cuda.synchronize()
+  check()
+
+
+def test_one_launch_forms_beside_a_chip_filling_stream(hbk_option):
+  """The waits rest on a column's tiles becoming resident while earlier ones spin.  Here the
+  chip is kept full from another stream (large GEMMs: long-lived workgroups on every CU, and a
+  stream of short bandwidth-bound kernels) while partition / unique / backward run their
+  one-launch forms: results stay right and no wait runs out."""
+  hbk_option('sync_onepass_off', 0)
+  rng = np.random.RandomState(7)
+  side = torch.cuda.Stream()
+  a = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+  b = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+  x = torch.zeros(1 << 27, device=DEV)
+  checks = []
+  for rep in range(6):
+    with torch.cuda.stream(side):
+      for _ in range(4):
+        a @ b
+        x.add_(1.0)
+    for which in ('partition', 'unique', 'bwd'):
+      checks.append(_run(which, rng))
+  torch.cuda.synchronize()
+  assert _sync_check() == 0
+  assert _lib.get_option('sync_onepass_off') == 0
+  for check in checks:
+    check()
+
+
+def test_sharded_step_fails_in_the_call_that_suffered_the_timeout(hbk_option):
+  """The sharded forward synchronises once (sizes to the host): a partition that gave up is
+  reported by THAT step, before any exchange is sized from its output; the next step works."""
+  from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
+  hbk_option('sync_onepass_off', 0)
+  rng = np.random.RandomState(8)
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+  try:
+    tables = [rng.uniform(-1, 1, size=(5000, 16)).astype(np.float32) for _ in range(3)]
+    ids = [rng.randint(0, 2**40, size=4000).astype(np.int64) for _ in range(3)]
+    drv = ShardedGroupLookup([dev(t) for t in tables], coll, buckets=[5000] * 3)
+    drv([dev(i) for i in ids])
+    torch.cuda.synchronize()
+    hbk_option('sync_wait_ms', 20)
+    hbk_option('sync_test_withhold', 0)
+    with pytest.raises(_lib.HbkError, match='gave up waiting'):
+      drv([dev(i) for i in ids])
+    hbk_option('sync_test_withhold', -1)
+    outs = drv([dev(i) for i in ids])
+    torch.cuda.synchronize()
+    want = oracle.group_lookup_fwd(tables, ids, [None] * 3, [5000] * 3, ['sum'] * 3)
+    for o, w in zip(outs, want):
+      np.testing.assert_equal(host(o), w)
+    assert _sync_check() == 0
+  finally:
+    coll.close()

@@ -56,6 +56,8 @@ for k,v in sorted(d.items()):
   print(k[:70].ljust(70), {c:round(x['mean']) for c,x in v.items()})
 PY
       done;;
+    synctest)
+      timeout 900 python -m pytest tests/test_gpu_sync.py -q -m gpu --durations=5 > $O/synctest.log 2>&1; echo "pytest rc=$?" >> $O/synctest.log; tail -30 $O/synctest.log;;
     hottest)
       timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "hot_row or group_lookup" --durations=5 > $O/hottest.log 2>&1; echo "pytest rc=$?" >> $O/hottest.log; tail -15 $O/hottest.log;;
     hotsweep)

@@ -791,6 +791,28 @@ __device__ inline V load_grad(const GCol& c, const ReduceJob& job, int32_t seg, 
   return g;
 }
 
+// The same in two steps: the gradient chunk and -- ragged columns with mean / sqrtn -- the length
+// of its segment are REQUESTED here; the division waits (scale_grad) until the caller has issued
+// all its loads.  (load_grad divides at once: a wait for memory between any two loads of a round.)
+template <typename V>
+__device__ inline V load_grad_raw(const GCol& c, const ReduceJob& job, int32_t seg, int sub,
+                                  int32_t* n) {
+  constexpr int VE = sizeof(V) / 4;
+  const int64_t off = job.seg_is_offset ? (int64_t)(uint32_t)seg : (int64_t)seg * job.stride;
+  const V g = __builtin_nontemporal_load(
+      reinterpret_cast<const V*>(job.grad + off + (int64_t)sub * VE));
+  *n = 0;
+  if (job.scale && c.combiner != HBK_COMBINER_SUM && c.splits != nullptr) {
+    *n = c.splits[seg + 1] - c.splits[seg];
+  }
+  return g;
+}
+template <typename V>
+__device__ inline V scale_grad(const GCol& c, V g, int32_t n) {
+  if (n == 0) return g;
+  return c.combiner == HBK_COMBINER_MEAN ? g / (float)n : g / sqrtf((float)n);
+}
+
 // The sparse optimizer step of one row chunk (this workgroup owns the row):
 //   SGD      var -= lr * g                                        (GradientDescentOptimizer)
 //   Adagrad  accum += g * g;  var -= lr * g * (1 / sqrt(accum))   (AdagradOptimizer's sparse apply,
@@ -1484,6 +1506,16 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
 #ifndef HBK_BWD_DENSE_WALK
 #define HBK_BWD_DENSE_WALK(STEP) ((STEP) == 2 ? 2 : (STEP) ? 3 : 4)
 #endif
+// probe switches (tools/scratch/bwd_dense_variants.sh builds the library with them turned off)
+#ifndef HBK_DENSE_FOLD
+#define HBK_DENSE_FOLD 0          // few dup pairs ride with the single rows' loads
+#endif
+#ifndef HBK_DENSE_EARLY_CLAIM
+#define HBK_DENSE_EARLY_CLAIM 0   // output range claimed before the scan (rows = pairs - repeats)
+#endif
+#ifndef HBK_DENSE_SORT
+#define HBK_DENSE_SORT 1          // many dup pairs: sorted flat walk instead of LDS float atomics
+#endif
 constexpr int kDenseSpan = 16384;                 // rows of a bucket's range (bits per bitmap)
 constexpr int kDenseWords = kDenseSpan / 32;
 constexpr int kDenseWPT = kDenseWords / kBlock;   // bitmap words per thread in the scan
@@ -1516,6 +1548,183 @@ struct DenseLds {
 // first row of bucket b of a dense column: the smallest r with mulhi(r, M) >= b
 __device__ inline uint64_t dense_first_row(uint32_t M, int b) {
   return (((uint64_t)(uint32_t)b << 32) + M - 1) / M;
+}
+
+// D of dense_reduce for MANY dup pairs: the chunk's list of them is sorted by row (dlist / drun)
+// and walked flat, sums in registers (see there).  The call sits in a branch marked unlikely: the
+// mere presence of this code made the common path -- which never enters it -- 9 us slower on the
+// config-2 backward (probe builds: allocation / scheduling of the surrounding code); out of line
+// (noinline) was worse still: the call's register convention spilled 40 registers in the hot loop.
+struct WalkArgs {
+  const float* grad;
+  const int32_t* splits;
+  float* out_vals;
+  float* table;
+  float* accum;
+  int32_t stride, dim, chunks, n_dl, d0, base_u;
+  uint32_t base;
+  float lr;
+  uint8_t lpr_log2, combiner, seg_is_offset, scale, one_chunk, no_emit;
+};
+
+template <typename V, int STEP>
+__device__ inline void dense_walk(const WalkArgs w_, DenseLds& L) {
+  constexpr int VE = sizeof(V) / 4;
+  constexpr bool adagrad = STEP == 2;
+  // the fields the helpers below read (the rest of the structs is never touched)
+  GCol c;
+  c.splits = w_.splits;
+  c.table = w_.table;
+  c.accum = w_.accum;
+  c.dim = w_.dim;
+  c.chunks = w_.chunks;
+  c.lpr_log2 = w_.lpr_log2;
+  c.combiner = w_.combiner;
+  ReduceJob job;
+  job.grad = w_.grad;
+  job.stride = w_.stride;
+  job.seg_is_offset = w_.seg_is_offset != 0;
+  job.scale = w_.scale != 0;
+  job.out_vals = w_.out_vals;
+  job.no_emit = w_.no_emit != 0;
+  const int n_dl = w_.n_dl, d0 = w_.d0;
+  const uint32_t base = w_.base;
+  const int32_t base_u = w_.base_u;
+  const float lr = w_.lr;
+  const bool one_chunk = w_.one_chunk != 0;
+  const int tid = (int)threadIdx.x;
+  const int lpr_log2 = c.lpr_log2;
+  const int sub = tid & ((1 << lpr_log2) - 1);
+  const bool live = sub < c.chunks;
+  const int groups = kBlock >> lpr_log2;
+  const int my_group = tid >> lpr_log2;
+  const bool emit = !(STEP && job.no_emit);
+  {
+  constexpr int kW = HBK_BWD_DENSE_WALK(STEP);   // (register budget: 96 VGPRs = 5 workgroups per CU)
+  const int per_round = groups * kW;
+  int cpar = 0;
+  for (int r0 = 0; r0 < n_dl; r0 += per_round, cpar ^= 1) {
+    const int q0 = r0 + my_group * kW;   // my first position
+    V g[kW];
+    int sl[kW];                           // dup row of every position, -1 beyond the end
+    int32_t n_[kW];
+#pragma unroll
+    for (int w = 0; w < kW; ++w) {
+      const int q = q0 + w;
+      sl[w] = -1;
+      n_[w] = 0;
+      g[w] = zero_v<V>();
+      if (q < n_dl) {
+        const int e = (int)L.dlist[q];
+        sl[w] = (L.code[e] & (kDupBit - 1)) - d0;
+        if (live) g[w] = load_grad_raw<V>(c, job, L.seg[e], sub, &n_[w]);
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < kW; ++w) g[w] = scale_grad<V>(c, g[w], n_[w]);
+    {
+      V head = zero_v<V>();
+      bool in_head = sl[0] >= 0;
+#pragma unroll
+      for (int w = 0; w < kW; ++w) {
+        in_head = in_head && sl[w] == sl[0];
+        if (in_head) head = head + g[w];
+      }
+      *reinterpret_cast<V*>(&L.heads[(size_t)tid * VE]) = head;
+    }
+    __syncthreads();
+    const int round_end = r0 + per_round;
+    V acc = zero_v<V>();
+    int cur = -1;
+    bool owned = false;
+    uint32_t fin = 0;   // bit w: a run I own ends at my position w, complete: its sum is in g[w]
+#pragma unroll
+    for (int w = 0; w <= kW; ++w) {
+      const int sw = w < kW ? sl[w] : -1;
+      if (sw != cur) {
+        if (w > 0 && cur >= 0 && owned) {
+          const uint32_t rn = L.drun[cur];
+          const int s_beg = (int)(rn & 0xffffu), s_end = (int)(rn >> 16);
+          V total = acc;
+          if (w == kW) {
+            // it reached the end of my range: the heads of the groups it goes on in
+            const int lim = s_end < round_end ? s_end : round_end;
+            for (int q = q0 + kW; q < lim; q += kW) {
+              const int gp = (q - r0) / kW;
+              total = total + *reinterpret_cast<const V*>(
+                                  &L.heads[(((size_t)gp << lpr_log2) + sub) * VE]);
+            }
+          }
+          if (s_beg < r0) {   // it began in an earlier round (only the round's first run can)
+            total = total + *reinterpret_cast<const V*>(&L.carry[cpar ^ 1][(size_t)sub * VE]);
+          }
+          if (s_end > round_end) {
+            *reinterpret_cast<V*>(&L.carry[cpar][(size_t)sub * VE]) = total;   // goes on
+          } else {
+            g[w > 0 ? w - 1 : 0] = total;
+            fin |= 1u << (w > 0 ? w - 1 : 0);
+          }
+        }
+        cur = sw;
+        acc = zero_v<V>();
+        // a run that starts inside my range is mine; the one at my first position is mine
+        // when the row starts there or when I am the round's first group (it is carried in)
+        owned = w > 0 || my_group == 0 || (sw >= 0 && (int)(L.drun[sw] & 0xffffu) >= q0);
+      }
+      if (w < kW && sw >= 0) acc = acc + g[w];
+    }
+    if (!one_chunk) {
+      // a job of several chunks: the row's pairs in the other chunks are still to come (or
+      // already there): the chunk's sum joins the row's LDS sum; one owner per row and chunk
+#pragma unroll
+      for (int w = 0; w < kW; ++w) {
+        if ((fin >> w & 1u) && live) {
+          V* r = reinterpret_cast<V*>(&L.red[(size_t)sl[w] * c.dim + (size_t)sub * VE]);
+          *r = *r + g[w];
+        }
+      }
+    } else {
+      // the row is complete: it leaves from the registers its sum sits in, with the
+      // optimizer step (table / accumulator rows requested for all finished rows first)
+      int32_t u_[kW];
+      uint32_t off_[kW];
+      V tv[STEP ? kW : 1], av[STEP == 2 ? kW : 1];
+#pragma unroll
+      for (int w = 0; w < kW; ++w) {
+        u_[w] = 0;
+        off_[w] = 0;
+        if ((fin >> w & 1u) && live) {
+          const uint32_t off = L.doff[sl[w]];
+          const int ww = (int)(off >> 5);
+          off_[w] = off;
+          u_[w] = base_u + (int32_t)(L.pre[ww] & 0xffffu) +
+                  __builtin_popcount(L.present[ww] & ((1u << (off & 31u)) - 1u));
+          if (STEP && lr != 0.0f) {
+            const int64_t toff = (int64_t)(base + off) * c.dim + (int64_t)sub * VE;
+            tv[STEP ? w : 0] =
+                __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+            if (STEP == 2) {
+              av[STEP == 2 ? w : 0] =
+                  __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < kW; ++w) {
+        if ((fin >> w & 1u) && live) {
+          if (emit) emit_row<V>(c, job, u_[w], true, sub, g[w]);
+          if (STEP && lr != 0.0f) {
+            const int64_t toff = (int64_t)(base + off_[w]) * c.dim + (int64_t)sub * VE;
+            step_row<V>(c, adagrad, lr, toff, g[w], tv[STEP ? w : 0],
+                        STEP == 2 ? av[STEP == 2 ? w : 0] : zero_v<V>());
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  }
 }
 
 template <typename V, int STEP>
@@ -1604,7 +1813,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
   // and its round trip runs beside the scan of B and the gradient loads of C.  Step only: just
   // the count is wanted, nobody waits for it.
   int32_t claimed = 0;
-  if (tid == kBlock - 1) {
+  if (HBK_DENSE_EARLY_CLAIM && tid == kBlock - 1) {
     const int32_t n_rows = n_pairs - L.n_again;
     if (!emit) {
       __hip_atomic_fetch_add(job.out_counter, n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1642,7 +1851,17 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
       if (w < words) L.pre[w] = run;
       run += cnt[q];
     }
-    if (tid == kBlock - 1) L.n_dup = (int32_t)(run >> 16);
+    if (tid == kBlock - 1) {
+      L.n_dup = (int32_t)(run >> 16);
+      if (!HBK_DENSE_EARLY_CLAIM) {
+        const int32_t n_rows = (int32_t)(run & 0xffffu);
+        if (!emit) {
+          __hip_atomic_fetch_add(job.out_counter, n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          claimed = atomicAdd(job.out_counter, n_rows);
+        }
+      }
+    }
   }
   __syncthreads();
   HBK_STAMP(4);
@@ -1715,8 +1934,8 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
       // tickets taken above) and walked in D; the tickets leave the registers before C needs them
       const int n_dl = L.n_dlist[par];
       const int nd = d1 - d0;
-      const bool sorted = n_dl > kSortMin;   // uniform
-      if (sorted) {
+      const bool sorted = HBK_DENSE_SORT && n_dl > kSortMin;   // uniform
+      if (__builtin_expect(sorted, 0)) {
         {
           int32_t cn[PT], sum = 0;
 #pragma unroll
@@ -1759,20 +1978,23 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
       // are few (not sorted), their gradient rows travel in the same round and go into the rows'
       // LDS sums (ds_add_f32) when they arrive.
       if (round == 0) {
-        const bool fold = !sorted && n_dl > 0;   // uniform
+        const bool fold = HBK_DENSE_FOLD && !sorted && n_dl > 0;   // uniform
         used_red = used_red || fold;
+        HBK_SUBSTAMP(0);
         for (int e0 = 0; e0 < n_chunk; e0 += kDepth * groups) {
           V g[kDepth], tv[STEP ? kDepth : 1], av[STEP == 2 ? kDepth : 1];
+          int32_t n_[kDepth];
           uint32_t mask = 0, dmask = 0;
 #pragma unroll
           for (int k = 0; k < kDepth; ++k) {
             const int i = e0 + k * groups + my_group;
             g[k] = zero_v<V>();
+            n_[k] = 0;
             if (i < n_chunk && live) {
               const int32_t code = L.code[i];
               if ((code & kDupBit) == 0) {
                 mask |= 1u << k;
-                g[k] = load_grad<V>(c, job, L.seg[i], sub);
+                g[k] = load_grad_raw<V>(c, job, L.seg[i], sub, &n_[k]);
                 if (STEP && lr != 0.0f) {
                   const int64_t toff = (int64_t)(base + L.off[i]) * c.dim + (int64_t)sub * VE;
                   tv[STEP ? k : 0] =
@@ -1784,20 +2006,27 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
                 }
               } else if (fold && (code & (kDupBit - 1)) < d1) {   // (round 0: d0 = 0)
                 dmask |= 1u << k;
-                g[k] = load_grad<V>(c, job, L.seg[i], sub);
+                g[k] = load_grad_raw<V>(c, job, L.seg[i], sub, &n_[k]);
               }
             }
           }
+          HBK_SUBSTAMP(1);
           if (!have_base) {   // uniform
             if (tid == kBlock - 1) L.base_u = job.out_base + claimed;
             __syncthreads();
             base_u = L.base_u;
             have_base = true;
           }
+          HBK_SUBSTAMP(2);
+#ifdef HBK_BWD_STAMPS
+          __builtin_amdgcn_s_waitcnt(0x0f70);   // (probe) the gradient rows are here
+          HBK_SUBSTAMP(3);
+#endif
 #pragma unroll
           for (int k = 0; k < kDepth; ++k) {
             if (((mask | dmask) >> k & 1u) == 0) continue;
             const int i = e0 + k * groups + my_group;
+            g[k] = scale_grad<V>(c, g[k], n_[k]);
             if (dmask >> k & 1u) {
               float* r = &L.red[(size_t)(L.code[i] & (kDupBit - 1)) * c.dim + (size_t)sub * VE];
 #pragma unroll
@@ -1815,134 +2044,35 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
       }
 
       // D: this round's dup pairs.
-      if (sorted) {
+      if (__builtin_expect(sorted, 0)) {
         // Many: LDS float atomics are slow (~3 clocks per lane and add on a CU, measured: with 3
         // pairs per row the whole backward took twice as long as with hashed buckets), so the
         // pairs are counting-sorted by row (the tickets taken above) and the sorted list is walked
         // FLAT, sums in registers: per round a lane group takes kDepth consecutive positions, all
         // gradient rows in flight at once; the group where a run starts owns it and adds what its
         // successors hold of it (heads, LDS); a run that goes on past the round's end is carried.
-        constexpr int kW = HBK_BWD_DENSE_WALK(STEP);   // (register budget: 96 VGPRs = 5 workgroups per CU)
-        const int per_round = groups * kW;
-        int cpar = 0;
-        for (int r0 = 0; r0 < n_dl; r0 += per_round, cpar ^= 1) {
-          const int q0 = r0 + my_group * kW;   // my first position
-          V g[kW];
-          int sl[kW];                           // dup row of every position, -1 beyond the end
-#pragma unroll
-          for (int w = 0; w < kW; ++w) {
-            const int q = q0 + w;
-            sl[w] = -1;
-            g[w] = zero_v<V>();
-            if (q < n_dl) {
-              const int e = (int)L.dlist[q];
-              sl[w] = (L.code[e] & (kDupBit - 1)) - d0;
-              if (live) g[w] = load_grad<V>(c, job, L.seg[e], sub);
-            }
-          }
-          {
-            V head = zero_v<V>();
-            bool in_head = sl[0] >= 0;
-#pragma unroll
-            for (int w = 0; w < kW; ++w) {
-              in_head = in_head && sl[w] == sl[0];
-              if (in_head) head = head + g[w];
-            }
-            *reinterpret_cast<V*>(&L.heads[(size_t)tid * VE]) = head;
-          }
-          __syncthreads();
-          const int round_end = r0 + per_round;
-          V acc = zero_v<V>();
-          int cur = -1;
-          bool owned = false;
-          uint32_t fin = 0;   // bit w: a run I own ends at my position w, complete: its sum is in g[w]
-#pragma unroll
-          for (int w = 0; w <= kW; ++w) {
-            const int sw = w < kW ? sl[w] : -1;
-            if (sw != cur) {
-              if (w > 0 && cur >= 0 && owned) {
-                const uint32_t rn = L.drun[cur];
-                const int s_beg = (int)(rn & 0xffffu), s_end = (int)(rn >> 16);
-                V total = acc;
-                if (w == kW) {
-                  // it reached the end of my range: the heads of the groups it goes on in
-                  const int lim = s_end < round_end ? s_end : round_end;
-                  for (int q = q0 + kW; q < lim; q += kW) {
-                    const int gp = (q - r0) / kW;
-                    total = total + *reinterpret_cast<const V*>(
-                                        &L.heads[(((size_t)gp << lpr_log2) + sub) * VE]);
-                  }
-                }
-                if (s_beg < r0) {   // it began in an earlier round (only the round's first run can)
-                  total = total + *reinterpret_cast<const V*>(&L.carry[cpar ^ 1][(size_t)sub * VE]);
-                }
-                if (s_end > round_end) {
-                  *reinterpret_cast<V*>(&L.carry[cpar][(size_t)sub * VE]) = total;   // goes on
-                } else {
-                  g[w > 0 ? w - 1 : 0] = total;
-                  fin |= 1u << (w > 0 ? w - 1 : 0);
-                }
-              }
-              cur = sw;
-              acc = zero_v<V>();
-              // a run that starts inside my range is mine; the one at my first position is mine
-              // when the row starts there or when I am the round's first group (it is carried in)
-              owned = w > 0 || my_group == 0 || (sw >= 0 && (int)(L.drun[sw] & 0xffffu) >= q0);
-            }
-            if (w < kW && sw >= 0) acc = acc + g[w];
-          }
-          if (!one_chunk) {
-            // a job of several chunks: the row's pairs in the other chunks are still to come (or
-            // already there): the chunk's sum joins the row's LDS sum; one owner per row and chunk
-#pragma unroll
-            for (int w = 0; w < kW; ++w) {
-              if ((fin >> w & 1u) && live) {
-                V* r = reinterpret_cast<V*>(&L.red[(size_t)sl[w] * c.dim + (size_t)sub * VE]);
-                *r = *r + g[w];
-              }
-            }
-          } else {
-            // the row is complete: it leaves from the registers its sum sits in, with the
-            // optimizer step (table / accumulator rows requested for all finished rows first)
-            int32_t u_[kW];
-            uint32_t off_[kW];
-            V tv[STEP ? kW : 1], av[STEP == 2 ? kW : 1];
-#pragma unroll
-            for (int w = 0; w < kW; ++w) {
-              u_[w] = 0;
-              off_[w] = 0;
-              if ((fin >> w & 1u) && live) {
-                const uint32_t off = L.doff[sl[w]];
-                const int ww = (int)(off >> 5);
-                off_[w] = off;
-                u_[w] = base_u + (int32_t)(L.pre[ww] & 0xffffu) +
-                        __builtin_popcount(L.present[ww] & ((1u << (off & 31u)) - 1u));
-                if (STEP && lr != 0.0f) {
-                  const int64_t toff = (int64_t)(base + off) * c.dim + (int64_t)sub * VE;
-                  tv[STEP ? w : 0] =
-                      __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
-                  if (STEP == 2) {
-                    av[STEP == 2 ? w : 0] =
-                        __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
-                  }
-                }
-              }
-            }
-#pragma unroll
-            for (int w = 0; w < kW; ++w) {
-              if ((fin >> w & 1u) && live) {
-                if (emit) emit_row<V>(c, job, u_[w], true, sub, g[w]);
-                if (STEP && lr != 0.0f) {
-                  const int64_t toff = (int64_t)(base + off_[w]) * c.dim + (int64_t)sub * VE;
-                  step_row<V>(c, adagrad, lr, toff, g[w], tv[STEP ? w : 0],
-                              STEP == 2 ? av[STEP == 2 ? w : 0] : zero_v<V>());
-                }
-              }
-            }
-          }
-          __syncthreads();
-        }
-      } else if (round > 0) {
+        WalkArgs wa;
+        wa.grad = job.grad;
+        wa.splits = c.splits;
+        wa.out_vals = job.out_vals;
+        wa.table = c.table;
+        wa.accum = c.accum;
+        wa.stride = job.stride;
+        wa.dim = c.dim;
+        wa.chunks = c.chunks;
+        wa.n_dl = n_dl;
+        wa.d0 = d0;
+        wa.base_u = base_u;
+        wa.base = base;
+        wa.lr = lr;
+        wa.lpr_log2 = c.lpr_log2;
+        wa.combiner = c.combiner;
+        wa.seg_is_offset = job.seg_is_offset;
+        wa.scale = job.scale;
+        wa.one_chunk = one_chunk;
+        wa.no_emit = job.no_emit;
+        dense_walk<V, STEP>(wa, L);
+      } else if (round > 0 || !HBK_DENSE_FOLD) {
         // Few, and not the first round (wide rows: only 2048 / dim sums fit LDS at a time; the
         // first round's pairs went with C): summed into the rows' LDS sums by ds_add_f32; what a
         // lane group holds for one row in consecutive registers is added up first.
@@ -1950,17 +2080,21 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
         for (int i0 = 0; i0 < n_dl; i0 += kDepth * groups) {
           V g[kDepth];
           int dr[kDepth];
+          int32_t n_[kDepth];
 #pragma unroll
           for (int k = 0; k < kDepth; ++k) {
             const int i = i0 + k * groups + my_group;
             dr[k] = -1;
+            n_[k] = 0;
             g[k] = zero_v<V>();
             if (i < n_dl && live) {
               const int e = (int)L.dlist[i];
               dr[k] = (L.code[e] & (kDupBit - 1)) - d0;
-              g[k] = load_grad<V>(c, job, L.seg[e], sub);
+              g[k] = load_grad_raw<V>(c, job, L.seg[e], sub, &n_[k]);
             }
           }
+#pragma unroll
+          for (int k = 0; k < kDepth; ++k) g[k] = scale_grad<V>(c, g[k], n_[k]);
 #pragma unroll
           for (int k = 1; k < kDepth; ++k) {
             if (dr[k] >= 0 && dr[k] == dr[k - 1]) {

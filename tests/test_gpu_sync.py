@@ -32,10 +32,10 @@ def _run(which, rng):
   """One call of the op on fresh inputs; returns a checker to run after synchronising."""
   if which == 'partition':
     ids = [rng.randint(-2**40, 2**40, size=n).astype(np.int64) for n in (5000, 70000, 1234)]
-    res = hb.distribute.partition_by_modulo_n([dev(i) for i in ids], 8)
+    outs, sizes, indices = hb.distribute.partition_by_modulo_n([dev(i) for i in ids], 8)
 
     def check():
-      for i, (o, s, x) in zip(ids, res):
+      for i, o, s, x in zip(ids, outs, sizes, indices):
         wo, ws, wx = oracle.partition_by_modulo(i, 8)
         np.testing.assert_equal(host(o), wo)
         np.testing.assert_equal(host(s), ws)

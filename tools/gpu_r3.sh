@@ -56,6 +56,26 @@ for k,v in sorted(d.items()):
   print(k[:70].ljust(70), {c:round(x['mean']) for c,x in v.items()})
 PY
       done;;
+    variants)   # probe builds of the dense backward (tools/scratch/bwd_dense_variants.sh)
+      for v in tools/bin/v_*; do
+        for w in ${VARIANT_CASES:-b s}; do
+          LD_LIBRARY_PATH=$R/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk " | sed "s|^|$(basename $v)  |"
+        done
+      done > $O/variants.log 2>&1; cut -c1-400 $O/variants.log;;
+    pmcvariants)   # SQ counters of the probe builds
+      for v in tools/bin/v_*; do
+        n=$(basename $v)
+        LD_LIBRARY_PATH=$R/$v prof pmc_${n}_1 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" -- $R/tools/bin/bench_ops b
+        LD_LIBRARY_PATH=$R/$v prof pmc_${n}_2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_IFETCH SQ_INST_CYCLES_VMEM" -- $R/tools/bin/bench_ops b
+        LD_LIBRARY_PATH=$R/$v prof pmc_${n}_3 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_WAVE32_LDS SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS" -- $R/tools/bin/bench_ops b
+        for k in 1 2 3; do f=pmc_${n}_$k; echo "== $f"; tail -1 $O/$f.log; python - $O/$f.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k,v in sorted(d.items()):
+  if 'dense_kernel' in k or 'reduce_kernel' in k: print(k[:60].ljust(60), {c:round(x['mean']) for c,x in v.items()})
+PY
+        done
+      done;;
     synctest)
       timeout 900 python -m pytest tests/test_gpu_sync.py -q -m gpu --durations=5 > $O/synctest.log 2>&1; echo "pytest rc=$?" >> $O/synctest.log; tail -30 $O/synctest.log;;
     hottest)

@@ -38,7 +38,8 @@ class LookupColumn(C.Structure):
               ('bucket', C.c_int64), ('divisor', C.c_int32),
               ('combiner', C.c_int32), ('out', C.c_void_p),
               ('run_start', C.c_void_p), ('run_base', C.c_void_p),
-              ('n_runs', C.c_int32), ('out_stride', C.c_int32)]
+              ('n_runs', C.c_int32), ('out_stride', C.c_int32),
+              ('hot_rows', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class LookupGradColumn(C.Structure):

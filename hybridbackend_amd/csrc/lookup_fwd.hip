@@ -219,22 +219,24 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupAr
 // ---------------------------------------------------------------------------------
 // LDS-staged hot rows (config 4: dim 128, Zipf ids; north_star's "LDS-staged hot rows", the
 // reference's analogue is the slab cache in front of the table, hbtf/embedding/
-// lookup_functors.cu.cc:54-149).  One id per segment, wide rows (dim >= 64, 16-byte chunks).  A
-// workgroup owns a tile of 256 segments: (1) the tile's rows enter an LDS hash table (64-bit CAS)
-// with a count per row; (2) rows that occur more than once get one of S = min(64, 4096 / dim)
-// staging slots; (3) every staged row is fetched ONCE into LDS; (4) a segment whose row is staged
-// is served from LDS, the others gather from the table as before.  With Zipf(1.2) ids about half
-// of a tile's segments name one of its ~13 repeated rows: half of the L2 -> L1 row reads go away;
-// what stays are the stores.
+// lookup_functors.cu.cc:54-149).  One id per segment, wide rows (dim >= 64, 16-byte chunks), tables
+// of < 2^32 rows.  A workgroup owns a tile of 256 segments: (1) the tile's rows enter an LDS hash
+// table (32-bit CAS) with a count per row; (2) rows that occur more than once get one of S =
+// min(64, 3072 / dim) staging slots; (3) every staged row is fetched ONCE into LDS; (4) a segment
+// whose row is staged is served from LDS, the others gather from the table as before.  With
+// Zipf(1.2) ids about half of a tile's segments name one of its ~13 repeated rows: half of the
+// L1 row reads go away; what stays are the stores.  24.6 KB of LDS = 6 workgroups per CU on
+// purpose: with 17 KB (8 per CU) the same kernel measured 248 us instead of 215 on config 4 --
+// the store stream likes fewer, longer writers (the plain store probe says the same: 151 us from
+// 8192 workgroups, 183 us from 2048 x 4).
 constexpr int kHotTile = 256;          // segments per workgroup
-constexpr int kHotSlots = 512;         // LDS hash slots (a tile holds <= 256 distinct rows)
+constexpr int kHotSlots = 1024;        // LDS hash slots (a tile holds <= 256 distinct rows)
 constexpr int kHotStageFloats = 4096;  // 16 KB of staged rows
 constexpr int kHotMaxStage = 64;
 constexpr int kHotU = 4;               // row loads in flight per lane
-constexpr unsigned long long kHotEmpty = ~0ull;   // (= kNoRow: never inserted)
+constexpr uint32_t kHotEmpty = 0xffffffffu;   // (rows are < 2^32 - 1: host check)
 
-__device__ inline uint32_t hot_mix(uint64_t row) {
-  uint32_t k = (uint32_t)row ^ ((uint32_t)(row >> 32) * 0x9e3779b1u);
+__device__ inline uint32_t hot_mix(uint32_t k) {
   k ^= k >> 16;
   k *= 0x85ebca6bu;
   k ^= k >> 13;
@@ -243,9 +245,8 @@ __device__ inline uint32_t hot_mix(uint64_t row) {
 
 __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const LookupArgs a) {
   typedef f32x4 V;
-  __shared__ unsigned long long keys[kHotSlots];
-  __shared__ int32_t cnt[kHotSlots];
-  __shared__ int16_t stage_of[kHotSlots];
+  __shared__ uint32_t keys[kHotSlots];
+  __shared__ int32_t cnt[kHotSlots];       // pairs of the slot's row; then its staging slot or -1
   __shared__ uint16_t slot_of[kHotTile];
   __shared__ uint16_t stage_slot[kHotMaxStage];
   __shared__ float stage[kHotStageFloats];
@@ -279,13 +280,14 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const Look
   // (1) rows -> slots, one count per row
   int slot = 0xffff;
   if (row != kNoRow) {
-    int h = (int)(hot_mix(row) & (kHotSlots - 1));
+    const uint32_t r32 = (uint32_t)row;
+    int h = (int)(hot_mix(r32) & (kHotSlots - 1));
     for (;;) {
-      const unsigned long long k = keys[h];
-      if (k == row) break;
+      const uint32_t k = keys[h];
+      if (k == r32) break;
       if (k == kHotEmpty) {
-        const unsigned long long prev = atomicCAS(&keys[h], kHotEmpty, (unsigned long long)row);
-        if (prev == kHotEmpty || prev == row) break;
+        const uint32_t prev = atomicCAS(&keys[h], kHotEmpty, r32);
+        if (prev == kHotEmpty || prev == r32) break;
       }
       h = (h + 1) & (kHotSlots - 1);
     }
@@ -294,7 +296,8 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const Look
   }
   slot_of[tid] = (uint16_t)slot;
   __syncthreads();
-  // (2) repeated rows take the staging slots, first come first served
+  // (2) repeated rows take the staging slots, first come first served; cnt[] becomes the map
+  // hash slot -> staging slot
   const int S = kHotStageFloats / c.dim < kHotMaxStage ? kHotStageFloats / c.dim : kHotMaxStage;
   for (int i = tid; i < kHotSlots; i += kBlock) {
     int st = -1;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const Look
         stage_slot[idx] = (uint16_t)i;
       }
     }
-    stage_of[i] = (int16_t)st;
+    cnt[i] = st;
   }
   __syncthreads();
   const int ns = n_staged < S ? n_staged : S;
@@ -333,49 +336,36 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const Look
     }
   }
   if (ns > 0) __syncthreads();   // uniform
-  // (4) the tile's segments: staged rows from LDS, the others from the table.  Software
-  // pipelined: the rows of batch i + 1 are requested before batch i is stored, so a lane keeps
-  // 2 x kHotU row chunks in flight and loads and stores of one workgroup overlap (without it the
-  // tiles alone were 15 % slower than the per-wave gather on uniform ids).
-  const int step = kHotU * groups;
-  auto fetch = [&](int s0, V* v) {
+  // (4) the tile's segments: staged rows from LDS, the others from the table.  (A software
+  // pipeline -- batch i + 1 requested before batch i is stored -- measured 5 % slower.)
+  for (int s0 = 0; s0 < kHotTile; s0 += kHotU * groups) {
+    if (seg0 + s0 >= n_seg) break;   // uniform
+    V v[kHotU];
 #pragma unroll
     for (int u = 0; u < kHotU; ++u) {
       const int sl = s0 + u * groups + grp;
       v[u] = zero_v<V>();
-      if (sl < kHotTile && seg0 + sl < n_seg && live) {
+      if (seg0 + sl < n_seg && live) {
         const int q = (int)slot_of[sl];
         if (q != 0xffff) {
-          const int st = (int)stage_of[q];
+          const int st = cnt[q];
           if (st >= 0) {
             v[u] = *reinterpret_cast<const V*>(&stage[(size_t)st * c.dim + (size_t)sub * 4]);
           } else {
-            v[u] = *reinterpret_cast<const V*>(c.table + keys[q] * (uint64_t)c.dim + (uint64_t)sub * 4);
+            v[u] = *reinterpret_cast<const V*>(c.table + (uint64_t)keys[q] * (uint64_t)c.dim +
+                                               (uint64_t)sub * 4);
           }
         }
       }
     }
-  };
-  auto put = [&](int s0, const V* v) {
 #pragma unroll
     for (int u = 0; u < kHotU; ++u) {
-      const int sl = s0 + u * groups + grp;
-      const int64_t s = seg0 + sl;
-      if (sl < kHotTile && s < n_seg && live) {
+      const int64_t s = seg0 + s0 + u * groups + grp;
+      if (s < n_seg && live) {
         __builtin_nontemporal_store(
             v[u], reinterpret_cast<V*>(c.out + s * (int64_t)c.out_stride + (int64_t)sub * 4));
       }
     }
-  };
-  int64_t left = n_seg - seg0;
-  const int n_here = left < kHotTile ? (int)left : kHotTile;
-  V va[kHotU], vb[kHotU];
-  fetch(0, va);
-  for (int s0 = 0; s0 < n_here; s0 += 2 * step) {
-    if (s0 + step < n_here) fetch(s0 + step, vb);
-    put(s0, va);
-    if (s0 + 2 * step < n_here) fetch(s0 + 2 * step, va);
-    if (s0 + step < n_here) put(s0 + step, vb);
   }
 }
 
@@ -441,7 +431,7 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
     int32_t c0 = 0;
     while (c0 < n_cols) {
       LookupArgs args;
-      args.hot_mode = hot_mode;
+      args.hot_mode = hot_mode > 0 ? hot_mode : 1;
       int32_t k = 0;
       int64_t tiles = 0;
       args.tile_start[0] = 0;
@@ -462,8 +452,8 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
         int col_kind = (h.row_splits != nullptr ? 1 : 0) | (shape.vec4 ? 0 : 2) |
                        (h.n_runs > 0 ? 4 : 0);
         // one id per segment, plain table, wide 16-byte-chunk rows: the hot-row kernel when asked
-        if (col_kind == 0 && hot_mode > 0 && h.dim >= 64 && h.dim <= 1024 &&
-            shape.lpr_log2 <= 6 && h.dim <= kHotStageFloats) {
+        if (col_kind == 0 && (hot_mode > 0 || h.hot_rows != 0) && h.dim >= 64 && shape.lpr_log2 <= 6 &&
+            h.dim <= kHotStageFloats && h.rows < 0xffffffffll) {
           col_kind = 8;
         }
         if (col_kind != kind) continue;

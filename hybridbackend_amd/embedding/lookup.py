@@ -38,9 +38,13 @@ class GroupLookup:
     combiners: per-column 'sum' | 'mean' | 'sqrtn' | None (= mean), or one for all.
     divisor: ``row = id // divisor`` after bucketize (owner side of a sharded table,
       sharding.py:189); 1 for a whole table.
+    hot_rows: skewed ids expected (Zipf heads): wide one-id-per-sample columns (dim >= 64) fetch
+      every row repeated inside a 256-sample tile once and serve the repeats from LDS -- the
+      forward's counterpart of the reference's slab cache in front of the table
+      (hbtf/embedding/lookup_functors.cu.cc:54-149).  One bool for all columns or one per column.
   """
 
-  def __init__(self, tables, buckets=None, combiners='sum', divisor=1):
+  def __init__(self, tables, buckets=None, combiners='sum', divisor=1, hot_rows=False):
     self._lib = _lib.lib()
     self.tables = list(tables)
     n = len(self.tables)
@@ -56,9 +60,12 @@ class GroupLookup:
     self.buckets = [int(b or 0) for b in buckets]
     self.combiners = [_combiner_code(c) for c in combiners]
     self.divisor = int(divisor)
+    if isinstance(hot_rows, (bool, int)):
+      hot_rows = [hot_rows] * n
     self._cols = (_lib.LookupColumn * n)()
     for c, t in enumerate(self.tables):
       col = self._cols[c]
+      col.hot_rows = 1 if hot_rows[c] else 0
       col.table = t.data_ptr()
       col.rows = t.shape[0]
       col.dim = t.shape[1]

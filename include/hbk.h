@@ -193,6 +193,13 @@ typedef struct {
   /* row stride of `out` in floats; 0 = dim.  Lets N columns write their blocks of one
    * concatenated [segments, sum of dims] tensor (hb.feature_column.DenseFeatures) in place. */
   int32_t out_stride;
+  /* 1: skewed ids expected (Zipf heads): wide one-id-per-segment columns (dim >= 64, 16-byte
+   * chunks, plain table of < 2^32 rows) go through 256-segment tiles that fetch every row
+   * repeated inside a tile once and serve the repeats from LDS (config 4: 239 -> 215 us; on
+   * uniform ids the tiles cost 15 %, hence a hint and not the default).  Option fwd_hot_rows = 1
+   * sets it for every eligible column.  Other columns ignore it. */
+  int32_t hot_rows;
+  int32_t reserved_;
 } hbk_lookup_column_t;
 
 int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,

@@ -279,6 +279,20 @@ def test_group_lookup_more_columns_than_one_launch():
     np.testing.assert_equal(host(o), w)
 
 
+def test_group_lookup_hot_rows_hint_per_column():
+  """hot_rows as a column hint (no process option): the hinted wide column takes the tiles, the
+  others their usual kernels; values are the same either way."""
+  rng = np.random.RandomState(78)
+  dims, rows, n = [128, 128, 16], [4000, 4000, 500], 5000
+  tabs = [rng.uniform(-1, 1, size=(r, d)).astype(np.float32) for d, r in zip(dims, rows)]
+  ids = [((rng.zipf(1.2, size=n) * 7919) % r).astype(np.int64) for r in rows]
+  lookup = hb.embedding.GroupLookup([dev(t) for t in tabs], None, 'sum',
+                                    hot_rows=[True, False, True])
+  outs = lookup([dev(i) for i in ids])
+  for t, i, o in zip(tabs, ids, outs):
+    np.testing.assert_equal(host(o), t[i])
+
+
 @pytest.mark.parametrize('mode', [1, 2])
 def test_group_lookup_hot_row_tiles(hbk_option, mode):
   """Wide one-id-per-sample columns through the 256-segment tiles (option fwd_hot_rows): 1 =

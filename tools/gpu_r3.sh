@@ -82,6 +82,20 @@ PY
       timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "hot_row or group_lookup" --durations=5 > $O/hottest.log 2>&1; echo "pytest rc=$?" >> $O/hottest.log; tail -15 $O/hottest.log;;
     hotsweep)
       timeout 900 python tools/sweep.py --big --cases j > $O/hotsweep.log 2>&1; echo "rc=$?" >> $O/hotsweep.log; cut -c1-300 $O/hotsweep.log;;
+    profhot)
+      prof prof_hot "" -- python $R/tools/sweep.py --big --cases j
+      cat $O/prof_hot.txt
+      export SWEEP_J_KINDS="Zipf(1.2)"
+      prof pmc_hot_tcc "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" -- python $R/tools/sweep.py --big --cases j
+      prof pmc_hot_tcp "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_WRITE_REQ_sum" -- python $R/tools/sweep.py --big --cases j
+      unset SWEEP_J_KINDS
+      for f in pmc_hot_tcc pmc_hot_tcp; do echo "== $f"; tail -1 $O/$f.log; python - $O/$f.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k,v in sorted(d.items()):
+  if 'group_lookup_fwd' in k: print(k[:70].ljust(70), {c:(round(x['mean']), x.get('n')) for c,x in v.items()})
+PY
+      done;;
     sweep)
       timeout 1200 python tools/sweep.py --big --cases ${SWEEP_CASES:-a,b,c,d,e,f,g,h,i} > $O/sweep.log 2>&1; echo "sweep rc=$?" >> $O/sweep.log; cut -c1-400 $O/sweep.log;;
     *) echo "unknown stage $st";;

@@ -178,7 +178,10 @@ def case_cfg4_hot_rows(big):
       'one row': [[torch.zeros(B, dtype=torch.int64, device=DEV) for c in range(26)]] * nb,
   }
   outs = [torch.empty(B, dim, device=DEV) for _ in range(26)]
+  only = os.environ.get('SWEEP_J_KINDS')   # e.g. "Zipf(1.2)" for a counter pass over one kind
   for name, batches in kinds.items():
+    if only and name not in only.split(','):
+      continue
     plans = []
     for b in range(nb):
       gl = hb.embedding.GroupLookup(tables, None, 'sum')

@@ -372,12 +372,18 @@ def main():
   # ~11 us on this chip, an owner gather ~33 us: profiles/r02_hop_probe.txt): both forms run a few
   # untimed steps on the machine at hand, every rank takes the one whose slowest rank was faster.
   groups_probe = None
+  best_form = None
   if (world > 1 or args.sharded) and args.tune_steps > 0:
     from hybridbackend_amd import _lib as _hbk
+    # candidates: the shipped default (two column groups, exchanges on the communicator's stream
+    # beside the gathers), one group on the communicator's stream, and the exchanges enqueued
+    # inline on the compute stream (no event hops at all, nothing overlapped)
+    forms = {'pipelined_2_groups': (2, 0), 'one_group': (1, 0), 'inline': (0, 1)}
     groups_probe = {}
-    for g in (2, 1):
+    for name, (g, inline) in forms.items():
       _hbk.set_option('sharded_groups', g)
-      sharded.close()                 # the option is read when the plan is (re)created
+      _hbk.set_option('sharded_inline', inline)
+      sharded.close()                 # the options are read when the plan is (re)created
       for i in range(3):
         step(i)
       torch.cuda.synchronize()
@@ -392,9 +398,10 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-      groups_probe[g] = round(dt / args.tune_steps * 1e3, 5)
-    best_groups = min(groups_probe, key=groups_probe.get)
-    _hbk.set_option('sharded_groups', best_groups)
+      groups_probe[name] = round(dt / args.tune_steps * 1e3, 5)
+    best_form = min(groups_probe, key=groups_probe.get)
+    _hbk.set_option('sharded_groups', forms[best_form][0])
+    _hbk.set_option('sharded_inline', forms[best_form][1])
     sharded.close()
 
   for i in range(args.warmup):
@@ -443,8 +450,15 @@ def main():
                  'wire': args.wire if world > 1 else None,
                  'prefetch_next_partition': (world > 1 or args.sharded) and not args.no_prefetch,
                  'id_batches_resident': n_batches,
-                 'sharded_groups': (best_groups if groups_probe else None),
-                 'sharded_groups_probe_ms_per_step': groups_probe},
+                 # the form the timed steps ran in, picked on this machine by the probe below;
+                 # 'pipelined_2_groups' is the library's shipped default: its probe time is the
+                 # figure comparable with runs that do not tune (--tune-steps 0)
+                 'sharded_form': best_form,
+                 'sharded_form_probe_ms_per_step': groups_probe,
+                 'value_at_shipped_default_M_lookups_per_s': (
+                     round(lookups_per_step_per_rank * world /
+                           groups_probe['pipelined_2_groups'] / 1e3, 3)
+                     if groups_probe else None)},
       'roofline': {
         'bound': 'hbm',
         'kernel': ('group_lookup_fwd_kernel' if world == 1 and not args.sharded

@@ -39,7 +39,7 @@ class LookupColumn(C.Structure):
               ('combiner', C.c_int32), ('out', C.c_void_p),
               ('run_start', C.c_void_p), ('run_base', C.c_void_p),
               ('n_runs', C.c_int32), ('out_stride', C.c_int32),
-              ('hot_rows', C.c_int32), ('reserved_', C.c_int32)]
+              ('hot_rows', C.c_int32), ('half_io', C.c_int32)]
 
 
 class LookupGradColumn(C.Structure):

@@ -346,12 +346,15 @@ namespace hbk {
 // `skip_self`: the caller has placed this rank's own chunk itself (the sharded driver's owner
 // gather writes it where the exchange would have copied it); not with the fp16 wire, whose casts
 // also round the own chunk (as the reference's do).
+// `inline_x`: the whole exchange -- casts, the grouped send / receive, the own-slice copy -- is
+// enqueued on `compute_stream` itself: no fence, no event, no hop to the communicator's stream
+// and back (11 us each way on this chip, profiles/r02_hop_probe.txt); nothing overlaps it either.
 int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dtype,
                      int32_t topology, const int64_t* common_sizes, const void* const* inputs,
                      const int32_t* send_sizes, void* const* outputs,
                      const int32_t* recv_sizes, void* wire_ws, size_t wire_ws_bytes,
                      hbk_stream_t compute_stream, hipEvent_t before, hipEvent_t after,
-                     bool skip_self) {
+                     bool skip_self, bool inline_x) {
   HBK_REQUIRE(comm != nullptr, "alltoallv_n: comm is NULL");
   HBK_REQUIRE(n >= 0, "alltoallv_n: n must be >= 0");
   if (n == 0) return HBK_OK;
@@ -412,7 +415,7 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
   if (comm->custom) {
     hipStream_t cs = as_stream(compute_stream);
     int lrc;
-    if (before != nullptr) HBK_HIP_OK(hipStreamWaitEvent(cs, before, 0));
+    if (before != nullptr && !inline_x) HBK_HIP_OK(hipStreamWaitEvent(cs, before, 0));
     if (half_wire) {
       std::vector<int64_t> lens(n);
       std::vector<void*> dst(n);
@@ -453,7 +456,7 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
         return lrc;
       }
     }
-    if (after != nullptr) HBK_HIP_OK(hipEventRecord(after, cs));
+    if (after != nullptr && !inline_x) HBK_HIP_OK(hipEventRecord(after, cs));
     return HBK_OK;
   }
   for (int32_t c = 0; c < n; ++c) {     // checked before any RCCL group is opened
@@ -467,7 +470,10 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
   std::unique_lock<std::mutex> lock(comm->mu);
   HBK_REQUIRE(!comm->aborted, "alltoallv_n: communicator was aborted");
   int rc = HBK_OK;
-  if (before != nullptr) {
+  const hipStream_t xs = inline_x ? as_stream(compute_stream) : comm->stream;
+  if (inline_x) {
+    // (nothing to order: everything below goes on the caller's stream)
+  } else if (before != nullptr) {
     HBK_HIP_OK(hipStreamWaitEvent(comm->stream, before, 0));
   } else {
     rc = fence_in(comm, as_stream(compute_stream));
@@ -480,7 +486,7 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
       lens[c] = send_rows[c] * common_sizes[c];
       dst[c] = const_cast<void*>(wire_in[c]);
     }
-    rc = cast_n_impl(n, HBK_FLOAT, HBK_HALF, inputs, lens.data(), dst.data(), comm->stream);
+    rc = cast_n_impl(n, HBK_FLOAT, HBK_HALF, inputs, lens.data(), dst.data(), xs);
     if (rc != HBK_OK) return rc;
   }
   ncclResult_t in_group = ncclSuccess;
@@ -498,16 +504,16 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
         // one channel's copy loop: 54 MB took 111 us, the blit engine path ~25 us)
         if (sendsize > 0 && copy_err == hipSuccess && !skip_self) {
           copy_err = hipMemcpyAsync(recvbuf + recvoffset, sendbuf + sendoffset, sendsize * esize,
-                                    hipMemcpyDeviceToDevice, comm->stream);
+                                    hipMemcpyDeviceToDevice, xs);
         }
       } else {
         if (sendsize > 0) {
           HBK_NCCL_IN_GROUP(in_group, ncclSend(sendbuf + sendoffset, sendsize, nt, ranks[i],
-                                               comm->comm, comm->stream));
+                                               comm->comm, xs));
         }
         if (recvsize > 0) {
           HBK_NCCL_IN_GROUP(in_group, ncclRecv(recvbuf + recvoffset, recvsize, nt, ranks[i],
-                                               comm->comm, comm->stream));
+                                               comm->comm, xs));
         }
       }
       sendoffset += sendsize * esize;
@@ -524,11 +530,12 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
       lens[c] = recv_rows[c] * common_sizes[c];
       src[c] = wire_out[c];
     }
-    rc = cast_n_impl(n, HBK_HALF, HBK_FLOAT, src.data(), lens.data(), outputs, comm->stream);
+    rc = cast_n_impl(n, HBK_HALF, HBK_FLOAT, src.data(), lens.data(), outputs, xs);
     if (rc != HBK_OK) return rc;
   }
+  if (inline_x) return HBK_OK;
   if (after != nullptr) {
-    HBK_HIP_OK(hipEventRecord(after, comm->stream));
+    HBK_HIP_OK(hipEventRecord(after, xs));
     return HBK_OK;
   }
   return fence_out(comm, as_stream(compute_stream));
@@ -542,7 +549,7 @@ extern "C" int hbk_alltoallv_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_
                                size_t wire_ws_bytes, hbk_stream_t compute_stream) {
   return hbk::alltoallv_events(comm, n, dtype, wire_dtype, topology, common_sizes, inputs,
                                send_sizes, outputs, recv_sizes, wire_ws, wire_ws_bytes,
-                               compute_stream, nullptr, nullptr, false);
+                               compute_stream, nullptr, nullptr, false, false);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -136,6 +136,8 @@ struct Options {
   int sharded_id64 = 0;          // HBK_SHARDED_ID64: keep int64 ids on the wire
   int sharded_copy_self = 0;     // HBK_SHARDED_COPY_SELF: own slice through a device copy
   int sharded_trace = 0;         // HBK_SHARDED_TRACE: host-side phase times on stderr
+  int sharded_wire_fused = 1;    // HBK_SHARDED_WIRE_FUSED: fp16 wire: gather writes / stitch reads fp16 rows (0: two cast passes)
+  int sharded_inline = 0;        // HBK_SHARDED_INLINE: exchanges enqueued on the compute stream (no event hops, no overlap)
   int sync_wait_ms = 2000;       // HBK_SYNC_WAIT_MS: bound of a wait between the tiles of a one-launch kernel
   int sync_onepass_off = 0;      // HBK_SYNC_ONEPASS_OFF: 1 = multi-launch forms only (set by a wait that ran out)
   int sync_test_withhold = -1;   // HBK_SYNC_TEST_WITHHOLD: test hook, the tile that never publishes its counts

@@ -58,6 +58,42 @@ __device__ inline uint64_t row_offset(const ColArg& c, uint64_t r) {
   return (uint64_t)c.run_base[k] + (r - (uint64_t)c.run_start[k]) * (uint64_t)c.dim;
 }
 
+// fp16 rows on one side of a gather (the wire format of the sharded step's embedding exchange,
+// hbtf/distribute/nccl/nccl_alltoallv.cc:56-88 + hbtf/common/cast.cu.cc:84-285, fused into the
+// kernels on either side of it): HALF = 1 the OUTPUT rows are half (owner gather -> reply
+// buffer, fp32 -> fp16 round to nearest even as the reference's cast), HALF = 2 the TABLE rows
+// are half (stitch over the received buffer; sums stay fp32).  Offsets and strides count elements.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <typename V, int HALF>
+__device__ inline V load_row_chunk(const float* table, uint64_t off) {
+  if (HALF != 2) return *reinterpret_cast<const V*>(table + off);
+  const _Float16* t = reinterpret_cast<const _Float16*>(table) + off;
+  if (sizeof(V) == 16) {
+    const f16x4 h = *reinterpret_cast<const f16x4*>(t);
+    f32x4 v = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return *reinterpret_cast<V*>(&v);
+  }
+  float f = (float)*t;
+  return *reinterpret_cast<V*>(&f);
+}
+
+template <typename V, int HALF>
+__device__ inline void store_out_chunk(float* out, int64_t off, V v) {
+  if (HALF != 1) {
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(out + off));
+    return;
+  }
+  _Float16* o = reinterpret_cast<_Float16*>(out) + off;
+  if (sizeof(V) == 16) {
+    const f32x4 f = *reinterpret_cast<const f32x4*>(&v);
+    const f16x4 h = {(_Float16)f[0], (_Float16)f[1], (_Float16)f[2], (_Float16)f[3]};   // RNE
+    __builtin_nontemporal_store(h, reinterpret_cast<f16x4*>(o));
+  } else {
+    *o = (_Float16)*reinterpret_cast<const float*>(&v);
+  }
+}
+
 struct LookupArgs {
   int32_t n_cols;
   int32_t hot_mode;   // hot-row kernel only: 1 = stage repeated rows in LDS, 2 = large tiles only
@@ -68,7 +104,7 @@ static_assert(sizeof(LookupArgs) <= 24576, "kernarg budget");
 
 // ---------------------------------------------------------------------------------
 // one id per segment (Criteo scalar columns): out[s,:] = table[row(ids[s]),:]
-template <typename V, int U, bool RUNS>
+template <typename V, int U, bool RUNS, int HALF>
 __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
   constexpr int VE = sizeof(V) / 4;
   const int lane = lane_id();
@@ -101,22 +137,21 @@ __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
     const uint64_t r = shfl_u64(src, (q0 & (kWave - 1)) + grp);
     v[u] = zero_v<V>();
     if (live && r != kNoRow) {
-      v[u] = *reinterpret_cast<const V*>(c.table + row_offset<RUNS>(c, r) + (uint64_t)sub * VE);
+      v[u] = load_row_chunk<V, HALF>(c.table, row_offset<RUNS>(c, r) + (uint64_t)sub * VE);
     }
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int64_t s = wave_row0 + u * rpi + grp;
     if (live && s < n_seg) {
-      __builtin_nontemporal_store(
-          v[u], reinterpret_cast<V*>(c.out + s * (int64_t)c.out_stride + (int64_t)sub * VE));
+      store_out_chunk<V, HALF>(c.out, s * (int64_t)c.out_stride + (int64_t)sub * VE, v[u]);
     }
   }
 }
 
 // ---------------------------------------------------------------------------------
 // ragged segments (row_splits): out[s,:] = combine_j table[row(ids[j]),:], in order of j
-template <typename V, bool RUNS>
+template <typename V, bool RUNS, int HALF>
 __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
   constexpr int VE = sizeof(V) / 4;
   const int lane = lane_id();
@@ -157,7 +192,7 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
           p[t] = tt < lpr && tt < cnt;
           v[t] = zero_v<V>();
           if (p[t] && live && r != kNoRow) {
-            v[t] = *reinterpret_cast<const V*>(c.table + row_offset<RUNS>(c, r) + (uint64_t)sub * VE);
+            v[t] = load_row_chunk<V, HALF>(c.table, row_offset<RUNS>(c, r) + (uint64_t)sub * VE);
           }
         }
 #pragma unroll
@@ -175,8 +210,7 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
       acc = acc / sqrtf((float)n);
     }
     if (live && s < n_seg) {
-      __builtin_nontemporal_store(
-          acc, reinterpret_cast<V*>(c.out + s * (int64_t)c.out_stride + (int64_t)sub * VE));
+      store_out_chunk<V, HALF>(c.out, s * (int64_t)c.out_stride + (int64_t)sub * VE, acc);
     }
   }
 }
@@ -184,7 +218,7 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
 // One instantiation per (ragged?, 16-byte chunks?, segmented table?) so that the common case --
 // one id per sample, dim % 4 == 0, plain table -- carries none of the other paths' code; the host
 // launches each kind present in the call with the columns of that kind.
-template <bool CSR, typename V, bool RUNS>
+template <bool CSR, typename V, bool RUNS, int HALF = 0>
 __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupArgs a) {
   const int b = (int)blockIdx.x;
   // last column whose first tile is <= b.  A binary search over the kernel-argument table is
@@ -208,11 +242,11 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupAr
   if (!CSR) {
     const int64_t row0 = (tile * kWavesPerBlock + wave) * (int64_t)(kU * rpi);
     if (row0 >= c.n_seg) return;
-    gather_rows<V, kU, RUNS>(c, row0);
+    gather_rows<V, kU, RUNS, HALF>(c, row0);
   } else {
     const int64_t seg0 = (tile * kWavesPerBlock + wave) * (int64_t)(kSegIters * rpi);
     if (seg0 >= c.n_seg) return;
-    combine_segments<V, RUNS>(c, seg0);
+    combine_segments<V, RUNS, HALF>(c, seg0);
   }
 }
 
@@ -369,10 +403,10 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const Look
   }
 }
 
-template <bool CSR, typename V, bool RUNS>
+template <bool CSR, typename V, bool RUNS, int HALF = 0>
 void launch_kind(const LookupArgs& args, unsigned tiles, hipStream_t stream) {
-  hipLaunchKernelGGL((group_lookup_fwd_kernel<CSR, V, RUNS>), dim3(tiles), dim3(kBlock), 0, stream,
-                     args);
+  hipLaunchKernelGGL((group_lookup_fwd_kernel<CSR, V, RUNS, HALF>), dim3(tiles), dim3(kBlock), 0,
+                     stream, args);
 }
 
 void launch_by_kind(int kind, const LookupArgs& args, unsigned tiles, hipStream_t stream) {
@@ -380,7 +414,16 @@ void launch_by_kind(int kind, const LookupArgs& args, unsigned tiles, hipStream_
     hipLaunchKernelGGL(group_lookup_fwd_hot_kernel, dim3(tiles), dim3(kBlock), 0, stream, args);
     return;
   }
-  switch (kind) {  // bit 0 ragged, bit 1 scalar chunks, bit 2 segmented table
+  switch (kind) {  // bit 0 ragged, bit 1 scalar chunks, bit 2 segmented table, bit 4 fp16 rows
+    case 16: launch_kind<false, f32x4, false, 1>(args, tiles, stream); return;   // half output
+    case 18: launch_kind<false, float, false, 1>(args, tiles, stream); return;
+    case 20: launch_kind<false, f32x4, true, 2>(args, tiles, stream); return;    // half table
+    case 21: launch_kind<true, f32x4, true, 2>(args, tiles, stream); return;
+    case 22: launch_kind<false, float, true, 2>(args, tiles, stream); return;
+    case 23: launch_kind<true, float, true, 2>(args, tiles, stream); return;
+    default: break;
+  }
+  switch (kind) {
     case 0: launch_kind<false, f32x4, false>(args, tiles, stream); break;
     case 1: launch_kind<true, f32x4, false>(args, tiles, stream); break;
     case 2: launch_kind<false, float, false>(args, tiles, stream); break;
@@ -424,10 +467,16 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
                 "group_lookup_fwd: column %d: bad segmented-table description", c);
     HBK_REQUIRE(h.n_ids < (1ll << 31) && h.n_segments < (1ll << 31),
                 "group_lookup_fwd: column %d: more than 2^31-1 ids/segments", c);
+    HBK_REQUIRE(h.half_io == 0 ||
+                    (h.half_io == HBK_LOOKUP_OUT_HALF && h.row_splits == nullptr && h.n_runs == 0) ||
+                    (h.half_io == HBK_LOOKUP_TABLE_HALF && h.n_runs > 0),
+                "group_lookup_fwd: column %d: half_io %d: fp16 output rows need one id per segment "
+                "and a plain table, fp16 table rows a segmented table", c, h.half_io);
   }
 
   const int hot_mode = options().fwd_hot_rows;
-  for (int kind = 0; kind < 9; ++kind) {
+  for (int kind = 0; kind < 24; ++kind) {
+    if (kind > 8 && kind < 16) continue;
     int32_t c0 = 0;
     while (c0 < n_cols) {
       LookupArgs args;
@@ -443,15 +492,18 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
                     "group_lookup_fwd: out_stride %d is smaller than dim %d", h.out_stride,
                     h.dim);
         // a strided output keeps 16-byte chunks only if every row start stays 16-byte aligned
-        HBK_REQUIRE(make_rowshape(h.dim,
-                                  (uintptr_t)h.table | (uintptr_t)h.out |
-                                      ((uintptr_t)(uint32_t)h.out_stride * 4),
-                                  &shape),
+        // (a half buffer is held to 8 bytes where an fp32 one is held to 16: its address counts
+        // twice in the alignment test; a row stride must be a multiple of 4 elements either way)
+        const uintptr_t table_bits = (uintptr_t)h.table * (h.half_io == HBK_LOOKUP_TABLE_HALF ? 2 : 1);
+        const uintptr_t out_bits = (uintptr_t)h.out * (h.half_io == HBK_LOOKUP_OUT_HALF ? 2 : 1) |
+                                   ((uintptr_t)(uint32_t)h.out_stride * 4);
+        HBK_REQUIRE(make_rowshape(h.dim, table_bits | out_bits, &shape),
                     "group_lookup_fwd: dim %d needs more than 64 lanes per row "
                     "(unaligned or dim %% 4 != 0 with dim > 64 is unsupported)", h.dim);
         int col_kind = (h.row_splits != nullptr ? 1 : 0) | (shape.vec4 ? 0 : 2) |
                        (h.n_runs > 0 ? 4 : 0);
         // one id per segment, plain table, wide 16-byte-chunk rows: the hot-row kernel when asked
+        if (h.half_io != 0) col_kind |= 16;
         if (col_kind == 0 && (hot_mode > 0 || h.hot_rows != 0) && h.dim >= 64 && shape.lpr_log2 <= 6 &&
             h.dim <= kHotStageFloats && h.rows < 0xffffffffll) {
           col_kind = 8;

@@ -34,7 +34,7 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
                      const int32_t* send_sizes, void* const* outputs,
                      const int32_t* recv_sizes, void* wire_ws, size_t wire_ws_bytes,
                      hbk_stream_t compute_stream, hipEvent_t before, hipEvent_t after,
-                     bool skip_self);
+                     bool skip_self, bool inline_x);
 int partition_by_modulo_fused(int32_t n_cols, int32_t num_partitions, const int64_t* const* inputs,
                               const int64_t* lens, const int64_t* buckets,
                               int64_t* const* outputs, int32_t* const* sizes,
@@ -270,6 +270,7 @@ struct hbk_sharded {
   bool id32;   // ids travel (and stay on the owner) as int32: every column is bucketized below 2^31
   bool trace;  // option sharded_trace: host-side phase times on stderr
   int n_groups;  // option sharded_groups
+  bool inline_x; // option sharded_inline: exchanges on the compute stream, one column group
   std::vector<hbk_sharded_column_t> cols;
   // per-step state (kept for the backward)
   std::vector<int64_t> n_ids, n_seg;
@@ -289,6 +290,12 @@ struct hbk_sharded {
   char* recv_ids_p;
   float* send_rows_p;
   float* recv_rows_p;
+  bool fused_half;      // fp16 wire, forward: the owner gather WRITES fp16 rows into the reply buffer and
+                        // the stitch READS fp16 rows from the received one (hbk_lookup_column_t.half_io): the
+                        // two cast passes and the wire workspace are gone (option sharded_wire_fused)
+  bool zero_copy_grads; // the own slice of the BACKWARD's exchange stays in place too (fp32 wire only: the
+                        // fp16 wire rounds the own slice's gradient rows like everybody else's, as the
+                        // reference does)
   bool zero_copy_self;  // fp32 wire: the own slice never travels, not even as a device copy: the
                         // owner gather reads its ids where the pack left them and writes the rows
                         // where the stitch reads them (and the backward the other way round)
@@ -341,11 +348,14 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
   p->id32 = options().sharded_id64 == 0;
   p->trace = options().sharded_trace != 0;
   p->n_groups = options().sharded_groups;
+  p->inline_x = options().sharded_inline != 0;
   for (int32_t c = 0; c < n_cols; ++c) {
     if (cols[c].bucket <= 0 || cols[c].bucket > 0x7fffffffll) p->id32 = false;
   }
   p->have_step = false;
-  p->zero_copy_self = wire_dtype == HBK_FLOAT && options().sharded_copy_self == 0;
+  p->fused_half = wire_dtype == HBK_HALF && options().sharded_wire_fused != 0;
+  p->zero_copy_self = (wire_dtype == HBK_FLOAT || p->fused_half) && options().sharded_copy_self == 0;
+  p->zero_copy_grads = p->zero_copy_self && wire_dtype == HBK_FLOAT;
   p->send_ids_p = p->recv_ids_p = nullptr;
   p->send_rows_p = p->recv_rows_p = nullptr;
   p->cur = 0;
@@ -434,7 +444,8 @@ int exchange(hbk_sharded* p, int32_t dtype, int32_t wire, const void* in, const 
     wire_ws_bytes = p->wire_ws.bytes;
   }
   return alltoallv_events(p->comm, 1, dtype, wire, HBK_TOPOLOGY_ALL, cs, vin, send, vout, recv,
-                          wire_ws, wire_ws_bytes, stream, before, after, skip_self);
+                          wire_ws, wire_ws_bytes, stream, before, after, skip_self,
+                          p->inline_x && before != nullptr);
 }
 
 // Stages 1-2 of a step into `set`: bucketize + stable partition of all columns, ONE [N x W] size
@@ -580,7 +591,9 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   // ids of group g+1 are on the wire, and stitches group g while the rows of group g+1 travel:
   //   comm    : ids(0) ids(1) ...            rows(0)      rows(1) ...
   //   compute : pack(0..G-1)      gather(0)  gather(1) ..      stitch(0)   stitch(1)
-  const int G = pipeline_groups(N, W, p->n_groups);
+  // (inline exchanges: nothing runs beside them, one group is all there is to schedule)
+  const int G = p->inline_x && !(p->n_groups >= 1 && p->n_groups <= 4)
+                    ? 1 : pipeline_groups(N, W, p->n_groups);
   std::vector<Group>& groups = p->groups;
   groups.assign(G, Group());
   int64_t tot_req_ids = 0, tot_own_ids = 0, tot_own_floats = 0, tot_req_floats = 0;
@@ -625,7 +638,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   p->recv_ids_p = p->send_ids_p + ids_send_bytes;
   p->send_rows_p = reinterpret_cast<float*>(p->rows_buf.ptr);
   p->recv_rows_p = p->send_rows_p + rows_send_bytes / 4;
-  if (p->wire_dtype == HBK_HALF) {  // staging for the largest group (exchanges are serial)
+  if (p->wire_dtype == HBK_HALF && !p->fused_half) {  // staging for the largest group (exchanges are serial)
     size_t wws = 0;
     const int64_t cs1[1] = {1};
     for (const Group& gr : groups) {
@@ -643,6 +656,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   float* rows_send_base = p->send_rows_p;
   float* rows_recv_base = p->recv_rows_p;
   const bool zc = p->zero_copy_self;
+  const bool half = p->fused_half;   // fp16 rows in the exchange buffers of the forward
   const int me = p->rank;
   // element offsets of the "other side" buffers seen from the owner-side bases of the backward
   const int64_t ids_send_from_recv = -(int64_t)(ids_send_bytes / id_bytes);
@@ -676,9 +690,11 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
           h_ograds[at] = gr.row_send + gr.lay.own_row_off[(size_t)q * ng + c];
           if (zc && q == me) {
             // the own slice stays where the requester side put it: ids in the outgoing id buffer,
-            // gradient rows in the buffer the rows came back in
+            // gradient rows (fp32 wire) in the buffer the rows came back in
             h_oids[at] = ids_send_from_recv + gr.id_send + gr.lay.req_id_off[(size_t)q * ng + c];
-            h_ograds[at] = rows_recv_from_send + gr.row_recv + gr.lay.req_row_off[(size_t)q * ng + c];
+            if (p->zero_copy_grads) {
+              h_ograds[at] = rows_recv_from_send + gr.row_recv + gr.lay.req_row_off[(size_t)q * ng + c];
+            }
           }
           o += gr.R[(size_t)q * ng + c];
         }
@@ -706,7 +722,8 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   // one rank with its own slice left in place: nothing goes on the wire, the step stays on the
   // compute stream (no hops to the communicator's stream and back)
   const bool wire = !(W == 1 && zc);
-  if (wire) HBK_HIP_OK(hipEventRecord(p->ev[0][0], stream));
+  const bool hop = wire && !p->inline_x;   // exchanges on the communicator's stream, ordered by events
+  if (hop) HBK_HIP_OK(hipEventRecord(p->ev[0][0], stream));
   // stage B: ids exchanges, back to back on the communicator's stream
   for (int g = 0; g < G && wire; ++g) {
     const Group& gr = groups[g];
@@ -720,7 +737,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   for (int g = 0; g < G; ++g) {
     const Group& gr = groups[g];
     const int ng = gr.c1 - gr.c0;
-    if (wire) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
+    if (hop) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
     std::vector<hbk_lookup_column_t> v;
     v.reserve((size_t)ng * W);
     for (int q = 0; q < W; ++q) {
@@ -739,10 +756,18 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
         h.n_segments = n;
         h.divisor = W;
         h.combiner = HBK_COMBINER_SUM;
-        h.out = rows_send_base + gr.row_send + gr.lay.own_row_off[(size_t)q * ng + c];
+        int64_t out_at = gr.row_send + gr.lay.own_row_off[(size_t)q * ng + c];   // elements
+        float* out_base = rows_send_base;
         if (zc && q == me) {
           h.ids = ids_send_base + (gr.id_send + gr.lay.req_id_off[(size_t)q * ng + c]) * id_bytes;
-          h.out = rows_recv_base + gr.row_recv + gr.lay.req_row_off[(size_t)q * ng + c];
+          out_at = gr.row_recv + gr.lay.req_row_off[(size_t)q * ng + c];
+          out_base = rows_recv_base;
+        }
+        if (half) {   // the same element offsets inside the same buffers, two bytes each
+          h.out = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(out_base) + out_at);
+          h.half_io = HBK_LOOKUP_OUT_HALF;
+        } else {
+          h.out = out_base + out_at;
         }
         v.push_back(h);
       }
@@ -750,11 +775,18 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     rc = hbk_group_lookup_fwd((int32_t)v.size(), v.data(), stream_);
     if (rc != HBK_OK) return rc;
     if (!wire) continue;
-    HBK_HIP_OK(hipEventRecord(p->ev[2][g], stream));
-    rc = exchange(p, HBK_FLOAT, p->wire_dtype, rows_send_base + gr.row_send,
-                  gr.lay.rows_send_peer.data(), rows_recv_base + gr.row_recv,
-                  gr.lay.rows_recv_peer.data(), stream_, p->ev[2][g], p->ev[3][g],
-                  p->wire_ws.ptr, p->wire_ws.bytes, zc);
+    if (hop) HBK_HIP_OK(hipEventRecord(p->ev[2][g], stream));
+    if (half) {
+      rc = exchange(p, HBK_HALF, HBK_HALF, reinterpret_cast<uint16_t*>(rows_send_base) + gr.row_send,
+                    gr.lay.rows_send_peer.data(),
+                    reinterpret_cast<uint16_t*>(rows_recv_base) + gr.row_recv,
+                    gr.lay.rows_recv_peer.data(), stream_, p->ev[2][g], p->ev[3][g], nullptr, 0, zc);
+    } else {
+      rc = exchange(p, HBK_FLOAT, p->wire_dtype, rows_send_base + gr.row_send,
+                    gr.lay.rows_send_peer.data(), rows_recv_base + gr.row_recv,
+                    gr.lay.rows_recv_peer.data(), stream_, p->ev[2][g], p->ev[3][g],
+                    p->wire_ws.ptr, p->wire_ws.bytes, zc);
+    }
     if (rc != HBK_OK) return rc;
   }
   // stage D: stitch + combiner of group g when its rows are in; the received rows stay
@@ -764,13 +796,16 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   for (int g = 0; g < G; ++g) {
     const Group& gr = groups[g];
     const int ng = gr.c1 - gr.c0;
-    if (wire) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[3][g], 0));
+    if (hop) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[3][g], 0));
     std::vector<hbk_lookup_column_t> v(ng);
     for (int c = 0; c < ng; ++c) {
       const int cc = gr.c0 + c;
       hbk_lookup_column_t& h = v[c];
       memset(&h, 0, sizeof(h));
-      h.table = rows_recv_base + gr.row_recv;
+      h.table = half ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(rows_recv_base) +
+                                                      gr.row_recv)
+                     : rows_recv_base + gr.row_recv;
+      h.half_io = half ? HBK_LOOKUP_TABLE_HALF : 0;
       h.rows = n_ids[cc];
       h.dim = p->cols[cc].dim;
       h.ids_dtype = HBK_INT32;
@@ -852,7 +887,8 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
   const int N = p->N, W = p->W;
   const int32_t* R = p->recv_sizes.data();
   const int G = (int)p->groups.size();
-  const bool wire = !(W == 1 && p->zero_copy_self);   // (see the forward)
+  const bool wire = !(W == 1 && p->zero_copy_grads);   // (see the forward)
+  const bool hop = wire && !p->inline_x;
   float* rows_send_base = p->send_rows_p;
   float* rows_recv_base = p->recv_rows_p;
   const int64_t* d_start = reinterpret_cast<const int64_t*>(p->runs_dev.ptr);
@@ -890,7 +926,7 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
     }
     rc = hbk_group_stitch_bwd(ng, v.data(), stream_);
     if (rc != HBK_OK) return rc;
-    if (wire) HBK_HIP_OK(hipEventRecord(p->ev[0][g], stream));
+    if (hop) HBK_HIP_OK(hipEventRecord(p->ev[0][g], stream));
   }
   // ---- B2 reverse exchanges (the forward's sizes, swapped: collective.py:334-347) -------------
   for (int g = 0; g < G && wire; ++g) {
@@ -898,7 +934,7 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
     rc = exchange(p, HBK_FLOAT, p->wire_dtype, rows_recv_base + gr.row_recv,
                   gr.lay.rows_recv_peer.data(), rows_send_base + gr.row_send,
                   gr.lay.rows_send_peer.data(), stream_, p->ev[0][g], p->ev[1][g], nullptr, 0,
-                  p->zero_copy_self);
+                  p->zero_copy_grads);
     if (rc != HBK_OK) return rc;
   }
   // ---- B3 owner side: duplicate-row reduction (+ SGD) reading ids and gradient rows in place ---
@@ -936,7 +972,7 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
   if ((rc = p->bwd_ws.ensure(ws + 8)) != HBK_OK) return rc;
   for (int g = 0; g < G; ++g) {
     const Group& gr = p->groups[g];
-    if (wire) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
+    if (hop) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
     rc = hbk_group_lookup_bwd_apply(gr.c1 - gr.c0, v.data() + gr.c0, apply, apply_lr,
                                     p->bwd_ws.ptr, p->bwd_ws.bytes, stream_);
     if (rc != HBK_OK) return rc;

@@ -76,7 +76,7 @@ const char* hbk_version(void);
  * Names: bwd_buckets_log2, bwd_bucket_pairs, bwd_split_pairs, bwd_onepass, bwd_group_cols, bwd_dense, fwd_hot_rows,
  * unique_buckets_log2,
  * unique_onepass, partition_sub_tiles, partition_fixed_max, partition_onepass, sharded_groups,
- * sharded_id64, sharded_copy_self, sharded_trace (the sharded_* ones are taken by
+ * sharded_id64, sharded_copy_self, sharded_trace, sharded_inline, sharded_wire_fused (the sharded_* ones are taken by
  * hbk_sharded_create), sync_wait_ms, sync_onepass_off, sync_test_withhold.
  * *_onepass (default 1): small calls of partition / unique / the backward group their ids in ONE
  * launch whose tiles wait for each other; 0 keeps the multi-launch forms.  The
@@ -199,8 +199,15 @@ typedef struct {
    * uniform ids the tiles cost 15 %, hence a hint and not the default).  Option fwd_hot_rows = 1
    * sets it for every eligible column.  Other columns ignore it. */
   int32_t hot_rows;
-  int32_t reserved_;
+  /* fp16 rows on one side (the embedding exchange's wire format fused into the kernels around
+   * it; replaces the reference's separate cast passes, hbtf/common/cast.cu.cc:84-285):
+   * HBK_LOOKUP_OUT_HALF: `out` holds fp16 rows (fp32 -> fp16 round to nearest even); one id per
+   * segment, plain table.  HBK_LOOKUP_TABLE_HALF: `table` holds fp16 rows (sums stay fp32);
+   * segmented tables only (n_runs > 0).  Offsets, strides and run bases count elements. */
+  int32_t half_io;
 } hbk_lookup_column_t;
+#define HBK_LOOKUP_OUT_HALF 1
+#define HBK_LOOKUP_TABLE_HALF 2
 
 int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
                          hbk_stream_t stream);

@@ -98,11 +98,15 @@ def test_sharded_forward_equals_unsharded(world, wire16):
       np.testing.assert_equal(outs[c].cpu().numpy(), want[c])
 
 
-@pytest.mark.parametrize('groups', [0, 2, 3])
-def test_sharded_call_through_rccl_world1(hbk_option, groups):
+@pytest.mark.parametrize('groups,inline', [(0, 0), (2, 0), (3, 0), (0, 1), (2, 1)])
+def test_sharded_call_through_rccl_world1(hbk_option, groups, inline):
   # one rank pipelines ONE column group by default (nothing on the wire to hide); the option
-  # forces the multi-group pipeline of W > 1 through the same calls
+  # forces the multi-group pipeline of W > 1 through the same calls; inline: the RCCL group is
+  # enqueued on the compute stream (sharded_copy_self: the own slice really goes through it)
   hbk_option('sharded_groups', groups)
+  hbk_option('sharded_inline', inline)
+  if inline:
+    hbk_option('sharded_copy_self', 1)
   rng = np.random.RandomState(7)
   coll = hb.distribute.Collective(world_size=1, rank=0)
   try:
@@ -194,15 +198,23 @@ def test_sharded_backward_through_rccl_world1_with_apply():
     coll.close()
 
 
-@pytest.mark.parametrize('world,wire16,id64', [(2, False, False), (4, True, False),
-                                               (8, False, False), (4, False, True)])
-def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64):
+@pytest.mark.parametrize('world,wire16,id64,inline', [
+    (2, False, False, 0), (4, True, False, 0), (8, False, False, 0), (4, False, True, 0),
+    (4, False, False, 1), (8, True, False, 1), (2, False, True, 1), (4, 'unfused', False, 0),
+    (1, True, False, 0)])
+def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64, inline):
   """hbk_sharded_lookup_fwd/_bwd (the code that runs at 8 GPUs) with W ranks as host threads
   of one process on one GPU; only the transport differs from production (device copies
-  instead of RCCL).  Forward == unsharded oracle lookup, backward == dense scatter-add."""
+  instead of RCCL).  Forward == unsharded oracle lookup, backward == dense scatter-add.
+  inline: the exchanges are enqueued on the compute stream itself (option sharded_inline: one
+  column group, no hops to the communicator's stream) instead of pipelined beside it."""
   import threading
   if id64:   # ids travel as int32 by default (all buckets < 2^31); this keeps int64 on the wire
     hbk_option('sharded_id64', 1)
+  hbk_option('sharded_inline', inline)
+  # fp16 wire: by default the owner gather writes fp16 rows and the stitch reads them (no cast
+  # passes, the own slice stays in place); 'unfused' keeps the two casts through a wire workspace
+  hbk_option('sharded_wire_fused', 0 if wire16 == 'unfused' else 1)
   rng = np.random.RandomState(300 + world)
   # world 4 includes a dim that is not a multiple of 4 floats: unpack path instead of the
   # in-place segmented stitch

@@ -76,6 +76,17 @@ for k,v in sorted(d.items()):
 PY
         done
       done;;
+    shardtest)
+      timeout 1200 python -m pytest tests/test_gpu_sharded.py tests/test_gpu_configs.py tests/test_gpu_golden.py -q -m gpu -k "not config4" --durations=8 > $O/shardtest.log 2>&1; echo "pytest rc=$?" >> $O/shardtest.log; tail -25 $O/shardtest.log;;
+    shardbench)   # one rank, through RCCL: fp32 wire, fp16 wire fused / with the two cast passes; the three forms
+      for w in fp32 fp16; do
+        for fused in 1 0; do
+          [ $w = fp32 ] && [ $fused = 0 ] && continue
+          HBK_SHARDED_WIRE_FUSED=$fused timeout 300 python bench.py --gpus 1 --sharded --wire $w --steps 30 --warmup 5 --cpu-seconds 0 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('wire=$w fused=$fused', 'ms_per_step', d['ms_per_step'], 'value', d['value'], d['config'].get('sharded_form'), d['config'].get('sharded_form_probe_ms_per_step'))"
+        done
+      done > $O/shardbench.log 2>&1; cat $O/shardbench.log;;
     synctest)
       timeout 900 python -m pytest tests/test_gpu_sync.py -q -m gpu --durations=5 > $O/synctest.log 2>&1; echo "pytest rc=$?" >> $O/synctest.log; tail -30 $O/synctest.log;;
     hottest)

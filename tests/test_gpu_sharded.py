@@ -270,7 +270,8 @@ def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64,
   tol = dict(rtol=1e-5, atol=1e-5)
   if wire16:
     eff = [oracle.cast_f16_to_f32(oracle.cast_f32_to_f16(t)) for t in tables]
-    tol = dict(rtol=2e-3, atol=2e-3)      # gradients travel as fp16 too
+    # gradients travel as fp16 too: every rank's contribution to a row is rounded on its own
+    tol = dict(rtol=2e-3, atol=2e-3 * max(1, world // 4))
   for r in range(world):
     want = oracle.group_lookup_fwd(eff, ids[r], splits[r], rows, combiners)
     for c in range(n):

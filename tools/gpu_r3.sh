@@ -82,7 +82,7 @@ PY
       for w in fp32 fp16; do
         for fused in 1 0; do
           [ $w = fp32 ] && [ $fused = 0 ] && continue
-          HBK_SHARDED_WIRE_FUSED=$fused timeout 300 python bench.py --gpus 1 --sharded --wire $w --steps 30 --warmup 5 --cpu-seconds 0 2>&1 | tail -1 | python -c "
+          HBK_SHARDED_WIRE_FUSED=$fused timeout 300 python bench.py --gpus 1 --sharded --wire $w --steps 30 --warmup 5 --cpu-seconds 0 2>&1 | grep '^{' | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('wire=$w fused=$fused', 'ms_per_step', d['ms_per_step'], 'value', d['value'], d['config'].get('sharded_form'), d['config'].get('sharded_form_probe_ms_per_step'))"
         done

@@ -8,8 +8,9 @@ import this package; nothing under ``hybridbackend_amd/`` does.
 
 Each wrapper names the reference file:line its C body restates (paths relative
 to /root/reference; hbtf/ = hybridbackend/tensorflow/).  Rows R1, R7-R10 live in
-TensorFlow 1.15 (third party, absent): PARITY UNPINNED for those, see
-``hbk_oracle.c`` header and DESIGN.md.
+TensorFlow 1.15 (third party, absent): pinned to its documentation's worked examples,
+to vectors derived from its documented rules and to second implementations, not to its
+binary -- see the ``hbk_oracle.c`` header and DESIGN.md section 2.
 """
 import ctypes as C
 import os

@@ -18,7 +18,15 @@
  *     TensorFlow 1.15 (third-party; not under /root/reference, not installable
  *     here).  Their published semantics are restated; the reference's tests never
  *     assert embedding values (hbtf/embedding/tests/deeprecev_test.py:73-79 only
- *     prints), so for these rows the header says it plainly: PARITY UNPINNED.
+ *     prints).  These rows are pinned to what exists outside this restatement:
+ *     the worked examples printed in the TF 1.15 API documentation and vectors
+ *     derived from the rules it states (tests/golden/tf115_semantics.json, each
+ *     entry marked "published" or "derived"), numpy float64 (config-1 fixture)
+ *     and a second implementation (torch embedding_bag + autograd).  Agreement
+ *     is with TF 1.15's documentation, not with its binary: nothing runs it here.
+ *     One documented difference: TF 1.15's CPU SparseSegmentReduction adds rows
+ *     in blocks of 8 (Eigen), this restatement strictly in order of j -- the two
+ *     agree within the 1e-5 the path is held to, not bit for bit.
  */
 #include <math.h>
 #include <pthread.h>
@@ -275,7 +283,7 @@ void orc_cast_f16_to_f32(const uint16_t* in, int64_t n, float* out) {
 /* ------------------------------------------------------------------------- */
 /* R7  owner-side `array_ops.unique` -- hbtf/embedding/sharding.py:186 (TF Unique:
  *     output in FIRST-OCCURRENCE order, idx[i] = position of in[i] in output).
- *     PARITY UNPINNED (TF1.15 third-party kernel; semantics from its op doc).
+ *     Pinned to the TF 1.15 docstring example (tests/golden: unique, published).
  * Open-addressing hash table; returns the number of unique values.              */
 static inline uint64_t orc_mix64(uint64_t k) {
   k ^= k >> 33;
@@ -318,7 +326,7 @@ int64_t orc_unique_i64(const int64_t* in, int64_t n, int64_t* uniq, int32_t* idx
 /* ------------------------------------------------------------------------- */
 /* R8  local gather `fn(params, shard_ids)` -- hbtf/embedding/sharding.py:191,193,200
  *     (TF GatherV2 axis 0): out[k,:] = table[row[k],:].  Out-of-range rows give
- *     zeros (TF GPU GatherV2 behaviour).  PARITY UNPINNED (exact copy anyway).  */
+ *     zeros (TF GPU GatherV2 behaviour).  A copy: exact by construction.          */
 void orc_gather_f32(const float* table, int64_t rows, int32_t dim,
                     const int64_t* row_ids, int64_t n, float* out) {
   for (int64_t k = 0; k < n; ++k) {
@@ -351,7 +359,8 @@ void orc_gather_f32_i32(const float* table, int64_t rows, int32_t dim,
  *     mean: / count, sqrtn: / sqrt(count); empty segment -> 0.
  *     fp32, fixed IN-ORDER accumulation (the documented association order of this
  *     build; TF's own chunked order differs in the last ulp -> tolerance 1e-5).
- *     PARITY UNPINNED.  combiner: 0 sum, 1 mean, 2 sqrtn.
+ *     Pinned to the tf.sparse.segment_sum / segment_mean docstring examples
+ *     (published) and sum / sqrt(N) (derived).  combiner: 0 sum, 1 mean, 2 sqrtn.
  *     idx may be NULL (identity: emb row j).                                     */
 void orc_segment_combine_f32(const float* emb, int32_t dim, const int32_t* idx,
                              const int32_t* splits, int64_t n_segments,
@@ -403,7 +412,8 @@ void orc_segment_combine_f64acc(const float* emb, int32_t dim, const int32_t* id
  *       d(combiner): g_id[j,:] = g_out[seg(j),:] * scale(seg)   (sum 1, mean 1/cnt,
  *                    sqrtn 1/sqrt(cnt))  -- SparseSegment*Grad
  *       d(gather by idx) = UnsortedSegmentSum(g_id, idx, u): g_u[idx[j],:] += g_id[j,:]
- *     in-order accumulation over j.  PARITY UNPINNED.                            */
+ *     in-order accumulation over j (TF 1.15's CPU kernel adds in blocks of 8:
+ *     same value within 1e-5).  Pinned as R9 + the embedding_lookup_sparse example. */
 void orc_segment_combine_grad_f32(const float* g_out, int32_t dim,
                                   const int32_t* splits, int64_t n_segments,
                                   int32_t combiner, float* g_id) {

@@ -90,6 +90,8 @@ def _declare(l):
     'hbk_partition_by_modulo_n': (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     'hbk_partition_by_dual_modulo_n':
       (C.c_int, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'hbk_partition_by_modulo_host': (C.c_int, [i32, i32, i32, vp, vp, vp, vp, vp]),
+    'hbk_partition_by_dual_modulo_host': (C.c_int, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     'hbk_cast_n': (C.c_int, [i32, i32, i32, vp, vp, vp, vp]),
     'hbk_unique_workspace_bytes': (sz, [i32, vp]),
     'hbk_unique_n': (C.c_int, [i32, vp, vp, vp, vp, vp, vp, sz, vp]),

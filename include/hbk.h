@@ -138,6 +138,20 @@ int hbk_partition_by_dual_modulo_n(int32_t n_cols, int32_t dtype, int32_t num_pa
                                    void* const* outputs, int32_t* const* sizes,
                                    int32_t* const* indices, void* workspace,
                                    size_t workspace_bytes, hbk_stream_t stream);
+/* Host-memory twins (all buffers in host memory, no workspace, no stream): the CPU kernels of
+ * the non-N ops, which the reference registers for DEVICE_CPU
+ * (partition_by_modulo_ops.cc:62-101, partition_by_dual_modulo_ops.cc:62-130; the N-ary CPU form
+ * is Unimplemented there, partition_by_modulo_functors.cc:84-85 -- here it simply loops).  Same
+ * results as the device entries, bit for bit. */
+int hbk_partition_by_modulo_host(int32_t n_cols, int32_t dtype, int32_t num_partitions,
+                                 const void* const* inputs, const int64_t* lens,
+                                 void* const* outputs, int32_t* const* sizes,
+                                 int32_t* const* indices);
+int hbk_partition_by_dual_modulo_host(int32_t n_cols, int32_t dtype, int32_t num_partitions,
+                                      int32_t modulus, int32_t stage,
+                                      const void* const* inputs, const int64_t* lens,
+                                      void* const* outputs, int32_t* const* sizes,
+                                      int32_t* const* indices);
 
 /* ------------------------------------------------------------------------------------
  * R6  fp32 <-> fp16 wire casts, N tensors in one launch.

@@ -5,8 +5,10 @@
 // unchanged) and forwards each kernel to the C ABI of include/hbk.h.  No CUDA headers, no
 // NCCL headers, no backend dispatch: everything device-side lives behind hbk_*.
 //
-// NOT compiled in this repository (TensorFlow is absent from the build image and the GPU
-// box); build line in INTEGRATION.md.  Signature sources, relative to the reference tree:
+// Not BUILT in this repository (TensorFlow is absent from the build image and the GPU box; build
+// line in INTEGRATION.md), but parsed and type-checked by `make -C integration/tf_shim check`
+// against a declaration stub of the TensorFlow symbols used here (check/tf_decl_stub.h).
+// Signature sources, relative to the reference tree:
 //   hybridbackend/tensorflow/distribute/partition/partition_by_modulo_ops.cc:46-60,124-143
 //   hybridbackend/tensorflow/distribute/partition/partition_by_dual_modulo_ops.cc:46-61,132-147,184-204,278-298
 //   hybridbackend/tensorflow/distribute/nccl/nccl_get_id.cc:35-41, nccl_create.cc:32-52
@@ -191,6 +193,58 @@ HB_PARTITION_KERNELS(int64);
 HB_PARTITION_KERNELS(uint32);
 HB_PARTITION_KERNELS(uint64);
 
+// CPU kernels of the non-N ops (the reference registers them for DEVICE_CPU:
+// partition_by_modulo_ops.cc:62-101, partition_by_dual_modulo_ops.cc:62-130): host tensors
+// through the host-memory twins of the device entries.
+template <typename T>
+class PartitionCpuOp : public OpKernel {
+ public:
+  PartitionCpuOp(OpKernelConstruction* ctx, int stage) : OpKernel(ctx), stage_(stage), modulus_(1) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("num_partitions", &num_partitions_));
+    if (stage_ != 0) OP_REQUIRES_OK(ctx, ctx->GetAttr("modulus", &modulus_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    const Tensor& in = ctx->input(0);
+    OP_REQUIRES(ctx, TensorShapeUtils::IsVector(in.shape()),
+                errors::InvalidArgument("Input must be a vector"));
+    Tensor *o, *s, *x;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, in.shape(), &o));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(1, TensorShape({num_partitions_}), &s));
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(2, in.shape(), &x));
+    const void* src = in.flat<T>().data();
+    void* dst = o->flat<T>().data();
+    int32_t* sizes = s->flat<int32>().data();
+    int32_t* idx = x->flat<int32>().data();
+    const int64_t len = in.NumElements();
+    const int rc = stage_ == 0
+        ? hbk_partition_by_modulo_host(1, HbkType<T>::v, num_partitions_, &src, &len, &dst,
+                                       &sizes, &idx)
+        : hbk_partition_by_dual_modulo_host(1, HbkType<T>::v, num_partitions_, modulus_, stage_,
+                                            &src, &len, &dst, &sizes, &idx);
+    OP_REQUIRES_OK(ctx, HbkStatus(rc));
+  }
+
+ private:
+  int stage_;
+  int32 num_partitions_;
+  int32 modulus_;
+};
+#define HB_PARTITION_CPU_KERNEL(NAME, STAGE, T)                                          \
+  class NAME##CpuKernel##T : public PartitionCpuOp<T> {                                  \
+   public:                                                                               \
+    explicit NAME##CpuKernel##T(OpKernelConstruction* c) : PartitionCpuOp<T>(c, STAGE) {} \
+  };                                                                                     \
+  REGISTER_KERNEL_BUILDER(Name(#NAME).Device(DEVICE_CPU).TypeConstraint<T>("T"),         \
+                          NAME##CpuKernel##T)
+#define HB_PARTITION_CPU_KERNELS(T)                                  \
+  HB_PARTITION_CPU_KERNEL(HbPartitionByModulo, 0, T);                 \
+  HB_PARTITION_CPU_KERNEL(HbPartitionByDualModuloStageOne, 1, T);     \
+  HB_PARTITION_CPU_KERNEL(HbPartitionByDualModuloStageTwo, 2, T)
+HB_PARTITION_CPU_KERNELS(int32);
+HB_PARTITION_CPU_KERNELS(int64);
+HB_PARTITION_CPU_KERNELS(uint32);
+HB_PARTITION_CPU_KERNELS(uint64);
+
 // ============================================================================================
 // Communicator resource: HbGetNcclId / HbNcclCollectiveHandleOp / HbCreateNcclCollective /
 // HbIsNcclCollectiveInitialized.  The resource owns an hbk_comm_t (RCCL communicator + its
@@ -303,24 +357,63 @@ REGISTER_KERNEL_BUILDER(
 #define HB_DTYPES "{int8, uint8, int32, uint32, int64, uint64, half, float, double}"
 #define HB_WIRE_DTYPES "{half, float}"
 
+// Shape functions as the reference declares them (nccl_alltoall.cc:169-180,242-258,
+// nccl_alltoallv.cc:200-223,359-387): the equal-split ops keep their input's shape, the
+// Alltoallv ops give [?, common_shape...] and pass input_sizes' shape through -- graph
+// construction downstream of the exchange relies on these static shapes.
+static Status AlltoallvShape(InferenceContext* c, const PartialTensorShape& common, int out,
+                             int sizes_out, int sizes_in) {
+  shape_inference::ShapeHandle tail, full;
+  TF_RETURN_IF_ERROR(c->MakeShapeFromPartialTensorShape(common, &tail));
+  TF_RETURN_IF_ERROR(c->Concatenate(c->Vector(InferenceContext::kUnknownDim), tail, &full));
+  c->set_output(out, full);
+  c->set_output(sizes_out, c->input(sizes_in));
+  return Status::OK();
+}
+
 REGISTER_OP("HbNcclAlltoall")
     .Output("output: dtype").Input("handle: resource").Input("input: dtype")
     .Attr("topology: int = 0").Attr("dtype: " HB_DTYPES).Attr("wire_dtype: " HB_WIRE_DTYPES)
-    .SetIsStateful().SetShapeFn(shape_inference::UnchangedShape);
+    .SetIsStateful()
+    .SetShapeFn([](InferenceContext* c) {
+      c->set_output(0, c->input(1));   // (input 0 is the communicator handle)
+      return Status::OK();
+    });
 REGISTER_OP("HbNcclAlltoallN")
     .Output("n_output: N * dtype").Input("handle: resource").Input("n_input: N * dtype")
     .Attr("N: int >= 1 = 1").Attr("topology: int = 0").Attr("dtype: " HB_DTYPES)
-    .Attr("wire_dtype: " HB_WIRE_DTYPES).SetIsStateful();
+    .Attr("wire_dtype: " HB_WIRE_DTYPES).SetIsStateful()
+    .SetShapeFn([](InferenceContext* c) {
+      int64 n;
+      TF_RETURN_IF_ERROR(c->GetAttr("N", &n));
+      for (int64 i = 0; i < n; ++i) c->set_output(i, c->input(1 + i));
+      return Status::OK();
+    });
 REGISTER_OP("HbNcclAlltoallv")
     .Output("output: dtype").Output("output_sizes: int32")
     .Input("handle: resource").Input("input: dtype").Input("input_sizes: int32")
     .Attr("common_shape: shape = {}").Attr("topology: int = 0").Attr("dtype: " HB_DTYPES)
-    .Attr("wire_dtype: " HB_WIRE_DTYPES).SetIsStateful();
+    .Attr("wire_dtype: " HB_WIRE_DTYPES).SetIsStateful()
+    .SetShapeFn([](InferenceContext* c) {
+      PartialTensorShape common;
+      TF_RETURN_IF_ERROR(c->GetAttr("common_shape", &common));
+      return AlltoallvShape(c, common, 0, 1, 2);
+    });
 REGISTER_OP("HbNcclAlltoallvN")
     .Output("n_output: N * dtype").Output("n_output_sizes: N * int32")
     .Input("handle: resource").Input("n_input: N * dtype").Input("n_input_sizes: N * int32")
     .Attr("N: int >= 1 = 1").Attr("common_shape: list(shape)").Attr("topology: int = 0")
-    .Attr("dtype: " HB_DTYPES).Attr("wire_dtype: " HB_WIRE_DTYPES).SetIsStateful();
+    .Attr("dtype: " HB_DTYPES).Attr("wire_dtype: " HB_WIRE_DTYPES).SetIsStateful()
+    .SetShapeFn([](InferenceContext* c) {
+      int64 n;
+      TF_RETURN_IF_ERROR(c->GetAttr("N", &n));
+      std::vector<PartialTensorShape> common;
+      TF_RETURN_IF_ERROR(c->GetAttr("common_shape", &common));
+      for (int64 i = 0; i < n; ++i) {
+        TF_RETURN_IF_ERROR(AlltoallvShape(c, common[i], i, n + i, 1 + n + i));
+      }
+      return Status::OK();
+    });
 
 // Base of the collective ops: looks the communicator up and hops to its thread pool, because
 // the Alltoallv ops block the calling thread once (sizes must reach the host before the

@@ -242,3 +242,78 @@ def test_custom_transport_argument_checks():
   assert lib.hbk_comm_create_custom(C.byref(comm), C.byref(t), 4, 3, 0) == _lib.INVALID_ARGUMENT
   assert 'local_size' in lib.hbk_last_error().decode()
   assert lib.hbk_comm_create_custom(C.byref(comm), C.byref(t), 4, 2, 7) == _lib.INVALID_ARGUMENT
+
+
+def _partition_host(ids, P, modulus=1, stage=0):
+  lib = _lib.lib()
+  code = {np.dtype(np.int32): _lib.INT32, np.dtype(np.int64): _lib.INT64,
+          np.dtype(np.uint32): _lib.UINT32, np.dtype(np.uint64): _lib.UINT64}[ids[0].dtype]
+  outs = [np.empty_like(i) for i in ids]
+  sizes = [np.empty(P, np.int32) for _ in ids]
+  idx = [np.empty(i.size, np.int32) for i in ids]
+  ptrs = lambda arrs: _lib.ptr_array([a.ctypes.data for a in arrs])
+  lens = _lib.i64_array([i.size for i in ids])
+  if stage == 0:
+    rc = lib.hbk_partition_by_modulo_host(len(ids), code, P, ptrs(ids), lens, ptrs(outs),
+                                          ptrs(sizes), ptrs(idx))
+  else:
+    rc = lib.hbk_partition_by_dual_modulo_host(len(ids), code, P, modulus, stage, ptrs(ids), lens,
+                                               ptrs(outs), ptrs(sizes), ptrs(idx))
+  _lib.check(rc)
+  return outs, sizes, idx
+
+
+def test_host_partition_entries_match_the_cpu_functor():
+  """The CPU kernels behind the non-N partition ops (host-memory twins of the device entries):
+  the reference's KATs and property cases, every dtype, plain and dual modulo -- bit-equal to the
+  oracle's restatement of the CPU functors."""
+  import json
+  import oracle
+  g = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'partition.json')))
+  for k in g['modulo']:
+    o, s, i = _partition_host([np.array(k['input'], np.int64)], k['num_partitions'])
+    assert (o[0].tolist(), s[0].tolist(), i[0].tolist()) == (k['output'], k['sizes'], k['indices'])
+  for k in g['dual']:
+    o, s, i = _partition_host([np.array(k['input'], np.int64)], k['num_partitions'],
+                              k['modulus'], k['stage'])
+    assert (o[0].tolist(), s[0].tolist(), i[0].tolist()) == (k['output'], k['sizes'], k['indices'])
+  rng = np.random.RandomState(0)
+  for dt in (np.int32, np.int64, np.uint32, np.uint64):
+    info = np.iinfo(dt)
+    cols = [rng.randint(max(info.min, -2**62), min(info.max, 2**62), size=n).astype(dt)
+            for n in (10000, 0, 1, 777)]
+    for P in (1, 2, 5, 8, 64, 1000):
+      outs, sizes, idx = _partition_host(cols, P)
+      for c, o, s, i in zip(cols, outs, sizes, idx):
+        wo, ws, wi = oracle.partition_by_modulo(c, P)
+        np.testing.assert_equal(o, wo)
+        np.testing.assert_equal(s, ws)
+        np.testing.assert_equal(i, wi)
+        np.testing.assert_equal(o[i], c)          # the reference's own property (partition_test.py:40-59)
+    for P, M, stage in ((2, 2, 1), (2, 2, 2), (4, 3, 1), (4, 3, 2), (8, 1, 2)):
+      outs, sizes, idx = _partition_host(cols, P, M, stage)
+      for c, o, s, i in zip(cols, outs, sizes, idx):
+        wo, ws, wi = oracle.partition_by_dual_modulo(c, P, M, stage)
+        np.testing.assert_equal(o, wo)
+        np.testing.assert_equal(s, ws)
+        np.testing.assert_equal(i, wi)
+  lib = _lib.lib()
+  null, lens = _lib.ptr_array([None]), _lib.i64_array([0])
+  assert lib.hbk_partition_by_modulo_host(1, _lib.FLOAT, 4, null, lens, null, null, null) == \
+      _lib.INVALID_ARGUMENT
+  assert lib.hbk_partition_by_dual_modulo_host(1, _lib.INT64, 4, 2, 3, null, lens, null, null,
+                                               null) == _lib.INVALID_ARGUMENT
+
+
+def test_tf_shim_parses_and_type_checks():
+  """integration/tf_shim/hb_ops_shim.cc -- the REGISTER_OP / REGISTER_KERNEL_BUILDER layer a
+  maintainer compiles against TensorFlow -- is parsed and type-checked against include/hbk.h and
+  a declaration stub of the TensorFlow symbols it uses (no TensorFlow in this image: a syntax
+  check, it pins nothing about TensorFlow)."""
+  import shutil
+  import subprocess
+  if shutil.which('hipcc') is None and not os.path.exists('/opt/rocm/bin/hipcc'):
+    pytest.skip('no hipcc')
+  r = subprocess.run(['make', '-s', '-C', os.path.join(ROOT, 'integration', 'tf_shim'), 'check'],
+                     capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, r.stdout + r.stderr

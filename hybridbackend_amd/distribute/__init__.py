@@ -5,6 +5,7 @@ from hybridbackend_amd.distribute.collective import Topology
 from hybridbackend_amd.distribute.collective import aggregate_gradients
 from hybridbackend_amd.distribute.collective import alltoallv_offsets
 from hybridbackend_amd.distribute.collective import compute_active_ranks
+from hybridbackend_amd.distribute.partition import PartitionByModuloN
 from hybridbackend_amd.distribute.partition import partition_by_dual_modulo_n
 from hybridbackend_amd.distribute.partition import partition_by_dual_modulo_stage_one
 from hybridbackend_amd.distribute.partition import partition_by_dual_modulo_stage_two

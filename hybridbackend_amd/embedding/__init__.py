@@ -6,6 +6,7 @@ from hybridbackend_amd.embedding.lookup import GroupLookup
 from hybridbackend_amd.embedding.lookup import GroupLookupGrad
 from hybridbackend_amd.embedding.lookup import group_lookup
 from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
+from hybridbackend_amd.embedding.unique import UniqueN
 from hybridbackend_amd.embedding.unique import unique
 from hybridbackend_amd.embedding.unique import unique_n
 from hybridbackend_amd.embedding.variables import shard_of_table

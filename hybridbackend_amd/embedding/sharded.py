@@ -210,8 +210,23 @@ class ShardedGroupLookup:
 
   def __call__(self, ids, row_splits=None, outs=None):
     """One forward step through the communicator.  ``ids[c]``: int64 device vector;
-    ``row_splits[c]``: int32 device vector or None.  Returns the per-column outputs."""
-    return self.launch(self.bind(ids, row_splits, outs))
+    ``row_splits[c]``: int32 device vector or None.  Returns the per-column outputs.
+    Handed the SAME tensors as the step before (resident buffers refilled in place, caller-owned
+    ``outs``) the marshalled arguments of that step are reused: validating and marshalling 26
+    columns costs ~130 us of Python, the reuse check ~15."""
+    cached = getattr(self, '_call_cache', None)
+    if cached is not None and outs is not None:
+      key, ptrs, bound = cached
+      tensors = list(ids) + [s for s in (row_splits or []) if s is not None] + list(outs)
+      if key == tuple(id(t) for t in tensors) and all(
+          t.data_ptr() == q and t.numel() == m for t, (q, m) in zip(tensors, ptrs)):
+        return self.launch(bound)
+    bound = self.bind(ids, row_splits, outs)
+    if outs is not None:
+      tensors = list(ids) + [s for s in (row_splits or []) if s is not None] + list(outs)
+      self._call_cache = (tuple(id(t) for t in tensors),
+                          [(t.data_ptr(), t.numel()) for t in tensors], bound)
+    return self.launch(bound)
 
   # ---- backward (SURVEY 3.4) -----------------------------------------------------------------
   # phase B1: d(stitch + combiner): per-id gradient rows in the order of the partitioned ids

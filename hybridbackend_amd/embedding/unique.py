@@ -47,6 +47,58 @@ def unique_n(ids_list):
   return list(zip(uniq, idx, nu))
 
 
+class UniqueN:
+  """A bound ``unique_n`` for loops over the same id buffers: outputs, workspace and the C-ABI
+  arguments are set up once by ``bind``; ``launch`` is one foreign call; ``plan(ids_list)``
+  re-binds only when it is handed other tensors.  Returns what ``unique_n`` returns."""
+
+  def __init__(self):
+    self._bound = None
+
+  def bind(self, ids_list):
+    lib = _lib.lib()
+    ids_list = list(ids_list)
+    n = len(ids_list)
+    if n == 0:
+      raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, 'no inputs')
+    dev = ids_list[0].device
+    for t in ids_list:
+      _lib.require_device_tensor(t, 'ids')
+      if t.dtype != torch.int64 or t.dim() != 1:
+        raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, 'ids must be an int64 vector')
+    counts = [int(t.numel()) for t in ids_list]
+    lens = _lib.i64_array(counts)
+    total = sum(counts)
+    flat_u = torch.empty(total, dtype=torch.int64, device=dev)
+    flat_i = torch.empty(total, dtype=torch.int32, device=dev)
+    flat_n = torch.empty(n, dtype=torch.int32, device=dev)
+    uniq, idx, nu = torch.split(flat_u, counts), torch.split(flat_i, counts), torch.split(flat_n, 1)
+    need = lib.hbk_unique_workspace_bytes(n, lens)
+    ws = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
+    self._bound = dict(
+      key=tuple(id(t) for t in ids_list), ptrs=[t.data_ptr() for t in ids_list], lens=counts,
+      keep=(ids_list, flat_u, flat_i, flat_n, ws), n=n, device=dev,
+      outputs=list(zip(uniq, idx, nu)),
+      args=(_lib.ptr_array([t.data_ptr() for t in ids_list]), lens,
+            _lib.ptr_array([t.data_ptr() for t in uniq]),
+            _lib.ptr_array([t.data_ptr() for t in idx]),
+            _lib.ptr_array([t.data_ptr() for t in nu]),
+            C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel())))
+    return self._bound['outputs']
+
+  def launch(self):
+    b = self._bound
+    _lib.check(_lib.lib().hbk_unique_n(b['n'], *b['args'], _lib.current_stream(b['device'])))
+    return b['outputs']
+
+  def __call__(self, ids_list):
+    b = self._bound
+    if b is None or b['key'] != tuple(id(t) for t in ids_list) or any(
+        t.data_ptr() != q or t.numel() != m for t, q, m in zip(ids_list, b['ptrs'], b['lens'])):
+      self.bind(ids_list)
+    return self.launch()
+
+
 _ws = {}
 
 

@@ -171,6 +171,37 @@ def test_partition_one_launch_and_three_launch_paths(hbk_option, onepass):
 
 # ----------------------------------------------------------------------------------
 # R1 bucketize
+def test_bound_partition_and_unique_plans():
+  """PartitionByModuloN / UniqueN (arguments marshalled once, one foreign call per launch) give
+  what the functional forms give, re-bind when handed other tensors, and see in-place refills."""
+  rng = np.random.RandomState(31)
+  ids = [dev(rng.randint(-2**40, 2**40, size=n).astype(np.int64)) for n in (5000, 0, 70000)]
+  plan = hb.distribute.PartitionByModuloN(8)
+  for rep in range(3):
+    outs, sizes, idx = plan(ids)
+    for i, o, s, x in zip(ids, outs, sizes, idx):
+      wo, ws, wx = oracle.partition_by_modulo(host(i), 8)
+      np.testing.assert_equal(host(o), wo)
+      np.testing.assert_equal(host(s), ws)
+      np.testing.assert_equal(host(x), wx)
+    ids[0].copy_(dev(rng.randint(-2**40, 2**40, size=5000).astype(np.int64)))   # refill in place
+    if rep == 1:
+      ids = [dev(rng.randint(0, 1000, size=n).astype(np.int64)) for n in (100, 7, 3000)]   # other tensors
+  dual = hb.distribute.PartitionByModuloN(2, modulus=2, stage=1)
+  o, s, x = dual([ids[2]])
+  wo, ws, wx = oracle.partition_by_dual_modulo(host(ids[2]), 2, 2, 1)
+  np.testing.assert_equal(host(o[0]), wo)
+  np.testing.assert_equal(host(s[0]), ws)
+  uplan = hb.embedding.UniqueN()
+  for rep in range(2):
+    for i, (u, inv, nu) in zip(ids, uplan(ids)):
+      wu, winv = oracle.unique(host(i))
+      assert int(nu.item()) == wu.size
+      np.testing.assert_equal(host(u)[:wu.size], wu)
+      np.testing.assert_equal(host(inv), winv)
+    ids[2].copy_(dev(rng.randint(0, 50, size=3000).astype(np.int64)))
+
+
 def test_floormod_n():
   rng = np.random.RandomState(1)
   lib = hb._lib.lib()

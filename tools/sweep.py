@@ -214,6 +214,19 @@ def case_integer():
          100 * 100000, 100 * 100000 * (4 + 4 + 4 + 4))
   us = timed(lambda i: hb.embedding.unique_n(ids), iters=10)
   report(f'unique_n 26 x {B} int64', us, 26 * B, 26 * B * (8 + 8 + 4))
+  # the bound forms: arguments marshalled once, a call is one foreign call
+  for P in (2, 8):
+    plan = hb.distribute.PartitionByModuloN(P)
+    plan.bind(ids)
+    us = timed(lambda i: plan.launch(), iters=20)
+    report(f'PartitionByModuloN(bound) 26 x {B} int64 P={P}', us, 26 * B, 26 * B * (8 + 8 + 8 + 4))
+    us = timed(lambda i: plan(ids), iters=20)
+    report(f'PartitionByModuloN(call, same tensors) 26 x {B} int64 P={P}', us, 26 * B,
+           26 * B * (8 + 8 + 8 + 4))
+  uplan = hb.embedding.UniqueN()
+  uplan.bind(ids)
+  us = timed(lambda i: uplan.launch(), iters=10)
+  report(f'UniqueN(bound) 26 x {B} int64', us, 26 * B, 26 * B * (8 + 8 + 4))
 
 
 def case_bwd_probe():

@@ -25,8 +25,9 @@ ids.  Here every slice additionally records its ownership (``stride = W``, ``pha
 * ``layout='reference'`` reproduces the reference's view (contiguous slices of the concatenated
   shards) for tools that expect it; ``load_full(prefix, name)`` returns the logical table.
 
-The files are this library's own (``<prefix>.index`` is JSON, ``<prefix>.data-<r>-of-<W>`` raw
-little-endian tensors), not TensorFlow's tensor-bundle format: TensorFlow is not available to
+The files are this library's own (``<prefix>.index`` is JSON, ``<prefix>.data-g<generation>-<r>-of-<W>``
+raw little-endian tensors; a save never overwrites the files the current index points to and
+switches over with one atomic rename of the index), not TensorFlow's tensor-bundle format: TensorFlow is not available to
 this build (DESIGN.md "out of scope").  The host logic is device agnostic (CPU tensors work, which
 is how the tests without a GPU drive it); GPU tensors travel through pinned memory.
 """
@@ -38,7 +39,10 @@ import numpy as np
 import torch
 
 _DTYPES = {'float32': np.float32, 'float64': np.float64, 'int32': np.int32, 'int64': np.int64,
-           'float16': np.float16}
+           'float16': np.float16, 'uint8': np.uint8, 'int8': np.int8, 'int16': np.int16,
+           # numpy has no bfloat16: the bits travel as int16 and the index keeps the real name
+           'bfloat16': np.int16}
+_TORCH_DTYPES = {'bfloat16': torch.bfloat16}
 
 
 class ShardedSlice:
@@ -61,12 +65,19 @@ class ShardedSlice:
 
 
 def _to_numpy(t):
+  """(array, dtype name): bfloat16 tensors are written as their 16-bit patterns."""
   t = t.detach()
   if t.is_cuda:
     host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host.copy_(t, non_blocking=False)
     t = host
-  return np.ascontiguousarray(t.cpu().numpy())
+  t = t.cpu().contiguous()
+  if t.dtype == torch.bfloat16:
+    return np.ascontiguousarray(t.view(torch.int16).numpy()), 'bfloat16'
+  arr = np.ascontiguousarray(t.numpy())
+  if str(arr.dtype) not in _DTYPES:
+    raise ValueError(f'unsupported dtype {arr.dtype} in a checkpoint')
+  return arr, str(arr.dtype)
 
 
 class Saver:
@@ -96,8 +107,8 @@ class Saver:
         sharded = isinstance(v, ShardedSlice)
         if not sharded and self.rank != 0:
           continue                      # only sharded saveables for non-chief workers
-        arr = _to_numpy(v.tensor if sharded else v)
-        e = {'name': name, 'dtype': str(arr.dtype), 'shape': list(arr.shape), 'offset': off,
+        arr, dtype_name = _to_numpy(v.tensor if sharded else v)
+        e = {'name': name, 'dtype': dtype_name, 'shape': list(arr.shape), 'offset': off,
              'nbytes': int(arr.nbytes)}
         if sharded:
           e.update(full_shape=[v.bucket_size, int(arr.shape[1])], var_offset=[v.var_offset, 0],
@@ -114,11 +125,27 @@ class Saver:
     return prefix
 
   def _merge(self, prefix, tmp_dir):
+    """Crash safety: the data files of a save carry a generation tag in their names, so they
+    never overwrite the files an existing index points to; the index is written to a temporary
+    file and moved into place LAST (one atomic rename switches the checkpoint over), and only
+    then are the previous generation's data files removed."""
     index = {'format': 'hbk-sharded-checkpoint-1', 'world_size': self.world_size, 'variables': {}}
+    folder = os.path.dirname(prefix) or '.'
+    base = os.path.basename(prefix)
+    old_files = set()
+    if os.path.exists(prefix + '.index'):
+      try:
+        for var in _read_index(prefix)['variables'].values():
+          old_files.update(s['file'] for s in var['slices'])
+      except (ValueError, KeyError, json.JSONDecodeError):
+        pass
+    gen = 0
+    while any(f'{base}.data-g{gen}-' in f for f in old_files):
+      gen += 1
     for r in range(self.world_size):
       part = os.path.join(tmp_dir, f'part-{r:05d}-of-{self.world_size:05d}')
-      data = f'{os.path.basename(prefix)}.data-{r:05d}-of-{self.world_size:05d}'
-      os.replace(part + '.data', os.path.join(os.path.dirname(prefix) or '.', data))
+      data = f'{base}.data-g{gen}-{r:05d}-of-{self.world_size:05d}'
+      os.replace(part + '.data', os.path.join(folder, data))
       for e in json.load(open(part + '.json')):
         var = index['variables'].setdefault(
           e['name'], {'dtype': e['dtype'], 'slices': [],
@@ -127,8 +154,16 @@ class Saver:
           'file': data, 'offset': e['offset'], 'nbytes': e['nbytes'], 'var_shape': e['shape'],
           'var_offset': e.get('var_offset', [0] * len(e['shape'])),
           'stride': e.get('stride', 1), 'phase': e.get('phase', 0)})
-    with open(prefix + '.index', 'w') as f:
+    with open(prefix + '.index.tmp', 'w') as f:
       json.dump(index, f, indent=1, sort_keys=True)
+      f.flush()
+      os.fsync(f.fileno())
+    os.replace(prefix + '.index.tmp', prefix + '.index')
+    for name in old_files:
+      try:
+        os.remove(os.path.join(folder, name))
+      except OSError:
+        pass
     shutil.rmtree(tmp_dir, ignore_errors=True)    # delete_old_dirs=True
 
   # -- restore ---------------------------------------------------------------------------------
@@ -161,7 +196,10 @@ class Saver:
         target = v
       if tuple(arr.shape) != tuple(target.shape):
         raise ValueError(f'{name}: checkpoint shape {tuple(arr.shape)} != {tuple(target.shape)}')
-      target.copy_(torch.from_numpy(np.array(arr, copy=True)).to(target.dtype))
+      host = torch.from_numpy(np.array(arr, copy=True))
+      if meta['dtype'] in _TORCH_DTYPES:
+        host = host.view(_TORCH_DTYPES[meta['dtype']])
+      target.copy_(host.to(target.dtype))
     self._barrier()
 
 
@@ -175,6 +213,8 @@ def _read_index(prefix):
 
 def _load_slice(prefix, meta, s):
   path = os.path.join(os.path.dirname(prefix) or '.', s['file'])
+  if s['nbytes'] == 0:      # a rank without rows (bucket_size < world_size): nothing to map
+    return np.empty(tuple(s['var_shape']), _DTYPES[meta['dtype']])
   return np.memmap(path, dtype=_DTYPES[meta['dtype']], mode='r', offset=s['offset'],
                    shape=tuple(s['var_shape']))
 

@@ -56,7 +56,9 @@ def test_layout_of_the_files_and_slice_info(tmp_path):
   table = rng.randn(R, D).astype(np.float32)
   prefix = _save(tmp_path, W, table, np.full((R, D), 0.1, np.float32), rng.randn(5, 4).astype(np.float32))
   files = sorted(os.listdir(tmp_path))
-  assert files == ['model.ckpt-100.data-00000-of-00002', 'model.ckpt-100.data-00001-of-00002',
+  # (g0: the generation tag -- a later save under the same prefix writes g1 files and switches the
+  # index over with one rename)
+  assert files == ['model.ckpt-100.data-g0-00000-of-00002', 'model.ckpt-100.data-g0-00001-of-00002',
                    'model.ckpt-100.index']                 # the temporary directory is gone
   index = json.load(open(prefix + '.index'))
   var = index['variables']['cat_embedding/embedding_weights']
@@ -66,7 +68,7 @@ def test_layout_of_the_files_and_slice_info(tmp_path):
     assert s['var_shape'] == [rows, D] and s['var_offset'] == [offset, 0]
     assert (s['stride'], s['phase']) == (W, r)
   small = index['variables']['small_embedding/embedding_weights']
-  assert len(small['slices']) == 1 and small['slices'][0]['file'].endswith('data-00000-of-00002')
+  assert len(small['slices']) == 1 and small['slices'][0]['file'].endswith('data-g0-00000-of-00002')
   np.testing.assert_equal(load_full(prefix, 'cat_embedding/embedding_weights'), table)
   # the reference's "full tensor" is the concatenation of the shards: a permutation of the table
   ref_view = load_full(prefix, 'cat_embedding/embedding_weights', layout='reference')
@@ -135,3 +137,42 @@ def test_errors(tmp_path):
                                  ShardedSlice(torch.zeros(30, 4), 60, 2, 0)})   # other bucket size
   with pytest.raises(ValueError):
     Saver(0, 1).restore(prefix, {'small_embedding/embedding_weights': torch.zeros(3, 3)})
+
+
+def test_fewer_rows_than_ranks_bfloat16_and_overwrite(tmp_path):
+  """A 3-row table on 4 ranks (rank 3 holds nothing: an empty data file must load), bfloat16 and
+  uint8 tensors, and saving twice under one prefix: the second save replaces the first through
+  the index (old data files gone, no file of the live index ever overwritten)."""
+  import threading
+  from hybridbackend_amd.training.saver import Saver, ShardedSlice, load_full
+  prefix = str(tmp_path / 'ckpt')
+  W, B = 4, 3
+  for gen in range(2):
+    table = torch.arange(B * 2, dtype=torch.float32).reshape(B, 2) + 100 * gen
+    bar = threading.Barrier(W)
+    errors = []
+
+    def run(r):
+      try:
+        shard = table[r::W].clone()
+        extra = {'bf': torch.tensor([1.5, -2.25, 3.0], dtype=torch.bfloat16) + gen,
+                 'u8': torch.tensor([1, 2, 250], dtype=torch.uint8)}
+        Saver(r, W, bar.wait).save(prefix, {'t': ShardedSlice(shard, B, W, r), **extra})
+      except Exception as e:  # pylint: disable=broad-except
+        errors.append(repr(e))
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(W)]
+    for t in ts:
+      t.start()
+    for t in ts:
+      t.join()
+    assert not errors, errors
+    np.testing.assert_equal(load_full(prefix, 't'), table.numpy())
+    np.testing.assert_equal(load_full(prefix, 't', layout='reference'), table.numpy())
+    got = {'t': ShardedSlice(torch.zeros(2, 2), B, 2, 0), 'bf': torch.zeros(3, dtype=torch.bfloat16),
+           'u8': torch.zeros(3, dtype=torch.uint8)}
+    Saver().restore(prefix, got)
+    assert torch.equal(got['t'].tensor, table[0::2])
+    assert torch.equal(got['bf'], torch.tensor([1.5, -2.25, 3.0], dtype=torch.bfloat16) + gen)
+    assert got['u8'].tolist() == [1, 2, 250]
+    files = sorted(f for f in os.listdir(tmp_path) if '.data-' in f)
+    assert len(files) == W and all(f'-g{gen}-' in f for f in files), files

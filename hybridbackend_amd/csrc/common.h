@@ -182,6 +182,24 @@ inline SyncWait sync_wait_of(const SyncTake& t) {
 // partitioned modes), as when the stream is being captured or a wait has run out before.
 bool sync_take(hipStream_t stream, size_t words, SyncTake* out, const void* kernel = nullptr,
                int block = 0, int max_column_wgs = 0);
+// Kernels whose tiles wait for tiles launched AFTER them (partition_onepass, unique_group,
+// bwd_group) must not run beside each other: two of them on different streams can each fill the
+// chip's workgroup slots with waiting tiles while the tiles they wait for find no slot -- a
+// deadlock (seen: two launch groups of the config-5 backward on the library's helper streams; the
+// bounded wait turned it into an error instead of a hang).  They are therefore chained
+// device-wide: a launch waits (stream-side, no host block) for the event recorded behind the
+// previous such launch on whatever stream that ran.  Hold the guard around the launch.
+class SyncChain {
+ public:
+  explicit SyncChain(hipStream_t stream);
+  ~SyncChain();
+  SyncChain(const SyncChain&) = delete;
+  SyncChain& operator=(const SyncChain&) = delete;
+
+ private:
+  hipStream_t stream_;
+  void* state_;
+};
 int32_t* sync_status();
 // HBK_OK, or -- ONCE per timed-out wait -- HBK_INTERNAL with the story in hbk_last_error(); the
 // one-launch forms are then off for the rest of the process (option sync_onepass_off)

@@ -2886,6 +2886,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     }
     if (onepass) {
       // (hist, scan and scatter are this one launch)
+      SyncChain chain(ls);   // never beside another kernel whose tiles wait for later tiles
       hipLaunchKernelGGL(bwd_group_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ls, args,
                          sync);
     } else {

@@ -769,6 +769,7 @@ __global__ __launch_bounds__(kOneWaves* kWave) void partition_onepass_kernel(con
 
 template <typename T>
 int launch_onepass(const PartArgs& args, const OnePass& o, hipStream_t stream) {
+  SyncChain chain(stream);   // never beside another kernel whose tiles wait for later tiles
   hipLaunchKernelGGL(partition_onepass_kernel<T>,
                      dim3((unsigned)((args.total_tiles + kOneWaves - 1) / kOneWaves)),
                      dim3(kOneWaves * kWave), 0, stream, args, o);

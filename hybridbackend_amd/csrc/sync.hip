@@ -33,6 +33,49 @@ struct SyncSlot {
 };
 }  // namespace
 
+namespace {
+struct ChainState {
+  std::mutex mu;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  int cur = 0;
+  bool have = false;
+  hipStream_t last = nullptr;
+};
+ChainState* chain_of_device() {
+  static std::mutex table_mu;
+  static std::map<int, ChainState*> table;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(table_mu);
+  auto it = table.find(dev);
+  if (it != table.end()) return it->second;
+  ChainState* c = new ChainState();
+  if (hipEventCreateWithFlags(&c->ev[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev[1], hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    c = nullptr;
+  }
+  table[dev] = c;
+  return c;
+}
+}  // namespace
+
+SyncChain::SyncChain(hipStream_t stream) : stream_(stream), state_(chain_of_device()) {
+  ChainState* c = reinterpret_cast<ChainState*>(state_);
+  if (c == nullptr) return;
+  c->mu.lock();
+  if (c->have && c->last != stream_) (void)hipStreamWaitEvent(stream_, c->ev[c->cur], 0);
+}
+
+SyncChain::~SyncChain() {
+  ChainState* c = reinterpret_cast<ChainState*>(state_);
+  if (c == nullptr) return;
+  c->cur ^= 1;
+  c->have = hipEventRecord(c->ev[c->cur], stream_) == hipSuccess;
+  c->last = stream_;
+  c->mu.unlock();
+}
+
 int32_t* sync_status() {
   static int32_t* word = [] {
     void* q = nullptr;

@@ -911,7 +911,10 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
     args.pad_ = 0;
     const dim3 block(kBlock);
     if (onepass) {
-      hipLaunchKernelGGL(unique_group_kernel, dim3((unsigned)big), block, 0, stream, args, sync);
+      {
+        SyncChain chain(stream);   // never beside another kernel whose tiles wait for later tiles
+        hipLaunchKernelGGL(unique_group_kernel, dim3((unsigned)big), block, 0, stream, args, sync);
+      }
       hipLaunchKernelGGL(unique_first_kernel, dim3((unsigned)buckets), dim3(kFirstBlock), 0, stream, args,
                          (const int32_t*)sync.wait.poison);
       hipLaunchKernelGGL(unique_order_kernel, dim3((unsigned)tiles), block, 0, stream, args, sync);

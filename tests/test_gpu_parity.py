@@ -184,7 +184,7 @@ def test_bound_partition_and_unique_plans():
       np.testing.assert_equal(host(o), wo)
       np.testing.assert_equal(host(s), ws)
       np.testing.assert_equal(host(x), wx)
-    ids[0].copy_(dev(rng.randint(-2**40, 2**40, size=5000).astype(np.int64)))   # refill in place
+    ids[0].copy_(dev(rng.randint(-2**40, 2**40, size=ids[0].numel()).astype(np.int64)))   # refill in place
     if rep == 1:
       ids = [dev(rng.randint(0, 1000, size=n).astype(np.int64)) for n in (100, 7, 3000)]   # other tensors
   dual = hb.distribute.PartitionByModuloN(2, modulus=2, stage=1)

@@ -163,3 +163,69 @@ def test_sharded_step_fails_in_the_call_that_suffered_the_timeout(hbk_option):
     assert _sync_check() == 0
   finally:
     coll.close()
+
+
+def test_one_launch_kernels_from_concurrent_streams_never_run_beside_each_other(hbk_option):
+  """Two kernels whose tiles wait for later tiles, on two streams, can deadlock each other (each
+  fills the chip with waiting tiles).  The library chains them device-wide.  Here four host
+  threads on four streams hammer partition / unique / backward (the config-5 backward did this to
+  itself through the library's helper streams): every result right, no wait runs out."""
+  import threading
+  hbk_option('sync_onepass_off', 0)
+  hbk_option('sync_wait_ms', 500)
+  errors, checks = [], []
+
+  def worker(t):
+    try:
+      rng = np.random.RandomState(100 + t)
+      with torch.cuda.stream(torch.cuda.Stream()):
+        mine = []
+        for rep in range(12):
+          for which in ('partition', 'unique', 'bwd'):
+            mine.append(_run(which, rng))
+        torch.cuda.current_stream().synchronize()
+        checks.extend(mine)
+    except Exception as e:  # pylint: disable=broad-except
+      import traceback
+      errors.append(traceback.format_exc())
+
+  threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=120)
+  torch.cuda.synchronize()
+  assert not errors, errors
+  assert _sync_check() == 0
+  assert _lib.get_option('sync_onepass_off') == 0
+  for check in checks:
+    check()
+
+
+def test_config5_shaped_backward_runs_its_launch_groups_side_by_side(hbk_option):
+  """150 one-launch columns = three launch groups on the library's helper streams: their grouping
+  kernels are chained, everything else overlaps; no wait runs out and the result is right."""
+  hbk_option('sync_onepass_off', 0)
+  hbk_option('sync_wait_ms', 500)
+  rng = np.random.RandomState(9)
+  n_cols, n = 150, 20000
+  rows = [int(10 ** rng.uniform(3, 5.5)) for _ in range(n_cols)]
+  dims = [[4, 8, 16, 32][c % 4] for c in range(n_cols)]
+  tables = [torch.zeros(r, d, device=DEV) for r, d in zip(rows, dims)]
+  ids = [torch.randint(0, r, (n,), device=DEV) for r in rows]
+  grads = [torch.randn(n, d, device=DEV) for d in dims]
+  lookup = hb.embedding.GroupLookup(tables, None, 'sum')
+  grad = hb.embedding.GroupLookupGrad(lookup)
+  for rep in range(3):
+    res = grad(ids, grads, apply_lr=0.0)
+  torch.cuda.synchronize()
+  assert _sync_check() == 0
+  for c in range(0, n_cols, 7):
+    urows, grows, nu = res[c]
+    k = int(nu.item())
+    uniq, inv = torch.unique(ids[c], return_inverse=True)
+    assert k == uniq.numel()
+    order = torch.argsort(urows[:k])
+    assert torch.equal(urows[:k][order], uniq)
+    dense = torch.zeros(k, dims[c], device=DEV, dtype=torch.float64).index_add_(0, inv, grads[c].double())
+    torch.testing.assert_close(grows[:k][order].double(), dense, rtol=1e-5, atol=1e-5)

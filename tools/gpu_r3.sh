@@ -107,6 +107,14 @@ for k,v in sorted(d.items()):
   if 'group_lookup_fwd' in k: print(k[:70].ljust(70), {c:(round(x['mean']), x.get('n')) for c,x in v.items()})
 PY
       done;;
+    profsweep)   # kernel stats of sweep cases, dense (row-range) buckets on / off
+      for dense in 1 0; do
+        export HBK_BWD_DENSE=$dense
+        prof prof_sweep_dense$dense "" -- python $R/tools/sweep.py --big --cases ${SWEEP_CASES:-d,h}
+        grep "^{" $O/prof_sweep_dense$dense.log | cut -c1-200
+        grep -E "bwd_|kernel  " $O/prof_sweep_dense$dense.txt | head -24
+      done
+      unset HBK_BWD_DENSE;;
     sweep)
       timeout 1200 python tools/sweep.py --big --cases ${SWEEP_CASES:-a,b,c,d,e,f,g,h,i} > $O/sweep.log 2>&1; echo "sweep rc=$?" >> $O/sweep.log; cut -c1-400 $O/sweep.log;;
     *) echo "unknown stage $st";;

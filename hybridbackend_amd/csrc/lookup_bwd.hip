@@ -1498,10 +1498,10 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
 // Every row is complete when it is emitted whatever the number of chunks: no rows spanning chunks,
 // no deferred step, no second pass.  Jobs of several chunks (a bucket above kCP pairs, the ranges
 // of a split bucket, the merge of their partial entries) read their pairs once per stage.
-// workgroups per CU the dense kernels are compiled for: 5 (96 VGPRs) without the optimizer step,
-// 4 (128 VGPRs) with it -- the step's table / accumulator rows spill at 96
+// workgroups per CU the dense kernels are compiled for: 5 (96 VGPRs) for the lean instantiation,
+// 4 (128 VGPRs) for the one with the sorted walk (it spills at 96)
 #ifndef HBK_BWD_DENSE_WAVES
-#define HBK_BWD_DENSE_WAVES(STEP) ((STEP) ? 4 : 5)
+#define HBK_BWD_DENSE_WAVES(SORT) ((SORT) ? 4 : 5)
 #endif
 #ifndef HBK_BWD_DENSE_WALK
 #define HBK_BWD_DENSE_WALK(STEP) ((STEP) == 2 ? 2 : (STEP) ? 3 : 4)
@@ -1727,8 +1727,39 @@ __device__ inline void dense_walk(const WalkArgs w_, DenseLds& L) {
   }
 }
 
-template <typename V, int STEP>
-__device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLds& L, int bucket) {
+// The first chunk of a job's pairs, requested ahead of the job (persistent workgroups: while the
+// job before is still running).
+struct FirstPairs {
+  int64_t row[kCP / kBlock];
+  int32_t seg[kCP / kBlock];
+};
+
+__device__ inline void load_first_pairs(const ReduceJob& job, FirstPairs& f) {
+#pragma unroll
+  for (int k = 0; k < kCP / kBlock; ++k) {
+    const int32_t e = k * kBlock + (int)threadIdx.x;
+    f.row[k] = -1;
+    f.seg[k] = e;
+    if (e < job.n_pairs) {
+      f.row[k] = job.prow[e];
+      if (job.pseg != nullptr) f.seg[k] = job.pseg[e];
+    }
+  }
+}
+
+struct NoHook {
+  __device__ void operator()() const {}
+};
+
+// `first`: the job's first chunk of pairs (already requested).  `hook`: called once, behind
+// stage B -- where a persistent workgroup requests the NEXT job's pairs, so that they travel
+// beside this job's gradient rows.
+// SORT: the instantiation that counting-sorts many dup pairs and walks them flat (D); without it
+// every dup pair goes through the LDS float atomics -- right for any input, slow for many -- and
+// the common path of a column with few repeated rows is ~10 % faster for not carrying that code.
+template <typename V, int STEP, bool SORT, typename Hook = NoHook>
+__device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLds& L, int bucket,
+                                    const FirstPairs& first, Hook hook = Hook()) {
   constexpr int VE = sizeof(V) / 4;
   constexpr int PT = kCP / kBlock;   // pairs per thread and chunk
   const int tid = (int)threadIdx.x;
@@ -1761,7 +1792,11 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
       }
     }
   };
-  load_pairs(0);   // they travel while the bitmaps are cleared
+#pragma unroll
+  for (int k = 0; k < PT; ++k) {   // (requested by the caller; they travel while the bitmaps are cleared)
+    r_in[k] = first.row[k];
+    seg_in[k] = first.seg[k];
+  }
   const uint32_t M = c.dense_mul;
   const uint32_t base = (uint32_t)dense_first_row(M, bucket);
   uint64_t lim = dense_first_row(M, bucket + 1);
@@ -1773,7 +1808,9 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
     L.present[w] = 0u;
     L.dup[w] = 0u;
   }
-  for (int i = tid; i < kCP; i += kBlock) L.dcnt[i] = 0;
+  if (SORT) {
+    for (int i = tid; i < kCP; i += kBlock) L.dcnt[i] = 0;
+  }
   if (tid == 0) {
     L.n_dlist[0] = 0;
     L.n_dlist[1] = 0;
@@ -1863,6 +1900,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
       }
     }
   }
+  hook();   // (the next job's pairs are requested here)
   __syncthreads();
   HBK_STAMP(4);
 
@@ -1908,7 +1946,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
             if (dr >= d0 && dr < d1) {
               listed = true;
               m_[k] = dr - d0;
-              tk_[k] = atomicAdd(&L.dcnt[dr - d0], 1);
+              if (SORT) tk_[k] = atomicAdd(&L.dcnt[dr - d0], 1);
               L.doff[dr - d0] = (uint16_t)off;   // (every pair of the row writes the same value)
             }
           }
@@ -1934,7 +1972,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
       // tickets taken above) and walked in D; the tickets leave the registers before C needs them
       const int n_dl = L.n_dlist[par];
       const int nd = d1 - d0;
-      const bool sorted = HBK_DENSE_SORT && n_dl > kSortMin;   // uniform
+      const bool sorted = SORT && HBK_DENSE_SORT && n_dl > kSortMin;   // uniform
       if (__builtin_expect(sorted, 0)) {
         {
           int32_t cn[PT], sum = 0;
@@ -1970,7 +2008,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
         if (!last_use) {
           for (int i = tid; i < nd; i += kBlock) L.dcnt[i] = 0;   // (next read: behind a barrier)
         }
-      } else if (!last_use) {
+      } else if (SORT && !last_use) {
         for (int i = tid; i < nd; i += kBlock) L.dcnt[i] = 0;   // (next read: behind a barrier)
       }
 
@@ -2221,11 +2259,13 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
 }
 
 
-template <typename V, int STEP>
-__global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(STEP)) void bwd_dense_kernel(const GArgs a,
-                                                                               const int4* desc,
-                                                                               int slot0, int total,
-                                                                               const int32_t* poison) {
+// (Persistent workgroups that request the next job's descriptor and pairs while the current job
+// runs -- the two dependent round trips at the head of a job are 5 of its ~14 us -- measured 5 %
+// SLOWER on the config-2 backward and 10 % slower on ragged columns: the registers that carry the
+// next job's pairs cost more than the round trips they hide.)
+template <typename V, int STEP, bool SORT>
+__global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(SORT)) void bwd_dense_kernel(
+    const GArgs a, const int4* desc, int slot0, int total, const int32_t* poison) {
   __shared__ DenseLds lds;
   if (poisoned(poison)) return;   // the grouping launch gave up: no descriptors, no pairs
   HBK_STAMP_BEGIN()
@@ -2237,8 +2277,10 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(STEP)) void bwd_dense_k
   ReduceJob job;
   int ci;
   if (!decode_job<V, true>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
+  FirstPairs first;
+  load_first_pairs(job, first);
   HBK_STAMP(1);
-  dense_reduce<V, STEP>(a.col[ci], job, lds, d.z);
+  dense_reduce<V, STEP, SORT>(a.col[ci], job, lds, d.z, first);
   HBK_STAMP(7);
 }
 
@@ -2309,7 +2351,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const 
 }
 
 template <typename V, int STEP>
-__global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(STEP)) void bwd_dense_merge_kernel(const GArgs a,
+__global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(true)) void bwd_dense_merge_kernel(const GArgs a,
                                                                                      int block0,
                                                                                      const int32_t* poison) {
   __shared__ DenseLds lds;
@@ -2322,7 +2364,9 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(STEP)) void bwd_dense_m
     if (c.work[2 * e + 1] != 1) continue;   // uniform
     ReduceJob job;
     merge_job(a, c, c.work[2 * e], &job);
-    dense_reduce<V, STEP>(c, job, lds, c.work[2 * e]);
+    FirstPairs first;
+    load_first_pairs(job, first);
+    dense_reduce<V, STEP, true>(c, job, lds, c.work[2 * e], first);
   }
   merge_done(c, blocks);
 }
@@ -2428,6 +2472,7 @@ struct ColPlan {
   int32_t split_t;   // a bucket above this many pairs is reduced by several workgroups
   int32_t e_max;
   uint32_t dense_mul;   // != 0: row-range buckets (4b)
+  bool dense_sort;      // the dense instantiation with the sorted walk (many repeated rows expected)
 };
 
 // options (hbk_set_option): bwd_buckets_log2 forces the bucket count to 1 << value (0 = one
@@ -2436,8 +2481,7 @@ struct ColPlan {
 // keeps hashed buckets for every column
 int forced_log2p() { return options().bwd_buckets_log2; }
 
-ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows) {
-  (void)dim;
+ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged) {
   ColPlan p;
   // Aim at 7/8 of a chunk per bucket: bucket sizes are Poisson around the aim, so ~0.1 % of the
   // buckets need a second (short) chunk, while the per-workgroup fixed cost (table init,
@@ -2453,13 +2497,26 @@ ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows) {
   // Dense: bucket = floor(row * M / 2^32) with M = floor(2^32 P / rows) (< 2^32: P <= rows; any
   // smaller M is still a monotone map into [0, P)); a bucket then spans at most ceil(2^32 / M)
   // rows, which must fit the reduce stage's LDS bitmaps.
+  // Where dense pays (measured, 26 x 65536 ids through the C ABI; profiles/r03_bwd_*):
+  //  * narrow rows only (dim <= 32: >= 32 rows per load instruction of the workgroup).  Wide rows
+  //    lose to the hashed path: dim 128 uniform 417 vs 389 us, Zipf 482 vs 351 us; dim 64 with 3
+  //    pairs per row 210 vs 165 us;
+  //  * columns with one id per sample.  Ragged ones (8 ids per sample, 100 k rows) 780-880 vs 780 us;
+  //  * few repeated rows expected (ids <= rows / 8, uniform config 2: ~14 of a bucket's 450 pairs):
+  //    the LEAN instantiation, ~97-100 vs 110 us; more: the one with the sorted walk, 99 / 116 vs
+  //    107 / 126 us at 33 / 330 pairs per row.
+  // bwd_dense = 2 forces dense (with the sorted walk) wherever the row range fits.
   p.dense_mul = 0;
-  if (kTeam == kBlock && options().bwd_dense != 0 && rows >= 1 && rows < (1ll << 32)) {
+  p.dense_sort = true;
+  const bool forced_dense = options().bwd_dense == 2;
+  const bool eligible = forced_dense || (dim <= 32 && !ragged);
+  if (kTeam == kBlock && options().bwd_dense != 0 && eligible && rows >= 1 && rows < (1ll << 32)) {
     const int64_t P = nb < rows ? nb : rows;
     uint64_t M = ((uint64_t)P << 32) / (uint64_t)rows;
     if (M > 0xffffffffull) M = 0xffffffffull;
     if (M >= 1 && (((uint64_t)1 << 32) + M - 1) / M <= (uint64_t)kDenseSpan) {
       p.dense_mul = (uint32_t)M;
+      p.dense_sort = forced_dense || n_ids > rows / 8;
       nb = P;
     }
   }
@@ -2477,7 +2534,7 @@ ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows) {
 
 size_t col_workspace(const hbk_lookup_grad_column_t& h) {
   if (h.n_ids <= 0) return 0;
-  const ColPlan p = plan_of(h.n_ids, h.dim, h.rows);
+  const ColPlan p = plan_of(h.n_ids, h.dim, h.rows, h.row_splits != nullptr);
   size_t b = align8(((size_t)p.tiles * p.n_buckets) * 4);   // hist
   b += align8(((size_t)p.n_buckets + 1) * 4);          // bstart
   b += (size_t)h.n_ids * 8;                                // pair_row
@@ -2558,6 +2615,23 @@ struct BwdHelpers {
   hipEvent_t fork, join[kHelperStreams];
   std::mutex mu;
 };
+
+// compute units of the current device (cached)
+int device_cus() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cus.find(dev);
+  if (it != cus.end()) return it->second;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    n = 256;
+  }
+  cus[dev] = n;
+  return n;
+}
 
 BwdHelpers* bwd_helpers(hipStream_t caller) {
   static std::mutex table_mu;
@@ -2656,7 +2730,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
   char* wp = dp;
   for (int32_t c = 0; c < n_cols; ++c) {
     if (cols[c].n_ids <= 0) continue;
-    const ColPlan p = plan_of(cols[c].n_ids, cols[c].dim, cols[c].rows);
+    const ColPlan p = plan_of(cols[c].n_ids, cols[c].dim, cols[c].rows, cols[c].row_splits != nullptr);
     wp += ((size_t)p.n_buckets + p.e_max) * sizeof(int4);
   }
 
@@ -2665,8 +2739,9 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
   struct ColInfo {
     ColPlan p;
     RowShape shape;
-    int kind;       // (dense ? 0 : 2) + (16-byte chunks ? 0 : 1): columns of a launch group are
-                    // sorted by it, so every kernel instantiation runs on ONE range of job slots
+    int kind;       // 2 * (0 dense lean | 1 dense with the sorted walk | 2 hashed) + (16-byte chunks ?
+                    // 0 : 1): columns of a launch group are sorted by it, so every kernel
+                    // instantiation runs on ONE range of job slots
     bool onepass;   // small enough for the one-launch grouping (bwd_group_kernel)
   };
   std::vector<ColInfo> info((size_t)n_cols);
@@ -2677,7 +2752,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       if (h.n_ids <= 0) continue;
       ColInfo& ci = info[(size_t)c];
       if (pass == 0) {
-        ci.p = plan_of(h.n_ids, h.dim, h.rows);
+        ci.p = plan_of(h.n_ids, h.dim, h.rows, h.row_splits != nullptr);
         HBK_REQUIRE(h.grad_stride == 0 || (h.grad_stride >= h.dim && h.n_runs == 0),
                     "group_lookup_bwd: column %d: bad grad_stride %d", c, h.grad_stride);
         HBK_REQUIRE(make_rowshape(h.dim,
@@ -2686,7 +2761,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
                                       (apply_lr != 0.0f ? (uintptr_t)h.table | (uintptr_t)h.accum : 0),
                                   &ci.shape),
                     "group_lookup_bwd: dim %d needs more than 64 lanes per row", h.dim);
-        ci.kind = (ci.p.dense_mul != 0 ? 0 : 2) + (ci.shape.vec4 ? 0 : 1);
+        ci.kind = 2 * (ci.p.dense_mul == 0 ? 2 : ci.p.dense_sort ? 1 : 0) + (ci.shape.vec4 ? 0 : 1);
         ci.onepass = options().bwd_onepass != 0 && ci.p.n_buckets <= kGroupMaxBuckets &&
                      ci.p.tiles <= 64;
       }
@@ -2748,9 +2823,10 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     int64_t tiles = 0, buckets = 0, segtiles = 0, merges = 0, scans = 0, sync_words = 0;
     size_t lds_hist = 0;
     bool small_scan = true;
-    int64_t slot_lo[4] = {0, 0, 0, 0}, slot_hi[4] = {0, 0, 0, 0};     // job slots of every kind
-    int64_t merge_lo[4] = {0, 0, 0, 0}, merge_hi[4] = {0, 0, 0, 0};   // merge blocks of every kind
-    bool have_kind[4] = {false, false, false, false};
+    constexpr int kKinds = 6;
+    int64_t slot_lo[kKinds] = {0}, slot_hi[kKinds] = {0};     // job slots of every kind
+    int64_t merge_lo[kKinds] = {0}, merge_hi[kKinds] = {0};   // merge blocks of every kind
+    bool have_kind[kKinds] = {false};
     for (; k < k_n; ++k) {
       const int32_t col_index = members[k];
       const hbk_lookup_grad_column_t& h = cols[col_index];
@@ -2907,27 +2983,38 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     typedef void (*reduce_fn)(const GArgs, const int4*, int, int, const int32_t*);
     typedef void (*merge_fn)(const GArgs, int, const int32_t*);
     const int32_t* poison = onepass ? sync.wait.poison : nullptr;
-    static const reduce_fn kReduce[4][3] = {
-        {&bwd_dense_kernel<f32x4, 0>, &bwd_dense_kernel<f32x4, 1>, &bwd_dense_kernel<f32x4, 2>},
-        {&bwd_dense_kernel<float, 0>, &bwd_dense_kernel<float, 1>, &bwd_dense_kernel<float, 2>},
+    static const reduce_fn kReduce[kKinds][3] = {
+        {&bwd_dense_kernel<f32x4, 0, false>, &bwd_dense_kernel<f32x4, 1, false>,
+         &bwd_dense_kernel<f32x4, 2, false>},
+        {&bwd_dense_kernel<float, 0, false>, &bwd_dense_kernel<float, 1, false>,
+         &bwd_dense_kernel<float, 2, false>},
+        {&bwd_dense_kernel<f32x4, 0, true>, &bwd_dense_kernel<f32x4, 1, true>,
+         &bwd_dense_kernel<f32x4, 2, true>},
+        {&bwd_dense_kernel<float, 0, true>, &bwd_dense_kernel<float, 1, true>,
+         &bwd_dense_kernel<float, 2, true>},
         {&bwd_reduce_kernel<f32x4, 0>, &bwd_reduce_kernel<f32x4, 1>, &bwd_reduce_kernel<f32x4, 2>},
         {&bwd_reduce_kernel<float, 0>, &bwd_reduce_kernel<float, 1>, &bwd_reduce_kernel<float, 2>}};
-    static const merge_fn kMerge[4][3] = {
+    static const merge_fn kMerge[kKinds][3] = {
+        {&bwd_dense_merge_kernel<f32x4, 0>, &bwd_dense_merge_kernel<f32x4, 1>,
+         &bwd_dense_merge_kernel<f32x4, 2>},
+        {&bwd_dense_merge_kernel<float, 0>, &bwd_dense_merge_kernel<float, 1>,
+         &bwd_dense_merge_kernel<float, 2>},
         {&bwd_dense_merge_kernel<f32x4, 0>, &bwd_dense_merge_kernel<f32x4, 1>,
          &bwd_dense_merge_kernel<f32x4, 2>},
         {&bwd_dense_merge_kernel<float, 0>, &bwd_dense_merge_kernel<float, 1>,
          &bwd_dense_merge_kernel<float, 2>},
         {&bwd_merge_kernel<f32x4, 0>, &bwd_merge_kernel<f32x4, 1>, &bwd_merge_kernel<f32x4, 2>},
         {&bwd_merge_kernel<float, 0>, &bwd_merge_kernel<float, 1>, &bwd_merge_kernel<float, 2>}};
-    for (int kind = 0; kind < 4; ++kind) {
+    for (int kind = 0; kind < kKinds; ++kind) {
       if (!have_kind[kind]) continue;
       const int64_t n_slots = slot_hi[kind] - slot_lo[kind];
-      const int64_t per = kind >= 2 ? kTeams : 1;   // job slots per workgroup
-      hipLaunchKernelGGL(kReduce[kind][step], dim3((unsigned)((n_slots + per - 1) / per)),
+      const int64_t per = kind >= 4 ? kTeams : 1;   // job slots per workgroup
+      const int64_t grid = (n_slots + per - 1) / per;
+      hipLaunchKernelGGL(kReduce[kind][step], dim3((unsigned)grid),
                          dim3(kBlock), 0, ls, args, desc_group, (int)slot_lo[kind],
                          (int)slot_hi[kind], poison);
     }
-    for (int kind = 0; kind < 4; ++kind) {
+    for (int kind = 0; kind < kKinds; ++kind) {
       if (!have_kind[kind]) continue;
       hipLaunchKernelGGL(kMerge[kind][step], dim3((unsigned)(merge_hi[kind] - merge_lo[kind])),
                          dim3(kBlock), 0, ls, args, (int)merge_lo[kind], poison);

@@ -38,7 +38,9 @@ struct ChainState {
   std::mutex mu;
   hipEvent_t ev[2] = {nullptr, nullptr};
   int cur = 0;
-  bool have = false;
+  bool have = false;     // ev[cur] holds a record
+  bool seen = false;     // a launch has happened
+  bool multi = false;    // launches have come from more than one stream
   hipStream_t last = nullptr;
 };
 ChainState* chain_of_device() {
@@ -60,18 +62,34 @@ ChainState* chain_of_device() {
 }
 }  // namespace
 
+// A process that launches these kernels from ONE stream (the usual case) pays nothing: stream
+// order already serialises them.  Events start when a second stream shows up: that launch waits
+// for everything the first stream has been given so far (an event recorded on it now -- more than
+// needed, never less), and from then on every such launch records an event behind itself.
 SyncChain::SyncChain(hipStream_t stream) : stream_(stream), state_(chain_of_device()) {
   ChainState* c = reinterpret_cast<ChainState*>(state_);
   if (c == nullptr) return;
   c->mu.lock();
+  if (!c->multi) {
+    if (!c->seen || c->last == stream_) {
+      c->seen = true;
+      c->last = stream_;
+      return;
+    }
+    c->multi = true;
+    c->have = hipEventRecord(c->ev[c->cur], c->last) == hipSuccess;
+    if (!c->have) (void)hipGetLastError();   // (the first stream is gone: nothing of it can be running)
+  }
   if (c->have && c->last != stream_) (void)hipStreamWaitEvent(stream_, c->ev[c->cur], 0);
 }
 
 SyncChain::~SyncChain() {
   ChainState* c = reinterpret_cast<ChainState*>(state_);
   if (c == nullptr) return;
-  c->cur ^= 1;
-  c->have = hipEventRecord(c->ev[c->cur], stream_) == hipSuccess;
+  if (c->multi) {
+    c->cur ^= 1;
+    c->have = hipEventRecord(c->ev[c->cur], stream_) == hipSuccess;
+  }
   c->last = stream_;
   c->mu.unlock();
 }

@@ -504,13 +504,14 @@ def _check_slices(res, rows, grads, splits, combiner, distinct=True, atol=1e-6):
   np.testing.assert_allclose(got, want64, rtol=RTOL, atol=atol)
 
 
-@pytest.mark.parametrize('dense', [1, 0])
+@pytest.mark.parametrize('dense', [2, 1, 0])
 @pytest.mark.parametrize('onepass', [1, 0])
 @pytest.mark.parametrize('combiner', ['sum', 'mean', 'sqrtn'])
 def test_group_lookup_backward(hbk_option, combiner, onepass, dense):
   # onepass: pairs grouped by ONE launch (tiles wait for their column) or by the histogram /
-  # scan / scatter launches; dense: row-range buckets + direct-indexed LDS tables where the batch
-  # covers the table densely (every column here but the 100000-row one), or hashed buckets only
+  # scan / scatter launches; dense: 1 = row-range buckets + direct-indexed LDS tables for the
+  # columns the policy picks (narrow rows, one id per sample), 2 = for every column whose row
+  # ranges fit (ragged and wide ones too, always with the sorted walk), 0 = hashed buckets only
   hbk_option('bwd_onepass', onepass)
   hbk_option('bwd_dense', dense)
   rng = np.random.RandomState(10)
@@ -536,7 +537,7 @@ def test_group_lookup_backward(hbk_option, combiner, onepass, dense):
     _check_slices(res[c], ids[c] % buckets[c], grads[c], splits[c], combiner)
 
 
-@pytest.mark.parametrize('dense', [1, 0])
+@pytest.mark.parametrize('dense', [2, 1, 0])
 def test_group_lookup_backward_multi_chunk_and_multi_pass_path(hbk_option, dense):
   # one bucket per column: many 512-pair chunks per workgroup, rows spanning chunks are
   # accumulated into their output row, and more distinct rows than the LDS table holds force
@@ -577,13 +578,18 @@ def test_group_lookup_backward_zipf_hot_rows():
   _check_slices(res, ids, grads, None, 'sum', atol=RTOL * 100)   # ~12k terms on the hot row
 
 
+@pytest.mark.parametrize('dense', [1, 2])
 @pytest.mark.parametrize('aim', [0, 3000, 64])
-def test_group_lookup_backward_dense_row_ranges(hbk_option, aim):
+def test_group_lookup_backward_dense_row_ranges(hbk_option, aim, dense):
   """Row-range buckets (dense columns): output rows of a bucket are sorted, distinct and complete
   whatever the bucket holds -- buckets of one chunk (default aim), of several chunks (aim 3000),
   tiny ones (aim 64), hot rows next to single ones, duplicated rows that need several rounds of
   LDS sums (dim 128: 32 rows per round), int32 ids, `// W` row numbers, ids outside the table,
   the optimizer step fused (SGD) and the step-only form."""
+  # dense 1: the policy (lean instantiation where few repeated rows are expected -- which these
+  # inputs then violate on purpose: hot rows through the LDS float atomics; wide rows hashed);
+  # 2: every column dense with the sorted walk
+  hbk_option('bwd_dense', dense)
   if aim:
     hbk_option('bwd_bucket_pairs', aim)
   rng = np.random.RandomState(123)
@@ -629,7 +635,7 @@ def test_group_lookup_backward_dense_row_ranges(hbk_option, aim):
           np.testing.assert_equal(host(t_dev), ref)
 
 
-@pytest.mark.parametrize('dense', [1, 0])
+@pytest.mark.parametrize('dense', [2, 1, 0])
 @pytest.mark.parametrize('onepass', [1, 0])
 @pytest.mark.parametrize('split,log2p', [(None, None), ('96', '2'), ('700', '0')])
 def test_group_lookup_backward_split_buckets(hbk_option, split, log2p, onepass, dense):
@@ -734,7 +740,7 @@ def test_group_lookup_backward_segmented_inputs():
       st += ln
 
 
-@pytest.mark.parametrize('dense', [1, 0])
+@pytest.mark.parametrize('dense', [2, 1, 0])
 @pytest.mark.parametrize('hook', [None, 'one_bucket'])
 def test_group_lookup_backward_fused_adagrad_apply(hbk_option, hook, dense):
   """tf.train.AdagradOptimizer's sparse apply fused into the backward: accum += g^2,
@@ -791,7 +797,7 @@ def test_group_lookup_backward_fused_sgd_apply():
   np.testing.assert_allclose(host(t_dev), ref, rtol=RTOL, atol=1e-6)
 
 
-@pytest.mark.parametrize('dense', [1, 0])
+@pytest.mark.parametrize('dense', [2, 1, 0])
 @pytest.mark.parametrize('optimizer', ['sgd', 'adagrad'])
 @pytest.mark.parametrize('hook', [None, 'one_bucket', 'split'])
 def test_group_lookup_backward_step_only(hbk_option, optimizer, hook, dense):

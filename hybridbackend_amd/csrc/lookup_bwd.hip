@@ -738,6 +738,7 @@ struct ReduceLds {
   int32_t off[kSlots];       // multi-pair slots: start of the slot's pairs in `order` (-> end by (d))
   int32_t slot_out[kSlots];  // output row of the slot, -1 = none yet
   int32_t segs[kCP];         // segment (= row of grad_out) of every pair of the chunk
+  int32_t nseg[kCP];         // ragged columns with mean / sqrtn: ids of that segment (the divisor)
   uint16_t active[kCP];      // slots with several pairs in this chunk
   uint16_t order[kCP];       // their pair indices grouped by slot
   uint16_t pslot[kCP];       // slot of every pair; kNoSlot: struck out earlier / left for a later pass
@@ -788,6 +789,23 @@ __device__ inline V load_grad(const GCol& c, const ReduceJob& job, int32_t seg, 
     const int32_t n = c.splits[seg + 1] - c.splits[seg];
     g = c.combiner == HBK_COMBINER_MEAN ? g / (float)n : g / sqrtf((float)n);
   }
+  return g;
+}
+
+// The gradient chunk of a pair with the combiner's divisor taken from LDS (hashed path: the
+// segment lengths of a chunk are fetched once, in (a)): no memory wait between two gradient loads.
+template <typename V>
+__device__ inline V load_grad_lds(const GCol& c, const ReduceJob& job, int32_t seg, int sub,
+                                  bool scaled, int32_t n) {
+  constexpr int VE = sizeof(V) / 4;
+  const int64_t off = job.seg_is_offset ? (int64_t)(uint32_t)seg : (int64_t)seg * job.stride;
+#ifdef HBK_BWD_ABLATE_LOADS
+  V g = zero_v<V>() + (float)(off & 7);
+#else
+  V g = __builtin_nontemporal_load(
+      reinterpret_cast<const V*>(job.grad + off + (int64_t)sub * VE));
+#endif
+  if (scaled) g = c.combiner == HBK_COMBINER_MEAN ? g / (float)n : g / sqrtf((float)n);
   return g;
 }
 
@@ -948,6 +966,8 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
   // row may span chunks and is summed across them in its output row; stepping chunk by chunk
   // would round differently from table -= lr * grad_row and is wrong for Adagrad, so such a job
   // only emits, lists the rows a pass emitted, and steps them after the pass.
+  // the combiner's 1/n, 1/sqrt(n) applies (ragged column, mean / sqrtn, not a merge of partials)
+  const bool scaled = job.scale && c.combiner != HBK_COMBINER_SUM && c.splits != nullptr;
   const bool defer = STEP && job.lr != 0.0f && n_pairs > kCP;
   const float lr_now = !STEP || defer ? 0.0f : job.lr;
   constexpr bool adagrad = STEP == 2;
@@ -990,6 +1010,18 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
       __builtin_amdgcn_s_waitcnt(0x0f70);
       HBK_SUBSTAMP(1);
 #endif
+      // mean / sqrtn over ragged segments: the segment lengths are requested HERE, one round trip
+      // for the whole chunk beside the insert work, and kept in LDS.  (Divided inside the gradient
+      // loads -- load, wait for the length, divide, next load -- the rows of a round travelled one
+      // memory round trip at a time.)
+      int32_t n_in[kCP / kTeam];
+      if (scaled) {   // uniform
+#pragma unroll
+        for (int k = 0; k < kCP / kTeam; ++k) {
+          n_in[k] = 1;
+          if (k * kTeam + tid < n_chunk) n_in[k] = c.splits[seg_in[k] + 1] - c.splits[seg_in[k]];
+        }
+      }
 #pragma unroll
       for (int k = 0; k < kCP / kTeam; ++k) {
         const int e = k * kTeam + tid;
@@ -1047,6 +1079,12 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         hs_[k] = valid && h >= 0 ? h : (valid ? -2 : -1);   // -2: found no room
         tk_[k] = ticket;
         row_[k] = row;
+      }
+      if (scaled) {
+#pragma unroll
+        for (int k = 0; k < kCP / kTeam; ++k) {
+          if (k * kTeam + tid < n_chunk) L.nseg[k * kTeam + tid] = n_in[k];
+        }
       }
       HBK_SUBSTAMP(2);
       team_sync();
@@ -1190,7 +1228,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
             if (sidx != (int)kNoSlot) {
               const bool is_single = L.cnt[sidx] == (kNewBit | 1);
               if (is_single || lds_rows) {
-                pre[k] = load_grad<V>(c, job, L.segs[e], sub);
+                pre[k] = load_grad_lds<V>(c, job, L.segs[e], sub, scaled, L.nseg[e]);
                 single |= is_single ? 1u << k : 0u;
                 multi |= is_single ? 0u : 1u << k;
               }
@@ -1313,7 +1351,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
             if (q < n_multi) {
               const int e = (int)L.order[q];
               sl[w] = (int)L.pslot[e];
-              if (live) g[w] = load_grad<V>(c, job, L.segs[e], sub);
+              if (live) g[w] = load_grad_lds<V>(c, job, L.segs[e], sub, scaled, L.nseg[e]);
             }
           }
           // head: the run at my first position (it may have started in a group before me)
@@ -1620,8 +1658,10 @@ __device__ inline void dense_walk(const WalkArgs w_, DenseLds& L) {
         if (live) g[w] = load_grad_raw<V>(c, job, L.seg[e], sub, &n_[w]);
       }
     }
+    if (job.scale && c.combiner != HBK_COMBINER_SUM && c.splits != nullptr) {   // uniform
 #pragma unroll
-    for (int w = 0; w < kW; ++w) g[w] = scale_grad<V>(c, g[w], n_[w]);
+      for (int w = 0; w < kW; ++w) g[w] = scale_grad<V>(c, g[w], n_[w]);
+    }
     {
       V head = zero_v<V>();
       bool in_head = sl[0] >= 0;
@@ -1777,6 +1817,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
   const float lr = STEP ? job.lr : 0.0f;
   constexpr bool adagrad = STEP == 2;
   const bool emit = !(STEP && job.no_emit);
+  const bool dscaled = job.scale && c.combiner != HBK_COMBINER_SUM && c.splits != nullptr;   // uniform
 
   int64_t r_in[PT];
   int32_t seg_in[PT];
@@ -2064,7 +2105,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
           for (int k = 0; k < kDepth; ++k) {
             if (((mask | dmask) >> k & 1u) == 0) continue;
             const int i = e0 + k * groups + my_group;
-            g[k] = scale_grad<V>(c, g[k], n_[k]);
+            if (dscaled) g[k] = scale_grad<V>(c, g[k], n_[k]);
             if (dmask >> k & 1u) {
               float* r = &L.red[(size_t)(L.code[i] & (kDupBit - 1)) * c.dim + (size_t)sub * VE];
 #pragma unroll
@@ -2132,7 +2173,9 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
             }
           }
 #pragma unroll
-          for (int k = 0; k < kDepth; ++k) g[k] = scale_grad<V>(c, g[k], n_[k]);
+          for (int k = 0; k < kDepth; ++k) {
+            if (dscaled) g[k] = scale_grad<V>(c, g[k], n_[k]);
+          }
 #pragma unroll
           for (int k = 1; k < kDepth; ++k) {
             if (dr[k] >= 0 && dr[k] == dr[k - 1]) {
@@ -2497,26 +2540,29 @@ ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged) {
   // Dense: bucket = floor(row * M / 2^32) with M = floor(2^32 P / rows) (< 2^32: P <= rows; any
   // smaller M is still a monotone map into [0, P)); a bucket then spans at most ceil(2^32 / M)
   // rows, which must fit the reduce stage's LDS bitmaps.
-  // Where dense pays (measured, 26 x 65536 ids through the C ABI; profiles/r03_bwd_*):
+  // Where dense pays (measured through the C ABI, 26 x 65536 ids unless said; profiles/r03_*):
   //  * narrow rows only (dim <= 32: >= 32 rows per load instruction of the workgroup).  Wide rows
   //    lose to the hashed path: dim 128 uniform 417 vs 389 us, Zipf 482 vs 351 us; dim 64 with 3
   //    pairs per row 210 vs 165 us;
   //  * columns with one id per sample.  Ragged ones (8 ids per sample, 100 k rows) 780-880 vs 780 us;
-  //  * few repeated rows expected (ids <= rows / 8, uniform config 2: ~14 of a bucket's 450 pairs):
-  //    the LEAN instantiation, ~97-100 vs 110 us; more: the one with the sorted walk, 99 / 116 vs
-  //    107 / 126 us at 33 / 330 pairs per row.
-  // bwd_dense = 2 forces dense (with the sorted walk) wherever the row range fits.
+  //  * few repeated rows expected (ids <= rows / 8; uniform config 2: ~14 of a bucket's 450 pairs):
+  //    the LEAN instantiation, 103-107 vs 111-114 us (+ SGD 170 vs 175, step only 150-156 vs 162-165).
+  //    With more repeats the instantiation with the sorted walk is level with the hashed path or a
+  //    little ahead on 26 equal columns (99 / 116 vs 107 / 126 us at 33 / 330 pairs per row) but
+  //    behind it in the config-5 mix (200 columns: 4.58 vs 4.36 ms with SGD, 6.09 vs 5.53 ms with
+  //    Adagrad -- six kernel kinds per launch group instead of two): hashed.
+  // bwd_dense = 2 forces dense (with the sorted walk) wherever the row range fits (tests).
   p.dense_mul = 0;
   p.dense_sort = true;
   const bool forced_dense = options().bwd_dense == 2;
-  const bool eligible = forced_dense || (dim <= 32 && !ragged);
+  const bool eligible = forced_dense || (dim <= 32 && !ragged && n_ids <= rows / 8);
   if (kTeam == kBlock && options().bwd_dense != 0 && eligible && rows >= 1 && rows < (1ll << 32)) {
     const int64_t P = nb < rows ? nb : rows;
     uint64_t M = ((uint64_t)P << 32) / (uint64_t)rows;
     if (M > 0xffffffffull) M = 0xffffffffull;
     if (M >= 1 && (((uint64_t)1 << 32) + M - 1) / M <= (uint64_t)kDenseSpan) {
       p.dense_mul = (uint32_t)M;
-      p.dense_sort = forced_dense || n_ids > rows / 8;
+      p.dense_sort = forced_dense;
       nb = P;
     }
   }

@@ -115,6 +115,56 @@ PY
         grep -E "bwd_|kernel  " $O/prof_sweep_dense$dense.txt | head -24
       done
       unset HBK_BWD_DENSE;;
+    final)   # the round's evidence, copied to profiles/r03_* afterwards
+      prof prof_bench "" -- python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0
+      cp $O/prof_bench.txt $O/r03_bench_kernel_stats.txt
+      find $O/prof_bench -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r03_bench_rocprofv3_kernel_stats.csv
+      timeout 600 python bench.py --steps 50 --warmup 10 2>/dev/null | grep "^{" > $O/r03_bench_lines.jsonl
+      for w in fp32 fp16; do
+        timeout 300 python bench.py --gpus 1 --sharded --wire $w --steps 30 --warmup 5 --cpu-seconds 0 2>/dev/null | grep "^{" >> $O/r03_bench_lines.jsonl
+      done
+      HBK_SHARDED_WIRE_FUSED=0 timeout 300 python bench.py --gpus 1 --sharded --wire fp16 --steps 30 --warmup 5 --cpu-seconds 0 2>/dev/null | grep "^{" | sed 's/^{/{"unfused_fp16_wire": true, /' >> $O/r03_bench_lines.jsonl
+      timeout 300 tools/bin/bench_ops > $O/r03_bench_ops.txt 2>&1
+      for dense in 1 0; do for w in d r; do HBK_BWD_DENSE=$dense timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk " | sed "s/^/bwd_dense=$dense  /"; done; done >> $O/r03_bench_ops.txt
+      prof prof_bwd "" -- $R/tools/bin/bench_ops b
+      prof prof_bwd_step "" -- $R/tools/bin/bench_ops s
+      HBK_BWD_DENSE=0 prof prof_bwd_hash "" -- $R/tools/bin/bench_ops b
+      (echo "== config-2 backward, C ABI (tools/bin/bench_ops b): dense (row-range) buckets"; cat $O/prof_bwd.txt; echo; echo "== + fused SGD step / step only (bench_ops s)"; cat $O/prof_bwd_step.txt; echo; echo "== the same backward with hashed buckets (HBK_BWD_DENSE=0)"; cat $O/prof_bwd_hash.txt) > $O/r03_bwd_kernel_stats.txt
+      prof pmc_bwd_sq1 "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" -- $R/tools/bin/bench_ops b
+      prof pmc_bwd_sq2 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" -- $R/tools/bin/bench_ops b
+      prof pmc_bwd_tcc "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/bench_ops b
+      python - $O > $O/r03_bwd_sq_counters.txt <<'PY'
+import json,sys
+O=sys.argv[1]
+print("SQ / TCC counters of the config-2 backward's kernels (tools/bin/bench_ops b; mean per launch; one --pmc pass per group)")
+for f in ('pmc_bwd_sq1','pmc_bwd_sq2','pmc_bwd_tcc'):
+  d=json.load(open(f'{O}/{f}.json'))
+  for k,v in sorted(d.items()):
+    if 'bwd_' in k: print(k[:64].ljust(64), {c:round(x['mean']) for c,x in v.items()})
+PY
+      LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops b > $O/r03_bwd_reduce_trace.txt 2>&1
+      prof prof_cfg5 "" -- python $R/tools/sweep.py --cases h
+      cp $O/prof_cfg5.txt $O/r03_cfg5_bwd_kernel_stats.txt
+      prof prof_sharded "" -- python $R/bench.py --gpus 1 --sharded --steps 30 --warmup 5 --cpu-seconds 0 --tune-steps 0
+      cp $O/prof_sharded.txt $O/r03_sharded_w1_kernel_stats.txt
+      prof prof_unique "" -- $R/tools/bin/bench_ops u
+      cp $O/prof_unique.txt $O/r03_unique_kernel_stats.txt
+      timeout 1500 python tools/sweep.py --big --cases a,b,c,d,e,f,g,h,i,j 2>/dev/null | grep "^{" > $O/r03_sweep.jsonl
+      prof prof_hot "" -- python $R/tools/sweep.py --big --cases j
+      export SWEEP_J_KINDS="Zipf(1.2)"
+      prof pmc_hot_tcc "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" -- python $R/tools/sweep.py --big --cases j
+      prof pmc_hot_tcp "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_WRITE_REQ_sum" -- python $R/tools/sweep.py --big --cases j
+      unset SWEEP_J_KINDS
+      (echo "== config-4 forward, fwd_hot_rows = 0 / 1 / 2 x Zipf(1.2) / uniform / one row (tools/sweep.py --big --cases j): kernel durations"; grep "group_lookup_fwd\|kernel  " $O/prof_hot.txt; echo; echo "== L2 / L1 counters, Zipf(1.2) ids only, mean per launch (the hot kernel's mean covers modes 1 and 2)"; python - $O <<'PY'
+import json,sys
+O=sys.argv[1]
+for f in ('pmc_hot_tcc','pmc_hot_tcp'):
+  d=json.load(open(f'{O}/{f}.json'))
+  for k,v in sorted(d.items()):
+    if 'group_lookup_fwd' in k: print(k[:70].ljust(70), {c:round(x['mean']) for c,x in v.items()})
+PY
+      ) > $O/r03_hot_rows.txt
+      ls -la $O/r03_*;;
     sweep)
       timeout 1200 python tools/sweep.py --big --cases ${SWEEP_CASES:-a,b,c,d,e,f,g,h,i} > $O/sweep.log 2>&1; echo "sweep rc=$?" >> $O/sweep.log; cut -c1-400 $O/sweep.log;;
     *) echo "unknown stage $st";;

@@ -214,7 +214,14 @@ class GroupLookupGrad:
                             self._grows[o_g:o_g + k * d].view(k, d), self._nu[c:c + 1]))
         o_r += k
         o_g += pad4(k * d)
-    for c in range(n):
+    # handed the SAME tensors as the call before (resident buffers refilled in place): the
+    # descriptors are still right -- validating and marshalling 26 columns is ~12 us of Python
+    tensors = list(ids) + list(grads) + [x for x in row_splits if x is not None]
+    key = (emit, tuple(id(t) for t in tensors))
+    cached = getattr(self, '_bound_key', None)
+    same = cached is not None and cached[0] == key and all(
+      t.data_ptr() == q and t.numel() == m for t, (q, m) in zip(tensors, cached[1]))
+    for c in range(0 if not same else n, n):
       i, g, s = ids[c], grads[c], row_splits[c]
       _lib.require_device_tensor(i, 'ids')
       _lib.require_device_tensor(g, 'grads', row_strided=True)
@@ -244,7 +251,9 @@ class GroupLookupGrad:
       col.unique_rows = urows.data_ptr() if emit else None
       col.grad_rows = grows.data_ptr() if emit else None
       col.n_unique = nu.data_ptr()
-    need = self._lib.hbk_group_lookup_bwd_workspace_bytes(n, self._cols)
+    if not same:
+      self._bound_key = (key, [(t.data_ptr(), t.numel()) for t in tensors])
+    need = self._lib.hbk_group_lookup_bwd_workspace_bytes(n, self._cols)   # (depends on options too)
     if self._ws is None or self._ws.numel() < need:
       self._ws = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
     self._keep = (ids, grads, row_splits)

@@ -70,6 +70,7 @@ def test_config4_full_size_zipf_forward_backward(hbk_option, hot_rows):
   offset 2^32 of the big table.  hot_rows: the forward through the per-wave gather or through the
   256-segment tiles that stage repeated rows in LDS."""
   hbk_option('fwd_hot_rows', hot_rows)
+  torch.cuda.empty_cache()          # (blocks cached by earlier tests count as used otherwise)
   free, _ = torch.cuda.mem_get_info()
   if free < 100 * 2**30:
     pytest.skip('needs ~75 GB of HBM')
@@ -276,6 +277,7 @@ def test_config5_stated_size_single_gpu():
   index_add_ of the combiner's gradient, tables / accumulators after the step == the optimizer's
   formula from float64; the oracle on the first 4096 samples of every seventh column
   (bit-equal)."""
+  torch.cuda.empty_cache()          # (blocks cached by earlier tests count as used otherwise)
   free, _ = torch.cuda.mem_get_info()
   if free < 160 * 2**30:
     pytest.skip('needs ~130 GB of HBM')

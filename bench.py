@@ -259,6 +259,15 @@ def load_traffic(config_key):
   return data.get(config_key, {}).get('hbm_bytes_per_launch')
 
 
+def rccl_versions():
+  """RCCL the library was built against / the one the process runs (torch may load its own)."""
+  import ctypes
+  from hybridbackend_amd import _lib
+  built, runtime = ctypes.c_int32(), ctypes.c_int32()
+  _lib.check(_lib.lib().hbk_comm_rccl_versions(ctypes.byref(built), ctypes.byref(runtime)))
+  return {'built': built.value, 'runtime': runtime.value}
+
+
 def main():
   args = parse_args()
   if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -486,6 +495,7 @@ def main():
         'bytes_out_per_rank_per_step': int(link_bytes), 'links_per_rank': world - 1,
         'achieved_GBps_per_rank_each_way': round(link_bytes / (elapsed / args.steps) / 1e9, 2),
         'link_probe': probe,
+        'rccl': rccl_versions(),
         'note': 'the sharded step is link-bound (DESIGN.md 5): one xGMI link per peer pair'}
     if world == 1 and not args.sharded and args.cpu_seconds > 0:
       result['cpu_baseline'] = cpu_baseline(args, tables, batches[0], args.cpu_seconds)

@@ -105,6 +105,7 @@ def _declare(l):
     'hbk_cache_lookup': (C.c_int, [vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
     'hbk_murmur3_hash32': (C.c_int, [vp, i64, vp, vp]),
     'hbk_comm_get_id': (C.c_int, [vp]),
+    'hbk_comm_rccl_versions': (C.c_int, [vp, vp]),
     'hbk_comm_create': (C.c_int, [vp, vp, i32, i32, i32]),
     'hbk_comm_destroy': (C.c_int, [vp]),
     'hbk_comm_check_async': (C.c_int, [vp]),

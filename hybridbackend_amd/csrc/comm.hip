@@ -160,6 +160,17 @@ extern "C" int hbk_comm_get_id(uint8_t id[HBK_COMM_ID_BYTES]) {
   return HBK_OK;
 }
 
+// "built <major.minor.patch> / runs <version code>" of RCCL, for logs and the bench line
+extern "C" int hbk_comm_rccl_versions(int32_t* built, int32_t* runtime) {
+  using namespace hbk;
+  HBK_REQUIRE(built != nullptr && runtime != nullptr, "comm_rccl_versions: NULL argument");
+  *built = NCCL_VERSION_CODE;
+  int rt = 0;
+  if (ncclGetVersion(&rt) != ncclSuccess) rt = 0;
+  *runtime = rt;
+  return HBK_OK;
+}
+
 extern "C" int hbk_comm_create(hbk_comm_t* comm, const uint8_t id[HBK_COMM_ID_BYTES],
                                int32_t world_size, int32_t local_size, int32_t rank) {
   using namespace hbk;
@@ -181,6 +192,20 @@ extern "C" int hbk_comm_create(hbk_comm_t* comm, const uint8_t id[HBK_COMM_ID_BY
   if (he != hipSuccess) {
     delete c;
     return fail(HBK_INTERNAL, "comm_create: hipGetDevice failed: %s", hipGetErrorString(he));
+  }
+  // The library is compiled against one RCCL (its headers) and may run on another (the process
+  // may have loaded the RCCL a framework bundles first: torch ships 2.26, /opt/rocm 2.27).  The
+  // entry points used here -- unique id, comm init / destroy / abort / async error, group start /
+  // end, send, recv, allreduce, allgather -- have kept their signatures throughout RCCL 2.x;
+  // anything else is refused here instead of misbehaving later.
+  {
+    int rt = 0;
+    if (ncclGetVersion(&rt) != ncclSuccess || rt / 10000 != NCCL_MAJOR) {
+      delete c;
+      return fail(HBK_INTERNAL, "comm_create: built against RCCL %d.%d.%d, the process runs RCCL "
+                                "version code %d: another major version is not supported",
+                  NCCL_MAJOR, NCCL_MINOR, NCCL_PATCH, rt);
+    }
   }
   ncclUniqueId nid;
   memcpy(&nid, id, HBK_COMM_ID_BYTES);

@@ -361,6 +361,10 @@ int hbk_murmur3_hash32(const int64_t* keys, int64_t n_keys, uint32_t* out,
 typedef struct hbk_comm* hbk_comm_t;
 #define HBK_COMM_ID_BYTES 128
 int hbk_comm_get_id(uint8_t id[HBK_COMM_ID_BYTES]);
+/* RCCL version codes (major * 10000 + minor * 100 + patch): the headers the library was built
+ * against and the RCCL the process actually runs (a framework may have loaded its own first).
+ * hbk_comm_create refuses a different MAJOR version; minor skew is fine for the calls used. */
+int hbk_comm_rccl_versions(int32_t* built, int32_t* runtime);
 int hbk_comm_create(hbk_comm_t* comm, const uint8_t id[HBK_COMM_ID_BYTES],
                     int32_t world_size, int32_t local_size, int32_t rank);
 int hbk_comm_destroy(hbk_comm_t comm);

@@ -132,7 +132,21 @@ class GroupLookup:
     _lib.check(self._lib.hbk_group_lookup_fwd(len(self.tables), self._cols, s))
 
   def __call__(self, ids, row_splits=None, outs=None):
-    outs = self.bind(ids, row_splits, outs)
+    # handed the SAME tensors as the call before (resident buffers refilled in place, caller-owned
+    # outputs): the descriptors are still right, the call is one foreign call
+    if outs is not None:
+      tensors = list(ids) + [x for x in (row_splits or []) if x is not None] + list(outs)
+      key = tuple(id(t) for t in tensors)
+      cached = getattr(self, '_call_key', None)
+      if cached is not None and cached[0] == key and all(
+          t.data_ptr() == q and t.numel() == m for t, (q, m) in zip(tensors, cached[1])):
+        self.launch()
+        return cached[2]
+      outs = self.bind(ids, row_splits, outs)
+      self._call_key = (key, [(t.data_ptr(), t.numel()) for t in tensors], outs)
+    else:
+      self._call_key = None
+      outs = self.bind(ids, row_splits, outs)
     self.launch()
     return outs
 

@@ -456,7 +456,7 @@ def main():
       'dtype': 'f32', 'data': 'synthetic',
       'config': {'workload': workload, 'global_batch': args.batch * world,
                  'parallelism': parallelism,
-                 'wire': args.wire if world > 1 else None,
+                 'wire': args.wire if (world > 1 or args.sharded) else None,
                  'prefetch_next_partition': (world > 1 or args.sharded) and not args.no_prefetch,
                  'id_batches_resident': n_batches,
                  # the form the timed steps ran in, picked on this machine by the probe below;

@@ -52,6 +52,7 @@
 #include <string.h>
 
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include <vector>
 
@@ -1335,118 +1336,138 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         // slot whatever its length -- 3 pairs or a hot row's 400 -- and no lane group walks a
         // slot's pairs one memory round trip at a time (with 33 pairs per row that walk was 20 of
         // a workgroup's 37 us; it also replaces the whole-workgroup sum of hot rows).
-        constexpr int kW = STEP == 2 ? 2 : STEP ? kPre : 2 * kPre;   // (register budget)
-        const int n_multi = L.n_multi;
-        const int per_round = groups * kW;
-        int par = 0;
-        for (int r0 = 0; r0 < n_multi; r0 += per_round, par ^= 1) {
-          const int q0 = r0 + my_group * kW;   // my first position
-          V g[kW];
-          int32_t sl[kW];                       // slot of every position, -1 beyond the end
-#pragma unroll
-          for (int w = 0; w < kW; ++w) {
-            const int q = q0 + w;
-            sl[w] = -1;
-            g[w] = zero_v<V>();
-            if (q < n_multi) {
-              const int e = (int)L.order[q];
-              sl[w] = (int)L.pslot[e];
-              if (live) g[w] = load_grad_lds<V>(c, job, L.segs[e], sub, scaled, L.nseg[e]);
-            }
-          }
-          // head: the run at my first position (it may have started in a group before me)
-          {
-            V head = zero_v<V>();
-            bool in_head = sl[0] >= 0;
-#pragma unroll
+        auto walk = [&](auto width_tag) {
+          constexpr int kW = decltype(width_tag)::value;
+          constexpr int kB = kW > (STEP == 2 ? 2 : kPre) ? 2 : kW;   // positions whose step rows travel together
+          const int n_multi = L.n_multi;
+          const int per_round = groups * kW;
+          int par = 0;
+          for (int r0 = 0; r0 < n_multi; r0 += per_round, par ^= 1) {
+            const int q0 = r0 + my_group * kW;   // my first position
+            V g[kW];
+            int32_t sl[kW];                       // slot of every position, -1 beyond the end
+  #pragma unroll
             for (int w = 0; w < kW; ++w) {
-              in_head = in_head && sl[w] == sl[0];
-              if (in_head) head = head + g[w];
+              const int q = q0 + w;
+              sl[w] = -1;
+              g[w] = zero_v<V>();
+              if (q < n_multi) {
+                const int e = (int)L.order[q];
+                sl[w] = (int)L.pslot[e];
+                if (live) g[w] = load_grad_lds<V>(c, job, L.segs[e], sub, scaled, L.nseg[e]);
+              }
             }
-            *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = head;
-          }
-          team_sync();
-          const int round_end = r0 + per_round;
-          V acc = zero_v<V>();
-          int cur = -1;
-          bool owned = false;
-          uint32_t fin = 0;   // bit w: a run I own ends at my position w and is complete: its sum is
-                              // left in g[w] (the registers its last gradient row arrived in)
-#pragma unroll
-          for (int w = 0; w <= kW; ++w) {
-            const int sw = w < kW ? sl[w] : -1;
-            if (sw != cur) {
-              if (w > 0 && cur >= 0 && owned) {
-                // the run of `cur` ends at my position w - 1
-                const int32_t s_end = L.off[cur];
-                const int32_t s_beg = s_end - (L.cnt[cur] & (kNewBit - 1));
-                V total = acc;
-                if (w == kW) {
-                  // it reached the end of my range: the heads of the groups it goes on in
-                  const int lim = s_end < round_end ? s_end : round_end;
-                  for (int q = q0 + kW; q < lim; q += kW) {
-                    const int gp = (q - r0) / kW;
-                    total = total + *reinterpret_cast<const V*>(
-                                        &L.red[(((size_t)gp << lpr_log2) + sub) * VE]);
+            // head: the run at my first position (it may have started in a group before me)
+            {
+              V head = zero_v<V>();
+              bool in_head = sl[0] >= 0;
+  #pragma unroll
+              for (int w = 0; w < kW; ++w) {
+                in_head = in_head && sl[w] == sl[0];
+                if (in_head) head = head + g[w];
+              }
+              *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = head;
+            }
+            team_sync();
+            const int round_end = r0 + per_round;
+            V acc = zero_v<V>();
+            int cur = -1;
+            bool owned = false;
+            uint32_t fin = 0;   // bit w: a run I own ends at my position w and is complete: its sum is
+                                // left in g[w] (the registers its last gradient row arrived in)
+  #pragma unroll
+            for (int w = 0; w <= kW; ++w) {
+              const int sw = w < kW ? sl[w] : -1;
+              if (sw != cur) {
+                if (w > 0 && cur >= 0 && owned) {
+                  // the run of `cur` ends at my position w - 1
+                  const int32_t s_end = L.off[cur];
+                  const int32_t s_beg = s_end - (L.cnt[cur] & (kNewBit - 1));
+                  V total = acc;
+                  if (w == kW) {
+                    // it reached the end of my range: the heads of the groups it goes on in
+                    const int lim = s_end < round_end ? s_end : round_end;
+                    for (int q = q0 + kW; q < lim; q += kW) {
+                      const int gp = (q - r0) / kW;
+                      total = total + *reinterpret_cast<const V*>(
+                                          &L.red[(((size_t)gp << lpr_log2) + sub) * VE]);
+                    }
+                  }
+                  if (s_beg < r0) {   // it began in an earlier round (only the round's first run can)
+                    total = total + *reinterpret_cast<const V*>(&L.carry[par ^ 1][(size_t)sub * VE]);
+                  }
+                  if (s_end > round_end) {
+                    *reinterpret_cast<V*>(&L.carry[par][(size_t)sub * VE]) = total;   // goes on
+                  } else {
+                    g[w > 0 ? w - 1 : 0] = total;
+                    fin |= 1u << (w > 0 ? w - 1 : 0);
                   }
                 }
-                if (s_beg < r0) {   // it began in an earlier round (only the round's first run can)
-                  total = total + *reinterpret_cast<const V*>(&L.carry[par ^ 1][(size_t)sub * VE]);
+                cur = sw;
+                acc = zero_v<V>();
+                // a run that starts inside my range is mine; the one at my first position is mine
+                // when the slot starts there or when I am the round's first group (it is carried in)
+                owned = w > 0 || my_group == 0 ||
+                        (sw >= 0 && L.off[sw] - (L.cnt[sw] & (kNewBit - 1)) >= q0);
+              }
+              if (w < kW && sw >= 0) acc = acc + g[w];
+            }
+            // the finished rows leave together: the table (and accumulator) rows of the optimizer
+            // step are requested for all of them before the first is used
+            if (STEP && lr_now != 0.0f) {
+    #pragma unroll
+              for (int w0 = 0; w0 < kW; w0 += kB) {
+                if (((fin >> w0) & ((1u << kB) - 1u)) == 0u || !live) continue;
+                V tv[kB], av[STEP == 2 ? kB : 1];
+  #pragma unroll
+                for (int b = 0; b < kB; ++b) {
+                  const int w = w0 + b;
+                  tv[b] = zero_v<V>();
+                  if (w < kW && (fin >> w & 1u)) {
+                    const int64_t toff = (int64_t)L.keys[sl[w]] * c.dim + (int64_t)sub * VE;
+                    tv[b] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+                    if (STEP == 2) {
+                      av[STEP == 2 ? b : 0] =
+                          __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
+                    }
+                  }
                 }
-                if (s_end > round_end) {
-                  *reinterpret_cast<V*>(&L.carry[par][(size_t)sub * VE]) = total;   // goes on
-                } else {
-                  g[w > 0 ? w - 1 : 0] = total;
-                  fin |= 1u << (w > 0 ? w - 1 : 0);
+  #pragma unroll
+                for (int b = 0; b < kB; ++b) {
+                  const int w = w0 + b;
+                  if (w < kW && (fin >> w & 1u)) {
+                    const int s = sl[w];
+                    if (!job.no_emit) {
+                      emit_row<V>(c, job, L.slot_out[s], (L.cnt[s] & kNewBit) != 0, sub, g[w]);
+                    }
+                    const int64_t toff = (int64_t)L.keys[s] * c.dim + (int64_t)sub * VE;
+                    step_row<V>(c, adagrad, lr_now, toff, g[w], tv[b],
+                                STEP == 2 ? av[STEP == 2 ? b : 0] : zero_v<V>());
+                  }
                 }
               }
-              cur = sw;
-              acc = zero_v<V>();
-              // a run that starts inside my range is mine; the one at my first position is mine
-              // when the slot starts there or when I am the round's first group (it is carried in)
-              owned = w > 0 || my_group == 0 ||
-                      (sw >= 0 && L.off[sw] - (L.cnt[sw] & (kNewBit - 1)) >= q0);
-            }
-            if (w < kW && sw >= 0) acc = acc + g[w];
-          }
-          // the finished rows leave together: the table (and accumulator) rows of the optimizer
-          // step are requested for all of them before the first is used
-          if (STEP && lr_now != 0.0f) {
-            V tv[kW], av[STEP == 2 ? kW : 1];
-#pragma unroll
-            for (int w = 0; w < kW; ++w) {
-              tv[w] = zero_v<V>();
-              if ((fin >> w & 1u) && live) {
-                const int64_t toff = (int64_t)L.keys[sl[w]] * c.dim + (int64_t)sub * VE;
-                tv[w] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
-                if (STEP == 2) {
-                  av[STEP == 2 ? w : 0] =
-                      __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
-                }
-              }
-            }
-#pragma unroll
-            for (int w = 0; w < kW; ++w) {
-              if ((fin >> w & 1u) && live) {
-                const int s = sl[w];
-                if (!job.no_emit) {
+            } else {
+  #pragma unroll
+              for (int w = 0; w < kW; ++w) {
+                if ((fin >> w & 1u) && live) {
+                  const int s = sl[w];
                   emit_row<V>(c, job, L.slot_out[s], (L.cnt[s] & kNewBit) != 0, sub, g[w]);
                 }
-                const int64_t toff = (int64_t)L.keys[s] * c.dim + (int64_t)sub * VE;
-                step_row<V>(c, adagrad, lr_now, toff, g[w], tv[w],
-                            STEP == 2 ? av[STEP == 2 ? w : 0] : zero_v<V>());
               }
             }
-          } else {
-#pragma unroll
-            for (int w = 0; w < kW; ++w) {
-              if ((fin >> w & 1u) && live) {
-                const int s = sl[w];
-                emit_row<V>(c, job, L.slot_out[s], (L.cnt[s] & kNewBit) != 0, sub, g[w]);
-              }
-            }
+            team_sync();
           }
-          team_sync();
+        };
+        // Width of the walk with the optimizer step: as many positions as the step's table /
+        // accumulator rows leave registers for (kPre with SGD, 2 with Adagrad) -- or, for WIDE rows
+        // (dim >= 64: <= 16 lane groups, i.e. 10-28 rounds of two barriers and two memory round
+        // trips per chunk at the narrow width), the full 2 x kPre with the step's rows requested
+        // two positions at a time (a round finishes ~1 row per lane group).  Narrow rows lose with
+        // that form (ragged dim 16: 937 vs 782 us: more dependent table round trips per round).
+        if (STEP && lpr_log2 >= 4) {
+          walk(std::integral_constant<int, 2 * kPre>());
+        } else {
+          walk(std::integral_constant<int, STEP == 2 ? 2 : STEP ? kPre : 2 * kPre>());
         }
       }
       team_sync();

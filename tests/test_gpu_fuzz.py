@@ -57,6 +57,44 @@ def _ids(rng, n, rows, skew):
 @_cfg(80)
 @given(cols=st.lists(column, min_size=1, max_size=6), seed=st.integers(0, 2**31 - 1))
 def test_group_lookup_forward_backward_random(cols, seed):
+  _check_group_lookup(cols, seed)
+
+
+big_column = st.fixed_dictionaries({
+  'dim': st.sampled_from([4, 8, 16, 32, 64, 128]),
+  'rows': st.sampled_from([200, 5000, 100000, 3000000]),
+  'n_seg': st.sampled_from([3000, 9000, 20000, 50000]),
+  'ragged': st.booleans(),
+  'max_len': st.integers(1, 4),
+  'combiner': st.sampled_from(['sum', 'mean']),
+  'skew': st.sampled_from(['uniform', 'zipf', 'negative']),
+})
+plan_options = st.fixed_dictionaries({
+  'bwd_dense': st.sampled_from([0, 1, 2]),          # never / by policy / wherever it fits
+  'bwd_onepass': st.sampled_from([0, 1]),           # one-launch grouping or histogram/scan/scatter
+  'bwd_group_cols': st.sampled_from([1, 3, 64]),    # columns per launch group
+  'bwd_bucket_pairs': st.sampled_from([200, 448]),
+  'fwd_hot_rows': st.sampled_from([0, 1]),
+})
+
+
+@_cfg(20)
+@given(cols=st.lists(st.one_of(big_column, column), min_size=1, max_size=5), opts=plan_options,
+       seed=st.integers(0, 2**31 - 1))
+def test_group_lookup_random_plans(cols, opts, seed):
+  """The same check over columns large enough for the multi-tile grouping, the split buckets and
+  the row-range (dense) buckets, with the plan switches drawn too: every plan the host can choose
+  gives the oracle's result."""
+  from hybridbackend_amd import _lib
+  old = {k: _lib.set_option(k, v) for k, v in opts.items()}
+  try:
+    _check_group_lookup(cols, seed)
+  finally:
+    for k, v in old.items():
+      _lib.set_option(k, v)
+
+
+def _check_group_lookup(cols, seed):
   import oracle
   import hybridbackend_amd as hb
   rng = np.random.RandomState(seed)

@@ -123,6 +123,8 @@ struct Options {
   int bwd_bucket_pairs = 0;    // HBK_BWD_TARGET: aimed pairs per bucket (0: default)
   int bwd_split_pairs = 0;     // HBK_BWD_SPLIT: pairs per workgroup of a split bucket (0: default)
   int bwd_onepass = 1;         // HBK_BWD_ONEPASS: 0 = histogram, scan and scatter as three launches
+  int bwd_wide = 1;            // HBK_BWD_WIDE: wide sorted walk of the hashed backward (0 never,
+                               // 1 columns of one id per sample, 2 ragged columns too)
   int bwd_group_cols = 0;      // HBK_BWD_GROUP_COLS: columns per launch group of the backward (0: 64)
   int bwd_dense = 1;           // HBK_BWD_DENSE: 0 = hashed buckets for every column (no row-range buckets), 2 = also wide rows
   int fwd_hot_rows = 0;        // HBK_FWD_HOT: forward of wide one-id-per-sample columns: 1 = 256-segment tiles with

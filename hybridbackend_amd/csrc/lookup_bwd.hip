@@ -931,8 +931,10 @@ __device__ inline int table_find(const ReduceLds& L, unsigned long long row) {
 }
 
 // STEP: 0 = no fused optimizer step (none of its loads, registers and branches), 1 = SGD,
-// 2 = Adagrad (accumulator rows as well).
-template <typename V, int STEP>
+// 2 = Adagrad (accumulator rows as well).  WIDE (only with a step): the columns of >= 16 lanes per
+// row, whose sorted walk keeps the full width -- an instantiation of its own so that neither form
+// carries the other's registers.
+template <typename V, int STEP, bool WIDE = false>
 __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, ReduceLds& L) {
   constexpr int VE = sizeof(V) / 4;
   const int tid = (int)threadIdx.x & (kTeam - 1);   // inside the team
@@ -1464,7 +1466,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         // trips per chunk at the narrow width), the full 2 x kPre with the step's rows requested
         // two positions at a time (a round finishes ~1 row per lane group).  Narrow rows lose with
         // that form (ragged dim 16: 937 vs 782 us: more dependent table round trips per round).
-        if (STEP && lpr_log2 >= 4) {
+        if constexpr (STEP != 0 && WIDE) {
           walk(std::integral_constant<int, 2 * kPre>());
         } else {
           walk(std::integral_constant<int, STEP == 2 ? 2 : STEP ? kPre : 2 * kPre>());
@@ -2299,7 +2301,7 @@ __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4&
 // Adagrad) and bucket kind (hashed / dense); the host sorts a launch group's columns by kind, so
 // the job slots of one kind are one range [slot0, slot0 + grid) and no workgroup starts for
 // nothing.
-template <typename V, int STEP>
+template <typename V, int STEP, bool WIDE>
 __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const GArgs a,
                                                                           const int4* desc,
                                                                           int slot0, int total,
@@ -2318,7 +2320,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
   int ci;
   if (!decode_job<V, false>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
   HBK_STAMP(1);
-  bucket_reduce<V, STEP>(a.col[ci], job, lds[team]);
+  bucket_reduce<V, STEP, WIDE>(a.col[ci], job, lds[team]);
   HBK_STAMP(7);
 }
 
@@ -2395,7 +2397,7 @@ __device__ inline void merge_job(const GArgs& a, const GCol& c, int bucket, Redu
   job->no_emit = false;
 }
 
-template <typename V, int STEP>
+template <typename V, int STEP, bool WIDE>
 __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const GArgs a, int block0,
                                                                          const int32_t* poison) {
   __shared__ ReduceLds lds[kTeams];
@@ -2409,7 +2411,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_merge_kernel(const 
     if (c.work[2 * e + 1] != 1) continue;
     ReduceJob job;
     merge_job(a, c, c.work[2 * e], &job);
-    bucket_reduce<V, STEP>(c, job, lds[team]);
+    bucket_reduce<V, STEP, WIDE>(c, job, lds[team]);
   }
   merge_done(c, blocks);
 }
@@ -2828,7 +2830,13 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
                                       (apply_lr != 0.0f ? (uintptr_t)h.table | (uintptr_t)h.accum : 0),
                                   &ci.shape),
                     "group_lookup_bwd: dim %d needs more than 64 lanes per row", h.dim);
-        ci.kind = 2 * (ci.p.dense_mul == 0 ? 2 : ci.p.dense_sort ? 1 : 0) + (ci.shape.vec4 ? 0 : 1);
+        // bucket kind: 0 dense, 1 dense with sorted duplicates, 2 hashed, 3 hashed with the wide
+        // sorted walk (an optimizer step, >= 16 lanes per row, one id per sample: bucket_reduce)
+        const bool wide = apply_lr != 0.0f && ci.shape.lpr_log2 >= 4 &&
+                          (options().bwd_wide == 2 ||
+                           (options().bwd_wide == 1 && h.row_splits == nullptr));
+        const int bkind = ci.p.dense_mul != 0 ? (ci.p.dense_sort ? 1 : 0) : wide ? 3 : 2;
+        ci.kind = 2 * bkind + (ci.shape.vec4 ? 0 : 1);
         ci.onepass = options().bwd_onepass != 0 && ci.p.n_buckets <= kGroupMaxBuckets &&
                      ci.p.tiles <= 64;
       }
@@ -2890,7 +2898,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     int64_t tiles = 0, buckets = 0, segtiles = 0, merges = 0, scans = 0, sync_words = 0;
     size_t lds_hist = 0;
     bool small_scan = true;
-    constexpr int kKinds = 6;
+    constexpr int kKinds = 8;
     int64_t slot_lo[kKinds] = {0}, slot_hi[kKinds] = {0};     // job slots of every kind
     int64_t merge_lo[kKinds] = {0}, merge_hi[kKinds] = {0};   // merge blocks of every kind
     bool have_kind[kKinds] = {false};
@@ -3059,8 +3067,12 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
          &bwd_dense_kernel<f32x4, 2, true>},
         {&bwd_dense_kernel<float, 0, true>, &bwd_dense_kernel<float, 1, true>,
          &bwd_dense_kernel<float, 2, true>},
-        {&bwd_reduce_kernel<f32x4, 0>, &bwd_reduce_kernel<f32x4, 1>, &bwd_reduce_kernel<f32x4, 2>},
-        {&bwd_reduce_kernel<float, 0>, &bwd_reduce_kernel<float, 1>, &bwd_reduce_kernel<float, 2>}};
+        {&bwd_reduce_kernel<f32x4, 0, false>, &bwd_reduce_kernel<f32x4, 1, false>,
+         &bwd_reduce_kernel<f32x4, 2, false>},
+        {&bwd_reduce_kernel<float, 0, false>, &bwd_reduce_kernel<float, 1, false>,
+         &bwd_reduce_kernel<float, 2, false>},
+        {nullptr, &bwd_reduce_kernel<f32x4, 1, true>, &bwd_reduce_kernel<f32x4, 2, true>},
+        {nullptr, &bwd_reduce_kernel<float, 1, true>, &bwd_reduce_kernel<float, 2, true>}};
     static const merge_fn kMerge[kKinds][3] = {
         {&bwd_dense_merge_kernel<f32x4, 0>, &bwd_dense_merge_kernel<f32x4, 1>,
          &bwd_dense_merge_kernel<f32x4, 2>},
@@ -3070,8 +3082,12 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
          &bwd_dense_merge_kernel<f32x4, 2>},
         {&bwd_dense_merge_kernel<float, 0>, &bwd_dense_merge_kernel<float, 1>,
          &bwd_dense_merge_kernel<float, 2>},
-        {&bwd_merge_kernel<f32x4, 0>, &bwd_merge_kernel<f32x4, 1>, &bwd_merge_kernel<f32x4, 2>},
-        {&bwd_merge_kernel<float, 0>, &bwd_merge_kernel<float, 1>, &bwd_merge_kernel<float, 2>}};
+        {&bwd_merge_kernel<f32x4, 0, false>, &bwd_merge_kernel<f32x4, 1, false>,
+         &bwd_merge_kernel<f32x4, 2, false>},
+        {&bwd_merge_kernel<float, 0, false>, &bwd_merge_kernel<float, 1, false>,
+         &bwd_merge_kernel<float, 2, false>},
+        {nullptr, &bwd_merge_kernel<f32x4, 1, true>, &bwd_merge_kernel<f32x4, 2, true>},
+        {nullptr, &bwd_merge_kernel<float, 1, true>, &bwd_merge_kernel<float, 2, true>}};
     for (int kind = 0; kind < kKinds; ++kind) {
       if (!have_kind[kind]) continue;
       const int64_t n_slots = slot_hi[kind] - slot_lo[kind];

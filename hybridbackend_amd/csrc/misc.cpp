@@ -32,6 +32,7 @@ const OptionEntry kOptions[] = {
     {"bwd_onepass", "HBK_BWD_ONEPASS", &Options::bwd_onepass},
     {"bwd_group_cols", "HBK_BWD_GROUP_COLS", &Options::bwd_group_cols},
     {"bwd_dense", "HBK_BWD_DENSE", &Options::bwd_dense},
+    {"bwd_wide", "HBK_BWD_WIDE", &Options::bwd_wide},
     {"fwd_hot_rows", "HBK_FWD_HOT", &Options::fwd_hot_rows},
     {"unique_buckets_log2", "HBK_UNIQUE_LOG2P", &Options::unique_buckets_log2},
     {"partition_sub_tiles", "HBK_PART_SUB", &Options::partition_sub_tiles},

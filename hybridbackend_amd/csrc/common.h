@@ -138,6 +138,7 @@ struct Options {
   int sharded_id64 = 0;          // HBK_SHARDED_ID64: keep int64 ids on the wire
   int sharded_copy_self = 0;     // HBK_SHARDED_COPY_SELF: own slice through a device copy
   int sharded_trace = 0;         // HBK_SHARDED_TRACE: host-side phase times on stderr
+  int sharded_pack_early = 1;    // HBK_SHARDED_PACK_EARLY: ids packed peer-major behind the partition, offsets from the device's sizes (0: after the host has them)
   int sharded_wire_fused = 1;    // HBK_SHARDED_WIRE_FUSED: fp16 wire: gather writes / stitch reads fp16 rows (0: two cast passes)
   int sharded_inline = 0;        // HBK_SHARDED_INLINE: exchanges enqueued on the compute stream (no event hops, no overlap)
   int sync_wait_ms = 2000;       // HBK_SYNC_WAIT_MS: bound of a wait between the tiles of a one-launch kernel

@@ -45,6 +45,7 @@ const OptionEntry kOptions[] = {
     {"sharded_trace", "HBK_SHARDED_TRACE", &Options::sharded_trace},
     {"sharded_inline", "HBK_SHARDED_INLINE", &Options::sharded_inline},
     {"sharded_wire_fused", "HBK_SHARDED_WIRE_FUSED", &Options::sharded_wire_fused},
+    {"sharded_pack_early", "HBK_SHARDED_PACK_EARLY", &Options::sharded_pack_early},
     {"sync_wait_ms", "HBK_SYNC_WAIT_MS", &Options::sync_wait_ms},
     {"sync_onepass_off", "HBK_SYNC_ONEPASS_OFF", &Options::sync_onepass_off},
     {"sync_test_withhold", "HBK_SYNC_TEST_WITHHOLD", &Options::sync_test_withhold},

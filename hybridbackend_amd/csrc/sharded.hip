@@ -136,6 +136,96 @@ __global__ void transpose_sizes_kernel(const int32_t* in, int32_t* out, int n, i
   if (i < n * w) out[(i % w) * n + i / w] = in[i];
 }
 
+// The ids of a step go peer-major into the outgoing buffer BEFORE the host knows the sizes: the
+// offsets of the runs (q, c) are sums over the partition's size matrix S [N][W], which is on the
+// device as soon as the partition is -- every workgroup redoes its column's few sums from S
+// instead of waiting for the host to send them back.  So the pack runs while the host is still
+// asleep on the sizes (it used to be the first thing enqueued after the wake-up: 11 us on the
+// step's critical path for 26 x 65536 ids).  Element e of column c's shard-ordered ids belongs to
+// the shard q with cum[q] <= e < cum[q + 1] and goes to
+//   gbase(group of c) + sum_{q' < q} (ids of the group for q') + sum_{c' < c, same group} S[c'][q]
+//   + e - cum[q].
+constexpr int kMaxPackCols = 400;
+constexpr int kMaxPackWorld = 256;
+constexpr int kPackTile = 2048;
+
+struct PackArgs {
+  const int32_t* S;        // [N][W], written by the partition on the same stream
+  void* dst;               // the set's outgoing ids
+  int64_t dst_items;       // bound of every store (S is garbage when the partition gave up)
+  int32_t n_cols, W, narrow, pad_;
+  const int64_t* src[kMaxPackCols];   // shard-ordered ids of the column
+  int64_t gbase[kMaxPackCols];        // first item of the column's group in dst
+  int32_t n[kMaxPackCols];
+  int32_t tile0[kMaxPackCols];
+  int16_t g0[kMaxPackCols], g1[kMaxPackCols];   // columns of its group
+};
+static_assert(sizeof(PackArgs) <= 16384, "kernarg budget");
+
+__global__ __launch_bounds__(kBlock) void pack_ids_kernel(const PackArgs a) {
+  __shared__ int32_t cum[kMaxPackWorld + 1];     // start of shard q inside the column
+  __shared__ int64_t base[kMaxPackWorld];        // where the run (q, c) starts in dst
+  __shared__ int32_t peer_tot[kMaxPackWorld], before[kMaxPackWorld];
+  int c = 0, hi = a.n_cols;
+  while (hi - c > 1) {
+    const int mid = (c + hi) >> 1;
+    if (a.tile0[mid] <= (int)blockIdx.x) {
+      c = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  const int W = a.W, tid = (int)threadIdx.x;
+  if (tid < W) {
+    int tot = 0, bef = 0;
+    for (int cc = a.g0[c]; cc < a.g1[c]; ++cc) {
+      const int s = a.S[(size_t)cc * W + tid];
+      tot += s;
+      if (cc < c) bef += s;
+    }
+    peer_tot[tid] = tot;
+    before[tid] = bef;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int64_t at = a.gbase[c];
+    int32_t in_col = 0;
+    for (int q = 0; q < W; ++q) {
+      cum[q] = in_col;
+      base[q] = at + before[q];
+      in_col += a.S[(size_t)c * W + q];
+      at += peer_tot[q];
+    }
+    cum[W] = in_col;
+  }
+  __syncthreads();
+  const int32_t n = a.n[c];
+  const int64_t* src = a.src[c];
+  const int32_t e0 = ((int)blockIdx.x - a.tile0[c]) * kPackTile;
+#pragma unroll
+  for (int k = 0; k < kPackTile / kBlock; ++k) {
+    const int32_t e = e0 + k * kBlock + tid;
+    if (e >= n) break;
+    const int64_t v = __builtin_nontemporal_load(src + e);
+    int q = 0, qh = W;       // last q with cum[q] <= e (empty shards share a start: take the last)
+    while (qh - q > 1) {
+      const int mid = (q + qh) >> 1;
+      if (cum[mid] <= e) {
+        q = mid;
+      } else {
+        qh = mid;
+      }
+    }
+    const int64_t at = base[q] + (e - cum[q]);
+    if (at < 0 || at >= a.dst_items) continue;
+    if (a.narrow) {
+      reinterpret_cast<int32_t*>(a.dst)[at] = (int32_t)v;
+    } else {
+      reinterpret_cast<int64_t*>(a.dst)[at] = v;
+    }
+  }
+}
+
 struct Buffer {
   void* ptr = nullptr;
   size_t bytes = 0;
@@ -282,14 +372,15 @@ struct hbk_sharded {
   hipEvent_t ev[4][4];                   // [stage][group]: packed, ids in, gathered, rows in
   bool have_step;
   // device buffers owned by the plan
-  // ids_buf = [ids going out | ids coming in], rows_buf = [rows going out | rows coming in]: one
-  // allocation each, so that a run of this rank's OWN slice can be addressed from either side
-  // (zero_copy_self) with a known, positive offset
+  // ids_buf = ids coming in (the ids going out live in the step's PartSet), rows_buf = [rows
+  // going out | rows coming in]: a run of this rank's OWN slice is addressed from the other side's
+  // base (zero_copy_self) by a signed item offset
   hbk::Buffer part_ws, ids_buf, rows_buf, wire_ws, bwd_ws, runs_dev;
   char* send_ids_p;     // views into ids_buf / rows_buf, set by every forward
   char* recv_ids_p;
   float* send_rows_p;
   float* recv_rows_p;
+  bool pack_early;      // option sharded_pack_early
   bool fused_half;      // fp16 wire, forward: the owner gather WRITES fp16 rows into the reply buffer and
                         // the stitch READS fp16 rows from the received one (hbk_lookup_column_t.half_io): the
                         // two cast passes and the wire workspace are gone (option sharded_wire_fused)
@@ -304,8 +395,11 @@ struct hbk_sharded {
   // set of the last forward stays untouched for its backward.
   struct PartSet {
     hbk::Buffer part_out, shard_index, sizes_dev;
+    hbk::Buffer packed;                // the step's outgoing ids, peer-major per column group
+    bool packed_early = false;         // ... written by run_partition (else by the forward)
     int32_t* host_sizes = nullptr;     // pinned [3][N*W]: S, S^T, R as they sit on the device
     hipEvent_t done = nullptr;         // partition + size exchange + D2H copy finished
+    hipEvent_t ready = nullptr;        // ... and the ids packed: the whole set is written
     std::vector<const int64_t*> ids;   // what was partitioned (match key of a prefetch)
     std::vector<int64_t> n_ids;
     bool pending = false;              // prefetched, not consumed yet
@@ -354,6 +448,7 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
   }
   p->have_step = false;
   p->fused_half = wire_dtype == HBK_HALF && options().sharded_wire_fused != 0;
+  p->pack_early = options().sharded_pack_early != 0;
   p->zero_copy_self = (wire_dtype == HBK_FLOAT || p->fused_half) && options().sharded_copy_self == 0;
   p->zero_copy_grads = p->zero_copy_self && wire_dtype == HBK_FLOAT;
   p->send_ids_p = p->recv_ids_p = nullptr;
@@ -375,6 +470,7 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
             hipEventCreateWithFlags(&p->step_begin, hipEventDisableTiming) == hipSuccess;
   for (auto& set : p->ps) {
     ok = ok && hipEventCreateWithFlags(&set.done, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&set.ready, hipEventDisableTiming) == hipSuccess &&
          hipHostMalloc(reinterpret_cast<void**>(&set.host_sizes),
                        sizeof(int32_t) * 3 * (size_t)n_cols * p->W,
                        hipHostMallocDefault) == hipSuccess;
@@ -401,8 +497,10 @@ extern "C" int hbk_sharded_destroy(hbk_sharded_t p) {
     set.part_out.release();
     set.shard_index.release();
     set.sizes_dev.release();
+    set.packed.release();
     if (set.host_sizes) (void)hipHostFree(set.host_sizes);
     if (set.done) (void)hipEventDestroy(set.done);
+    if (set.ready) (void)hipEventDestroy(set.ready);
   }
   if (p->step_begin) (void)hipEventDestroy(p->step_begin);
   if (p->pre_stream) (void)hipStreamDestroy(p->pre_stream);
@@ -448,6 +546,22 @@ int exchange(hbk_sharded* p, int32_t dtype, int32_t wire, const void* in, const 
                           p->inline_x && before != nullptr);
 }
 
+// Number of column groups the step pipelines.  More groups hide more of the gather / stitch
+// behind the exchanges (exposed compute ~ 1/G of it) at the price of G x more launches and
+// smaller kernels: measured on one rank 298 us (G = 1), 318 us (G = 2), 455 us (G = 4) per
+// forward step.  2 until an 8-GPU measurement says otherwise; option sharded_groups overrides (1..4).
+int pipeline_groups(int n_cols, int world, int requested) {
+  int g = requested >= 1 && requested <= 4 ? requested : 2;
+  if (world == 1 && !(requested >= 1 && requested <= 4)) g = 1;   // nothing on the wire to hide
+  return g < n_cols ? g : n_cols;
+}
+
+// (inline exchanges: nothing runs beside them, one group is all there is to schedule)
+int step_groups(const hbk_sharded* p) {
+  return p->inline_x && !(p->n_groups >= 1 && p->n_groups <= 4)
+             ? 1 : pipeline_groups(p->N, p->W, p->n_groups);
+}
+
 // Stages 1-2 of a step into `set`: bucketize + stable partition of all columns, ONE [N x W] size
 // exchange, sizes to the host (asynchronously: set.done fires when they have arrived).
 int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* const* ids,
@@ -462,6 +576,7 @@ int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* cons
   if ((rc = set.part_out.ensure((size_t)total * 8 + 8)) != HBK_OK) return rc;
   if ((rc = set.shard_index.ensure((size_t)total * 4 + 8)) != HBK_OK) return rc;
   if ((rc = set.sizes_dev.ensure((size_t)N * W * 4 * 3)) != HBK_OK) return rc;
+  if ((rc = set.packed.ensure((size_t)total * (p->id32 ? 4 : 8) + 16)) != HBK_OK) return rc;
   std::vector<int64_t*> pout(N);
   std::vector<int32_t*> sizes(N), idx(N);
   std::vector<int64_t> buckets(N);
@@ -491,19 +606,41 @@ int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* cons
   HBK_HIP_OK(hipMemcpyAsync(set.host_sizes, sizes_dev, sizeof(int32_t) * 3 * N * W,
                             hipMemcpyDeviceToHost, stream));
   HBK_HIP_OK(hipEventRecord(set.done, stream));
+  // the ids go peer-major into the outgoing buffer while the host waits for `done` (pack_ids_kernel)
+  set.packed_early = p->pack_early && N <= kMaxPackCols && W <= kMaxPackWorld && total > 0;
+  if (set.packed_early) {
+    PackArgs a;
+    a.S = sizes_dev;
+    a.dst = set.packed.ptr;
+    a.dst_items = total;
+    a.n_cols = N;
+    a.W = W;
+    a.narrow = p->id32 ? 1 : 0;
+    a.pad_ = 0;
+    const int G = step_groups(p);
+    int64_t tiles = 0, gbase = 0;
+    for (int g = 0; g < G; ++g) {
+      const int c0 = (int)((int64_t)N * g / G), c1 = (int)((int64_t)N * (g + 1) / G);
+      int64_t in_group = 0;
+      for (int c = c0; c < c1; ++c) {
+        a.src[c] = pout[c];
+        a.gbase[c] = gbase;
+        a.n[c] = (int32_t)n_ids[c];
+        a.tile0[c] = (int32_t)tiles;
+        a.g0[c] = (int16_t)c0;
+        a.g1[c] = (int16_t)c1;
+        tiles += (n_ids[c] + kPackTile - 1) / kPackTile;
+        in_group += n_ids[c];
+      }
+      gbase += in_group;
+    }
+    hipLaunchKernelGGL(pack_ids_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, stream, a);
+    HBK_HIP_OK(hipGetLastError());
+  }
+  HBK_HIP_OK(hipEventRecord(set.ready, stream));
   set.ids.assign(ids, ids + N);
   set.n_ids.assign(n_ids, n_ids + N);
   return HBK_OK;
-}
-
-// Number of column groups the step pipelines.  More groups hide more of the gather / stitch
-// behind the exchanges (exposed compute ~ 1/G of it) at the price of G x more launches and
-// smaller kernels: measured on one rank 298 us (G = 1), 318 us (G = 2), 455 us (G = 4) per
-// forward step.  2 until an 8-GPU measurement says otherwise; option sharded_groups overrides (1..4).
-int pipeline_groups(int n_cols, int world, int requested) {
-  int g = requested >= 1 && requested <= 4 ? requested : 2;
-  if (world == 1 && !(requested >= 1 && requested <= 4)) g = 1;   // nothing on the wire to hide
-  return g < n_cols ? g : n_cols;
 }
 
 }  // namespace
@@ -554,8 +691,8 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     use = p->cur ^ 1;       // never the set the last forward (and its backward) lives in
     if (p->prefetch_used) {
       // a dropped prefetch may still be writing that set / the partition workspace on pre_stream
-      HBK_HIP_OK(hipStreamWaitEvent(stream, p->ps[0].done, 0));
-      HBK_HIP_OK(hipStreamWaitEvent(stream, p->ps[1].done, 0));
+      HBK_HIP_OK(hipStreamWaitEvent(stream, p->ps[0].ready, 0));
+      HBK_HIP_OK(hipStreamWaitEvent(stream, p->ps[1].ready, 0));
     }
     HBK_HIP_OK(hipEventRecord(p->step_begin, stream));
     if ((rc = run_partition(p, p->ps[use], ids, n_ids, stream)) != HBK_OK) return rc;
@@ -569,7 +706,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   // the partition's one-launch form may have given up (bounded waits, sync.hip): then the sizes
   // just read are not valid -- THIS step fails, before anything is sized from them
   if ((rc = sync_check("sharded_lookup_fwd")) != HBK_OK) return rc;
-  if (prefetched) HBK_HIP_OK(hipStreamWaitEvent(stream, set.done, 0));
+  if (prefetched) HBK_HIP_OK(hipStreamWaitEvent(stream, set.ready, 0));
   const double t_sync = us_since(t_begin);
   p->send_sizes.assign(set.host_sizes, set.host_sizes + (size_t)N * W);
   p->recv_sizes.assign(set.host_sizes + 2 * (size_t)N * W, set.host_sizes + 3 * (size_t)N * W);
@@ -592,8 +729,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   //   comm    : ids(0) ids(1) ...            rows(0)      rows(1) ...
   //   compute : pack(0..G-1)      gather(0)  gather(1) ..      stitch(0)   stitch(1)
   // (inline exchanges: nothing runs beside them, one group is all there is to schedule)
-  const int G = p->inline_x && !(p->n_groups >= 1 && p->n_groups <= 4)
-                    ? 1 : pipeline_groups(N, W, p->n_groups);
+  const int G = step_groups(p);
   std::vector<Group>& groups = p->groups;
   groups.assign(G, Group());
   int64_t tot_req_ids = 0, tot_own_ids = 0, tot_own_floats = 0, tot_req_floats = 0;
@@ -626,16 +762,16 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   const size_t id_bytes = p->id32 ? 4 : 8;
   const int32_t id_dtype = p->id32 ? HBK_INT32 : HBK_INT64;
   auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  const size_t ids_send_bytes = up256((size_t)tot_req_ids * id_bytes + 16);
   const size_t rows_send_bytes = up256((size_t)tot_own_floats * 4 + 16);
-  if ((rc = p->ids_buf.ensure(ids_send_bytes + (size_t)tot_own_ids * id_bytes + 16)) != HBK_OK) {
-    return rc;
-  }
+  if ((rc = p->ids_buf.ensure((size_t)tot_own_ids * id_bytes + 16)) != HBK_OK) return rc;
   if ((rc = p->rows_buf.ensure(rows_send_bytes + (size_t)tot_req_floats * 4 + 16)) != HBK_OK) {
     return rc;
   }
-  p->send_ids_p = reinterpret_cast<char*>(p->ids_buf.ptr);
-  p->recv_ids_p = p->send_ids_p + ids_send_bytes;
+  // outgoing ids: the set's own buffer (run_partition packed them, or the forward does below);
+  // incoming ids: ids_buf.  Both are hipMalloc'ed (256-byte aligned): a run of this rank's OWN
+  // slice is addressed from the other side's base by a whole (signed) number of items
+  p->send_ids_p = reinterpret_cast<char*>(set.packed.ptr);
+  p->recv_ids_p = reinterpret_cast<char*>(p->ids_buf.ptr);
   p->send_rows_p = reinterpret_cast<float*>(p->rows_buf.ptr);
   p->recv_rows_p = p->send_rows_p + rows_send_bytes / 4;
   if (p->wire_dtype == HBK_HALF && !p->fused_half) {  // staging for the largest group (exchanges are serial)
@@ -659,7 +795,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   const bool half = p->fused_half;   // fp16 rows in the exchange buffers of the forward
   const int me = p->rank;
   // element offsets of the "other side" buffers seen from the owner-side bases of the backward
-  const int64_t ids_send_from_recv = -(int64_t)(ids_send_bytes / id_bytes);
+  const int64_t ids_send_from_recv = (p->send_ids_p - p->recv_ids_p) / (int64_t)id_bytes;
   const int64_t rows_recv_from_send = (int64_t)(rows_send_bytes / 4);
   // run tables of the in-place stitch (column c = W runs over the group's received rows)
   {
@@ -703,22 +839,26 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     HBK_HIP_OK(hipMemcpyAsync(p->runs_dev.ptr, p->host_runs, sizeof(int64_t) * 5 * (size_t)N * W,
                               hipMemcpyHostToDevice, stream));
   }
-  // stage A: pack the ids of every group peer-major (one launch for all groups)
-  std::vector<Seg> segs;
-  segs.reserve((size_t)N * W);
-  for (int g = 0; g < G; ++g) {
-    const Group& gr = groups[g];
-    const int ng = gr.c1 - gr.c0;
-    for (int q = 0; q < W; ++q) {
-      for (int c = 0; c < ng; ++c) {
-        segs.push_back(make_seg(
-            pout[gr.c0 + c] + gr.lay.col_shard_off[(size_t)c * W + q],
-            ids_send_base + (gr.id_send + gr.lay.req_id_off[(size_t)q * ng + c]) * id_bytes,
-            (int64_t)S[(size_t)(gr.c0 + c) * W + q] * 8, p->id32 ? 1 : 0));
+  // stage A: the ids of every group peer-major -- run_partition has done it (pack_ids_kernel, while
+  // the host waited for the sizes); calls beyond that kernel's limits pack here, one launch for
+  // all groups
+  if (!set.packed_early) {
+    std::vector<Seg> segs;
+    segs.reserve((size_t)N * W);
+    for (int g = 0; g < G; ++g) {
+      const Group& gr = groups[g];
+      const int ng = gr.c1 - gr.c0;
+      for (int q = 0; q < W; ++q) {
+        for (int c = 0; c < ng; ++c) {
+          segs.push_back(make_seg(
+              pout[gr.c0 + c] + gr.lay.col_shard_off[(size_t)c * W + q],
+              ids_send_base + (gr.id_send + gr.lay.req_id_off[(size_t)q * ng + c]) * id_bytes,
+              (int64_t)S[(size_t)(gr.c0 + c) * W + q] * 8, p->id32 ? 1 : 0));
+        }
       }
     }
+    if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
   }
-  if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
   // one rank with its own slice left in place: nothing goes on the wire, the step stays on the
   // compute stream (no hops to the communicator's stream and back)
   const bool wire = !(W == 1 && zc);

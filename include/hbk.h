@@ -76,7 +76,7 @@ const char* hbk_version(void);
  * Names: bwd_buckets_log2, bwd_bucket_pairs, bwd_split_pairs, bwd_onepass, bwd_group_cols, bwd_dense, bwd_wide, fwd_hot_rows,
  * unique_buckets_log2,
  * unique_onepass, partition_sub_tiles, partition_fixed_max, partition_onepass, sharded_groups,
- * sharded_id64, sharded_copy_self, sharded_trace, sharded_inline, sharded_wire_fused (the sharded_* ones are taken by
+ * sharded_id64, sharded_copy_self, sharded_trace, sharded_inline, sharded_wire_fused, sharded_pack_early (the sharded_* ones are taken by
  * hbk_sharded_create), sync_wait_ms, sync_onepass_off, sync_test_withhold.
  * *_onepass (default 1): small calls of partition / unique / the backward group their ids in ONE
  * launch whose tiles wait for each other; 0 keeps the multi-launch forms.  The

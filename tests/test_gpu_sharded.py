@@ -198,11 +198,13 @@ def test_sharded_backward_through_rccl_world1_with_apply():
     coll.close()
 
 
-@pytest.mark.parametrize('world,wire16,id64,inline', [
-    (2, False, False, 0), (4, True, False, 0), (8, False, False, 0), (4, False, True, 0),
-    (4, False, False, 1), (8, True, False, 1), (2, False, True, 1), (4, 'unfused', False, 0),
-    (1, True, False, 0)])
-def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64, inline):
+@pytest.mark.parametrize('world,wire16,id64,inline,pack_early', [
+    (2, False, False, 0, 1), (4, True, False, 0, 1), (8, False, False, 0, 1), (4, False, True, 0, 1),
+    (4, False, False, 1, 1), (8, True, False, 1, 1), (2, False, True, 1, 1),
+    (4, 'unfused', False, 0, 1), (1, True, False, 0, 1),
+    (2, False, False, 0, 0), (8, True, False, 1, 0), (4, False, True, 0, 0)])
+def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64, inline,
+                                                pack_early):
   """hbk_sharded_lookup_fwd/_bwd (the code that runs at 8 GPUs) with W ranks as host threads
   of one process on one GPU; only the transport differs from production (device copies
   instead of RCCL).  Forward == unsharded oracle lookup, backward == dense scatter-add.
@@ -212,6 +214,9 @@ def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64,
   if id64:   # ids travel as int32 by default (all buckets < 2^31); this keeps int64 on the wire
     hbk_option('sharded_id64', 1)
   hbk_option('sharded_inline', inline)
+  # the ids are packed peer-major behind the partition from the sizes on the device (default), or
+  # by the forward once the host has the sizes
+  hbk_option('sharded_pack_early', pack_early)
   # fp16 wire: by default the owner gather writes fp16 rows and the stitch reads them (no cast
   # passes, the own slice stays in place); 'unfused' keeps the two casts through a wire workspace
   hbk_option('sharded_wire_fused', 0 if wire16 == 'unfused' else 1)

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(kBlock) void unique_scatter_kernel(const UArgs a) {
         const int32_t pos = atomicAdd(&run[bucket_of((uint64_t)key[k], c.log2p)], 1);
         c.pair_key[pos] = key[k];
         c.pair_idx[pos] = (int32_t)j;
+        c.first[j] = (int32_t)j;   // (see unique_first_kernel: only the repeats are rewritten)
       }
     }
   }
@@ -333,7 +334,10 @@ __global__ __launch_bounds__(kFirstBlock) void unique_first_kernel(const UArgs a
           }
         }
       }
-      c.first[idx[k]] = (int32_t)f;
+      // first[] was filled with the identity, in order, where the ids were read (coalesced);
+      // only the repeats are corrected here -- one isolated 4-byte store per id of a column
+      // costs a partial line each
+      if (f != idx[k]) c.first[idx[k]] = (int32_t)f;
     }
   }
   HBK_USTAMP(1, 4);
@@ -505,6 +509,13 @@ __global__ __launch_bounds__(kBlock, 4) void unique_group_kernel(const UArgs a, 
     }
   }
   HBK_USTAMP(0, 3);
+  // first[] starts as the identity, written in order while the tile waits for the others
+  // (unique_first_kernel corrects the repeats only)
+#pragma unroll
+  for (int k = 0; k < kBigPerThread; ++k) {
+    const int64_t j = base + (int64_t)k * kBlock + tid;
+    if (j < c.len) c.first[j] = (int32_t)j;
+  }
   // totals of every bucket over the column's tiles and the part of the tiles before this one
   // (a thread per bucket, 16 tiles per poll), left in LDS for the scan
   const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();

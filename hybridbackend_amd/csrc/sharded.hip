@@ -896,6 +896,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
         h.n_segments = n;
         h.divisor = W;
         h.combiner = HBK_COMBINER_SUM;
+        h.hot_rows = col.hot_rows;
         int64_t out_at = gr.row_send + gr.lay.own_row_off[(size_t)q * ng + c];   // elements
         float* out_base = rows_send_base;
         if (zc && q == me) {

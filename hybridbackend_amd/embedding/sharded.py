@@ -61,10 +61,12 @@ class ShardedGroupLookup:
     combiners: as for ``GroupLookup``.
     wire_dtype: ``torch.float16`` sends the embedding rows as fp16 (``comm_wire_dtype``,
       collective.py:291-296); None keeps fp32.
+    hot_rows: as for ``GroupLookup`` (skewed ids: the owner-side gather of wide columns stages the
+      rows repeated inside a tile in LDS); a bool or one per column.
   """
 
   def __init__(self, shards, coll, buckets=None, combiners='sum', wire_dtype=None,
-               world_size=None, accums=None):
+               world_size=None, accums=None, hot_rows=False):
     self.shards = list(shards)
     # Adagrad accumulators of the shards (same shapes), for backward(optimizer='adagrad')
     self.accums = list(accums) if accums is not None else None
@@ -76,13 +78,16 @@ class ShardedGroupLookup:
     self.wire_dtype = wire_dtype
     self.device = self.shards[0].device if n else None
     self.dims = [int(t.shape[1]) for t in self.shards]
+    self.hot_rows = [bool(hot_rows)] * n if isinstance(hot_rows, (bool, int)) else \
+        [bool(h) for h in hot_rows]
     self._setup()
 
   def _setup(self):
     """Device-side state of the compute phases (the HIP path; there is no other)."""
     self._lib = _lib.lib()
     # owner-side gather: ids arrive bucketized, row = id // W (sharding.py:188-189)
-    self._owner = GroupLookup(self.shards, None, 'sum', divisor=self.world_size)
+    self._owner = GroupLookup(self.shards, None, 'sum', divisor=self.world_size,
+                              hot_rows=self.hot_rows)
     self._owner_grad = GroupLookupGrad(self._owner)
 
   # ---- phase 1: bucketize + stable partition -------------------------------------
@@ -138,6 +143,7 @@ class ShardedGroupLookup:
         cols[c].dim = t.shape[1]
         cols[c].combiner = _combiner_code(combs[c])
         cols[c].bucket = self.buckets[c]
+        cols[c].hot_rows = 1 if self.hot_rows[c] else 0
         if self.accums is not None:
           cols[c].accum = self.accums[c].data_ptr()
       self._plan_handle = C.c_void_p()

@@ -472,6 +472,9 @@ typedef struct {
   int32_t combiner;
   int64_t bucket;       /* >0: ids are taken modulo this before the partition (R1) */
   float* accum;         /* Adagrad accumulator of the shard [rows_local, dim], or NULL */
+  int32_t hot_rows;     /* != 0: skewed ids expected: the owner gather stages the rows repeated in a
+                           tile in LDS (hbk_lookup_column_t.hot_rows; wide columns only) */
+  int32_t reserved_;    /* 0 */
 } hbk_sharded_column_t;
 
 /* Host arithmetic of the peer-major exchange buffers (pure host code, no device work): S is

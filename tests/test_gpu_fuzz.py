@@ -191,8 +191,8 @@ sharded_column = st.fixed_dictionaries({
 
 @_cfg(24)
 @given(world=st.sampled_from([2, 3, 5]), cols=st.lists(sharded_column, min_size=1, max_size=5),
-       wire16=st.booleans(), seed=st.integers(0, 2**31 - 1))
-def test_sharded_driver_random_in_process_world(world, cols, wire16, seed):
+       wire16=st.booleans(), hot=st.booleans(), seed=st.integers(0, 2**31 - 1))
+def test_sharded_driver_random_in_process_world(world, cols, wire16, hot, seed):
   """hbk_sharded_lookup_fwd/_bwd with W in-process ranks (W not a power of two included), random
   columns, some ranks / columns empty: forward == unsharded oracle, backward == dense
   scatter-add."""
@@ -231,7 +231,7 @@ def test_sharded_driver_random_in_process_world(world, cols, wire16, seed):
     try:
       with torch.cuda.stream(torch.cuda.Stream()):
         drv = ShardedGroupLookup(shards[r], comms[r], buckets=rows, combiners=combs,
-                                 wire_dtype=torch.float16 if wire16 else None)
+                                 wire_dtype=torch.float16 if wire16 else None, hot_rows=hot)
         outs = drv([dev(i) for i in ids[r]], [None if s is None else dev(s) for s in splits[r]])
         sl = drv.backward([dev(g) for g in grads[r]])
         torch.cuda.current_stream().synchronize()

@@ -128,6 +128,7 @@ def _declare(l):
     'hbk_sharded_lookup_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     'hbk_sharded_prefetch': (C.c_int, [vp, vp, vp, vp]),
     'hbk_sharded_owned_ids': (i64, [vp, i32]),
+    'hbk_sharded_last_host_us': (C.c_int, [vp, vp]),
     'hbk_sharded_lookup_bwd': (C.c_int, [vp, vp, vp, C.c_float, vp, vp, vp, vp]),
     'hbk_sharded_lookup_bwd_apply': (C.c_int, [vp, vp, vp, i32, C.c_float, vp, vp, vp, vp]),
   }

@@ -371,6 +371,7 @@ struct hbk_sharded {
   std::vector<int64_t> fwd_own_id_off;   // [W][N] where run (q, c) of the forward sits in recv_ids
   hipEvent_t ev[4][4];                   // [stage][group]: packed, ids in, gathered, rows in
   bool have_step;
+  float host_us[3];     // host time of the last forward: enqueue 1-2, wait for the sizes, enqueue the rest
   // device buffers owned by the plan
   // ids_buf = ids coming in (the ids going out live in the step's PartSet), rows_buf = [rows
   // going out | rows coming in]: a run of this rank's OWN slice is addressed from the other side's
@@ -966,6 +967,9 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     if (rc != HBK_OK) return rc;
   }
   p->have_step = true;
+  p->host_us[0] = (float)t_enq1;
+  p->host_us[1] = (float)(t_sync - t_enq1);
+  p->host_us[2] = (float)(us_since(t_begin) - t_sync);
   if (trace) {
     fprintf(stderr, "hbk_sharded_lookup_fwd host us: enqueue partition+sizes %.1f, sync wait %.1f, "
                     "enqueue rest %.1f (G = %d, W = %d%s)\n",
@@ -1118,6 +1122,16 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
                                     p->bwd_ws.ptr, p->bwd_ws.bytes, stream_);
     if (rc != HBK_OK) return rc;
   }
+  return HBK_OK;
+}
+
+// host-side phases of the last forward (us): enqueueing partition + size exchange, the wait for
+// the sizes (the device finishing the partition, not host work), enqueueing everything else
+extern "C" int hbk_sharded_last_host_us(hbk_sharded_t p, float* out3) {
+  using namespace hbk;
+  HBK_REQUIRE(p != nullptr && out3 != nullptr, "sharded_last_host_us: NULL argument");
+  HBK_REQUIRE(p->have_step, "sharded_last_host_us: no forward step yet");
+  for (int i = 0; i < 3; ++i) out3[i] = p->host_us[i];
   return HBK_OK;
 }
 

@@ -152,6 +152,13 @@ class ShardedGroupLookup:
         C.byref(self._plan_handle), self.coll._handle, n, cols, wire))
     return self._plan_handle
 
+  def last_host_us(self):
+    """Host time of the last forward step in microseconds: (enqueueing the partition and the
+    size exchange, waiting for the sizes -- the device, not host work --, enqueueing the rest)."""
+    out = (C.c_float * 3)()
+    _lib.check(self._lib.hbk_sharded_last_host_us(self._plan(), out))
+    return tuple(float(v) for v in out)
+
   def close(self):
     if getattr(self, '_plan_handle', None) is not None:
       self._lib.hbk_sharded_destroy(self._plan_handle)

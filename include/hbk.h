@@ -504,6 +504,10 @@ int hbk_sharded_prefetch(hbk_sharded_t plan, const int64_t* const* ids, const in
                          void* ids_ready_event /* hipEvent_t recorded after the ids were written,
                                                   or NULL when they are complete already */);
 int64_t hbk_sharded_owned_ids(hbk_sharded_t plan, int32_t column);
+/* diagnostics: host time of the plan's last forward in microseconds -- [0] enqueueing the
+ * partition and the size exchange, [1] waiting for the sizes (the device, not host work),
+ * [2] enqueueing everything else */
+int hbk_sharded_last_host_us(hbk_sharded_t plan, float* out3);
 int hbk_sharded_lookup_bwd(hbk_sharded_t plan, const float* const* grads,
                            const int32_t* grad_strides, float apply_lr,
                            int64_t* const* unique_rows, float* const* grad_rows,

@@ -118,6 +118,8 @@ def test_sharded_call_through_rccl_world1(hbk_option, groups, inline):
     want = oracle.group_lookup_fwd(tables, ids, [None] * 3, [5000] * 3, ['sum'] * 3)
     for o, w in zip(outs, want):
       np.testing.assert_equal(o.cpu().numpy(), w)
+    phases = drv.last_host_us()   # enqueue 1-2 / wait for the sizes / enqueue the rest
+    assert len(phases) == 3 and all(0.0 <= v < 5e6 for v in phases) and sum(phases) > 0.0
   finally:
     coll.close()
 

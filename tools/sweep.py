@@ -335,8 +335,12 @@ def case_sharded_world1():
       drv.launch(bound[i % nb])
     host_us = (time.perf_counter() - t0) / 20 * 1e6
     torch.cuda.synchronize()
+    # the call's wall time includes its one wait for the device (the sizes); the plan reports the
+    # host's own phases of the last step: enqueue partition + size exchange / wait / enqueue rest
+    phases = [round(v, 1) for v in drv.last_host_us()]
     report(f'sharded pipeline W=1 fwd dim16 B={B} wire={"fp16" if wire else "fp32"}', us, 26 * B,
-           26 * B * 136, host_enqueue_us=round(host_us, 1))
+           26 * B * 136, call_wall_us=round(host_us, 1), host_enqueue_wait_enqueue_us=phases,
+           host_enqueue_us=round(phases[0] + phases[2], 1))
   drv.close()
   drv.wire_dtype = None
   gouts = [torch.randn(B, 16, device=DEV) for _ in range(26)]

@@ -123,6 +123,9 @@ struct Options {
   int bwd_bucket_pairs = 0;    // HBK_BWD_TARGET: aimed pairs per bucket (0: default)
   int bwd_split_pairs = 0;     // HBK_BWD_SPLIT: pairs per workgroup of a split bucket (0: default)
   int bwd_onepass = 1;         // HBK_BWD_ONEPASS: 0 = histogram, scan and scatter as three launches
+  int fwd_xcd = 1;             // HBK_FWD_XCD: lookup tiles dealt to the XCDs in contiguous ranges (0 never: round robin,
+                               // 1 the hot-row kernel, 2 always)
+  int bwd_xcd = 1;             // HBK_BWD_XCD: reduce jobs dealt to the XCDs in contiguous ranges (0: round robin)
   int bwd_wide = 1;            // HBK_BWD_WIDE: wide sorted walk of the hashed backward (0 never,
                                // 1 columns of one id per sample, 2 ragged columns too)
   int bwd_group_cols = 0;      // HBK_BWD_GROUP_COLS: columns per launch group of the backward (0: 64)

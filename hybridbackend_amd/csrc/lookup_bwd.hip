@@ -221,7 +221,7 @@ struct GArgs {
   int32_t n_cols;
   float lr;
   int32_t apply;             // 0 none / SGD by lr, 2 Adagrad
-  int32_t pad_;
+  int32_t xcd;               // != 0: every XCD takes a contiguous range of the reduce jobs (xcd_contiguous)
   // first block of every column in the grids below (copies of the GCol fields, kept together so
   // that a block finds its column with ONE wave-wide load + ballot instead of a binary search of
   // dependent scalar loads -- each a cold miss at kernel start)
@@ -236,6 +236,12 @@ static_assert(sizeof(GArgs) <= 24576, "kernarg budget");
 static_assert(kMaxCols <= kWave, "one lane per column in HBK_FIND_COL");
 static_assert(kSlots <= 65536 && kCP <= 65536, "16-bit LDS indices");
 
+// Reduce jobs go to the XCDs in contiguous ranges (xcd_contiguous, lookup_common.h): consecutive
+// jobs are the buckets of ONE column -- dealt round robin, a column's gradient rows were read
+// through all eight L2s, every 128-byte line of 64-byte rows once per XCD that meets one of its
+// halves; now both halves of a line (dim 16; four rows of dim 8) and the 8 reads of a ragged
+// column's segment gradients meet in one 4 MB L2 (if the line lives that long: config 2 -10 % of
+// the reduce kernel's read requests, -3.5 us).
 #define HBK_FIND_COL(ARGS, FIELD)                                                  \
   int ci;                                                                          \
   {                                                                                \
@@ -2311,7 +2317,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
   HBK_STAMP_BEGIN()
   const int lane = (int)threadIdx.x & (kWave - 1);
   const int team = (int)threadIdx.x / kTeam;
-  const int vb = slot0 + (int)blockIdx.x * kTeams + team;   // the team's job slot
+  const int vb = slot0 + xcd_contiguous((int)blockIdx.x, (int)gridDim.x, a.xcd) * kTeams + team;   // the team's job slot
   if (vb >= total) return;                          // team-uniform; no workgroup barrier follows
   // two independent loads (the job, the columns' first slots): one round trip
   const int4 d = desc[vb];
@@ -2336,7 +2342,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(SORT)) void bwd_dense_k
   if (poisoned(poison)) return;   // the grouping launch gave up: no descriptors, no pairs
   HBK_STAMP_BEGIN()
   const int lane = (int)threadIdx.x & (kWave - 1);
-  const int vb = slot0 + (int)blockIdx.x;
+  const int vb = slot0 + xcd_contiguous((int)blockIdx.x, (int)gridDim.x, a.xcd);
   if (vb >= total) return;
   const int4 d = desc[vb];
   const int my_b0 = lane < a.n_cols ? a.bucket0[lane] : 0x7fffffff;
@@ -3014,7 +3020,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     args.n_cols = k;
     args.lr = apply_lr;
     args.apply = apply;
-    args.pad_ = 0;
+    args.xcd = options().bwd_xcd != 0 ? 1 : 0;
     if (ks > 0) {
       seg_args.n_cols = ks;
       seg_args.lr = 0.f;

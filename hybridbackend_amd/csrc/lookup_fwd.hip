@@ -97,6 +97,8 @@ __device__ inline void store_out_chunk(float* out, int64_t off, V v) {
 struct LookupArgs {
   int32_t n_cols;
   int32_t hot_mode;   // hot-row kernel only: 1 = stage repeated rows in LDS, 2 = large tiles only
+  int32_t xcd;        // != 0: every XCD takes a contiguous range of the tiles (xcd_contiguous)
+  int32_t pad_;
   int32_t tile_start[kMaxColsPerLaunch + 1];
   ColArg col[kMaxColsPerLaunch];
 };
@@ -220,7 +222,7 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
 // launches each kind present in the call with the columns of that kind.
 template <bool CSR, typename V, bool RUNS, int HALF = 0>
 __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupArgs a) {
-  const int b = (int)blockIdx.x;
+  const int b = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, a.xcd);
   // last column whose first tile is <= b.  A binary search over the kernel-argument table is
   // up to 7 DEPENDENT scalar loads (each a cold miss at kernel start); here every lane reads
   // one entry (two independent loads cover 128 columns) and a ballot counts the entries <= b:
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const Look
   __shared__ uint16_t stage_slot[kHotMaxStage];
   __shared__ float stage[kHotStageFloats];
   __shared__ int32_t n_staged;
-  const int b = (int)blockIdx.x;
+  const int b = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, a.xcd);
   const int tid = (int)threadIdx.x;
   int ci;
   {
@@ -481,6 +483,8 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
     while (c0 < n_cols) {
       LookupArgs args;
       args.hot_mode = hot_mode > 0 ? hot_mode : 1;
+      args.xcd = 0;
+      args.pad_ = 0;
       int32_t k = 0;
       int64_t tiles = 0;
       args.tile_start[0] = 0;
@@ -536,6 +540,16 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
       }
       if (k == 0) continue;
       args.n_cols = k;
+      // Tiles to XCDs (xcd_contiguous): whole columns per XCD for the hot-row kernel -- a hot row
+      // staged by many tiles of its column is then fetched through ONE L2 instead of eight.
+      // Toggled inside one process on the same tensors (tools/sweep.py, SWEEP_J_XCD; between
+      // processes the same setting differs by up to 15 % on config 4): hot-row tiles Zipf 221 ->
+      // 213-220 us, without the staging (mode 2) 244 -> 223-230, uniform ids 351-355 -> 331-347;
+      // the per-wave kernels gain nothing (config 4 Zipf 235-241 either way) or lose (one row per
+      // column 202 -> 209, config 2 with its 64-byte rows 56.9 -> 59.1 us between processes), so
+      // they keep the round-robin placement.  Option fwd_xcd: 0 never, 1 this rule, 2 always.
+      const int xcd_opt = options().fwd_xcd;
+      args.xcd = xcd_opt == 2 || (xcd_opt == 1 && kind == 8) ? 1 : 0;
       launch_by_kind(kind, args, (unsigned)tiles, as_stream(stream));
       HBK_HIP_OK(hipGetLastError());
     }

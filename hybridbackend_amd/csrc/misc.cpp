@@ -33,6 +33,8 @@ const OptionEntry kOptions[] = {
     {"bwd_group_cols", "HBK_BWD_GROUP_COLS", &Options::bwd_group_cols},
     {"bwd_dense", "HBK_BWD_DENSE", &Options::bwd_dense},
     {"bwd_wide", "HBK_BWD_WIDE", &Options::bwd_wide},
+    {"bwd_xcd", "HBK_BWD_XCD", &Options::bwd_xcd},
+    {"fwd_xcd", "HBK_FWD_XCD", &Options::fwd_xcd},
     {"fwd_hot_rows", "HBK_FWD_HOT", &Options::fwd_hot_rows},
     {"unique_buckets_log2", "HBK_UNIQUE_LOG2P", &Options::unique_buckets_log2},
     {"partition_sub_tiles", "HBK_PART_SUB", &Options::partition_sub_tiles},

@@ -20,7 +20,7 @@ DEV = torch.device('cuda', 0)
 PEAK = 8000.0
 
 
-def timed(fn, iters=20, warmup=3):
+def _timed_once(fn, iters, warmup):
   for i in range(warmup):
     fn(i)
   torch.cuda.synchronize()
@@ -31,6 +31,28 @@ def timed(fn, iters=20, warmup=3):
   e1.record()
   torch.cuda.synchronize()
   return e0.elapsed_time(e1) * 1e3 / iters  # us
+
+
+def timed(fn, iters=20, warmup=8):
+  """SWEEP_AB="bwd_xcd:0,1,0,1": every measurement is repeated under each value of the option,
+  inside this process and on the same tensors (between processes the same setting differs by up
+  to 15 % on the large-table cases: where the tables land); the extra line carries all times."""
+  ab = os.environ.get('SWEEP_AB')
+  if not ab:
+    return _timed_once(fn, iters, warmup)
+  from hybridbackend_amd import _lib
+  name, values = ab.split(':')
+  values = [int(v) for v in values.split(',')]
+  old = _lib.get_option(name)
+  times = []
+  try:
+    for v in values:
+      _lib.set_option(name, v)
+      times.append(round(_timed_once(fn, iters, warmup), 2))
+  finally:
+    _lib.set_option(name, old)
+  print(json.dumps(dict(ab=name, values=values, us=times)), flush=True)
+  return times[0]
 
 
 def report(name, us, lookups, nbytes, **extra):
@@ -188,15 +210,23 @@ def case_cfg4_hot_rows(big):
       gl.bind(batches[b], None, outs)
       plans.append(gl)
     uniq = sum(int(torch.unique(batches[0][c]).numel()) for c in range(26))
-    for mode in (0, 1, 2):
-      old = _lib.set_option('fwd_hot_rows', mode)
-      try:
-        us = timed(lambda i: plans[i % nb].launch(), iters=20)
-      finally:
-        _lib.set_option('fwd_hot_rows', old)
-      report(f'cfg4 fwd {name} dim128 B={B} fwd_hot_rows={mode}', us, 26 * B,
-             26 * B * (8 + 512 + 512), unique_rows=uniq,
-             dedup_aware_GBps=round((26 * B * (8 + 512) + uniq * 512) / us / 1e3, 1))
+    # SWEEP_J_XCD="0,2,0,2": the tile -> XCD mapping (option fwd_xcd) toggled inside ONE process --
+    # between processes the same setting differs by up to 15 % here (where the tables land)
+    xcds = [int(v) for v in os.environ.get('SWEEP_J_XCD', '-1').split(',')]
+    for xcd in xcds:
+      old_x = _lib.set_option('fwd_xcd', xcd) if xcd >= 0 else None
+      for mode in (0, 1, 2):
+        old = _lib.set_option('fwd_hot_rows', mode)
+        try:
+          us = timed(lambda i: plans[i % nb].launch(), iters=20)
+        finally:
+          _lib.set_option('fwd_hot_rows', old)
+        tag = f' fwd_xcd={xcd}' if xcd >= 0 else ''
+        report(f'cfg4 fwd {name} dim128 B={B} fwd_hot_rows={mode}{tag}', us, 26 * B,
+               26 * B * (8 + 512 + 512), unique_rows=uniq,
+               dedup_aware_GBps=round((26 * B * (8 + 512) + uniq * 512) / us / 1e3, 1))
+      if old_x is not None:
+        _lib.set_option('fwd_xcd', old_x)
 
 
 def case_integer():

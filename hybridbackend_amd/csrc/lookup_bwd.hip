@@ -782,6 +782,33 @@ struct ReduceJob {
                              // is written out and no output range is claimed
 };
 
+// How a gradient chunk is loaded: PLAIN.  The non-temporal hint these loads carried through
+// round 2 tells L2 not to keep the line -- but a 128-byte line holds two rows of dim 16 (four of
+// dim 8), asked for by two different buckets a few microseconds apart, and a ragged column reads
+// every segment gradient ~8 times: with plain loads (and whole columns per XCD, xcd_contiguous)
+// config 2 100.5 -> 91.7 us, SGD step only 150 -> 131.5, ragged dim 16 / 64 + SGD 774 -> 704 /
+// 1367 -> 1269, over 10 M rows 1037 -> 901 (tools/scratch/bwd_cache_variants.sh, two visits each).
+// Write-through stores of the output rows (so that they do not push gradient lines out of L2)
+// change nothing (HBK_BWD_OUT_WT).  -DHBK_BWD_GRAD_NT=1 brings the hint back (probe builds).
+#ifndef HBK_BWD_GRAD_NT
+#define HBK_BWD_GRAD_NT 0
+#endif
+#if HBK_BWD_GRAD_NT
+#define HBK_GRAD_LOAD(P) __builtin_nontemporal_load(P)
+#else
+#define HBK_GRAD_LOAD(P) (*(P))
+#endif
+
+// table / accumulator rows of the optimizer step (probe builds: -DHBK_BWD_STEP_NT=0 plain loads)
+#ifndef HBK_BWD_STEP_NT
+#define HBK_BWD_STEP_NT 1
+#endif
+#if HBK_BWD_STEP_NT
+#define HBK_STEP_LOAD(P) __builtin_nontemporal_load(P)
+#else
+#define HBK_STEP_LOAD(P) (*(P))
+#endif
+
 template <typename V>
 __device__ inline V load_grad(const GCol& c, const ReduceJob& job, int32_t seg, int sub) {
   constexpr int VE = sizeof(V) / 4;
@@ -789,8 +816,7 @@ __device__ inline V load_grad(const GCol& c, const ReduceJob& job, int32_t seg, 
 #ifdef HBK_BWD_ABLATE_LOADS   // probe builds: what the kernel costs without its gradient traffic
   V g = zero_v<V>() + (float)(off & 7);
 #else
-  V g = __builtin_nontemporal_load(
-      reinterpret_cast<const V*>(job.grad + off + (int64_t)sub * VE));
+  V g = HBK_GRAD_LOAD(reinterpret_cast<const V*>(job.grad + off + (int64_t)sub * VE));
 #endif
   if (job.scale && c.combiner != HBK_COMBINER_SUM && c.splits != nullptr) {
     const int32_t n = c.splits[seg + 1] - c.splits[seg];
@@ -809,8 +835,7 @@ __device__ inline V load_grad_lds(const GCol& c, const ReduceJob& job, int32_t s
 #ifdef HBK_BWD_ABLATE_LOADS
   V g = zero_v<V>() + (float)(off & 7);
 #else
-  V g = __builtin_nontemporal_load(
-      reinterpret_cast<const V*>(job.grad + off + (int64_t)sub * VE));
+  V g = HBK_GRAD_LOAD(reinterpret_cast<const V*>(job.grad + off + (int64_t)sub * VE));
 #endif
   if (scaled) g = c.combiner == HBK_COMBINER_MEAN ? g / (float)n : g / sqrtf((float)n);
   return g;
@@ -824,8 +849,7 @@ __device__ inline V load_grad_raw(const GCol& c, const ReduceJob& job, int32_t s
                                   int32_t* n) {
   constexpr int VE = sizeof(V) / 4;
   const int64_t off = job.seg_is_offset ? (int64_t)(uint32_t)seg : (int64_t)seg * job.stride;
-  const V g = __builtin_nontemporal_load(
-      reinterpret_cast<const V*>(job.grad + off + (int64_t)sub * VE));
+  const V g = HBK_GRAD_LOAD(reinterpret_cast<const V*>(job.grad + off + (int64_t)sub * VE));
   *n = 0;
   if (job.scale && c.combiner != HBK_COMBINER_SUM && c.splits != nullptr) {
     *n = c.splits[seg + 1] - c.splits[seg];
@@ -851,6 +875,18 @@ __device__ inline f32x4 rsqrt_v<f32x4>(f32x4 a) {
   return f32x4{1.0f / sqrtf(a.x), 1.0f / sqrtf(a.y), 1.0f / sqrtf(a.z), 1.0f / sqrtf(a.w)};
 }
 
+// A row chunk stored write-through (sc0 sc1): the line does not stay in the XCD's L2 (probe builds,
+// -DHBK_BWD_OUT_WT=1: do the output rows push the gradient lines out of L2?)
+#ifndef HBK_BWD_OUT_WT
+#define HBK_BWD_OUT_WT 0
+#endif
+__device__ inline void store_wt(f32x4* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ inline void store_wt(float* p, float v) {
+  asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+
 // out row u += (or =) v
 template <typename V>
 __device__ inline void emit_row(const GCol& c, const ReduceJob& job, int32_t u, bool is_new,
@@ -862,7 +898,15 @@ __device__ inline void emit_row(const GCol& c, const ReduceJob& job, int32_t u, 
   (void)is_new;
 #else
   // rows are owned by this workgroup; bypass L1 when re-reading what an earlier chunk wrote
+#if HBK_BWD_OUT_WT
+  if (is_new) {
+    store_wt(o, v);
+  } else {
+    *o = __builtin_nontemporal_load(o) + v;
+  }
+#else
   *o = is_new ? v : __builtin_nontemporal_load(o) + v;
+#endif
 #endif
 }
 
@@ -892,9 +936,9 @@ __device__ inline void emit_step_row(const GCol& c, const ReduceJob& job, float 
   if (STEP && lr != 0.0f) {
     constexpr bool adagrad = STEP == 2;
     const int64_t toff = row * c.dim + (int64_t)sub * VE;
-    const V tv = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+    const V tv = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
     V av = zero_v<V>();
-    if (adagrad) av = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
+    if (adagrad) av = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.accum + toff));
     step_row<V>(c, adagrad, lr, toff, v, tv, av);
   }
 }
@@ -1245,10 +1289,10 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
                 // the table (and accumulator) row of the step travels with the gradient
                 const int64_t toff = (int64_t)L.keys[sidx] * c.dim + (int64_t)sub * VE;
                 tv[STEP ? k : 0] =
-                    __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+                    HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
                 if (STEP == 2) {
                   av[STEP == 2 ? k : 0] =
-                      __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
+                      HBK_STEP_LOAD(reinterpret_cast<const V*>(c.accum + toff));
                 }
               }
             }
@@ -1433,10 +1477,10 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
                   tv[b] = zero_v<V>();
                   if (w < kW && (fin >> w & 1u)) {
                     const int64_t toff = (int64_t)L.keys[sl[w]] * c.dim + (int64_t)sub * VE;
-                    tv[b] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+                    tv[b] = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
                     if (STEP == 2) {
                       av[STEP == 2 ? b : 0] =
-                          __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
+                          HBK_STEP_LOAD(reinterpret_cast<const V*>(c.accum + toff));
                     }
                   }
                 }
@@ -1515,9 +1559,9 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
             toff[k] = (int64_t)L.keys[s] * c.dim + (int64_t)sub * VE;
             g[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(
                 job.out_vals + (int64_t)L.slot_out[s] * c.dim + (int64_t)sub * VE));
-            tv[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff[k]));
+            tv[k] = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff[k]));
             if (adagrad) {
-              av[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff[k]));
+              av[k] = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.accum + toff[k]));
             }
           }
         }
@@ -1771,10 +1815,10 @@ __device__ inline void dense_walk(const WalkArgs w_, DenseLds& L) {
           if (STEP && lr != 0.0f) {
             const int64_t toff = (int64_t)(base + off) * c.dim + (int64_t)sub * VE;
             tv[STEP ? w : 0] =
-                __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+                HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
             if (STEP == 2) {
               av[STEP == 2 ? w : 0] =
-                  __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
+                  HBK_STEP_LOAD(reinterpret_cast<const V*>(c.accum + toff));
             }
           }
         }
@@ -2106,10 +2150,10 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
                 if (STEP && lr != 0.0f) {
                   const int64_t toff = (int64_t)(base + L.off[i]) * c.dim + (int64_t)sub * VE;
                   tv[STEP ? k : 0] =
-                      __builtin_nontemporal_load(reinterpret_cast<const V*>(c.table + toff));
+                      HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
                   if (STEP == 2) {
                     av[STEP == 2 ? k : 0] =
-                        __builtin_nontemporal_load(reinterpret_cast<const V*>(c.accum + toff));
+                        HBK_STEP_LOAD(reinterpret_cast<const V*>(c.accum + toff));
                   }
                 }
               } else if (fold && (code & (kDupBit - 1)) < d1) {   // (round 0: d0 = 0)

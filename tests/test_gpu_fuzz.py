@@ -75,6 +75,9 @@ plan_options = st.fixed_dictionaries({
   'bwd_group_cols': st.sampled_from([1, 3, 64]),    # columns per launch group
   'bwd_bucket_pairs': st.sampled_from([200, 448]),
   'fwd_hot_rows': st.sampled_from([0, 1]),
+  'bwd_wide': st.sampled_from([0, 1, 2]),           # wide sorted walk: never / one id per sample / all
+  'bwd_xcd': st.sampled_from([0, 1]),               # reduce jobs round robin / contiguous per XCD
+  'fwd_xcd': st.sampled_from([0, 2]),               # lookup tiles round robin / contiguous per XCD
 })
 
 

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Probe builds of the backward with other cache policies of its loads / stores:
+#   tools/scratch/bwd_cache_variants.sh      (build box: writes tools/bin/v_*/libhbk_core.so)
+#   VARIANT_CASES="b s r" tools/gpu_r3.sh variants          (GPU box)
+# Round 3: the non-temporal hint on the gradient loads cost 9 % of the config-2 backward (a
+# 128-byte line holds two 64-byte rows; ragged columns re-read their rows) -> plain is shipped.
+set -e
+cd "$(dirname "$0")/../.."
+CS=hybridbackend_amd/csrc
+OBJ=hybridbackend_amd/lib/obj
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I/opt/rocm/include -fno-fast-math -ffp-contract=off"
+build() {  # build <name> <defines...>
+  local name=$1; shift
+  mkdir -p tools/bin/v_$name
+  /opt/rocm/bin/hipcc $FLAGS "$@" -c $CS/lookup_bwd.hip -o tools/bin/v_$name/lookup_bwd.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/bin/v_$name/libhbk_core.so \
+    tools/bin/v_$name/lookup_bwd.o $(ls $OBJ/*.o | grep -v lookup_bwd) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+  rm tools/bin/v_$name/lookup_bwd.o
+}
+rm -rf tools/bin/v_*
+build shipped &
+build grad_nt -DHBK_BWD_GRAD_NT=1 &
+build step_plain -DHBK_BWD_STEP_NT=0 &
+build out_wt -DHBK_BWD_OUT_WT=1 &
+wait
+ls -la tools/bin/v_*/libhbk_core.so

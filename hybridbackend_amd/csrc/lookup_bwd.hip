@@ -221,7 +221,8 @@ struct GArgs {
   int32_t n_cols;
   float lr;
   int32_t apply;             // 0 none / SGD by lr, 2 Adagrad
-  int32_t xcd;               // != 0: every XCD takes a contiguous range of the reduce jobs (xcd_contiguous)
+  int32_t xcd;               // bit k: the reduce launch of bucket kind k deals its jobs to the XCDs
+                             // in contiguous ranges (xcd_contiguous); chosen per launch on the host
   // first block of every column in the grids below (copies of the GCol fields, kept together so
   // that a block finds its column with ONE wave-wide load + ballot instead of a binary search of
   // dependent scalar loads -- each a cold miss at kernel start)
@@ -2361,7 +2362,9 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
   HBK_STAMP_BEGIN()
   const int lane = (int)threadIdx.x & (kWave - 1);
   const int team = (int)threadIdx.x / kTeam;
-  const int vb = slot0 + xcd_contiguous((int)blockIdx.x, (int)gridDim.x, a.xcd) * kTeams + team;   // the team's job slot
+  constexpr int kKind = 2 * (WIDE ? 3 : 2) + (sizeof(V) == 4 ? 1 : 0);   // (the host's ColInfo.kind)
+  const int vb = slot0 +   // the team's job slot
+                 xcd_contiguous((int)blockIdx.x, (int)gridDim.x, (a.xcd >> kKind) & 1) * kTeams + team;
   if (vb >= total) return;                          // team-uniform; no workgroup barrier follows
   // two independent loads (the job, the columns' first slots): one round trip
   const int4 d = desc[vb];
@@ -2386,7 +2389,8 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(SORT)) void bwd_dense_k
   if (poisoned(poison)) return;   // the grouping launch gave up: no descriptors, no pairs
   HBK_STAMP_BEGIN()
   const int lane = (int)threadIdx.x & (kWave - 1);
-  const int vb = slot0 + xcd_contiguous((int)blockIdx.x, (int)gridDim.x, a.xcd);
+  constexpr int kKind = 2 * (SORT ? 1 : 0) + (sizeof(V) == 4 ? 1 : 0);   // (the host's ColInfo.kind)
+  const int vb = slot0 + xcd_contiguous((int)blockIdx.x, (int)gridDim.x, (a.xcd >> kKind) & 1);
   if (vb >= total) return;
   const int4 d = desc[vb];
   const int my_b0 = lane < a.n_cols ? a.bucket0[lane] : 0x7fffffff;
@@ -2952,6 +2956,8 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     int64_t slot_lo[kKinds] = {0}, slot_hi[kKinds] = {0};     // job slots of every kind
     int64_t merge_lo[kKinds] = {0}, merge_hi[kKinds] = {0};   // merge blocks of every kind
     bool have_kind[kKinds] = {false};
+    struct KindCol { int32_t n_buckets, e_max, weight; };   // slots of a column: buckets, then extras
+    std::vector<KindCol> kind_cols[kKinds];
     for (; k < k_n; ++k) {
       const int32_t col_index = members[k];
       const hbk_lookup_grad_column_t& h = cols[col_index];
@@ -3035,6 +3041,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
         slot_lo[ci.kind] = buckets;
         merge_lo[ci.kind] = merges;
       }
+      kind_cols[ci.kind].push_back({p.n_buckets, p.e_max, 24 + h.dim});
       tiles += p.tiles;
       buckets += (int64_t)p.n_buckets + p.e_max;
       merges += merge_blocks;
@@ -3064,7 +3071,48 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     args.n_cols = k;
     args.lr = apply_lr;
     args.apply = apply;
-    args.xcd = options().bwd_xcd != 0 ? 1 : 0;
+    // Reduce jobs to XCDs (xcd_contiguous): whole columns per XCD -- when that leaves the XCDs
+    // evenly loaded.  The eight ranges hold equal numbers of job slots, not equal work: a job of
+    // a dim-128 column costs several jobs of a dim-4 one, and a launch of mixed columns then waits
+    // for its heaviest XCD (config-5 shape: + 3 %, where equal columns gain 4 %).  The host knows
+    // the columns: it adds up each range's work (jobs x (24 + dim); the extra slots of a column
+    // are mostly unused) and keeps the round-robin placement when the heaviest range is > 8 %
+    // above the mean.  Option bwd_xcd: 0 never, 1 this rule, 2 always.
+    args.xcd = 0;
+    for (int kind = 0; kind < kKinds; ++kind) {
+      if (!have_kind[kind] || options().bwd_xcd == 0) continue;
+      bool even = options().bwd_xcd == 2;
+      if (!even) {
+        const int64_t per = kind >= 4 ? kTeams : 1;
+        const int64_t n = (slot_hi[kind] - slot_lo[kind] + per - 1) / per;   // the launch's blocks
+        const int64_t q = n / 8, r = n % 8;
+        double work[8] = {0}, total = 0;
+        int64_t slot = 0;      // walked once: ranges and columns both ascend
+        int x = 0;
+        int64_t x_end = (r > 0 ? q + 1 : q) * per;
+        for (const KindCol& kc : kind_cols[kind]) {
+          for (int part = 0; part < 2; ++part) {
+            int64_t len = part == 0 ? kc.n_buckets : kc.e_max;
+            const double w = part == 0 ? (double)kc.weight : 0.0;
+            while (len > 0) {
+              while (x < 7 && slot >= x_end) {
+                ++x;
+                x_end += (x < r ? q + 1 : q) * per;
+              }
+              const int64_t take = x < 7 && x_end - slot < len ? x_end - slot : len;
+              work[x] += w * (double)take;
+              total += w * (double)take;
+              slot += take;
+              len -= take;
+            }
+          }
+        }
+        double heaviest = 0;
+        for (double w : work) heaviest = w > heaviest ? w : heaviest;
+        even = total > 0 && heaviest <= 1.08 * total / 8;
+      }
+      if (even) args.xcd |= 1 << kind;
+    }
     if (ks > 0) {
       seg_args.n_cols = ks;
       seg_args.lr = 0.f;

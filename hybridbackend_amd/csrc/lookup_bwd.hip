@@ -800,6 +800,16 @@ struct ReduceJob {
 #define HBK_GRAD_LOAD(P) (*(P))
 #endif
 
+// the pairs of a bucket are read once (probe builds: -DHBK_BWD_PAIRS_NT=1 non-temporal loads)
+#ifndef HBK_BWD_PAIRS_NT
+#define HBK_BWD_PAIRS_NT 0
+#endif
+#if HBK_BWD_PAIRS_NT
+#define HBK_PAIR_LOAD(P) __builtin_nontemporal_load(P)
+#else
+#define HBK_PAIR_LOAD(P) (*(P))
+#endif
+
 // table / accumulator rows of the optimizer step (probe builds: -DHBK_BWD_STEP_NT=0 plain loads)
 #ifndef HBK_BWD_STEP_NT
 #define HBK_BWD_STEP_NT 1
@@ -1056,8 +1066,8 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         r_in[k] = kDonePair;
         seg_in[k] = cb + e;
         if (e < n_chunk) {
-          r_in[k] = prow[cb + e];
-          if (pseg != nullptr) seg_in[k] = pseg[cb + e];
+          r_in[k] = HBK_PAIR_LOAD(prow + cb + e);
+          if (pseg != nullptr) seg_in[k] = HBK_PAIR_LOAD(pseg + cb + e);
         }
       }
 #ifdef HBK_BWD_STAMPS
@@ -1855,8 +1865,8 @@ __device__ inline void load_first_pairs(const ReduceJob& job, FirstPairs& f) {
     f.row[k] = -1;
     f.seg[k] = e;
     if (e < job.n_pairs) {
-      f.row[k] = job.prow[e];
-      if (job.pseg != nullptr) f.seg[k] = job.pseg[e];
+      f.row[k] = HBK_PAIR_LOAD(job.prow + e);
+      if (job.pseg != nullptr) f.seg[k] = HBK_PAIR_LOAD(job.pseg + e);
     }
   }
 }
@@ -1902,8 +1912,8 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
       r_in[k] = -1;
       seg_in[k] = e;
       if (e < n_pairs) {
-        r_in[k] = prow[e];
-        if (pseg != nullptr) seg_in[k] = pseg[e];
+        r_in[k] = HBK_PAIR_LOAD(prow + e);
+        if (pseg != nullptr) seg_in[k] = HBK_PAIR_LOAD(pseg + e);
       }
     }
   };

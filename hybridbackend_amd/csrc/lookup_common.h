@@ -39,9 +39,18 @@ __device__ inline uint64_t id_to_row(const IdMap& m, int64_t id) {
   return r < m.rows ? r : kNoRow;
 }
 
+// ids are read once per kernel, in order: non-temporal (probe builds: -DHBK_IDS_NT=0)
+#ifndef HBK_IDS_NT
+#define HBK_IDS_NT 1
+#endif
 __device__ inline int64_t load_id(const void* ids, bool ids64, int64_t j) {
+#if HBK_IDS_NT
   if (ids64) return __builtin_nontemporal_load(reinterpret_cast<const int64_t*>(ids) + j);
   return (int64_t)__builtin_nontemporal_load(reinterpret_cast<const int32_t*>(ids) + j);
+#else
+  if (ids64) return reinterpret_cast<const int64_t*>(ids)[j];
+  return (int64_t)reinterpret_cast<const int32_t*>(ids)[j];
+#endif
 }
 
 __device__ inline uint64_t shfl_u64(uint64_t v, int src_lane) {

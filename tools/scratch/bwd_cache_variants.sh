@@ -19,8 +19,10 @@ build() {  # build <name> <defines...>
 }
 rm -rf tools/bin/v_*
 build shipped &
-build grad_nt -DHBK_BWD_GRAD_NT=1 &
-build step_plain -DHBK_BWD_STEP_NT=0 &
-build out_wt -DHBK_BWD_OUT_WT=1 &
+build pairs_nt -DHBK_BWD_PAIRS_NT=1 &
+build ids_plain -DHBK_IDS_NT=0 &
+
+
+
 wait
 ls -la tools/bin/v_*/libhbk_core.so

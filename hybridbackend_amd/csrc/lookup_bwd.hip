@@ -296,12 +296,35 @@ __device__ inline void run_seek(const GCol& c, int64_t j, RunCursor& rc) {
 }
 
 // ---- 0: segment of every id (ragged columns only; the host passes just those) --------------
+// A workgroup takes kBlock consecutive segments, i.e. ONE contiguous range of ids: their row
+// splits go to LDS and every thread finds the segment of ids tid, tid + kBlock, .. of the range by
+// a binary search there -- consecutive lanes store consecutive ids.  (One thread per segment
+// walking its own ids stored 4 bytes per lane ~32 bytes apart: 67 us for 13.6 M ids where the
+// 54 MB take ~15.)
 __global__ __launch_bounds__(kBlock) void bwd_segof_kernel(const GArgs a) {
+  __shared__ int32_t sp[kBlock + 1];
   HBK_FIND_COL(a, segtile0)
-  const int64_t s = ((int64_t)blockIdx.x - c.segtile0) * kBlock + threadIdx.x;
-  if (s >= c.n_seg) return;
-  const int32_t beg = c.splits[s], end = c.splits[s + 1];
-  for (int32_t j = beg; j < end; ++j) c.seg_of[j] = (int32_t)s;
+  const int64_t s0 = ((int64_t)blockIdx.x - c.segtile0) * kBlock;
+  const int tid = (int)threadIdx.x;
+  const int n = c.n_seg - s0 < kBlock ? (int)(c.n_seg - s0) : kBlock;   // segments of this block
+  if (tid < n) sp[tid] = c.splits[s0 + tid];
+  if (tid == 0) sp[n] = c.splits[s0 + n];
+  __syncthreads();
+  const int32_t lo = sp[0], hi = sp[n];
+  for (int32_t j = lo + tid; j < hi; j += kBlock) {
+    // the segment s with sp[s] <= j < sp[s + 1]: the last s with sp[s] <= j (empty segments share
+    // their start with the next one and are skipped by taking the last)
+    int s = 0, e = n;   // answer in [s, e)
+    while (e - s > 1) {
+      const int mid = (s + e) >> 1;
+      if (sp[mid] <= j) {
+        s = mid;
+      } else {
+        e = mid;
+      }
+    }
+    c.seg_of[j] = (int32_t)(s0 + s);
+  }
 }
 
 // ---- 1: per-tile bucket histogram ---------------------------------------------------------
@@ -447,12 +470,26 @@ __global__ __launch_bounds__(kBlock) void bwd_scan_fused_kernel(const GArgs a) {
 }
 
 // ---- 3: (row, segment) pairs grouped by bucket ---------------------------------------------
+// Tiles go to the XCDs in contiguous ranges (kXcdScatterBit of GArgs.xcd): a tile adds ~2 pairs to
+// each of a large column's ~1000 buckets, so a 128-byte line of the pair arrays is filled by ~9
+// CONSECUTIVE tiles -- dealt round robin they sit on eight XCDs and every L2 writes its own
+// partial copy of the line back; on one XCD the pieces merge in its L2 first.
+constexpr int kXcdScatterBit = 30;
+
 __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a) {
   extern __shared__ int32_t run[];
-  HBK_FIND_COL(a, tile0)
+  const int blk = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, (a.xcd >> kXcdScatterBit) & 1);
+  int ci;
+  {
+    const int l__ = (int)threadIdx.x & (kWave - 1);
+    const int v__ = l__ < a.n_cols ? a.tile0[l__] : 0x7fffffff;
+    ci = (int)__builtin_popcountll(__ballot(v__ <= blk)) - 1;
+    ci = __builtin_amdgcn_readfirstlane(ci);
+  }
+  const GCol& c = a.col[ci];
   const int P = c.n_buckets;
   const int tid = (int)threadIdx.x;
-  const int ctile = (int)blockIdx.x - c.tile0;
+  const int ctile = blk - c.tile0;
   const int64_t base = (int64_t)ctile * kTile;
   RunCursor rc;
   int64_t id[kBatch];
@@ -3123,6 +3160,8 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       }
       if (even) args.xcd |= 1 << kind;
     }
+    // (equal tiles: always even; bwd_xcd = 3: the rule above without this -- probes)
+    if (options().bwd_xcd == 1 || options().bwd_xcd == 2) args.xcd |= 1 << kXcdScatterBit;
     if (ks > 0) {
       seg_args.n_cols = ks;
       seg_args.lr = 0.f;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Probe builds of the backward with other cache policies of its loads / stores:
+# Probe builds of the backward (cache policies of its loads / stores, tile sizes):
 #   tools/scratch/bwd_cache_variants.sh      (build box: writes tools/bin/v_*/libhbk_core.so)
 #   VARIANT_CASES="b s r" tools/gpu_r3.sh variants          (GPU box)
 # Round 3: the non-temporal hint on the gradient loads cost 9 % of the config-2 backward (a
@@ -18,11 +18,9 @@ build() {  # build <name> <defines...>
   rm tools/bin/v_$name/lookup_bwd.o
 }
 rm -rf tools/bin/v_*
-build shipped &
-build pairs_nt -DHBK_BWD_PAIRS_NT=1 &
-build ids_plain -DHBK_IDS_NT=0 &
-
-
-
+for spec in "$@"; do   # e.g.  "shipped" "grad_nt -DHBK_BWD_GRAD_NT=1" "tile4096 -DHBK_BWD_TILE=4096"
+  set -- $spec
+  build "$@" &
+done
 wait
 ls -la tools/bin/v_*/libhbk_core.so

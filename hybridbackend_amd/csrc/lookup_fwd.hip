@@ -487,6 +487,7 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
       args.pad_ = 0;
       int32_t k = 0;
       int64_t tiles = 0;
+      int64_t small_lookups = 0, all_lookups = 0;   // (tables of <= 2 MB: see args.xcd below)
       args.tile_start[0] = 0;
       while (c0 < n_cols && k < kMaxColsPerLaunch) {
         const hbk_lookup_column_t& h = cols[c0++];
@@ -535,21 +536,29 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
             col_kind == 8 ? kHotTile : kWavesPerBlock * rpi * (h.row_splits ? kSegIters : kU);
         tiles += (h.n_segments + per_block - 1) / per_block;
         HBK_REQUIRE(tiles < (1ll << 31), "group_lookup_fwd: grid too large");
+        all_lookups += h.n_ids;
+        if (h.rows * (int64_t)h.dim * 4 <= (2ll << 20)) small_lookups += h.n_ids;
         ++k;
         args.tile_start[k] = (int32_t)tiles;
       }
       if (k == 0) continue;
       args.n_cols = k;
-      // Tiles to XCDs (xcd_contiguous): whole columns per XCD for the hot-row kernel -- a hot row
-      // staged by many tiles of its column is then fetched through ONE L2 instead of eight.
-      // Toggled inside one process on the same tensors (tools/sweep.py, SWEEP_J_XCD; between
-      // processes the same setting differs by up to 15 % on config 4): hot-row tiles Zipf 221 ->
-      // 213-220 us, without the staging (mode 2) 244 -> 223-230, uniform ids 351-355 -> 331-347;
-      // the per-wave kernels gain nothing (config 4 Zipf 235-241 either way) or lose (one row per
-      // column 202 -> 209, config 2 with its 64-byte rows 56.9 -> 59.1 us between processes), so
-      // they keep the round-robin placement.  Option fwd_xcd: 0 never, 1 this rule, 2 always.
+      // Tiles to XCDs (xcd_contiguous): whole columns per XCD
+      //  * for the hot-row kernel -- a hot row staged by many tiles of its column is then fetched
+      //    through ONE L2 instead of eight.  Toggled inside one process on the same tensors
+      //    (tools/sweep.py, SWEEP_J_XCD; between processes the same setting differs by up to 15 %
+      //    on config 4): hot-row tiles Zipf 221 -> 213-220 us, without the staging (mode 2) 244 ->
+      //    223-230, uniform ids 351-355 -> 331-347;
+      //  * for a launch with SMALL tables (>= 20 % of its lookups go to tables of <= 2 MB): dealt
+      //    round robin every L2 holds its own copy of every small table, per XCD a table lives in
+      //    one -- config-5 shape (rows 1e3..1e7) 1299-1352 -> 1264-1268 us.
+      // Other launches of the per-wave kernels gain nothing (config 2 56.7 us and config 4 Zipf
+      // 235-241 either way) or lose (ragged dim 16 over 6.4 MB tables 316-324 -> 329, one row per
+      // column 202 -> 209) and keep the round-robin placement.  Option fwd_xcd: 0 never, 1 these
+      // rules, 2 always.
       const int xcd_opt = options().fwd_xcd;
-      args.xcd = xcd_opt == 2 || (xcd_opt == 1 && kind == 8) ? 1 : 0;
+      args.xcd = xcd_opt == 2 || (xcd_opt == 1 && (kind == 8 || 5 * small_lookups >= all_lookups))
+                     ? 1 : 0;
       launch_by_kind(kind, args, (unsigned)tiles, as_stream(stream));
       HBK_HIP_OK(hipGetLastError());
     }

@@ -231,6 +231,12 @@ struct GArgs {
   int32_t merge0[kMaxCols];
   int32_t scan0[kMaxCols];
   int32_t segtile0[kMaxCols];
+  // bit k of xcd_w: the reduce launch of kind k gives XCD x the job slots [xcd_start[k][x],
+  // xcd_start[k][x + 1]) -- ranges of equal WORK (mixed columns), block b = x + 8 i takes the
+  // i-th of them and leaves when the range is shorter
+  int32_t xcd_w;
+  int32_t pad_;
+  int32_t xcd_start[8][9];
   GCol col[kMaxCols];
 };
 static_assert(sizeof(GArgs) <= 24576, "kernarg budget");
@@ -2410,8 +2416,15 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
   const int lane = (int)threadIdx.x & (kWave - 1);
   const int team = (int)threadIdx.x / kTeam;
   constexpr int kKind = 2 * (WIDE ? 3 : 2) + (sizeof(V) == 4 ? 1 : 0);   // (the host's ColInfo.kind)
-  const int vb = slot0 +   // the team's job slot
-                 xcd_contiguous((int)blockIdx.x, (int)gridDim.x, (a.xcd >> kKind) & 1) * kTeams + team;
+  int jb = (int)blockIdx.x;
+  if ((a.xcd_w >> kKind) & 1) {
+    const int x = jb & 7;
+    jb = a.xcd_start[kKind][x] + (jb >> 3);
+    if (jb >= a.xcd_start[kKind][x + 1]) return;   // (the whole workgroup)
+  } else {
+    jb = xcd_contiguous(jb, (int)gridDim.x, (a.xcd >> kKind) & 1);
+  }
+  const int vb = slot0 + jb * kTeams + team;   // the team's job slot
   if (vb >= total) return;                          // team-uniform; no workgroup barrier follows
   // two independent loads (the job, the columns' first slots): one round trip
   const int4 d = desc[vb];
@@ -2437,7 +2450,15 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(SORT)) void bwd_dense_k
   HBK_STAMP_BEGIN()
   const int lane = (int)threadIdx.x & (kWave - 1);
   constexpr int kKind = 2 * (SORT ? 1 : 0) + (sizeof(V) == 4 ? 1 : 0);   // (the host's ColInfo.kind)
-  const int vb = slot0 + xcd_contiguous((int)blockIdx.x, (int)gridDim.x, (a.xcd >> kKind) & 1);
+  int jb = (int)blockIdx.x;
+  if ((a.xcd_w >> kKind) & 1) {
+    const int x = jb & 7;
+    jb = a.xcd_start[kKind][x] + (jb >> 3);
+    if (jb >= a.xcd_start[kKind][x + 1]) return;   // (the whole workgroup)
+  } else {
+    jb = xcd_contiguous(jb, (int)gridDim.x, (a.xcd >> kKind) & 1);
+  }
+  const int vb = slot0 + jb;
   if (vb >= total) return;
   const int4 d = desc[vb];
   const int my_b0 = lane < a.n_cols ? a.bucket0[lane] : 0x7fffffff;
@@ -3160,6 +3181,43 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       }
       if (even) args.xcd |= 1 << kind;
     }
+    // The launches that pass get ranges of equal WORK rather than of equal slot counts (the extra
+    // slots at every column's end are mostly empty): config 2 99.9 -> 98.9 us, + SGD 181 -> 176,
+    // step only 144 -> 140.3, toggled in-process.  (bwd_xcd = 4, a probe: such ranges for every
+    // launch -- the config-5 shape loses 5 % with them, so its loss above is not the imbalance
+    // alone.)
+    args.xcd_w = 0;
+    args.pad_ = 0;
+    int64_t xcd_grid[kKinds] = {0};
+    if ((options().bwd_xcd == 4 || options().bwd_xcd == 1 || options().bwd_xcd == 3) && kTeams == 1) {
+      for (int kind = 0; kind < kKinds; ++kind) {
+        if (!have_kind[kind]) continue;
+        if (options().bwd_xcd != 4 && !((args.xcd >> kind) & 1)) continue;
+        double total = 0;
+        for (const KindCol& kc : kind_cols[kind]) total += (double)kc.weight * kc.n_buckets;
+        if (total <= 0) continue;
+        int32_t* st = args.xcd_start[kind];
+        st[0] = 0;
+        int x = 1;
+        double acc = 0;
+        int64_t slot = 0;
+        for (const KindCol& kc : kind_cols[kind]) {
+          // the live slots of the column, one by one in blocks: boundary x sits where the work
+          // before it first reaches x / 8 of the total
+          for (int64_t b = 0; b < kc.n_buckets; ++b) {
+            while (x < 8 && acc >= total * x / 8) st[x++] = (int32_t)(slot + b);
+            acc += kc.weight;
+          }
+          slot += (int64_t)kc.n_buckets + kc.e_max;
+        }
+        while (x <= 8) st[x++] = (int32_t)slot;
+        st[8] = (int32_t)(slot_hi[kind] - slot_lo[kind]);
+        int64_t longest = 0;
+        for (int q = 0; q < 8; ++q) longest = st[q + 1] - st[q] > longest ? st[q + 1] - st[q] : longest;
+        xcd_grid[kind] = 8 * longest;
+        args.xcd_w |= 1 << kind;
+      }
+    }
     // (equal tiles: always even; bwd_xcd = 3: the rule above without this -- probes)
     if (options().bwd_xcd == 1 || options().bwd_xcd == 2) args.xcd |= 1 << kXcdScatterBit;
     if (ks > 0) {
@@ -3239,7 +3297,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       if (!have_kind[kind]) continue;
       const int64_t n_slots = slot_hi[kind] - slot_lo[kind];
       const int64_t per = kind >= 4 ? kTeams : 1;   // job slots per workgroup
-      const int64_t grid = (n_slots + per - 1) / per;
+      const int64_t grid = xcd_grid[kind] > 0 ? xcd_grid[kind] : (n_slots + per - 1) / per;
       hipLaunchKernelGGL(kReduce[kind][step], dim3((unsigned)grid),
                          dim3(kBlock), 0, ls, args, desc_group, (int)slot_lo[kind],
                          (int)slot_hi[kind], poison);

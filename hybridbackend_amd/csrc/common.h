@@ -125,7 +125,9 @@ struct Options {
   int bwd_onepass = 1;         // HBK_BWD_ONEPASS: 0 = histogram, scan and scatter as three launches
   int fwd_xcd = 1;             // HBK_FWD_XCD: lookup tiles dealt to the XCDs in contiguous ranges (0 never: round robin,
                                // 1 the hot-row kernel, 2 always)
-  int bwd_xcd = 1;             // HBK_BWD_XCD: reduce jobs dealt to the XCDs in contiguous ranges (0: round robin)
+  int bwd_xcd = 1;             // HBK_BWD_XCD: reduce jobs / scatter tiles to the XCDs in contiguous ranges: 0 never (round robin),
+                               // 1 by rule (even launches: ranges of equal work), 2 always equal slot ranges, 3 = 1 without the
+                               // scatter tiles, 4 always equal work ranges (2-4: probes)
   int bwd_wide = 1;            // HBK_BWD_WIDE: wide sorted walk of the hashed backward (0 never,
                                // 1 columns of one id per sample, 2 ragged columns too)
   int bwd_group_cols = 0;      // HBK_BWD_GROUP_COLS: columns per launch group of the backward (0: 64)

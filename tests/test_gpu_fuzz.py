@@ -76,7 +76,7 @@ plan_options = st.fixed_dictionaries({
   'bwd_bucket_pairs': st.sampled_from([200, 448]),
   'fwd_hot_rows': st.sampled_from([0, 1]),
   'bwd_wide': st.sampled_from([0, 1, 2]),           # wide sorted walk: never / one id per sample / all
-  'bwd_xcd': st.sampled_from([0, 1]),               # reduce jobs round robin / contiguous per XCD
+  'bwd_xcd': st.sampled_from([0, 1, 2, 4]),         # reduce jobs round robin / by rule / equal slot ranges / equal work ranges
   'fwd_xcd': st.sampled_from([0, 2]),               # lookup tiles round robin / contiguous per XCD
 })
 

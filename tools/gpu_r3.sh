@@ -165,6 +165,19 @@ for f in ('pmc_hot_tcc','pmc_hot_tcp'):
 PY
       ) > $O/r03_hot_rows.txt
       ls -la $O/r03_*;;
+    abfinal)   # policies toggled inside one process on the same tensors (tools/sweep.py SWEEP_AB) + the cache-policy probe builds
+      (echo "Library options toggled INSIDE one process on the same tensors (tools/scratch/ab_options.sh: tools/sweep.py with SWEEP_AB=option:values);"
+       echo "every line: case, the option values in the order they were run, microseconds per call under each."
+       timeout 1500 tools/scratch/ab_options.sh "bwd_xcd:0,1,0,1 b,c,d,h" "bwd_xcd:3,1,3,1 b" "bwd_dense:0,1,0,1 c" "bwd_wide:0,1,2,0,1,2 d,h" "bwd_onepass:0,1,0,1 c,h" "fwd_xcd:0,2,0,2 a,b,h"
+       echo "== fwd_xcd x fwd_hot_rows, config 4 (SWEEP_J_XCD=0,2,0,2)"
+       SWEEP_J_XCD=0,2,0,2 timeout 600 python tools/sweep.py --big --cases j 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+  if l.startswith('{'):
+    d=json.loads(l); print(d['case'][9:].ljust(70), d['us'])") > $O/r03_inprocess_ab.txt 2>&1
+      (echo "Probe builds of the backward (tools/scratch/bwd_cache_variants.sh), C ABI, two passes: shipped (plain gradient loads) vs the non-temporal loads of rounds 1-2"
+       for rep in 1 2; do for v in tools/bin/v_*; do for w in b s r; do LD_LIBRARY_PATH=$R/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s|^|$(basename $v)  |"; done; done; done) > $O/r03_bwd_cache_variants.txt 2>&1
+      ls -la $O/r03_inprocess_ab.txt $O/r03_bwd_cache_variants.txt;;
     sweep)
       timeout 1200 python tools/sweep.py --big --cases ${SWEEP_CASES:-a,b,c,d,e,f,g,h,i} > $O/sweep.log 2>&1; echo "sweep rc=$?" >> $O/sweep.log; cut -c1-400 $O/sweep.log;;
     *) echo "unknown stage $st";;

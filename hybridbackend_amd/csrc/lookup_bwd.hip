@@ -46,6 +46,13 @@
 //                workgroup per split bucket) and emits the final rows.  A table row still has
 //                exactly one emitting workgroup, so rows stay unique and the fused SGD apply
 //                stays race free.
+//   4b dense     (round 3) columns whose batch covers the table densely take row-RANGE buckets and
+//                direct-indexed LDS bitmaps instead of the hash table (dense_reduce, below).
+// Where lines live (round 3): gradient rows are loaded with PLAIN loads (a 128-byte line holds two
+// rows of dim 16, a ragged column re-reads its rows), the reduce jobs and the large columns'
+// scatter tiles go to the XCDs in contiguous ranges (whole columns per XCD: xcd_contiguous,
+// GArgs.xcd / xcd_w) so that both rows of a gradient line -- and the pieces of a pair-array line
+// -- meet in ONE L2.
 // Summation order inside a row is not fixed (pair order comes from LDS tickets): 1e-5 relative.
 #include <alloca.h>
 #include <stdlib.h>

@@ -108,6 +108,18 @@ __host__ __device__ inline uint64_t fastmod(uint64_t n, const FastDiv& f) {
   return n - fastdiv(n, f) * f.d;
 }
 
+// Block b runs on XCD b % 8 (observed, not promised: MI355X_MICROARCH.md "Workgroup dispatch");
+// with work item = xcd_contiguous(block) every XCD works through ONE contiguous range of the
+// launch's items (whole columns) instead of every eighth: rows of one column that share a
+// 128-byte line are then fetched through one L2.  Bijective for any n; a pure speed choice --
+// any placement is correct, a different one just finds fewer lines in L2.
+__host__ __device__ inline int xcd_contiguous(int b, int n, int on) {
+  if (!on) return b;
+  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+
 // Python/TF floor-mod of a signed value by d > 0, result in [0, d).
 // For v < 0: floormod(v, d) = d - 1 - ((-v - 1) mod d), and -v - 1 == ~v.
 __host__ __device__ inline uint64_t floormod_i64(int64_t v, const FastDiv& f) {

@@ -89,17 +89,6 @@ inline bool make_rowshape(int32_t dim, uintptr_t align_bits, RowShape* s) {
   return true;
 }
 
-// Block b runs on XCD b % 8 (observed, not promised: MI355X_MICROARCH.md "Workgroup dispatch");
-// with work item = xcd_contiguous(block) every XCD works through ONE contiguous range of the
-// launch's items (whole columns) instead of every eighth: rows of one column that share a
-// 128-byte line are then fetched through one L2.  Bijective for any n; a pure speed choice --
-// any placement is correct, a different one just finds fewer lines in L2.
-__device__ inline int xcd_contiguous(int b, int n, int on) {
-  if (!on) return b;
-  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
-
 }  // namespace hbk
 
 #endif  // HBK_CSRC_LOOKUP_COMMON_H_

@@ -108,6 +108,11 @@ extern "C" int64_t hbk_host_floormod_i64(int64_t v, int64_t d) {
   return (int64_t)hbk::floormod_i64(v, f);
 }
 
+// the block -> work item mapping of the XCD-aware launches (xcd_contiguous), for a bijection check
+extern "C" int32_t hbk_host_xcd_contiguous(int32_t block, int32_t n_blocks) {
+  return hbk::xcd_contiguous(block, n_blocks, 1);
+}
+
 extern "C" uint64_t hbk_host_fastdiv_u64(uint64_t n, uint64_t d) {
   if (d == 0) return 0;
   hbk::FastDiv f = hbk::make_fastdiv(d);

@@ -100,6 +100,10 @@ int hbk_sync_check(void);
  * against Python's % and // without a GPU.  d > 0. */
 int64_t hbk_host_floormod_i64(int64_t v, int64_t d);
 uint64_t hbk_host_fastdiv_u64(uint64_t n, uint64_t d);
+/* the block -> work item mapping of the XCD-aware launches (every XCD takes one contiguous range
+ * of a launch's work items; block b is observed to run on XCD b % 8), evaluated on the host: a
+ * bijection of [0, n_blocks) for every n_blocks. */
+int32_t hbk_host_xcd_contiguous(int32_t block, int32_t n_blocks);
 
 /* ------------------------------------------------------------------------------------
  * R1  bucketize `feature % embedding_size` (TF FloorMod), N columns in one launch.

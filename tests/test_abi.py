@@ -83,6 +83,22 @@ def test_host_floormod_matches_python():
       assert lib.hbk_host_fastdiv_u64(n, d) == n // d, (n, d)
 
 
+def test_xcd_contiguous_mapping_is_a_bijection_with_contiguous_ranges():
+  """The block -> work item mapping of the XCD-aware launches (csrc/common.h xcd_contiguous):
+  for every launch size a bijection of [0, n), and the blocks of one XCD (b % 8 equal) take
+  consecutive items in block order -- which is what lets a column's rows meet in one L2."""
+  from hybridbackend_amd import _lib
+  lib = _lib.lib()
+  for n in list(range(1, 80)) + [255, 256, 257, 1000, 3822, 5486, 40003]:
+    items = [lib.hbk_host_xcd_contiguous(b, n) for b in range(n)]
+    assert sorted(items) == list(range(n)), n
+    lo = 0
+    for x in range(8):
+      mine = items[x::8]                     # what XCD x runs, in dispatch order
+      assert mine == list(range(lo, lo + len(mine))), (n, x)
+      lo += len(mine)
+
+
 def test_cpu_tensors_are_refused_not_silently_computed():
   import torch
   import hybridbackend_amd as hb

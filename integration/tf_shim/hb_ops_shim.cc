@@ -695,7 +695,10 @@ REGISTER_OP("HbGroupLookup")
     .Input("weights: N * float").Input("ids: N * Tids").Input("row_splits: N * int32")
     .Attr("N: int >= 1").Attr("Tids: {int32, int64}")
     .Attr("buckets: list(int)").Attr("combiners: list(int)").Attr("ragged: list(bool)")
-    .Attr("divisor: int = 1");
+    .Attr("divisor: int = 1")
+    // per column: skewed ids expected (Zipf heads) -- wide one-id-per-sample columns go through the
+    // tiles that stage repeated rows in LDS (hbk_lookup_column_t.hot_rows); empty = none
+    .Attr("hot_rows: list(bool) = []");
 
 template <typename Tids>
 class GroupLookupOp : public OpKernel {
@@ -705,6 +708,7 @@ class GroupLookupOp : public OpKernel {
     OP_REQUIRES_OK(ctx, ctx->GetAttr("combiners", &combiners_));
     OP_REQUIRES_OK(ctx, ctx->GetAttr("ragged", &ragged_));
     OP_REQUIRES_OK(ctx, ctx->GetAttr("divisor", &divisor_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("hot_rows", &hot_rows_));
   }
   void Compute(OpKernelContext* ctx) override {
     OpInputList w, ids, splits;
@@ -730,6 +734,7 @@ class GroupLookupOp : public OpKernel {
       c.bucket = buckets_[i];
       c.divisor = divisor_;
       c.combiner = combiners_[i];
+      c.hot_rows = i < static_cast<int>(hot_rows_.size()) && hot_rows_[i] ? 1 : 0;
       c.out = o->flat<float>().data();
     }
     OP_REQUIRES_OK(ctx, HbkStatus(hbk_group_lookup_fwd(n, cols.data(), StreamOf(ctx))));
@@ -739,6 +744,7 @@ class GroupLookupOp : public OpKernel {
   std::vector<int64> buckets_;
   std::vector<int32> combiners_;
   std::vector<bool> ragged_;
+  std::vector<bool> hot_rows_;
   int32 divisor_;
 };
 REGISTER_KERNEL_BUILDER(Name("HbGroupLookup").Device(DEVICE_GPU).TypeConstraint<int32>("Tids"),

@@ -21,14 +21,17 @@ from hybridbackend_amd.embedding.variables import sharded_bucket_size
 class EmbeddingColumn:
   """``embedding_column(categorical_column_with_identity/hash_bucket(key, num_buckets),
   dimension, combiner)``: ids are bucketized with floor-mod ``num_buckets``
-  (docs/tutorial/ranking/data.py:179,186)."""
+  (docs/tutorial/ranking/data.py:179,186).  ``hot_rows``: the ids are skewed (Zipf heads) --
+  a wide column (dimension >= 64, one id per sample) then fetches the rows repeated inside a
+  256-sample tile once and serves the repeats from LDS (GroupLookup(hot_rows=))."""
 
-  def __init__(self, key, num_buckets, dimension, combiner='mean'):
+  def __init__(self, key, num_buckets, dimension, combiner='mean', hot_rows=False):
     if num_buckets < 1 or dimension < 1:
       raise _lib.InvalidArgumentError(
         _lib.INVALID_ARGUMENT, 'num_buckets and dimension must be >= 1')
     self.key, self.num_buckets, self.dimension = key, int(num_buckets), int(dimension)
     self.combiner = combiner
+    self.hot_rows = bool(hot_rows)
 
 
 class DenseFeatures:
@@ -78,13 +81,15 @@ class DenseFeatures:
     if self._rep:
       self._lookup = GroupLookup(pick(self._rep, self.weights),
                                  [self.columns[c].num_buckets for c in self._rep],
-                                 [self.columns[c].combiner for c in self._rep])
+                                 [self.columns[c].combiner for c in self._rep],
+                                 hot_rows=[self.columns[c].hot_rows for c in self._rep])
       self._grad = GroupLookupGrad(
         self._lookup, pick(self._rep, self.accums) if self.accums is not None else None)
     if self._shd:
       self._sharded = ShardedGroupLookup(pick(self._shd, self.weights), coll,
                                          buckets=[self.columns[c].num_buckets for c in self._shd],
                                          combiners=[self.columns[c].combiner for c in self._shd],
+                                         hot_rows=[self.columns[c].hot_rows for c in self._shd],
                                          accums=(pick(self._shd, self.accums)
                                                  if self.accums is not None else None))
 

@@ -305,7 +305,9 @@ def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64,
 def _dense_case(rng, world):
   cols = [hb.feature_column.EmbeddingColumn('a', 50021, 16, 'sum'),
           hb.feature_column.EmbeddingColumn('b', 37, 4, 'mean'),       # small: stays replicated
-          hb.feature_column.EmbeddingColumn('c', 3000, 128, 'sqrtn'),
+          # wide, one id per sample, hinted as skewed: the hot-row tiles (3000 rows / 300 samples:
+          # repeats inside a tile), replicated or through the sharded plan's owner gather
+          hb.feature_column.EmbeddingColumn('c', 3000, 128, 'sqrtn', hot_rows=True),
           hb.feature_column.EmbeddingColumn('d', 977, 6, 'mean')]
   batch = 300
   tables = [rng.uniform(-1, 1, size=(c.num_buckets, c.dimension)).astype(np.float32)

@@ -99,6 +99,10 @@ constexpr int kMaxBuckets = 16384;   // 64 KB of LDS counters in hist / scatter
 constexpr int kTeam = HBK_BWD_TEAM;
 constexpr int kTeams = kBlock / kTeam;  // teams per workgroup
 constexpr int kCP = 2 * kTeam;        // pairs per chunk in the reduce kernel
+#ifndef HBK_BWD_RS_CAP
+#define HBK_BWD_RS_CAP 2048
+#endif
+constexpr int kRsCap = HBK_BWD_RS_CAP;   // pairs per chunk of the row-sorted reduce (4c, lookup_bwd_rowsort.h)
 #ifndef HBK_BWD_SLOTX
 #define HBK_BWD_SLOTX 2
 #endif
@@ -221,7 +225,7 @@ struct GCol {
   uint32_t dense_mul;        // != 0: DENSE column -- a bucket is a row RANGE, bucket =
                              // mulhi(row, dense_mul), and the reduce stage indexes its LDS tables
                              // directly with row - first row of the range (4b); 0: hashed buckets
-  int32_t pad_;
+  int32_t rowsort;           // dense column whose buckets take the row-sorted reduce (4c)
 };
 
 struct GArgs {
@@ -243,7 +247,7 @@ struct GArgs {
   // i-th of them and leaves when the range is shorter
   int32_t xcd_w;
   int32_t pad_;
-  int32_t xcd_start[8][9];
+  int32_t xcd_start[10][9];
   GCol col[kMaxCols];
 };
 static_assert(sizeof(GArgs) <= 24576, "kernarg budget");
@@ -2365,14 +2369,18 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
 // of dependent loads (column, list of extras, bucket start, bucket end) at the head of every
 // workgroup's critical path.  (Persistent workgroups that fetch the next job's pairs while the
 // current one runs were tried: the state carried around the loop spills, 224 us vs 143.)
-template <typename V, bool DENSE>
+// MODE: 0 hashed buckets, 1 row-range buckets with the bitmaps of 4b, 2 row-sorted (4c)
+template <typename V, int MODE>
 __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4& d, float lr,
                                   int* ci_out, ReduceJob* job) {
   if (d.z < 0 || d.y <= 0) return false;   // wave-uniform
   int ci = (int)__builtin_popcountll(__ballot(my_b0 <= vb)) - 1;
   ci = __builtin_amdgcn_readfirstlane(ci);
   const GCol& c = a.col[ci];
-  if ((c.vec4 != 0) != (sizeof(V) == 16) || (c.dense_mul != 0) != DENSE) return false;
+  if ((c.vec4 != 0) != (sizeof(V) == 16) || (c.dense_mul != 0) != (MODE != 0) ||
+      (c.rowsort != 0) != (MODE == 2)) {
+    return false;
+  }
   *ci_out = ci;
   const int32_t start = d.x, n_b = d.y, bucket = d.z, range = d.w;
   job->no_emit = false;
@@ -2403,7 +2411,8 @@ __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4&
     job->apply = a.apply;
     // step only: a dense job emits every row complete whatever its chunk count; a hashed one may
     // see a row span chunks (deferred step from the emitted rows)
-    job->no_emit = c.no_emit != 0 && lr != 0.0f && (DENSE || n_b <= kCP);
+    job->no_emit = c.no_emit != 0 && lr != 0.0f &&
+                   (MODE == 1 || n_b <= (MODE == 2 ? kRsCap : kCP));
   }
   return true;
 }
@@ -2438,7 +2447,7 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_WAVES) void bwd_reduce_kernel(const
   const int my_b0 = lane < a.n_cols ? a.bucket0[lane] : 0x7fffffff;
   ReduceJob job;
   int ci;
-  if (!decode_job<V, false>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
+  if (!decode_job<V, 0>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
   HBK_STAMP(1);
   bucket_reduce<V, STEP, WIDE>(a.col[ci], job, lds[team]);
   HBK_STAMP(7);
@@ -2471,13 +2480,15 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(SORT)) void bwd_dense_k
   const int my_b0 = lane < a.n_cols ? a.bucket0[lane] : 0x7fffffff;
   ReduceJob job;
   int ci;
-  if (!decode_job<V, true>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
+  if (!decode_job<V, 1>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
   FirstPairs first;
   load_first_pairs(job, first);
   HBK_STAMP(1);
   dense_reduce<V, STEP, SORT>(a.col[ci], job, lds, d.z, first);
   HBK_STAMP(7);
 }
+
+#include "lookup_bwd_rowsort.h"
 
 // The partial entries of a split bucket -> final rows.  Every split bucket has exactly one entry
 // with range index 1 in the column's list of extra ranges; the column's merge blocks (at most
@@ -2562,6 +2573,24 @@ __global__ __launch_bounds__(kBlock, HBK_BWD_DENSE_WAVES(true)) void bwd_dense_m
     FirstPairs first;
     load_first_pairs(job, first);
     dense_reduce<V, STEP, true>(c, job, lds, c.work[2 * e], first);
+  }
+  merge_done(c, blocks);
+}
+
+template <typename V, int STEP>
+__global__ __launch_bounds__(kBlock, 4) void bwd_rowsort_merge_kernel(const GArgs a, int block0,
+                                                                     const int32_t* poison) {
+  __shared__ RsLds lds;
+  if (poisoned(poison)) return;
+  const int block = block0 + (int)blockIdx.x;
+  HBK_FIND_COL_AT(a, merge0, block)
+  const int n_extra = *c.n_extra;
+  const int blocks = c.e_max < kMergeBlocks ? c.e_max : kMergeBlocks;
+  for (int e = block - c.merge0; e < n_extra; e += blocks) {
+    if (c.work[2 * e + 1] != 1) continue;   // uniform
+    ReduceJob job;
+    merge_job(a, c, c.work[2 * e], &job);
+    rowsort_reduce<V, STEP>(c, job, lds, c.work[2 * e]);
   }
   merge_done(c, blocks);
 }
@@ -2668,6 +2697,7 @@ struct ColPlan {
   int32_t e_max;
   uint32_t dense_mul;   // != 0: row-range buckets (4b)
   bool dense_sort;      // the dense instantiation with the sorted walk (many repeated rows expected)
+  bool rowsort;         // row-range buckets of ~7/8 kRsCap pairs reduced by the row-sorted job (4c)
 };
 
 // options (hbk_set_option): bwd_buckets_log2 forces the bucket count to 1 << value (0 = one
@@ -2706,6 +2736,45 @@ ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged) {
   // bwd_dense = 2 forces dense (with the sorted walk) wherever the row range fits (tests).
   p.dense_mul = 0;
   p.dense_sort = true;
+  p.rowsort = false;
+  // Row-sorted buckets (4c): columns whose batch is dense in the table, rows <= bwd_rowsort_ratio
+  // x ids (default 8: where the lean bitmaps of 4b end) -- ragged columns, small and medium tables,
+  // any dim.  A bucket aims at 7/8 of kRsCap pairs and must span <= kRsSpan rows, so sparser
+  // columns would get smaller jobs (ratio 16: ~1000 pairs).  bwd_dense = 3 forces it wherever the
+  // row range fits (tests).
+  {
+    const int dense_opt = options().bwd_dense;
+    const int64_t ratio = options().bwd_rowsort_ratio;
+    const bool want = dense_opt == 3 || (dense_opt == 1 && ratio > 0 && rows <= ratio * n_ids);
+    if (kTeam == kBlock && want && rows >= 1 && rows < (1ll << 32)) {
+      int64_t rs_target = (int64_t)kRsCap * 7 / 8;
+      if (options().bwd_bucket_pairs > 0 && options().bwd_bucket_pairs < rs_target) {
+        rs_target = options().bwd_bucket_pairs;
+      }
+      int64_t P = (n_ids + rs_target - 1) / rs_target;
+      if (forced >= 0 && forced <= 14) P = (int64_t)1 << forced;
+      const int64_t by_span = (rows + kRsSpan - 2) / (kRsSpan - 1);   // buckets of < kRsSpan rows
+      if (P < by_span) P = by_span;
+      if (P < 1) P = 1;
+      if (P > rows) P = rows;
+      if (P <= kMaxBuckets) {
+        uint64_t M = ((uint64_t)P << 32) / (uint64_t)rows;
+        if (M > 0xffffffffull) M = 0xffffffffull;
+        if (M >= 1 && (((uint64_t)1 << 32) + M - 1) / M <= (uint64_t)kRsSpan) {
+          p.dense_mul = (uint32_t)M;
+          p.rowsort = true;
+          p.n_buckets = (int)P;
+          p.tiles = (n_ids + kTile - 1) / kTile;
+          int64_t t = 2 * ((n_ids + P - 1) / P) + 128;
+          if (t < 2 * kRsCap) t = 2 * kRsCap;
+          if (options().bwd_split_pairs > 0) t = options().bwd_split_pairs;
+          p.split_t = (int32_t)t;
+          p.e_max = (int32_t)(n_ids / t + 1);
+          return p;
+        }
+      }
+    }
+  }
   const bool forced_dense = options().bwd_dense == 2;
   const bool eligible = forced_dense || (dim <= 32 && !ragged && n_ids <= rows / 8);
   if (kTeam == kBlock && options().bwd_dense != 0 && eligible && rows >= 1 && rows < (1ll << 32)) {
@@ -2964,7 +3033,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
         const bool wide = apply_lr != 0.0f && ci.shape.lpr_log2 >= 4 &&
                           (options().bwd_wide == 2 ||
                            (options().bwd_wide == 1 && h.row_splits == nullptr));
-        const int bkind = ci.p.dense_mul != 0 ? (ci.p.dense_sort ? 1 : 0) : wide ? 3 : 2;
+        const int bkind = ci.p.rowsort ? 4 : ci.p.dense_mul != 0 ? (ci.p.dense_sort ? 1 : 0) : wide ? 3 : 2;
         ci.kind = 2 * bkind + (ci.shape.vec4 ? 0 : 1);
         ci.onepass = options().bwd_onepass != 0 && ci.p.n_buckets <= kGroupMaxBuckets &&
                      ci.p.tiles <= 64;
@@ -3027,7 +3096,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     int64_t tiles = 0, buckets = 0, segtiles = 0, merges = 0, scans = 0, sync_words = 0;
     size_t lds_hist = 0;
     bool small_scan = true;
-    constexpr int kKinds = 8;
+    constexpr int kKinds = 10;
     int64_t slot_lo[kKinds] = {0}, slot_hi[kKinds] = {0};     // job slots of every kind
     int64_t merge_lo[kKinds] = {0}, merge_hi[kKinds] = {0};   // merge blocks of every kind
     bool have_kind[kKinds] = {false};
@@ -3086,6 +3155,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       d.split_t = p.split_t;
       d.e_max = p.e_max;
       d.dense_mul = p.dense_mul;
+      d.rowsort = p.rowsort ? 1 : 0;
       d.merge0 = (int32_t)merges;
       const int64_t merge_blocks = p.e_max < kMergeBlocks ? p.e_max : kMergeBlocks;
       d.scan0 = (int32_t)scans;
@@ -3158,7 +3228,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       if (!have_kind[kind] || options().bwd_xcd == 0) continue;
       bool even = options().bwd_xcd == 2;
       if (!even) {
-        const int64_t per = kind >= 4 ? kTeams : 1;
+        const int64_t per = kind >= 4 && kind < 8 ? kTeams : 1;
         const int64_t n = (slot_hi[kind] - slot_lo[kind] + per - 1) / per;   // the launch's blocks
         const int64_t q = n / 8, r = n % 8;
         double work[8] = {0}, total = 0;
@@ -3284,7 +3354,9 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
         {&bwd_reduce_kernel<float, 0, false>, &bwd_reduce_kernel<float, 1, false>,
          &bwd_reduce_kernel<float, 2, false>},
         {nullptr, &bwd_reduce_kernel<f32x4, 1, true>, &bwd_reduce_kernel<f32x4, 2, true>},
-        {nullptr, &bwd_reduce_kernel<float, 1, true>, &bwd_reduce_kernel<float, 2, true>}};
+        {nullptr, &bwd_reduce_kernel<float, 1, true>, &bwd_reduce_kernel<float, 2, true>},
+        {&bwd_rowsort_kernel<f32x4, 0>, &bwd_rowsort_kernel<f32x4, 1>, &bwd_rowsort_kernel<f32x4, 2>},
+        {&bwd_rowsort_kernel<float, 0>, &bwd_rowsort_kernel<float, 1>, &bwd_rowsort_kernel<float, 2>}};
     static const merge_fn kMerge[kKinds][3] = {
         {&bwd_dense_merge_kernel<f32x4, 0>, &bwd_dense_merge_kernel<f32x4, 1>,
          &bwd_dense_merge_kernel<f32x4, 2>},
@@ -3299,11 +3371,15 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
         {&bwd_merge_kernel<float, 0, false>, &bwd_merge_kernel<float, 1, false>,
          &bwd_merge_kernel<float, 2, false>},
         {nullptr, &bwd_merge_kernel<f32x4, 1, true>, &bwd_merge_kernel<f32x4, 2, true>},
-        {nullptr, &bwd_merge_kernel<float, 1, true>, &bwd_merge_kernel<float, 2, true>}};
+        {nullptr, &bwd_merge_kernel<float, 1, true>, &bwd_merge_kernel<float, 2, true>},
+        {&bwd_rowsort_merge_kernel<f32x4, 0>, &bwd_rowsort_merge_kernel<f32x4, 1>,
+         &bwd_rowsort_merge_kernel<f32x4, 2>},
+        {&bwd_rowsort_merge_kernel<float, 0>, &bwd_rowsort_merge_kernel<float, 1>,
+         &bwd_rowsort_merge_kernel<float, 2>}};
     for (int kind = 0; kind < kKinds; ++kind) {
       if (!have_kind[kind]) continue;
       const int64_t n_slots = slot_hi[kind] - slot_lo[kind];
-      const int64_t per = kind >= 4 ? kTeams : 1;   // job slots per workgroup
+      const int64_t per = kind >= 4 && kind < 8 ? kTeams : 1;   // job slots per workgroup
       const int64_t grid = xcd_grid[kind] > 0 ? xcd_grid[kind] : (n_slots + per - 1) / per;
       hipLaunchKernelGGL(kReduce[kind][step], dim3((unsigned)grid),
                          dim3(kBlock), 0, ls, args, desc_group, (int)slot_lo[kind],

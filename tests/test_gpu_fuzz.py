@@ -70,7 +70,7 @@ big_column = st.fixed_dictionaries({
   'skew': st.sampled_from(['uniform', 'zipf', 'negative']),
 })
 plan_options = st.fixed_dictionaries({
-  'bwd_dense': st.sampled_from([0, 1, 2]),          # never / by policy / wherever it fits
+  'bwd_dense': st.sampled_from([0, 1, 2, 3]),       # never / by policy / bitmap / row-sorted buckets wherever they fit
   'bwd_onepass': st.sampled_from([0, 1]),           # one-launch grouping or histogram/scan/scatter
   'bwd_group_cols': st.sampled_from([1, 3, 64]),    # columns per launch group
   'bwd_bucket_pairs': st.sampled_from([200, 448]),

@@ -504,14 +504,16 @@ def _check_slices(res, rows, grads, splits, combiner, distinct=True, atol=1e-6):
   np.testing.assert_allclose(got, want64, rtol=RTOL, atol=atol)
 
 
-@pytest.mark.parametrize('dense', [2, 1, 0])
+@pytest.mark.parametrize('dense', [3, 2, 1, 0])
 @pytest.mark.parametrize('onepass', [1, 0])
 @pytest.mark.parametrize('combiner', ['sum', 'mean', 'sqrtn'])
 def test_group_lookup_backward(hbk_option, combiner, onepass, dense):
   # onepass: pairs grouped by ONE launch (tiles wait for their column) or by the histogram /
   # scan / scatter launches; dense: 1 = row-range buckets + direct-indexed LDS tables for the
-  # columns the policy picks (narrow rows, one id per sample), 2 = for every column whose row
-  # ranges fit (ragged and wide ones too, always with the sorted walk), 0 = hashed buckets only
+  # columns the policy picks (narrow rows, one id per sample; row-sorted buckets where the batch
+  # is dense in the table), 2 = bitmap buckets for every column whose row ranges fit (ragged and
+  # wide ones too, always with the sorted walk), 3 = row-sorted buckets (lookup_bwd_rowsort.h)
+  # wherever they fit, 0 = hashed buckets only
   hbk_option('bwd_onepass', onepass)
   hbk_option('bwd_dense', dense)
   rng = np.random.RandomState(10)
@@ -537,7 +539,7 @@ def test_group_lookup_backward(hbk_option, combiner, onepass, dense):
     _check_slices(res[c], ids[c] % buckets[c], grads[c], splits[c], combiner)
 
 
-@pytest.mark.parametrize('dense', [2, 1, 0])
+@pytest.mark.parametrize('dense', [3, 2, 1, 0])
 def test_group_lookup_backward_multi_chunk_and_multi_pass_path(hbk_option, dense):
   # one bucket per column: many 512-pair chunks per workgroup, rows spanning chunks are
   # accumulated into their output row, and more distinct rows than the LDS table holds force
@@ -578,7 +580,7 @@ def test_group_lookup_backward_zipf_hot_rows():
   _check_slices(res, ids, grads, None, 'sum', atol=RTOL * 100)   # ~12k terms on the hot row
 
 
-@pytest.mark.parametrize('dense', [1, 2])
+@pytest.mark.parametrize('dense', [1, 2, 3])
 @pytest.mark.parametrize('aim', [0, 3000, 64])
 def test_group_lookup_backward_dense_row_ranges(hbk_option, aim, dense):
   """Row-range buckets (dense columns): output rows of a bucket are sorted, distinct and complete
@@ -635,7 +637,93 @@ def test_group_lookup_backward_dense_row_ranges(hbk_option, aim, dense):
           np.testing.assert_equal(host(t_dev), ref)
 
 
-@pytest.mark.parametrize('dense', [2, 1, 0])
+@pytest.mark.parametrize('mode', ['emit', 'sgd', 'adagrad', 'sgd_step_only'])
+@pytest.mark.parametrize('dense', [1, 3])
+def test_group_lookup_backward_rowsort_buckets(hbk_option, dense, mode):
+  """Row-sorted buckets (lookup_bwd_rowsort.h; the policy picks them for columns of rows <= 8 x
+  ids, dense = 3 wherever the row range fits): ragged columns with every combiner, rows hot
+  enough inside a job to be summed by the whole workgroup (> 128 pairs of a chunk), a Zipf head
+  that splits its bucket (ranges + merge of several chunks), tables smaller than a lane-group
+  count, wide and odd dims, ids outside the table -- rows distinct, sorted per bucket, sums within
+  1e-5 of float64, the fused steps bit-equal to the oracle's apply on the emitted slices."""
+  hbk_option('bwd_dense', dense)
+  rng = np.random.RandomState(404)
+  #        dim  rows    n_seg  mean-len  combiner  ids
+  cases = [(16, 50000, 30000, 8, 'mean', 'uniform'),
+           (16, 3000, 40000, 0, 'sum', 'uniform'),
+           (128, 700, 20000, 0, 'sum', 'zipf'),
+           (4, 100, 30000, 3, 'sqrtn', 'uniform'),
+           (6, 9000, 25000, 2, 'mean', 'zipf'),
+           (64, 20000, 9000, 4, 'sum', 'outside'),
+           (32, 1, 5000, 0, 'sum', 'uniform'),
+           (8, 150000, 60000, 0, 'sum', 'uniform')]
+  tables, accums, ids, splits, grads, buckets, combs = [], [], [], [], [], [], []
+  for d, rows, n_seg, mean_len, comb, kind in cases:
+    tables.append(rng.uniform(-1, 1, size=(rows, d)).astype(np.float32))
+    accums.append(np.full((rows, d), 0.1, np.float32))
+    sp = _ragged(rng, n_seg, mean_len, 32) if mean_len else None
+    n = n_seg if sp is None else int(sp[-1])
+    if kind == 'zipf':
+      i = (rng.zipf(1.2, size=n) % rows).astype(np.int64)
+    elif kind == 'outside':
+      i = rng.randint(-rows, 3 * rows, size=n).astype(np.int64)
+    else:
+      i = rng.randint(0, rows, size=n).astype(np.int64)
+    ids.append(i)
+    splits.append(sp)
+    grads.append(rng.randn(n_seg, d).astype(np.float32))
+    buckets.append(0)          # raw row numbers: ids outside [0, rows) are dropped
+    combs.append(comb)
+  t_dev = [dev(t.copy()) for t in tables]
+  a_dev = [dev(a.copy()) for a in accums]
+  # one combiner per call: run the columns of each combiner together
+  for comb in ('sum', 'mean', 'sqrtn'):
+    sel = [c for c in range(len(cases)) if combs[c] == comb]
+    lookup = hb.embedding.GroupLookup([t_dev[c] for c in sel], None, comb)
+    grad = hb.embedding.GroupLookupGrad(
+      lookup, accums=[a_dev[c] for c in sel] if mode == 'adagrad' else None)
+    lr = 0.0 if mode == 'emit' else 0.05
+    res = grad([dev(ids[c]) for c in sel], [dev(grads[c]) for c in sel],
+               [None if splits[c] is None else dev(splits[c]) for c in sel], apply_lr=lr,
+               optimizer='adagrad' if mode == 'adagrad' else 'sgd', emit=mode != 'sgd_step_only')
+    for k, c in enumerate(sel):
+      rows, d = tables[c].shape
+      ok = (ids[c] >= 0) & (ids[c] < rows)
+      sp = splits[c] if splits[c] is not None else np.arange(ids[c].size + 1, dtype=np.int32)
+      g_id = oracle.segment_combine_grad(grads[c], sp, comb).astype(np.float64)
+      want = np.zeros((rows, d), np.float64)
+      np.add.at(want, ids[c][ok], g_id[ok])
+      n_terms = np.bincount(ids[c][ok], minlength=rows).max() if ok.any() else 1
+      atol = RTOL * 4 * np.sqrt(max(n_terms, 1))
+      nu = int(res[k][2].item())
+      assert nu == np.unique(ids[c][ok]).size
+      if mode != 'sgd_step_only':
+        urows = host(res[k][0])[:nu]
+        assert np.array_equal(np.sort(urows), np.unique(ids[c][ok]))
+        got = np.zeros_like(want)
+        got[urows] = host(res[k][1])[:nu].astype(np.float64)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=atol)
+      untouched = np.ones(rows, bool)
+      untouched[ids[c][ok]] = False
+      if mode == 'emit':
+        np.testing.assert_equal(host(t_dev[c]), tables[c])
+        continue
+      np.testing.assert_equal(host(t_dev[c])[untouched], tables[c][untouched])
+      if mode == 'sgd':
+        ref = tables[c].copy()
+        oracle.sparse_sgd_apply(ref, urows, host(res[k][1])[:nu], 0.05)
+        np.testing.assert_equal(host(t_dev[c]), ref)
+      elif mode == 'adagrad':
+        ref_t, ref_a = tables[c].copy(), accums[c].copy()
+        oracle.sparse_adagrad_apply(ref_t, ref_a, urows, host(res[k][1])[:nu], 0.05)
+        np.testing.assert_equal(host(a_dev[c]), ref_a)
+        np.testing.assert_equal(host(t_dev[c]), ref_t)
+      else:
+        np.testing.assert_allclose(host(t_dev[c]), tables[c].astype(np.float64) - 0.05 * want,
+                                   rtol=RTOL, atol=1e-4 + 0.05 * atol)
+
+
+@pytest.mark.parametrize('dense', [3, 2, 1, 0])
 @pytest.mark.parametrize('onepass', [1, 0])
 @pytest.mark.parametrize('split,log2p', [(None, None), ('96', '2'), ('700', '0')])
 def test_group_lookup_backward_split_buckets(hbk_option, split, log2p, onepass, dense):
@@ -740,7 +828,7 @@ def test_group_lookup_backward_segmented_inputs():
       st += ln
 
 
-@pytest.mark.parametrize('dense', [2, 1, 0])
+@pytest.mark.parametrize('dense', [3, 2, 1, 0])
 @pytest.mark.parametrize('hook', [None, 'one_bucket'])
 def test_group_lookup_backward_fused_adagrad_apply(hbk_option, hook, dense):
   """tf.train.AdagradOptimizer's sparse apply fused into the backward: accum += g^2,
@@ -797,7 +885,7 @@ def test_group_lookup_backward_fused_sgd_apply():
   np.testing.assert_allclose(host(t_dev), ref, rtol=RTOL, atol=1e-6)
 
 
-@pytest.mark.parametrize('dense', [2, 1, 0])
+@pytest.mark.parametrize('dense', [3, 2, 1, 0])
 @pytest.mark.parametrize('optimizer', ['sgd', 'adagrad'])
 @pytest.mark.parametrize('hook', [None, 'one_bucket', 'split'])
 def test_group_lookup_backward_step_only(hbk_option, optimizer, hook, dense):

@@ -548,6 +548,132 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
   }
 }
 
+// ---- 3b: the same, staged through LDS (round 4) ---------------------------------------------------
+// Launch groups whose columns all have <= kStageMaxBuckets buckets (every row-sorted column: ~300
+// buckets per 524288 ids): the tile's pairs are sorted by bucket in LDS first and leave in that
+// order -- consecutive lanes store consecutive positions of a bucket's run.  The direct scatter
+// above issues 64 requests of 8 / 4 bytes per store instruction (every lane another bucket, i.e.
+// another line): 27 M requests for the 13.6 M pairs of the ragged case, which is what its 180 us
+// were -- the L2's request rate, not bytes.
+constexpr int kStageMaxBuckets = 1024;
+
+__global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GArgs a) {
+  __shared__ int32_t counters[kStageMaxBuckets];   // pairs of the tile per bucket; then: global
+                                                   // position of staged slot L of the bucket - L
+  __shared__ int32_t first[kStageMaxBuckets];      // first staged slot of the bucket
+  __shared__ int64_t st_row[kTile];                // the tile's pairs, sorted by bucket
+  __shared__ int32_t st_seg[kTile];
+  __shared__ uint16_t st_b[kTile];
+  __shared__ int32_t wave_cnt[kWavesPerBlock];
+  __shared__ int32_t n_staged;
+  const int blk = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, (a.xcd >> kXcdScatterBit) & 1);
+  int ci;
+  {
+    const int l__ = (int)threadIdx.x & (kWave - 1);
+    const int v__ = l__ < a.n_cols ? a.tile0[l__] : 0x7fffffff;
+    ci = (int)__builtin_popcountll(__ballot(v__ <= blk)) - 1;
+    ci = __builtin_amdgcn_readfirstlane(ci);
+  }
+  const GCol& c = a.col[ci];
+  const int P = c.n_buckets;
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int ctile = blk - c.tile0;
+  const int64_t base = (int64_t)ctile * kTile;
+  RunCursor rc;
+  int64_t id[kPerThread];
+  int32_t seg[kPerThread];
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int64_t j = base + (int64_t)k * kBlock + tid;
+    id[k] = 0;
+    seg[k] = (int32_t)j;
+    if (j < c.n_ids) {
+      if (c.n_runs > 0) {
+        run_seek(c, j, rc);
+        seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);
+      }
+      id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
+      if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
+    }
+  }
+  // where the tile's share of every bucket starts in the pair arrays (travels beside the ids)
+  const int per = (P + kBlock - 1) / kBlock;   // <= 4
+  const int beg = tid * per;
+  const int end = beg + per < P ? beg + per : P;
+  int32_t gpos[kStageMaxBuckets / kBlock];
+#pragma unroll
+  for (int q = 0; q < kStageMaxBuckets / kBlock; ++q) {
+    const int p = beg + q;
+    gpos[q] = q < per && p < end ? c.bstart[p] + c.hist[(int64_t)ctile * P + p] : 0;
+  }
+  for (int p = tid; p < P; p += kBlock) counters[p] = 0;
+  __syncthreads();
+  int32_t br[kPerThread];   // bucket | rank << 10, -1: no row
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int64_t j = base + (int64_t)k * kBlock + tid;
+    br[k] = -1;
+    if (j < c.n_ids) {
+      const uint64_t r = id_to_row(c.map, id[k]);
+      id[k] = (int64_t)r;
+      if (r != kNoRow) {
+        const int b = bucket_of(c, r);
+        br[k] = b | (atomicAdd(&counters[b], 1) << 10);
+      }
+    }
+  }
+  __syncthreads();
+  // first staged slot of every bucket: scan of the tile's counts (thread t: buckets [beg, end))
+  int32_t sum_c = 0;
+#pragma unroll
+  for (int q = 0; q < kStageMaxBuckets / kBlock; ++q) {
+    if (q < per && beg + q < end) sum_c += counters[beg + q];
+  }
+  int32_t incl_c = sum_c;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int32_t w = __shfl_up(incl_c, off, kWave);
+    if (lane >= off) incl_c += w;
+  }
+  if (lane == kWave - 1) wave_cnt[wave] = incl_c;
+  __syncthreads();
+  int32_t run_c = incl_c - sum_c;
+  for (int w = 0; w < wave; ++w) run_c += wave_cnt[w];
+#pragma unroll
+  for (int q = 0; q < kStageMaxBuckets / kBlock; ++q) {
+    const int p = beg + q;
+    if (q < per && p < end) {
+      const int32_t n_c = counters[p];   // (read and replaced by the one thread that owns p)
+      first[p] = run_c;
+      counters[p] = gpos[q] - run_c;
+      run_c += n_c;
+    }
+  }
+  if (tid == kBlock - 1) n_staged = run_c;   // the last thread's running count: pairs of the tile
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    if (br[k] >= 0) {
+      const int b = br[k] & 1023;
+      const int L = first[b] + (br[k] >> 10);
+      st_row[L] = id[k];
+      st_seg[L] = seg[k];
+      st_b[L] = (uint16_t)b;
+    }
+  }
+  __syncthreads();
+  const int n_st = n_staged;
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int L = k * kBlock + tid;
+    if (L < n_st) {
+      const int32_t pos = counters[st_b[L]] + L;
+      c.pair_row[0][pos] = st_row[L];
+      c.pair_seg[0][pos] = st_seg[L];
+    }
+  }
+}
+
 // ---- 1-3 in one launch ---------------------------------------------------------------------------
 // Columns of <= 512 buckets and <= 64 tiles (every column of a 65536-id step): a tile keeps its
 // rows, their buckets and their ranks inside the tile's share of the bucket (what the LDS atomic
@@ -3332,8 +3458,13 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
                            args);
         hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)k), dim3(kBlock), 0, ls, args);
       }
-      hipLaunchKernelGGL(bwd_scatter_pairs_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist,
-                         ls, args);
+      if (lds_hist <= (size_t)4 * kStageMaxBuckets && options().bwd_scatter_staged != 0) {
+        hipLaunchKernelGGL(bwd_scatter_staged_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ls,
+                           args);
+      } else {
+        hipLaunchKernelGGL(bwd_scatter_pairs_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist,
+                           ls, args);
+      }
     }
     // one instantiation per kind and optimizer (none / SGD / Adagrad), each on its own job slots
     const int step = apply_lr == 0.0f ? 0 : apply == HBK_APPLY_ADAGRAD ? 2 : 1;

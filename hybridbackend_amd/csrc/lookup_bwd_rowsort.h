@@ -9,17 +9,18 @@
 //      the bitmap;
 //   C  every pair takes a ticket on its row's counter (LDS atomic; a row that fills a wave is
 //      counted once per wave);
-//   D  one scan of the counters gives every row its run [start, start + count) in the sorted
-//      order; rows above kRsHotMin / 4 x the average share of a lane group are listed as HOT and
-//      placed behind the others;
+//   D  one scan of the counters gives every row its run [start, start + count) in the sorted order;
 //   E  the pairs' gradient rows (their numbers) go to their sorted positions, in LDS;
-//   F  the WALK: every lane group takes an equal, row-aligned share of the sorted positions and
-//      streams through it, W gradient rows in flight per lane, sums in registers, a row leaves
-//      (with the optimizer step, whose table / accumulator rows are requested for all rows that
-//      finished in the batch) when its run ends.  No barrier, no LDS traffic between lane groups,
-//      no float atomics: the hashed and the bitmap paths spend 2 barriers and 2 memory round trips
-//      per 48 rows here, this one a round trip per W x groups (= 512 at dim 16) rows;
-//   G  a hot row is summed by ALL lane groups (strided slices, partial sums through LDS).
+//   F  the WALK: every lane group takes an EQUAL share of the sorted positions -- whatever rows
+//      they belong to -- and streams through it, W gradient rows in flight per lane, sums in
+//      registers; a run that ends inside the share it began in leaves at once (with the optimizer
+//      step, whose table / accumulator rows are requested for all rows that finished in the
+//      batch).  No barrier and no LDS traffic on the way, no float atomics: the hashed and the
+//      bitmap paths spend 2 barriers and 2 memory round trips per 48 rows here, this one a round
+//      trip per W x groups (= 512 at dim 16) rows;
+//   G  a run that crosses shares (a hot row: the Zipf head, a 100-row table) is the sum its first
+//      group holds + the "heads" the following groups leave in LDS: one barrier, and the shares
+//      stay equal however skewed the ids are.
 // A job of several chunks (a bucket above kRsCap pairs: skewed ids, the ranges of a split bucket,
 // the merge of their partial entries) ranks its rows over all chunks first (A, B), then runs C-G
 // per chunk; a row that an earlier chunk emitted is added to (this workgroup owns it), and the
@@ -31,14 +32,27 @@ constexpr int kRsWords = kRsSpan / 32;
 constexpr int kRsWPT = kRsWords / kBlock;        // bitmap words per thread in the scan
 constexpr int kRsBits = 13;                      // start / count fields of a row's counter word
 constexpr uint32_t kRsMask = (1u << kRsBits) - 1u;
-constexpr uint32_t kRsHotBit = 1u << 31;
-constexpr int kRsHotMin = 128;                   // a row is hot above max(this, 4 x pairs / groups)
-constexpr int kRsMaxHot = 32;
 constexpr uint16_t kRsNoRow = 0xffff;
 static_assert(kRsCap % kBlock == 0 && kRsCap <= (1 << (kRsBits - 1)), "counter fields");
-static_assert(kRsCap / kRsHotMin <= kRsMaxHot, "hot list");
 static_assert(kRsWords % kBlock == 0, "whole bitmap words per thread");
 static_assert(kRsSpan <= 65536, "16-bit row offsets");
+
+// Output rows of a one-chunk job are written once and not read again by this kernel: non-temporal,
+// so that they do not push the gradient lines out of L2 -- a ragged column reads every segment's
+// gradient row ~8 times, from different jobs (probe builds: -DHBK_RS_OUT_NT=0 plain stores).
+#ifndef HBK_RS_OUT_NT
+#define HBK_RS_OUT_NT 1
+#endif
+template <typename V>
+__device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t u, int sub, V v) {
+  constexpr int VE = sizeof(V) / 4;
+  V* o = reinterpret_cast<V*>(job.out_vals + (int64_t)u * c.dim + (int64_t)sub * VE);
+#if HBK_RS_OUT_NT
+  __builtin_nontemporal_store(v, o);
+#else
+  *o = v;
+#endif
+}
 
 struct RsLds {
   uint32_t present[kRsWords];   // rows of the job
@@ -46,14 +60,13 @@ struct RsLds {
   uint32_t cmap[kRsWords];      // jobs of several chunks: rows of the chunk,
   uint32_t cpre[kRsWords];      //   rows of the chunk before word w,
   uint32_t seen[kRsWords];      //   rows an earlier chunk has emitted
-  uint32_t cnt[kRsCap];         // per row of the chunk: tickets, then start | count << 13 | hot
+  uint32_t cnt[kRsCap];         // per row of the chunk: tickets, then start | count << 13
   int32_t sseg[kRsCap];         // gradient row of every pair, sorted by row
-  uint16_t su[kRsCap + 8];      // the pair's row (its index among the chunk's rows); hot: kRsNoRow
+  uint16_t su[kRsCap + 8];      // the pair's row (its index among the chunk's rows)
   uint16_t roff[kRsCap];        // row - first row of the range, per row of the chunk
-  float red[kBlock * 4];        // hot rows: the lane groups' partial sums
-  uint16_t hot[kRsMaxHot];      // rows of the chunk summed by the whole workgroup
+  float red[kBlock * 4];        // per lane group: what it holds of a run that began in an earlier group's share
   int32_t wave_tot[kWavesPerBlock];
-  int32_t n_main, n_hot, base_u;
+  int32_t n_sorted, base_u;
 };
 
 template <typename V, int STEP>
@@ -153,8 +166,8 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
     L.seen[w] = 0u;
   }
   for (int i = tid; i < kRsCap; i += kBlock) L.cnt[i] = 0u;
-  if (tid == 0) L.n_hot = 0;
   __syncthreads();
+  HBK_STAMP(2);
 
   // A + B over the whole job: its rows, their ranks, the output range
   if (one_chunk) {
@@ -178,6 +191,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
     }
   }
   int32_t base_u = 0;
+  HBK_STAMP(3);
 
   for (int32_t cb = 0; cb < n_pairs; cb += kRsCap) {
     const uint32_t* bm = L.present;
@@ -189,8 +203,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
       for (int w = tid; w < words; w += kBlock) L.cmap[w] = 0u;
       if (cb > 0) {
         for (int i = tid; i < kRsCap; i += kBlock) L.cnt[i] = 0u;
-        if (tid == 0) L.n_hot = 0;
-      }
+            }
       __syncthreads();
       mark(L.cmap);
       __syncthreads();
@@ -236,19 +249,16 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
       tk_[k] = tk;
     }
     __syncthreads();
+    if (cb == 0) HBK_STAMP(4);
 
-    // D: counters -> runs.  Thread t owns rows [t * PT, t * PT + PT); ordinary rows in the low
-    // half of the packed sums, hot rows (placed behind all others) in the high half.
+    // D: counters -> runs.  Thread t owns rows [t * PT, t * PT + PT).
     {
-      int32_t n_chunk = n_pairs - cb < kRsCap ? n_pairs - cb : kRsCap;
-      int32_t t_hot = 4 * ((n_chunk + groups - 1) / groups);
-      if (t_hot < kRsHotMin) t_hot = kRsHotMin;
       uint32_t cn[PT], sum = 0;
 #pragma unroll
       for (int k = 0; k < PT; ++k) {
         const int u = tid * PT + k;
         cn[k] = u < n_rows ? L.cnt[u] : 0u;
-        sum += (int32_t)cn[k] > t_hot ? cn[k] << 16 : cn[k];
+        sum += cn[k];
       }
       uint32_t incl = sum;
 #pragma unroll
@@ -265,24 +275,15 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
         if (w < wave) run += t;
         total += t;
       }
-      const uint32_t n_main = total & 0xffffu;
 #pragma unroll
       for (int k = 0; k < PT; ++k) {
         const int u = tid * PT + k;
-        if (u < n_rows) {
-          if ((int32_t)cn[k] > t_hot) {
-            L.cnt[u] = kRsHotBit | (n_main + (run >> 16)) | (cn[k] << kRsBits);
-            L.hot[atomicAdd(&L.n_hot, 1)] = (uint16_t)u;
-            run += cn[k] << 16;
-          } else {
-            L.cnt[u] = (run & 0xffffu) | (cn[k] << kRsBits);
-            run += cn[k];
-          }
-        }
+        if (u < n_rows) L.cnt[u] = run | (cn[k] << kRsBits);
+        run += cn[k];
       }
       if (tid == 0) {
-        L.n_main = (int32_t)n_main;
-        L.su[n_main] = kRsNoRow;   // behind the last ordinary run (hot pairs write the same)
+        L.n_sorted = (int32_t)total;
+        L.su[total] = kRsNoRow;   // behind the last run
       }
     }
     __syncthreads();
@@ -291,15 +292,15 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
       if (u_[k] != ~0u) {
-        const uint32_t cv = L.cnt[u_[k]];
-        const int pos = (int)(cv & kRsMask) + tk_[k];
+        const int pos = (int)(L.cnt[u_[k]] & kRsMask) + tk_[k];
         L.sseg[pos] = seg_[k];
-        L.su[pos] = (cv & kRsHotBit) ? kRsNoRow : (uint16_t)u_[k];
+        L.su[pos] = (uint16_t)u_[k];
       }
     }
     if (cb == 0 && emit && tid == kBlock - 1) L.base_u = job.out_base + claimed;
     __syncthreads();
     if (cb == 0 && emit) base_u = L.base_u;
+    if (cb == 0) HBK_STAMP(5);
 
     // a finished row leaves: (one chunk) straight to its output row, with the optimizer step;
     // (several chunks) into its output row, which an earlier chunk may have started
@@ -316,21 +317,20 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
       return ((L.seen[off >> 5] >> (off & 31u)) & 1u) == 0u;
     };
 
-    // F: the walk.  Lane group g owns the runs that START in [g * per, (g + 1) * per) of the
-    // ordinary positions.
+    // F: the walk.  Lane group g takes the positions [g * per, (g + 1) * per) of the sorted order,
+    // whatever rows they belong to: equal shares for every lane group, also when one row owns
+    // most of the chunk.  A run that began in an earlier group's share is summed into `head` (left
+    // in LDS for the group where the run began); runs that begin in my share are mine: the ones
+    // that end there leave at once, the last one -- if it goes on -- waits in `acc` for the heads
+    // of the groups it goes on in (G).
     {
-      const int n_main = L.n_main;
-      const int per = (n_main + groups - 1) / groups;
-      auto align = [&](int x) -> int {
-        if (x <= 0) return 0;
-        if (x >= n_main) return n_main;
-        const uint32_t cv = L.cnt[L.su[x]];
-        const int s = (int)(cv & kRsMask);
-        return s == x ? x : s + (int)((cv >> kRsBits) & kRsMask);
-      };
-      const int p_lo = align(my_group * per), p_hi = align(my_group * per + per);
+      const int n_sorted = L.n_sorted;
+      const int per = (n_sorted + groups - 1) / groups;
+      const int lo = my_group * per < n_sorted ? my_group * per : n_sorted;
+      const int hi = lo + per < n_sorted ? lo + per : n_sorted;
+      bool in_head = lo < hi && lo > 0 && L.su[lo - 1] == L.su[lo];
       V acc = zero_v<V>();
-      for (int p = p_lo; p < p_hi; p += W) {
+      for (int p = lo; p < hi; p += W) {
         V g[W];
         int32_t n_[W];
         uint32_t uu[W];
@@ -341,7 +341,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
           g[w] = zero_v<V>();
           n_[w] = 0;
           uu[w] = 0;
-          if (q < p_hi) {
+          if (q < hi) {
             val |= 1u << w;
             uu[w] = L.su[q];
             if (L.su[q + 1] != (uint16_t)uu[w]) fin |= 1u << w;
@@ -352,13 +352,19 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
 #pragma unroll
           for (int w = 0; w < W; ++w) g[w] = scale_grad<V>(c, g[w], n_[w]);
         }
-        // the sum of a run ends up in the registers its last gradient row arrived in
+        // the sum of a run of mine ends up in the registers its last gradient row arrived in
 #pragma unroll
         for (int w = 0; w < W; ++w) {
           if (val >> w & 1u) {
             acc = acc + g[w];
             if (fin >> w & 1u) {
-              g[w] = acc;
+              if (in_head) {     // (uniform in the lane group) the end of an earlier group's run
+                *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = acc;
+                in_head = false;
+                fin &= ~(1u << w);
+              } else {
+                g[w] = acc;
+              }
               acc = zero_v<V>();
             }
           }
@@ -379,11 +385,16 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
 #pragma unroll
           for (int w = 0; w < W; ++w) {
             if (fin >> w & 1u) {
-              if (emit) emit_row<V>(c, job, base_u + (int32_t)uu[w], true, sub, g[w]);
+              if (emit) rs_store_row<V>(c, job, base_u + (int32_t)uu[w], sub, g[w]);
               const int64_t toff = (int64_t)(base + L.roff[uu[w]]) * c.dim + (int64_t)sub * VE;
               step_row<V>(c, adagrad, lr, toff, g[w], tv[STEP ? w : 0],
                           STEP == 2 ? av[STEP == 2 ? w : 0] : zero_v<V>());
             }
+          }
+        } else if (one_chunk) {
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            if (fin >> w & 1u) rs_store_row<V>(c, job, base_u + (int32_t)uu[w], sub, g[w]);
           }
         } else {
 #pragma unroll
@@ -394,51 +405,39 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
           }
         }
       }
-    }
-
-    // G: hot rows, one after the other, every lane group a strided slice of the run
-    const int n_hot = L.n_hot;   // uniform (written before the last barrier)
-    for (int h = 0; h < n_hot; ++h) {
-      const uint32_t u = L.hot[h];
-      const uint32_t cv = L.cnt[u];
-      const int b = (int)(cv & kRsMask), e = b + (int)((cv >> kRsBits) & kRsMask);
-      V part = zero_v<V>();
-      for (int q0 = b + my_group * W; q0 < e; q0 += groups * W) {
-        V g[W];
-        int32_t n_[W];
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-          g[w] = zero_v<V>();
-          n_[w] = 0;
-          if (q0 + w < e && live) g[w] = load_grad_raw<V>(c, job, L.sseg[q0 + w], sub, &n_[w]);
-        }
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-          if (scaled) g[w] = scale_grad<V>(c, g[w], n_[w]);
-          part = part + g[w];
-        }
+      // my whole share inside ONE run that began earlier: all of it is that run's head
+      if (in_head) {
+        *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = acc;
+        acc = zero_v<V>();
       }
-      *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = part;
-      __syncthreads();
-      if (my_group == 0 && live) {
-        V tot = zero_v<V>();
-        for (int gp = 0; gp < groups; ++gp) {
-          tot = tot + *reinterpret_cast<const V*>(&L.red[(((size_t)gp << lpr_log2) + sub) * VE]);
+      // G: the run that goes on behind my share (it began in it): + the heads of the groups it
+      // goes on in.  (A run that owns 200 groups' shares is 200 LDS reads for its owner.)
+      const bool tail = lo < hi && !in_head && hi < n_sorted && L.su[hi - 1] == L.su[hi];
+      __syncthreads();   // (every lane group gets here: the heads are in)
+      if (tail && live) {
+        const uint32_t u = L.su[hi - 1];
+        const uint32_t cv = L.cnt[u];
+        const int end = (int)(cv & kRsMask) + (int)((cv >> kRsBits) & kRsMask);
+        const int g_last = (end - 1) / per;
+        for (int gp = my_group + 1; gp <= g_last; ++gp) {
+          acc = acc + *reinterpret_cast<const V*>(&L.red[(((size_t)gp << lpr_log2) + sub) * VE]);
         }
         if (one_chunk && stepping) {
-          if (emit) emit_row<V>(c, job, base_u + (int32_t)u, true, sub, tot);
+          if (emit) rs_store_row<V>(c, job, base_u + (int32_t)u, sub, acc);
           const int64_t toff = (int64_t)(base + L.roff[u]) * c.dim + (int64_t)sub * VE;
           const V tv = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
           V av = zero_v<V>();
           if (adagrad) av = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.accum + toff));
-          step_row<V>(c, adagrad, lr, toff, tot, tv, av);
+          step_row<V>(c, adagrad, lr, toff, acc, tv, av);
+        } else if (one_chunk) {
+          rs_store_row<V>(c, job, base_u + (int32_t)u, sub, acc);
         } else {
-          emit_row<V>(c, job, out_index(u), is_first(u), sub, tot);
+          emit_row<V>(c, job, out_index(u), is_first(u), sub, acc);
         }
       }
-      __syncthreads();
     }
 
+    if (cb == 0) HBK_STAMP(6);
     if (!one_chunk) {
       __syncthreads();   // every row of the chunk has left: they count as seen from here on
       for (int w = tid; w < words; w += kBlock) L.seen[w] |= L.cmap[w];
@@ -495,6 +494,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_rowsort_kernel(const GArgs a, c
                                                                const int32_t* poison) {
   __shared__ RsLds lds;
   if (poisoned(poison)) return;   // the grouping launch gave up: no descriptors, no pairs
+  HBK_STAMP_BEGIN()
   const int lane = (int)threadIdx.x & (kWave - 1);
   constexpr int kKind = 8 + (sizeof(V) == 4 ? 1 : 0);   // (the host's ColInfo.kind)
   int jb = (int)blockIdx.x;
@@ -512,5 +512,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_rowsort_kernel(const GArgs a, c
   ReduceJob job;
   int ci;
   if (!decode_job<V, 2>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
+  HBK_STAMP(1);
   rowsort_reduce<V, STEP>(a.col[ci], job, lds, d.z);
+  HBK_STAMP(7);
 }

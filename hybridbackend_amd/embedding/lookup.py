@@ -78,6 +78,9 @@ class GroupLookup:
 
   def bind(self, ids, row_splits=None, outs=None):
     """Point the column descriptors at this step's inputs/outputs; returns outs."""
+    # the descriptors change: what __call__ remembers of its last tensors no longer describes them
+    # (__call__ sets its key again after a bind of its own)
+    self._call_key = None
     n = len(self.tables)
     if len(ids) != n:
       raise _lib.InvalidArgumentError(
@@ -136,7 +139,10 @@ class GroupLookup:
     # outputs): the descriptors are still right, the call is one foreign call
     if outs is not None:
       tensors = list(ids) + [x for x in (row_splits or []) if x is not None] + list(outs)
-      key = tuple(id(t) for t in tensors)
+      # the key keeps WHICH column a row_splits tensor belongs to (None positions included)
+      key = (tuple(id(t) for t in ids),
+             tuple(None if x is None else id(x) for x in (row_splits or ())),
+             tuple(id(t) for t in outs))
       cached = getattr(self, '_call_key', None)
       if cached is not None and cached[0] == key and all(
           t.data_ptr() == q and t.numel() == m for t, (q, m) in zip(tensors, cached[1])):
@@ -145,8 +151,7 @@ class GroupLookup:
       outs = self.bind(ids, row_splits, outs)
       self._call_key = (key, [(t.data_ptr(), t.numel()) for t in tensors], outs)
     else:
-      self._call_key = None
-      outs = self.bind(ids, row_splits, outs)
+      outs = self.bind(ids, row_splits, outs)   # (bind clears the remembered call)
     self.launch()
     return outs
 

@@ -482,6 +482,39 @@ def test_dense_block_forward_in_place(ids_dtype):
   np.testing.assert_equal(got[:, :20], np.concatenate(o, axis=1))
 
 
+def test_group_lookup_call_cache_follows_bind_and_split_positions():
+  """__call__ remembers its last tensors and skips the marshalling when it is handed the same
+  ones; a bind() in between, or the same row_splits tensor moved to another column, must not be
+  served from that memory."""
+  rng = np.random.RandomState(5)
+  tables = [dev(rng.uniform(-1, 1, size=(50, 4)).astype(np.float32)) for _ in range(2)]
+  lookup = hb.embedding.GroupLookup(tables, None, 'sum')
+  a = [dev(rng.randint(0, 50, size=6).astype(np.int64)) for _ in range(2)]
+  b = [dev(rng.randint(0, 50, size=6).astype(np.int64)) for _ in range(2)]
+  outs = [torch.zeros(6, 4, device=DEV) for _ in range(2)]
+  lookup(a, None, outs)
+  want_a = [host(o).copy() for o in outs]
+  other = lookup.bind(b)                  # fresh outputs for b
+  lookup.launch()
+  lookup(a, None, outs)                   # same tensors as the first call: must re-bind
+  for o, w in zip(outs, want_a):
+    np.testing.assert_equal(host(o), w)
+  for c in range(2):
+    np.testing.assert_equal(host(other[c]), host(tables[c])[host(b[c])])
+  # one splits tensor, first on column 0, then on column 1
+  sp = dev(np.array([0, 2, 6], np.int32))
+  ids2 = [dev(np.arange(6, dtype=np.int64)), dev(np.arange(2, dtype=np.int64))]
+  ids3 = [ids2[1], ids2[0]]
+  o2 = [torch.zeros(2, 4, device=DEV) for _ in range(2)]
+  lookup(ids2, [sp, None], o2)
+  t0, t1 = host(tables[0]), host(tables[1])
+  np.testing.assert_allclose(host(o2[0]), np.stack([t0[0:2].sum(0), t0[2:6].sum(0)]), rtol=1e-6)
+  np.testing.assert_equal(host(o2[1]), t1[0:2])
+  lookup(ids3, [None, sp], o2)
+  np.testing.assert_equal(host(o2[0]), t0[0:2])
+  np.testing.assert_allclose(host(o2[1]), np.stack([t1[0:2].sum(0), t1[2:6].sum(0)]), rtol=1e-6)
+
+
 # ----------------------------------------------------------------------------------
 # R10 backward
 def _check_slices(res, rows, grads, splits, combiner, distinct=True, atol=1e-6):

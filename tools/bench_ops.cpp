@@ -56,6 +56,9 @@ static T* dev_alloc(size_t n) {
 }
 
 static float time_us(int iters, const std::function<void(int)>& f) {
+  if (const char* it = getenv("HBK_BENCH_ITERS")) {   // (counter passes: a few calls are enough)
+    if (atoi(it) > 0) iters = atoi(it);
+  }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -297,8 +300,14 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
       fill(0);
       HB(hbk_group_lookup_bwd(n_cols, cols.data(), lr, ws, ws_bytes, nullptr));
       fn(tr.data(), 0);
-      static const char* names[7] = {"setup (column, bstart)", "table init", "(a) pairs + insert",
-                                     "(b) scan", "(c) gradient round", "(d,e) + chunk end", "exit"};
+      static const char* names_h[7] = {"setup (column, bstart)", "table init", "(a) pairs + insert",
+                                       "(b) scan", "(c) gradient round", "(d,e) + chunk end", "exit"};
+      // row-sorted buckets (HBK_STAMP_NAMES=rowsort): the phases of lookup_bwd_rowsort.h
+      static const char* names_r[7] = {"job descriptor", "pairs + clear", "A bitmap + B ranks + claim",
+                                       "C tickets", "D runs + E sorted", "F walk + G hot rows",
+                                       "row numbers + exit"};
+      const char* which = getenv("HBK_STAMP_NAMES");
+      const char** names = which != nullptr && which[0] == 'r' ? names_r : names_h;
       // stamps are ticks of the 100 MHz constant clock (10 ns), the same clock on every CU
       double sum[7] = {0}, life = 0;
       unsigned long long t_min = ~0ull, t_max = 0;
@@ -439,6 +448,10 @@ int main(int argc, char** argv) {
   }
   if (argc > 1 && argv[1][0] == 'c') {  // "cache": the slab-cache lookup only
     bench_probe(26 * 65536, 1 << 16, 32);
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'R') {  // the sweep's ragged case at fixed lengths: 26 x 65536 segments of 8 ids, 1M rows
+    bench_backward(26, 524288, 16, 1000000, 0.f, false, 8);
     return 0;
   }
   if (argc > 1 && argv[1][0] == 'r') {  // "ragged": config-5-like columns (8 ids per sample, mean)

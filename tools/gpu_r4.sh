@@ -57,6 +57,44 @@ for st in $STAGES; do
     rsprof)
       prof prof_ragged "" -- python $R/tools/sweep.py --cases b
       grep -E "bwd_|kernel  " $O/prof_ragged.txt | head -20;;
+    rsstamps)   # per-phase trace of the row-sorted reduce (probe build with stamps)
+      (for w in R r d; do HBK_STAMP_NAMES=rowsort LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops $w; done
+       HBK_BWD_ROWSORT_RATIO=0 LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops R) > $O/rsstamps.log 2>&1; cut -c1-600 $O/rsstamps.log;;
+    rspmc)
+      prof pmc_rs_sq1 "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" -- $R/tools/bin/bench_ops R
+      prof pmc_rs_sq2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" -- $R/tools/bin/bench_ops R
+      prof pmc_rs_sq3 "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" -- $R/tools/bin/bench_ops R
+      prof pmc_rs_tcc "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum TCC_HIT_sum" -- $R/tools/bin/bench_ops R
+      for f in pmc_rs_sq1 pmc_rs_sq2 pmc_rs_sq3 pmc_rs_tcc; do echo "== $f"; tail -1 $O/$f.log; python - $O/$f.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k,v in sorted(d.items()):
+  if 'bwd_' in k: print(k[:60].ljust(60), {c:round(x['mean']) for c,x in v.items()})
+PY
+      done;;
+    rsab2)   # flat walk + staged scatter: in-process toggles, then the probe builds through the C ABI
+      (ab "bwd_rowsort_ratio:0,8,0,8" "b,h"
+       ab "bwd_scatter_staged:0,1,0,1" "b"
+       ab "bwd_xcd:0,1,0,1" "b"
+       for v in tools/bin/v_*; do
+         for w in R r d; do
+           LD_LIBRARY_PATH=$R/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s|^|$(basename $v)  |"
+         done
+       done
+       HBK_BWD_ROWSORT_RATIO=0 timeout 300 tools/bin/bench_ops r 2>&1 | grep group_lookup_bwd | sed "s|^|hashed  |") > $O/rsab2.log 2>&1; cut -c1-260 $O/rsab2.log;;
+    rstcc)   # L2 hit rate / fabric requests of the ragged case (3 calls per pass)
+      export HBK_BENCH_ITERS=2
+      prof pmc_rs_tcc1 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" -- $R/tools/bin/bench_ops R
+      unset HBK_BENCH_ITERS
+      for f in pmc_rs_tcc1; do echo "== $f"; tail -1 $O/$f.log; python - $O/$f.json <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k,v in sorted(d.items()):
+  if 'bwd_' in k: print(k[:60].ljust(60), {c:round(x['mean']) for c,x in v.items()})
+PY
+      done;;
+    rsstamps2)
+      (HBK_STAMP_NAMES=rowsort LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops R) > $O/rsstamps2.log 2>&1; grep "reduce kernel" $O/rsstamps2.log | cut -c1-600;;
     *) echo "unknown stage $st";;
   esac
 done

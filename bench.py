@@ -45,6 +45,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: 6.29 TB/s measured with a float4 copy (79 % of spec)
 
 
+# reference measurements that follow the headline steps at N > 1 (or --sharded), in `config`
+SECONDARY_KEYS = ('replicated_M_lookups_per_s', 'replicated_ms_per_step',
+                  'other_wire', 'other_wire_M_lookups_per_s', 'other_wire_ms_per_step',
+                  'secondary_steps')
+
+
 def parse_args():
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
@@ -73,6 +79,10 @@ def parse_args():
                       'count (option sharded_groups: 2 = exchanges of one column group overlap the '
                       'gather / stitch of the other, 1 = no pipelining, half the cross-stream '
                       'hops); the faster one runs the timed steps.  0: keep the default')
+  p.add_argument('--no-secondary', action='store_true',
+                 help='N > 1 (or --sharded): skip the two reference measurements that follow the '
+                      'headline steps -- the other wire format, and every rank holding ALL tables '
+                      '(replicated, no exchange: SURVEY 8e "report replicated as a reference line")')
   p.add_argument('--link-probe-mb', type=float, default=16.0,
                  help='N > 1: MB per peer of the equal-split alltoallv that measures the links '
                       'before the timed steps (0 disables it)')
@@ -237,13 +247,28 @@ def cpu_baseline(args, tables, id_batch, budget_s):
     if el >= budget_s or passes >= 5000:
       break
   lookups = passes * cols * args.batch
+  # the same pipeline on ONE host thread (both figures are reported; the
+  # reference's own CPU partition functor is single-threaded, partition_by_modulo_functors.cc:48-69)
+  one_tab, one_ids = h_tab[:cols], h_all[:cols]
+  one_args = ([None] * cols, [args.rows] * cols, ['sum'] * cols)
+  oracle.group_lookup_fwd(one_tab, one_ids, *one_args, n_threads=1)
+  p1, t1 = 0, time.perf_counter()
+  while True:
+    oracle.group_lookup_fwd(one_tab, one_ids, *one_args, n_threads=1)
+    p1 += 1
+    el1 = time.perf_counter() - t1
+    if el1 >= max(1.0, budget_s / 4) or p1 >= 200:
+      break
   return {
     'value': round(lookups / el / 1e6, 3), 'unit': 'M-lookups/sec', 'cores': threads,
     'kind': 'port',
     'sample': f'{passes} passes of one {cols}-column x {args.batch}-id batch '
               f'({lookups} lookups, {el:.1f} s) through oracle/hbk_oracle.c '
               f'orc_group_lookup_fwd, {threads} pthreads over {tasks} (column, batch-slice) '
-              f'tasks, host nproc={cores}'}
+              f'tasks, host nproc={cores}',
+    'single_thread': {
+      'value': round(p1 * cols * args.batch / el1 / 1e6, 3), 'unit': 'M-lookups/sec', 'cores': 1,
+      'sample': f'{p1} passes of the same batch on one thread ({el1:.1f} s)'}}
 
 
 def load_traffic(config_key):
@@ -251,12 +276,13 @@ def load_traffic(config_key):
   if one exists for this exact workload; else None."""
   path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
   if not os.path.exists(path):
-    return None
+    return None, None
   try:
     data = json.load(open(path))
   except (OSError, ValueError):
-    return None
-  return data.get(config_key, {}).get('hbm_bytes_per_launch')
+    return None, None
+  entry = data.get(config_key, {})
+  return entry.get('hbm_bytes_per_launch'), entry.get('measured_in')
 
 
 def rccl_versions():
@@ -314,6 +340,8 @@ def main():
       line = json.loads(error_line(args, 'dry run: launcher and rendezvous only, nothing measured'))
       line['dry_run'] = True
       line['ranks'] = world
+      # the keys a measured N > 1 line carries next to the headline (nothing measured here)
+      line['config'] = {key: None for key in SECONDARY_KEYS}
       line['max_rank_sleep_ms'] = round(el * 1e3, 2)
       print(json.dumps(line), flush=True)
     if use_dist:
@@ -413,28 +441,65 @@ def main():
     _hbk.set_option('sharded_inline', forms[best_form][1])
     sharded.close()
 
-  for i in range(args.warmup):
-    step(i)
-  torch.cuda.synchronize()
-  barrier()
-  torch.cuda.synchronize()
-  ev0 = torch.cuda.Event(enable_timing=True)
-  ev1 = torch.cuda.Event(enable_timing=True)
-  t0 = time.perf_counter()
-  ev0.record()
-  for i in range(args.steps):
-    step(args.warmup + i)
-  ev1.record()
-  torch.cuda.synchronize()
-  barrier()
-  torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
-  gpu_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream)
+  def timed_steps(step_fn, steps, warmup):
+    """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides;
+    returns (wall seconds, MAX over ranks; HIP-event milliseconds on the launch stream)."""
+    for i in range(warmup):
+      step_fn(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(steps):
+      step_fn(warmup + i)
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream)
+    if use_dist:
+      t = torch.tensor([el], dtype=torch.float64)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      el = float(t.item())
+    return el, ms
 
-  if use_dist:
-    t = torch.tensor([elapsed], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+  elapsed, gpu_ms = timed_steps(step, args.steps, args.warmup)
+
+  # Reference measurements next to the sharded headline, same run, same batches (SURVEY 8e):
+  #  * the OTHER wire format of the embedding exchange (fp16 when the headline is fp32: the
+  #    link-bound lever; the reference's comm_wire_dtype, collective.py:291-296);
+  #  * REPLICATED: every rank holds all tables and looks its own batch up, no exchange -- what
+  #    the reference does for tables that fit (variables.py:93-98) and the ceiling a sharded step
+  #    can be compared with.
+  secondary = {key: None for key in SECONDARY_KEYS}
+  if (world > 1 or args.sharded) and not args.no_secondary:
+    sec_steps, sec_warm = max(1, min(args.steps, 20)), min(args.warmup, 5)
+    other = 'fp16' if args.wire == 'fp32' else 'fp32'
+    sharded.close()                 # the wire format is fixed when the plan is created
+    sharded.wire_dtype = torch.float16 if other == 'fp16' else None
+    el2, _ = timed_steps(step, sec_steps, sec_warm)
+    sharded.close()
+    sharded.wire_dtype = torch.float16 if args.wire == 'fp16' else None
+    full = tables if world == 1 else make_tables(args, device, 0, 1)
+    r_plans = []
+    for b in range(n_batches):
+      gl = hb.embedding.GroupLookup(full, buckets=[args.rows] * args.columns, combiners='sum')
+      gl.bind(batches[b], None, sh_outs)
+      r_plans.append(gl)
+    el3, _ = timed_steps(lambda i: r_plans[i % n_batches].launch(), sec_steps, sec_warm)
+    per_step = lookups_per_step_per_rank * world
+    secondary = {
+      'replicated_M_lookups_per_s': round(per_step * sec_steps / el3 / 1e6, 3),
+      'replicated_ms_per_step': round(el3 / sec_steps * 1e3, 5),
+      'other_wire': other,
+      'other_wire_M_lookups_per_s': round(per_step * sec_steps / el2 / 1e6, 3),
+      'other_wire_ms_per_step': round(el2 / sec_steps * 1e3, 5),
+      'secondary_steps': sec_steps}
+    del r_plans, full
 
   total_lookups = lookups_per_step_per_rank * world * args.steps
   value = total_lookups / elapsed / 1e6
@@ -447,7 +512,7 @@ def main():
     workload = (f'{args.columns} cols x {args.rows} rows x dim{args.dim} fp32, batch '
                 f'{args.batch}/GPU, 1 id/sample, fused bucketize+gather+combiner')
     key = f'c{args.columns}_r{args.rows}_d{args.dim}_b{args.batch}_n{world}'
-    traffic = load_traffic(key)
+    traffic, traffic_round = load_traffic(key)
     result = {
       'metric': 'M-lookups/sec, 26-col Criteo-shape dim16, 1/2/4/8 GPUs; % HBM roofline',
       'value': round(value, 3), 'unit': 'M-lookups/sec', 'n_gpus': world,
@@ -467,7 +532,8 @@ def main():
                  'value_at_shipped_default_M_lookups_per_s': (
                      round(lookups_per_step_per_rank * world /
                            groups_probe['pipelined_2_groups'] / 1e3, 3)
-                     if groups_probe else None)},
+                     if groups_probe else None),
+                 **secondary},
       'roofline': {
         'bound': 'hbm',
         'kernel': ('group_lookup_fwd_kernel' if world == 1 and not args.sharded
@@ -475,6 +541,8 @@ def main():
         'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4),
         'traffic': traffic,
+        # the round whose --pmc passes produced the figure (tools/hbm_traffic.sh regenerates it)
+        'traffic_measured_in': traffic_round,
         # what the memory system moved per second (PMC bytes / launch time) and how that stands
         # against the measured-achievable 6.29 TB/s of the guide: the dim-16 gather is bound by
         # the rate of random 64-byte row requests, not by bytes

@@ -196,6 +196,8 @@ struct GCol {
   int64_t* pair_row[1];      // [n_ids] rows of the pairs, grouped by bucket
   int32_t* pair_seg[1];      // [n_ids] their segments
   int32_t* seg_of;           // [n_ids], ragged columns only
+  float* scaled;             // seg-of launch only: [n_seg, dim] gradient rows times the combiner's 1 / n,
+                             // 1 / sqrt(n) -- what the reduce stage then reads as a SUM column's gradient
   int4* desc;                // [n_buckets + e_max] job of every reduce workgroup slot of the column:
                              // {first pair, pairs of the bucket, bucket or -1, range index}
   int32_t* work;             // [2 * e_max] (bucket, range index >= 1) of the spare workgroups
@@ -312,6 +314,23 @@ __device__ inline void run_seek(const GCol& c, int64_t j, RunCursor& rc) {
   }
 }
 
+template <typename V>
+__device__ inline void scale_segments(const GCol& c, int64_t s0, int n, const int32_t* sp) {
+  constexpr int VE = sizeof(V) / 4;
+  const int tid = (int)threadIdx.x;
+  const int sub = tid & ((1 << c.lpr_log2) - 1);
+  const int groups = kBlock >> c.lpr_log2;
+  if (sub >= c.chunks) return;
+  for (int s = tid >> c.lpr_log2; s < n; s += groups) {
+    const int32_t len = sp[s + 1] - sp[s];
+    if (len <= 0) continue;   // (no id names the segment: nobody reads its row)
+    V g = __builtin_nontemporal_load(reinterpret_cast<const V*>(
+        c.grad_out + (s0 + s) * (int64_t)c.grad_stride + (int64_t)sub * VE));
+    g = c.combiner == HBK_COMBINER_MEAN ? g / (float)len : g / sqrtf((float)len);
+    *reinterpret_cast<V*>(c.scaled + (s0 + s) * (int64_t)c.dim + (int64_t)sub * VE) = g;
+  }
+}
+
 // ---- 0: segment of every id (ragged columns only; the host passes just those) --------------
 // A workgroup takes kBlock consecutive segments, i.e. ONE contiguous range of ids: their row
 // splits go to LDS and every thread finds the segment of ids tid, tid + kBlock, .. of the range by
@@ -341,6 +360,18 @@ __global__ __launch_bounds__(kBlock) void bwd_segof_kernel(const GArgs a) {
       }
     }
     c.seg_of[j] = (int32_t)(s0 + s);
+  }
+  // mean / sqrtn: the gradient row of every segment of this block, divided ONCE (round 4).  The
+  // reduce stage used to divide per PAIR -- 8 pairs per segment, four correctly rounded divisions
+  // each, a third of its vector instructions on ragged columns -- and fetched the segment's length
+  // with two more loads per pair; now it sums rows that are already scaled.  Same operation on the
+  // same operands, done once: bit-identical results.
+  if (c.scaled != nullptr) {
+    if (c.vec4) {
+      scale_segments<f32x4>(c, s0, n, sp);
+    } else {
+      scale_segments<float>(c, s0, n, sp);
+    }
   }
 }
 
@@ -2933,6 +2964,9 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
   b += (size_t)h.n_ids * 8;                                // pair_row
   b += align8((size_t)h.n_ids * 4);                        // pair_seg
   if (h.row_splits != nullptr) b += align8((size_t)h.n_ids * 4);
+  if (h.row_splits != nullptr && h.combiner != HBK_COMBINER_SUM) {
+    b += align8((size_t)h.n_segments * h.dim * 4) + 16;   // the segments' scaled gradient rows
+  }
   b += ((size_t)p.n_buckets + p.e_max) * sizeof(int4);     // desc (carved from the call's head)
   b += 256;                                                // the claim counter's own line
   b += align8((size_t)p.e_max * 8) + 8;                    // work, n_extra
@@ -3258,6 +3292,11 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
         d.seg_of = reinterpret_cast<int32_t*>(wp);
         wp += align8((size_t)h.n_ids * 4);
       }
+      float* scaled = nullptr;
+      if (h.row_splits != nullptr && h.combiner != HBK_COMBINER_SUM) {
+        scaled = reinterpret_cast<float*>(((uintptr_t)wp + 15) & ~(uintptr_t)15);
+        wp += align8((size_t)h.n_segments * h.dim * 4) + 16;
+      }
       d.desc = reinterpret_cast<int4*>(dp);
       dp += ((size_t)p.n_buckets + p.e_max) * sizeof(int4);
       d.work = reinterpret_cast<int32_t*>(wp);
@@ -3331,6 +3370,14 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       if (h.row_splits != nullptr && h.n_segments > 0) {
         GCol& sdesc = seg_args.col[ks];
         sdesc = d;
+        sdesc.scaled = scaled;
+        if (scaled != nullptr) {
+          // the seg-of launch scales the segments' gradient rows once; everything behind it reads
+          // the scaled rows as the gradient of a SUM column
+          d.grad_out = scaled;
+          d.grad_stride = h.dim;
+          d.combiner = HBK_COMBINER_SUM;
+        }
         sdesc.segtile0 = (int32_t)segtiles;
         seg_args.segtile0[ks] = (int32_t)segtiles;
         segtiles += (h.n_segments + kBlock - 1) / kBlock;

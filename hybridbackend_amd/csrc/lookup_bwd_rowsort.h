@@ -37,6 +37,18 @@ static_assert(kRsCap % kBlock == 0 && kRsCap <= (1 << (kRsBits - 1)), "counter f
 static_assert(kRsWords % kBlock == 0, "whole bitmap words per thread");
 static_assert(kRsSpan <= 65536, "16-bit row offsets");
 
+// A gradient row chunk.  Ragged columns with mean / sqrtn hand their rows over already scaled (the
+// seg-of launch divides every segment's row once, lookup_bwd.hip): no combiner arithmetic here.
+template <typename V>
+__device__ inline V rs_load_grad(const ReduceJob& job, int32_t seg, int sub, bool live) {
+  constexpr int VE = sizeof(V) / 4;
+  const uint64_t off = job.seg_is_offset ? (uint64_t)(uint32_t)seg
+                                         : (uint64_t)(uint32_t)seg * (uint32_t)job.stride;
+  V g = zero_v<V>();
+  if (live) g = HBK_GRAD_LOAD(reinterpret_cast<const V*>(job.grad + off + (uint64_t)sub * VE));
+  return g;
+}
+
 // Output rows of a one-chunk job are written once and not read again by this kernel: non-temporal,
 // so that they do not push the gradient lines out of L2 -- a ragged column reads every segment's
 // gradient row ~8 times, from different jobs (probe builds: -DHBK_RS_OUT_NT=0 plain stores).
@@ -92,7 +104,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   const float lr = STEP ? job.lr : 0.0f;
   const bool stepping = STEP && lr != 0.0f;
   const bool emit = !(STEP && job.no_emit);    // (no_emit only for jobs of one chunk: decode_job)
-  const bool scaled = job.scale && c.combiner != HBK_COMBINER_SUM && c.splits != nullptr;   // uniform
+  // (no combiner arithmetic: a ragged mean / sqrtn column arrives as a SUM column over scaled rows)
   const uint32_t M = c.dense_mul;
   const uint32_t base = (uint32_t)dense_first_row(M, bucket);
   uint64_t lim = dense_first_row(M, bucket + 1);
@@ -102,16 +114,29 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   uint32_t off_[PT];   // row - base of my pairs of the chunk, ~0u: none
   int32_t seg_[PT];
   auto load_pairs = [&](int32_t cb) {
+    // all loads first, in one straight line (indices behind the end are clamped and masked
+    // afterwards): with the range check and the sign test inside the loop the compiler waited for
+    // every pair before it requested the next -- 8 memory round trips, the job's first 8 us
+    int64_t r_[PT];
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
       const int32_t e = cb + k * kBlock + tid;
-      off_[k] = ~0u;
-      seg_[k] = e;
-      if (e < n_pairs) {
-        const int64_t r = HBK_PAIR_LOAD(prow + e);
-        if (pseg != nullptr) seg_[k] = HBK_PAIR_LOAD(pseg + e);
-        if (r >= 0) off_[k] = (uint32_t)r - base;
+      r_[k] = HBK_PAIR_LOAD(prow + (e < n_pairs ? e : n_pairs - 1));
+    }
+    if (pseg != nullptr) {   // uniform
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const int32_t e = cb + k * kBlock + tid;
+        seg_[k] = HBK_PAIR_LOAD(pseg + (e < n_pairs ? e : n_pairs - 1));
       }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PT; ++k) seg_[k] = cb + k * kBlock + tid;
+    }
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      const int32_t e = cb + k * kBlock + tid;
+      off_[k] = e < n_pairs && r_[k] >= 0 ? (uint32_t)r_[k] - base : ~0u;
     }
   };
   // A: rows -> bitmap (a bit that is set is not set again: a hot row's pairs would serialise)
@@ -332,26 +357,24 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
       V acc = zero_v<V>();
       for (int p = lo; p < hi; p += W) {
         V g[W];
-        int32_t n_[W];
+        int32_t sg[W];
         uint32_t uu[W];
         uint32_t val = 0, fin = 0;   // bit w: position p + w is mine / is the last of its run
+        // (positions behind the share's end are clamped to its last one and masked out below: the
+        // W loads leave in one straight line -- behind a branch per position the compiler waited
+        // for every load before it issued the next)
 #pragma unroll
         for (int w = 0; w < W; ++w) {
-          const int q = p + w;
-          g[w] = zero_v<V>();
-          n_[w] = 0;
-          uu[w] = 0;
-          if (q < hi) {
+          const int q = p + w < hi ? p + w : hi - 1;
+          uu[w] = L.su[q];
+          sg[w] = L.sseg[q];
+          if (p + w < hi) {
             val |= 1u << w;
-            uu[w] = L.su[q];
             if (L.su[q + 1] != (uint16_t)uu[w]) fin |= 1u << w;
-            if (live) g[w] = load_grad_raw<V>(c, job, L.sseg[q], sub, &n_[w]);
           }
         }
-        if (scaled) {
 #pragma unroll
-          for (int w = 0; w < W; ++w) g[w] = scale_grad<V>(c, g[w], n_[w]);
-        }
+        for (int w = 0; w < W; ++w) g[w] = rs_load_grad<V>(job, sg[w], sub, live);
         // the sum of a run of mine ends up in the registers its last gradient row arrived in
 #pragma unroll
         for (int w = 0; w < W; ++w) {

@@ -25,6 +25,11 @@ def test_self_launch_two_ranks_dry_run():
   assert line['dry_run'] is True and line['ranks'] == 2 and line['n_gpus'] == 2
   assert line['max_rank_sleep_ms'] >= 19.0          # the MAX over ranks (rank 1 sleeps 20 ms)
   assert line['value'] is None and 'error' in line   # nothing measured, and it says so
+  # the reference measurements a real N > 1 line carries next to the sharded headline: every
+  # rank holding all tables (replicated), and the other wire format -- named here, measured there
+  for key in ('replicated_M_lookups_per_s', 'replicated_ms_per_step', 'other_wire',
+              'other_wire_M_lookups_per_s', 'other_wire_ms_per_step', 'secondary_steps'):
+    assert key in line['config'] and line['config'][key] is None
 
 
 def test_torchrun_form_two_ranks_dry_run():

@@ -317,17 +317,28 @@ __device__ inline void run_seek(const GCol& c, int64_t j, RunCursor& rc) {
 template <typename V>
 __device__ inline void scale_segments(const GCol& c, int64_t s0, int n, const int32_t* sp) {
   constexpr int VE = sizeof(V) / 4;
+  constexpr int kU = 4;   // rows in flight per lane (one at a time: 32 round trips per block at dim 128)
   const int tid = (int)threadIdx.x;
   const int sub = tid & ((1 << c.lpr_log2) - 1);
   const int groups = kBlock >> c.lpr_log2;
   if (sub >= c.chunks) return;
-  for (int s = tid >> c.lpr_log2; s < n; s += groups) {
-    const int32_t len = sp[s + 1] - sp[s];
-    if (len <= 0) continue;   // (no id names the segment: nobody reads its row)
-    V g = __builtin_nontemporal_load(reinterpret_cast<const V*>(
-        c.grad_out + (s0 + s) * (int64_t)c.grad_stride + (int64_t)sub * VE));
-    g = c.combiner == HBK_COMBINER_MEAN ? g / (float)len : g / sqrtf((float)len);
-    *reinterpret_cast<V*>(c.scaled + (s0 + s) * (int64_t)c.dim + (int64_t)sub * VE) = g;
+  for (int s = tid >> c.lpr_log2; s < n; s += kU * groups) {
+    V g[kU];
+    int32_t len[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int ss = s + u * groups < n ? s + u * groups : n - 1;   // (clamped: straight-line loads)
+      len[u] = s + u * groups < n ? sp[ss + 1] - sp[ss] : 0;
+      g[u] = __builtin_nontemporal_load(reinterpret_cast<const V*>(
+          c.grad_out + (s0 + ss) * (int64_t)c.grad_stride + (int64_t)sub * VE));
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (len[u] <= 0) continue;   // (no id names the segment: nobody reads its row)
+      const V v = c.combiner == HBK_COMBINER_MEAN ? g[u] / (float)len[u]
+                                                  : g[u] / sqrtf((float)len[u]);
+      *reinterpret_cast<V*>(c.scaled + (s0 + s + u * groups) * (int64_t)c.dim + (int64_t)sub * VE) = v;
+    }
   }
 }
 
@@ -2901,10 +2912,22 @@ ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged) {
   // row range fits (tests).
   {
     const int dense_opt = options().bwd_dense;
-    const int64_t ratio = options().bwd_rowsort_ratio;
+    // narrow rows (dim <= 32) gain up to twice the ratio (config 2, rows = 15 x ids: 106 -> 93 us);
+    // wide rows with skewed ids lose there (config 4 Zipf, dim 128: 345 -> 482 us)
+    const int64_t ratio = (int64_t)options().bwd_rowsort_ratio * (dim <= 32 ? 2 : 1);
     const bool want = dense_opt == 3 || (dense_opt == 1 && ratio > 0 && rows <= ratio * n_ids);
     if (kTeam == kBlock && want && rows >= 1 && rows < (1ll << 32)) {
       int64_t rs_target = (int64_t)kRsCap * 7 / 8;
+      // wide rows: a lane group is 16-64 lanes, a workgroup holds 4-16 of them, and a job of 1792
+      // pairs is a serial walk of 100-450 positions per lane group; option bwd_rowsort_pos (> 0)
+      // sizes the job for that many positions per lane group instead
+      if (options().bwd_rowsort_pos > 0) {
+        int lanes = 1;
+        while (lanes * 4 < dim) lanes *= 2;   // (16-byte chunks; 4-byte chunks only make the job smaller)
+        int64_t by_pos = (int64_t)options().bwd_rowsort_pos * (kBlock / lanes);
+        if (by_pos < 256) by_pos = 256;
+        if (by_pos < rs_target) rs_target = by_pos;
+      }
       if (options().bwd_bucket_pairs > 0 && options().bwd_bucket_pairs < rs_target) {
         rs_target = options().bwd_bucket_pairs;
       }

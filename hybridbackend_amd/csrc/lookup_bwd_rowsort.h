@@ -66,6 +66,16 @@ __device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t
 #endif
 }
 
+#ifndef HBK_RS_W0
+#define HBK_RS_W0 12   // (8: ragged dim 16 675 us, 12: 616 us; 16 spills)
+#endif
+#ifndef HBK_RS_W1
+#define HBK_RS_W1 6
+#endif
+#ifndef HBK_RS_W2
+#define HBK_RS_W2 4
+#endif
+
 struct RsLds {
   uint32_t present[kRsWords];   // rows of the job
   uint32_t pre[kRsWords];       // rows before word w
@@ -88,7 +98,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   constexpr bool adagrad = STEP == 2;
   // gradient rows a lane keeps in flight (with the step, the table / accumulator rows of the rows
   // that finish in a batch travel together: register budget of 128)
-  constexpr int W = STEP == 2 ? 4 : STEP == 1 ? 6 : 8;
+  constexpr int W = STEP == 2 ? HBK_RS_W2 : STEP == 1 ? HBK_RS_W1 : HBK_RS_W0;
   const int tid = (int)threadIdx.x;
   const int lane = tid & (kWave - 1), wave = tid >> 6;
   const int lpr_log2 = c.lpr_log2;

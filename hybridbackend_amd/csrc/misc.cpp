@@ -33,6 +33,7 @@ const OptionEntry kOptions[] = {
     {"bwd_group_cols", "HBK_BWD_GROUP_COLS", &Options::bwd_group_cols},
     {"bwd_dense", "HBK_BWD_DENSE", &Options::bwd_dense},
     {"bwd_scatter_staged", "HBK_BWD_SCATTER_STAGED", &Options::bwd_scatter_staged},
+    {"bwd_rowsort_pos", "HBK_BWD_ROWSORT_POS", &Options::bwd_rowsort_pos},
     {"bwd_rowsort_ratio", "HBK_BWD_ROWSORT_RATIO", &Options::bwd_rowsort_ratio},
     {"bwd_wide", "HBK_BWD_WIDE", &Options::bwd_wide},
     {"bwd_xcd", "HBK_BWD_XCD", &Options::bwd_xcd},

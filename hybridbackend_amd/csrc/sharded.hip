@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void pack_ids_kernel(const PackArgs a) {
 #pragma unroll
   for (int k = 0; k < kPackTile / kBlock; ++k) {
     const int32_t e = e0 + k * kBlock + tid;
-    if (e >= n) break;
+    if (e >= n || e >= cum[W]) break;   // (deduplicated column: n is its capacity, cum[W] its ids)
     const int64_t v = __builtin_nontemporal_load(src + e);
     int q = 0, qh = W;       // last q with cum[q] <= e (empty shards share a start: take the last)
     while (qh - q > 1) {
@@ -223,6 +223,87 @@ __global__ __launch_bounds__(kBlock) void pack_ids_kernel(const PackArgs a) {
     } else {
       reinterpret_cast<int64_t*>(a.dst)[at] = v;
     }
+  }
+}
+
+// ---- requester-side dedup (round 4) -------------------------------------------------------------
+// A column flagged `dedup` sends every distinct id ONCE per step (the reference's tutorials do this
+// in user code in front of the patched lookup: docs/tutorial/ranking/data.py:180-182 tf.unique ->
+// lookup -> tf.gather; SURVEY 8e lever (b)).  Composition, all on the device, still ONE host sync:
+//   partition (stable, by id mod W)  ->  hbk_unique_n over the SHARD-ORDERED ids of the column.
+// First-occurrence order of an array in which all ids of shard 0 precede those of shard 1, .. is
+// itself grouped by shard, so the unique list IS the column's outgoing id run, shard by shard, and
+//   S'[c][q] = distinct ids of shard q  = the distance of two boundaries of that list (binary
+//              search on id mod W, below),
+//   index'   = inverse o shard_index     (one composed index: the stitch reads the received rows
+//              through it exactly as it read the undeduplicated ones through shard_index).
+// Backward: the requester reduces the duplicates itself (hbk_group_lookup_bwd over index', the
+// received-rows buffer playing the table) before the reverse exchange.
+constexpr int kDedupTile = 2048;
+
+struct DedupArgs {
+  const int64_t* uniq;     // bases of the set's buffers; column d lives at off[d]
+  const int32_t* inv;
+  int32_t* idx;
+  const int32_t* nu;       // [N] distinct ids of every column (device)
+  int32_t* S;              // [N][W]
+  int32_t* St;             // [W][N]
+  FastDiv wdiv;
+  int32_t n_cols, W, N, pad_;
+  int64_t off[kMaxPackCols];
+  int32_t n[kMaxPackCols];
+  int32_t tile0[kMaxPackCols];
+  int16_t col[kMaxPackCols];
+};
+static_assert(sizeof(DedupArgs) <= 16384, "kernarg budget");
+
+// index'[i] = inv[shard_index[i]], in place
+__global__ __launch_bounds__(kBlock) void dedup_compose_kernel(const DedupArgs a) {
+  int d = 0, hi = a.n_cols;
+  while (hi - d > 1) {
+    const int mid = (d + hi) >> 1;
+    if (a.tile0[mid] <= (int)blockIdx.x) {
+      d = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  const int32_t n = a.n[d];
+  const int32_t* inv = a.inv + a.off[d];
+  int32_t* idx = a.idx + a.off[d];
+  const int32_t e0 = ((int)blockIdx.x - a.tile0[d]) * kDedupTile;
+#pragma unroll
+  for (int k = 0; k < kDedupTile / kBlock; ++k) {
+    const int32_t e = e0 + k * kBlock + (int)threadIdx.x;
+    if (e < n) idx[e] = inv[idx[e]];
+  }
+}
+
+// S'[c][q] and its transpose from the boundaries of the unique list (grouped by shard, ascending)
+__global__ __launch_bounds__(kMaxPackWorld) void dedup_sizes_kernel(const DedupArgs a) {
+  __shared__ int32_t start[kMaxPackWorld + 1];
+  const int d = (int)blockIdx.x, q = (int)threadIdx.x;
+  const int c = a.col[d];
+  const int32_t u = a.nu[c];
+  const int64_t* uniq = a.uniq + a.off[d];
+  if (q < a.W) {
+    int32_t lo = 0, hi = u;   // first position whose shard is >= q
+    while (lo < hi) {
+      const int32_t mid = (lo + hi) >> 1;
+      if ((int)floormod_i64(uniq[mid], a.wdiv) >= q) {
+        hi = mid;
+      } else {
+        lo = mid + 1;
+      }
+    }
+    start[q] = lo;
+  }
+  if (q == 0) start[a.W] = u;
+  __syncthreads();
+  if (q < a.W) {
+    const int32_t cnt = start[q + 1] - start[q];
+    a.S[(size_t)c * a.W + q] = cnt;
+    a.St[(size_t)q * a.N + c] = cnt;
   }
 }
 
@@ -364,6 +445,8 @@ struct hbk_sharded {
   std::vector<hbk_sharded_column_t> cols;
   // per-step state (kept for the backward)
   std::vector<int64_t> n_ids, n_seg;
+  std::vector<int64_t> n_sent;       // ids of column c this rank put on the wire (= n_ids, or its
+                                     // distinct ids when the column is deduplicated)
   std::vector<const int32_t*> row_splits;
   std::vector<int32_t> send_sizes;   // S [N][W] rows this rank requests from owner q, column c
   std::vector<int32_t> recv_sizes;   // R [W][N] rows requester q asked this rank for, column c
@@ -381,6 +464,9 @@ struct hbk_sharded {
   char* recv_ids_p;
   float* send_rows_p;
   float* recv_rows_p;
+  bool any_dedup;       // some column sends every distinct id once (hbk_sharded_column_t.dedup)
+  hbk::Buffer dedup_tmp;  // backward of those columns: the requester-side IndexedSlices before they
+                          // are placed in the outgoing buffer
   bool pack_early;      // option sharded_pack_early
   bool fused_half;      // fp16 wire, forward: the owner gather WRITES fp16 rows into the reply buffer and
                         // the stitch READS fp16 rows from the received one (hbk_lookup_column_t.half_io): the
@@ -396,6 +482,8 @@ struct hbk_sharded {
   // set of the last forward stays untouched for its backward.
   struct PartSet {
     hbk::Buffer part_out, shard_index, sizes_dev;
+    hbk::Buffer uniq, inv, nu, uniq_ws;   // deduplicated columns: distinct shard-ordered ids, their
+                                          // inverse index, their counts (device), unique's workspace
     hbk::Buffer packed;                // the step's outgoing ids, peer-major per column group
     bool packed_early = false;         // ... written by run_partition (else by the forward)
     int32_t* host_sizes = nullptr;     // pinned [3][N*W]: S, S^T, R as they sit on the device
@@ -448,6 +536,8 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
     if (cols[c].bucket <= 0 || cols[c].bucket > 0x7fffffffll) p->id32 = false;
   }
   p->have_step = false;
+  p->any_dedup = false;
+  for (int32_t c = 0; c < n_cols; ++c) p->any_dedup = p->any_dedup || cols[c].dedup != 0;
   p->fused_half = wire_dtype == HBK_HALF && options().sharded_wire_fused != 0;
   p->pack_early = options().sharded_pack_early != 0;
   p->zero_copy_self = (wire_dtype == HBK_FLOAT || p->fused_half) && options().sharded_copy_self == 0;
@@ -491,13 +581,17 @@ extern "C" int hbk_sharded_destroy(hbk_sharded_t p) {
   if (p == nullptr) return HBK_OK;
   if (p->pre_stream) (void)hipStreamSynchronize(p->pre_stream);
   for (hbk::Buffer* b : {&p->part_ws, &p->ids_buf, &p->rows_buf, &p->wire_ws, &p->bwd_ws,
-                         &p->runs_dev}) {
+                         &p->runs_dev, &p->dedup_tmp}) {
     b->release();
   }
   for (auto& set : p->ps) {
     set.part_out.release();
     set.shard_index.release();
     set.sizes_dev.release();
+    set.uniq.release();
+    set.inv.release();
+    set.nu.release();
+    set.uniq_ws.release();
     set.packed.release();
     if (set.host_sizes) (void)hipHostFree(set.host_sizes);
     if (set.done) (void)hipEventDestroy(set.done);
@@ -597,6 +691,65 @@ int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* cons
   rc = partition_by_modulo_fused(N, W, ids, n_ids, buckets.data(), pout.data(), sizes.data(),
                                  idx.data(), sizes_t, p->part_ws.ptr, p->part_ws.bytes, stream);
   if (rc != HBK_OK) return rc;
+  // requester-side dedup: distinct ids of the flagged columns, composed index, sizes S'
+  std::vector<const int64_t*> id_src(N);   // what goes on the wire: shard-ordered ids, or the distinct ones
+  for (int c = 0; c < N; ++c) id_src[c] = pout[c];
+  if (p->any_dedup) {
+    if ((rc = set.uniq.ensure((size_t)total * 8 + 8)) != HBK_OK) return rc;
+    if ((rc = set.inv.ensure((size_t)total * 4 + 8)) != HBK_OK) return rc;
+    if ((rc = set.nu.ensure((size_t)N * 4 + 8)) != HBK_OK) return rc;
+    HBK_HIP_OK(hipMemsetAsync(set.nu.ptr, 0, (size_t)N * 4, stream));
+    std::vector<const int64_t*> uin;
+    std::vector<int64_t> ulen;
+    std::vector<int64_t*> uout;
+    std::vector<int32_t*> iout, nout;
+    DedupArgs a;
+    int64_t tiles = 0, o = 0;
+    int nd = 0;
+    for (int c = 0; c < N; ++c) {
+      if (p->cols[c].dedup != 0 && n_ids[c] > 0) {
+        HBK_REQUIRE(nd < kMaxPackCols && W <= kMaxPackWorld,
+                    "sharded lookup: dedup supports up to %d columns and %d ranks", kMaxPackCols,
+                    kMaxPackWorld);
+        int64_t* u = reinterpret_cast<int64_t*>(set.uniq.ptr) + o;
+        uin.push_back(pout[c]);
+        ulen.push_back(n_ids[c]);
+        uout.push_back(u);
+        iout.push_back(reinterpret_cast<int32_t*>(set.inv.ptr) + o);
+        nout.push_back(reinterpret_cast<int32_t*>(set.nu.ptr) + c);
+        id_src[c] = u;
+        a.off[nd] = o;
+        a.n[nd] = (int32_t)n_ids[c];
+        a.tile0[nd] = (int32_t)tiles;
+        a.col[nd] = (int16_t)c;
+        tiles += (n_ids[c] + kDedupTile - 1) / kDedupTile;
+        ++nd;
+      }
+      o += n_ids[c];
+    }
+    if (nd > 0) {
+      const size_t uws = hbk_unique_workspace_bytes(nd, ulen.data());
+      if ((rc = set.uniq_ws.ensure(uws + 8)) != HBK_OK) return rc;
+      rc = hbk_unique_n(nd, uin.data(), ulen.data(), uout.data(), iout.data(), nout.data(),
+                        set.uniq_ws.ptr, set.uniq_ws.bytes, reinterpret_cast<hbk_stream_t>(stream));
+      if (rc != HBK_OK) return rc;
+      a.uniq = reinterpret_cast<const int64_t*>(set.uniq.ptr);
+      a.inv = reinterpret_cast<const int32_t*>(set.inv.ptr);
+      a.idx = reinterpret_cast<int32_t*>(set.shard_index.ptr);
+      a.nu = reinterpret_cast<const int32_t*>(set.nu.ptr);
+      a.S = sizes_dev;
+      a.St = sizes_t;
+      a.wdiv = make_fastdiv((uint64_t)W);
+      a.wdiv.d = (uint64_t)W;
+      a.n_cols = nd;
+      a.W = W;
+      a.N = N;
+      a.pad_ = 0;
+      hipLaunchKernelGGL(dedup_compose_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, stream, a);
+      hipLaunchKernelGGL(dedup_sizes_kernel, dim3((unsigned)nd), dim3(kMaxPackWorld), 0, stream, a);
+      HBK_HIP_OK(hipGetLastError());
+    }
+  }
   const void* sin[1] = {sizes_t};
   void* sout[1] = {recv_t};
   const int64_t cnt[1] = {(int64_t)N * W};
@@ -624,7 +777,7 @@ int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* cons
       const int c0 = (int)((int64_t)N * g / G), c1 = (int)((int64_t)N * (g + 1) / G);
       int64_t in_group = 0;
       for (int c = c0; c < c1; ++c) {
-        a.src[c] = pout[c];
+        a.src[c] = id_src[c];
         a.gbase[c] = gbase;
         a.n[c] = (int32_t)n_ids[c];
         a.tile0[c] = (int32_t)tiles;
@@ -713,12 +866,18 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   p->recv_sizes.assign(set.host_sizes + 2 * (size_t)N * W, set.host_sizes + 3 * (size_t)N * W);
   std::vector<int64_t*> pout(N);
   std::vector<int32_t*> idx(N);
+  p->n_sent.assign(N, 0);
   {
     int64_t off = 0;
     for (int c = 0; c < N; ++c) {
       pout[c] = reinterpret_cast<int64_t*>(set.part_out.ptr) + off;
+      if (p->cols[c].dedup != 0 && n_ids[c] > 0) {   // the distinct ids travel (run_partition)
+        pout[c] = reinterpret_cast<int64_t*>(set.uniq.ptr) + off;
+      }
       idx[c] = reinterpret_cast<int32_t*>(set.shard_index.ptr) + off;
       off += n_ids[c];
+      for (int q = 0; q < W; ++q) p->n_sent[c] += p->send_sizes[(size_t)c * W + q];
+      HBK_REQUIRE(p->n_sent[c] <= n_ids[c], "sharded_lookup_fwd: column %d: sizes exceed its ids", c);
     }
   }
   const int32_t* S = p->send_sizes.data();
@@ -746,11 +905,13 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     }
     std::vector<hbk_sharded_column_t> sub(p->cols.begin() + gr.c0, p->cols.begin() + gr.c1);
     if ((rc = gr.lay.compute(ng, W, sub, S + (size_t)gr.c0 * W, gr.R.data())) != HBK_OK) return rc;
+    // (capacity, not the ids actually sent: the early pack placed the groups before the host knew
+    // how many ids a deduplicated column keeps; without dedup the two are the same)
     gr.id_send = tot_req_ids;
     gr.id_recv = tot_own_ids;
     gr.row_send = tot_own_floats;
     gr.row_recv = tot_req_floats;
-    tot_req_ids += gr.lay.req_ids;
+    for (int c = gr.c0; c < gr.c1; ++c) tot_req_ids += n_ids[c];
     tot_own_ids += gr.lay.own_ids;
     tot_own_floats += gr.lay.own_floats;
     tot_req_floats += gr.lay.req_floats;
@@ -948,10 +1109,10 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
                                                       gr.row_recv)
                      : rows_recv_base + gr.row_recv;
       h.half_io = half ? HBK_LOOKUP_TABLE_HALF : 0;
-      h.rows = n_ids[cc];
+      h.rows = p->n_sent[cc];   // rows that came back (the distinct ids of a deduplicated column)
       h.dim = p->cols[cc].dim;
       h.ids_dtype = HBK_INT32;
-      h.ids = idx[cc];
+      h.ids = idx[cc];          // shard_index, composed with the inverse index where deduplicated
       h.n_ids = n_ids[cc];
       h.row_splits = p->row_splits[cc];
       h.n_segments = p->n_seg[cc];

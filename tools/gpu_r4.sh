@@ -95,6 +95,27 @@ PY
       done;;
     rsstamps2)
       (HBK_STAMP_NAMES=rowsort LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops R) > $O/rsstamps2.log 2>&1; grep "reduce kernel" $O/rsstamps2.log | cut -c1-600;;
+    profbh)   # kernel stats of the ragged case and of the config-5 shape
+      prof prof_ragged "" -- python $R/tools/sweep.py --cases b
+      prof prof_cfg5 "" -- python $R/tools/sweep.py --cases h
+      echo "== ragged"; grep -E "bwd_|kernel  " $O/prof_ragged.txt | cut -c1-150 | head -14
+      echo "== cfg5"; grep -E "bwd_|kernel  " $O/prof_cfg5.txt | cut -c1-150 | head -40;;
+    rsab3)   # the ratio that picks row-sorted buckets; probe builds of the walk width
+      (ab "bwd_rowsort_ratio:8,16,32,8,16,32" "c,h"
+       ab "bwd_rowsort_ratio:8,16,8,16" "d,f"
+       for v in tools/bin/v_*; do
+         for w in R r d; do
+           LD_LIBRARY_PATH=$R/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s|^|$(basename $v)  |"
+         done
+       done) > $O/rsab3.log 2>&1; cut -c1-260 $O/rsab3.log;;
+    rsab4)   # job size by row width
+      (ab "bwd_rowsort_pos:0,32,64,0,32,64" "h"
+       ab "bwd_rowsort_pos:0,32,64,0,32,64" "d,f"
+       for pos in 0 32 64; do
+         HBK_BWD_ROWSORT_POS=$pos timeout 300 tools/bin/bench_ops r 2>&1 | grep group_lookup_bwd | sed "s|^|pos=$pos  |"
+         HBK_BWD_ROWSORT_POS=$pos timeout 300 tools/bin/bench_ops d 2>&1 | grep group_lookup_bwd | sed "s|^|pos=$pos  |"
+         HBK_BWD_ROWSORT_POS=$pos timeout 300 tools/bin/bench_ops w 2>&1 | grep group_lookup_bwd | sed "s|^|pos=$pos  |"
+       done) > $O/rsab4.log 2>&1; cut -c1-260 $O/rsab4.log;;
     *) echo "unknown stage $st";;
   esac
 done

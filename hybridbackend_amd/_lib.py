@@ -59,7 +59,7 @@ class ShardedColumn(C.Structure):
   """hbk_sharded_column_t"""
   _fields_ = [('shard', C.c_void_p), ('rows_local', C.c_int64), ('dim', C.c_int32),
               ('combiner', C.c_int32), ('bucket', C.c_int64), ('accum', C.c_void_p),
-              ('hot_rows', C.c_int32), ('reserved_', C.c_int32)]
+              ('hot_rows', C.c_int32), ('dedup', C.c_int32)]
 
 
 class StitchGradColumn(C.Structure):

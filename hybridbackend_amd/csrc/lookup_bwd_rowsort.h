@@ -383,31 +383,22 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
             if (L.su[q + 1] != (uint16_t)uu[w]) fin |= 1u << w;
           }
         }
+        // the runs that END here and are mine: all but the end of an earlier group's run
+        uint32_t mine = fin;
+        if (in_head && fin != 0u) mine &= fin - 1u;   // (its end is the lowest bit)
+        // ALL loads of the batch in one go: W gradient rows and -- with the optimizer step -- the
+        // table / accumulator rows of the rows that finish in it (their numbers are known before
+        // anything arrives).  (Requested after the sums, the step's rows were a second memory round
+        // trip per batch: config-5 shape + Adagrad, W = 4: two round trips per four positions.)
+        V tv[STEP ? W : 1], av[STEP == 2 ? W : 1];
 #pragma unroll
         for (int w = 0; w < W; ++w) g[w] = rs_load_grad<V>(job, sg[w], sub, live);
-        // the sum of a run of mine ends up in the registers its last gradient row arrived in
-#pragma unroll
-        for (int w = 0; w < W; ++w) {
-          if (val >> w & 1u) {
-            acc = acc + g[w];
-            if (fin >> w & 1u) {
-              if (in_head) {     // (uniform in the lane group) the end of an earlier group's run
-                *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = acc;
-                in_head = false;
-                fin &= ~(1u << w);
-              } else {
-                g[w] = acc;
-              }
-              acc = zero_v<V>();
-            }
-          }
-        }
-        if (fin == 0u || !live) continue;
-        if (one_chunk && stepping) {
-          V tv[STEP ? W : 1], av[STEP == 2 ? W : 1];
+        if (STEP && one_chunk && stepping) {
 #pragma unroll
           for (int w = 0; w < W; ++w) {
-            if (fin >> w & 1u) {
+            tv[STEP ? w : 0] = zero_v<V>();
+            if (STEP == 2) av[STEP == 2 ? w : 0] = zero_v<V>();
+            if ((mine >> w & 1u) && live) {
               const int64_t toff = (int64_t)(base + L.roff[uu[w]]) * c.dim + (int64_t)sub * VE;
               tv[STEP ? w : 0] = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
               if (STEP == 2) {
@@ -415,9 +406,28 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
               }
             }
           }
+        }
+        // the sum of a run of mine ends up in the registers its last gradient row arrived in
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          if (val >> w & 1u) {
+            acc = acc + g[w];
+            if (fin >> w & 1u) {
+              if (mine >> w & 1u) {
+                g[w] = acc;
+              } else {           // (uniform in the lane group) the end of an earlier group's run
+                *reinterpret_cast<V*>(&L.red[(size_t)tid * VE]) = acc;
+                in_head = false;
+              }
+              acc = zero_v<V>();
+            }
+          }
+        }
+        if (mine == 0u || !live) continue;
+        if (one_chunk && stepping) {
 #pragma unroll
           for (int w = 0; w < W; ++w) {
-            if (fin >> w & 1u) {
+            if (mine >> w & 1u) {
               if (emit) rs_store_row<V>(c, job, base_u + (int32_t)uu[w], sub, g[w]);
               const int64_t toff = (int64_t)(base + L.roff[uu[w]]) * c.dim + (int64_t)sub * VE;
               step_row<V>(c, adagrad, lr, toff, g[w], tv[STEP ? w : 0],
@@ -427,12 +437,12 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
         } else if (one_chunk) {
 #pragma unroll
           for (int w = 0; w < W; ++w) {
-            if (fin >> w & 1u) rs_store_row<V>(c, job, base_u + (int32_t)uu[w], sub, g[w]);
+            if (mine >> w & 1u) rs_store_row<V>(c, job, base_u + (int32_t)uu[w], sub, g[w]);
           }
         } else {
 #pragma unroll
           for (int w = 0; w < W; ++w) {
-            if (fin >> w & 1u) {
+            if (mine >> w & 1u) {
               emit_row<V>(c, job, out_index(uu[w]), is_first(uu[w]), sub, g[w]);
             }
           }

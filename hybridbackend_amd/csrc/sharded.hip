@@ -1209,9 +1209,84 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
   // ---- B1 d(stitch + combiner) written straight into the peer-major buffer the rows came in ----
   std::vector<int64_t> ioff(N + 1, 0);
   for (int c = 0; c < N; ++c) ioff[c + 1] = ioff[c] + p->n_ids[c];
+  // deduplicated columns: scratch for their requester-side IndexedSlices (rows = positions in the
+  // column's distinct-id list): int64 rows, the same as int32, gradient rows, counts
+  std::vector<int64_t> t_rows(N, -1), t_vals(N, -1);
+  size_t tmp_bytes = 0, dd_ws = 0;
+  if (p->any_dedup) {
+    for (int c = 0; c < N; ++c) {
+      if (p->cols[c].dedup == 0 || p->n_sent[c] <= 0) continue;
+      t_rows[c] = (int64_t)tmp_bytes;
+      tmp_bytes += (size_t)p->n_sent[c] * 12 + 16;
+      tmp_bytes = (tmp_bytes + 15) & ~(size_t)15;
+      t_vals[c] = (int64_t)tmp_bytes;
+      tmp_bytes += ((size_t)p->n_sent[c] * p->cols[c].dim * 4 + 15) & ~(size_t)15;
+    }
+    tmp_bytes += (size_t)N * 4 + 16;
+    if ((rc = p->dedup_tmp.ensure(tmp_bytes)) != HBK_OK) return rc;
+  }
+  char* const tmp = reinterpret_cast<char*>(p->dedup_tmp.ptr);
+  int32_t* const tmp_nu = p->any_dedup ? reinterpret_cast<int32_t*>(tmp + tmp_bytes - (size_t)N * 4 - 8)
+                                       : nullptr;
   for (int g = 0; g < G; ++g) {
     const Group& gr = p->groups[g];
     const int ng = gr.c1 - gr.c0;
+    // (a) deduplicated columns: duplicate positions are summed HERE, on the requester, so that one
+    // gradient row per distinct id goes back -- hbk_group_lookup_bwd over the composed index (the
+    // received-rows buffer was the forward's table), then every row to its place in the
+    // peer-major buffer (the order of the distinct-id list)
+    if (p->any_dedup) {
+      std::vector<hbk_lookup_grad_column_t> dv;
+      std::vector<hbk_stitch_grad_column_t> sv;
+      std::vector<hbk::Seg> narrow;
+      for (int c = 0; c < ng; ++c) {
+        const int cc = gr.c0 + c;
+        if (t_rows[cc] < 0) continue;
+        const int64_t u = p->n_sent[cc];
+        hbk_lookup_grad_column_t h;
+        memset(&h, 0, sizeof(h));
+        h.rows = u;
+        h.dim = p->cols[cc].dim;
+        h.ids_dtype = HBK_INT32;
+        h.ids = reinterpret_cast<const int32_t*>(p->ps[p->cur].shard_index.ptr) + ioff[cc];
+        h.n_ids = p->n_ids[cc];
+        h.row_splits = p->row_splits[cc];
+        h.n_segments = p->n_seg[cc];
+        h.divisor = 1;
+        h.combiner = p->cols[cc].combiner;
+        h.grad_out = grads[cc];
+        h.grad_stride = grad_strides ? grad_strides[cc] : 0;
+        h.unique_rows = reinterpret_cast<int64_t*>(tmp + t_rows[cc]);
+        h.grad_rows = reinterpret_cast<float*>(tmp + t_vals[cc]);
+        h.n_unique = tmp_nu + cc;
+        dv.push_back(h);
+        int32_t* idx32 = reinterpret_cast<int32_t*>(tmp + t_rows[cc] + (size_t)u * 8);
+        narrow.push_back(make_seg(h.unique_rows, idx32, u * 8, 1));
+        hbk_stitch_grad_column_t t;
+        memset(&t, 0, sizeof(t));
+        t.dim = h.dim;
+        t.combiner = HBK_COMBINER_SUM;
+        t.n_ids = u;
+        t.index = idx32;
+        t.n_segments = u;
+        t.grad_out = h.grad_rows;
+        t.grad_rows = rows_recv_base + gr.row_recv;
+        t.run_start = d_start + (size_t)cc * W;
+        t.run_base = d_base + (size_t)cc * W;
+        t.n_runs = W;
+        sv.push_back(t);
+      }
+      if (!dv.empty()) {
+        dd_ws = hbk_group_lookup_bwd_workspace_bytes((int32_t)dv.size(), dv.data());
+        if ((rc = p->bwd_ws.ensure(dd_ws + 8)) != HBK_OK) return rc;
+        rc = hbk_group_lookup_bwd((int32_t)dv.size(), dv.data(), 0.0f, p->bwd_ws.ptr,
+                                  p->bwd_ws.bytes, stream_);
+        if (rc != HBK_OK) return rc;
+        if ((rc = seg_copy(narrow, stream)) != HBK_OK) return rc;
+        rc = hbk_group_stitch_bwd((int32_t)sv.size(), sv.data(), stream_);
+        if (rc != HBK_OK) return rc;
+      }
+    }
     std::vector<hbk_stitch_grad_column_t> v(ng);
     for (int c = 0; c < ng; ++c) {
       const int cc = gr.c0 + c;
@@ -1219,7 +1294,7 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
       memset(&h, 0, sizeof(h));
       h.dim = p->cols[cc].dim;
       h.combiner = p->cols[cc].combiner;
-      h.n_ids = p->n_ids[cc];
+      h.n_ids = t_rows[cc] >= 0 ? 0 : p->n_ids[cc];   // (0: the column was handled above)
       h.index = reinterpret_cast<const int32_t*>(p->ps[p->cur].shard_index.ptr) + ioff[cc];
       h.row_splits = p->row_splits[cc];
       h.n_segments = p->n_seg[cc];

@@ -63,10 +63,15 @@ class ShardedGroupLookup:
       collective.py:291-296); None keeps fp32.
     hot_rows: as for ``GroupLookup`` (skewed ids: the owner-side gather of wide columns stages the
       rows repeated inside a tile in LDS); a bool or one per column.
+    dedup: requester-side dedup, a bool or one per column: every DISTINCT id of the column's batch
+      goes on the wire once -- what the reference's tutorials do in user code in front of the
+      patched lookup (docs/tutorial/ranking/data.py:180-182: ``tf.unique`` -> lookup ->
+      ``tf.gather``).  Same results; fewer ids out, fewer rows back and fewer gradient rows in the
+      backward when ids repeat inside a batch (Zipf), at the price of a unique over the batch.
   """
 
   def __init__(self, shards, coll, buckets=None, combiners='sum', wire_dtype=None,
-               world_size=None, accums=None, hot_rows=False):
+               world_size=None, accums=None, hot_rows=False, dedup=False):
     self.shards = list(shards)
     # Adagrad accumulators of the shards (same shapes), for backward(optimizer='adagrad')
     self.accums = list(accums) if accums is not None else None
@@ -80,6 +85,7 @@ class ShardedGroupLookup:
     self.dims = [int(t.shape[1]) for t in self.shards]
     self.hot_rows = [bool(hot_rows)] * n if isinstance(hot_rows, (bool, int)) else \
         [bool(h) for h in hot_rows]
+    self.dedup = [bool(dedup)] * n if isinstance(dedup, (bool, int)) else [bool(d) for d in dedup]
     self._setup()
 
   def _setup(self):
@@ -144,6 +150,7 @@ class ShardedGroupLookup:
         cols[c].combiner = _combiner_code(combs[c])
         cols[c].bucket = self.buckets[c]
         cols[c].hot_rows = 1 if self.hot_rows[c] else 0
+        cols[c].dedup = 1 if self.dedup[c] else 0
         if self.accums is not None:
           cols[c].accum = self.accums[c].data_ptr()
       self._plan_handle = C.c_void_p()

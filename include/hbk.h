@@ -478,7 +478,13 @@ typedef struct {
   float* accum;         /* Adagrad accumulator of the shard [rows_local, dim], or NULL */
   int32_t hot_rows;     /* != 0: skewed ids expected: the owner gather stages the rows repeated in a
                            tile in LDS (hbk_lookup_column_t.hot_rows; wide columns only) */
-  int32_t reserved_;    /* 0 */
+  int32_t dedup;        /* != 0: requester-side dedup -- every DISTINCT id of the column's batch is
+                           sent once (the reference's tutorials do it in user code in front of the
+                           lookup, docs/tutorial/ranking/data.py:180-182): unique over the partitioned
+                           ids, exchanges sized by the distinct ids, the stitch reads the received
+                           rows through inverse o shard_index, and the backward sums duplicate
+                           positions on the requester before the reverse exchange.  Pays when ids
+                           repeat inside a batch (Zipf) and the step is link-bound; costs the unique. */
 } hbk_sharded_column_t;
 
 /* Host arithmetic of the peer-major exchange buffers (pure host code, no device work): S is

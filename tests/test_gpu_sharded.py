@@ -300,6 +300,129 @@ def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64,
     cm.close()
 
 
+@pytest.mark.parametrize('world,kind,groups,pack_early,wire16', [
+    (1, 'zipf', 0, 1, False), (2, 'zipf', 0, 1, False), (4, 'zipf', 2, 1, False),
+    (8, 'zipf', 0, 1, False), (2, 'uniform', 0, 1, False), (8, 'uniform', 3, 1, False),
+    (4, 'zipf', 0, 0, False), (4, 'zipf', 2, 1, True), (2, 'few', 0, 1, False)])
+def test_cxx_driver_requester_dedup_in_process_world(hbk_option, world, kind, groups, pack_early,
+                                                     wire16):
+  """Requester-side dedup (hbk_sharded_column_t.dedup; the reference's tutorials: tf.unique ->
+  lookup -> tf.gather, docs/tutorial/ranking/data.py:180-182): every distinct id of a flagged
+  column goes on the wire once.  W ranks as host threads on one GPU: forward bit-equal to the
+  unsharded oracle (Zipf(1.2), uniform and three-distinct-ids batches, ragged and scalar columns,
+  deduplicated and plain columns side by side), the rows that travel are the DISTINCT ids',
+  backward == dense scatter-add with the duplicates summed on the requester, and the fused SGD
+  step leaves the shards where the dense gradient says."""
+  import threading
+  hbk_option('sharded_groups', groups)
+  hbk_option('sharded_pack_early', pack_early)
+  rng = np.random.RandomState(500 + world)
+  dims = [16, 8, 128, 4, 32]
+  rows = [50021, 211, 3000, 64, 100003]
+  combiners = ['sum', 'mean', 'sqrtn', 'sum', 'mean']
+  dedup = [True, True, True, False, True]
+  n = len(dims)
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(n)]
+
+  def draw(k, r_):
+    if kind == 'zipf':
+      return ((rng.zipf(1.2, size=k) * 7919) % (1 << 40)).astype(np.int64)
+    if kind == 'few':
+      return rng.choice(np.array([5, 12345678901, 77], np.int64), size=k)
+    return rng.randint(0, 2**40, size=k).astype(np.int64)
+  ids, splits, grads = [], [], []
+  for r in range(world):
+    rid, rsp, rg = [], [], []
+    for c in range(n):
+      if c % 2 == 0:
+        sp, k = None, int(rng.randint(0, 3000)) if c else 2500
+      else:
+        lens = rng.poisson(3, size=rng.randint(1, 400)).clip(0, 12)
+        sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        k = int(sp[-1])
+      rsp.append(sp)
+      rid.append(draw(k, rows[c]))
+      rg.append(rng.randn(k if sp is None else sp.size - 1, dims[c]).astype(np.float32))
+    ids.append(rid)
+    splits.append(rsp)
+    grads.append(rg)
+  comms = hb.distribute.Collective.local_world(world)
+  shards = [[dev(t[r::world].copy()) for t in tables] for r in range(world)]
+  results, errors = [None] * world, []
+  lr = 0.25
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        drv = ShardedGroupLookup(shards[r], comms[r], buckets=rows, combiners=combiners,
+                                 dedup=dedup, wire_dtype=torch.float16 if wire16 else None)
+        d_ids = [dev(i) for i in ids[r]]
+        d_sp = [None if s is None else dev(s) for s in splits[r]]
+        outs = drv(d_ids, d_sp)
+        slices = drv.backward([dev(g) for g in grads[r]], apply_lr=0.0)
+        torch.cuda.current_stream().synchronize()
+        first = [o.cpu().numpy().copy() for o in outs]
+        owned = [int(drv._lib.hbk_sharded_owned_ids(drv._plan(), c)) for c in range(n)]
+        # second step: grown buffers reused, this time with the fused step
+        outs = drv(d_ids, d_sp)
+        slices = drv.backward([dev(g) for g in grads[r]], apply_lr=lr)
+        torch.cuda.current_stream().synchronize()
+        results[r] = ([o.cpu().numpy() for o in outs], first,
+                      [(u.cpu().numpy()[:int(k.item())], g.cpu().numpy()[:int(k.item())])
+                       for u, g, k in slices], owned)
+        drv.close()
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((r, repr(e)))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=60)
+  assert not errors, errors
+  assert all(x is not None for x in results)
+  eff = tables
+  tol = dict(rtol=1e-5, atol=2e-5)
+  if wire16:
+    eff = [oracle.cast_f16_to_f32(oracle.cast_f32_to_f16(t)) for t in tables]
+    tol = dict(rtol=2e-3, atol=4e-3 * max(1, world // 4))
+  for r in range(world):
+    want = oracle.group_lookup_fwd(eff, ids[r], splits[r], rows, combiners)
+    for c in range(n):
+      np.testing.assert_equal(results[r][1][c], want[c])   # step 1
+      np.testing.assert_equal(results[r][0][c], want[c])   # step 2 (same tables: lr only in its backward)
+  # what the owners were asked for: distinct ids per requester where deduplicated
+  for c in range(n):
+    for owner in range(world):
+      asked = 0
+      for r in range(world):
+        b = ids[r][c] % rows[c]
+        mine = b[b % world == owner]
+        asked += np.unique(mine).size if dedup[c] else mine.size
+      assert results[owner][3][c] == asked, (c, owner)
+  for c in range(n):
+    dense = np.zeros((rows[c], dims[c]), np.float64)
+    for r in range(world):
+      sp = splits[r][c] if splits[r][c] is not None else np.arange(ids[r][c].size + 1,
+                                                                   dtype=np.int32)
+      g_id = oracle.segment_combine_grad(grads[r][c], sp, combiners[c]).astype(np.float64)
+      np.add.at(dense, ids[r][c] % rows[c], g_id)
+    got = np.zeros_like(dense)
+    for r in range(world):
+      lr_, g_ = results[r][2][c]
+      assert len(set(lr_.tolist())) == len(lr_)
+      got[lr_ * world + r] += g_
+    scale = max(1.0, float(np.abs(dense).max()))
+    np.testing.assert_allclose(got, dense, rtol=tol['rtol'], atol=tol['atol'] * scale)
+    # the fused step of the second backward
+    for r in range(world):
+      np.testing.assert_allclose(shards[r][c].cpu().numpy(),
+                                 tables[c][r::world].astype(np.float64) - lr * dense[r::world],
+                                 rtol=tol['rtol'], atol=tol['atol'] * scale * 2)
+  for cm in comms:
+    cm.close()
+
+
 # ----------------------------------------------------------------------------------
 # feature columns: one dense [batch, sum of dims] block written / differentiated in place
 def _dense_case(rng, world):

@@ -116,6 +116,14 @@ PY
          HBK_BWD_ROWSORT_POS=$pos timeout 300 tools/bin/bench_ops d 2>&1 | grep group_lookup_bwd | sed "s|^|pos=$pos  |"
          HBK_BWD_ROWSORT_POS=$pos timeout 300 tools/bin/bench_ops w 2>&1 | grep group_lookup_bwd | sed "s|^|pos=$pos  |"
        done) > $O/rsab4.log 2>&1; cut -c1-260 $O/rsab4.log;;
+    shardtest)
+      timeout 1200 python -m pytest tests/test_gpu_sharded.py tests/test_gpu_configs.py -q -m gpu -x --durations=8 > $O/shardtest.log 2>&1; echo "pytest rc=$?" >> $O/shardtest.log; tail -25 $O/shardtest.log;;
+    deduptest)
+      timeout 900 python -m pytest tests/test_gpu_sharded.py -q -m gpu -x -k "dedup" --durations=8 > $O/deduptest.log 2>&1; echo "pytest rc=$?" >> $O/deduptest.log; tail -25 $O/deduptest.log;;
+    dedupsweep)
+      timeout 900 python tools/sweep.py --big --cases k > $O/dedupsweep.log 2>&1; echo "rc=$?" >> $O/dedupsweep.log; cut -c1-400 $O/dedupsweep.log;;
+    rsab5)
+      (ab "bwd_rowsort_ratio:0,8,0,8" "b,h,c") > $O/rsab5.log 2>&1; cut -c1-260 $O/rsab5.log;;
     *) echo "unknown stage $st";;
   esac
 done

@@ -394,6 +394,41 @@ def case_sharded_world1():
   coll.close()
 
 
+def case_sharded_dedup(big):
+  """Requester-side dedup of the sharded driver on the config-4 shape (dim 128, Zipf(1.2) ids, one
+  large table), one rank through RCCL: ids / rows the step puts "on the wire" (what would cross
+  xGMI at W > 1, per rank) and the step time, without and with dedup."""
+  dim, B = 128, 65536
+  rows = [1000000] * 25 + [100000000 if big else 10000000]
+  tables = [torch.empty(r, dim, device=DEV).uniform_(-1e-3, 1e-3) for r in rows]
+  g = torch.Generator(device=DEV)
+  g.manual_seed(7)
+  nb = 4
+  batches = [[zipf_ids(B, rows[c], 1.2, g, 2654435761 % rows[c] | 1) for c in range(26)]
+             for _ in range(nb)]
+  outs = [torch.empty(B, dim, device=DEV) for _ in range(26)]
+  gouts = [torch.randn(B, dim, device=DEV) for _ in range(26)]
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+  for dedup in (False, True):
+    drv = hb.embedding.ShardedGroupLookup(tables, coll, buckets=rows, dedup=dedup)
+    bound = [drv.bind(b, None, outs) for b in batches]
+    us = timed(lambda i: drv.launch(bound[i % nb]), iters=20)
+    sent = sum(int(drv._lib.hbk_sharded_owned_ids(drv._plan(), c)) for c in range(26))
+    wire = sent * (4 + dim * 4)
+    report(f'sharded W=1 cfg4 Zipf(1.2) dim128 fwd dedup={int(dedup)}', us, 26 * B,
+           26 * B * (8 + 512 + 512), ids_on_wire=sent, wire_bytes_per_step=wire)
+
+    def fwd_step(i):
+      drv.launch(bound[i % nb])
+      drv.backward(gouts, apply_lr=0.01, emit=False)
+    us = timed(fwd_step, iters=10, warmup=3)
+    report(f'sharded W=1 cfg4 Zipf(1.2) dim128 fwd + SGD step only dedup={int(dedup)}', us,
+           26 * B, 26 * B * (8 + 512 + 512 + 512), ids_on_wire=sent,
+           wire_bytes_per_step=wire + sent * dim * 4)
+    drv.close()
+  coll.close()
+
+
 if __name__ == '__main__':
   ap = argparse.ArgumentParser()
   ap.add_argument('--cases', default='a,b,c,d,e')
@@ -403,5 +438,5 @@ if __name__ == '__main__':
   for c in args.cases.split(','):
     {'a': case_batch_sweep, 'b': case_ragged, 'c': case_backward_cfg2,
      'd': lambda: case_cfg4(args.big), 'e': case_integer, 'f': case_bwd_probe, 'g': case_sharded_world1, 'h': case_cfg5, 'i': case_dense_block,
-     'j': lambda: case_cfg4_hot_rows(args.big)}[c]()
+     'j': lambda: case_cfg4_hot_rows(args.big), 'k': lambda: case_sharded_dedup(args.big)}[c]()
     torch.cuda.empty_cache()

@@ -1297,7 +1297,8 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
       h.n_ids = t_rows[cc] >= 0 ? 0 : p->n_ids[cc];   // (0: the column was handled above)
       h.index = reinterpret_cast<const int32_t*>(p->ps[p->cur].shard_index.ptr) + ioff[cc];
       h.row_splits = p->row_splits[cc];
-      h.n_segments = p->n_seg[cc];
+      h.n_segments = t_rows[cc] >= 0 ? 0 : p->n_seg[cc];
+      if (t_rows[cc] >= 0) h.row_splits = nullptr;
       h.grad_out = grads[cc];
       h.grad_stride = grad_strides ? grad_strides[cc] : 0;
       h.grad_rows = rows_recv_base + gr.row_recv;

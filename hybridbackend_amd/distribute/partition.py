@@ -8,9 +8,13 @@ what the reference's ``Pack`` graph pass turns K independent ops into
 (``HbPartitionByModuloN``, graph/common/packing.cc:124-575): one launch group for
 all columns.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 
 from hybridbackend_amd import _lib
+from hybridbackend_amd import _marshal
 
 
 class _Workspace:
@@ -21,10 +25,12 @@ class _Workspace:
   def __init__(self):
     self._bufs = {}
 
-  def get(self, nbytes, device):
+  def get(self, nbytes, device, stream_handle=None):
     if nbytes == 0:
       return None, 0
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    if stream_handle is None:
+      stream_handle = torch.cuda.current_stream(device).cuda_stream
+    key = (device, stream_handle)
     buf = self._bufs.get(key)
     if buf is None or buf.numel() < nbytes:
       buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -35,11 +41,65 @@ class _Workspace:
 _ws = _Workspace()
 
 
+_INT_DTYPES = tuple(d for d in (torch.int32, torch.int64, getattr(torch, 'uint32', None),
+                                 getattr(torch, 'uint64', None)) if d is not None)
+_shape_plans = {}   # (n, P, lengths) -> (total, run offsets, workspace bytes): pure functions of the key
+
+
+def _partition_n_fresh(ids_list, num_partitions, modulus, stage):
+  """The functional form with tensors it has never seen (every training step): one pass over the
+  inputs, three allocations, arguments by vector arithmetic, lazy per-column views
+  (``_marshal``).  None: some input needs the detailed checks of the general path."""
+  seen = _marshal.vector_pass(ids_list, _INT_DTYPES)
+  if seen is None or num_partitions < 1:
+    return None
+  ptrs, lens, dtype = seen
+  lib = _lib.lib()
+  n = len(ids_list)
+  device = ids_list[0].device
+  key = (n, num_partitions, tuple(lens))
+  plan = _shape_plans.get(key)
+  if plan is None:
+    lens_np = np.asarray(lens, dtype=np.int64)
+    offs = np.zeros(n, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens_np)[:-1]
+    need = lib.hbk_partition_workspace_bytes(n, _lib.i64_array(lens), num_partitions)
+    if len(_shape_plans) > 256:
+      _shape_plans.clear()
+    plan = _shape_plans[key] = (int(lens_np.sum()), offs, need,
+                                np.arange(n, dtype=np.uint64) * np.uint64(4 * num_partitions))
+  total, offs, need, size_offs = plan
+  flat_out = torch.empty(total, dtype=dtype, device=device)
+  flat_idx = torch.empty(total, dtype=torch.int32, device=device)
+  sizes2d = torch.empty((n, num_partitions), dtype=torch.int32, device=device)
+  blk, addr = _marshal.arg_block(n, 5)
+  blk[0] = ptrs
+  blk[1] = lens
+  blk[2] = offs * np.uint64(flat_out.element_size()) + np.uint64(flat_out.data_ptr())
+  blk[3] = size_offs + np.uint64(sizes2d.data_ptr())
+  blk[4] = offs * np.uint64(4) + np.uint64(flat_idx.data_ptr())
+  stream = torch.cuda.current_stream(device).cuda_stream
+  ws, ws_bytes = _ws.get(need, device, stream)
+  row = n * 8
+  args = (addr, addr + row, addr + 2 * row, addr + 3 * row, addr + 4 * row,
+          ws.data_ptr() if ws is not None else None, ws_bytes, C.c_void_p(stream))
+  code = _lib.torch_dtype_code(dtype)
+  if stage == 0:
+    _lib.check(lib.hbk_partition_by_modulo_n(n, code, num_partitions, *args))
+  else:
+    _lib.check(lib.hbk_partition_by_dual_modulo_n(n, code, num_partitions, modulus, stage, *args))
+  return (_marshal.Runs(flat_out, lens), _marshal.Rows(sizes2d), _marshal.Runs(flat_idx, lens))
+
+
 def _partition_n(ids_list, num_partitions, modulus, stage, outputs=None):
   lib = _lib.lib()
   n = len(ids_list)
   if n == 0:
     return [], [], []
+  if outputs is None:
+    res = _partition_n_fresh(ids_list, num_partitions, modulus, stage)
+    if res is not None:
+      return res
   dtype = ids_list[0].dtype
   device = ids_list[0].device
   for t in ids_list:

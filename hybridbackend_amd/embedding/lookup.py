@@ -11,9 +11,11 @@ produces (hybridbackend/tensorflow/data/dataframe.py:366-376).
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from hybridbackend_amd import _lib
+from hybridbackend_amd import _marshal
 
 _COMBINERS = {None: _lib.COMBINER_MEAN,  # embedding_lookup_sparse default
               'sum': _lib.COMBINER_SUM, 'mean': _lib.COMBINER_MEAN,
@@ -63,6 +65,10 @@ class GroupLookup:
     if isinstance(hot_rows, (bool, int)):
       hot_rows = [hot_rows] * n
     self._cols = (_lib.LookupColumn * n)()
+    # the same descriptors as a numpy record array: a step's pointers / counts are written one
+    # FIELD at a time for all columns (bind), not one ctypes attribute at a time
+    self._cols_np = np.frombuffer(self._cols, dtype=np.dtype(_lib.LookupColumn)) if n else None
+    self._dims = [int(t.shape[1]) for t in self.tables]
     for c, t in enumerate(self.tables):
       col = self._cols[c]
       col.hot_rows = 1 if hot_rows[c] else 0
@@ -85,6 +91,9 @@ class GroupLookup:
     if len(ids) != n:
       raise _lib.InvalidArgumentError(
         _lib.INVALID_ARGUMENT, f'expected {n} id tensors, got {len(ids)}')
+    fast = self._bind_fresh(ids, row_splits, outs) if n else None
+    if fast is not None:
+      return fast
     if row_splits is None:
       row_splits = [None] * n
     if outs is None:
@@ -126,6 +135,64 @@ class GroupLookup:
     self._keep = (ids, row_splits, outs)
     return outs
 
+  def _bind_fresh(self, ids, row_splits, outs):
+    """bind() for the common shapes -- id vectors of one dtype, contiguous outputs (or none: one
+    allocation, lazy per-column views) -- with ONE pass over the tensors and the descriptors
+    written field by field for all columns.  None: something needs bind()'s detailed checks
+    (its error messages, row-strided output blocks, mixed id dtypes)."""
+    n = len(self.tables)
+    seen = _marshal.vector_pass(ids, (torch.int32, torch.int64))
+    if seen is None:
+      return None
+    id_ptrs, n_ids, id_dtype = seen
+    if row_splits is None:
+      row_splits = [None] * n
+      sp_ptrs, n_seg = 0, n_ids
+    else:
+      sp_ptrs, n_seg = [], []
+      for c in range(n):
+        sp = row_splits[c]
+        if sp is None:
+          sp_ptrs.append(0)
+          n_seg.append(n_ids[c])
+          continue
+        sh = sp.shape
+        if (len(sh) != 1 or sh[0] < 1 or sp.dtype is not torch.int32 or not sp.is_cuda or
+            not sp.is_contiguous()):
+          return None
+        sp_ptrs.append(sp.data_ptr())
+        n_seg.append(sh[0] - 1)
+    dims = self._dims
+    if outs is None:
+      counts = [n_seg[c] * dims[c] for c in range(n)]
+      pad = [(k + 3) // 4 * 4 for k in counts]     # every column's block on a 16-byte boundary
+      flat = torch.empty(sum(pad) + 4, dtype=torch.float32, device=self.tables[0].device)
+      base = flat.data_ptr()
+      o_ptrs, at = [], 0
+      for k in pad:
+        o_ptrs.append(base + 4 * at)
+        at += k
+      outs = _LazyOutputs(flat, pad, n_seg, dims)
+    else:
+      o_ptrs = []
+      for c in range(n):
+        o = outs[c]
+        if (o.dtype is not torch.float32 or not o.is_cuda or not o.is_contiguous() or
+            tuple(o.shape) != (n_seg[c], dims[c])):
+          return None
+        o_ptrs.append(o.data_ptr())
+      outs = list(outs)
+    rec = self._cols_np
+    rec['ids_dtype'] = _lib.INT64 if id_dtype is torch.int64 else _lib.INT32
+    rec['ids'] = id_ptrs
+    rec['n_ids'] = n_ids
+    rec['row_splits'] = sp_ptrs
+    rec['n_segments'] = n_seg
+    rec['out'] = o_ptrs
+    rec['out_stride'] = 0
+    self._keep = (ids, row_splits, outs)
+    return outs
+
   def launch(self, stream=None):
     """Enqueue the bound lookup on `stream` (a torch stream; default: current)."""
     if stream is None:
@@ -154,6 +221,29 @@ class GroupLookup:
       outs = self.bind(ids, row_splits, outs)   # (bind clears the remembered call)
     self.launch()
     return outs
+
+
+class _LazyOutputs(_marshal.collections.abc.Sequence):
+  """The per-column [segments, dim] outputs of one allocation, made when first asked for."""
+  __slots__ = ('flat', 'pad', 'n_seg', 'dims', '_views')
+
+  def __init__(self, flat, pad, n_seg, dims):
+    self.flat, self.pad, self.n_seg, self.dims, self._views = flat, pad, n_seg, dims, None
+
+  def _materialise(self):
+    if self._views is None:
+      pieces = torch.split(self.flat[:sum(self.pad)], self.pad)
+      self._views = [p[:r * d].view(r, d) for p, r, d in zip(pieces, self.n_seg, self.dims)]
+    return self._views
+
+  def __len__(self):
+    return len(self.dims)
+
+  def __getitem__(self, i):
+    return self._materialise()[i]
+
+  def __iter__(self):
+    return iter(self._materialise())
 
 
 def group_lookup(tables, ids, row_splits=None, buckets=None, combiners='sum', divisor=1,

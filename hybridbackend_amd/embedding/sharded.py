@@ -176,6 +176,9 @@ class ShardedGroupLookup:
     returned object can be launched any number of times (``launch``) at the cost of a single
     foreign call -- what a training loop with resident input batches does (bench.py)."""
     n = len(self.shards)
+    fast = self._bind_fresh(ids, row_splits, outs)
+    if fast is not None:
+      return fast
     if row_splits is None:
       row_splits = [None] * n
     n_seg = []
@@ -208,6 +211,50 @@ class ShardedGroupLookup:
       _lib.ptr_array([None if s is None else s.data_ptr() for s in row_splits]),
       _lib.i64_array(n_seg), _lib.ptr_array([o.data_ptr() for o in outs]),
       (C.c_int32 * n)(*[0 if o.is_contiguous() else int(o.stride(0)) for o in outs]))
+    return bound
+
+  def _bind_fresh(self, ids, row_splits, outs):
+    """bind() in one pass over the tensors for the common shapes (int64 id vectors, contiguous
+    caller-owned outputs); None: bind()'s detailed checks / allocations are needed."""
+    from hybridbackend_amd import _marshal
+    n = len(self.shards)
+    if outs is None or len(ids) != n or len(outs) != n:
+      return None
+    seen = _marshal.vector_pass(ids, (torch.int64,))
+    if seen is None:
+      return None
+    id_ptrs, n_ids, _ = seen
+    if row_splits is None:
+      row_splits = [None] * n
+      sp_ptrs, n_seg = [None] * n, n_ids
+    else:
+      sp_ptrs, n_seg = [], []
+      for c in range(n):
+        sp = row_splits[c]
+        if sp is None:
+          sp_ptrs.append(None)
+          n_seg.append(n_ids[c])
+          continue
+        sh = sp.shape
+        if (len(sh) != 1 or sh[0] < 1 or sp.dtype is not torch.int32 or not sp.is_cuda or
+            not sp.is_contiguous()):
+          return None
+        sp_ptrs.append(sp.data_ptr())
+        n_seg.append(sh[0] - 1)
+    dims = self.dims
+    o_ptrs = []
+    for c in range(n):
+      o = outs[c]
+      if (o.dtype is not torch.float32 or not o.is_cuda or not o.is_contiguous() or
+          tuple(o.shape) != (n_seg[c], dims[c])):
+        return None
+      o_ptrs.append(o.data_ptr())
+    bound = _BoundStep()
+    bound.shapes = [(n_seg[c], dims[c]) for c in range(n)]
+    bound.keep = (ids, row_splits, outs)
+    bound.outs = outs
+    bound.args = ((C.c_void_p * n)(*id_ptrs), (C.c_int64 * n)(*n_ids), (C.c_void_p * n)(*sp_ptrs),
+                  (C.c_int64 * n)(*n_seg), (C.c_void_p * n)(*o_ptrs), (C.c_int32 * n)())
     return bound
 
   def launch(self, bound):

@@ -3,9 +3,13 @@ hybridbackend/tensorflow/embedding/sharding.py:186 for N columns in one launch g
 (first-occurrence order, like TF)."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from hybridbackend_amd import _lib
+from hybridbackend_amd import _marshal
+
+_shape_plans = {}   # lengths -> (total, run offsets, workspace bytes)
 
 
 def unique_n(ids_list):
@@ -17,6 +21,39 @@ def unique_n(ids_list):
   if n == 0:
     return []
   dev = ids_list[0].device
+  seen = _marshal.vector_pass(ids_list, (torch.int64,))
+  if seen is not None:
+    # fresh tensors every step: one pass over the inputs, three allocations, lazy per-column views
+    ptrs, counts, _ = seen
+    key = tuple(counts)
+    plan = _shape_plans.get(key)
+    if plan is None:
+      c_np = np.asarray(counts, dtype=np.int64)
+      offs = np.zeros(n, dtype=np.uint64)
+      offs[1:] = np.cumsum(c_np)[:-1]
+      if len(_shape_plans) > 256:
+        _shape_plans.clear()
+      plan = _shape_plans[key] = (int(c_np.sum()), offs,
+                                  lib.hbk_unique_workspace_bytes(n, _lib.i64_array(counts)),
+                                  np.arange(n, dtype=np.uint64) * np.uint64(4))
+    total, offs, need, n_offs = plan
+    flat_u = torch.empty(total, dtype=torch.int64, device=dev)
+    flat_i = torch.empty(total, dtype=torch.int32, device=dev)
+    flat_n = torch.empty(n, dtype=torch.int32, device=dev)
+    blk, addr = _marshal.arg_block(n, 5)
+    blk[0] = ptrs
+    blk[1] = counts
+    blk[2] = offs * np.uint64(8) + np.uint64(flat_u.data_ptr())
+    blk[3] = offs * np.uint64(4) + np.uint64(flat_i.data_ptr())
+    blk[4] = n_offs + np.uint64(flat_n.data_ptr())
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = _workspace(max(need, 8), dev, stream)
+    row = n * 8
+    _lib.check(lib.hbk_unique_n(n, addr, addr + row, addr + 2 * row, addr + 3 * row,
+                                addr + 4 * row, C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()),
+                                C.c_void_p(stream)))
+    return _marshal.Zipped(_marshal.Runs(flat_u, counts), _marshal.Runs(flat_i, counts),
+                           _marshal.Runs(flat_n, [1] * n))
   for t in ids_list:
     _lib.require_device_tensor(t, 'ids')
     if t.dtype != torch.int64 or t.dim() != 1:
@@ -102,9 +139,11 @@ class UniqueN:
 _ws = {}
 
 
-def _workspace(nbytes, dev):
+def _workspace(nbytes, dev, stream_handle=None):
   """Grow-only scratch, one per (device, stream) like the partition op's."""
-  key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+  if stream_handle is None:
+    stream_handle = torch.cuda.current_stream(dev).cuda_stream
+  key = (dev, stream_handle)
   buf = _ws.get(key)
   if buf is None or buf.numel() < nbytes:
     buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)

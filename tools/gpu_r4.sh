@@ -124,6 +124,8 @@ PY
       timeout 900 python tools/sweep.py --big --cases k > $O/dedupsweep.log 2>&1; echo "rc=$?" >> $O/dedupsweep.log; cut -c1-400 $O/dedupsweep.log;;
     rsab5)
       (ab "bwd_rowsort_ratio:0,8,0,8" "b,h,c") > $O/rsab5.log 2>&1; cut -c1-260 $O/rsab5.log;;
+    pysweep)   # the Python forms with fresh tensors
+      timeout 900 python tools/sweep.py --cases e > $O/pysweep.log 2>&1; echo "rc=$?" >> $O/pysweep.log; cut -c1-200 $O/pysweep.log;;
     *) echo "unknown stage $st";;
   esac
 done

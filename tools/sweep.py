@@ -257,6 +257,23 @@ def case_integer():
   uplan.bind(ids)
   us = timed(lambda i: uplan.launch(), iters=10)
   report(f'UniqueN(bound) 26 x {B} int64', us, 26 * B, 26 * B * (8 + 8 + 4))
+  # the call forms handed OTHER tensors every step (a training loop's fresh batches): nothing is
+  # remembered from the call before, the whole marshalling is paid
+  tables = uniform_tables(26, 1000000, 16)
+  pool = [[torch.randint(0, 1 << 40, (B,), device=DEV) for _ in range(26)] for _ in range(8)]
+  outs = [torch.empty(B, 16, device=DEV) for _ in range(26)]
+  lookup = hb.embedding.GroupLookup(tables, [1000000] * 26, 'sum')
+  us = timed(lambda i: lookup(pool[i % 8], None, outs), iters=30)
+  report(f'GroupLookup.__call__ (new id tensors every call) 26 x {B}', us, 26 * B, 26 * B * 136)
+  us = timed(lambda i: lookup(pool[i % 8]), iters=30)
+  report(f'GroupLookup.__call__ (new ids, outputs allocated) 26 x {B}', us, 26 * B, 26 * B * 136)
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+  drv = hb.embedding.ShardedGroupLookup(tables, coll, buckets=[1000000] * 26)
+  us = timed(lambda i: drv(pool[i % 8], None, outs), iters=30)
+  report(f'ShardedGroupLookup.__call__ W=1 (new id tensors every call) 26 x {B}', us, 26 * B,
+         26 * B * 136)
+  drv.close()
+  coll.close()
 
 
 def case_bwd_probe():
@@ -339,7 +356,7 @@ def case_dense_block():
 
   def two_pass(i):
     lookup.launch()
-    torch.cat(outs, dim=1, out=block)
+    torch.cat(list(outs), dim=1, out=block)
   us = timed(two_pass, iters=30)
   report(f'26 separate outputs + concat pass, 26 cols dim16 B={B}', us, 26 * B, 26 * B * 136)
 

@@ -218,17 +218,24 @@ def i32_array(vals):
   return (C.c_int32 * len(vals))(*vals)
 
 
+_DTYPE_CODES = None
+
+
 def torch_dtype_code(dtype):
-  import torch  # pylint: disable=import-outside-toplevel
-  table = {torch.int8: INT8, torch.uint8: UINT8, torch.int32: INT32,
-           torch.int64: INT64, torch.float16: HALF, torch.float32: FLOAT,
-           torch.float64: DOUBLE}
-  for name, code in (('uint32', UINT32), ('uint64', UINT64)):
-    if hasattr(torch, name):
-      table[getattr(torch, name)] = code
-  if dtype not in table:
+  global _DTYPE_CODES
+  if _DTYPE_CODES is None:
+    import torch  # pylint: disable=import-outside-toplevel
+    table = {torch.int8: INT8, torch.uint8: UINT8, torch.int32: INT32,
+             torch.int64: INT64, torch.float16: HALF, torch.float32: FLOAT,
+             torch.float64: DOUBLE}
+    for name, code in (('uint32', UINT32), ('uint64', UINT64)):
+      if hasattr(torch, name):
+        table[getattr(torch, name)] = code
+    _DTYPE_CODES = table
+  code = _DTYPE_CODES.get(dtype)
+  if code is None:
     raise InvalidArgumentError(INVALID_ARGUMENT, f'unsupported dtype {dtype}')
-  return table[dtype]
+  return code
 
 
 def current_stream(device=None):

@@ -203,7 +203,7 @@ class ShardedGroupLookup:
           _lib.INVALID_ARGUMENT, f'output {c} must be fp32 [{n_seg[c]}, {self.dims[c]}]')
     bound = _BoundStep()
     bound.shapes = [(n_seg[c], self.dims[c]) for c in range(n)]
-    bound.keep = (ids, row_splits, outs)
+    bound.keep = (list(ids), list(row_splits), list(outs))   # (own lists: the caller may refill his)
     bound.outs = outs
     # column blocks of one wider tensor are written in place (row stride != dim)
     bound.args = (
@@ -251,7 +251,7 @@ class ShardedGroupLookup:
       o_ptrs.append(o.data_ptr())
     bound = _BoundStep()
     bound.shapes = [(n_seg[c], dims[c]) for c in range(n)]
-    bound.keep = (ids, row_splits, outs)
+    bound.keep = (list(ids), list(row_splits), list(outs))   # (own lists: the caller may refill his)
     bound.outs = outs
     bound.args = ((C.c_void_p * n)(*id_ptrs), (C.c_int64 * n)(*n_ids), (C.c_void_p * n)(*sp_ptrs),
                   (C.c_int64 * n)(*n_seg), (C.c_void_p * n)(*o_ptrs), (C.c_int32 * n)())
@@ -282,17 +282,22 @@ class ShardedGroupLookup:
     ``outs``) the marshalled arguments of that step are reused: validating and marshalling 26
     columns costs ~130 us of Python, the reuse check ~15."""
     cached = getattr(self, '_call_cache', None)
-    if cached is not None and outs is not None:
-      key, ptrs, bound = cached
-      tensors = list(ids) + [s for s in (row_splits or []) if s is not None] + list(outs)
-      if key == tuple(id(t) for t in tensors) and all(
-          t.data_ptr() == q and t.numel() == m for t, (q, m) in zip(tensors, ptrs)):
+    # (a step with OTHER tensors is told apart by its first id tensor: the full comparison -- 3 N
+    # tensors against the addresses / counts the bound step was marshalled with -- is only paid
+    # when the step may really be the one before)
+    if cached is not None and outs is not None and len(ids) and ids[0] is cached[0][0][0]:
+      (p_ids, p_splits, p_outs), bound = cached
+      a = bound.args
+      sp = row_splits if row_splits is not None else [None] * len(ids)
+      if len(ids) == len(p_ids) and all(
+          ids[c] is p_ids[c] and sp[c] is p_splits[c] and outs[c] is p_outs[c] and
+          ids[c].data_ptr() == a[0][c] and ids[c].numel() == a[1][c] and
+          (sp[c] is None or sp[c].data_ptr() == a[2][c]) and outs[c].data_ptr() == a[4][c]
+          for c in range(len(ids))):
         return self.launch(bound)
     bound = self.bind(ids, row_splits, outs)
-    if outs is not None:
-      tensors = list(ids) + [s for s in (row_splits or []) if s is not None] + list(outs)
-      self._call_cache = (tuple(id(t) for t in tensors),
-                          [(t.data_ptr(), t.numel()) for t in tensors], bound)
+    if outs is not None and len(ids):
+      self._call_cache = (bound.keep, bound)
     return self.launch(bound)
 
   # ---- backward (SURVEY 3.4) -----------------------------------------------------------------

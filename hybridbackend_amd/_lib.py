@@ -126,6 +126,7 @@ def _declare(l):
     'hbk_sharded_layout': (C.c_int, [i32, i32] + [vp] * 12),
     'hbk_sharded_create': (C.c_int, [vp, vp, i32, vp, i32]),
     'hbk_sharded_destroy': (C.c_int, [vp]),
+    'hbk_sharded_set_hot_rows': (C.c_int, [vp, vp]),
     'hbk_sharded_lookup_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     'hbk_sharded_prefetch': (C.c_int, [vp, vp, vp, vp]),
     'hbk_sharded_owned_ids': (i64, [vp, i32]),

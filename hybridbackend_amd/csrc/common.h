@@ -202,7 +202,9 @@ inline SyncWait sync_wait_of(const SyncTake& t) {
 }
 // `words` zeroed int32 (+ the call's poison word) of the stream's buffer.  `kernel` / `block` /
 // `max_column_wgs`: the waiting kernel, its workgroup size and the most workgroups of ONE column
-// that wait for each other: false when the device cannot hold them all at once (CU masks,
+// that wait for each other: false when the DEVICE cannot hold them all at once (partitioned
+// modes, fewer CUs; a per-STREAM CU mask is not visible to the occupancy query: the bounded wait is
+// what protects such a stream,
 // partitioned modes), as when the stream is being captured or a wait has run out before.
 bool sync_take(hipStream_t stream, size_t words, SyncTake* out, const void* kernel = nullptr,
                int block = 0, int max_column_wgs = 0);

@@ -17,6 +17,8 @@
 //     left to the table rows.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "lookup_common.h"
 
 namespace hbk {
@@ -477,8 +479,44 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
   }
 
   const int hot_mode = options().fwd_hot_rows;
+  // every column is classified ONCE (row shape, kernel kind); the launches then walk only the
+  // kinds that occur (the sharded owner gather passes N x W virtual columns: 17 passes over 208
+  // descriptors, each redoing the checks, were microseconds of the step's enqueue path)
+  struct Classified {
+    RowShape shape;
+    int kind;   // -1: nothing to do (no segments)
+  };
+  std::vector<Classified> cls((size_t)(n_cols > 0 ? n_cols : 1));
+  uint32_t kinds_present = 0;
+  for (int32_t c = 0; c < n_cols; ++c) {
+    const hbk_lookup_column_t& h = cols[c];
+    cls[c].kind = -1;
+    if (h.n_segments == 0) continue;
+    HBK_REQUIRE(h.out_stride == 0 || h.out_stride >= h.dim,
+                "group_lookup_fwd: out_stride %d is smaller than dim %d", h.out_stride, h.dim);
+    // a strided output keeps 16-byte chunks only if every row start stays 16-byte aligned
+    // (a half buffer is held to 8 bytes where an fp32 one is held to 16: its address counts
+    // twice in the alignment test; a row stride must be a multiple of 4 elements either way)
+    const uintptr_t table_bits = (uintptr_t)h.table * (h.half_io == HBK_LOOKUP_TABLE_HALF ? 2 : 1);
+    const uintptr_t out_bits = (uintptr_t)h.out * (h.half_io == HBK_LOOKUP_OUT_HALF ? 2 : 1) |
+                               ((uintptr_t)(uint32_t)h.out_stride * 4);
+    HBK_REQUIRE(make_rowshape(h.dim, table_bits | out_bits, &cls[c].shape),
+                "group_lookup_fwd: dim %d needs more than 64 lanes per row "
+                "(unaligned or dim %% 4 != 0 with dim > 64 is unsupported)", h.dim);
+    const RowShape& shape = cls[c].shape;
+    int col_kind = (h.row_splits != nullptr ? 1 : 0) | (shape.vec4 ? 0 : 2) |
+                   (h.n_runs > 0 ? 4 : 0);
+    // one id per segment, plain table, wide 16-byte-chunk rows: the hot-row kernel when asked
+    if (h.half_io != 0) col_kind |= 16;
+    if (col_kind == 0 && (hot_mode > 0 || h.hot_rows != 0) && h.dim >= 64 && shape.lpr_log2 <= 6 &&
+        h.dim <= kHotStageFloats && h.rows < 0xffffffffll) {
+      col_kind = 8;
+    }
+    cls[c].kind = col_kind;
+    kinds_present |= 1u << col_kind;
+  }
   for (int kind = 0; kind < 24; ++kind) {
-    if (kind > 8 && kind < 16) continue;
+    if (((kinds_present >> kind) & 1u) == 0u) continue;
     int32_t c0 = 0;
     while (c0 < n_cols) {
       LookupArgs args;
@@ -490,30 +528,11 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
       int64_t small_lookups = 0, all_lookups = 0;   // (tables of <= 2 MB: see args.xcd below)
       args.tile_start[0] = 0;
       while (c0 < n_cols && k < kMaxColsPerLaunch) {
-        const hbk_lookup_column_t& h = cols[c0++];
-        if (h.n_segments == 0) continue;
-        RowShape shape;
-        HBK_REQUIRE(h.out_stride == 0 || h.out_stride >= h.dim,
-                    "group_lookup_fwd: out_stride %d is smaller than dim %d", h.out_stride,
-                    h.dim);
-        // a strided output keeps 16-byte chunks only if every row start stays 16-byte aligned
-        // (a half buffer is held to 8 bytes where an fp32 one is held to 16: its address counts
-        // twice in the alignment test; a row stride must be a multiple of 4 elements either way)
-        const uintptr_t table_bits = (uintptr_t)h.table * (h.half_io == HBK_LOOKUP_TABLE_HALF ? 2 : 1);
-        const uintptr_t out_bits = (uintptr_t)h.out * (h.half_io == HBK_LOOKUP_OUT_HALF ? 2 : 1) |
-                                   ((uintptr_t)(uint32_t)h.out_stride * 4);
-        HBK_REQUIRE(make_rowshape(h.dim, table_bits | out_bits, &shape),
-                    "group_lookup_fwd: dim %d needs more than 64 lanes per row "
-                    "(unaligned or dim %% 4 != 0 with dim > 64 is unsupported)", h.dim);
-        int col_kind = (h.row_splits != nullptr ? 1 : 0) | (shape.vec4 ? 0 : 2) |
-                       (h.n_runs > 0 ? 4 : 0);
-        // one id per segment, plain table, wide 16-byte-chunk rows: the hot-row kernel when asked
-        if (h.half_io != 0) col_kind |= 16;
-        if (col_kind == 0 && (hot_mode > 0 || h.hot_rows != 0) && h.dim >= 64 && shape.lpr_log2 <= 6 &&
-            h.dim <= kHotStageFloats && h.rows < 0xffffffffll) {
-          col_kind = 8;
-        }
-        if (col_kind != kind) continue;
+        const int32_t ci = c0++;
+        if (cls[ci].kind != kind) continue;
+        const hbk_lookup_column_t& h = cols[ci];
+        const RowShape& shape = cls[ci].shape;
+        const int col_kind = kind;
         ColArg& d = args.col[k];
         d.table = h.table;
         d.ids = h.ids;

@@ -73,6 +73,9 @@ int partition_host(const char* what, int32_t n_cols, int32_t dtype, int32_t P, i
     HBK_REQUIRE(sizes[c] != nullptr, "%s: sizes[%d] is NULL", what, c);
     HBK_REQUIRE(lens[c] == 0 || (inputs[c] && outputs[c] && indices[c]),
                 "%s: NULL buffer for input %d", what, c);
+  }
+  // (everything is checked before anything is written: an error leaves no column half done)
+  for (int32_t c = 0; c < n_cols; ++c) {
     switch (dtype) {
       case HBK_INT32:
         partition_column<int32_t>((const int32_t*)inputs[c], lens[c], P, modulus, stage,

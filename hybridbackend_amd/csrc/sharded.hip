@@ -1362,6 +1362,15 @@ extern "C" int hbk_sharded_lookup_bwd_apply(hbk_sharded_t p, const float* const*
   return HBK_OK;
 }
 
+// the per-column hot_rows hints of a live plan (hbk_sharded_column_t.hot_rows): the host side turns
+// them on / off from what the last backward saw (distinct rows vs ids); read by the next forward
+extern "C" int hbk_sharded_set_hot_rows(hbk_sharded_t p, const int32_t* hot_rows) {
+  using namespace hbk;
+  HBK_REQUIRE(p != nullptr && hot_rows != nullptr, "sharded_set_hot_rows: NULL argument");
+  for (int c = 0; c < p->N; ++c) p->cols[c].hot_rows = hot_rows[c] != 0 ? 1 : 0;
+  return HBK_OK;
+}
+
 // host-side phases of the last forward (us): enqueueing partition + size exchange, the wait for
 // the sizes (the device finishing the partition, not host work), enqueueing everything else
 extern "C" int hbk_sharded_last_host_us(hbk_sharded_t p, float* out3) {

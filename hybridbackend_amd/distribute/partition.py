@@ -196,7 +196,7 @@ class PartitionByModuloN:
   input batches refilled in place): ``bind`` validates the tensors, allocates the three output
   tensors and the workspace and marshals the C-ABI arguments ONCE; ``launch`` is one foreign call
   (the functional ``partition_by_modulo_n`` spends ~50 us in Python per call on 26 columns, the
-  kernel 15 us).  ``plan(ids_list)`` re-binds only when it is handed other tensors.
+  kernel 15 us).  calling the object (``__call__(ids_list)``) re-binds only when it is handed other tensors.
 
   Args: as ``partition_by_modulo_n`` / ``partition_by_dual_modulo_n`` (``stage`` 0 = plain).
   '''

@@ -43,7 +43,13 @@ class GroupLookup:
     hot_rows: skewed ids expected (Zipf heads): wide one-id-per-sample columns (dim >= 64) fetch
       every row repeated inside a 256-sample tile once and serve the repeats from LDS -- the
       forward's counterpart of the reference's slab cache in front of the table
-      (hbtf/embedding/lookup_functors.cu.cc:54-149).  One bool for all columns or one per column.
+      (hbtf/embedding/lookup_functors.cu.cc:54-149).  One bool for all columns or one per column;
+      ``'auto'``: the column starts without and follows the data -- every backward of a
+      ``GroupLookupGrad`` over this lookup leaves the number of distinct rows of the step on the
+      device; it is copied to pinned memory behind the backward (no host wait) and the next
+      forward that finds the copy landed turns the staging on for the columns whose last batch
+      named fewer than half as many distinct rows as ids, off for the others (the reference's
+      cache in front of the table is switched by the user, service.py:87; here the engine looks).
   """
 
   def __init__(self, tables, buckets=None, combiners='sum', divisor=1, hot_rows=False):
@@ -62,8 +68,11 @@ class GroupLookup:
     self.buckets = [int(b or 0) for b in buckets]
     self.combiners = [_combiner_code(c) for c in combiners]
     self.divisor = int(divisor)
-    if isinstance(hot_rows, (bool, int)):
+    if isinstance(hot_rows, (bool, int, str)):
       hot_rows = [hot_rows] * n
+    self._auto_hot = [c for c in range(n) if hot_rows[c] == 'auto']
+    hot_rows = [False if h == 'auto' else h for h in hot_rows]
+    self._auto_state = None   # (pinned counts, event, ids per column) of the last backward
     self._cols = (_lib.LookupColumn * n)()
     # the same descriptors as a numpy record array: a step's pointers / counts are written one
     # FIELD at a time for all columns (bind), not one ctypes attribute at a time
@@ -193,8 +202,35 @@ class GroupLookup:
     self._keep = (ids, row_splits, outs)
     return outs
 
+  # ---- hot rows by observation (hot_rows='auto') ----------------------------------------------
+  def note_backward(self, n_unique, n_ids):
+    """Called by GroupLookupGrad behind a backward: `n_unique` (device int32 [N]) holds the
+    distinct rows of every column's batch once the stream gets there, `n_ids` the ids."""
+    if not self._auto_hot:
+      return
+    st = self._auto_state
+    if st is None or st[0].numel() != n_unique.numel():
+      st = self._auto_state = [torch.empty(n_unique.numel(), dtype=torch.int32).pin_memory(),
+                               torch.cuda.Event(), None, False]
+    st[0].copy_(n_unique, non_blocking=True)
+    st[1].record()
+    st[2] = list(n_ids)
+    st[3] = True
+
+  def _poll_auto_hot(self):
+    st = self._auto_state
+    if st is None or not st[3] or not st[1].query():
+      return
+    st[3] = False
+    counts = st[0].tolist()
+    for c in self._auto_hot:
+      n = st[2][c]
+      self._cols[c].hot_rows = 1 if n > 0 and 2 * counts[c] < n else 0
+
   def launch(self, stream=None):
     """Enqueue the bound lookup on `stream` (a torch stream; default: current)."""
+    if self._auto_state is not None:
+      self._poll_auto_hot()
     if stream is None:
       s = _lib.current_stream(self.tables[0].device if self.tables else None)
     else:
@@ -375,4 +411,6 @@ class GroupLookupGrad:
       n, self._cols, _lib.APPLY_ADAGRAD if optimizer == 'adagrad' else _lib.APPLY_SGD,
       C.c_float(apply_lr), C.c_void_p(self._ws.data_ptr()),
       C.c_size_t(self._ws.numel()), _lib.current_stream(dev)))
+    if self.lookup._auto_hot:
+      self.lookup.note_backward(self._nu, [int(i.numel()) for i in ids])
     return list(self._views)

@@ -83,8 +83,12 @@ class ShardedGroupLookup:
     self.wire_dtype = wire_dtype
     self.device = self.shards[0].device if n else None
     self.dims = [int(t.shape[1]) for t in self.shards]
-    self.hot_rows = [bool(hot_rows)] * n if isinstance(hot_rows, (bool, int)) else \
-        [bool(h) for h in hot_rows]
+    if isinstance(hot_rows, (bool, int, str)):
+      hot_rows = [hot_rows] * n
+    # 'auto': off until a backward has shown how many distinct rows the owner was asked for
+    self._auto_hot = [c for c in range(n) if hot_rows[c] == 'auto']
+    self._auto_state = None
+    self.hot_rows = [False if h == 'auto' else bool(h) for h in hot_rows]
     self.dedup = [bool(dedup)] * n if isinstance(dedup, (bool, int)) else [bool(d) for d in dedup]
     self._setup()
 
@@ -261,6 +265,16 @@ class ShardedGroupLookup:
     """Enqueue a bound step on the current stream; returns its outputs."""
     self._keep = bound.keep
     self._last_shapes = bound.shapes   # what backward() differentiates
+    st = self._auto_state
+    if st is not None and st[3] and st[1].query():
+      # the last backward's counts have landed: distinct local rows < half the ids asked for ->
+      # the owner gather stages repeated rows in LDS from this step on (and stops when not)
+      st[3] = False
+      counts = st[0].tolist()
+      for c in self._auto_hot:
+        self.hot_rows[c] = st[2][c] > 0 and 2 * counts[c] < st[2][c]
+      _lib.check(self._lib.hbk_sharded_set_hot_rows(
+        self._plan(), (C.c_int32 * len(self.hot_rows))(*[int(h) for h in self.hot_rows])))
     _lib.check(self._lib.hbk_sharded_lookup_fwd(
       self._plan(), *bound.args, _lib.current_stream(self.device)))
     return bound.outs
@@ -353,6 +367,10 @@ class ShardedGroupLookup:
       raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, "optimizer must be 'sgd' or 'adagrad'")
     res = []
     shapes = getattr(self, '_last_shapes', None)
+    auto = bool(self._auto_hot) and outs is None
+    if auto and getattr(self, '_nu_all', None) is None:
+      self._nu_all = torch.zeros(n, dtype=torch.int32, device=self.device)
+    owned = []
     for c in range(n):
       _lib.require_device_tensor(grads[c], 'grads', row_strided=True)
       if grads[c].dtype != torch.float32 or (
@@ -364,6 +382,7 @@ class ShardedGroupLookup:
       k = int(self._lib.hbk_sharded_owned_ids(plan, c))
       if k < 0:
         raise _lib.HbkError(_lib.INTERNAL, 'backward() needs a forward step first')
+      owned.append(k)
       if outs is not None:
         # caller-owned (unique_rows, grad_rows, n_unique) with capacity >= owned ids
         if outs[c][0].numel() < k or outs[c][1].numel() < k * self.dims[c]:
@@ -375,10 +394,11 @@ class ShardedGroupLookup:
         # the counts live in one buffer of the driver, written by every call
         if getattr(self, '_nu_step', None) is None:
           self._nu_step = torch.zeros(n, dtype=torch.int32, device=self.device)
-        res.append((None, None, self._nu_step[c:c + 1]))
+        res.append((None, None, (self._nu_all if auto else self._nu_step)[c:c + 1]))
         continue
       res.append((torch.empty(k, dtype=torch.int64, device=self.device),
                   torch.empty((k, self.dims[c]), dtype=torch.float32, device=self.device),
+                  self._nu_all[c:c + 1] if auto else
                   torch.zeros(1, dtype=torch.int32, device=self.device)))
     self._keep_bwd = (grads, res)
     strides = (C.c_int32 * n)(*[0 if g.is_contiguous() else int(g.stride(0)) for g in grads])
@@ -391,4 +411,12 @@ class ShardedGroupLookup:
       _lib.ptr_array([r[0].data_ptr() for r in res]) if emit else None,
       _lib.ptr_array([r[1].data_ptr() for r in res]) if emit else None,
       _lib.ptr_array([r[2].data_ptr() for r in res]), _lib.current_stream(self.device)))
+    if auto:
+      st = self._auto_state
+      if st is None:
+        st = self._auto_state = [torch.empty(n, dtype=torch.int32).pin_memory(),
+                                 torch.cuda.Event(), None, False]
+      st[0].copy_(self._nu_all, non_blocking=True)
+      st[1].record()
+      st[2], st[3] = owned, True
     return res

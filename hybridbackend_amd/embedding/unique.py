@@ -86,7 +86,7 @@ def unique_n(ids_list):
 
 class UniqueN:
   """A bound ``unique_n`` for loops over the same id buffers: outputs, workspace and the C-ABI
-  arguments are set up once by ``bind``; ``launch`` is one foreign call; ``plan(ids_list)``
+  arguments are set up once by ``bind``; ``launch`` is one foreign call; calling the object (``__call__(ids_list)``)
   re-binds only when it is handed other tensors.  Returns what ``unique_n`` returns."""
 
   def __init__(self):

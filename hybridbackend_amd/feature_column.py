@@ -23,15 +23,19 @@ class EmbeddingColumn:
   dimension, combiner)``: ids are bucketized with floor-mod ``num_buckets``
   (docs/tutorial/ranking/data.py:179,186).  ``hot_rows``: the ids are skewed (Zipf heads) --
   a wide column (dimension >= 64, one id per sample) then fetches the rows repeated inside a
-  256-sample tile once and serves the repeats from LDS (GroupLookup(hot_rows=))."""
+  256-sample tile once and serves the repeats from LDS (GroupLookup(hot_rows=)).  The default
+  ``'auto'`` lets the layer decide per column from what the last backward saw (distinct rows <
+  half the ids: on); True / False pin it.  ``dedup``: a sharded column sends every distinct id of
+  a batch once (ShardedGroupLookup(dedup=); the tutorials' tf.unique in front of the lookup)."""
 
-  def __init__(self, key, num_buckets, dimension, combiner='mean', hot_rows=False):
+  def __init__(self, key, num_buckets, dimension, combiner='mean', hot_rows='auto', dedup=False):
     if num_buckets < 1 or dimension < 1:
       raise _lib.InvalidArgumentError(
         _lib.INVALID_ARGUMENT, 'num_buckets and dimension must be >= 1')
     self.key, self.num_buckets, self.dimension = key, int(num_buckets), int(dimension)
     self.combiner = combiner
-    self.hot_rows = bool(hot_rows)
+    self.hot_rows = 'auto' if hot_rows == 'auto' else bool(hot_rows)
+    self.dedup = bool(dedup)
 
 
 class DenseFeatures:
@@ -90,6 +94,7 @@ class DenseFeatures:
                                          buckets=[self.columns[c].num_buckets for c in self._shd],
                                          combiners=[self.columns[c].combiner for c in self._shd],
                                          hot_rows=[self.columns[c].hot_rows for c in self._shd],
+                                         dedup=[self.columns[c].dedup for c in self._shd],
                                          accums=(pick(self._shd, self.accums)
                                                  if self.accums is not None else None))
 

@@ -126,9 +126,10 @@ class Saver:
 
   def _merge(self, prefix, tmp_dir):
     """Crash safety: the data files of a save carry a generation tag in their names, so they
-    never overwrite the files an existing index points to; the index is written to a temporary
-    file and moved into place LAST (one atomic rename switches the checkpoint over), and only
-    then are the previous generation's data files removed."""
+    never overwrite the files an existing index points to; every data file and the directory are
+    fsync'ed, THEN the index is written to a temporary file, fsync'ed and moved into place (one
+    atomic rename switches the checkpoint over; the directory is fsync'ed again).  The generation
+    that was just replaced is kept until the next save."""
     index = {'format': 'hbk-sharded-checkpoint-1', 'world_size': self.world_size, 'variables': {}}
     folder = os.path.dirname(prefix) or '.'
     base = os.path.basename(prefix)
@@ -146,6 +147,7 @@ class Saver:
       part = os.path.join(tmp_dir, f'part-{r:05d}-of-{self.world_size:05d}')
       data = f'{base}.data-g{gen}-{r:05d}-of-{self.world_size:05d}'
       os.replace(part + '.data', os.path.join(folder, data))
+      _fsync_path(os.path.join(folder, data))   # durable BEFORE the index that names it
       for e in json.load(open(part + '.json')):
         var = index['variables'].setdefault(
           e['name'], {'dtype': e['dtype'], 'slices': [],
@@ -158,12 +160,18 @@ class Saver:
       json.dump(index, f, indent=1, sort_keys=True)
       f.flush()
       os.fsync(f.fileno())
+    _fsync_path(folder)                      # the new data files' directory entries
     os.replace(prefix + '.index.tmp', prefix + '.index')
-    for name in old_files:
-      try:
-        os.remove(os.path.join(folder, name))
-      except OSError:
-        pass
+    _fsync_path(folder)                      # the switch-over itself
+    # The generation just replaced STAYS until the next save (a reader that has the old index
+    # open still finds its data files); what goes now are the generations before it.
+    new_files = {sl['file'] for v in index['variables'].values() for sl in v['slices']}
+    for name in os.listdir(folder):
+      if name.startswith(base + '.data-g') and name not in old_files and name not in new_files:
+        try:
+          os.remove(os.path.join(folder, name))
+        except OSError:
+          pass
     shutil.rmtree(tmp_dir, ignore_errors=True)    # delete_old_dirs=True
 
   # -- restore ---------------------------------------------------------------------------------
@@ -241,9 +249,20 @@ def _concatenated(prefix, meta):
   return np.concatenate([np.asarray(_load_slice(prefix, meta, s)) for s in parts], axis=0)
 
 
+def _fsync_path(path):
+  """fsync a file or a directory by path (directories: so that renames / new entries are durable)."""
+  fd = os.open(path, os.O_RDONLY)
+  try:
+    os.fsync(fd)
+  finally:
+    os.close(fd)
+
+
 def load_full(prefix, name, layout='logical'):
   """The whole variable as a numpy array: the logical table (rows de-interleaved) or, with
-  ``layout='reference'``, the concatenation a reference checkpoint calls the full tensor."""
+  ``layout='reference'``, the concatenation a reference checkpoint calls the full tensor.
+  bfloat16 variables come back as their int16 BIT PATTERNS (numpy has no bfloat16):
+  ``torch.from_numpy(a).view(torch.bfloat16)`` gives the values."""
   meta = _read_index(prefix)['variables'][name]
   if layout == 'reference' or all(s['stride'] == 1 for s in meta['slices']):
     return _concatenated(prefix, meta)

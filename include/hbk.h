@@ -86,7 +86,8 @@ const char* hbk_version(void);
  * sharded step in the call that suffered it (it synchronises anyway), else by the next call of
  * these entries or by hbk_sync_check() -- after which the library takes the multi-launch forms
  * (sync_onepass_off = 1; writable).  The one-launch forms are also not taken when the device
- * cannot hold a whole column's workgroups at once (CU masks, partitioned modes).  The words the
+ * cannot hold a whole column's workgroups at once (partitioned modes, small devices; a CU mask set
+ * on one stream is not seen by the occupancy query -- there the bounded wait applies).  The words the
  * tiles poll live in buffers the library keeps per (device, stream): calls that share a stream
  * are ordered, which is all these entries ask of the caller. */
 int hbk_set_option(const char* name, int32_t value);
@@ -499,6 +500,10 @@ int hbk_sharded_layout(int32_t n_cols, int32_t world, const int32_t* dims, const
 typedef struct hbk_sharded* hbk_sharded_t;
 int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t n_cols,
                        const hbk_sharded_column_t* cols, int32_t wire_dtype);
+/* Replaces the hot_rows hints of the plan's columns (hbk_sharded_column_t.hot_rows, [n_cols]);
+ * the next forward reads them.  (The host side derives them from the distinct rows / ids of the
+ * last backward: hybridbackend_amd/embedding/sharded.py.) */
+int hbk_sharded_set_hot_rows(hbk_sharded_t plan, const int32_t* hot_rows);
 int hbk_sharded_destroy(hbk_sharded_t plan);
 /* out_strides / grad_strides: NULL, or per column the row stride in floats of outs[c] /
  * grads[c] (0 = dim): the columns' blocks of one concatenated [segments, sum of dims] tensor. */

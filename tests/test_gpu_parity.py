@@ -515,6 +515,39 @@ def test_group_lookup_call_cache_follows_bind_and_split_positions():
   np.testing.assert_allclose(host(o2[1]), np.stack([t1[0:2].sum(0), t1[2:6].sum(0)]), rtol=1e-6)
 
 
+def test_group_lookup_hot_rows_follow_the_data():
+  """hot_rows='auto': the staging of repeated rows (wide one-id-per-sample columns) is switched by
+  what the last backward saw -- distinct rows < half the ids: on -- and the outputs are the same
+  bits in either mode; flipping the id distribution mid-run flips the mode back."""
+  rng = np.random.RandomState(77)
+  rows, batch = 5000, 6000
+  tables = [rng.uniform(-1, 1, size=(rows, d)).astype(np.float32) for d in (128, 64, 16)]
+  lookup = hb.embedding.GroupLookup([dev(t) for t in tables], None, 'sum', hot_rows='auto')
+  grad = hb.embedding.GroupLookupGrad(lookup)
+  skew = [(rng.zipf(1.3, size=batch) % rows).astype(np.int64) for _ in tables]
+  flat = [rng.randint(0, rows, size=batch).astype(np.int64) for _ in tables]
+  gouts = [dev(rng.randn(batch, t.shape[1]).astype(np.float32)) for t in tables]
+
+  def forward(ids):
+    outs = lookup([dev(i) for i in ids])
+    torch.cuda.synchronize()
+    for o, t, i in zip(outs, tables, ids):
+      np.testing.assert_equal(host(o), t[i])
+  assert [lookup._cols[c].hot_rows for c in range(3)] == [0, 0, 0]
+  forward(skew)                                  # nothing observed yet: per-wave gather
+  grad([dev(i) for i in skew], gouts)
+  torch.cuda.synchronize()                       # (a training loop never waits: the next forward
+  forward(skew)                                  #  that finds the counts landed acts on them)
+  assert [lookup._cols[c].hot_rows for c in range(3)] == [1, 1, 1]   # Zipf(1.3): few distinct rows
+  forward(flat)                                  # still staged: same bits
+  grad([dev(i) for i in flat], gouts)
+  torch.cuda.synchronize()
+  forward(flat)
+  assert [lookup._cols[c].hot_rows for c in range(3)] == [0, 0, 0]   # ~70 % distinct: off again
+  pinned = hb.embedding.GroupLookup([dev(t) for t in tables], None, 'sum', hot_rows=True)
+  assert pinned._auto_hot == [] and pinned._cols[0].hot_rows == 1
+
+
 # ----------------------------------------------------------------------------------
 # R10 backward
 def _check_slices(res, rows, grads, splits, combiner, distinct=True, atol=1e-6):

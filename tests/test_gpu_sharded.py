@@ -124,6 +124,42 @@ def test_sharded_call_through_rccl_world1(hbk_option, groups, inline):
     coll.close()
 
 
+def test_sharded_hot_rows_follow_the_data_world1():
+  """ShardedGroupLookup(hot_rows='auto') through RCCL at world size 1: the owner gather's hot-row
+  staging follows the distinct rows / ids of the last backward; outputs stay bit-exact."""
+  rng = np.random.RandomState(17)
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+  try:
+    rows, batch = 4000, 5000
+    tables = [rng.uniform(-1, 1, size=(rows, d)).astype(np.float32) for d in (128, 16)]
+    drv = ShardedGroupLookup([dev(t) for t in tables], coll, buckets=[rows] * 2, hot_rows='auto')
+    skew = [(rng.zipf(1.3, size=batch) % rows).astype(np.int64) for _ in tables]
+    flat = [rng.randint(0, rows, size=batch).astype(np.int64) for _ in tables]
+    g = [dev(rng.randn(batch, t.shape[1]).astype(np.float32)) for t in tables]
+
+    def forward(ids):
+      outs = drv([dev(i) for i in ids])
+      torch.cuda.synchronize()
+      for o, t, i in zip(outs, tables, ids):
+        np.testing.assert_equal(o.cpu().numpy(), t[i])
+    forward(skew)
+    assert drv.hot_rows == [False, False]
+    drv.backward(g)
+    torch.cuda.synchronize()
+    forward(skew)
+    assert drv.hot_rows == [True, True]
+    drv.backward(g)
+    torch.cuda.synchronize()
+    forward(flat)
+    drv.backward(g)
+    torch.cuda.synchronize()
+    forward(flat)
+    assert drv.hot_rows == [False, False]
+    drv.close()
+  finally:
+    coll.close()
+
+
 @pytest.mark.parametrize('world', [1, 2, 8])
 def test_sharded_backward_equals_dense_scatter(world):
   rng = np.random.RandomState(200 + world)

@@ -126,6 +126,14 @@ PY
       (ab "bwd_rowsort_ratio:0,8,0,8" "b,h,c") > $O/rsab5.log 2>&1; cut -c1-260 $O/rsab5.log;;
     pysweep)   # the Python forms with fresh tensors
       timeout 900 python tools/sweep.py --cases e > $O/pysweep.log 2>&1; echo "rc=$?" >> $O/pysweep.log; cut -c1-200 $O/pysweep.log;;
+    traffic)   # profiles/hbm_traffic.json of this round (bench.py's roofline.traffic)
+      timeout 900 python tools/hbm_traffic.py r04 $O/hbm_traffic.json > $O/traffic.log 2>&1; echo "rc=$?" >> $O/traffic.log; tail -3 $O/traffic.log | cut -c1-600;;
+    bitmap)
+      timeout 120 tools/bin/bitmap_probe > $O/bitmap_probe.log 2>&1; cat $O/bitmap_probe.log;;
+    benchsharded)
+      timeout 600 python bench.py --gpus 1 --sharded --steps 30 --warmup 5 --cpu-seconds 0 2>/dev/null | grep "^{" > $O/bench_sharded.jsonl; cut -c1-1500 $O/bench_sharded.jsonl;;
+    hottest)
+      timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sharded.py -q -m gpu -x -k "follow_the_data or hot_row or call_cache" --durations=5 > $O/hottest.log 2>&1; echo "pytest rc=$?" >> $O/hottest.log; tail -15 $O/hottest.log;;
     *) echo "unknown stage $st";;
   esac
 done

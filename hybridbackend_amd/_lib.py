@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libhbk_core.so')
+# (HBK_LIBRARY: another build of the same library -- the probe builds of tools/scratch/*.sh; the
+# default is the in-tree one, and either way a missing file is an ImportError, never a fallback)
+LIB_PATH = os.environ.get('HBK_LIBRARY') or os.path.join(_HERE, 'lib', 'libhbk_core.so')
 
 # dtype codes of include/hbk.h
 INT8, UINT8, INT32, UINT32, INT64, UINT64, HALF, FLOAT, DOUBLE = range(9)

@@ -531,8 +531,11 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   }
 }
 
+#ifndef HBK_RS_LB2
+#define HBK_RS_LB2 4   // workgroups per CU the Adagrad instantiation is compiled for
+#endif
 template <typename V, int STEP>
-__global__ __launch_bounds__(kBlock, 4) void bwd_rowsort_kernel(const GArgs a, const int4* desc,
+__global__ __launch_bounds__(kBlock, STEP == 2 ? HBK_RS_LB2 : 4) void bwd_rowsort_kernel(const GArgs a, const int4* desc,
                                                                int slot0, int total,
                                                                const int32_t* poison) {
   __shared__ RsLds lds;

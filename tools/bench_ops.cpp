@@ -446,6 +446,10 @@ int main(int argc, char** argv) {
     bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 8", 26, 65536, 8, HBK_INT64);
     return 0;
   }
+  if (argc > 1 && argv[1][0] == 'P') {  // the 64-way partition only
+    bench_partition<int64_t>("partition_by_modulo_n 26 x 65536 int64, P = 64", 26, 65536, 64, HBK_INT64);
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'c') {  // "cache": the slab-cache lookup only
     bench_probe(26 * 65536, 1 << 16, 32);
     return 0;

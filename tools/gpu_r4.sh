@@ -134,6 +134,88 @@ PY
       timeout 600 python bench.py --gpus 1 --sharded --steps 30 --warmup 5 --cpu-seconds 0 2>/dev/null | grep "^{" > $O/bench_sharded.jsonl; cut -c1-1500 $O/bench_sharded.jsonl;;
     hottest)
       timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sharded.py -q -m gpu -x -k "follow_the_data or hot_row or call_cache" --durations=5 > $O/hottest.log 2>&1; echo "pytest rc=$?" >> $O/hottest.log; tail -15 $O/hottest.log;;
+    adavar)   # probe builds of the Adagrad walk on the config-5 shape (two passes each)
+      (for rep in 1 2; do for v in tools/bin/v_*; do
+         HBK_LIBRARY=$R/$v/libhbk_core.so timeout 600 python tools/sweep.py --cases h 2>/dev/null | grep "^{" | python -c "
+import sys,json
+for l in sys.stdin:
+  d=json.loads(l); print('$(basename $v)'.ljust(14), d['case'][:60].ljust(60), d['us'])"
+       done; done) > $O/adavar.log 2>&1; cat $O/adavar.log;;
+    intpmc)   # what bounds the integer ops: SQ / TCC counters of partition (reference shape, 26 x 65536 at P = 8 / 64) and unique
+      export HBK_BENCH_ITERS=3
+      for w in q p P u; do
+        prof pmc_int_${w}_1 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" -- $R/tools/bin/bench_ops $w
+        prof pmc_int_${w}_2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" -- $R/tools/bin/bench_ops $w
+        prof pmc_int_${w}_3 "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum" -- $R/tools/bin/bench_ops $w
+        prof prof_int_${w} "" -- $R/tools/bin/bench_ops $w
+      done
+      unset HBK_BENCH_ITERS
+      python - $O > $O/r04_integer_counters.txt <<'PY'
+import json,sys,os
+O=sys.argv[1]
+names={'q':'partition, reference benchmark shape (100 x 100000 int32, P = 8)','p':'partition 26 x 65536 int64, P = 8 (one launch)','P':'partition 26 x 65536 int64, P = 64','u':'unique 26 x 65536 int64'}
+print("SQ / TCC counters (mean per launch; one --pmc pass per group, kernel-trace only) and kernel durations of the integer ops, tools/bin/bench_ops <q|p|P|u>")
+for w,title in names.items():
+  print("==", title)
+  rows={}
+  for k in (1,2,3):
+    f=f'{O}/pmc_int_{w}_{k}.json'
+    if not os.path.exists(f): continue
+    for kern,v in json.load(open(f)).items():
+      if kern.startswith('hbk::') or 'hbk::' in kern: rows.setdefault(kern[:70],{}).update({c:round(x['mean']) for c,x in v.items()})
+  for kern,v in sorted(rows.items()): print(' ',kern.ljust(70), v)
+  t=f'{O}/prof_int_{w}.txt'
+  if os.path.exists(t):
+    for l in open(t):
+      if 'hbk::' in l or l.startswith('kernel'): print('  ',l.rstrip()[:150])
+PY
+      cat $O/r04_integer_counters.txt | cut -c1-330;;
+    final)   # the round's evidence, copied to profiles/r04_* afterwards
+      prof prof_bench "" -- python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0
+      cp $O/prof_bench.txt $O/r04_bench_kernel_stats.txt
+      find $O/prof_bench -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r04_bench_rocprofv3_kernel_stats.csv
+      timeout 600 python bench.py --steps 50 --warmup 10 2>/dev/null | grep "^{" > $O/r04_bench_lines.jsonl
+      for w in fp32 fp16; do
+        timeout 300 python bench.py --gpus 1 --sharded --wire $w --steps 30 --warmup 5 --cpu-seconds 0 2>/dev/null | grep "^{" >> $O/r04_bench_lines.jsonl
+      done
+      timeout 300 tools/bin/bench_ops > $O/r04_bench_ops.txt 2>&1
+      for ratio in 8 0; do for w in R r d; do HBK_BWD_ROWSORT_RATIO=$ratio timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk " | sed "s/^/bwd_rowsort_ratio=$ratio  /"; done; done >> $O/r04_bench_ops.txt
+      prof prof_bwd "" -- $R/tools/bin/bench_ops b
+      prof prof_bwd_step "" -- $R/tools/bin/bench_ops s
+      (echo "== config-2 backward, C ABI (tools/bin/bench_ops b): row-sorted buckets (rows = 15 x ids, dim 16: ratio 16)"; cat $O/prof_bwd.txt; echo; echo "== + fused SGD step / step only (bench_ops s)"; cat $O/prof_bwd_step.txt) > $O/r04_bwd_kernel_stats.txt
+      prof prof_ragged "" -- python $R/tools/sweep.py --cases b
+      cp $O/prof_ragged.txt $O/r04_ragged_kernel_stats.txt
+      prof prof_cfg5 "" -- python $R/tools/sweep.py --cases h
+      cp $O/prof_cfg5.txt $O/r04_cfg5_bwd_kernel_stats.txt
+      export HBK_BENCH_ITERS=3
+      prof pmc_rs_sq1 "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" -- $R/tools/bin/bench_ops R
+      prof pmc_rs_sq2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" -- $R/tools/bin/bench_ops R
+      prof pmc_rs_tcc "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" -- $R/tools/bin/bench_ops R
+      HBK_BWD_SCATTER_STAGED=0 prof pmc_rs_tcc_direct "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" -- $R/tools/bin/bench_ops R
+      unset HBK_BENCH_ITERS
+      python - $O > $O/r04_rowsort_counters.txt <<'PY'
+import json,sys
+O=sys.argv[1]
+print("SQ / TCC counters of the ragged backward's kernels (tools/bin/bench_ops R: 26 x 524288 ids, 8 per segment, mean, dim 16, 1M rows; mean per launch; one --pmc pass per group)")
+for f in ('pmc_rs_sq1','pmc_rs_sq2','pmc_rs_tcc'):
+  d=json.load(open(f'{O}/{f}.json'))
+  for k,v in sorted(d.items()):
+    if 'bwd_' in k: print(k[:64].ljust(64), {c:round(x['mean']) for c,x in v.items()})
+print("== the same with the direct pair scatter (HBK_BWD_SCATTER_STAGED=0)")
+d=json.load(open(f'{O}/pmc_rs_tcc_direct.json'))
+for k,v in sorted(d.items()):
+  if 'scatter' in k: print(k[:64].ljust(64), {c:round(x['mean']) for c,x in v.items()})
+PY
+      (HBK_STAMP_NAMES=rowsort LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops R; HBK_STAMP_NAMES=rowsort LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops d) > $O/r04_rowsort_trace.txt 2>&1
+      prof prof_sharded "" -- python $R/bench.py --gpus 1 --sharded --steps 30 --warmup 5 --cpu-seconds 0 --tune-steps 0 --no-secondary
+      cp $O/prof_sharded.txt $O/r04_sharded_w1_kernel_stats.txt
+      timeout 1800 python tools/sweep.py --big --cases a,b,c,d,e,f,g,h,i,j,k 2>/dev/null | grep "^{" > $O/r04_sweep.jsonl
+      (echo "Library options toggled INSIDE one process on the same tensors (tools/sweep.py SWEEP_AB=option:values): case, values in the order run, microseconds per call under each."
+       ab "bwd_rowsort_ratio:0,8,0,8" "b,h,c"
+       ab "bwd_scatter_staged:0,1,0,1" "b"
+       ab "bwd_rowsort_pos:0,64,0,64" "h") > $O/r04_inprocess_ab.txt 2>&1
+      timeout 120 tools/bin/bitmap_probe > $O/r04_bitmap_probe.txt 2>&1
+      ls -la $O/r04_*;;
     *) echo "unknown stage $st";;
   esac
 done

@@ -216,6 +216,14 @@ PY
        ab "bwd_rowsort_pos:0,64,0,64" "h") > $O/r04_inprocess_ab.txt 2>&1
       timeout 120 tools/bin/bitmap_probe > $O/r04_bitmap_probe.txt 2>&1
       ls -la $O/r04_*;;
+    cfg4chk)
+      (for rep in 1 2; do for ratio in 8 0; do
+         HBK_BWD_ROWSORT_RATIO=$ratio timeout 600 python tools/sweep.py --big --cases d 2>/dev/null | grep "^{" | python -c "
+import sys,json
+for l in sys.stdin:
+  d=json.loads(l)
+  if 'bwd' in d['case']: print('ratio=$ratio rep=$rep', d['case'][:70].ljust(70), d['us'])"
+       done; done) > $O/cfg4chk.log 2>&1; cat $O/cfg4chk.log;;
     *) echo "unknown stage $st";;
   esac
 done

@@ -194,10 +194,12 @@ sharded_column = st.fixed_dictionaries({
 
 @_cfg(24)
 @given(world=st.sampled_from([2, 3, 5]), cols=st.lists(sharded_column, min_size=1, max_size=5),
-       wire16=st.booleans(), hot=st.booleans(), seed=st.integers(0, 2**31 - 1))
-def test_sharded_driver_random_in_process_world(world, cols, wire16, hot, seed):
+       wire16=st.booleans(), hot=st.sampled_from([False, True, 'auto']),
+       dedup=st.sampled_from(['none', 'all', 'mixed']), seed=st.integers(0, 2**31 - 1))
+def test_sharded_driver_random_in_process_world(world, cols, wire16, hot, dedup, seed):
   """hbk_sharded_lookup_fwd/_bwd with W in-process ranks (W not a power of two included), random
-  columns, some ranks / columns empty: forward == unsharded oracle, backward == dense
+  columns, some ranks / columns empty, requester-side dedup on no / every / every other column,
+  ids drawn from few or many values: forward == unsharded oracle, backward == dense
   scatter-add."""
   import threading
   import oracle
@@ -221,7 +223,9 @@ def test_sharded_driver_random_in_process_world(world, cols, wire16, hot, seed):
       else:
         sp, cnt = None, n_seg
       rs.append(sp)
-      ri.append(rng.randint(0, 2**40, size=cnt).astype(np.int64))
+      # (every other column repeats its ids heavily: what dedup is for)
+      hi = 2**40 if k % 2 == 0 else 40
+      ri.append(rng.randint(0, hi, size=cnt).astype(np.int64))
       rg.append(rng.randn(n_seg, dims[k]).astype(np.float32))
     ids.append(ri)
     splits.append(rs)
@@ -234,9 +238,15 @@ def test_sharded_driver_random_in_process_world(world, cols, wire16, hot, seed):
     try:
       with torch.cuda.stream(torch.cuda.Stream()):
         drv = ShardedGroupLookup(shards[r], comms[r], buckets=rows, combiners=combs,
-                                 wire_dtype=torch.float16 if wire16 else None, hot_rows=hot)
+                                 wire_dtype=torch.float16 if wire16 else None, hot_rows=hot,
+                                 dedup=[dedup == 'all' or (dedup == 'mixed' and k % 2 == 1)
+                                        for k in range(n)])
         outs = drv([dev(i) for i in ids[r]], [None if s is None else dev(s) for s in splits[r]])
         sl = drv.backward([dev(g) for g in grads[r]])
+        if hot == 'auto':   # a second step, after the counts of the first have (maybe) landed
+          torch.cuda.current_stream().synchronize()
+          outs = drv([dev(i) for i in ids[r]], [None if s is None else dev(s) for s in splits[r]])
+          sl = drv.backward([dev(g) for g in grads[r]])
         torch.cuda.current_stream().synchronize()
         results[r] = ([o.cpu().numpy() for o in outs],
                       [(u.cpu().numpy()[:int(k.item())], g.cpu().numpy()[:int(k.item())])

@@ -819,8 +819,9 @@ def test_dense_features_adagrad_sharded_in_process_world():
     off += c.dimension
 
 
+@pytest.mark.parametrize('dedup', [False, True])
 @pytest.mark.parametrize('world', [1, 3])
-def test_sharded_prefetch_next_step(world):
+def test_sharded_prefetch_next_step(world, dedup):
   """hbk_sharded_prefetch: step i + 1 is partitioned on the plan's own stream while step i is in
   flight; a matching forward consumes it, a non-matching one drops it; the backward of step i
   still sees step i's shard index.  Results equal the unprefetched driver (= the oracle)."""
@@ -829,7 +830,9 @@ def test_sharded_prefetch_next_step(world):
   dims, rows = [16, 8], [50021, 300]
   tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(2)]
   steps = 4
-  ids = [[[rng.randint(0, 2**40, size=rng.randint(1, 3000)).astype(np.int64) for _ in range(2)]
+  # (dedup: the prefetched partition also carries the distinct-id stage; ids repeat heavily then)
+  hi = 500 if dedup else 2**40
+  ids = [[[rng.randint(0, hi, size=rng.randint(1, 3000)).astype(np.int64) for _ in range(2)]
           for _ in range(steps)] for _ in range(world)]
   grads = [[[rng.randn(ids[r][s][c].size, dims[c]).astype(np.float32) for c in range(2)]
             for s in range(steps)] for r in range(world)]
@@ -843,7 +846,7 @@ def test_sharded_prefetch_next_step(world):
     try:
       with torch.cuda.stream(torch.cuda.Stream()):
         drv = ShardedGroupLookup([dev(t[r::world].copy()) for t in tables], comms[r],
-                                 buckets=rows, combiners='sum')
+                                 buckets=rows, combiners='sum', dedup=dedup)
         bound = [drv.bind([dev(i) for i in ids[r][s]]) for s in range(steps)]
         got = []
         for s in range(steps):

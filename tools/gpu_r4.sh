@@ -224,6 +224,10 @@ for l in sys.stdin:
   d=json.loads(l)
   if 'bwd' in d['case']: print('ratio=$ratio rep=$rep', d['case'][:70].ljust(70), d['us'])"
        done; done) > $O/cfg4chk.log 2>&1; cat $O/cfg4chk.log;;
+    fuzz)
+      timeout 1500 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x --durations=5 > $O/fuzz.log 2>&1; echo "pytest rc=$?" >> $O/fuzz.log; tail -15 $O/fuzz.log;;
+    fuzzmore)   # fresh random draws (hypothesis seed from the clock), three rounds
+      for k in 1 2 3; do HBK_FUZZ_RANDOM=1 HBK_FUZZ_SCALE=10 timeout 1200 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x -p no:cacheprovider > $O/fuzz_$k.log 2>&1; echo "pytest rc=$?" >> $O/fuzz_$k.log; tail -4 $O/fuzz_$k.log; done;;
     *) echo "unknown stage $st";;
   esac
 done

@@ -439,6 +439,18 @@ __device__ inline void scan_tiles_of_bucket(const GCol& c, int p) {
   int32_t* h = c.hist + p;
   int32_t run = 0;
   int t = 0;
+  // 16 tiles per memory round trip (the loads of a step cannot pass the stores of the step before:
+  // same array; with 4 per step a 256-tile column was 64 dependent round trips, 23 us)
+  for (; t + 16 <= n_tiles; t += 16) {
+    int32_t x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = h[(int64_t)(t + k) * P];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      h[(int64_t)(t + k) * P] = run;
+      run += x[k];
+    }
+  }
   for (; t + 4 <= n_tiles; t += 4) {
     int32_t x[4];
 #pragma unroll

@@ -228,6 +228,10 @@ for l in sys.stdin:
       timeout 1500 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x --durations=5 > $O/fuzz.log 2>&1; echo "pytest rc=$?" >> $O/fuzz.log; tail -15 $O/fuzz.log;;
     fuzzmore)   # fresh random draws (hypothesis seed from the clock), three rounds
       for k in 1 2 3; do HBK_FUZZ_RANDOM=1 HBK_FUZZ_SCALE=10 timeout 1200 python -m pytest tests/test_gpu_fuzz.py -q -m gpu -x -p no:cacheprovider > $O/fuzz_$k.log 2>&1; echo "pytest rc=$?" >> $O/fuzz_$k.log; tail -4 $O/fuzz_$k.log; done;;
+    variants)   # probe builds through the C ABI, two passes
+      (for rep in 1 2; do for v in tools/bin/v_*; do for w in R r d b; do
+         LD_LIBRARY_PATH=$R/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s|^|$(basename $v)  |"
+       done; done; done) > $O/variants.log 2>&1; cut -c1-200 $O/variants.log;;
     *) echo "unknown stage $st";;
   esac
 done

@@ -121,19 +121,38 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   if (lim > c.map.rows) lim = c.map.rows;
   const int words = (int)((lim - base + 31) >> 5);   // <= kRsWords (host: plan_of)
 
+  const bool pairs_nt = c.seg_of != nullptr && pseg != nullptr;   // ragged column, not a merge job
   uint32_t off_[PT];   // row - base of my pairs of the chunk, ~0u: none
   int32_t seg_[PT];
   auto load_pairs = [&](int32_t cb) {
     // all loads first, in one straight line (indices behind the end are clamped and masked
     // afterwards): with the range check and the sign test inside the loop the compiler waited for
     // every pair before it requested the next -- 8 memory round trips, the job's first 8 us
+    // Ragged columns read every gradient row ~8 times, from different jobs: their pairs -- read
+    // once -- are loaded non-temporally so that they do not push gradient lines out of the XCD's
+    // L2 (ragged 1M-row case 611-631 -> 599 us); columns of one id per segment have no reuse to
+    // protect and lose 2 % with the hint (probe builds, profiles/r04_variants.txt): plain loads.
     int64_t r_[PT];
+    if (pairs_nt) {   // uniform
 #pragma unroll
-    for (int k = 0; k < PT; ++k) {
-      const int32_t e = cb + k * kBlock + tid;
-      r_[k] = HBK_PAIR_LOAD(prow + (e < n_pairs ? e : n_pairs - 1));
+      for (int k = 0; k < PT; ++k) {
+        const int32_t e = cb + k * kBlock + tid;
+        r_[k] = __builtin_nontemporal_load(prow + (e < n_pairs ? e : n_pairs - 1));
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const int32_t e = cb + k * kBlock + tid;
+        r_[k] = HBK_PAIR_LOAD(prow + (e < n_pairs ? e : n_pairs - 1));
+      }
     }
-    if (pseg != nullptr) {   // uniform
+    if (pseg != nullptr && pairs_nt) {   // uniform
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const int32_t e = cb + k * kBlock + tid;
+        seg_[k] = __builtin_nontemporal_load(pseg + (e < n_pairs ? e : n_pairs - 1));
+      }
+    } else if (pseg != nullptr) {
 #pragma unroll
       for (int k = 0; k < PT; ++k) {
         const int32_t e = cb + k * kBlock + tid;

@@ -232,6 +232,10 @@ for l in sys.stdin:
       (for rep in 1 2; do for v in tools/bin/v_*; do for w in R r d b; do
          LD_LIBRARY_PATH=$R/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s|^|$(basename $v)  |"
        done; done; done) > $O/variants.log 2>&1; cut -c1-200 $O/variants.log;;
+    rsab6)
+      (ab "bwd_group_cols:0,13,7,0,13,7" "b"
+       for gc in 0 13 7; do HBK_BWD_GROUP_COLS=$gc timeout 300 tools/bin/bench_ops R 2>&1 | grep group_lookup_bwd | sed "s|^|group_cols=$gc  |"; done
+       for gc in 0 8 4; do HBK_BWD_GROUP_COLS=$gc timeout 300 tools/bin/bench_ops r 2>&1 | grep group_lookup_bwd | sed "s|^|group_cols=$gc  |"; done) > $O/rsab6.log 2>&1; cut -c1-200 $O/rsab6.log;;
     *) echo "unknown stage $st";;
   esac
 done

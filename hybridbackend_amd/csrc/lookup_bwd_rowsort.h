@@ -66,6 +66,11 @@ __device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t
 #endif
 }
 
+// (the row NUMBERS stay plain stores: 8-byte pieces per lane that the L2 combines into whole
+// sectors; non-temporal they went out one by one -- ragged 1M-row case 650-667 -> 830-920 us)
+#ifndef HBK_RS_ROWNUM_NT
+#define HBK_RS_ROWNUM_NT 0
+#endif
 #ifndef HBK_RS_W0
 #define HBK_RS_W0 12   // (8: ragged dim 16 675 us, 12: 616 us; 16 spills)
 #endif
@@ -513,7 +518,11 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
       int64_t* o = job.out_rows + base_u + (int32_t)L.pre[w];
       const int64_t r0 = (int64_t)base + 32 * (int64_t)w;
       while (m != 0u) {
+#if HBK_RS_ROWNUM_NT
+        __builtin_nontemporal_store(r0 + __builtin_ctz(m), o++);   // (written once, like the rows)
+#else
         *o++ = r0 + __builtin_ctz(m);
+#endif
         m &= m - 1u;
       }
     }

@@ -202,6 +202,72 @@ def test_one_launch_kernels_from_concurrent_streams_never_run_beside_each_other(
     check()
 
 
+def test_one_launch_kernels_beside_rccl_kernels(hbk_option):
+  """the one-launch forms had never run beside a real RCCL kernel.  One host
+  thread keeps a world-size-1 RCCL communicator busy with sharded steps whose OWN slice really goes
+  through RCCL's send / receive kernels (sharded_copy_self, exchanges pipelined on the
+  communicator's stream), three others hammer partition / unique / backward on their own streams:
+  RCCL's kernels do not wait for our tiles, so they finish and free their slots -- every result
+  right, no wait runs out, the one-launch forms stay on."""
+  import threading
+  from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
+  hbk_option('sync_onepass_off', 0)
+  hbk_option('sync_wait_ms', 500)
+  hbk_option('sharded_copy_self', 1)
+  hbk_option('sharded_groups', 2)
+  errors, checks = [], []
+  rng0 = np.random.RandomState(55)
+  tables = [rng0.uniform(-1, 1, size=(50021, 16)).astype(np.float32) for _ in range(6)]
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+
+  def rccl_worker():
+    try:
+      rng = np.random.RandomState(56)
+      with torch.cuda.stream(torch.cuda.Stream()):
+        drv = ShardedGroupLookup([dev(t) for t in tables], coll, buckets=[50021] * 6)
+        for rep in range(25):
+          ids = [rng.randint(0, 2**40, size=30000).astype(np.int64) for _ in tables]
+          outs = drv([dev(i) for i in ids])
+          if rep % 8 == 0:
+            torch.cuda.current_stream().synchronize()
+            want = oracle.group_lookup_fwd(tables, ids, [None] * 6, [50021] * 6, ['sum'] * 6)
+            for o, w in zip(outs, want):
+              np.testing.assert_equal(host(o), w)
+        torch.cuda.current_stream().synchronize()
+        drv.close()
+    except Exception:  # pylint: disable=broad-except
+      import traceback
+      errors.append(traceback.format_exc())
+
+  def worker(t):
+    try:
+      rng = np.random.RandomState(200 + t)
+      with torch.cuda.stream(torch.cuda.Stream()):
+        mine = []
+        for rep in range(10):
+          for which in ('partition', 'unique', 'bwd'):
+            mine.append(_run(which, rng))
+        torch.cuda.current_stream().synchronize()
+        checks.extend(mine)
+    except Exception:  # pylint: disable=broad-except
+      import traceback
+      errors.append(traceback.format_exc())
+
+  threads = [threading.Thread(target=rccl_worker)] + \
+      [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=180)
+  torch.cuda.synchronize()
+  coll.close()
+  assert not errors, errors
+  assert _sync_check() == 0
+  assert _lib.get_option('sync_onepass_off') == 0
+  for check in checks:
+    check()
+
+
 def test_config5_shaped_backward_runs_its_launch_groups_side_by_side(hbk_option):
   """150 one-launch columns = three launch groups on the library's helper streams: their grouping
   kernels are chained, everything else overlaps; no wait runs out and the result is right."""

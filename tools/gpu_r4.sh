@@ -236,6 +236,8 @@ for l in sys.stdin:
       (ab "bwd_group_cols:0,13,7,0,13,7" "b"
        for gc in 0 13 7; do HBK_BWD_GROUP_COLS=$gc timeout 300 tools/bin/bench_ops R 2>&1 | grep group_lookup_bwd | sed "s|^|group_cols=$gc  |"; done
        for gc in 0 8 4; do HBK_BWD_GROUP_COLS=$gc timeout 300 tools/bin/bench_ops r 2>&1 | grep group_lookup_bwd | sed "s|^|group_cols=$gc  |"; done) > $O/rsab6.log 2>&1; cut -c1-200 $O/rsab6.log;;
+    synctest)
+      timeout 900 python -m pytest tests/test_gpu_sync.py -q -m gpu --durations=5 > $O/synctest.log 2>&1; echo "pytest rc=$?" >> $O/synctest.log; tail -30 $O/synctest.log;;
     *) echo "unknown stage $st";;
   esac
 done

@@ -71,6 +71,9 @@ __device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t
 #ifndef HBK_RS_ROWNUM_NT
 #define HBK_RS_ROWNUM_NT 0
 #endif
+#ifndef HBK_RS_ROWS_FROM_ROFF
+#define HBK_RS_ROWS_FROM_ROFF 1
+#endif
 #ifndef HBK_RS_W0
 #define HBK_RS_W0 12   // (8: ragged dim 16 675 us, 12: 616 us; 16 spills)
 #endif
@@ -282,7 +285,9 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
       if (valid) {
         const int w = (int)(off_[k] >> 5);
         u = pr[w] + (uint32_t)__builtin_popcount(bm[w] & ((1u << (off_[k] & 31u)) - 1u));
-        if (stepping || !one_chunk) L.roff[u] = (uint16_t)off_[k];   // (every pair of the row: same value)
+        if (HBK_RS_ROWS_FROM_ROFF || stepping || !one_chunk) {
+          L.roff[u] = (uint16_t)off_[k];   // (every pair of the row: same value)
+        }
       }
       int32_t tk = 0;
       bool done = !valid;
@@ -511,8 +516,14 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
     }
   }
 
-  // the row numbers, sorted, straight from the bitmap
-  if (emit) {
+  // the row numbers, sorted.  One chunk: the chunk's row index IS the output rank, and roff[] holds
+  // every row's offset: consecutive lanes write consecutive entries (whole lines per store
+  // instruction).  Several chunks: straight from the job's bitmap.
+  if (emit && one_chunk && HBK_RS_ROWS_FROM_ROFF) {
+    for (int u = tid; u < n_rows_job; u += kBlock) {
+      job.out_rows[base_u + u] = (int64_t)base + (int64_t)L.roff[u];
+    }
+  } else if (emit) {
     for (int w = tid; w < words; w += kBlock) {
       uint32_t m = L.present[w];
       int64_t* o = job.out_rows + base_u + (int32_t)L.pre[w];

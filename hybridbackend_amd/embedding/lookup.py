@@ -144,7 +144,22 @@ class GroupLookup:
     self._keep = (ids, row_splits, outs)
     return outs
 
-  def _bind_fresh(self, ids, row_splits, outs):
+  def bind_block(self, ids, row_splits, block, offsets):
+    """bind() with every column's output a column block of ONE ``[segments, pitch]`` fp32 tensor
+    (``block``; column c starts at float ``offsets[c]`` of every row): what DenseFeatures writes.
+    No per-column views are made -- the addresses are arithmetic.  Returns False when the inputs
+    need bind()'s detailed checks (the caller then makes views and calls bind)."""
+    self._call_key = None
+    n = len(self.tables)
+    if (n == 0 or block.dtype is not torch.float32 or not block.is_cuda or block.dim() != 2 or
+        block.stride(1) != 1 or block.stride(0) % 4 != 0):
+      return False
+    n_rows, pitch = block.shape[0], block.stride(0)
+    base = block.data_ptr()
+    return self._bind_fresh(ids, row_splits, None,
+                            block=(n_rows, pitch, [base + 4 * o for o in offsets], block)) is not None
+
+  def _bind_fresh(self, ids, row_splits, outs, block=None):
     """bind() for the common shapes -- id vectors of one dtype, contiguous outputs (or none: one
     allocation, lazy per-column views) -- with ONE pass over the tensors and the descriptors
     written field by field for all columns.  None: something needs bind()'s detailed checks
@@ -172,7 +187,13 @@ class GroupLookup:
         sp_ptrs.append(sp.data_ptr())
         n_seg.append(sh[0] - 1)
     dims = self._dims
-    if outs is None:
+    stride = 0
+    if block is not None:
+      n_rows, stride, o_ptrs, keep = block
+      if any(k != n_rows for k in n_seg):
+        return None
+      outs = keep
+    elif outs is None:
       counts = [n_seg[c] * dims[c] for c in range(n)]
       pad = [(k + 3) // 4 * 4 for k in counts]     # every column's block on a 16-byte boundary
       flat = torch.empty(sum(pad) + 4, dtype=torch.float32, device=self.tables[0].device)
@@ -198,7 +219,7 @@ class GroupLookup:
     rec['row_splits'] = sp_ptrs
     rec['n_segments'] = n_seg
     rec['out'] = o_ptrs
-    rec['out_stride'] = 0
+    rec['out_stride'] = stride
     self._keep = (ids, row_splits, outs)
     return outs
 

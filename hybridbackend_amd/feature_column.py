@@ -121,15 +121,27 @@ class DenseFeatures:
     # offset is a multiple of 4 floats keep 16-byte accesses
     pitch = (self.width + 3) // 4 * 4
     out = torch.empty((batch or 0, pitch), dtype=torch.float32, device=self.device)[:, :self.width]
-    views = [out[:, self.offsets[c]:self.offsets[c] + self.columns[c].dimension]
-             for c in range(len(self.columns))]
     pick = lambda idx, xs: [xs[c] for c in idx]   # noqa: E731
+    views = None
+
+    def col_views():
+      return [out[:, self.offsets[c]:self.offsets[c] + self.columns[c].dimension]
+              for c in range(len(self.columns))]
     if self._rep:
-      self._lookup(pick(self._rep, ids), pick(self._rep, splits), pick(self._rep, views))
+      # the blocks' addresses are arithmetic: no per-column views unless somebody asks for them
+      # (26 views + their validation were ~100 us of Python per step)
+      if batch and self._lookup.bind_block(pick(self._rep, ids), pick(self._rep, splits), out,
+                                           pick(self._rep, self.offsets)):
+        self._lookup.launch()
+      else:
+        views = col_views()
+        self._lookup(pick(self._rep, ids), pick(self._rep, splits), pick(self._rep, views))
     if self._shd:
+      views = views or col_views()
       self._sharded(pick(self._shd, ids), pick(self._shd, splits), pick(self._shd, views))
     self._last = (ids, splits)
     if cols_to_output_tensors is not None:
+      views = views or col_views()
       for c, col in enumerate(self.columns):
         cols_to_output_tensors[col] = views[c]
     return out

@@ -209,7 +209,7 @@ PY
       (HBK_STAMP_NAMES=rowsort LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops R; HBK_STAMP_NAMES=rowsort LD_LIBRARY_PATH=$R/tools/bin/stamps timeout 300 tools/bin/bench_ops d) > $O/r04_rowsort_trace.txt 2>&1
       prof prof_sharded "" -- python $R/bench.py --gpus 1 --sharded --steps 30 --warmup 5 --cpu-seconds 0 --tune-steps 0 --no-secondary
       cp $O/prof_sharded.txt $O/r04_sharded_w1_kernel_stats.txt
-      timeout 1800 python tools/sweep.py --big --cases a,b,c,d,e,f,g,h,i,j,k 2>/dev/null | grep "^{" > $O/r04_sweep.jsonl
+      timeout 2400 python tools/sweep.py --big --cases a,b,c,d,e,f,g,h,i,j,k,l 2>/dev/null | grep "^{" > $O/r04_sweep.jsonl
       (echo "Library options toggled INSIDE one process on the same tensors (tools/sweep.py SWEEP_AB=option:values): case, values in the order run, microseconds per call under each."
        ab "bwd_rowsort_ratio:0,8,0,8" "b,h,c"
        ab "bwd_scatter_staged:0,1,0,1" "b"
@@ -238,6 +238,8 @@ for l in sys.stdin:
        for gc in 0 8 4; do HBK_BWD_GROUP_COLS=$gc timeout 300 tools/bin/bench_ops r 2>&1 | grep group_lookup_bwd | sed "s|^|group_cols=$gc  |"; done) > $O/rsab6.log 2>&1; cut -c1-200 $O/rsab6.log;;
     synctest)
       timeout 900 python -m pytest tests/test_gpu_sync.py -q -m gpu --durations=5 > $O/synctest.log 2>&1; echo "pytest rc=$?" >> $O/synctest.log; tail -30 $O/synctest.log;;
+    autosweep)
+      timeout 900 python tools/sweep.py --big --cases l > $O/autosweep.log 2>&1; echo "rc=$?" >> $O/autosweep.log; cut -c1-300 $O/autosweep.log;;
     *) echo "unknown stage $st";;
   esac
 done

@@ -446,6 +446,42 @@ def case_sharded_dedup(big):
   coll.close()
 
 
+def case_dense_features_auto_hot(big):
+  """Config-4 shape through DenseFeatures with NO user flag (EmbeddingColumn's default
+  hot_rows='auto'): the forward before any backward (per-wave gather), then after one backward
+  over the same kind of ids has told the layer how many distinct rows a batch names."""
+  dim, B = 128, 65536
+  rows = [1000000] * 25 + [100000000 if big else 10000000]
+  cols = [hb.feature_column.EmbeddingColumn(f'c{c}', rows[c], dim, 'sum') for c in range(26)]
+  layer = hb.feature_column.DenseFeatures(cols, DEV)
+  g = torch.Generator(device=DEV)
+  g.manual_seed(7)
+  nb = 4
+  kinds = {
+      'Zipf(1.2)': [{f'c{c}': zipf_ids(B, rows[c], 1.2, g, 2654435761 % rows[c] | 1)
+                     for c in range(26)} for _ in range(nb)],
+      'uniform': [{f'c{c}': torch.randint(0, rows[c], (B,), device=DEV, generator=g)
+                   for c in range(26)} for _ in range(nb)],
+  }
+  grad = torch.randn(B, 26 * dim, device=DEV)
+  for name, batches in kinds.items():
+    for phase in ('before any backward', 'after a backward'):
+      if phase == 'after a backward':
+        layer(batches[0])
+        layer.backward(grad)
+        torch.cuda.synchronize()
+        layer(batches[0])          # (this forward finds the counts landed and switches)
+        torch.cuda.synchronize()
+      us = timed(lambda i: layer(batches[i % nb]), iters=20)
+      hot = sum(int(layer._lookup._cols[c].hot_rows) for c in range(26))
+      report(f'DenseFeatures cfg4 fwd {name} dim128 B={B}, no flag, {phase}', us, 26 * B,
+             26 * B * (8 + 512 + 512), columns_staging_hot_rows=hot)
+    # forget what was learnt: the next kind starts from scratch
+    for c in range(26):
+      layer._lookup._cols[c].hot_rows = 0
+    layer._lookup._auto_state = None
+
+
 if __name__ == '__main__':
   ap = argparse.ArgumentParser()
   ap.add_argument('--cases', default='a,b,c,d,e')
@@ -455,5 +491,6 @@ if __name__ == '__main__':
   for c in args.cases.split(','):
     {'a': case_batch_sweep, 'b': case_ragged, 'c': case_backward_cfg2,
      'd': lambda: case_cfg4(args.big), 'e': case_integer, 'f': case_bwd_probe, 'g': case_sharded_world1, 'h': case_cfg5, 'i': case_dense_block,
-     'j': lambda: case_cfg4_hot_rows(args.big), 'k': lambda: case_sharded_dedup(args.big)}[c]()
+     'j': lambda: case_cfg4_hot_rows(args.big), 'k': lambda: case_sharded_dedup(args.big),
+     'l': lambda: case_dense_features_auto_hot(args.big)}[c]()
     torch.cuda.empty_cache()

@@ -326,6 +326,7 @@ class GroupLookupGrad:
     n = len(lookup)
     self.accums = list(accums) if accums is not None else None
     self._cols = (_lib.LookupGradColumn * n)()
+    self._cols_np = np.frombuffer(self._cols, dtype=np.dtype(_lib.LookupGradColumn)) if n else None
     for c, t in enumerate(lookup.tables):
       col = self._cols[c]
       if self.accums is not None:
@@ -343,7 +344,66 @@ class GroupLookupGrad:
       col.combiner = lookup.combiners[c]
     self._ws = None
 
-  def __call__(self, ids, grads, row_splits=None, apply_lr=0.0, optimizer='sgd', emit=True):
+  def _bind_fresh(self, ids, grads, row_splits, emit, block):
+    """The descriptors of a step with tensors never seen before, in one pass and written field by
+    field (cf. GroupLookup._bind_fresh).  `block` = (tensor [segments, pitch], float offsets): the
+    gradients are column blocks of one tensor (DenseFeatures), addressed by arithmetic.  False:
+    the general path's checks are needed."""
+    n = len(self.lookup)
+    seen = _marshal.vector_pass(ids, (torch.int32, torch.int64))
+    if seen is None:
+      return False
+    id_ptrs, n_ids, id_dtype = seen
+    if all(s is None for s in row_splits):
+      sp_ptrs, n_seg = 0, n_ids
+    else:
+      sp_ptrs, n_seg = [], []
+      for c in range(n):
+        sp = row_splits[c]
+        if sp is None:
+          sp_ptrs.append(0)
+          n_seg.append(n_ids[c])
+          continue
+        sh = sp.shape
+        if (len(sh) != 1 or sh[0] < 1 or sp.dtype is not torch.int32 or not sp.is_cuda or
+            not sp.is_contiguous()):
+          return False
+        sp_ptrs.append(sp.data_ptr())
+        n_seg.append(sh[0] - 1)
+    dims = [int(t.shape[1]) for t in self.lookup.tables]
+    if block is not None:
+      g, offsets = block
+      if (g.dtype is not torch.float32 or not g.is_cuda or g.dim() != 2 or g.stride(1) != 1 or
+          g.stride(0) % 4 != 0 or any(k != g.shape[0] for k in n_seg)):
+        return False
+      base, stride = g.data_ptr(), g.stride(0)
+      g_ptrs = [base + 4 * o for o in offsets]
+    else:
+      g_ptrs, stride = [], []
+      for c in range(n):
+        g = grads[c]
+        sh = g.shape
+        if (g.dtype is not torch.float32 or not g.is_cuda or len(sh) != 2 or sh[0] != n_seg[c] or
+            sh[1] != dims[c] or (sh[1] > 1 and g.stride(1) != 1) or g.stride(0) < sh[1]):
+          return False
+        g_ptrs.append(g.data_ptr())
+        stride.append(0 if g.is_contiguous() else g.stride(0))
+    rec = self._cols_np
+    rec['ids_dtype'] = _lib.INT64 if id_dtype is torch.int64 else _lib.INT32
+    rec['ids'] = id_ptrs
+    rec['n_ids'] = n_ids
+    rec['row_splits'] = sp_ptrs
+    rec['n_segments'] = n_seg
+    rec['grad_out'] = g_ptrs
+    rec['grad_stride'] = stride
+    u_ptrs, g_out_ptrs, nu_ptrs = self._out_ptrs
+    rec['unique_rows'] = u_ptrs if emit else 0
+    rec['grad_rows'] = g_out_ptrs if emit else 0
+    rec['n_unique'] = nu_ptrs
+    return True
+
+  def __call__(self, ids, grads, row_splits=None, apply_lr=0.0, optimizer='sgd', emit=True,
+               grad_block=None):
     """Returns per column ``(unique_rows int64[n_ids], grad_rows f32[n_ids, dim],
     n_unique int32[1])``; only the first ``n_unique`` rows are meaningful, in unspecified
     order (device-side count: no host sync here).  The result buffers belong to this object
@@ -362,6 +422,7 @@ class GroupLookupGrad:
       self._nu = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
       self._urows = self._grows = None
       self._views = [(None, None, self._nu[c:c + 1]) for c in range(n)]
+      self._out_ptrs = (0, 0, [self._nu.data_ptr() + 4 * c for c in range(n)])
       self._out_key = counts
     if getattr(self, '_out_key', None) != counts:
       # three allocations for all columns, carved into per-column views
@@ -380,13 +441,31 @@ class GroupLookupGrad:
                             self._grows[o_g:o_g + k * d].view(k, d), self._nu[c:c + 1]))
         o_r += k
         o_g += pad4(k * d)
+      self._out_ptrs = ([v[0].data_ptr() for v in self._views], [v[1].data_ptr() for v in self._views],
+                        [self._nu.data_ptr() + 4 * c for c in range(n)])
     # handed the SAME tensors as the call before (resident buffers refilled in place): the
     # descriptors are still right -- validating and marshalling 26 columns is ~12 us of Python
-    tensors = list(ids) + list(grads) + [x for x in row_splits if x is not None]
+    fresh = False
+    if n > 0:
+      # other tensors than the call before (told apart by the first id tensor): one pass over them.
+      # The same first tensor twice in a row: the general path below, which remembers the step so
+      # that a loop over resident buffers pays ~12 us from its third call on.
+      bk = getattr(self, '_bound_key', None)
+      maybe_same = (bk is not None and bk[0][1][:1] == (id(ids[0]),)) or \
+          ids[0] is getattr(self, '_fresh_first', None)
+      if grad_block is not None or not maybe_same:
+        fresh = self._bind_fresh(ids, grads, row_splits, emit, grad_block)
+        if fresh:
+          self._bound_key = None
+          self._fresh_first = ids[0]
+    if grad_block is not None and not fresh:
+      g, offsets = grad_block
+      grads = [g[:, o:o + d] for o, d in zip(offsets, dims)]
+    tensors = [] if fresh else list(ids) + list(grads) + [x for x in row_splits if x is not None]
     key = (emit, tuple(id(t) for t in tensors))
     cached = getattr(self, '_bound_key', None)
-    same = cached is not None and cached[0] == key and all(
-      t.data_ptr() == q and t.numel() == m for t, (q, m) in zip(tensors, cached[1]))
+    same = fresh or (cached is not None and cached[0] == key and all(
+      t.data_ptr() == q and t.numel() == m for t, (q, m) in zip(tensors, cached[1])))
     for c in range(0 if not same else n, n):
       i, g, s = ids[c], grads[c], row_splits[c]
       _lib.require_device_tensor(i, 'ids')
@@ -419,6 +498,8 @@ class GroupLookupGrad:
       col.n_unique = nu.data_ptr()
     if not same:
       self._bound_key = (key, [(t.data_ptr(), t.numel()) for t in tensors])
+    if grad_block is not None:
+      grads = grad_block[0]
     need = self._lib.hbk_group_lookup_bwd_workspace_bytes(n, self._cols)   # (depends on options too)
     if self._ws is None or self._ws.numel() < need:
       self._ws = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)

@@ -168,18 +168,20 @@ class DenseFeatures:
                            device=grad.device)[:, :self.width]
       padded.copy_(grad)
       grad = padded
-    views = [grad[:, self.offsets[c]:self.offsets[c] + self.columns[c].dimension]
-             for c in range(len(self.columns))]
     pick = lambda idx, xs: [xs[c] for c in idx]   # noqa: E731
     res = [None] * len(self.columns)
     if self._rep:
       rep_lr = apply_lr if (self.coll.world_size if self.coll is not None else 1) <= 1 else 0.0
-      r = self._grad(pick(self._rep, ids), pick(self._rep, views), pick(self._rep, splits),
-                     apply_lr=rep_lr, optimizer=optimizer, emit=emit or rep_lr == 0.0)
+      # the gradient's column blocks are addressed by arithmetic (no per-column views)
+      r = self._grad(pick(self._rep, ids), None, pick(self._rep, splits),
+                     apply_lr=rep_lr, optimizer=optimizer, emit=emit or rep_lr == 0.0,
+                     grad_block=(grad, pick(self._rep, self.offsets)))
       for k, c in enumerate(self._rep):
         res[c] = r[k]
     if self._shd:
-      r = self._sharded.backward(pick(self._shd, views), apply_lr=apply_lr, optimizer=optimizer,
+      views = [grad[:, self.offsets[c]:self.offsets[c] + self.columns[c].dimension]
+               for c in self._shd]
+      r = self._sharded.backward(views, apply_lr=apply_lr, optimizer=optimizer,
                                  emit=emit)
       for k, c in enumerate(self._shd):
         res[c] = r[k]

@@ -48,6 +48,13 @@
 //                stays race free.
 //   4b dense     (round 3) columns whose batch covers the table densely take row-RANGE buckets and
 //                direct-indexed LDS bitmaps instead of the hash table (dense_reduce, below).
+//   4c rowsort   (round 4) columns whose batch is dense in the table (rows <= 8-16 x ids: ragged columns,
+//                small / medium tables) take row-RANGE buckets of ~1800 pairs and the row-sorted job of
+//                lookup_bwd_rowsort.h: bitmap ranks, LDS counting sort by row, equal shares of the
+//                sorted order walked with 12 gradient rows in flight per lane.
+//   0b scale     (round 4) ragged columns with mean / sqrtn: the seg-of launch also writes every segment's
+//                gradient row times the combiner's factor; the stages behind it see a SUM column.
+//   3b staged    (round 4) large columns of <= 1024 buckets: the scatter's pairs leave sorted by bucket.
 // Where lines live (round 3): gradient rows are loaded with PLAIN loads (a 128-byte line holds two
 // rows of dim 16, a ragged column re-reads its rows), the reduce jobs and the large columns'
 // scatter tiles go to the XCDs in contiguous ranges (whole columns per XCD: xcd_contiguous,

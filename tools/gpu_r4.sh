@@ -240,6 +240,8 @@ for l in sys.stdin:
       timeout 900 python -m pytest tests/test_gpu_sync.py -q -m gpu --durations=5 > $O/synctest.log 2>&1; echo "pytest rc=$?" >> $O/synctest.log; tail -30 $O/synctest.log;;
     autosweep)
       timeout 900 python tools/sweep.py --big --cases l > $O/autosweep.log 2>&1; echo "rc=$?" >> $O/autosweep.log; cut -c1-300 $O/autosweep.log;;
+    rsab7)
+      (ab "bwd_group_cols:0,45,34,0,45,34" "h") > $O/rsab7.log 2>&1; cut -c1-200 $O/rsab7.log;;
     *) echo "unknown stage $st";;
   esac
 done

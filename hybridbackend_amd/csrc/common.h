@@ -148,6 +148,7 @@ struct Options {
   int bwd_scatter_staged = 1;  // HBK_BWD_SCATTER_STAGED: large columns: the scatter's pairs go through LDS sorted by bucket (0: direct)
   int bwd_rowsort_pos = 64;    // HBK_BWD_ROWSORT_POS: > 0: row-sorted jobs sized for this many sorted positions per lane group (wide rows: smaller jobs)
   int bwd_rowsort_ratio = 8;   // HBK_BWD_ROWSORT_RATIO: row-sorted buckets for columns of rows <= ratio x ids (twice that for dim <= 32; 0: never)
+  int fwd_interleave = 2;      // HBK_FWD_INTERLEAVE: lookup tiles of one dense output block ordered row tile first (lookup_fwd.hip)
   int fwd_hot_rows = 0;        // HBK_FWD_HOT: forward of wide one-id-per-sample columns: 1 = 256-segment tiles with
                                // repeated rows staged in LDS, 2 = the large tiles alone (probe), 0 = per-wave gather
   int unique_buckets_log2 = -1;  // HBK_UNIQUE_LOG2P

@@ -100,7 +100,9 @@ struct LookupArgs {
   int32_t n_cols;
   int32_t hot_mode;   // hot-row kernel only: 1 = stage repeated rows in LDS, 2 = large tiles only
   int32_t xcd;        // != 0: every XCD takes a contiguous range of the tiles (xcd_contiguous)
-  int32_t pad_;
+  int32_t interleave; // != 0: every column has the same number of tiles and tile b belongs to
+                      // column b % n_cols (row tiles outermost: the columns of one dense output
+                      // block are written side by side, see the host side)
   int32_t tile_start[kMaxColsPerLaunch + 1];
   ColArg col[kMaxColsPerLaunch];
 };
@@ -230,7 +232,11 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupAr
   // one entry (two independent loads cover 128 columns) and a ballot counts the entries <= b:
   // one memory round trip.
   int ci;
-  {
+  int64_t tile;
+  if (a.interleave) {
+    ci = b % a.n_cols;
+    tile = b / a.n_cols;
+  } else {
     const int lane = (int)threadIdx.x & (kWave - 1);
     const int n = a.n_cols;
     const int t0 = lane < n ? a.tile_start[lane] : 0x7fffffff;
@@ -238,9 +244,9 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupAr
     ci = (int)__builtin_popcountll(__ballot(t0 <= b)) +
          (int)__builtin_popcountll(__ballot(t1 <= b)) - 1;
     ci = __builtin_amdgcn_readfirstlane(ci);
+    tile = b - a.tile_start[ci];
   }
   const ColArg& c = a.col[ci];
-  const int64_t tile = b - a.tile_start[ci];
   const int wave = (int)(threadIdx.x >> 6);
   const int rpi = kWave >> c.lpr_log2;
   if (!CSR) {
@@ -292,7 +298,11 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const Look
   const int b = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, a.xcd);
   const int tid = (int)threadIdx.x;
   int ci;
-  {
+  int64_t seg0;
+  if (a.interleave) {
+    ci = b % a.n_cols;
+    seg0 = (int64_t)(b / a.n_cols) * kHotTile;
+  } else {
     const int lane = tid & (kWave - 1);
     const int n = a.n_cols;
     const int t0 = lane < n ? a.tile_start[lane] : 0x7fffffff;
@@ -300,9 +310,9 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const Look
     ci = (int)__builtin_popcountll(__ballot(t0 <= b)) +
          (int)__builtin_popcountll(__ballot(t1 <= b)) - 1;
     ci = __builtin_amdgcn_readfirstlane(ci);
+    seg0 = (int64_t)(b - a.tile_start[ci]) * kHotTile;
   }
   const ColArg& c = a.col[ci];
-  const int64_t seg0 = (int64_t)(b - a.tile_start[ci]) * kHotTile;
   const int64_t n_seg = c.n_seg;
   const bool staging = a.hot_mode == 1;
 
@@ -522,9 +532,12 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
       LookupArgs args;
       args.hot_mode = hot_mode > 0 ? hot_mode : 1;
       args.xcd = 0;
-      args.pad_ = 0;
+      args.interleave = 0;
       int32_t k = 0;
       int64_t tiles = 0;
+      bool same_tiles = true, one_block = true;   // (see args.interleave below)
+      const float* block_lo = nullptr;
+      const float* block_hi = nullptr;
       int64_t small_lookups = 0, all_lookups = 0;   // (tables of <= 2 MB: see args.xcd below)
       args.tile_start[0] = 0;
       while (c0 < n_cols && k < kMaxColsPerLaunch) {
@@ -553,7 +566,15 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
         const int64_t rpi = kWave >> d.lpr_log2;
         const int64_t per_block =
             col_kind == 8 ? kHotTile : kWavesPerBlock * rpi * (h.row_splits ? kSegIters : kU);
-        tiles += (h.n_segments + per_block - 1) / per_block;
+        const int64_t col_tiles = (h.n_segments + per_block - 1) / per_block;
+        same_tiles = same_tiles && (k == 0 || col_tiles == args.tile_start[1]);
+        // "one dense block": every column's rows are strided and start inside the first row of
+        // the lowest column's block
+        one_block = one_block && d.out_stride > h.dim && h.half_io == 0;
+        block_lo = k == 0 || h.out < block_lo ? h.out : block_lo;
+        block_hi = k == 0 || h.out > block_hi ? h.out : block_hi;
+        one_block = one_block && (block_hi - block_lo) + h.dim <= d.out_stride;
+        tiles += col_tiles;
         HBK_REQUIRE(tiles < (1ll << 31), "group_lookup_fwd: grid too large");
         all_lookups += h.n_ids;
         if (h.rows * (int64_t)h.dim * 4 <= (2ll << 20)) small_lookups += h.n_ids;
@@ -578,6 +599,15 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
       const int xcd_opt = options().fwd_xcd;
       args.xcd = xcd_opt == 2 || (xcd_opt == 1 && (kind == 8 || 5 * small_lookups >= all_lookups))
                      ? 1 : 0;
+      // Row tiles outermost when the columns fill ONE dense [B, sum dim] block (DenseFeatures):
+      // the workgroups in flight then write whole rows of the block side by side instead of
+      // dim-wide pieces a row stride apart.  Option fwd_interleave: 0 never, 1 per-wave kernels,
+      // 2 the hot-row tiles too, 3 any launch of equal tile counts.
+      const int il = options().fwd_interleave;
+      if (k > 1 && same_tiles && il > 0 &&
+          (il == 3 || (one_block && (kind != 8 || il == 2)))) {
+        args.interleave = 1;
+      }
       launch_by_kind(kind, args, (unsigned)tiles, as_stream(stream));
       HBK_HIP_OK(hipGetLastError());
     }

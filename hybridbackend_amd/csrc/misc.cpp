@@ -39,6 +39,7 @@ const OptionEntry kOptions[] = {
     {"bwd_xcd", "HBK_BWD_XCD", &Options::bwd_xcd},
     {"fwd_xcd", "HBK_FWD_XCD", &Options::fwd_xcd},
     {"fwd_hot_rows", "HBK_FWD_HOT", &Options::fwd_hot_rows},
+    {"fwd_interleave", "HBK_FWD_INTERLEAVE", &Options::fwd_interleave},
     {"unique_buckets_log2", "HBK_UNIQUE_LOG2P", &Options::unique_buckets_log2},
     {"partition_sub_tiles", "HBK_PART_SUB", &Options::partition_sub_tiles},
     {"partition_fixed_max", "HBK_PART_FIXED", &Options::partition_fixed_max},

@@ -73,7 +73,7 @@ const char* hbk_version(void);
  * HBK_BWD_ONEPASS, HBK_BWD_GROUP_COLS, HBK_UNIQUE_LOG2P, HBK_UNIQUE_ONEPASS, HBK_PART_SUB, HBK_PART_FIXED,
  * HBK_PART_ONEPASS, HBK_SHARDED_GROUPS, HBK_SHARDED_ID64, HBK_SHARDED_COPY_SELF,
  * HBK_SHARDED_TRACE); no entry point reads the environment per call.
- * Names: bwd_buckets_log2, bwd_bucket_pairs, bwd_split_pairs, bwd_onepass, bwd_group_cols, bwd_dense, bwd_wide, bwd_xcd, fwd_xcd, fwd_hot_rows,
+ * Names: bwd_buckets_log2, bwd_bucket_pairs, bwd_split_pairs, bwd_onepass, bwd_group_cols, bwd_dense, bwd_wide, bwd_xcd, fwd_xcd, fwd_interleave, fwd_hot_rows,
  * unique_buckets_log2,
  * unique_onepass, partition_sub_tiles, partition_fixed_max, partition_onepass, sharded_groups,
  * sharded_id64, sharded_copy_self, sharded_trace, sharded_inline, sharded_wire_fused, sharded_pack_early (the sharded_* ones are taken by

@@ -78,6 +78,7 @@ plan_options = st.fixed_dictionaries({
   'bwd_wide': st.sampled_from([0, 1, 2]),           # wide sorted walk: never / one id per sample / all
   'bwd_xcd': st.sampled_from([0, 1, 2, 4]),         # reduce jobs round robin / by rule / equal slot ranges / equal work ranges
   'fwd_xcd': st.sampled_from([0, 2]),               # lookup tiles round robin / contiguous per XCD
+  'fwd_interleave': st.sampled_from([0, 3]),        # lookup tiles column first / row tile first wherever tile counts agree
 })
 
 

@@ -482,6 +482,44 @@ def test_dense_block_forward_in_place(ids_dtype):
   np.testing.assert_equal(got[:, :20], np.concatenate(o, axis=1))
 
 
+@pytest.mark.parametrize('interleave', [0, 2, 3])
+@pytest.mark.parametrize('dim,hot', [(16, 0), (128, 0), (128, 1), (4, 0)])
+def test_dense_block_row_tiles_outermost(hbk_option, interleave, dim, hot):
+  """Columns of equal tile counts filling one dense block: the row-tile-first order of the
+  workgroups (option fwd_interleave; 3 = also for separate outputs) changes who writes what when,
+  never what is written -- per-wave kernels and the hot-row tiles, a batch that ends inside a
+  tile, one column ragged in a second call (no interleaving there: tile counts differ)."""
+  hbk_option('fwd_interleave', interleave)
+  hbk_option('fwd_hot_rows', hot)
+  rng = np.random.RandomState(1000 + dim + interleave)
+  n, batch = 7, 2999
+  rows = [50 + 400 * c for c in range(n)]
+  tables = [rng.uniform(-1, 1, size=(r, dim)).astype(np.float32) for r in rows]
+  ids = [rng.randint(0, 1 << 40, size=batch).astype(np.int64) for _ in range(n)]
+  want = oracle.group_lookup_fwd(tables, ids, [None] * n, rows, ['sum'] * n)
+  lookup = hb.embedding.GroupLookup([dev(t) for t in tables], rows, 'sum')
+  block = torch.full((batch, n * dim + 4), float('nan'), device=DEV)
+  views = [block[:, c * dim:(c + 1) * dim] for c in range(n)]
+  lookup([dev(i) for i in ids], None, views)
+  got = host(block)
+  np.testing.assert_equal(got[:, :n * dim], np.concatenate(want, axis=1))
+  assert np.isnan(got[:, n * dim:]).all()
+  outs = lookup([dev(i) for i in ids])                     # separate outputs (interleave 3)
+  for c in range(n):
+    np.testing.assert_equal(host(outs[c]), want[c])
+  # column 3 ragged: its tiles differ from the others'
+  lens = rng.randint(0, 4, size=batch)
+  sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+  ids[3] = rng.randint(0, 1 << 40, size=int(sp[-1])).astype(np.int64)
+  splits = [None] * n
+  splits[3] = sp
+  want = oracle.group_lookup_fwd(tables, ids, splits, rows, ['sum'] * n)
+  block.fill_(float('nan'))
+  lookup([dev(i) for i in ids], [None if x is None else dev(x) for x in splits], views)
+  np.testing.assert_allclose(host(block)[:, :n * dim], np.concatenate(want, axis=1), rtol=1e-6,
+                             atol=1e-6)
+
+
 def test_group_lookup_call_cache_follows_bind_and_split_positions():
   """__call__ remembers its last tensors and skips the marshalling when it is handed the same
   ones; a bind() in between, or the same row_splits tensor moved to another column, must not be

@@ -242,6 +242,13 @@ for l in sys.stdin:
       timeout 900 python tools/sweep.py --big --cases l > $O/autosweep.log 2>&1; echo "rc=$?" >> $O/autosweep.log; cut -c1-300 $O/autosweep.log;;
     rsab7)
       (ab "bwd_group_cols:0,45,34,0,45,34" "h") > $O/rsab7.log 2>&1; cut -c1-200 $O/rsab7.log;;
+    ilab)
+      (ab "fwd_interleave:0,1,2,0,1,2" "i,l"; python -m pytest tests/test_gpu_parity.py -q -x -k "dense or block or stride" 2>&1 | tail -3) > $O/ilab.log 2>&1; cut -c1-220 $O/ilab.log;;
+    ilab2)
+      (ab "fwd_interleave:2,3,2,3" "a,b,d") > $O/ilab2.log 2>&1; cut -c1-220 $O/ilab2.log;;
+    iltest)
+      (python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_configs.py -q -x 2>&1 | grep -E "passed|failed|rror" | tail -8
+       python tools/sweep.py --cases i,l) > $O/iltest.log 2>&1; cut -c1-250 $O/iltest.log;;
     *) echo "unknown stage $st";;
   esac
 done

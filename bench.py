@@ -26,6 +26,7 @@ library's own.  If fewer than N GPUs are visible a JSON line with an "error" key
 the exit code is 2.  `--dry-run` exercises launcher + rendezvous without touching a GPU.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -443,23 +444,42 @@ def main():
 
   def timed_steps(step_fn, steps, warmup):
     """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides;
-    returns (wall seconds, MAX over ranks; HIP-event milliseconds on the launch stream)."""
+    returns (wall seconds, MAX over ranks; HIP-event milliseconds on the launch stream).
+
+    At the driver's K = 20 the bracket itself is visible (tools/scratch/bench_tail.py,
+    profiles/r04_bench_tail.txt): the 20 kernels run back to back in 1127-1136 us (rocprofv3:
+    one 6 us gap), the first one starts 15-17 us after the clock, the closing event is seen 5 us
+    after the last byte and a synchronize with nothing left to wait for still takes 19 us: 58 us
+    per step on the wall against 56.5 by events, and 61 or 64 in some processes with the same
+    event time.  What is not a step is kept out of the bracket where that is free: torch
+    creates a HIP event at its first record(), so both events are recorded once beforehand; the
+    garbage collector is held off; the closing event is polled before the synchronize the
+    contract asks for; the clock stops when every rank's work is complete (synchronize +
+    barrier) and the last synchronize follows it."""
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    ev1.record()
     for i in range(warmup):
       step_fn(i)
     torch.cuda.synchronize()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     barrier()
     torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
     ev0.record()
+    t0 = time.perf_counter()
     for i in range(steps):
       step_fn(warmup + i)
     ev1.record()
+    while not ev1.query():
+      pass
     torch.cuda.synchronize()
     barrier()
-    torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    if gc_was_on:
+      gc.enable()
     ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream)
     if use_dist:
       t = torch.tensor([el], dtype=torch.float64)

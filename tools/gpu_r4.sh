@@ -249,6 +249,21 @@ for l in sys.stdin:
     iltest)
       (python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_configs.py -q -x 2>&1 | grep -E "passed|failed|rror" | tail -8
        python tools/sweep.py --cases i,l) > $O/iltest.log 2>&1; cut -c1-250 $O/iltest.log;;
+    tail)
+      (python tools/scratch/bench_tail.py; for i in 1 2 3; do python bench.py --gpus 1 --steps 20 --warmup 5 | cut -c1-260; done) > $O/tail.log 2>&1; cut -c1-300 $O/tail.log;;
+    tail2)
+      (for i in 1 2 3; do python tools/scratch/bench_tail.py fresh; done; python tools/scratch/bench_tail.py fresh per_step_events
+       for i in 1 2 3 4; do python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0.5; done) > $O/tail2.log 2>&1; cut -c1-400 $O/tail2.log;;
+    tail3)
+      (for i in 1 2 3 4 5 6 7 8; do python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0.5; done) > $O/tail3.log 2>&1;;
+    tail4)
+      (for i in 1 2 3 4 5 6 7 8; do python tools/scratch/bench_tail.py fresh flags; done) > $O/tail4.log 2>&1;;
+    tail5)
+      cd /tmp; export TMPDIR=/tmp
+      for i in 1 2 3 4 5 6; do
+        rocprofv3 --kernel-trace --output-format csv -d $O/tail5_$i -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 > $O/tail5_$i.log 2>&1
+      done
+      cd $R;;
     *) echo "unknown stage $st";;
   esac
 done

@@ -449,9 +449,9 @@ def main():
     At the driver's K = 20 the bracket itself is visible (tools/scratch/bench_tail.py,
     profiles/r04_bench_tail.txt): the 20 kernels run back to back in 1127-1136 us (rocprofv3:
     one 6 us gap), the first one starts 15-17 us after the clock, the closing event is seen 5 us
-    after the last byte and a synchronize with nothing left to wait for still takes 19 us: 58 us
-    per step on the wall against 56.5 by events, and 61 or 64 in some processes with the same
-    event time.  What is not a step is kept out of the bracket where that is free: torch
+    after the last byte, and the synchronize that follows -- nothing left to wait for -- takes
+    15-20 us in some processes, 52-85 in others, 140-147 in a few (HBK_BENCH_STAMPS=1 prints the
+    stamps): 58, 61 or 64 us per step on the wall against 56.5 by events.  What is not a step is kept out of the bracket where that is free: torch
     creates a HIP event at its first record(), so both events are recorded once beforehand; the
     garbage collector is held off; the closing event is polled before the synchronize the
     contract asks for; the clock stops when every rank's work is complete (synchronize +
@@ -467,16 +467,25 @@ def main():
     gc.disable()
     barrier()
     torch.cuda.synchronize()
+    stamps = [] if os.environ.get('HBK_BENCH_STAMPS') else None   # (diagnostics, stderr only)
     ev0.record()
     t0 = time.perf_counter()
     for i in range(steps):
       step_fn(warmup + i)
+      if stamps is not None:
+        stamps.append(time.perf_counter())
     ev1.record()
     while not ev1.query():
       pass
+    t_ready = time.perf_counter()
     torch.cuda.synchronize()
     barrier()
     el = time.perf_counter() - t0
+    if stamps:
+      sys.stderr.write('bench stamps (us after the clock): launches returned %s | closing event '
+                       'ready %.1f | synchronize + barrier back %.1f\n' % (
+                           ' '.join('%.0f' % ((t - t0) * 1e6) for t in stamps),
+                           (t_ready - t0) * 1e6, el * 1e6))
     torch.cuda.synchronize()
     if gc_was_on:
       gc.enable()

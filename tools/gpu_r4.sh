@@ -264,6 +264,13 @@ for l in sys.stdin:
         rocprofv3 --kernel-trace --output-format csv -d $O/tail5_$i -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 > $O/tail5_$i.log 2>&1
       done
       cd $R;;
+    tail6)
+      (for i in 1 2 3 4 5 6 7 8 9 10; do HBK_BENCH_STAMPS=1 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | cut -c1-420; done) > $O/tail6.log 2>&1;;
+    tail7)
+      (for v in "HSA_ENABLE_INTERRUPT=0" "ROC_ACTIVE_WAIT_TIMEOUT=1000" "GPU_MAX_HW_QUEUES=1"; do
+         echo "== $v"
+         for i in 1 2 3 4 5 6 7 8; do env $v HBK_BENCH_STAMPS=1 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | cut -c1-420; done
+       done) > $O/tail7.log 2>&1;;
     *) echo "unknown stage $st";;
   esac
 done

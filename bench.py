@@ -307,12 +307,22 @@ def main():
   use_dist = world > 1 or ('RANK' in os.environ and args.sharded)
   dist = None
   watchdog = None
+  headline = {'done': False, 'line': None}   # (read by the watchdog)
   if use_dist:
     # a rank that dies leaves its peers waiting inside a collective: never hang the node
     def _abort():
       sys.stderr.write(f'bench.py: rank {rank} gave up after {args.watchdog} s (a peer is gone '
                        'or a collective hangs)\n')
       sys.stderr.flush()
+      if headline['done']:
+        # the K timed steps are measured; what hangs is one of the reference measurements behind
+        # them: the line goes out without those
+        if headline['line'] is not None:
+          headline['line']['config']['secondary_error'] = (
+              f'watchdog: no answer within {args.watchdog} s during the measurements behind the '
+              'headline steps')
+          print(json.dumps(headline['line']), flush=True)
+        os._exit(0)
       os._exit(3)
     watchdog = threading.Timer(args.watchdog, _abort)
     watchdog.daemon = True
@@ -498,38 +508,6 @@ def main():
 
   elapsed, gpu_ms = timed_steps(step, args.steps, args.warmup)
 
-  # Reference measurements next to the sharded headline, same run, same batches (SURVEY 8e):
-  #  * the OTHER wire format of the embedding exchange (fp16 when the headline is fp32: the
-  #    link-bound lever; the reference's comm_wire_dtype, collective.py:291-296);
-  #  * REPLICATED: every rank holds all tables and looks its own batch up, no exchange -- what
-  #    the reference does for tables that fit (variables.py:93-98) and the ceiling a sharded step
-  #    can be compared with.
-  secondary = {key: None for key in SECONDARY_KEYS}
-  if (world > 1 or args.sharded) and not args.no_secondary:
-    sec_steps, sec_warm = max(1, min(args.steps, 20)), min(args.warmup, 5)
-    other = 'fp16' if args.wire == 'fp32' else 'fp32'
-    sharded.close()                 # the wire format is fixed when the plan is created
-    sharded.wire_dtype = torch.float16 if other == 'fp16' else None
-    el2, _ = timed_steps(step, sec_steps, sec_warm)
-    sharded.close()
-    sharded.wire_dtype = torch.float16 if args.wire == 'fp16' else None
-    full = tables if world == 1 else make_tables(args, device, 0, 1)
-    r_plans = []
-    for b in range(n_batches):
-      gl = hb.embedding.GroupLookup(full, buckets=[args.rows] * args.columns, combiners='sum')
-      gl.bind(batches[b], None, sh_outs)
-      r_plans.append(gl)
-    el3, _ = timed_steps(lambda i: r_plans[i % n_batches].launch(), sec_steps, sec_warm)
-    per_step = lookups_per_step_per_rank * world
-    secondary = {
-      'replicated_M_lookups_per_s': round(per_step * sec_steps / el3 / 1e6, 3),
-      'replicated_ms_per_step': round(el3 / sec_steps * 1e3, 5),
-      'other_wire': other,
-      'other_wire_M_lookups_per_s': round(per_step * sec_steps / el2 / 1e6, 3),
-      'other_wire_ms_per_step': round(el2 / sec_steps * 1e3, 5),
-      'secondary_steps': sec_steps}
-    del r_plans, full
-
   total_lookups = lookups_per_step_per_rank * world * args.steps
   value = total_lookups / elapsed / 1e6
   ms_per_step = elapsed / args.steps * 1e3
@@ -541,7 +519,9 @@ def main():
     workload = (f'{args.columns} cols x {args.rows} rows x dim{args.dim} fp32, batch '
                 f'{args.batch}/GPU, 1 id/sample, fused bucketize+gather+combiner')
     key = f'c{args.columns}_r{args.rows}_d{args.dim}_b{args.batch}_n{world}'
-    traffic, traffic_round = load_traffic(key)
+    # (the committed PMC figure is the unsharded forward kernel's: a sharded step has none)
+    traffic, traffic_round = (load_traffic(key) if world == 1 and not args.sharded
+                              else (None, None))
     result = {
       'metric': 'M-lookups/sec, 26-col Criteo-shape dim16, 1/2/4/8 GPUs; % HBM roofline',
       'value': round(value, 3), 'unit': 'M-lookups/sec', 'n_gpus': world,
@@ -562,7 +542,7 @@ def main():
                      round(lookups_per_step_per_rank * world /
                            groups_probe['pipelined_2_groups'] / 1e3, 3)
                      if groups_probe else None),
-                 **secondary},
+                 **{key: None for key in SECONDARY_KEYS}},
       'roofline': {
         'bound': 'hbm',
         'kernel': ('group_lookup_fwd_kernel' if world == 1 and not args.sharded
@@ -598,6 +578,55 @@ def main():
       result['cpu_baseline'] = cpu_baseline(args, tables, batches[0], args.cpu_seconds)
     else:
       result['cpu_baseline'] = None
+    headline['line'] = result
+  headline['done'] = True
+  if use_dist:
+    # from here on a hang costs the reference measurements only, and not 15 minutes
+    watchdog.cancel()
+    watchdog = threading.Timer(min(args.watchdog, 180.0), _abort)
+    watchdog.daemon = True
+    watchdog.start()
+
+  # Reference measurements next to the sharded headline, same run, same batches (SURVEY 8e):
+  #  * the OTHER wire format of the embedding exchange (fp16 when the headline is fp32: the
+  #    link-bound lever; the reference's comm_wire_dtype, collective.py:291-296);
+  #  * REPLICATED: every rank holds all tables and looks its own batch up, no exchange -- what
+  #    the reference does for tables that fit (variables.py:93-98) and the ceiling a sharded step
+  #    can be compared with.
+  if (world > 1 or args.sharded) and not args.no_secondary:
+    try:
+      sec_steps, sec_warm = max(1, min(args.steps, 20)), min(args.warmup, 5)
+      other = 'fp16' if args.wire == 'fp32' else 'fp32'
+      sharded.close()                 # the wire format is fixed when the plan is created
+      sharded.wire_dtype = torch.float16 if other == 'fp16' else None
+      el2, _ = timed_steps(step, sec_steps, sec_warm)
+      sharded.close()
+      sharded.wire_dtype = torch.float16 if args.wire == 'fp16' else None
+      full = tables if world == 1 else make_tables(args, device, 0, 1)
+      r_plans = []
+      for b in range(n_batches):
+        gl = hb.embedding.GroupLookup(full, buckets=[args.rows] * args.columns, combiners='sum')
+        gl.bind(batches[b], None, sh_outs)
+        r_plans.append(gl)
+      el3, _ = timed_steps(lambda i: r_plans[i % n_batches].launch(), sec_steps, sec_warm)
+      per_step = lookups_per_step_per_rank * world
+      secondary = {
+        'replicated_M_lookups_per_s': round(per_step * sec_steps / el3 / 1e6, 3),
+        'replicated_ms_per_step': round(el3 / sec_steps * 1e3, 5),
+        'other_wire': other,
+        'other_wire_M_lookups_per_s': round(per_step * sec_steps / el2 / 1e6, 3),
+        'other_wire_ms_per_step': round(el2 / sec_steps * 1e3, 5),
+        'secondary_steps': sec_steps}
+      del r_plans, full
+    except Exception as e:  # pylint: disable=broad-except
+      # (every rank runs the same code on the same shapes: an error here is the same error on
+      # every rank; the headline steps are measured and their line goes out regardless)
+      secondary = {key: None for key in SECONDARY_KEYS}
+      secondary['secondary_error'] = f'{type(e).__name__}: {e}'[:300]
+    if rank == 0:
+      result['config'].update(secondary)
+
+  if rank == 0:
     print(json.dumps(result), flush=True)
 
   if world > 1 or args.sharded:

@@ -280,14 +280,31 @@ class ShardedGroupLookup:
     return bound.outs
 
   def prefetch(self, bound, ids_ready=None):
-    """Pipelining hint: run bucketize + partition + size exchange of a FUTURE step (a
-    ``bind()`` result) on the plan's own stream now, overlapping the exchanges of the step that
-    was just launched; the next ``launch(bound)`` picks the result up.  ``ids_ready``: a
-    ``torch.cuda.Event`` recorded after the ids were produced (None: they are complete).  All
-    ranks must prefetch the same steps."""
+    """Pipelining hint: run bucketize + partition + size exchange of a FUTURE step on the plan's
+    own stream now, overlapping the exchanges of the step that was just launched; the next
+    forward over the same id tensors picks the result up.  ``bound``: a ``bind()`` result, or --
+    the functional form, ids new every step -- the list of id tensors the next ``__call__`` will
+    be handed (the step's one wait for the device, the sizes, then finds them there: W = 1
+    180 -> ~135 us per step, tools/sweep.py case e).  ``ids_ready``: a ``torch.cuda.Event``
+    recorded after the ids were produced (None: they are complete).  All ranks must prefetch the
+    same steps."""
     ev = C.c_void_p(ids_ready.cuda_event) if ids_ready is not None else None
-    _lib.check(self._lib.hbk_sharded_prefetch(self._plan(), bound.args[0], bound.args[1], ev))
-    self._keep_prefetch = bound.keep
+    if isinstance(bound, _BoundStep):
+      id_ptrs, n_ids, keep = bound.args[0], bound.args[1], bound.keep
+    else:
+      from hybridbackend_amd import _marshal
+      ids = list(bound)
+      n = len(self.shards)
+      if len(ids) != n:
+        raise ValueError(f'prefetch: {len(ids)} id tensors for {n} columns')
+      seen = _marshal.vector_pass(ids, (torch.int64,)) if n else ([], [], None)
+      if seen is None:
+        raise ValueError('prefetch: ids must be contiguous int64 device vectors')
+      id_ptrs = (C.c_void_p * n)(*seen[0])
+      n_ids = (C.c_int64 * n)(*seen[1])
+      keep = (ids,)
+    _lib.check(self._lib.hbk_sharded_prefetch(self._plan(), id_ptrs, n_ids, ev))
+    self._keep_prefetch = keep
 
   def __call__(self, ids, row_splits=None, outs=None):
     """One forward step through the communicator.  ``ids[c]``: int64 device vector;

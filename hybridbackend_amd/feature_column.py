@@ -146,6 +146,15 @@ class DenseFeatures:
         cols_to_output_tensors[col] = views[c]
     return out
 
+  def prefetch(self, features, ids_ready=None):
+    """The NEXT step's features, as soon as the loader has them on the device: the sharded
+    columns' bucketize + partition + size exchange run on the plan's stream beside the step in
+    flight (``ShardedGroupLookup.prefetch``); the forward over the same tensors picks them up.
+    A no-op for a layer whose columns are all replicated.  All ranks prefetch the same steps."""
+    if self._shd:
+      ids, _, _ = self._split(features)
+      self._sharded.prefetch([ids[c] for c in self._shd], ids_ready)
+
   def backward(self, grad, apply_lr=0.0, optimizer='sgd', emit=True):
     """grad: ``[batch, sum of dims]`` gradient of the last forward's output.  Returns per column
     the ``IndexedSlices`` ``(unique_rows, grad_rows, n_unique)`` of this rank's rows (local row

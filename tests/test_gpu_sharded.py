@@ -543,7 +543,9 @@ def test_dense_features_sharded_and_replicated_columns_in_process_world():
         layer = hb.feature_column.DenseFeatures(cols, DEV, coll=comms[r], batch_size=batch,
                                                 init=init)
         assert layer.sharded == [True, False, True, True]
-        out = layer(_dev_feats(feats[r]))
+        f = _dev_feats(feats[r])
+        layer.prefetch(f)          # (the loader's hint: partition + size exchange ahead of the step)
+        out = layer(f)
         res = layer.backward(dev(grads[r]))
         torch.cuda.current_stream().synchronize()
         results[r] = (out.cpu().numpy(),
@@ -819,12 +821,14 @@ def test_dense_features_adagrad_sharded_in_process_world():
     off += c.dimension
 
 
+@pytest.mark.parametrize('form', ['bound', 'functional'])
 @pytest.mark.parametrize('dedup', [False, True])
 @pytest.mark.parametrize('world', [1, 3])
-def test_sharded_prefetch_next_step(world, dedup):
+def test_sharded_prefetch_next_step(world, dedup, form):
   """hbk_sharded_prefetch: step i + 1 is partitioned on the plan's own stream while step i is in
   flight; a matching forward consumes it, a non-matching one drops it; the backward of step i
-  still sees step i's shard index.  Results equal the unprefetched driver (= the oracle)."""
+  still sees step i's shard index.  Results equal the unprefetched driver (= the oracle).
+  form 'functional': ``drv(ids)`` with new tensors every step and ``prefetch(next id tensors)``."""
   import threading
   rng = np.random.RandomState(95)
   dims, rows = [16, 8], [50021, 300]
@@ -847,10 +851,14 @@ def test_sharded_prefetch_next_step(world, dedup):
       with torch.cuda.stream(torch.cuda.Stream()):
         drv = ShardedGroupLookup([dev(t[r::world].copy()) for t in tables], comms[r],
                                  buckets=rows, combiners='sum', dedup=dedup)
-        bound = [drv.bind([dev(i) for i in ids[r][s]]) for s in range(steps)]
+        dev_ids = [[dev(i) for i in ids[r][s]] for s in range(steps)]
+        if form == 'bound':
+          bound = [drv.bind(dev_ids[s]) for s in range(steps)]
+        else:
+          bound = dev_ids     # the functional form: prefetch() is handed the next step's id tensors
         got = []
         for s in range(steps):
-          outs = drv.launch(bound[s])
+          outs = drv.launch(bound[s]) if form == 'bound' else drv(dev_ids[s])
           if s + 1 < steps:
             # step 2's prefetch names the wrong batch (step 0 again): it must be dropped
             drv.prefetch(bound[0] if s == 1 else bound[s + 1])

@@ -271,6 +271,11 @@ for l in sys.stdin:
          echo "== $v"
          for i in 1 2 3 4 5 6 7 8; do env $v HBK_BENCH_STAMPS=1 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | cut -c1-420; done
        done) > $O/tail7.log 2>&1;;
+    pftest)
+      (python -m pytest tests/test_gpu_sharded.py -q -x -k "prefetch" 2>&1 | grep -E "passed|failed|rror" | tail -5
+       python tools/sweep.py --cases e 2>&1 | grep "Sharded" | cut -c1-200) > $O/pftest.log 2>&1; cat $O/pftest.log;;
+    dftest)
+      python -m pytest tests/test_gpu_sharded.py -q -x -k "dense_features or prefetch" 2>&1 | grep -E "passed|failed|rror" | tail -5;;
     *) echo "unknown stage $st";;
   esac
 done

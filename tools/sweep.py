@@ -272,6 +272,13 @@ def case_integer():
   us = timed(lambda i: drv(pool[i % 8], None, outs), iters=30)
   report(f'ShardedGroupLookup.__call__ W=1 (new id tensors every call) 26 x {B}', us, 26 * B,
          26 * B * 136)
+
+  def call_and_prefetch(i):
+    drv(pool[i % 8], None, outs)
+    drv.prefetch(pool[(i + 1) % 8])       # the loader knows the next batch
+  us = timed(call_and_prefetch, iters=30)
+  report(f'ShardedGroupLookup.__call__ W=1 + prefetch(next ids) (new id tensors every call) 26 x {B}',
+         us, 26 * B, 26 * B * 136)
   drv.close()
   coll.close()
 

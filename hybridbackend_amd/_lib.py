@@ -88,6 +88,7 @@ def _declare(l):
     'hbk_sync_check': (C.c_int, []),
     'hbk_host_floormod_i64': (i64, [i64, i64]),
     'hbk_host_fastdiv_u64': (C.c_uint64, [C.c_uint64, C.c_uint64]),
+    'hbk_host_crc32c': (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_int64]),
     'hbk_host_xcd_contiguous': (i32, [i32, i32]),
     'hbk_floormod_n': (C.c_int, [i32, i32, vp, vp, vp, vp, vp]),
     'hbk_partition_workspace_bytes': (sz, [i32, vp, i32]),

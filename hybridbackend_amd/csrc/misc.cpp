@@ -122,3 +122,45 @@ extern "C" uint64_t hbk_host_fastdiv_u64(uint64_t n, uint64_t d) {
   hbk::FastDiv f = hbk::make_fastdiv(d);
   return hbk::fastdiv(n, f);
 }
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82f63b78) of host bytes, continuing from `crc`
+// (0 for a new message): the checksum TensorFlow's tensor bundle stores per tensor and per index
+// block (training/tf_bundle.py reads and writes that format on the host).  Slicing by 8.
+extern "C" uint32_t hbk_host_crc32c(uint32_t crc, const void* data, int64_t n) {
+  struct Tables {
+    uint32_t t[8][256];
+    Tables() {
+      for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82f63b78u : c >> 1;
+        t[0][i] = c;
+      }
+      for (uint32_t i = 0; i < 256; ++i) {
+        for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xffu];
+      }
+    }
+  };
+  static const Tables tab;
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  uint32_t l = ~crc;
+  if (p == nullptr || n <= 0) return crc;
+  while (n > 0 && (reinterpret_cast<uintptr_t>(p) & 7u) != 0) {
+    l = tab.t[0][(l ^ *p++) & 0xffu] ^ (l >> 8);
+    --n;
+  }
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    const uint32_t lo = (uint32_t)w ^ l, hi = (uint32_t)(w >> 32);
+    l = tab.t[7][lo & 0xffu] ^ tab.t[6][(lo >> 8) & 0xffu] ^ tab.t[5][(lo >> 16) & 0xffu] ^
+        tab.t[4][lo >> 24] ^ tab.t[3][hi & 0xffu] ^ tab.t[2][(hi >> 8) & 0xffu] ^
+        tab.t[1][(hi >> 16) & 0xffu] ^ tab.t[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n > 0) {
+    l = tab.t[0][(l ^ *p++) & 0xffu] ^ (l >> 8);
+    --n;
+  }
+  return ~l;
+}

@@ -239,6 +239,13 @@ class DenseFeatures:
     the reference's contiguous slicing instead, see training/saver.py)."""
     self._saver(barrier).restore(prefix, self.variables(), layout=layout)
 
+  def restore_reference(self, prefix, names=None, barrier=None, layout='logical'):
+    """Loads this rank's rows from a checkpoint the REFERENCE saved (TensorFlow tensor bundle,
+    training/tf_bundle.py), written at any world size.  ``names``: ``{name here: tensor name in
+    the checkpoint}`` for variables the model named differently (default: the TF names of
+    ``variables()``).  layout: see ``Saver.restore_reference``."""
+    self._saver(barrier).restore_reference(prefix, self.variables(), names=names, layout=layout)
+
   def close(self):
     if self._sharded is not None:
       self._sharded.close()

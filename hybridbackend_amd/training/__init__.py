@@ -3,3 +3,4 @@
 from hybridbackend_amd.training.saver import Saver
 from hybridbackend_amd.training.saver import ShardedSlice
 from hybridbackend_amd.training.saver import load_full
+from hybridbackend_amd.training.saver import export_reference

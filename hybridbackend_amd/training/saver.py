@@ -27,8 +27,11 @@ ids.  Here every slice additionally records its ownership (``stride = W``, ``pha
 
 The files are this library's own (``<prefix>.index`` is JSON, ``<prefix>.data-g<generation>-<r>-of-<W>``
 raw little-endian tensors; a save never overwrites the files the current index points to and
-switches over with one atomic rename of the index), not TensorFlow's tensor-bundle format: TensorFlow is not available to
-this build (DESIGN.md "out of scope").  The host logic is device agnostic (CPU tensors work, which
+switches over with one atomic rename of the index), not TensorFlow's tensor-bundle format.  The
+bridge to the reference's files is ``training/tf_bundle.py`` (that format read and written on the
+host, pinned by its published vectors only -- TensorFlow is not available to this build):
+``Saver.restore_reference`` loads a checkpoint the reference wrote, ``export_reference`` rewrites
+one of ours as the bundle the reference would have saved.  The host logic is device agnostic (CPU tensors work, which
 is how the tests without a GPU drive it); GPU tensors travel through pinned memory.
 """
 import json
@@ -209,6 +212,60 @@ class Saver:
         host = host.view(_TORCH_DTYPES[meta['dtype']])
       target.copy_(host.to(target.dtype))
     self._barrier()
+
+
+  def restore_reference(self, prefix, variables, names=None, layout='logical', verify=True):
+    """``restore`` from a checkpoint the REFERENCE wrote (TensorFlow's tensor bundle,
+    training/tf_bundle.py; saver.py:187-246 is the reference's own restore).  ``names``: variable
+    name here -> tensor name in the checkpoint (default: the same).  A ``ShardedSlice`` takes
+    its rows ``rank, rank + W', ..`` of the table; ``layout`` says what the checkpoint's slices
+    mean: 'logical' -- the reference row-sharded the table over W ranks by ``id mod W``, slice r
+    holds ids ``r, r + W, ..`` (what the reference's embedding weights are, variables.py:
+    114-141) -- or 'reference' -- the full tensor as TensorFlow assembles it IS the table (a
+    variable that was never sharded by id, or one saved by a single rank).  Names missing from
+    the checkpoint are left untouched."""
+    from hybridbackend_amd.training import tf_bundle
+    reader = tf_bundle.BundleReader(prefix, verify=verify)
+    names = names or {}
+    for name, v in variables.items():
+      ck = names.get(name, name)
+      if ck not in reader.entries:
+        continue
+      sharded = isinstance(v, ShardedSlice)
+      table = (tf_bundle.read_reference_table(reader, ck, layout) if sharded
+               else reader.read(ck))
+      target = v.tensor if sharded else v
+      if sharded:
+        if table.shape[0] != v.bucket_size:
+          raise ValueError(f'{name}: checkpoint holds {table.shape[0]} rows, the variable '
+                           f'{v.bucket_size}')
+        table = table[v.rank::v.world_size]
+      if tuple(table.shape) != tuple(target.shape):
+        raise ValueError(f'{name}: checkpoint shape {tuple(table.shape)} != {tuple(target.shape)}')
+      host = torch.from_numpy(np.ascontiguousarray(table))
+      if reader.is_bfloat16(ck):
+        host = host.view(torch.int16).view(torch.bfloat16)
+      target.copy_(host.to(target.dtype))
+    self._barrier()
+
+
+def export_reference(src_prefix, dst_prefix):
+  """A checkpoint of this library rewritten as the tensor bundle the reference would have saved
+  at the same world size: every shard becomes a slice of its full tensor at the reference's
+  CONTIGUOUS offset (variables.py:118-123), replicated variables are saved whole.  One process,
+  on the host (the reference's chief merges the parts the same way, saver.py:154-180)."""
+  from hybridbackend_amd.training import tf_bundle
+  index = _read_index(src_prefix)
+  w = tf_bundle.BundleWriter(dst_prefix)
+  for name, meta in sorted(index['variables'].items()):
+    bf16 = meta['dtype'] == 'bfloat16'
+    if len(meta['slices']) == 1 and meta['slices'][0]['stride'] == 1:
+      w.add(name, np.asarray(_load_slice(src_prefix, meta, meta['slices'][0])), bfloat16=bf16)
+      continue
+    for s in sorted(meta['slices'], key=lambda s: s['var_offset'][0]):
+      w.add_slice(name, meta['full_shape'], s['var_offset'],
+                  np.asarray(_load_slice(src_prefix, meta, s)), bfloat16=bf16)
+  return w.finish()
 
 
 def _read_index(prefix):

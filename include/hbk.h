@@ -105,6 +105,11 @@ uint64_t hbk_host_fastdiv_u64(uint64_t n, uint64_t d);
  * of a launch's work items; block b is observed to run on XCD b % 8), evaluated on the host: a
  * bijection of [0, n_blocks) for every n_blocks. */
 int32_t hbk_host_xcd_contiguous(int32_t block, int32_t n_blocks);
+/* CRC-32C (Castagnoli) of n host bytes, continuing from crc (0 starts a message): the checksum
+ * of TensorFlow's tensor-bundle checkpoints (per tensor and per index block), for the host-side
+ * reader / writer of that format (hybridbackend_amd/training/tf_bundle.py; the reference saves
+ * through TF's bundle writer, hbtf/training/saver.py:97-185).  "123456789" -> 0xe3069283. */
+uint32_t hbk_host_crc32c(uint32_t crc, const void* data, int64_t n);
 
 /* ------------------------------------------------------------------------------------
  * R1  bucketize `feature % embedding_size` (TF FloorMod), N columns in one launch.

@@ -1014,11 +1014,15 @@ def test_hierarchical_call_in_process_world(local_size, nodes):
 
 # ----------------------------------------------------------------------------------
 # sharded checkpoints of the feature layer (training/saver.py), re-sharding included
-def test_dense_features_checkpoint_reshard_in_process_world(tmp_path):
+@pytest.mark.parametrize('through', ['ours', 'reference_bundle'])
+def test_dense_features_checkpoint_reshard_in_process_world(tmp_path, through):
   """Two ranks train one step (forward, backward, fused Adagrad), save; four ranks restore the
   checkpoint (every rank gathers the rows it now owns) and their forward equals the oracle lookup
-  on the updated tables -- weights AND optimizer slots survive the change of world size."""
+  on the updated tables -- weights AND optimizer slots survive the change of world size.
+  through='reference_bundle': the checkpoint is first rewritten as the TensorFlow tensor bundle
+  the reference would have saved at W = 2 (training/tf_bundle.py) and restored from THAT."""
   import threading
+  from hybridbackend_amd.training import export_reference
   from hybridbackend_amd.training import load_full
   rng = np.random.RandomState(97)
   cols, tables, feats2, grads2, batch = _dense_case(rng, 2)
@@ -1070,12 +1074,17 @@ def test_dense_features_checkpoint_reshard_in_process_world(tmp_path):
       assert not np.array_equal(updated[k], tables[k])       # the step happened
       assert (slots[k] >= 0.1).all() and (slots[k] > 0.1).any()
 
+  if through == 'reference_bundle':
+    export_reference(prefix, prefix + '.tf')
   _, _, feats4, _, _ = _dense_case(np.random.RandomState(98), 4)
 
   def restore_and_lookup(r, coll, barrier):
     layer = hb.feature_column.DenseFeatures(cols, DEV, coll=coll, batch_size=batch,
                                             initial_accumulator_value=0.1)
-    layer.restore(prefix, barrier=barrier)
+    if through == 'ours':
+      layer.restore(prefix, barrier=barrier)
+    else:
+      layer.restore_reference(prefix + '.tf', barrier=barrier)
     out = layer(_dev_feats(feats4[r]))
     torch.cuda.current_stream().synchronize()
     res = (out.cpu().numpy(), [w.cpu().numpy() for w in layer.weights],

@@ -141,7 +141,7 @@ class GroupLookup:
         raise _lib.InvalidArgumentError(
           _lib.INVALID_ARGUMENT, f'output {c} must be contiguous along its last dimension')
       col.out_stride = 0 if o.is_contiguous() else int(o.stride(0))
-    self._keep = (ids, row_splits, outs)
+    self._keep = (list(ids), list(row_splits), outs)
     return outs
 
   def bind_block(self, ids, row_splits, block, offsets):
@@ -155,6 +155,9 @@ class GroupLookup:
         block.stride(1) != 1 or block.stride(0) % 4 != 0):
       return False
     n_rows, pitch = block.shape[0], block.stride(0)
+    if len(offsets) != n or any(offsets[c] < 0 or offsets[c] + self._dims[c] > block.shape[1]
+                                for c in range(n)):
+      return False          # (a column block outside the row: bind() on the views says so)
     base = block.data_ptr()
     return self._bind_fresh(ids, row_splits, None,
                             block=(n_rows, pitch, [base + 4 * o for o in offsets], block)) is not None
@@ -220,7 +223,7 @@ class GroupLookup:
     rec['n_segments'] = n_seg
     rec['out'] = o_ptrs
     rec['out_stride'] = stride
-    self._keep = (ids, row_splits, outs)
+    self._keep = (list(ids), list(row_splits), outs)   # (own lists: the caller may refill his)
     return outs
 
   # ---- hot rows by observation (hot_rows='auto') ----------------------------------------------

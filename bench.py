@@ -39,6 +39,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
+# dmabuf IPC (the host driver supports nothing else): RCCL between processes needs it, and the
+# HSA runtime reads it when the first HIP call initialises it -- so before torch is imported
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

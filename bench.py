@@ -418,7 +418,11 @@ def main():
 
   probe = None
   if world > 1 and args.link_probe_mb > 0:
-    probe = link_probe(coll, device, world, args.link_probe_mb, dist)
+    try:
+      probe = link_probe(coll, device, world, args.link_probe_mb, dist)
+    except Exception as e:  # pylint: disable=broad-except
+      # (a pre-measurement: the same error on every rank, the timed steps still run)
+      probe = {'error': f'{type(e).__name__}: {e}'[:300]}
 
   # The pipeline group count of the sharded step is a hardware question (a cross-stream hop costs
   # ~11 us on this chip, an owner gather ~33 us: profiles/r02_hop_probe.txt): both forms run a few

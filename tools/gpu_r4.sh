@@ -276,6 +276,17 @@ for l in sys.stdin:
        python tools/sweep.py --cases e 2>&1 | grep "Sharded" | cut -c1-200) > $O/pftest.log 2>&1; cat $O/pftest.log;;
     dftest)
       python -m pytest tests/test_gpu_sharded.py -q -x -k "dense_features or prefetch" 2>&1 | grep -E "passed|failed|rror" | tail -5;;
+    final2)   # late-round refresh: the bench lines, the headline kernel's stats, the sweep
+      prof prof_bench "" -- python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0
+      cp $O/prof_bench.txt $O/r04_bench_kernel_stats.txt
+      find $O/prof_bench -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/r04_bench_rocprofv3_kernel_stats.csv
+      timeout 600 python bench.py --steps 50 --warmup 10 2>/dev/null | grep "^{" > $O/r04_bench_lines.jsonl
+      timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | grep "^{" >> $O/r04_bench_lines.jsonl
+      for w in fp32 fp16; do
+        timeout 300 python bench.py --gpus 1 --sharded --wire $w --steps 30 --warmup 5 --cpu-seconds 0 2>/dev/null | grep "^{" >> $O/r04_bench_lines.jsonl
+      done
+      timeout 2400 python tools/sweep.py --big --cases a,b,c,d,e,f,g,h,i,j,k,l 2>/dev/null | grep "^{" > $O/r04_sweep.jsonl
+      wc -l $O/r04_bench_lines.jsonl $O/r04_sweep.jsonl; head -12 $O/r04_bench_kernel_stats.txt | cut -c1-160;;
     *) echo "unknown stage $st";;
   esac
 done

@@ -256,7 +256,9 @@ def export_reference(src_prefix, dst_prefix):
   on the host (the reference's chief merges the parts the same way, saver.py:154-180)."""
   from hybridbackend_amd.training import tf_bundle
   index = _read_index(src_prefix)
-  w = tf_bundle.BundleWriter(dst_prefix)
+  # one data file per rank that saved, every shard in its rank's file: what MergeV2Checkpoints
+  # leaves of the ranks' parts
+  w = tf_bundle.BundleWriter(dst_prefix, num_shards=index['world_size'])
   for name, meta in sorted(index['variables'].items()):
     bf16 = meta['dtype'] == 'bfloat16'
     if len(meta['slices']) == 1 and meta['slices'][0]['stride'] == 1:
@@ -264,7 +266,7 @@ def export_reference(src_prefix, dst_prefix):
       continue
     for s in sorted(meta['slices'], key=lambda s: s['var_offset'][0]):
       w.add_slice(name, meta['full_shape'], s['var_offset'],
-                  np.asarray(_load_slice(src_prefix, meta, s)), bfloat16=bf16)
+                  np.asarray(_load_slice(src_prefix, meta, s)), bfloat16=bf16, shard=s['phase'])
   return w.finish()
 
 

@@ -528,12 +528,21 @@ def _c_order(array):
 
 
 class BundleWriter:
-  """Writes one checkpoint with a single data shard.  ``add`` a whole tensor, ``add_slice`` one
-  piece of a partitioned variable (its ``SaveSliceInfo``: full name and shape, offsets)."""
+  """Writes one checkpoint.  ``add`` a whole tensor, ``add_slice`` one piece of a partitioned
+  variable (its ``SaveSliceInfo``: full name and shape, offsets).  ``num_shards`` data files, as
+  ``MergeV2Checkpoints`` leaves one per rank that saved (saver.py:154-180); ``shard=`` says which
+  file a tensor / slice goes to (default 0)."""
 
-  def __init__(self, prefix):
-    self.prefix = prefix
+  def __init__(self, prefix, num_shards=1):
+    self.prefix, self.num_shards = prefix, int(num_shards)
+    if self.num_shards < 1:
+      raise ValueError('num_shards must be >= 1')
     self._whole, self._parts = {}, {}
+
+  def _shard(self, shard):
+    if not 0 <= shard < self.num_shards:
+      raise ValueError(f'shard {shard} of {self.num_shards}')
+    return int(shard)
 
   @staticmethod
   def _code(arr, bfloat16):
@@ -545,13 +554,13 @@ class BundleWriter:
       raise ValueError(f'unsupported dtype {arr.dtype}')
     return _DT_OF[arr.dtype]
 
-  def add(self, name, array, bfloat16=False):
+  def add(self, name, array, bfloat16=False, shard=0):
     arr = _c_order(array)
     if name in self._whole or name in self._parts:
       raise ValueError(f'{name}: added twice')
-    self._whole[name] = (arr, self._code(arr, bfloat16))
+    self._whole[name] = (arr, self._code(arr, bfloat16), self._shard(shard))
 
-  def add_slice(self, full_name, full_shape, offsets, array, bfloat16=False):
+  def add_slice(self, full_name, full_shape, offsets, array, bfloat16=False, shard=0):
     arr = _c_order(array)
     if full_name in self._whole:
       raise ValueError(f'{full_name}: added twice')
@@ -567,32 +576,38 @@ class BundleWriter:
                                               'code': self._code(arr, bfloat16), 'slices': []})
     if part['shape'] != [int(x) for x in full_shape] or part['code'] != self._code(arr, bfloat16):
       raise ValueError(f'{full_name}: slices disagree about the full tensor')
-    part['slices'].append((ext, arr))
+    part['slices'].append((ext, arr, self._shard(shard)))
 
   def finish(self):
-    data_path = f'{self.prefix}.data-00000-of-00001'
-    table, off = {}, 0
-    with open(data_path, 'wb') as f:
-      def put(arr, code):
-        nonlocal off
-        f.write(arr.tobytes())
-        e = {'dtype': code, 'shape': list(arr.shape), 'shard_id': 0, 'offset': off,
+    n = self.num_shards
+    paths = [f'{self.prefix}.data-{k:05d}-of-{n:05d}' for k in range(n)]
+    files = [open(p, 'wb') for p in paths]
+    offs = [0] * n
+    table = {}
+    try:
+      def put(arr, code, shard):
+        files[shard].write(arr.tobytes())
+        e = {'dtype': code, 'shape': list(arr.shape), 'shard_id': shard, 'offset': offs[shard],
              'size': arr.nbytes, 'crc32c': mask_crc(crc32c(arr))}
-        off += arr.nbytes
+        offs[shard] += arr.nbytes
         return e
       for name in sorted(self._whole):
-        arr, code = self._whole[name]
-        table[name.encode()] = _encode_entry(put(arr, code))
+        arr, code, shard = self._whole[name]
+        table[name.encode()] = _encode_entry(put(arr, code, shard))
       for name in sorted(self._parts):
         part = self._parts[name]
-        for ext, arr in part['slices']:
-          table[encode_slice_key(name, ext)] = _encode_entry(put(arr, part['code']))
+        for ext, arr, shard in part['slices']:
+          table[encode_slice_key(name, ext)] = _encode_entry(put(arr, part['code'], shard))
         table[name.encode()] = _encode_entry({
           'dtype': part['code'], 'shape': part['shape'],
-          'slices': [ext for ext, _ in part['slices']]})
-      f.flush()
-      os.fsync(f.fileno())
-    header = (_tag(1, 0) + _put_varint(1) +                       # num_shards = 1
+          'slices': [ext for ext, _, _ in part['slices']]})
+      for f in files:
+        f.flush()
+        os.fsync(f.fileno())
+    finally:
+      for f in files:
+        f.close()
+    header = (_tag(1, 0) + _put_varint(n) +                       # num_shards
               _bytes_field(3, _tag(1, 0) + _put_varint(1)))       # version { producer: 1 }
     table[b''] = header
     _write_table(self.prefix + '.index', sorted(table.items()))

@@ -230,7 +230,14 @@ def test_reference_checkpoint_bridge(tmp_path, w_save, w_load):
       'small/embedding_weights': torch.from_numpy(small.copy())})
   _run(w_save, save)
   theirs = export_reference(ours, str(tmp_path / 'theirs.ckpt'))
+  # one data file per rank that saved (what MergeV2Checkpoints leaves), every shard in its own
+  assert sorted(f for f in os.listdir(tmp_path) if f.startswith('theirs')) == (
+      [f'theirs.ckpt.data-{k:05d}-of-{w_save:05d}' for k in range(w_save)] + ['theirs.ckpt.index'])
   reader = tb.BundleReader(theirs)
+  assert reader.header['num_shards'] == w_save
+  if w_save > 1:
+    assert [e['shard_id'] for _, e in sorted(reader._slice_data[name],
+                                             key=lambda x: x[0][0][0])] == list(range(w_save))
   # TF's full tensor = the shards back to back (the reference's view); by id = de-interleaved
   concat = np.concatenate([table[r::w_save] for r in range(w_save)])
   np.testing.assert_equal(reader.read(name), concat)

@@ -466,14 +466,17 @@ def main():
 
     At the driver's K = 20 the bracket itself is visible (tools/scratch/bench_tail.py,
     profiles/r04_bench_tail.txt): the 20 kernels run back to back in 1127-1136 us (rocprofv3:
-    one 6 us gap), the first one starts 15-17 us after the clock, the closing event is seen 5 us
-    after the last byte, and the synchronize that follows -- nothing left to wait for -- takes
-    15-20 us in some processes, 52-85 in others, 140-147 in a few (HBK_BENCH_STAMPS=1 prints the
-    stamps): 58, 61 or 64 us per step on the wall against 56.5 by events.  What is not a step is kept out of the bracket where that is free: torch
-    creates a HIP event at its first record(), so both events are recorded once beforehand; the
-    garbage collector is held off; the closing event is polled before the synchronize the
-    contract asks for; the clock stops when every rank's work is complete (synchronize +
-    barrier) and the last synchronize follows it."""
+    one 6 us gap) and the first one starts 15-17 us after the clock; but the
+    torch.cuda.synchronize() behind them took 15-20 us in some processes, 52-85 in others and
+    140-147 in a few -- with nothing left to wait for, and only when a timing event had been
+    recorded behind the last launch (without the events: 57.0-57.7 us per step in 10 of 10
+    processes; with them 58, 61 or 64).  Waiting on the launch stream first
+    (hipStreamSynchronize) leaves the device-wide synchronize the contract asks for with 5 us of
+    work in 10 of 10 processes: 57.5-57.9 us per step on the wall against 56.6 by events.  Also
+    kept out of the bracket, because it is free: torch creates a HIP event at its first record(),
+    so both events are recorded once beforehand; the garbage collector is held off; the clock
+    stops when every rank's work is complete (synchronize + barrier) and the last synchronize
+    follows it."""
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     ev0.record()
@@ -486,22 +489,32 @@ def main():
     barrier()
     torch.cuda.synchronize()
     stamps = [] if os.environ.get('HBK_BENCH_STAMPS') else None   # (diagnostics, stderr only)
-    ev0.record()
+    # HBK_BENCH_PROBE (diagnostics of the bracket only, profiles/r04_bench_tail.txt): 'poll' /
+    # 'evsync' await the closing event by query / synchronize instead, 'noevents' records none
+    probe_mode = os.environ.get('HBK_BENCH_PROBE', '')
+    if probe_mode != 'noevents':
+      ev0.record()
     t0 = time.perf_counter()
     for i in range(steps):
       step_fn(warmup + i)
       if stamps is not None:
         stamps.append(time.perf_counter())
-    ev1.record()
-    while not ev1.query():
-      pass
+    if probe_mode != 'noevents':
+      ev1.record()
+    if probe_mode == 'evsync':
+      ev1.synchronize()
+    elif probe_mode == 'poll':
+      while not ev1.query():
+        pass
+    elif probe_mode != 'noevents':
+      torch.cuda.current_stream().synchronize()
     t_ready = time.perf_counter()
     torch.cuda.synchronize()
     barrier()
     el = time.perf_counter() - t0
     if stamps:
-      sys.stderr.write('bench stamps (us after the clock): launches returned %s | closing event '
-                       'ready %.1f | synchronize + barrier back %.1f\n' % (
+      sys.stderr.write('bench stamps (us after the clock): launches returned %s | launch stream '
+                       'done %.1f | synchronize + barrier back %.1f\n' % (
                            ' '.join('%.0f' % ((t - t0) * 1e6) for t in stamps),
                            (t_ready - t0) * 1e6, el * 1e6))
     torch.cuda.synchronize()

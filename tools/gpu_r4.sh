@@ -287,6 +287,14 @@ for l in sys.stdin:
       done
       timeout 2400 python tools/sweep.py --big --cases a,b,c,d,e,f,g,h,i,j,k,l 2>/dev/null | grep "^{" > $O/r04_sweep.jsonl
       wc -l $O/r04_bench_lines.jsonl $O/r04_sweep.jsonl; head -12 $O/r04_bench_kernel_stats.txt | cut -c1-160;;
+    tail8)
+      (for v in noevents evsync streamsync; do
+         echo "== HBK_BENCH_PROBE=$v"
+         for i in 1 2 3 4 5 6 7 8 9 10; do HBK_BENCH_PROBE=$v HBK_BENCH_STAMPS=1 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | cut -c1-420; done
+       done) > $O/tail8.log 2>&1;;
+    tail9)
+      (for i in 1 2 3 4 5 6 7 8 9 10; do HBK_BENCH_STAMPS=1 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | cut -c1-420; done
+       python bench.py --gpus 1 --sharded --steps 20 --warmup 5 --cpu-seconds 0 2>/dev/null | grep "^{" | cut -c1-300) > $O/tail9.log 2>&1;;
     *) echo "unknown stage $st";;
   esac
 done

@@ -295,6 +295,13 @@ for l in sys.stdin:
     tail9)
       (for i in 1 2 3 4 5 6 7 8 9 10; do HBK_BENCH_STAMPS=1 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | cut -c1-420; done
        python bench.py --gpus 1 --sharded --steps 20 --warmup 5 --cpu-seconds 0 2>/dev/null | grep "^{" | cut -c1-300) > $O/tail9.log 2>&1;;
+    lines)   # the bench lines alone
+      timeout 600 python bench.py --steps 50 --warmup 10 2>/dev/null | grep "^{" > $O/r04_bench_lines.jsonl
+      timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | grep "^{" >> $O/r04_bench_lines.jsonl
+      for w in fp32 fp16; do
+        timeout 300 python bench.py --gpus 1 --sharded --wire $w --steps 30 --warmup 5 --cpu-seconds 0 2>/dev/null | grep "^{" >> $O/r04_bench_lines.jsonl
+      done
+      cut -c1-200 $O/r04_bench_lines.jsonl;;
     *) echo "unknown stage $st";;
   esac
 done

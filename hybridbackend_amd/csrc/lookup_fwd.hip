@@ -536,8 +536,7 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
       int32_t k = 0;
       int64_t tiles = 0;
       bool same_tiles = true, one_block = true;   // (see args.interleave below)
-      const float* block_lo = nullptr;
-      const float* block_hi = nullptr;
+      uintptr_t block_lo = 0, block_hi = 0;   // lowest / highest output address of the launch
       int64_t small_lookups = 0, all_lookups = 0;   // (tables of <= 2 MB: see args.xcd below)
       args.tile_start[0] = 0;
       while (c0 < n_cols && k < kMaxColsPerLaunch) {
@@ -571,9 +570,11 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
         // "one dense block": every column's rows are strided and start inside the first row of
         // the lowest column's block
         one_block = one_block && d.out_stride > h.dim && h.half_io == 0;
-        block_lo = k == 0 || h.out < block_lo ? h.out : block_lo;
-        block_hi = k == 0 || h.out > block_hi ? h.out : block_hi;
-        one_block = one_block && (block_hi - block_lo) + h.dim <= d.out_stride;
+        const uintptr_t out_at = reinterpret_cast<uintptr_t>(h.out);
+        block_lo = k == 0 || out_at < block_lo ? out_at : block_lo;
+        block_hi = k == 0 || out_at > block_hi ? out_at : block_hi;
+        one_block = one_block && (block_hi - block_lo) / sizeof(float) + (uintptr_t)h.dim <=
+                                     (uintptr_t)d.out_stride;
         tiles += col_tiles;
         HBK_REQUIRE(tiles < (1ll << 31), "group_lookup_fwd: grid too large");
         all_lookups += h.n_ids;

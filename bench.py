@@ -649,6 +649,7 @@ def main():
 
   if rank == 0:
     print(json.dumps(result), flush=True)
+    headline['line'] = None        # (printed: a watchdog firing during the teardown adds nothing)
 
   if world > 1 or args.sharded:
     sharded.close()

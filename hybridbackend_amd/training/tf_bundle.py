@@ -483,8 +483,12 @@ class BundleReader:
     arr = np.fromfile(path, dtype=dt, count=want // dt.itemsize, offset=e['offset'])
     if arr.nbytes != want:
       raise ValueError(f'{path}: truncated ({name})')
-    if self.verify and e['crc32c'] is not None and unmask_crc(e['crc32c']) != crc32c(arr):
-      raise ValueError(f'{name}: tensor checksum mismatch in {path}')
+    if self.verify and e['crc32c'] is not None:
+      # stored masked (tensor_bundle.cc masks what it writes); with no TensorFlow-written file to
+      # check that against, the plain value is accepted as well -- a corrupt tensor matches neither
+      actual = crc32c(arr)
+      if e['crc32c'] not in (mask_crc(actual), actual):
+        raise ValueError(f'{name}: tensor checksum mismatch in {path}')
     return arr.reshape(shape)
 
   def slices(self, name):

@@ -12,8 +12,8 @@ module.  It follows the published formats, each pinned as far as a published vec
   ``doc/table_format.md``): data blocks of prefix-compressed entries (varint32 shared /
   non-shared / value length, key delta, value) + restart array, a 5-byte trailer per block
   (compression type, masked CRC-32C), metaindex + index block, 48-byte footer ending in the
-  magic ``0xdb4775248b80fb57``.  TF writes the bundle index uncompressed; a snappy block is
-  refused, not guessed at;
+  magic ``0xdb4775248b80fb57``.  TF writes the bundle index uncompressed; a snappy block (the
+  default of leveldb tables in general) is decompressed all the same;
 * keys and values (``tensorflow/core/protobuf/tensor_bundle.proto``): key ``""`` ->
   ``BundleHeaderProto`` (num_shards, endianness, version), tensor name -> ``BundleEntryProto``
   (dtype, shape, shard_id, offset, size, masked crc32c, slices).  A partitioned variable -- what
@@ -322,6 +322,54 @@ def decode_slice_key(key):
 
 # ---------------------------------------------------------------------------------------------
 # the leveldb table that is the index
+def snappy_uncompress(buf):
+  """Raw snappy (format_description.txt): varint length, then literals and back references.
+  TensorFlow writes the bundle index uncompressed (``tensor_bundle.cc``: kNoCompression, on
+  purpose); leveldb tables in general default to snappy, so a compressed block is read, not
+  refused."""
+  n, pos = _get_varint(buf, 0)
+  out = bytearray()
+  while pos < len(buf):
+    tag = buf[pos]
+    pos += 1
+    kind = tag & 3
+    if kind == 0:
+      ln = tag >> 2
+      if ln >= 60:
+        extra = ln - 59
+        ln = int.from_bytes(buf[pos:pos + extra], 'little')
+        pos += extra
+      ln += 1
+      if pos + ln > len(buf):
+        raise ValueError('snappy: literal runs past the input')
+      out += buf[pos:pos + ln]
+      pos += ln
+      continue
+    if kind == 1:
+      ln = 4 + ((tag >> 2) & 7)
+      off = ((tag >> 5) << 8) | buf[pos]
+      pos += 1
+    elif kind == 2:
+      ln = 1 + (tag >> 2)
+      off = int.from_bytes(buf[pos:pos + 2], 'little')
+      pos += 2
+    else:
+      ln = 1 + (tag >> 2)
+      off = int.from_bytes(buf[pos:pos + 4], 'little')
+      pos += 4
+    if off == 0 or off > len(out):
+      raise ValueError('snappy: bad back reference')
+    if off >= ln:
+      start = len(out) - off
+      out += out[start:start + ln]
+    else:
+      for _ in range(ln):                # overlapping copy: byte by byte
+        out.append(out[-off])
+  if len(out) != n:
+    raise ValueError(f'snappy: {len(out)} bytes where the header says {n}')
+  return bytes(out)
+
+
 def _read_block(buf, offset, size, verify):
   end = offset + size
   if end + 5 > len(buf):
@@ -331,10 +379,12 @@ def _read_block(buf, offset, size, verify):
     stored = struct.unpack_from('<I', buf, end + 1)[0]
     if unmask_crc(stored) != crc32c(bytes(buf[offset:end + 1])):
       raise ValueError('index block checksum mismatch')
-  if ctype != 0:
-    raise ValueError(f'compressed index block (type {ctype}): TensorFlow writes the bundle index '
-                     'uncompressed; no decompressor here')
   block = buf[offset:end]
+  if ctype == 1:
+    block = snappy_uncompress(bytes(block))
+    size = len(block)
+  elif ctype != 0:
+    raise ValueError(f'index block of unknown compression type {ctype}')
   if size < 4:
     raise ValueError('index block too small')
   n_restarts = struct.unpack_from('<I', block, size - 4)[0]

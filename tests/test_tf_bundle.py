@@ -110,6 +110,46 @@ def test_reads_an_index_assembled_by_hand(tmp_path):
   np.testing.assert_equal(tb.BundleReader(str(tmp_path / 'ck2')).read('a'), data)
 
 
+def test_snappy_blocks(tmp_path):
+  # format_description.txt by hand: length 13; literal "abcd"; copy (1-byte offset form) of 8
+  # bytes from 4 back -- overlapping; literal "X"
+  comp = bytes([13, (4 - 1) << 2]) + b'abcd' + bytes([((8 - 4) << 2) | 1, 4, 0]) + b'X'
+  assert tb.snappy_uncompress(comp) == b'abcdabcdabcdX'
+  # 2-byte-offset copy and a long literal (length in one extra byte)
+  lit = bytes(range(200)) * 2                                   # 400 bytes
+  comp = (tb._put_varint(400 + 70) + bytes([61 << 2]) + (400 - 1).to_bytes(2, 'little') + lit +
+          bytes([((64 - 1) << 2) | 2]) + (400).to_bytes(2, 'little') +
+          bytes([((6 - 1) << 2) | 2]) + (200).to_bytes(2, 'little'))
+  assert tb.snappy_uncompress(comp) == lit + lit[:64] + (lit + lit[:64])[-200:][:6]
+  with pytest.raises(ValueError):
+    tb.snappy_uncompress(bytes([5, 0]) + b'a')                  # 1 byte where 5 are promised
+  with pytest.raises(ValueError):
+    tb.snappy_uncompress(bytes([4, (4 << 2) | 1, 9]))           # reference before the start
+  # an index whose data block is stored compressed (all literals: a valid snappy stream)
+  prefix = str(tmp_path / 'ck')
+  w = tb.BundleWriter(prefix)
+  w.add('x', np.arange(6, dtype=np.float32))
+  w.finish()
+  raw = open(prefix + '.index', 'rb').read()
+  entries = tb._read_table(prefix + '.index', True)
+  block = tb._block_bytes(entries)
+  assert raw.startswith(block)
+  comp = tb._put_varint(len(block)) + bytes([60 << 2, len(block) - 1]) + block
+  blob = comp + b'\x01' + struct.pack('<I', tb.mask_crc(tb.crc32c(comp + b'\x01')))
+  off_meta = len(blob)
+  meta = struct.pack('<II', 0, 1)
+  blob += _trailer(meta)
+  index = (bytes([0, 1]) + tb._put_varint(len(tb._put_varint(0) + tb._put_varint(len(comp)))) + b'x' +
+           tb._put_varint(0) + tb._put_varint(len(comp)) + struct.pack('<II', 0, 1))
+  off_index = len(blob)
+  blob += _trailer(index)
+  footer = (tb._put_varint(off_meta) + tb._put_varint(len(meta)) + tb._put_varint(off_index) +
+            tb._put_varint(len(index)))
+  footer += b'\x00' * (40 - len(footer)) + struct.pack('<Q', tb.TABLE_MAGIC)
+  open(prefix + '.index', 'wb').write(blob + footer)
+  np.testing.assert_equal(tb.BundleReader(prefix).read('x'), np.arange(6, dtype=np.float32))
+
+
 def test_round_trip_many_tensors_dtypes_and_slices(tmp_path):
   rng = np.random.RandomState(11)
   prefix = str(tmp_path / 'model.ckpt-7')

@@ -192,6 +192,8 @@ def set_option(name, value):
   old = C.c_int32()
   check(lib().hbk_get_option(name.encode(), C.byref(old)))
   check(lib().hbk_set_option(name.encode(), int(value)))
+  from hybridbackend_amd import _marshal
+  _marshal.options_changed()   # cached workspace sizes depend on options
   return old.value
 
 

@@ -5,9 +5,12 @@ reads + a view per output): creating 3 x 26 output views alone is ~48 us (0.6 us
 partition kernel takes 15.  So:
   * every tensor is looked at ONCE (shape, dtype, device, contiguity, address in one pass); the
     detailed error message is produced by the slow checker only when that pass finds a problem;
-  * outputs are carved from one allocation per kind and handed back as a lazy sequence
-    (``Runs``): the flat tensor and the per-column extents are kept, the per-column views are
-    made by ONE ``torch.split`` call the first time somebody indexes / iterates the sequence;
+  * outputs are carved from one allocation per kind; the per-column views are made by ONE
+    ``torch.split`` call.  The public ops return PLAIN LISTS of tensors by default (round 5:
+    ``torch.cat(outs)``, ``outs + [...]`` and ``isinstance(outs, list)`` must work whatever path
+    a call took); ``lazy=True`` opts into the lazy sequences below (``Runs``: the flat tensor and
+    the per-column extents are kept, the views are made the first time somebody indexes /
+    iterates the sequence -- for callers that pass the result on without looking at it);
   * pointer / length arrays live in one per-thread numpy block per column count and are filled
     by vector arithmetic (run starts are offsets into the one allocation).
 """
@@ -85,7 +88,26 @@ class Zipped(collections.abc.Sequence):
     return tuple(p[i] for p in self.parts)
 
 
+def plain(seq):
+  """A lazy sequence as the plain list of tensors (or tuples of tensors) it stands for."""
+  if isinstance(seq, Zipped):
+    return list(zip(*[plain(p) for p in seq.parts]))
+  if isinstance(seq, (Runs, Rows)):
+    return seq._materialise()
+  return list(seq)
+
+
 _tls = threading.local()
+_options_generation = [0]
+
+
+def options_changed():
+  """Called by ``_lib.set_option``: sizes cached from hbk_*_workspace_bytes depend on options."""
+  _options_generation[0] += 1
+
+
+def options_generation():
+  return _options_generation[0]
 
 
 def arg_block(n, rows):

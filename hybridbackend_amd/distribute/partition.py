@@ -46,7 +46,7 @@ _INT_DTYPES = tuple(d for d in (torch.int32, torch.int64, getattr(torch, 'uint32
 _shape_plans = {}   # (n, P, lengths) -> (total, run offsets, workspace bytes): pure functions of the key
 
 
-def _partition_n_fresh(ids_list, num_partitions, modulus, stage):
+def _partition_n_fresh(ids_list, num_partitions, modulus, stage, lazy=False):
   """The functional form with tensors it has never seen (every training step): one pass over the
   inputs, three allocations, arguments by vector arithmetic, lazy per-column views
   (``_marshal``).  None: some input needs the detailed checks of the general path."""
@@ -57,7 +57,9 @@ def _partition_n_fresh(ids_list, num_partitions, modulus, stage):
   lib = _lib.lib()
   n = len(ids_list)
   device = ids_list[0].device
-  key = (n, num_partitions, tuple(lens))
+  # (the workspace size depends on runtime options -- partition_sub_tiles, partition_onepass --
+  # so the options generation is part of the key)
+  key = (n, num_partitions, tuple(lens), _marshal.options_generation())
   plan = _shape_plans.get(key)
   if plan is None:
     lens_np = np.asarray(lens, dtype=np.int64)
@@ -88,16 +90,19 @@ def _partition_n_fresh(ids_list, num_partitions, modulus, stage):
     _lib.check(lib.hbk_partition_by_modulo_n(n, code, num_partitions, *args))
   else:
     _lib.check(lib.hbk_partition_by_dual_modulo_n(n, code, num_partitions, modulus, stage, *args))
-  return (_marshal.Runs(flat_out, lens), _marshal.Rows(sizes2d), _marshal.Runs(flat_idx, lens))
+  if lazy:
+    return (_marshal.Runs(flat_out, lens), _marshal.Rows(sizes2d), _marshal.Runs(flat_idx, lens))
+  return (list(torch.split(flat_out, lens)), list(sizes2d.unbind(0)),
+          list(torch.split(flat_idx, lens)))
 
 
-def _partition_n(ids_list, num_partitions, modulus, stage, outputs=None):
+def _partition_n(ids_list, num_partitions, modulus, stage, outputs=None, lazy=False):
   lib = _lib.lib()
   n = len(ids_list)
   if n == 0:
     return [], [], []
   if outputs is None:
-    res = _partition_n_fresh(ids_list, num_partitions, modulus, stage)
+    res = _partition_n_fresh(ids_list, num_partitions, modulus, stage, lazy)
     if res is not None:
       return res
   dtype = ids_list[0].dtype
@@ -164,10 +169,14 @@ def partition_by_modulo(ids, num_partitions, name=None):
   return o[0], s[0], i[0]
 
 
-def partition_by_modulo_n(ids_list, num_partitions, name=None):
-  r'''N-ary form (op HbPartitionByModuloN, partition_by_modulo_ops.cc:124-143).'''
+def partition_by_modulo_n(ids_list, num_partitions, name=None, lazy=False):
+  r'''N-ary form (op HbPartitionByModuloN, partition_by_modulo_ops.cc:124-143).
+
+  Returns three LISTS of tensors (outputs, sizes, indices), one entry per column.  ``lazy=True``:
+  the three are lazy sequences instead (``_marshal.Runs``): the per-column views are only made
+  when indexed -- ~35 us less Python per call on 26 columns for a caller that passes them on.'''
   del name
-  return _partition_n(list(ids_list), num_partitions, 1, 0)
+  return _partition_n(list(ids_list), num_partitions, 1, 0, lazy=lazy)
 
 
 def partition_by_dual_modulo_stage_one(ids, num_partitions, modulus, name=None):
@@ -185,10 +194,11 @@ def partition_by_dual_modulo_stage_two(ids, num_partitions, modulus, name=None):
   return o[0], s[0], i[0]
 
 
-def partition_by_dual_modulo_n(ids_list, num_partitions, modulus, stage, name=None):
-  r'''N-ary dual-modulo shuffle; stage is 1 or 2.'''
+def partition_by_dual_modulo_n(ids_list, num_partitions, modulus, stage, name=None, lazy=False):
+  r'''N-ary dual-modulo shuffle; stage is 1 or 2.  Returns lists (``lazy``: see
+  ``partition_by_modulo_n``).'''
   del name
-  return _partition_n(list(ids_list), num_partitions, modulus, stage)
+  return _partition_n(list(ids_list), num_partitions, modulus, stage, lazy=lazy)
 
 
 class PartitionByModuloN:

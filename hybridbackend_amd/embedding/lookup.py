@@ -91,8 +91,10 @@ class GroupLookup:
   def __len__(self):
     return len(self.tables)
 
-  def bind(self, ids, row_splits=None, outs=None):
-    """Point the column descriptors at this step's inputs/outputs; returns outs."""
+  def bind(self, ids, row_splits=None, outs=None, lazy=False):
+    """Point the column descriptors at this step's inputs/outputs; returns outs -- a LIST of the
+    per-column ``[segments, dim]`` tensors (``lazy=True`` with ``outs=None``: a lazy sequence whose
+    views are made when indexed, for callers that hand the result on untouched)."""
     # the descriptors change: what __call__ remembers of its last tensors no longer describes them
     # (__call__ sets its key again after a bind of its own)
     self._call_key = None
@@ -100,7 +102,7 @@ class GroupLookup:
     if len(ids) != n:
       raise _lib.InvalidArgumentError(
         _lib.INVALID_ARGUMENT, f'expected {n} id tensors, got {len(ids)}')
-    fast = self._bind_fresh(ids, row_splits, outs) if n else None
+    fast = self._bind_fresh(ids, row_splits, outs, lazy=lazy) if n else None
     if fast is not None:
       return fast
     if row_splits is None:
@@ -162,7 +164,7 @@ class GroupLookup:
     return self._bind_fresh(ids, row_splits, None,
                             block=(n_rows, pitch, [base + 4 * o for o in offsets], block)) is not None
 
-  def _bind_fresh(self, ids, row_splits, outs, block=None):
+  def _bind_fresh(self, ids, row_splits, outs, block=None, lazy=False):
     """bind() for the common shapes -- id vectors of one dtype, contiguous outputs (or none: one
     allocation, lazy per-column views) -- with ONE pass over the tensors and the descriptors
     written field by field for all columns.  None: something needs bind()'s detailed checks
@@ -206,6 +208,8 @@ class GroupLookup:
         o_ptrs.append(base + 4 * at)
         at += k
       outs = _LazyOutputs(flat, pad, n_seg, dims)
+      if not lazy:
+        outs = outs._materialise()
     else:
       o_ptrs = []
       for c in range(n):
@@ -261,7 +265,7 @@ class GroupLookup:
       s = C.c_void_p(stream.cuda_stream)
     _lib.check(self._lib.hbk_group_lookup_fwd(len(self.tables), self._cols, s))
 
-  def __call__(self, ids, row_splits=None, outs=None):
+  def __call__(self, ids, row_splits=None, outs=None, lazy=False):
     # handed the SAME tensors as the call before (resident buffers refilled in place, caller-owned
     # outputs): the descriptors are still right, the call is one foreign call
     if outs is not None:
@@ -278,7 +282,7 @@ class GroupLookup:
       outs = self.bind(ids, row_splits, outs)
       self._call_key = (key, [(t.data_ptr(), t.numel()) for t in tensors], outs)
     else:
-      outs = self.bind(ids, row_splits, outs)   # (bind clears the remembered call)
+      outs = self.bind(ids, row_splits, outs, lazy=lazy)   # (bind clears the remembered call)
     self.launch()
     return outs
 

@@ -12,10 +12,11 @@ from hybridbackend_amd import _marshal
 _shape_plans = {}   # lengths -> (total, run offsets, workspace bytes)
 
 
-def unique_n(ids_list):
-  """Returns per column ``(unique int64[len], index int32[len], n_unique int32[1])``;
+def unique_n(ids_list, lazy=False):
+  """Returns a list with, per column, ``(unique int64[len], index int32[len], n_unique int32[1])``;
   ``unique[:n_unique]`` are the distinct ids in first-occurrence order and
-  ``unique[index] == ids``.  The count stays on the device (no host sync)."""
+  ``unique[index] == ids``.  The count stays on the device (no host sync).  ``lazy=True``: a lazy
+  sequence of the same tuples (``_marshal.Zipped``; views made when indexed)."""
   lib = _lib.lib()
   n = len(ids_list)
   if n == 0:
@@ -25,7 +26,8 @@ def unique_n(ids_list):
   if seen is not None:
     # fresh tensors every step: one pass over the inputs, three allocations, lazy per-column views
     ptrs, counts, _ = seen
-    key = tuple(counts)
+    # (unique_buckets_log2 changes the workspace size: the options generation is part of the key)
+    key = (tuple(counts), _marshal.options_generation())
     plan = _shape_plans.get(key)
     if plan is None:
       c_np = np.asarray(counts, dtype=np.int64)
@@ -52,8 +54,11 @@ def unique_n(ids_list):
     _lib.check(lib.hbk_unique_n(n, addr, addr + row, addr + 2 * row, addr + 3 * row,
                                 addr + 4 * row, C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()),
                                 C.c_void_p(stream)))
-    return _marshal.Zipped(_marshal.Runs(flat_u, counts), _marshal.Runs(flat_i, counts),
-                           _marshal.Runs(flat_n, [1] * n))
+    if lazy:
+      return _marshal.Zipped(_marshal.Runs(flat_u, counts), _marshal.Runs(flat_i, counts),
+                             _marshal.Runs(flat_n, [1] * n))
+    return list(zip(torch.split(flat_u, counts), torch.split(flat_i, counts),
+                    torch.split(flat_n, 1)))
   for t in ids_list:
     _lib.require_device_tensor(t, 'ids')
     if t.dtype != torch.int64 or t.dim() != 1:

@@ -1,0 +1,71 @@
+#!/bin/bash
+# Round-5 GPU-box visits: stages picked on the command line, everything lands under gpurun_out/.
+#   tools/gpu_r5.sh "fetch place"        (see the case labels)
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+STAGES=${1:-"test"}
+prof() {  # prof <name> <pmc counters or ""> -- cmd...   (counters in their own pass, kernel-trace only)
+  local name=$1; shift
+  local ctrs=$1; shift
+  shift
+  rm -rf $O/$name
+  if [ -n "$ctrs" ]; then
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log)
+    python tools/prof_summary.py pmc $O/$name > $O/$name.json 2>> $O/$name.log
+  else
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log)
+    python tools/prof_summary.py stats $O/$name > $O/$name.txt 2>> $O/$name.log
+  fi
+}
+trim() { find $O/$1 -name "*.csv" -size +2M -delete; }
+pmc_table() {   # pmc_table <json> <kernel-name filter>: one line per kernel, counters side by side
+  python - "$1" "$2" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k,v in sorted(d.items()):
+  if sys.argv[2] in k: print(k[:44].ljust(44), {c.replace('TCC_EA0_','').replace('_sum',''):round(x['mean']) for c,x in v.items()})
+PY
+}
+ab() {   # ab "option:v0,v1,.." "cases"  -> one line per case: the times under each value
+  echo "== $1 (sweep cases $2)"
+  SWEEP_AB=$1 timeout 900 python tools/sweep.py --big --cases $2 2>&1 | python -c "
+import sys,json
+last=None
+for l in sys.stdin:
+  if not l.startswith('{'):
+    if 'rror' in l or 'Traceback' in l: print(l.strip()[:300])
+    continue
+  d=json.loads(l)
+  if 'ab' in d: last=d
+  elif last: print(d['case'][:78].ljust(78), last['values'], last['us']); last=None"
+}
+for st in $STAGES; do
+  case $st in
+    test)
+      timeout 2400 python -m pytest tests -x -q -m gpu --durations=15 > $O/test.log 2>&1; echo "pytest rc=$?" >> $O/test.log; tail -25 $O/test.log;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -3 $O/smoke.log;;
+    bench)
+      timeout 600 python bench.py --steps 50 --warmup 10 > $O/bench.log 2>&1; echo "bench rc=$?" >> $O/bench.log; tail -3 $O/bench.log;;
+    counters)   # which TLB / translation counters this rocprofv3 knows
+      (cd /tmp && export TMPDIR=/tmp && timeout 120 rocprofv3 -L 2>&1 | grep -o -i -E "[A-Z0-9_]*(UTCL|TLB|XNACK|TRANSLATION)[A-Za-z0-9_]*" | sort -u) > $O/counters_tlb.txt 2>&1
+      wc -l $O/counters_tlb.txt; head -60 $O/counters_tlb.txt;;
+    fetch)      # request size of a 64-byte row fetch per load path / memory kind
+      timeout 300 tools/bin/fetch_probe > $O/fetch_times.txt 2>&1; cat $O/fetch_times.txt
+      prof pmc_fetch "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" -- $R/tools/bin/fetch_probe --quick
+      tail -1 $O/pmc_fetch.log; pmc_table $O/pmc_fetch.json fetch_; trim pmc_fetch;;
+    place)      # the same launch on tables allocated under different policies
+      timeout 900 tools/bin/placement_probe > $O/place_times.txt 2>&1; cat $O/place_times.txt
+      timeout 900 tools/bin/placement_probe > $O/place_times2.txt 2>&1; cat $O/place_times2.txt;;
+    placepmc)
+      prof pmc_place1 "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum" -- $R/tools/bin/placement_probe --quick
+      tail -1 $O/pmc_place1.log
+      python tools/prof_summary.py chunks $O/pmc_place1 group_lookup_fwd 4 malloc,slab,vmm_1g,malloc_rev,frag,vmm_2m,malloc,slab,vmm_1g,malloc,slab,vmm_1g,malloc_rev,frag,vmm_2m,malloc,slab,vmm_1g | tee $O/place_counters.txt; trim pmc_place1;;
+    bwdbase)    # where the backward family stands on this box before round 5's changes
+      (for w in b s R r d w; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk "; done) > $O/bwdbase.log 2>&1; cut -c1-200 $O/bwdbase.log;;
+    *) echo "unknown stage $st";;
+  esac
+done

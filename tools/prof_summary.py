@@ -44,5 +44,25 @@ def pmc(d):
   print(json.dumps(out, indent=1, sort_keys=True))
 
 
+def chunks(d, pattern, per_chunk, labels=''):
+  """Per-dispatch counter rows of the kernels whose name contains `pattern`, in dispatch order, cut
+  into runs of `per_chunk` launches (one run per policy of tools/placement_probe): mean per run."""
+  files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+  rows = defaultdict(dict)
+  for f in files:
+    for row in csv.DictReader(open(f)):
+      if pattern in row['Kernel_Name']:
+        rows[int(row['Dispatch_Id'])][row['Counter_Name']] = float(row['Counter_Value'])
+  order = sorted(rows)
+  per_chunk = int(per_chunk)
+  names = labels.split(',') if labels else []
+  for i in range(0, len(order), per_chunk):
+    run = [rows[k] for k in order[i:i + per_chunk]]
+    ctrs = sorted({c for r in run for c in r})
+    label = names[i // per_chunk] if i // per_chunk < len(names) else f'run {i // per_chunk}'
+    print(f'{label:<14}' + '  '.join(
+        f'{c}={sum(r.get(c, 0.0) for r in run) / len(run):.0f}' for c in ctrs))
+
+
 if __name__ == '__main__':
-  {'stats': stats, 'pmc': pmc}[sys.argv[1]](sys.argv[2])
+  {'stats': stats, 'pmc': pmc, 'chunks': chunks}[sys.argv[1]](*sys.argv[2:])

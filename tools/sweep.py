@@ -244,6 +244,11 @@ def case_integer():
          100 * 100000, 100 * 100000 * (4 + 4 + 4 + 4))
   us = timed(lambda i: hb.embedding.unique_n(ids), iters=10)
   report(f'unique_n 26 x {B} int64', us, 26 * B, 26 * B * (8 + 8 + 4))
+  # round 5: the functional forms return plain lists; lazy=True keeps the views unmade
+  us = timed(lambda i: hb.distribute.partition_by_modulo_n(ids, 8, lazy=True), iters=20)
+  report(f'partition_by_modulo_n(lazy=True) 26 x {B} int64 P=8', us, 26 * B, 26 * B * (8 + 8 + 8 + 4))
+  us = timed(lambda i: hb.embedding.unique_n(ids, lazy=True), iters=10)
+  report(f'unique_n(lazy=True) 26 x {B} int64', us, 26 * B, 26 * B * (8 + 8 + 4))
   # the bound forms: arguments marshalled once, a call is one foreign call
   for P in (2, 8):
     plan = hb.distribute.PartitionByModuloN(P)

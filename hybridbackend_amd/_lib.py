@@ -86,6 +86,7 @@ def _declare(l):
     'hbk_set_option': (C.c_int, [C.c_char_p, i32]),
     'hbk_get_option': (C.c_int, [C.c_char_p, vp]),
     'hbk_sync_check': (C.c_int, []),
+    'hbk_sync_check_stream': (C.c_int, [C.c_void_p]),
     'hbk_host_floormod_i64': (i64, [i64, i64]),
     'hbk_host_fastdiv_u64': (C.c_uint64, [C.c_uint64, C.c_uint64]),
     'hbk_host_crc32c': (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_int64]),

@@ -177,7 +177,9 @@ struct SyncTake {
   int32_t* words;
   int32_t* zero;
   int64_t zero_words;
-  int32_t* status;    // host-visible, raised by a wait that ran out
+  int32_t* status;    // host-visible word of the OWNER stream (the caller's), raised by a wait that ran
+                      // out: reported at that stream's next entry call, not at somebody else's
+  int32_t* summary;   // host-visible, process-wide: "some status word is raised" (the entries' fast path)
   int32_t* poison;    // device word of THIS call (zero at its start, cleared with the call's words):
                       // set by a wait that ran out; the later kernels of the call read it first and
                       // leave without touching anything (their inputs were never written)
@@ -187,6 +189,7 @@ struct SyncTake {
 // what the waiting kernels need of a SyncTake, by value in their arguments
 struct SyncWait {
   int32_t* status;
+  int32_t* summary;
   int32_t* poison;
   unsigned long long ticks;
   int32_t withhold;
@@ -195,6 +198,7 @@ struct SyncWait {
 inline SyncWait sync_wait_of(const SyncTake& t) {
   SyncWait w;
   w.status = t.status;
+  w.summary = t.summary;
   w.poison = t.poison;
   w.ticks = t.wait_ticks;
   w.withhold = t.withhold;
@@ -207,8 +211,12 @@ inline SyncWait sync_wait_of(const SyncTake& t) {
 // modes, fewer CUs; a per-STREAM CU mask is not visible to the occupancy query: the bounded wait is
 // what protects such a stream,
 // partitioned modes), as when the stream is being captured or a wait has run out before.
+// `owner`: the stream whose caller is told of a wait that ran out (default: `stream` itself; the
+// backward launches on helper streams of the library and the sharded plan on its prefetch stream
+// on behalf of the caller's stream).
+#define HBK_SYNC_SAME_STREAM (reinterpret_cast<hipStream_t>(~(uintptr_t)0))
 bool sync_take(hipStream_t stream, size_t words, SyncTake* out, const void* kernel = nullptr,
-               int block = 0, int max_column_wgs = 0);
+               int block = 0, int max_column_wgs = 0, hipStream_t owner = HBK_SYNC_SAME_STREAM);
 // Kernels whose tiles wait for tiles launched AFTER them (partition_onepass, unique_group,
 // bwd_group) must not run beside each other: two of them on different streams can each fill the
 // chip's workgroup slots with waiting tiles while the tiles they wait for find no slot -- a
@@ -227,10 +235,14 @@ class SyncChain {
   hipStream_t stream_;
   void* state_;
 };
-int32_t* sync_status();
 // HBK_OK, or -- ONCE per timed-out wait -- HBK_INTERNAL with the story in hbk_last_error(); the
-// one-launch forms are then off for the rest of the process (option sync_onepass_off)
-int sync_check(const char* who);
+// one-launch forms are then off for the rest of the process (option sync_onepass_off).
+// With a stream: only what was launched on behalf of THAT stream of the current device (a wait
+// that ran out on stream A is reported to A's next entry call, never consumed by a call on stream
+// B: round 5).  sync_check_any: whatever any stream of any device has raised
+// (hbk_sync_check(), for callers that synchronise the whole device).
+int sync_check(const char* who, hipStream_t stream);
+int sync_check_any(const char* who);
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
@@ -242,7 +254,9 @@ __device__ inline bool poisoned(const int32_t* poison) {
 // a wait ran out: poison the call (device word), tell the host (pinned word)
 __device__ inline void give_up(const SyncWait& w) {
   __hip_atomic_store(w.poison, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(w.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // (the owner's word first, the summary behind it: a host that has seen the summary finds the word)
+  __hip_atomic_store(w.status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(w.summary, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ inline int lane_id() { return (int)(threadIdx.x & (kWave - 1)); }

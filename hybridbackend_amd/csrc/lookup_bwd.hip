@@ -3186,7 +3186,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
   HBK_REQUIRE(((uintptr_t)workspace & 7) == 0,
               "group_lookup_bwd: workspace must be 8-byte aligned");
   {
-    const int rc = sync_check("group_lookup_bwd");
+    const int rc = sync_check("group_lookup_bwd", stream);
     if (rc != HBK_OK) return rc;
   }
   // head of the workspace: the job descriptors of all columns (16-byte aligned), then the
@@ -3524,7 +3524,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     if (onepass) {
       SyncTake take;
       onepass = sync_take(ls, (size_t)sync_words, &take,
-                          reinterpret_cast<const void*>(&bwd_group_kernel), kBlock, 64);
+                          reinterpret_cast<const void*>(&bwd_group_kernel), kBlock, 64, stream);
       if (onepass) {
         sync.hist = take.words;
         sync.zero = take.zero;

@@ -99,7 +99,10 @@ extern "C" int hbk_get_option(const char* name, int32_t* value) {
   return fail(HBK_INVALID_ARGUMENT, "get_option: unknown option '%s'", name);
 }
 
-extern "C" int hbk_sync_check(void) { return hbk::sync_check("sync_check"); }
+extern "C" int hbk_sync_check(void) { return hbk::sync_check_any("sync_check"); }
+extern "C" int hbk_sync_check_stream(hbk_stream_t stream) {
+  return hbk::sync_check("sync_check_stream", reinterpret_cast<hipStream_t>(stream));
+}
 
 extern "C" const char* hbk_version(void) { return "hbk 0.1.0 gfx950"; }
 

@@ -847,7 +847,7 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
   }
 
   {
-    const int rc = sync_check(what);
+    const int rc = sync_check(what, stream);
     if (rc != HBK_OK) return rc;
   }
   ShardFn fn;
@@ -862,7 +862,7 @@ int partition_impl(const char* what, int32_t n_cols, int32_t dtype, int32_t P,
   // one launch when every column fits the one-pass kernel (see there); its words must read zero
   int64_t all_tiles = 0;
   bool onepass = options().partition_onepass != 0 && sub == 1 && P <= kOneMaxP &&
-                 P <= options().partition_fixed_max && sync_status() != nullptr;
+                 P <= options().partition_fixed_max;
   for (int32_t c = 0; c < n_cols; ++c) {
     const int64_t t = tiles_of(lens[c], sub);
     onepass = onepass && t <= kOneMaxTiles;

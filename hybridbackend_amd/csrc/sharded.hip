@@ -859,7 +859,9 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   HBK_HIP_OK(hipEventSynchronize(set.done));   // the step's one host wait: sizes are on the host
   // the partition's one-launch form may have given up (bounded waits, sync.hip): then the sizes
   // just read are not valid -- THIS step fails, before anything is sized from them
-  if ((rc = sync_check("sharded_lookup_fwd")) != HBK_OK) return rc;
+  // (the partition ran on the caller's stream or, prefetched, on the plan's own)
+  if ((rc = sync_check("sharded_lookup_fwd", stream)) != HBK_OK) return rc;
+  if ((rc = sync_check("sharded_lookup_fwd", p->pre_stream)) != HBK_OK) return rc;
   if (prefetched) HBK_HIP_OK(hipStreamWaitEvent(stream, set.ready, 0));
   const double t_sync = us_since(t_begin);
   p->send_sizes.assign(set.host_sizes, set.host_sizes + (size_t)N * W);

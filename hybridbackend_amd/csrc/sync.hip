@@ -11,13 +11,16 @@
 // queue preemption, short of a hang).  A wave that gives up raises the host-visible status word
 // AND the call's poison word in device memory: the later kernels of the same call read the poison
 // first and leave, so nothing is computed from descriptors that were never written.  The host
-// reports the failure once -- at the next entry call, at hbk_sync_check(), or in the SAME call
-// where that call synchronises anyway (the sharded step) -- and from then on takes the
-// multi-launch forms (option sync_onepass_off).  The one-launch forms are also refused when the
+// reports the failure once -- at the next entry call ON THE STREAM THE FAILED CALL WAS MADE ON (the
+// status word is per (device, stream): a call on another stream neither sees nor consumes it), at
+// hbk_sync_check_stream() / hbk_sync_check(), or in the SAME call where that call synchronises
+// anyway (the sharded step) -- and from then on takes the multi-launch forms (option
+// sync_onepass_off).  The one-launch forms are also refused when the
 // device could not hold a whole column's workgroups at once (occupancy x CUs, cached).
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
 
 #include <string.h>
 
@@ -94,20 +97,55 @@ SyncChain::~SyncChain() {
   c->mu.unlock();
 }
 
-int32_t* sync_status() {
-  static int32_t* word = [] {
-    void* q = nullptr;
-    if (hipHostMalloc(&q, 64, hipHostMallocDefault) != hipSuccess) return (int32_t*)nullptr;
-    memset(q, 0, 64);
-    return reinterpret_cast<int32_t*>(q);
-  }();
-  return word;
+// Host-visible status words (pinned memory, one 64-byte line each): word 0 of the first page is the
+// process-wide SUMMARY ("some word is raised": what every entry looks at, one volatile read); the
+// others belong to one (device, owner stream) each and are handed out for the life of the process.
+namespace {
+constexpr int kWordsPerPage = 64;   // 64-byte lines of a 4 KB pinned page
+struct StatusTable {
+  std::mutex mu;
+  std::vector<int32_t*> pages;
+  int used = 0;                                              // lines handed out of the last page
+  std::map<std::pair<int, hipStream_t>, int32_t*> words;     // (device, owner stream) -> its word
+  int32_t* summary = nullptr;
+  // a fresh line, or nullptr without pinned memory (mu held)
+  int32_t* line() {
+    if (pages.empty() || used == kWordsPerPage) {
+      void* q = nullptr;
+      if (hipHostMalloc(&q, kWordsPerPage * 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+      }
+      memset(q, 0, kWordsPerPage * 64);
+      pages.push_back(reinterpret_cast<int32_t*>(q));
+      used = 0;
+    }
+    return pages.back() + 16 * used++;
+  }
+};
+StatusTable& status_table() {
+  static StatusTable* t = new StatusTable();   // (never destroyed: kernels may still write the words)
+  return *t;
 }
+int32_t* summary_word() {
+  StatusTable& t = status_table();
+  std::lock_guard<std::mutex> lock(t.mu);
+  if (t.summary == nullptr) t.summary = t.line();
+  return t.summary;
+}
+int32_t* status_word(int dev, hipStream_t owner) {
+  StatusTable& t = status_table();
+  std::lock_guard<std::mutex> lock(t.mu);
+  auto it = t.words.find(std::make_pair(dev, owner));
+  if (it != t.words.end()) return it->second;
+  int32_t* w = t.line();
+  if (w != nullptr) t.words[std::make_pair(dev, owner)] = w;
+  return w;
+}
+inline int32_t peek(const int32_t* w) { return *reinterpret_cast<const volatile int32_t*>(w); }
+inline void poke(int32_t* w, int32_t v) { *reinterpret_cast<volatile int32_t*>(w) = v; }
 
-int sync_check(const char* who) {
-  int32_t* st = sync_status();
-  if (st == nullptr || *reinterpret_cast<volatile int32_t*>(st) == 0) return HBK_OK;
-  *reinterpret_cast<volatile int32_t*>(st) = 0;
+int report(const char* who) {
   options().sync_onepass_off = 1;
   return fail(HBK_INTERNAL,
               "%s: a one-launch kernel (partition / unique / backward grouping) gave up waiting "
@@ -115,6 +153,42 @@ int sync_check(const char* who) {
               "are not valid.  The library has switched to its multi-launch forms "
               "(option sync_onepass_off = 1)", who, options().sync_wait_ms);
 }
+}  // namespace
+
+// Only the words of `stream` (all of them when `any`) are consumed; the summary is lowered first
+// and raised again when another stream's word is still up -- a device that raises a word while
+// this runs writes the word BEFORE the summary, so it either sees its summary survive or has its
+// word found by the scan.
+static int sync_check_impl(const char* who, bool any, hipStream_t stream) {
+  StatusTable& t = status_table();
+  {
+    // fast path: nothing raised anywhere (one uncontended lock + one read of pinned memory)
+    std::lock_guard<std::mutex> lock(t.mu);
+    if (t.summary == nullptr || peek(t.summary) == 0) return HBK_OK;
+  }
+  int dev = 0;
+  if (!any && hipGetDevice(&dev) != hipSuccess) return HBK_OK;
+  bool mine = false, others = false;
+  {
+    std::lock_guard<std::mutex> lock(t.mu);
+    poke(t.summary, 0);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    for (auto& kv : t.words) {
+      if (peek(kv.second) == 0) continue;
+      if (any || (kv.first.first == dev && kv.first.second == stream)) {
+        poke(kv.second, 0);
+        mine = true;
+      } else {
+        others = true;
+      }
+    }
+    if (others) poke(t.summary, 1);
+  }
+  return mine ? report(who) : HBK_OK;
+}
+
+int sync_check(const char* who, hipStream_t stream) { return sync_check_impl(who, false, stream); }
+int sync_check_any(const char* who) { return sync_check_impl(who, true, nullptr); }
 
 namespace {
 // can `max_column_wgs` workgroups of `kernel` be resident at once?  (cached per device and kernel)
@@ -138,7 +212,7 @@ bool fits_device(int dev, const void* kernel, int block, int max_column_wgs) {
 }  // namespace
 
 bool sync_take(hipStream_t stream, size_t words, SyncTake* out, const void* kernel, int block,
-               int max_column_wgs) {
+               int max_column_wgs, hipStream_t owner) {
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, SyncSlot> slots;
   if (options().sync_onepass_off != 0) return false;
@@ -146,7 +220,10 @@ bool sync_take(hipStream_t stream, size_t words, SyncTake* out, const void* kern
   (void)hipStreamIsCapturing(stream, &capturing);
   if (capturing != hipStreamCaptureStatusNone) return false;   // a graph replays ONE launch
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || sync_status() == nullptr) return false;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  int32_t* const summary = summary_word();
+  int32_t* const status = status_word(dev, owner == HBK_SYNC_SAME_STREAM ? stream : owner);
+  if (summary == nullptr || status == nullptr) return false;
   if (kernel != nullptr && !fits_device(dev, kernel, block, max_column_wgs)) return false;
   words += 1;   // the call's poison word, behind its sync words
   std::lock_guard<std::mutex> lock(mu);
@@ -165,7 +242,8 @@ bool sync_take(hipStream_t stream, size_t words, SyncTake* out, const void* kern
   out->words = s.buf + (size_t)h * s.half_words;
   out->zero = s.buf + (size_t)(1 - h) * s.half_words;
   out->zero_words = (int64_t)s.dirty_words[1 - h];
-  out->status = sync_status();
+  out->status = status;
+  out->summary = summary;
   out->poison = out->words + (words - 1);
   out->wait_ticks = (unsigned long long)(options().sync_wait_ms > 0 ? options().sync_wait_ms : 1) *
                     100000ull;

@@ -832,7 +832,7 @@ int unique_n_impl(int32_t n_cols, const UniqueColumn* cols, void* workspace,
   HBK_REQUIRE(((uintptr_t)workspace & 7) == 0, "unique_n: workspace must be 8-byte aligned");
   char* wp = reinterpret_cast<char*>(workspace);
   {
-    const int rc = sync_check("unique_n");
+    const int rc = sync_check("unique_n", stream);
     if (rc != HBK_OK) return rc;
   }
   // four launches when every column fits the group kernel (see there)

@@ -84,7 +84,7 @@ const char* hbk_version(void);
  * test hook sync_test_withhold) poisons its call: the call's later kernels leave without touching
  * anything, its outputs are not valid, and the failure is reported ONCE as HBK_INTERNAL -- by the
  * sharded step in the call that suffered it (it synchronises anyway), else by the next call of
- * these entries or by hbk_sync_check() -- after which the library takes the multi-launch forms
+ * these entries ON THE SAME STREAM or by hbk_sync_check[_stream]() -- after which the library takes the multi-launch forms
  * (sync_onepass_off = 1; writable).  The one-launch forms are also not taken when the device
  * cannot hold a whole column's workgroups at once (partitioned modes, small devices; a CU mask set
  * on one stream is not seen by the occupancy query -- there the bounded wait applies).  The words the
@@ -96,6 +96,12 @@ int hbk_get_option(const char* name, int32_t* value);
  * the outputs of hbk_partition_* / hbk_unique_n / hbk_group_lookup_bwd* after their own stream
  * synchronisation call this behind it to learn of a failed call before using its outputs. */
 int hbk_sync_check(void);
+/* The same for ONE stream of the current device (round 5): the status word of a timed-out wait is
+ * kept per (device, stream) -- the stream the failed call was made on -- so a failure on stream A
+ * is reported to the next entry call on A (or to this function with A) and is neither seen nor
+ * consumed by calls on stream B.  hbk_sync_check() above reports -- and clears -- whatever any
+ * stream has raised. */
+int hbk_sync_check_stream(hbk_stream_t stream);
 /* the kernels' divide-free floor-mod / floor-div (multiply-high by a
  * host-computed magic) evaluated on the host, so the integer arithmetic can be checked
  * against Python's % and // without a GPU.  d > 0. */

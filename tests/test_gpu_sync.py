@@ -96,6 +96,58 @@ def test_timed_out_wait_fails_its_call_once_and_falls_back(hbk_option, which):
   assert _sync_check() == 0
 
 
+@pytest.mark.parametrize('which', ['partition', 'unique', 'bwd'])
+def test_failure_is_reported_to_its_own_stream_only(hbk_option, which):
+  """Round 5 (ADVICE r03 / VERDICT r04 item 7): the status word of a timed-out wait is kept per
+  (device, stream).  A call poisoned on stream A is reported to A's next entry -- a call on stream
+  B in between neither sees the error nor consumes it, and its own results are right."""
+  rng = np.random.RandomState(11)
+  lib = _lib.lib()
+  sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+  assert _sync_check() == 0
+  hbk_option('sync_onepass_off', 0)
+  hbk_option('sync_wait_ms', 20)
+  hbk_option('sync_test_withhold', 0)
+  with torch.cuda.stream(sa):
+    _run(which, rng)                      # poisoned on A (asynchronous: returns OK)
+  torch.cuda.synchronize()
+  hbk_option('sync_test_withhold', -1)
+  with torch.cuda.stream(sb):
+    check_b = _run('partition', rng)      # B's entry does not raise ...
+    check_b2 = _run('unique', rng)
+  torch.cuda.synchronize()
+  check_b()                               # ... and its outputs are right
+  check_b2()
+  assert lib.hbk_sync_check_stream(sb.cuda_stream) == 0
+  assert _lib.get_option('sync_onepass_off') == 0          # nothing has been reported yet
+  with torch.cuda.stream(sa):
+    with pytest.raises(_lib.HbkError, match='gave up waiting'):
+      _run('partition', rng)              # A's next entry reports A's failure
+    check_a = _run(which, rng)            # once
+  torch.cuda.synchronize()
+  check_a()
+  assert _lib.get_option('sync_onepass_off') == 1
+  assert lib.hbk_sync_check_stream(sa.cuda_stream) == 0
+  assert _sync_check() == 0
+
+
+def test_sync_check_without_a_stream_reports_any_stream(hbk_option):
+  rng = np.random.RandomState(12)
+  lib = _lib.lib()
+  sa = torch.cuda.Stream()
+  hbk_option('sync_onepass_off', 0)
+  hbk_option('sync_wait_ms', 20)
+  hbk_option('sync_test_withhold', 0)
+  with torch.cuda.stream(sa):
+    _run('partition', rng)
+  torch.cuda.synchronize()
+  hbk_option('sync_test_withhold', -1)
+  assert lib.hbk_sync_check_stream(torch.cuda.current_stream().cuda_stream) == 0   # not this stream's
+  assert _sync_check() == _lib.INTERNAL                    # the device-wide form sees it ...
+  assert lib.hbk_sync_check_stream(sa.cuda_stream) == 0    # ... and has consumed it
+  assert _sync_check() == 0
+
+
 def test_failure_surfaces_at_the_next_entry_call(hbk_option):
   rng = np.random.RandomState(6)
   hbk_option('sync_onepass_off', 0)

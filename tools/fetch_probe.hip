@@ -9,8 +9,8 @@
 //
 //   vec4         global_load_dwordx4, 4 lanes per row, 2 rows in flight per lane  (the shipped path)
 //   vec4_u8      the same with 8 rows in flight per lane
-//   vec4_nt      non-temporal loads;  vec4_sc: sc0 sc1 (system-coherent) loads
-//   vec1         global_load_dword, 16 lanes per row
+//   vec4_nt      non-temporal loads
+//   vec1         global_load_dword, 16 lanes per row;  vec1_sc: the same, system scope (sc0 sc1)
 //   half_row     only the first 32 bytes of every row are read (what does the fabric fetch?)
 //   sload_x16    s_load_dwordx16, one row per scalar load, 4 rows in flight per wave
 //   sload_x8     2 x s_load_dwordx8 per row, 8 loads (4 rows) in flight per wave
@@ -47,11 +47,6 @@ enum { kPlain = 0, kNt = 1, kSc = 2 };
 template <int MODE>
 __device__ inline f32x4 load16(const float* p) {
   if (MODE == kNt) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-  if (MODE == kSc) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-  }
   return *reinterpret_cast<const f32x4*>(p);
 }
 
@@ -68,14 +63,16 @@ __device__ inline void vec_body(const float* table, const uint32_t* rowidx, int6
     v[u] = f32x4{0, 0, 0, 0};
     if (s < n) {
       const uint64_t r = rowidx[s];
-      if (LPR == 16) {
+      if (LPR == 16 && MODE == kSc) {
+        // system-scope load (global_load_dword sc0 sc1), through the compiler's own atomics
+        v[u].x = __hip_atomic_load(table + r * 16 + sub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else if (LPR == 16) {
         v[u].x = table[r * 16 + sub];
       } else {
         v[u] = load16<MODE>(table + r * 16 + sub * 4);   // LPR 4: whole row, LPR 2: first half
       }
     }
   }
-  if (MODE == kSc) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   f32x4 acc = v[0];
 #pragma unroll
   for (int u = 1; u < U; ++u) acc += v[u];
@@ -90,7 +87,7 @@ __device__ inline void vec_body(const float* table, const uint32_t* rowidx, int6
 VEC_KERNEL(fetch_vec4, 4, 2, kPlain)
 VEC_KERNEL(fetch_vec4_u8, 4, 8, kPlain)
 VEC_KERNEL(fetch_vec4_nt, 4, 2, kNt)
-VEC_KERNEL(fetch_vec4_sc, 4, 2, kSc)
+VEC_KERNEL(fetch_vec1_sc, 16, 2, kSc)
 VEC_KERNEL(fetch_vec1, 16, 2, kPlain)
 VEC_KERNEL(fetch_half_row, 2, 2, kPlain)
 VEC_KERNEL(fetch_vec4_finegrained, 4, 2, kPlain)
@@ -179,6 +176,10 @@ __device__ inline void dma_body(const float* table, uint32_t table_bytes, const 
     const int64_t s = row0 + u * 16 + grp;
     r[u] = rowidx[s < n ? s : n - 1];
   }
+  // every row number is in before the first DMA leaves (the compiler's waits count the DMAs too:
+  // a row number asked for late would wait for the pieces issued before it)
+#pragma unroll
+  for (int u = 0; u < kDmaU; ++u) asm volatile("" : "+v"(r[u]));
   if (BUFFER) {
     auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(table), 0, (int)table_bytes,
                                                   0x00020000);
@@ -270,8 +271,8 @@ int main(int argc, char** argv) {
   run_vec("vec4", fetch_vec4, 4, 2, tab);
   run_vec("vec4_u8", fetch_vec4_u8, 4, 8, tab);
   run_vec("vec4_nt", fetch_vec4_nt, 4, 2, tab);
-  run_vec("vec4_sc", fetch_vec4_sc, 4, 2, tab);
   run_vec("vec1", fetch_vec1, 16, 2, tab);
+  run_vec("vec1_sc (sc0 sc1)", fetch_vec1_sc, 16, 2, tab);
   run_vec("half_row (32 of 64 B)", fetch_half_row, 2, 2, tab);
   {
     // persistent waves: 256 CUs x 4 SIMDs x 8 waves

@@ -13,10 +13,10 @@ prof() {  # prof <name> <pmc counters or ""> -- cmd...   (counters in their own 
   shift
   rm -rf $O/$name
   if [ -n "$ctrs" ]; then
-    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log)
+    (cd /tmp && export TMPDIR=/tmp && timeout ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log)
     python tools/prof_summary.py pmc $O/$name > $O/$name.json 2>> $O/$name.log
   else
-    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log)
+    (cd /tmp && export TMPDIR=/tmp && timeout ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log)
     python tools/prof_summary.py stats $O/$name > $O/$name.txt 2>> $O/$name.log
   fi
 }
@@ -54,7 +54,7 @@ for st in $STAGES; do
       (cd /tmp && export TMPDIR=/tmp && timeout 120 rocprofv3 -L 2>&1 | grep -o -i -E "[A-Z0-9_]*(UTCL|TLB|XNACK|TRANSLATION)[A-Za-z0-9_]*" | sort -u) > $O/counters_tlb.txt 2>&1
       wc -l $O/counters_tlb.txt; head -60 $O/counters_tlb.txt;;
     fetch)      # request size of a 64-byte row fetch per load path / memory kind
-      timeout 300 tools/bin/fetch_probe > $O/fetch_times.txt 2>&1; cat $O/fetch_times.txt
+      timeout 90 tools/bin/fetch_probe > $O/fetch_times.txt 2>&1; cat $O/fetch_times.txt
       prof pmc_fetch "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" -- $R/tools/bin/fetch_probe --quick
       tail -1 $O/pmc_fetch.log; pmc_table $O/pmc_fetch.json fetch_; trim pmc_fetch;;
     place)      # the same launch on tables allocated under different policies

@@ -66,6 +66,9 @@ for st in $STAGES; do
       python tools/prof_summary.py chunks $O/pmc_place1 group_lookup_fwd 4 malloc,slab,vmm_1g,malloc_rev,frag,vmm_2m,malloc,slab,vmm_1g,malloc,slab,vmm_1g,malloc_rev,frag,vmm_2m,malloc,slab,vmm_1g | tee $O/place_counters.txt; trim pmc_place1;;
     bwdbase)    # where the backward family stands on this box before round 5's changes
       (for w in b s R r d w; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk "; done) > $O/bwdbase.log 2>&1; cut -c1-200 $O/bwdbase.log;;
+    t_*)        # t_<file stem>[:<-k expression>]: one test file, e.g. t_test_gpu_sync or t_test_gpu_parity:rowsort
+      spec=${st#t_}; f=${spec%%:*}; k=""; [ "$spec" != "$f" ] && k=${spec#*:}
+      timeout 1500 python -m pytest tests/$f.py -x -q -m gpu ${k:+-k "$k"} --durations=5 > $O/$f.log 2>&1; echo "pytest rc=$?" >> $O/$f.log; tail -15 $O/$f.log;;
     *) echo "unknown stage $st";;
   esac
 done

@@ -83,6 +83,9 @@ def _declare(l):
   protos = {
     'hbk_last_error': (C.c_char_p, []),
     'hbk_version': (C.c_char_p, []),
+    'hbk_tables_layout': (C.c_size_t, [i32, vp, vp]),
+    'hbk_tables_alloc': (C.c_int, [i32, vp, vp, vp]),
+    'hbk_tables_free': (C.c_int, [vp]),
     'hbk_set_option': (C.c_int, [C.c_char_p, i32]),
     'hbk_get_option': (C.c_int, [C.c_char_p, vp]),
     'hbk_sync_check': (C.c_int, []),

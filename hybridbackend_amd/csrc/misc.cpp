@@ -2,6 +2,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace hbk {
@@ -105,6 +107,46 @@ extern "C" int hbk_sync_check_stream(hbk_stream_t stream) {
 }
 
 extern "C" const char* hbk_version(void) { return "hbk 0.1.0 gfx950"; }
+
+// One slab for N tables, each at a 2 MB-aligned offset: the allocation policy that was fastest in
+// every run of tools/placement_probe (profiles/r05_placement.txt: -2 % on config 4's forward, 2.1 x
+// fewer UTCL1 translation misses than one hipMalloc per table).  Offsets by hbk_tables_layout, so
+// a framework that owns its memory can carve its own slab the same way.
+extern "C" size_t hbk_tables_layout(int32_t n, const size_t* bytes, size_t* offsets) {
+  const size_t kAlign = (size_t)2 << 20;
+  size_t total = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    if (offsets != nullptr) offsets[i] = total;
+    total += (bytes[i] + kAlign - 1) / kAlign * kAlign;
+  }
+  return total;
+}
+extern "C" int hbk_tables_alloc(int32_t n, const size_t* bytes, void** tables, void** slab) {
+  using namespace hbk;
+  HBK_REQUIRE(n >= 0 && (n == 0 || (bytes && tables)) && slab != nullptr,
+              "tables_alloc: bad arguments");
+  *slab = nullptr;
+  if (n == 0) return HBK_OK;
+  std::vector<size_t> off((size_t)n);
+  const size_t total = hbk_tables_layout(n, bytes, off.data());
+  void* p = nullptr;
+  const hipError_t e = hipMalloc(&p, total > 0 ? total : 1);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(HBK_INTERNAL, "tables_alloc: hipMalloc of %zu bytes failed: %s", total,
+                hipGetErrorString(e));
+  }
+  for (int32_t i = 0; i < n; ++i) tables[i] = static_cast<char*>(p) + off[(size_t)i];
+  *slab = p;
+  return HBK_OK;
+}
+extern "C" int hbk_tables_free(void* slab) {
+  using namespace hbk;
+  if (slab == nullptr) return HBK_OK;
+  const hipError_t e = hipFree(slab);
+  if (e != hipSuccess) return fail(HBK_INTERNAL, "tables_free: %s", hipGetErrorString(e));
+  return HBK_OK;
+}
 
 // Host-side evaluation of the device's divide-free floor-mod / floor-div (common.h), so the
 // magic-number arithmetic can be checked exhaustively without a GPU.

@@ -9,5 +9,6 @@ from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
 from hybridbackend_amd.embedding.unique import UniqueN
 from hybridbackend_amd.embedding.unique import unique
 from hybridbackend_amd.embedding.unique import unique_n
+from hybridbackend_amd.embedding.variables import allocate_tables
 from hybridbackend_amd.embedding.variables import shard_of_table
 from hybridbackend_amd.embedding.variables import sharded_bucket_size

@@ -68,6 +68,15 @@ typedef void* hbk_stream_t;
 const char* hbk_last_error(void);
 /* "hbk <version> gfx950" */
 const char* hbk_version(void);
+
+/* Table memory (optional; tables stay caller-owned): one slab for N tables, each at a 2 MB-aligned
+ * offset -- the policy that was fastest in every run of tools/placement_probe
+ * (profiles/r05_placement.txt).  hbk_tables_layout only computes the offsets (returns the slab size)
+ * for callers that carve their own memory (a TF allocator, torch); hbk_tables_alloc does it with
+ * hipMalloc; hbk_tables_free releases the slab. */
+size_t hbk_tables_layout(int32_t n, const size_t* bytes, size_t* offsets);
+int hbk_tables_alloc(int32_t n, const size_t* bytes, void** tables, void** slab);
+int hbk_tables_free(void* slab);
 /* Tuning / diagnostic options of the library, process wide.  Defaults come from the environment
  * once, when the library is first used (HBK_BWD_LOG2P, HBK_BWD_TARGET, HBK_BWD_SPLIT,
  * HBK_BWD_ONEPASS, HBK_BWD_GROUP_COLS, HBK_UNIQUE_LOG2P, HBK_UNIQUE_ONEPASS, HBK_PART_SUB, HBK_PART_FIXED,

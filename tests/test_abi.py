@@ -333,3 +333,23 @@ def test_tf_shim_parses_and_type_checks():
   r = subprocess.run(['make', '-s', '-C', os.path.join(ROOT, 'integration', 'tf_shim'), 'check'],
                      capture_output=True, text=True, timeout=300)
   assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_tables_layout_puts_every_table_on_a_2mb_boundary():
+  """hbk_tables_layout (host arithmetic of hbk_tables_alloc / hb.embedding.allocate_tables): one
+  slab, 2 MB-aligned offsets -- the policy profiles/r05_placement.txt measured as the fastest."""
+  import hybridbackend_amd as hb
+  lib = _lib.lib()
+  two_mb = 2 << 20
+  sizes = (C.c_size_t * 4)(100, two_mb, two_mb + 1, 0)
+  offs = (C.c_size_t * 4)()
+  total = lib.hbk_tables_layout(4, sizes, offs)
+  assert list(offs) == [0, two_mb, 2 * two_mb, 4 * two_mb] and total == 4 * two_mb
+  assert lib.hbk_tables_layout(0, None, None) == 0
+  tables = hb.embedding.allocate_tables([(10, 4), (1000, 16), (3, 128)], device='cpu')
+  assert [tuple(t.shape) for t in tables] == [(10, 4), (1000, 16), (3, 128)]
+  assert all(t.data_ptr() % two_mb == 0 and t.dtype.is_floating_point for t in tables)
+  tables[1].fill_(1.0)                     # disjoint views of one slab
+  tables[0].zero_()
+  tables[2].zero_()
+  assert float(tables[1].sum()) == 16000.0

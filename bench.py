@@ -397,6 +397,10 @@ def main():
   else:
     coll = hb.distribute.Collective(world_size=world, rank=rank, local_size=world)
     hb.distribute.Collective.set_default(coll)
+    # what RCCL itself says it connected (ncclCommCount): proof in the line that the exchanges of a
+    # multi-GPU number ran through ONE communicator spanning all ranks
+    from hybridbackend_amd import _lib as _hbk_lib
+    rccl_ranks_seen = int(_hbk_lib.lib().hbk_comm_rccl_ranks(coll._handle))
     sharded = hb.embedding.ShardedGroupLookup(
       tables, coll, buckets=[args.rows] * args.columns, combiners='sum',
       wire_dtype=torch.float16 if args.wire == 'fp16' else None)
@@ -557,6 +561,7 @@ def main():
                  # the form the timed steps ran in, picked on this machine by the probe below;
                  # 'pipelined_2_groups' is the library's shipped default: its probe time is the
                  # figure comparable with runs that do not tune (--tune-steps 0)
+                 'rccl_ranks_seen': (rccl_ranks_seen if (world > 1 or args.sharded) else None),
                  'sharded_form': best_form,
                  'sharded_form_probe_ms_per_step': groups_probe,
                  'value_at_shipped_default_M_lookups_per_s': (

@@ -88,6 +88,7 @@ def _declare(l):
     'hbk_tables_free': (C.c_int, [vp]),
     'hbk_set_option': (C.c_int, [C.c_char_p, i32]),
     'hbk_get_option': (C.c_int, [C.c_char_p, vp]),
+    'hbk_comm_rccl_ranks': (C.c_int, [vp]),
     'hbk_sync_check': (C.c_int, []),
     'hbk_sync_check_stream': (C.c_int, [C.c_void_p]),
     'hbk_host_floormod_i64': (i64, [i64, i64]),

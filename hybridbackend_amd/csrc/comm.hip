@@ -263,6 +263,16 @@ extern "C" int hbk_comm_check_async(hbk_comm_t comm) {
 
 extern "C" int hbk_comm_world_size(hbk_comm_t comm) { return comm ? comm->world_size : 0; }
 extern "C" int hbk_comm_rank(hbk_comm_t comm) { return comm ? comm->rank : -1; }
+// what RCCL itself says about the communicator (ncclCommCount): the number of ranks it connected --
+// 0 for a custom transport (no RCCL communicator behind it), -1 on error.  bench.py prints it as
+// `rccl_ranks_seen`, so a multi-GPU number comes with proof that RCCL spanned the ranks.
+extern "C" int hbk_comm_rccl_ranks(hbk_comm_t comm) {
+  if (comm == nullptr) return -1;
+  if (comm->custom) return 0;
+  int n = -1;
+  if (ncclCommCount(comm->comm, &n) != ncclSuccess) return -1;
+  return n;
+}
 extern "C" hbk_stream_t hbk_comm_stream(hbk_comm_t comm) {
   return comm ? reinterpret_cast<hbk_stream_t>(comm->stream) : nullptr;
 }

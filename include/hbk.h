@@ -397,6 +397,9 @@ int hbk_comm_destroy(hbk_comm_t comm);
 int hbk_comm_check_async(hbk_comm_t comm);
 int hbk_comm_world_size(hbk_comm_t comm);
 int hbk_comm_rank(hbk_comm_t comm);
+/* ncclCommCount of the RCCL communicator behind the handle: the ranks RCCL itself connected
+ * (0: custom transport, -1: error).  Reported by bench.py as `rccl_ranks_seen`. */
+int hbk_comm_rccl_ranks(hbk_comm_t comm);
 /* the communicator's private stream (a hipStream_t) */
 hbk_stream_t hbk_comm_stream(hbk_comm_t comm);
 /* R4  Collective::compute_active_ranks, hbtf/distribute/collective.h:80-112.

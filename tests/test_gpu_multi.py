@@ -1,0 +1,115 @@
+"""Real RCCL between real processes: one process per GPU, `hbk_comm_create`
+over `ncclCommInitRank`, and through it the reference's 2-rank known-answer vectors
+(hybridbackend/tensorflow/distribute/tests/alltoall_test.py:219-269), Alltoallv[N] against the offset
+arithmetic of nccl_collective.cc:250-288, the equal split, `hbk_sharded_lookup_fwd/_bwd` in every form
+(pipelined / one group / inline exchanges, fp32 and fp16 wire, int32 and int64 ids, early and late id
+pack, requester-side dedup) against the UNSHARDED oracle -- forward bit-exact, backward == the dense
+scatter-add of all ranks' gradients, the fused SGD step on the shard -- and the gradient aggregation
+(Allreduce / Allgatherv).
+
+The tests ARM THEMSELVES: a world of W ranks runs when `torch.cuda.device_count() >= W` and is
+skipped otherwise, so on the 1-GPU box only the world-1 cases run (they validate the harness and RCCL's
+self path) and the first multi-GPU box yields a parity verdict for R5 / R12 / (e), not only a
+throughput number.  The rank program is tests/support/multi_worker.py."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, 'tests', 'support', 'multi_worker.py')
+GROUPS = {
+    'collectives': 'kat,alltoallv,alltoall,reduce',
+    'sharded': 'sharded',
+    'dedup': 'dedup',
+}
+
+
+def _devices():
+  try:
+    return torch.cuda.device_count()
+  except Exception:  # pylint: disable=broad-except
+    return 0
+
+
+def run_world(world, cases, tmp_path, timeout_s=420, local_size=0):
+  """Start `world` rank processes, wait for their result files, kill the rest when one fails."""
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+  procs, logs = [], []
+  for r in range(world):
+    log = open(os.path.join(tmp_path, f'rank_{r}.log'), 'w')
+    logs.append(log)
+    procs.append(subprocess.Popen(
+        [sys.executable, WORKER, '--rank', str(r), '--world', str(world), '--dir', str(tmp_path),
+         '--cases', cases, '--local-size', str(local_size)],
+        stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT))
+  deadline = time.time() + timeout_s
+  failed = None
+  try:
+    while time.time() < deadline:
+      codes = [p.poll() for p in procs]
+      if any(c is not None and c != 0 for c in codes):
+        failed = [r for r, c in enumerate(codes) if c is not None and c != 0]
+        break
+      if all(c == 0 for c in codes):
+        break
+      time.sleep(0.05)
+    else:
+      failed = 'timeout'
+  finally:
+    for p in procs:          # exactly the processes started here
+      if p.poll() is None:
+        p.kill()
+    for p in procs:
+      p.wait()
+    for log in logs:
+      log.close()
+  results = []
+  for r in range(world):
+    path = os.path.join(tmp_path, f'result_{r}.json')
+    results.append(json.load(open(path)) if os.path.exists(path) else None)
+
+  def tail(r):
+    with open(os.path.join(tmp_path, f'rank_{r}.log')) as f:
+      return f.read()[-3000:]
+  if failed is not None:
+    detail = []
+    for r in range(world):
+      res = results[r]
+      if res is None or not res['ok']:
+        detail.append(f'--- rank {r}: ' + ('\n'.join(res['errors']) if res else 'no result file')
+                      + '\n' + tail(r))
+    pytest.fail(f'world {world}, cases {cases}: {failed}\n' + '\n'.join(detail)[:12000])
+  return results
+
+
+@pytest.mark.parametrize('group', sorted(GROUPS))
+@pytest.mark.parametrize('world', [1, 2, 4, 8])
+def test_real_rccl_ranks(world, group, tmp_path):
+  if _devices() < world:
+    pytest.skip(f'needs {world} GPUs, {_devices()} visible')
+  results = run_world(world, GROUPS[group], str(tmp_path))
+  wanted = [c for c in GROUPS[group].split(',')]
+  for r, res in enumerate(results):
+    assert res is not None and res['ok'], (r, res)
+    assert res['rccl_ranks_seen'] == world          # ncclCommCount: RCCL itself spans the ranks
+    assert res['passed'] == wanted, (r, res['passed'])
+
+
+@pytest.mark.parametrize('local_size,nodes', [(2, 2), (4, 2), (2, 4)])
+def test_real_rccl_sub_group_topologies(local_size, nodes, tmp_path):
+  """INTRA_NODE / INTER_NODE exchanges (R4, collective.h:80-112) on a single box: the world is
+  declared as `nodes` x `local_size`; the sharded step itself always runs on Topology.ALL."""
+  world = local_size * nodes
+  if _devices() < world:
+    pytest.skip(f'needs {world} GPUs, {_devices()} visible')
+  results = run_world(world, 'topology', str(tmp_path), local_size=local_size)
+  for res in results:
+    assert res is not None and res['ok'] and res['passed'] == ['topology'], res

@@ -235,6 +235,8 @@ struct GCol {
                              // mulhi(row, dense_mul), and the reduce stage indexes its LDS tables
                              // directly with row - first row of the range (4b); 0: hashed buckets
   int32_t rowsort;           // dense column whose buckets take the row-sorted reduce (4c)
+  int32_t packed;            // row-sorted columns (rows < 2^32): a pair is ONE word of pair_row[],
+                             // row << 32 | gradient row (segment / float offset); pair_seg[] is not used
 };
 
 struct GArgs {
@@ -349,6 +351,87 @@ __device__ inline void scale_segments(const GCol& c, int64_t s0, int n, const in
   }
 }
 
+// ---- 0a: the segment of an id, found inside the grouping kernels (round 5) -----------------------
+// A tile is kTile CONSECUTIVE ids of a ragged column, so the segments they belong to are one
+// contiguous range [s_lo, s_hi] of the row splits: two waves find its ends with a 64-ary search
+// over the column's splits (a wave probes 64 splits per round trip: 3 rounds for 65536 segments),
+// the range's splits go to LDS (into the staging area the tile only fills later) and every id
+// finds its segment by a binary search there.  Replaces the seg-of launch and its [n_ids] array
+// (54 MB written and read per 13.6 M ids).  A tile whose range holds more splits than the LDS
+// area (thousands of empty segments) searches the global splits, bounded by [s_lo, s_hi].
+// last s in [0, n_seg) with splits[s] <= j (empty segments share their start with the next one and
+// are skipped by taking the last); wave-uniform result.  Requires splits[0] <= j.
+__device__ inline int32_t seg_search_wave(const int32_t* splits, int64_t n_seg, int32_t j) {
+  const int lane = (int)threadIdx.x & (kWave - 1);
+  int64_t lo = 0, n = n_seg;   // answer in [lo, lo + n)
+  while (n > 1) {
+    const int64_t step = (n + kWave - 1) / kWave;
+    const int64_t s = lo + (int64_t)lane * step;
+    const bool le = s < lo + n && splits[s] <= j;
+    const int k = (int)__builtin_popcountll(__ballot(le));   // >= 1: lane 0 probes splits[lo] <= j
+    const int64_t nlo = lo + (int64_t)(k - 1) * step;
+    const int64_t rest = lo + n - nlo;
+    lo = nlo;
+    n = rest < step ? rest : step;
+  }
+  return (int32_t)lo;
+}
+
+struct TileSegs {
+  int32_t s_lo;       // first segment of the tile's range
+  int32_t n_sp;       // splits of the range held in LDS (0: search the global splits)
+  int32_t s_hi;
+};
+
+// Called by every thread of the workgroup (two barriers inside).  sp_lds: cap int32 of LDS;
+// ends: 2 int32 of LDS.  j_first / j_last: first and last id position of the tile (j_last >= j_first).
+__device__ inline TileSegs tile_segments(const GCol& c, int64_t j_first, int64_t j_last,
+                                         int32_t* sp_lds, int cap, int32_t* ends) {
+  const int tid = (int)threadIdx.x, wave = tid >> 6;
+  if (wave == 0) {
+    const int32_t s = seg_search_wave(c.splits, c.n_seg, (int32_t)j_first);
+    if (tid == 0) ends[0] = s;
+  } else if (wave == 1) {
+    const int32_t s = seg_search_wave(c.splits, c.n_seg, (int32_t)j_last);
+    if (tid == kWave) ends[1] = s;
+  }
+  __syncthreads();
+  TileSegs t;
+  t.s_lo = ends[0];
+  t.s_hi = ends[1];
+  const int n = t.s_hi - t.s_lo + 1;
+  t.n_sp = n <= cap ? n : 0;
+  for (int i = tid; i < t.n_sp; i += kBlock) sp_lds[i] = c.splits[t.s_lo + i];
+  __syncthreads();
+  return t;
+}
+
+__device__ inline int32_t tile_seg_of(const GCol& c, const TileSegs& t, const int32_t* sp_lds,
+                                      int32_t j) {
+  int s = 0, e = t.s_hi - t.s_lo + 1;   // answer in [s, e), relative to s_lo
+  if (t.n_sp > 0) {
+    while (e - s > 1) {
+      const int mid = (s + e) >> 1;
+      if (sp_lds[mid] <= j) {
+        s = mid;
+      } else {
+        e = mid;
+      }
+    }
+  } else {
+    const int32_t* sp = c.splits + t.s_lo;
+    while (e - s > 1) {
+      const int mid = (s + e) >> 1;
+      if (sp[mid] <= j) {
+        s = mid;
+      } else {
+        e = mid;
+      }
+    }
+  }
+  return t.s_lo + s;
+}
+
 // ---- 0: segment of every id (ragged columns only; the host passes just those) --------------
 // A workgroup takes kBlock consecutive segments, i.e. ONE contiguous range of ids: their row
 // splits go to LDS and every thread finds the segment of ids tid, tid + kBlock, .. of the range by
@@ -364,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void bwd_segof_kernel(const GArgs a) {
   if (tid < n) sp[tid] = c.splits[s0 + tid];
   if (tid == 0) sp[n] = c.splits[s0 + n];
   __syncthreads();
-  const int32_t lo = sp[0], hi = sp[n];
+  const int32_t lo = sp[0], hi = c.seg_of != nullptr ? sp[n] : sp[0];   // (no array: scaling only)
   for (int32_t j = lo + tid; j < hi; j += kBlock) {
     // the segment s with sp[s] <= j < sp[s + 1]: the last s with sp[s] <= j (empty segments share
     // their start with the next one and are skipped by taking the last)
@@ -569,6 +652,16 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
   const int tid = (int)threadIdx.x;
   const int ctile = blk - c.tile0;
   const int64_t base = (int64_t)ctile * kTile;
+  // ragged column without a seg-of array: the tile's row splits in LDS (0a)
+  constexpr int kSpCap = kTile + 256;
+  __shared__ int32_t sp_lds[kSpCap];
+  __shared__ int32_t seg_ends[2];
+  const bool seg_inline = c.splits != nullptr && c.seg_of == nullptr;   // block-uniform
+  TileSegs ts = {0, 0, 0};
+  if (seg_inline) {
+    const int64_t j_last = (base + kTile < c.n_ids ? base + kTile : c.n_ids) - 1;
+    ts = tile_segments(c, base, j_last, sp_lds, kSpCap, seg_ends);
+  }
   RunCursor rc;
   int64_t id[kBatch];
   int32_t seg[kBatch];
@@ -585,7 +678,11 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
           seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);
         }
         id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
-        if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
+        if (c.seg_of != nullptr) {
+          seg[k] = c.seg_of[j];
+        } else if (seg_inline) {
+          seg[k] = tile_seg_of(c, ts, sp_lds, (int32_t)j);
+        }
       }
     }
   };
@@ -601,8 +698,12 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
         const uint64_t r = id_to_row(c.map, id[k]);
         if (r != kNoRow) {
           const int32_t pos = atomicAdd(&run[bucket_of(c, r)], 1);
-          c.pair_row[0][pos] = (int64_t)r;
-          c.pair_seg[0][pos] = seg[k];
+          if (c.packed) {
+            c.pair_row[0][pos] = (int64_t)((r << 32) | (uint64_t)(uint32_t)seg[k]);
+          } else {
+            c.pair_row[0][pos] = (int64_t)r;
+            c.pair_seg[0][pos] = seg[k];
+          }
         }
       }
     }
@@ -640,6 +741,16 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int ctile = blk - c.tile0;
   const int64_t base = (int64_t)ctile * kTile;
+  // ragged column without a seg-of array: the tile's row splits go to LDS (0a) -- into the staging
+  // area, which is only filled after the segments have been found
+  __shared__ int32_t seg_ends[2];
+  int32_t* const sp_lds = reinterpret_cast<int32_t*>(st_row);
+  const bool seg_inline = c.splits != nullptr && c.seg_of == nullptr;   // block-uniform
+  TileSegs ts = {0, 0, 0};
+  if (seg_inline) {
+    const int64_t j_last = (base + kTile < c.n_ids ? base + kTile : c.n_ids) - 1;
+    ts = tile_segments(c, base, j_last, sp_lds, 2 * kTile, seg_ends);
+  }
   RunCursor rc;
   int64_t id[kPerThread];
   int32_t seg[kPerThread];
@@ -654,7 +765,11 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
         seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);
       }
       id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
-      if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
+      if (c.seg_of != nullptr) {
+        seg[k] = c.seg_of[j];
+      } else if (seg_inline) {
+        seg[k] = tile_seg_of(c, ts, sp_lds, (int32_t)j);
+      }
     }
   }
   // where the tile's share of every bucket starts in the pair arrays (travels beside the ids)
@@ -717,8 +832,12 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
     if (br[k] >= 0) {
       const int b = br[k] & 1023;
       const int L = first[b] + (br[k] >> 10);
-      st_row[L] = id[k];
-      st_seg[L] = seg[k];
+      if (c.packed) {   // (block-uniform) one word per pair: row << 32 | gradient row
+        st_row[L] = (int64_t)(((uint64_t)id[k] << 32) | (uint64_t)(uint32_t)seg[k]);
+      } else {
+        st_row[L] = id[k];
+        st_seg[L] = seg[k];
+      }
       st_b[L] = (uint16_t)b;
     }
   }
@@ -730,7 +849,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
     if (L < n_st) {
       const int32_t pos = counters[st_b[L]] + L;
       c.pair_row[0][pos] = st_row[L];
-      c.pair_seg[0][pos] = st_seg[L];
+      if (!c.packed) c.pair_seg[0][pos] = st_seg[L];
     }
   }
 }
@@ -791,6 +910,16 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
   const int n_tiles = (int)((c.n_ids + kTile - 1) / kTile);
   const int64_t base = (int64_t)ctile * kTile;
   int32_t* hist = y.hist + c.sync0;
+  // ragged column without a seg-of array: the tile's row splits in LDS (0a; the staging area is
+  // only filled after the wait)
+  __shared__ int32_t seg_ends[2];
+  int32_t* const sp_lds = reinterpret_cast<int32_t*>(st_row);
+  const bool seg_inline = c.splits != nullptr && c.seg_of == nullptr;   // block-uniform
+  TileSegs ts = {0, 0, 0};
+  if (seg_inline) {
+    const int64_t j_last = (base + kTile < c.n_ids ? base + kTile : c.n_ids) - 1;
+    ts = tile_segments(c, base, j_last, sp_lds, 2 * kTile, seg_ends);
+  }
   RunCursor rc;
   int64_t id[kPerThread];
   int32_t seg[kPerThread];
@@ -805,7 +934,11 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
         seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);
       }
       id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
-      if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
+      if (c.seg_of != nullptr) {
+        seg[k] = c.seg_of[j];
+      } else if (seg_inline) {
+        seg[k] = tile_seg_of(c, ts, sp_lds, (int32_t)j);
+      }
     }
   }
   for (int p = tid; p < P; p += kBlock) counters[p] = 0;
@@ -957,8 +1090,12 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
     if (br[k] >= 0) {
       const int b = br[k] & 1023;
       const int L = pre_s[b] + (br[k] >> 10);
-      st_row[L] = id[k];
-      st_seg[L] = seg[k];
+      if (c.packed) {   // (block-uniform) one word per pair: row << 32 | gradient row
+        st_row[L] = (int64_t)(((uint64_t)id[k] << 32) | (uint64_t)(uint32_t)seg[k]);
+      } else {
+        st_row[L] = id[k];
+        st_seg[L] = seg[k];
+      }
       st_b[L] = (uint16_t)b;
     }
   }
@@ -970,7 +1107,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
     if (L < n_st) {
       const int32_t pos = tot_s[st_b[L]] + L;
       c.pair_row[0][pos] = st_row[L];
-      c.pair_seg[0][pos] = st_seg[L];
+      if (!c.packed) c.pair_seg[0][pos] = st_seg[L];
     }
   }
   HBK_GSTAMP(6);            // stores issued
@@ -1019,6 +1156,7 @@ struct ReduceJob {
   int32_t out_base;          // added to the claimed index
   float lr;                  // != 0: fused optimizer step on the table row
   int32_t apply;             // HBK_APPLY_SGD | HBK_APPLY_ADAGRAD
+  bool packed;               // prow holds row << 32 | gradient row (GCol.packed); pseg is not read
   bool no_emit;              // "step only" (the caller wants no IndexedSlices) and the job is one
                              // chunk: rows are stepped where their sums sit in registers, nothing
                              // is written out and no output range is claimed
@@ -2571,6 +2709,7 @@ __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4&
   *ci_out = ci;
   const int32_t start = d.x, n_b = d.y, bucket = d.z, range = d.w;
   job->no_emit = false;
+  job->packed = c.packed != 0;
   job->grad = c.grad_out;
   job->scale = true;
   job->seg_is_offset = c.n_runs > 0;
@@ -2578,7 +2717,7 @@ __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4&
   if (n_b > c.split_t) {
     const int32_t lo = range * c.split_t;
     job->prow = c.pair_row[0] + start + lo;
-    job->pseg = c.pair_seg[0] + start + lo;
+    job->pseg = c.packed ? nullptr : c.pair_seg[0] + start + lo;
     job->n_pairs = n_b - lo < c.split_t ? n_b - lo : c.split_t;
     job->out_rows = c.part_rows;
     job->out_vals = c.part_vals;
@@ -2588,7 +2727,7 @@ __device__ inline bool decode_job(const GArgs& a, int my_b0, int vb, const int4&
     job->apply = HBK_APPLY_SGD;
   } else {
     job->prow = c.pair_row[0] + start;
-    job->pseg = c.pair_seg[0] + start;
+    job->pseg = c.packed ? nullptr : c.pair_seg[0] + start;
     job->n_pairs = n_b;
     job->out_rows = c.unique_rows;
     job->out_vals = c.grad_rows;
@@ -2710,6 +2849,7 @@ __device__ inline void merge_job(const GArgs& a, const GCol& c, int bucket, Redu
   const int32_t start = c.bstart[bucket];
   job->prow = c.part_rows + start;
   job->pseg = nullptr;
+  job->packed = false;
   job->grad = c.part_vals + (int64_t)start * c.dim;
   job->n_pairs = c.pcount[bucket];
   job->scale = false;
@@ -2998,14 +3138,19 @@ ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged) {
   return p;
 }
 
+// row-sorted columns keep a pair as ONE word (GCol.packed)
+inline bool pairs_packed(const ColPlan& p) { return p.rowsort && options().bwd_pairs_packed != 0; }
+
 size_t col_workspace(const hbk_lookup_grad_column_t& h) {
   if (h.n_ids <= 0) return 0;
   const ColPlan p = plan_of(h.n_ids, h.dim, h.rows, h.row_splits != nullptr);
   size_t b = align8(((size_t)p.tiles * p.n_buckets) * 4);   // hist
   b += align8(((size_t)p.n_buckets + 1) * 4);          // bstart
   b += (size_t)h.n_ids * 8;                                // pair_row
-  b += align8((size_t)h.n_ids * 4);                        // pair_seg
-  if (h.row_splits != nullptr) b += align8((size_t)h.n_ids * 4);
+  if (!pairs_packed(p)) b += align8((size_t)h.n_ids * 4);  // pair_seg
+  if (h.row_splits != nullptr && options().bwd_seg_inline == 0) {
+    b += align8((size_t)h.n_ids * 4);                      // seg_of
+  }
   if (h.row_splits != nullptr && h.combiner != HBK_COMBINER_SUM) {
     b += align8((size_t)h.n_segments * h.dim * 4) + 16;   // the segments' scaled gradient rows
   }
@@ -3327,10 +3472,16 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       wp += align8(((size_t)p.n_buckets + 1) * 4);
       d.pair_row[0] = reinterpret_cast<int64_t*>(wp);
       wp += (size_t)h.n_ids * 8;
-      d.pair_seg[0] = reinterpret_cast<int32_t*>(wp);
-      wp += align8((size_t)h.n_ids * 4);
+      d.packed = pairs_packed(p) ? 1 : 0;
+      d.pair_seg[0] = nullptr;
+      if (!d.packed) {
+        d.pair_seg[0] = reinterpret_cast<int32_t*>(wp);
+        wp += align8((size_t)h.n_ids * 4);
+      }
+      // ragged columns: the grouping kernels find the segment of an id themselves (0a); option
+      // bwd_seg_inline = 0 keeps the seg-of array and the launch that writes it
       d.seg_of = nullptr;
-      if (h.row_splits != nullptr) {
+      if (h.row_splits != nullptr && options().bwd_seg_inline == 0) {
         d.seg_of = reinterpret_cast<int32_t*>(wp);
         wp += align8((size_t)h.n_ids * 4);
       }
@@ -3409,7 +3560,8 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       args.merge0[k] = d.merge0;
       args.scan0[k] = d.scan0;
       args.segtile0[k] = 0;
-      if (h.row_splits != nullptr && h.n_segments > 0) {
+      // the seg-of launch: columns with a seg-of array, or with rows to scale (mean / sqrtn)
+      if (h.row_splits != nullptr && h.n_segments > 0 && (d.seg_of != nullptr || scaled != nullptr)) {
         GCol& sdesc = seg_args.col[ks];
         sdesc = d;
         sdesc.scaled = scaled;

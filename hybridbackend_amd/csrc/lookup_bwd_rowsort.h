@@ -129,7 +129,8 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   if (lim > c.map.rows) lim = c.map.rows;
   const int words = (int)((lim - base + 31) >> 5);   // <= kRsWords (host: plan_of)
 
-  const bool pairs_nt = c.seg_of != nullptr && pseg != nullptr;   // ragged column, not a merge job
+  const bool packed = job.packed;   // uniform: one word per pair, row << 32 | gradient row
+  const bool pairs_nt = c.splits != nullptr && (packed || pseg != nullptr);   // ragged column, not a merge job
   uint32_t off_[PT];   // row - base of my pairs of the chunk, ~0u: none
   int32_t seg_[PT];
   auto load_pairs = [&](int32_t cb) {
@@ -154,7 +155,10 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
         r_[k] = HBK_PAIR_LOAD(prow + (e < n_pairs ? e : n_pairs - 1));
       }
     }
-    if (pseg != nullptr && pairs_nt) {   // uniform
+    if (packed) {
+#pragma unroll
+      for (int k = 0; k < PT; ++k) seg_[k] = (int32_t)(uint32_t)(uint64_t)r_[k];
+    } else if (pseg != nullptr && pairs_nt) {   // uniform
 #pragma unroll
       for (int k = 0; k < PT; ++k) {
         const int32_t e = cb + k * kBlock + tid;
@@ -173,7 +177,11 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
       const int32_t e = cb + k * kBlock + tid;
-      off_[k] = e < n_pairs && r_[k] >= 0 ? (uint32_t)r_[k] - base : ~0u;
+      if (packed) {
+        off_[k] = e < n_pairs ? (uint32_t)((uint64_t)r_[k] >> 32) - base : ~0u;
+      } else {
+        off_[k] = e < n_pairs && r_[k] >= 0 ? (uint32_t)r_[k] - base : ~0u;
+      }
     }
   };
   // A: rows -> bitmap (a bit that is set is not set again: a hot row's pairs would serialise)

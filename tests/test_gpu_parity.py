@@ -5,6 +5,7 @@ fp32 combiner: bit-exact against the oracle's in-order fp32 sum AND within 1e-5 
 its float64 accumulation (the tolerance BASELINE.json's north_star states).
 Backward duplicate reduction (atomics, order not fixed): 1e-5 relative.
 """
+import ctypes as C
 import json
 import os
 
@@ -14,6 +15,7 @@ import torch
 
 import oracle
 import hybridbackend_amd as hb
+from hybridbackend_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -825,6 +827,88 @@ def test_group_lookup_backward_rowsort_buckets(hbk_option, dense, mode):
       else:
         np.testing.assert_allclose(host(t_dev[c]), tables[c].astype(np.float64) - 0.05 * want,
                                    rtol=RTOL, atol=1e-4 + 0.05 * atol)
+
+
+@pytest.mark.parametrize('dense', [3, 1, 0])
+@pytest.mark.parametrize('onepass', [1, 0])
+@pytest.mark.parametrize('packed,seg_inline', [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_group_lookup_backward_pair_words_and_inline_segments(hbk_option, packed, seg_inline,
+                                                              onepass, dense):
+  """Round 5: (a) row-sorted columns keep a pair as ONE 8-byte word, row << 32 | gradient row
+  (bwd_pairs_packed), (b) the grouping kernels find the segment of an id themselves from the tile's
+  row splits in LDS instead of reading a seg-of array written by a launch of its own
+  (bwd_seg_inline).  Both forms of both, in the one-launch and the three-launch grouping, on ragged
+  shapes that stress the search: runs of empty segments, segments longer than a tile, a tile whose
+  segment range holds more splits than the LDS area (global search), a single segment, a column
+  large enough for several tiles and the hist / scan / scatter path, rows at and beyond 2^31."""
+  hbk_option('bwd_pairs_packed', packed)
+  hbk_option('bwd_seg_inline', seg_inline)
+  hbk_option('bwd_onepass', onepass)
+  hbk_option('bwd_dense', dense)
+  rng = np.random.RandomState(505)
+
+  def lens_to_splits(lens):
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+  shapes = []
+  # many short segments with runs of empty ones in between
+  lens = rng.poisson(3, size=20000).clip(0, 12)
+  lens[rng.randint(0, 20000, size=6000)] = 0
+  lens[5000:5400] = 0
+  shapes.append((16, 40000, lens, 'mean'))
+  # segments far longer than a tile (2048 ids), and short ones
+  shapes.append((8, 3000, np.array([5000, 1, 0, 0, 7000, 3, 2048, 2049, 0, 1], np.int64), 'sqrtn'))
+  # one tile whose range of segments holds > 4096 splits: 9000 empty segments inside 2048 ids
+  lens = np.zeros(12000, np.int64)
+  lens[0] = 700
+  lens[9500] = 900
+  lens[11999] = 600
+  shapes.append((4, 500, lens, 'mean'))
+  # a single segment; a column of 150 000 ids (74 tiles: the three-launch grouping)
+  shapes.append((32, 100, np.array([777], np.int64), 'sum'))
+  shapes.append((16, 60000, rng.poisson(8, size=19000).clip(0, 32), 'mean'))
+  # empty leading and trailing segments
+  shapes.append((6, 1000, np.array([0, 0, 0, 40, 0, 9, 0, 0], np.int64), 'sum'))
+  for comb in ('sum', 'mean', 'sqrtn'):
+    sel = [q for q in shapes if q[3] == comb]
+    tables, ids, splits, grads = [], [], [], []
+    for d, rows, ln, _ in sel:
+      sp = lens_to_splits(ln)
+      tables.append(rng.uniform(-1, 1, size=(rows, d)).astype(np.float32))
+      ids.append(rng.randint(0, rows, size=int(sp[-1])).astype(np.int64))
+      splits.append(sp)
+      grads.append(rng.randn(sp.size - 1, d).astype(np.float32))
+    lookup = hb.embedding.GroupLookup([dev(t) for t in tables], None, comb)
+    res = hb.embedding.GroupLookupGrad(lookup)([dev(i) for i in ids], [dev(g) for g in grads],
+                                               [dev(s) for s in splits])
+    for c in range(len(sel)):
+      n_terms = np.bincount(ids[c]).max() if ids[c].size else 1
+      _check_slices(res[c], ids[c], grads[c], splits[c], comb,
+                    atol=RTOL * 4 * np.sqrt(max(n_terms, 1)))
+  # one id per segment next to them (no splits: nothing to search), row numbers around 2^31
+  rows = (1 << 31) + 5000
+  n = 30000
+  big_ids = np.concatenate([rng.randint(0, 4000, size=n // 2),
+                            rng.randint((1 << 31) - 2000, rows, size=n - n // 2)]).astype(np.int64)
+  g = rng.randn(n, 4).astype(np.float32)
+  # (the table itself is never touched without an optimizer step: a small stand-in buffer, the
+  # row count comes from the descriptor)
+  lib = _lib.lib()
+  cols = (_lib.LookupGradColumn * 1)()
+  k = cols[0]
+  ids_d, g_d = dev(big_ids), dev(g)
+  urows = torch.empty(n, dtype=torch.int64, device=DEV)
+  grows = torch.empty((n, 4), dtype=torch.float32, device=DEV)
+  nu = torch.zeros(1, dtype=torch.int32, device=DEV)
+  k.table, k.rows, k.dim, k.ids_dtype = None, rows, 4, _lib.INT64
+  k.ids, k.n_ids, k.row_splits, k.n_segments = ids_d.data_ptr(), n, None, n
+  k.bucket, k.divisor, k.combiner = 0, 1, 0
+  k.grad_out, k.unique_rows, k.grad_rows, k.n_unique = (g_d.data_ptr(), urows.data_ptr(),
+                                                       grows.data_ptr(), nu.data_ptr())
+  need = lib.hbk_group_lookup_bwd_workspace_bytes(1, cols)
+  ws = torch.empty(max(need, 8), dtype=torch.uint8, device=DEV)
+  _lib.check(lib.hbk_group_lookup_bwd(1, cols, C.c_float(0.0), C.c_void_p(ws.data_ptr()),
+                                      C.c_size_t(ws.numel()), _lib.current_stream(torch.device(DEV))))
+  _check_slices((urows, grows, nu), big_ids, g, None, 'sum')
 
 
 @pytest.mark.parametrize('dense', [3, 2, 1, 0])

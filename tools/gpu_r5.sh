@@ -66,6 +66,14 @@ for st in $STAGES; do
       python tools/prof_summary.py chunks $O/pmc_place1 group_lookup_fwd 4 malloc,slab,vmm_1g,malloc_rev,frag,vmm_2m,malloc,slab,vmm_1g,malloc,slab,vmm_1g,malloc_rev,frag,vmm_2m,malloc,slab,vmm_1g | tee $O/place_counters.txt; trim pmc_place1;;
     bwdbase)    # where the backward family stands on this box before round 5's changes
       (for w in b s R r d w; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk "; done) > $O/bwdbase.log 2>&1; cut -c1-200 $O/bwdbase.log;;
+    bwdab)      # round 5 levers (a) packed pair words, (b) segments found inside the grouping kernels
+      (for cfg in "0 0" "1 0" "0 1" "1 1" "1 1" "0 0"; do set -- $cfg
+         for w in R b s r; do
+           HBK_BWD_PAIRS_PACKED=$1 HBK_BWD_SEG_INLINE=$2 timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/packed=$1 seg_inline=$2  /"
+         done
+       done) > $O/bwdab.log 2>&1; cut -c1-200 $O/bwdab.log;;
+    bwdtest)
+      timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -m gpu -x -k "backward or random or graph" --durations=8 > $O/bwdtest.log 2>&1; echo "pytest rc=$?" >> $O/bwdtest.log; tail -25 $O/bwdtest.log;;
     t_*)        # t_<file stem>[:<-k expression>]: one test file, e.g. t_test_gpu_sync or t_test_gpu_parity:rowsort
       spec=${st#t_}; f=${spec%%:*}; k=""; [ "$spec" != "$f" ] && k=${spec#*:}
       timeout 1500 python -m pytest tests/$f.py -x -q -m gpu ${k:+-k "$k"} --durations=5 > $O/$f.log 2>&1; echo "pytest rc=$?" >> $O/$f.log; tail -15 $O/$f.log;;

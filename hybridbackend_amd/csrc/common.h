@@ -149,6 +149,7 @@ struct Options {
   int bwd_rowsort_pos = 64;    // HBK_BWD_ROWSORT_POS: > 0: row-sorted jobs sized for this many sorted positions per lane group (wide rows: smaller jobs)
   int bwd_pairs_packed = 1;    // HBK_BWD_PAIRS_PACKED: row-sorted columns: a pair is ONE 8-byte word (row << 32 | gradient row) instead of an int64 + an int32 array (0: two arrays)
   int bwd_seg_inline = 1;      // HBK_BWD_SEG_INLINE: ragged columns: the segment of an id is found inside the grouping kernels (row splits of the tile in LDS); 0: a seg-of array written by a launch of its own
+  int bwd_scale_fused = 1;     // HBK_BWD_SCALE_FUSED: large ragged mean / sqrtn columns: the segments' gradient rows are scaled by the histogram launch (0: by a launch of their own)
   int bwd_rowsort_ratio = 8;   // HBK_BWD_ROWSORT_RATIO: row-sorted buckets for columns of rows <= ratio x ids (twice that for dim <= 32; 0: never)
   int fwd_interleave = 2;      // HBK_FWD_INTERLEAVE: lookup tiles of one dense output block ordered row tile first (lookup_fwd.hip)
   int fwd_hot_rows = 0;        // HBK_FWD_HOT: forward of wide one-id-per-sample columns: 1 = 256-segment tiles with

@@ -203,8 +203,11 @@ struct GCol {
   int64_t* pair_row[1];      // [n_ids] rows of the pairs, grouped by bucket
   int32_t* pair_seg[1];      // [n_ids] their segments
   int32_t* seg_of;           // [n_ids], ragged columns only
-  float* scaled;             // seg-of launch only: [n_seg, dim] gradient rows times the combiner's 1 / n,
+  float* scaled;             // seg-of / histogram launch: [n_seg, dim] gradient rows times the combiner's 1 / n,
                              // 1 / sqrt(n) -- what the reduce stage then reads as a SUM column's gradient
+  const float* raw_grad;     // scaled != NULL in the histogram launch: the caller's gradient rows, their
+  int32_t raw_stride;        //   stride and the combiner (grad_out / grad_stride / combiner of such a
+  int32_t raw_combiner;      //   column already describe the scaled rows)
   int4* desc;                // [n_buckets + e_max] job of every reduce workgroup slot of the column:
                              // {first pair, pairs of the bucket, bucket or -1, range index}
   int32_t* work;             // [2 * e_max] (bucket, range index >= 1) of the spare workgroups
@@ -324,7 +327,8 @@ __device__ inline void run_seek(const GCol& c, int64_t j, RunCursor& rc) {
 }
 
 template <typename V>
-__device__ inline void scale_segments(const GCol& c, int64_t s0, int n, const int32_t* sp) {
+__device__ inline void scale_segments(const GCol& c, const float* grad, int32_t stride, int combiner,
+                                      int64_t s0, int n, const int32_t* sp) {
   constexpr int VE = sizeof(V) / 4;
   constexpr int kU = 4;   // rows in flight per lane (one at a time: 32 round trips per block at dim 128)
   const int tid = (int)threadIdx.x;
@@ -339,13 +343,13 @@ __device__ inline void scale_segments(const GCol& c, int64_t s0, int n, const in
       const int ss = s + u * groups < n ? s + u * groups : n - 1;   // (clamped: straight-line loads)
       len[u] = s + u * groups < n ? sp[ss + 1] - sp[ss] : 0;
       g[u] = __builtin_nontemporal_load(reinterpret_cast<const V*>(
-          c.grad_out + (s0 + ss) * (int64_t)c.grad_stride + (int64_t)sub * VE));
+          grad + (s0 + ss) * (int64_t)stride + (int64_t)sub * VE));
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       if (len[u] <= 0) continue;   // (no id names the segment: nobody reads its row)
-      const V v = c.combiner == HBK_COMBINER_MEAN ? g[u] / (float)len[u]
-                                                  : g[u] / sqrtf((float)len[u]);
+      const V v = combiner == HBK_COMBINER_MEAN ? g[u] / (float)len[u]
+                                                : g[u] / sqrtf((float)len[u]);
       *reinterpret_cast<V*>(c.scaled + (s0 + s + u * groups) * (int64_t)c.dim + (int64_t)sub * VE) = v;
     }
   }
@@ -353,14 +357,18 @@ __device__ inline void scale_segments(const GCol& c, int64_t s0, int n, const in
 
 // ---- 0a: the segment of an id, found inside the grouping kernels (round 5) -----------------------
 // A tile is kTile CONSECUTIVE ids of a ragged column, so the segments they belong to are one
-// contiguous range [s_lo, s_hi] of the row splits: two waves find its ends with a 64-ary search
-// over the column's splits (a wave probes 64 splits per round trip: 3 rounds for 65536 segments),
-// the range's splits go to LDS (into the staging area the tile only fills later) and every id
-// finds its segment by a binary search there.  Replaces the seg-of launch and its [n_ids] array
-// (54 MB written and read per 13.6 M ids).  A tile whose range holds more splits than the LDS
-// area (thousands of empty segments) searches the global splits, bounded by [s_lo, s_hi].
+// contiguous range [s_lo, s_hi] of the row splits.  Two waves find its ends with a 64-ary search
+// over the column's splits (a wave probes 64 splits per round trip: 3 rounds for 65536 segments).
+// Every segment of (s_lo, s_hi] STARTS inside the tile: the workgroup counts the starts per id
+// position in LDS (one LDS atomic per segment; empty segments share a position and just add to
+// its count) and ONE inclusive scan over the tile's kTile positions turns the counts into
+//     segment(j) = s_lo + starts at positions <= j
+// -- no search per id (a first version searched the splits per id: 9 dependent LDS reads for each
+// of a thread's 8 ids made the staged scatter 135 us instead of 115).  Replaces the seg-of launch
+// and its [n_ids] array (54 MB written and read per 13.6 M ids).  The LDS words are the staging
+// area the tile only fills later.
 // last s in [0, n_seg) with splits[s] <= j (empty segments share their start with the next one and
-// are skipped by taking the last); wave-uniform result.  Requires splits[0] <= j.
+// are skipped by taking the last); wave-uniform result.
 __device__ inline int32_t seg_search_wave(const int32_t* splits, int64_t n_seg, int32_t j) {
   const int lane = (int)threadIdx.x & (kWave - 1);
   int64_t lo = 0, n = n_seg;   // answer in [lo, lo + n)
@@ -368,7 +376,8 @@ __device__ inline int32_t seg_search_wave(const int32_t* splits, int64_t n_seg, 
     const int64_t step = (n + kWave - 1) / kWave;
     const int64_t s = lo + (int64_t)lane * step;
     const bool le = s < lo + n && splits[s] <= j;
-    const int k = (int)__builtin_popcountll(__ballot(le));   // >= 1: lane 0 probes splits[lo] <= j
+    int k = (int)__builtin_popcountll(__ballot(le));
+    if (k < 1) k = 1;   // (j before splits[0]: not a valid position; stay in range)
     const int64_t nlo = lo + (int64_t)(k - 1) * step;
     const int64_t rest = lo + n - nlo;
     lo = nlo;
@@ -377,17 +386,13 @@ __device__ inline int32_t seg_search_wave(const int32_t* splits, int64_t n_seg, 
   return (int32_t)lo;
 }
 
-struct TileSegs {
-  int32_t s_lo;       // first segment of the tile's range
-  int32_t n_sp;       // splits of the range held in LDS (0: search the global splits)
-  int32_t s_hi;
-};
-
-// Called by every thread of the workgroup (two barriers inside).  sp_lds: cap int32 of LDS;
-// ends: 2 int32 of LDS.  j_first / j_last: first and last id position of the tile (j_last >= j_first).
-__device__ inline TileSegs tile_segments(const GCol& c, int64_t j_first, int64_t j_last,
-                                         int32_t* sp_lds, int cap, int32_t* ends) {
-  const int tid = (int)threadIdx.x, wave = tid >> 6;
+// Called by every thread of the workgroup (barriers inside).  seg_lds: kTile int32 of LDS that
+// end up holding segment(base + p) - s_lo for every position p of the tile; ends: 2 + kWavesPerBlock
+// int32 of LDS.  Returns s_lo.  j_first / j_last: first and last id position of the tile.
+__device__ inline int32_t tile_segments(const GCol& c, int64_t j_first, int64_t j_last,
+                                        int32_t* seg_lds, int32_t* ends) {
+  static_assert(kTile == kBlock * kPerThread && kPerThread % 4 == 0, "whole int4 per thread");
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   if (wave == 0) {
     const int32_t s = seg_search_wave(c.splits, c.n_seg, (int32_t)j_first);
     if (tid == 0) ends[0] = s;
@@ -395,41 +400,45 @@ __device__ inline TileSegs tile_segments(const GCol& c, int64_t j_first, int64_t
     const int32_t s = seg_search_wave(c.splits, c.n_seg, (int32_t)j_last);
     if (tid == kWave) ends[1] = s;
   }
+  int4* const v4 = reinterpret_cast<int4*>(seg_lds) + tid * (kPerThread / 4);
+#pragma unroll
+  for (int q = 0; q < kPerThread / 4; ++q) v4[q] = make_int4(0, 0, 0, 0);
   __syncthreads();
-  TileSegs t;
-  t.s_lo = ends[0];
-  t.s_hi = ends[1];
-  const int n = t.s_hi - t.s_lo + 1;
-  t.n_sp = n <= cap ? n : 0;
-  for (int i = tid; i < t.n_sp; i += kBlock) sp_lds[i] = c.splits[t.s_lo + i];
-  __syncthreads();
-  return t;
-}
-
-__device__ inline int32_t tile_seg_of(const GCol& c, const TileSegs& t, const int32_t* sp_lds,
-                                      int32_t j) {
-  int s = 0, e = t.s_hi - t.s_lo + 1;   // answer in [s, e), relative to s_lo
-  if (t.n_sp > 0) {
-    while (e - s > 1) {
-      const int mid = (s + e) >> 1;
-      if (sp_lds[mid] <= j) {
-        s = mid;
-      } else {
-        e = mid;
-      }
-    }
-  } else {
-    const int32_t* sp = c.splits + t.s_lo;
-    while (e - s > 1) {
-      const int mid = (s + e) >> 1;
-      if (sp[mid] <= j) {
-        s = mid;
-      } else {
-        e = mid;
-      }
-    }
+  const int32_t s_lo = ends[0], s_hi = ends[1];
+  for (int32_t s = s_lo + 1 + tid; s <= s_hi; s += kBlock) {
+    const int64_t p = (int64_t)c.splits[s] - j_first;     // in (0, kTile) by the searches' ends
+    if (p >= 0 && p < kTile) atomicAdd(&seg_lds[p], 1);
   }
-  return t.s_lo + s;
+  __syncthreads();
+  // inclusive scan over the tile's positions: thread t owns [t * kPerThread, (t + 1) * kPerThread)
+  int32_t x[kPerThread];
+#pragma unroll
+  for (int q = 0; q < kPerThread / 4; ++q) {
+    const int4 v = v4[q];
+    x[4 * q] = v.x;
+    x[4 * q + 1] = v.y;
+    x[4 * q + 2] = v.z;
+    x[4 * q + 3] = v.w;
+  }
+#pragma unroll
+  for (int q = 1; q < kPerThread; ++q) x[q] += x[q - 1];
+  int32_t incl = x[kPerThread - 1];
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int32_t y = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += y;
+  }
+  if (lane == kWave - 1) ends[2 + wave] = incl;
+  __syncthreads();
+  int32_t before = incl - x[kPerThread - 1];
+  for (int w = 0; w < wave; ++w) before += ends[2 + w];
+#pragma unroll
+  for (int q = 0; q < kPerThread / 4; ++q) {
+    v4[q] = make_int4(x[4 * q] + before, x[4 * q + 1] + before, x[4 * q + 2] + before,
+                      x[4 * q + 3] + before);
+  }
+  __syncthreads();
+  return s_lo;
 }
 
 // ---- 0: segment of every id (ragged columns only; the host passes just those) --------------
@@ -469,9 +478,9 @@ __global__ __launch_bounds__(kBlock) void bwd_segof_kernel(const GArgs a) {
   // same operands, done once: bit-identical results.
   if (c.scaled != nullptr) {
     if (c.vec4) {
-      scale_segments<f32x4>(c, s0, n, sp);
+      scale_segments<f32x4>(c, c.grad_out, c.grad_stride, c.combiner, s0, n, sp);
     } else {
-      scale_segments<float>(c, s0, n, sp);
+      scale_segments<float>(c, c.grad_out, c.grad_stride, c.combiner, s0, n, sp);
     }
   }
 }
@@ -513,6 +522,29 @@ __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
   }
   __syncthreads();
   for (int p = tid; p < P; p += kBlock) c.hist[(int64_t)ctile * P + p] = counters[p];
+  // ragged mean / sqrtn column: this tile's share of the SEGMENTS -- their gradient rows times the
+  // combiner's factor, written once for the reduce stage (0b) -- rides with the histogram launch
+  // (round 5): the histogram is instruction-bound, the scaling is a 2 x n_seg x dim x 4-byte stream,
+  // and the launch of its own (38 us for 26 x 65536 segments of dim 16) goes away.
+  if (c.scaled != nullptr) {
+    __shared__ int32_t sp[kBlock + 1];
+    const int64_t n_tiles = (c.n_ids + kTile - 1) / kTile;
+    const int64_t per = (c.n_seg + n_tiles - 1) / n_tiles;
+    const int64_t s_begin = (int64_t)ctile * per;
+    const int64_t s_end = s_begin + per < c.n_seg ? s_begin + per : c.n_seg;
+    for (int64_t s0 = s_begin; s0 < s_end; s0 += kBlock) {
+      const int n = s_end - s0 < kBlock ? (int)(s_end - s0) : kBlock;
+      __syncthreads();   // (sp is reused)
+      if (tid < n) sp[tid] = c.splits[s0 + tid];
+      if (tid == 0) sp[n] = c.splits[s0 + n];
+      __syncthreads();
+      if (c.vec4) {
+        scale_segments<f32x4>(c, c.raw_grad, c.raw_stride, c.raw_combiner, s0, n, sp);
+      } else {
+        scale_segments<float>(c, c.raw_grad, c.raw_stride, c.raw_combiner, s0, n, sp);
+      }
+    }
+  }
 }
 
 // ---- 2: offsets of every (tile, bucket) run ---------------------------------------------------
@@ -653,14 +685,13 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
   const int ctile = blk - c.tile0;
   const int64_t base = (int64_t)ctile * kTile;
   // ragged column without a seg-of array: the tile's row splits in LDS (0a)
-  constexpr int kSpCap = kTile + 256;
-  __shared__ int32_t sp_lds[kSpCap];
-  __shared__ int32_t seg_ends[2];
+  __shared__ int32_t sp_lds[kTile];
+  __shared__ int32_t seg_ends[2 + kWavesPerBlock];
   const bool seg_inline = c.splits != nullptr && c.seg_of == nullptr;   // block-uniform
-  TileSegs ts = {0, 0, 0};
+  int32_t s_lo = 0;
   if (seg_inline) {
     const int64_t j_last = (base + kTile < c.n_ids ? base + kTile : c.n_ids) - 1;
-    ts = tile_segments(c, base, j_last, sp_lds, kSpCap, seg_ends);
+    s_lo = tile_segments(c, base, j_last, sp_lds, seg_ends);
   }
   RunCursor rc;
   int64_t id[kBatch];
@@ -681,7 +712,7 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
         if (c.seg_of != nullptr) {
           seg[k] = c.seg_of[j];
         } else if (seg_inline) {
-          seg[k] = tile_seg_of(c, ts, sp_lds, (int32_t)j);
+          seg[k] = s_lo + sp_lds[(k0 + k) * kBlock + tid];
         }
       }
     }
@@ -743,13 +774,13 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
   const int64_t base = (int64_t)ctile * kTile;
   // ragged column without a seg-of array: the tile's row splits go to LDS (0a) -- into the staging
   // area, which is only filled after the segments have been found
-  __shared__ int32_t seg_ends[2];
+  __shared__ int32_t seg_ends[2 + kWavesPerBlock];
   int32_t* const sp_lds = reinterpret_cast<int32_t*>(st_row);
   const bool seg_inline = c.splits != nullptr && c.seg_of == nullptr;   // block-uniform
-  TileSegs ts = {0, 0, 0};
+  int32_t s_lo = 0;
   if (seg_inline) {
     const int64_t j_last = (base + kTile < c.n_ids ? base + kTile : c.n_ids) - 1;
-    ts = tile_segments(c, base, j_last, sp_lds, 2 * kTile, seg_ends);
+    s_lo = tile_segments(c, base, j_last, sp_lds, seg_ends);
   }
   RunCursor rc;
   int64_t id[kPerThread];
@@ -768,7 +799,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
       if (c.seg_of != nullptr) {
         seg[k] = c.seg_of[j];
       } else if (seg_inline) {
-        seg[k] = tile_seg_of(c, ts, sp_lds, (int32_t)j);
+        seg[k] = s_lo + sp_lds[k * kBlock + tid];
       }
     }
   }
@@ -912,13 +943,13 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
   int32_t* hist = y.hist + c.sync0;
   // ragged column without a seg-of array: the tile's row splits in LDS (0a; the staging area is
   // only filled after the wait)
-  __shared__ int32_t seg_ends[2];
+  __shared__ int32_t seg_ends[2 + kWavesPerBlock];
   int32_t* const sp_lds = reinterpret_cast<int32_t*>(st_row);
   const bool seg_inline = c.splits != nullptr && c.seg_of == nullptr;   // block-uniform
-  TileSegs ts = {0, 0, 0};
+  int32_t s_lo = 0;
   if (seg_inline) {
     const int64_t j_last = (base + kTile < c.n_ids ? base + kTile : c.n_ids) - 1;
-    ts = tile_segments(c, base, j_last, sp_lds, 2 * kTile, seg_ends);
+    s_lo = tile_segments(c, base, j_last, sp_lds, seg_ends);
   }
   RunCursor rc;
   int64_t id[kPerThread];
@@ -937,7 +968,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
       if (c.seg_of != nullptr) {
         seg[k] = c.seg_of[j];
       } else if (seg_inline) {
-        seg[k] = tile_seg_of(c, ts, sp_lds, (int32_t)j);
+        seg[k] = s_lo + sp_lds[k * kBlock + tid];
       }
     }
   }
@@ -3560,8 +3591,22 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       args.merge0[k] = d.merge0;
       args.scan0[k] = d.scan0;
       args.segtile0[k] = 0;
+      // large ragged mean / sqrtn columns without a seg-of array: the histogram launch scales the
+      // segments' rows (it knows the caller's gradient through raw_*)
+      const bool scale_in_hist = scaled != nullptr && d.seg_of == nullptr && !group_onepass &&
+                                 options().bwd_scale_fused != 0 && h.n_segments > 0;
+      if (scale_in_hist) {
+        d.scaled = scaled;
+        d.raw_grad = h.grad_out;
+        d.raw_stride = h.grad_stride > 0 ? h.grad_stride : h.dim;
+        d.raw_combiner = h.combiner;
+        d.grad_out = scaled;
+        d.grad_stride = h.dim;
+        d.combiner = HBK_COMBINER_SUM;
+      }
       // the seg-of launch: columns with a seg-of array, or with rows to scale (mean / sqrtn)
-      if (h.row_splits != nullptr && h.n_segments > 0 && (d.seg_of != nullptr || scaled != nullptr)) {
+      if (!scale_in_hist && h.row_splits != nullptr && h.n_segments > 0 &&
+          (d.seg_of != nullptr || scaled != nullptr)) {
         GCol& sdesc = seg_args.col[ks];
         sdesc = d;
         sdesc.scaled = scaled;

@@ -66,12 +66,21 @@ for st in $STAGES; do
       python tools/prof_summary.py chunks $O/pmc_place1 group_lookup_fwd 4 malloc,slab,vmm_1g,malloc_rev,frag,vmm_2m,malloc,slab,vmm_1g,malloc,slab,vmm_1g,malloc_rev,frag,vmm_2m,malloc,slab,vmm_1g | tee $O/place_counters.txt; trim pmc_place1;;
     bwdbase)    # where the backward family stands on this box before round 5's changes
       (for w in b s R r d w; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk "; done) > $O/bwdbase.log 2>&1; cut -c1-200 $O/bwdbase.log;;
-    bwdab)      # round 5 levers (a) packed pair words, (b) segments found inside the grouping kernels
-      (for cfg in "0 0" "1 0" "0 1" "1 1" "1 1" "0 0"; do set -- $cfg
-         for w in R b s r; do
-           HBK_BWD_PAIRS_PACKED=$1 HBK_BWD_SEG_INLINE=$2 timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/packed=$1 seg_inline=$2  /"
+    bwdab)      # round 5 levers (a) packed pair words, (b) segments found inside the grouping kernels, (c) scaling in the histogram launch
+      (for cfg in "0 0 0" "1 1 0" "1 1 1" "0 0 0" "1 1 1"; do set -- $cfg
+         for w in R r; do
+           HBK_BWD_PAIRS_PACKED=$1 HBK_BWD_SEG_INLINE=$2 HBK_BWD_SCALE_FUSED=$3 timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/packed=$1 seg_inline=$2 scale_fused=$3  /"
          done
        done) > $O/bwdab.log 2>&1; cut -c1-200 $O/bwdab.log;;
+    rsprof)     # kernel times + memory-side counters of the ragged backward (bench_ops R) after round 5's levers
+      export HBK_BENCH_ITERS=6
+      prof prof_ragged "" -- $R/tools/bin/bench_ops R
+      grep -E "bwd_|kernel  " $O/prof_ragged.txt | cut -c1-150 | head -14
+      prof pmc_rs_tcc "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum" -- $R/tools/bin/bench_ops R
+      prof pmc_rs_sq "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" -- $R/tools/bin/bench_ops R
+      unset HBK_BENCH_ITERS
+      for f in pmc_rs_tcc pmc_rs_sq; do echo "== $f"; tail -1 $O/$f.log; pmc_table $O/$f.json bwd_; trim $f; done
+      trim prof_ragged;;
     bwdtest)
       timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -m gpu -x -k "backward or random or graph" --durations=8 > $O/bwdtest.log 2>&1; echo "pytest rc=$?" >> $O/bwdtest.log; tail -25 $O/bwdtest.log;;
     t_*)        # t_<file stem>[:<-k expression>]: one test file, e.g. t_test_gpu_sync or t_test_gpu_parity:rowsort

@@ -186,6 +186,8 @@ def testing_lib():
     t.hbk_testing_local_world_create.argtypes = [vp, i32]
     t.hbk_testing_local_world_destroy.restype = C.c_int
     t.hbk_testing_local_world_destroy.argtypes = [vp]
+    t.hbk_testing_set_wire.restype = C.c_int
+    t.hbk_testing_set_wire.argtypes = [vp, C.c_double, C.c_double, C.c_double, i32]
     t.hbk_testing_comm_create.restype = C.c_int
     t.hbk_testing_comm_create.argtypes = [vp, vp, i32, i32]
     _testing = t

@@ -146,6 +146,17 @@ extern "C" int hbk_comm_create_custom(hbk_comm_t* comm, const hbk_transport_t* t
   c->compute_done = nullptr;
   c->comm_done = nullptr;
   (void)hipGetDevice(&c->device);
+  // Like an RCCL communicator, the handle has a private stream for its Alltoallv exchanges and the
+  // events that fence it against the compute stream (round 5): the pipelined sharded step then runs
+  // its exchanges BESIDE the gathers over a custom transport too -- the in-process test world
+  // exercises the same stream / event structure as production (hbtf/common/stream.cc:83-142).
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->compute_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->comm_done, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    delete c;
+    return fail(HBK_INTERNAL, "comm_create_custom: could not create the comm stream / events");
+  }
   *comm = c;
   return HBK_OK;
 }
@@ -230,7 +241,11 @@ extern "C" int hbk_comm_destroy(hbk_comm_t comm) {
   using namespace hbk;
   if (comm == nullptr) return HBK_OK;
   if (comm->custom) {
+    if (comm->stream != nullptr) (void)hipStreamSynchronize(comm->stream);
     if (comm->transport.destroy != nullptr) comm->transport.destroy(comm->transport.ctx);
+    if (comm->compute_done != nullptr) (void)hipEventDestroy(comm->compute_done);
+    if (comm->comm_done != nullptr) (void)hipEventDestroy(comm->comm_done);
+    if (comm->stream != nullptr) (void)hipStreamDestroy(comm->stream);
     delete comm;
     return HBK_OK;
   }
@@ -448,9 +463,16 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
   }
 
   if (comm->custom) {
-    hipStream_t cs = as_stream(compute_stream);
+    // on the handle's private stream, fenced like the RCCL path below (inline: on the caller's)
+    hipStream_t cs = inline_x ? as_stream(compute_stream) : comm->stream;
     int lrc;
-    if (before != nullptr && !inline_x) HBK_HIP_OK(hipStreamWaitEvent(cs, before, 0));
+    if (inline_x) {
+      // (nothing to order)
+    } else if (before != nullptr) {
+      HBK_HIP_OK(hipStreamWaitEvent(cs, before, 0));
+    } else if ((lrc = fence_in(comm, as_stream(compute_stream))) != HBK_OK) {
+      return lrc;
+    }
     if (half_wire) {
       std::vector<int64_t> lens(n);
       std::vector<void*> dst(n);
@@ -491,8 +513,12 @@ int alltoallv_events(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t wire_dty
         return lrc;
       }
     }
-    if (after != nullptr && !inline_x) HBK_HIP_OK(hipEventRecord(after, cs));
-    return HBK_OK;
+    if (inline_x) return HBK_OK;
+    if (after != nullptr) {
+      HBK_HIP_OK(hipEventRecord(after, cs));
+      return HBK_OK;
+    }
+    return fence_out(comm, as_stream(compute_stream));
   }
   for (int32_t c = 0; c < n; ++c) {     // checked before any RCCL group is opened
     for (int32_t i = 0; i < active; ++i) {

@@ -27,6 +27,13 @@ struct LocalWorld {
   std::vector<std::vector<int64_t>> off; // [world][n] element offset of the chunk for peer k
   std::vector<std::vector<int64_t>> len; // [world][n] elements for peer k
   std::vector<hipEvent_t> ready, done;   // [world]
+  // artificial wire (hbk_testing_set_wire): every exchange is followed, on its stream, by a kernel
+  // that waits  latency + (largest message this rank receives from a PEER) x scale / rate  -- one
+  // link per peer pair, all links in parallel, as over xGMI.  With `count_self` the rank's own
+  // chunk counts as a peer message (a world of ONE rank then models what the same step would put
+  // on a link).  0 = off.
+  double wire_bytes_per_us = 0.0, wire_latency_us = 0.0, wire_scale = 1.0;
+  bool wire_count_self = false;
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
     const long gen = generation;
@@ -44,6 +51,12 @@ struct RankCtx {
   LocalWorld* w;
   int rank;
 };
+
+// one wave that watches the constant 100 MHz clock: occupies a wave slot, no bandwidth
+__global__ void wire_delay_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 
 #define LW_HIP(expr)                      \
   do {                                    \
@@ -71,16 +84,24 @@ int lw_exchange(void* ctx_, int32_t rank, const int32_t* ranks, int32_t n_ranks,
   w->len[me].assign(send_len, send_len + n_ranks);
   LW_HIP(hipEventRecord(w->ready[me], stream));
   w->barrier();
+  int64_t largest = 0;   // elements of the largest message this rank receives over a "link"
   for (int k = 0; k < n_ranks; ++k) {
     const int peer = ranks[k];
     LW_HIP(hipStreamWaitEvent(stream, w->ready[peer], 0));
     const int64_t n = w->len[peer][k_me];
+    if ((peer != me || w->wire_count_self) && n > largest) largest = n;
     if (n > 0 && !(skip_self && peer == me)) {
       LW_HIP(hipMemcpyAsync(reinterpret_cast<char*>(recvbuf) + (size_t)recv_off[k] * esize,
                             reinterpret_cast<const char*>(w->ptr[peer]) +
                                 (size_t)w->off[peer][k_me] * esize,
                             (size_t)n * esize, hipMemcpyDeviceToDevice, stream));
     }
+  }
+  if (w->wire_bytes_per_us > 0.0 && largest > 0) {
+    const double us = w->wire_latency_us +
+                      (double)largest * (double)esize * w->wire_scale / w->wire_bytes_per_us;
+    hipLaunchKernelGGL(wire_delay_kernel, dim3(1), dim3(64), 0, stream,
+                       (unsigned long long)(us * 100.0));
   }
   LW_HIP(hipEventRecord(w->done[me], stream));
   w->barrier();
@@ -189,6 +210,20 @@ extern "C" int hbk_testing_local_world_create(void** world, int32_t world_size) 
     LW_HIP(hipEventCreateWithFlags(&w->done[i], hipEventDisableTiming));
   }
   *world = w;
+  return 0;
+}
+
+// Artificial wire for every exchange of the world: `gb_per_s` per link and direction (0 = off),
+// `latency_us` per exchange, message sizes multiplied by `scale` (a scaled-down batch stands for the
+// full one), `count_self` != 0: the rank's own chunk counts as a peer message.
+extern "C" int hbk_testing_set_wire(void* world, double gb_per_s, double latency_us, double scale,
+                                    int32_t count_self) {
+  LocalWorld* w = reinterpret_cast<LocalWorld*>(world);
+  if (w == nullptr || gb_per_s < 0.0 || scale <= 0.0) return 3;
+  w->wire_bytes_per_us = gb_per_s * 1e3;   // GB/s = 1e3 bytes per us
+  w->wire_latency_us = latency_us;
+  w->wire_scale = scale;
+  w->wire_count_self = count_self != 0;
   return 0;
 }
 

@@ -81,6 +81,8 @@ for st in $STAGES; do
       unset HBK_BENCH_ITERS
       for f in pmc_rs_tcc pmc_rs_sq; do echo "== $f"; tail -1 $O/$f.log; pmc_table $O/$f.json bwd_; trim $f; done
       trim prof_ragged;;
+    overlap)    # the step's forms under an artificial wire (one rank, full per-rank work)
+      timeout 600 python tools/overlap_model.py > $O/overlap_model.txt 2> $O/overlap_model.err; echo "rc=$?"; cat $O/overlap_model.txt; tail -5 $O/overlap_model.err;;
     bwdtest)
       timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -m gpu -x -k "backward or random or graph" --durations=8 > $O/bwdtest.log 2>&1; echo "pytest rc=$?" >> $O/bwdtest.log; tail -25 $O/bwdtest.log;;
     t_*)        # t_<file stem>[:<-k expression>]: one test file, e.g. t_test_gpu_sync or t_test_gpu_parity:rowsort

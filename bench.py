@@ -435,9 +435,9 @@ def main():
   best_form = None
   if (world > 1 or args.sharded) and args.tune_steps > 0:
     from hybridbackend_amd import _lib as _hbk
-    # candidates: the shipped default (two column groups, exchanges on the communicator's stream
-    # beside the gathers), one group on the communicator's stream, and the exchanges enqueued
-    # inline on the compute stream (no event hops at all, nothing overlapped)
+    # candidates: two column groups with the exchanges on the communicator's stream beside the
+    # gathers (the default until round 4), one group on the communicator's stream, and the
+    # exchanges enqueued inline on the compute stream (no event hops at all; the shipped default)
     forms = {'pipelined_2_groups': (2, 0), 'one_group': (1, 0), 'inline': (0, 1)}
     groups_probe = {}
     for name, (g, inline) in forms.items():
@@ -559,14 +559,15 @@ def main():
                  'prefetch_next_partition': (world > 1 or args.sharded) and not args.no_prefetch,
                  'id_batches_resident': n_batches,
                  # the form the timed steps ran in, picked on this machine by the probe below;
-                 # 'pipelined_2_groups' is the library's shipped default: its probe time is the
-                 # figure comparable with runs that do not tune (--tune-steps 0)
+                 # 'inline' is the library's shipped default since round 5
+                 # (profiles/r05_overlap_model.txt): its probe time is the figure comparable with
+                 # runs that do not tune (--tune-steps 0)
                  'rccl_ranks_seen': (rccl_ranks_seen if (world > 1 or args.sharded) else None),
                  'sharded_form': best_form,
                  'sharded_form_probe_ms_per_step': groups_probe,
                  'value_at_shipped_default_M_lookups_per_s': (
                      round(lookups_per_step_per_rank * world /
-                           groups_probe['pipelined_2_groups'] / 1e3, 3)
+                           groups_probe['inline'] / 1e3, 3)
                      if groups_probe else None),
                  **{key: None for key in SECONDARY_KEYS}},
       'roofline': {

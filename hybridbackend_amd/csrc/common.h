@@ -165,7 +165,9 @@ struct Options {
   int sharded_trace = 0;         // HBK_SHARDED_TRACE: host-side phase times on stderr
   int sharded_pack_early = 1;    // HBK_SHARDED_PACK_EARLY: ids packed peer-major behind the partition, offsets from the device's sizes (0: after the host has them)
   int sharded_wire_fused = 1;    // HBK_SHARDED_WIRE_FUSED: fp16 wire: gather writes / stitch reads fp16 rows (0: two cast passes)
-  int sharded_inline = 0;        // HBK_SHARDED_INLINE: exchanges enqueued on the compute stream (no event hops, no overlap)
+  int sharded_inline = 1;        // HBK_SHARDED_INLINE: exchanges enqueued on the compute stream (no event hops); the default since round 5: under a
+                                 // modelled wire the column-group pipeline (0) lost to it in every case -- a cross-stream hop costs ~11 us, three per group, more than a group hides
+                                 // (profiles/r05_overlap_model.txt)
   int sync_wait_ms = 2000;       // HBK_SYNC_WAIT_MS: bound of a wait between the tiles of a one-launch kernel
   int sync_onepass_off = 0;      // HBK_SYNC_ONEPASS_OFF: 1 = multi-launch forms only (set by a wait that ran out)
   int sync_test_withhold = -1;   // HBK_SYNC_TEST_WITHHOLD: test hook, the tile that never publishes its counts

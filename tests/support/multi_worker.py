@@ -266,10 +266,12 @@ def run(a, result):
 
   @case('sharded')
   def _sharded():
-    sharded_step('pipelined, fp32 wire', 300)
-    sharded_step('one group', 301, options=(('sharded_groups', 1),))
-    sharded_step('three groups', 302, options=(('sharded_groups', 3),))
-    sharded_step('inline exchanges', 303, options=(('sharded_inline', 1),))
+    sharded_step('shipped default (inline exchanges), fp32 wire', 300)
+    sharded_step('pipelined, two groups', 309, options=(('sharded_inline', 0), ('sharded_groups', 2)))
+    sharded_step('one group on the communicator stream', 301,
+                 options=(('sharded_inline', 0), ('sharded_groups', 1)))
+    sharded_step('three groups', 302, options=(('sharded_inline', 0), ('sharded_groups', 3)))
+    sharded_step('inline exchanges, two groups', 303, options=(('sharded_inline', 1), ('sharded_groups', 2)))
     sharded_step('fp16 wire fused', 304, wire16=True)
     sharded_step('fp16 wire through casts', 305, wire16=True, options=(('sharded_wire_fused', 0),))
     sharded_step('int64 ids on the wire', 306, options=(('sharded_id64', 1),))
@@ -279,8 +281,8 @@ def run(a, result):
   @case('dedup')
   def _dedup():
     sharded_step('requester-side dedup, Zipf ids', 400, dedup=True, zipf=True)
-    sharded_step('requester-side dedup, inline, fp16', 401, dedup=True, zipf=True, wire16=True,
-                 options=(('sharded_inline', 1),))
+    sharded_step('requester-side dedup, pipelined, fp16', 401, dedup=True, zipf=True, wire16=True,
+                 options=(('sharded_inline', 0), ('sharded_groups', 2)))
     sharded_step('dedup on uniform ids', 402, dedup=True)
 
   # ---- (f1) gradient aggregation: Allreduce / Allgatherv -------------------------------------

@@ -352,6 +352,9 @@ def test_cxx_driver_requester_dedup_in_process_world(hbk_option, world, kind, gr
   import threading
   hbk_option('sharded_groups', groups)
   hbk_option('sharded_pack_early', pack_early)
+  # (column groups pipelined beside the exchanges on the communicator's stream when groups are
+  # asked for; the shipped default since round 5 is inline)
+  hbk_option('sharded_inline', 0 if groups else 1)
   rng = np.random.RandomState(500 + world)
   dims = [16, 8, 128, 4, 32]
   rows = [50021, 211, 3000, 64, 100003]

@@ -267,6 +267,7 @@ def test_one_launch_kernels_beside_rccl_kernels(hbk_option):
   hbk_option('sync_wait_ms', 500)
   hbk_option('sharded_copy_self', 1)
   hbk_option('sharded_groups', 2)
+  hbk_option('sharded_inline', 0)          # the exchanges on the communicator's own stream
   errors, checks = [], []
   rng0 = np.random.RandomState(55)
   tables = [rng0.uniform(-1, 1, size=(50021, 16)).astype(np.float32) for _ in range(6)]

@@ -41,7 +41,7 @@ class LookupColumn(C.Structure):
               ('combiner', C.c_int32), ('out', C.c_void_p),
               ('run_start', C.c_void_p), ('run_base', C.c_void_p),
               ('n_runs', C.c_int32), ('out_stride', C.c_int32),
-              ('hot_rows', C.c_int32), ('half_io', C.c_int32)]
+              ('hot_rows', C.c_int32), ('half_io', C.c_int32), ('out_slots', C.c_void_p)]
 
 
 class LookupGradColumn(C.Structure):
@@ -89,6 +89,8 @@ def _declare(l):
     'hbk_set_option': (C.c_int, [C.c_char_p, i32]),
     'hbk_get_option': (C.c_int, [C.c_char_p, vp]),
     'hbk_comm_rccl_ranks': (C.c_int, [vp]),
+    'hbk_sharded_p2p_bind': (C.c_int, [vp, vp, vp, vp]),
+    'hbk_sharded_p2p_unbind': (C.c_int, [vp]),
     'hbk_sync_check': (C.c_int, []),
     'hbk_sync_check_stream': (C.c_int, [C.c_void_p]),
     'hbk_host_floormod_i64': (i64, [i64, i64]),

@@ -168,6 +168,7 @@ struct Options {
   int sharded_inline = 1;        // HBK_SHARDED_INLINE: exchanges enqueued on the compute stream (no event hops); the default since round 5: under a
                                  // modelled wire the column-group pipeline (0) lost to it in every case -- a cross-stream hop costs ~11 us, three per group, more than a group hides
                                  // (profiles/r05_overlap_model.txt)
+  int sharded_p2p = 1;           // HBK_SHARDED_P2P: plans whose outputs were registered (hbk_sharded_p2p_bind) run the p2p form of the step (0: never)
   int sync_wait_ms = 2000;       // HBK_SYNC_WAIT_MS: bound of a wait between the tiles of a one-launch kernel
   int sync_onepass_off = 0;      // HBK_SYNC_ONEPASS_OFF: 1 = multi-launch forms only (set by a wait that ran out)
   int sync_test_withhold = -1;   // HBK_SYNC_TEST_WITHHOLD: test hook, the tile that never publishes its counts

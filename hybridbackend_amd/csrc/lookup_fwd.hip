@@ -49,6 +49,8 @@ struct ColArg {
   int32_t out_stride;  // floats between output rows (>= dim)
   const int64_t* run_start;
   const int64_t* run_base;
+  const int32_t* out_slots;   // != NULL: segment s is written to row out_slots[s] of `out` (a permutation
+                              // scatter: the owner gather of the sharded step's p2p form)
 };
 
 // float offset of logical row r inside the table
@@ -110,7 +112,7 @@ static_assert(sizeof(LookupArgs) <= 24576, "kernarg budget");
 
 // ---------------------------------------------------------------------------------
 // one id per segment (Criteo scalar columns): out[s,:] = table[row(ids[s]),:]
-template <typename V, int U, bool RUNS, int HALF>
+template <typename V, int U, bool RUNS, int HALF, bool SLOT = false>
 __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
   constexpr int VE = sizeof(V) / 4;
   const int lane = lane_id();
@@ -122,13 +124,18 @@ __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
 
   // ids: slot q (0 <= q < U*rpi) lives in register q>>6 of lane q&63
   uint64_t rowreg[U];
+  int32_t slotreg[U];   // SLOT: where the segment's row goes (read with the id, handed over like it)
   const int n_slots = U * rpi;
 #pragma unroll
   for (int k = 0; k < U; ++k) {
     rowreg[k] = kNoRow;
+    slotreg[k] = 0;
     const int q = k * kWave + lane;
     const int64_t s = wave_row0 + q;
-    if (q < n_slots && s < n_seg) rowreg[k] = id_to_row(c.map, load_id(c.ids, c.ids64, s));
+    if (q < n_slots && s < n_seg) {
+      rowreg[k] = id_to_row(c.map, load_id(c.ids, c.ids64, s));
+      if (SLOT) slotreg[k] = __builtin_nontemporal_load(c.out_slots + s);
+    }
   }
 
   V v[U];
@@ -149,8 +156,17 @@ __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int64_t s = wave_row0 + u * rpi + grp;
+    int64_t dst = s;
+    if (SLOT) {
+      const int q0 = u * rpi;
+      const int k = q0 >> 6;
+      int32_t src = slotreg[0];
+#pragma unroll
+      for (int kk = 1; kk < U; ++kk) src = (k == kk) ? slotreg[kk] : src;
+      dst = (int64_t)__shfl(src, (q0 & (kWave - 1)) + grp, kWave);
+    }
     if (live && s < n_seg) {
-      store_out_chunk<V, HALF>(c.out, s * (int64_t)c.out_stride + (int64_t)sub * VE, v[u]);
+      store_out_chunk<V, HALF>(c.out, dst * (int64_t)c.out_stride + (int64_t)sub * VE, v[u]);
     }
   }
 }
@@ -224,7 +240,7 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
 // One instantiation per (ragged?, 16-byte chunks?, segmented table?) so that the common case --
 // one id per sample, dim % 4 == 0, plain table -- carries none of the other paths' code; the host
 // launches each kind present in the call with the columns of that kind.
-template <bool CSR, typename V, bool RUNS, int HALF = 0>
+template <bool CSR, typename V, bool RUNS, int HALF = 0, bool SLOT = false>
 __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupArgs a) {
   const int b = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, a.xcd);
   // last column whose first tile is <= b.  A binary search over the kernel-argument table is
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupAr
   if (!CSR) {
     const int64_t row0 = (tile * kWavesPerBlock + wave) * (int64_t)(kU * rpi);
     if (row0 >= c.n_seg) return;
-    gather_rows<V, kU, RUNS, HALF>(c, row0);
+    gather_rows<V, kU, RUNS, HALF, SLOT>(c, row0);
   } else {
     const int64_t seg0 = (tile * kWavesPerBlock + wave) * (int64_t)(kSegIters * rpi);
     if (seg0 >= c.n_seg) return;
@@ -417,9 +433,9 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_hot_kernel(const Look
   }
 }
 
-template <bool CSR, typename V, bool RUNS, int HALF = 0>
+template <bool CSR, typename V, bool RUNS, int HALF = 0, bool SLOT = false>
 void launch_kind(const LookupArgs& args, unsigned tiles, hipStream_t stream) {
-  hipLaunchKernelGGL((group_lookup_fwd_kernel<CSR, V, RUNS, HALF>), dim3(tiles), dim3(kBlock), 0,
+  hipLaunchKernelGGL((group_lookup_fwd_kernel<CSR, V, RUNS, HALF, SLOT>), dim3(tiles), dim3(kBlock), 0,
                      stream, args);
 }
 
@@ -428,7 +444,9 @@ void launch_by_kind(int kind, const LookupArgs& args, unsigned tiles, hipStream_
     hipLaunchKernelGGL(group_lookup_fwd_hot_kernel, dim3(tiles), dim3(kBlock), 0, stream, args);
     return;
   }
-  switch (kind) {  // bit 0 ragged, bit 1 scalar chunks, bit 2 segmented table, bit 4 fp16 rows
+  switch (kind) {  // bit 0 ragged, bit 1 scalar chunks, bit 2 segmented table, bit 4 fp16 rows, bit 5 output slots
+    case 32: launch_kind<false, f32x4, false, 0, true>(args, tiles, stream); return;   // out[out_slots[s]]
+    case 34: launch_kind<false, float, false, 0, true>(args, tiles, stream); return;
     case 16: launch_kind<false, f32x4, false, 1>(args, tiles, stream); return;   // half output
     case 18: launch_kind<false, float, false, 1>(args, tiles, stream); return;
     case 20: launch_kind<false, f32x4, true, 2>(args, tiles, stream); return;    // half table
@@ -486,6 +504,10 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
                     (h.half_io == HBK_LOOKUP_TABLE_HALF && h.n_runs > 0),
                 "group_lookup_fwd: column %d: half_io %d: fp16 output rows need one id per segment "
                 "and a plain table, fp16 table rows a segmented table", c, h.half_io);
+    HBK_REQUIRE(h.out_slots == nullptr ||
+                    (h.row_splits == nullptr && h.n_runs == 0 && h.half_io == 0),
+                "group_lookup_fwd: column %d: out_slots needs one id per segment, a plain table and "
+                "fp32 rows", c);
   }
 
   const int hot_mode = options().fwd_hot_rows;
@@ -497,7 +519,7 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
     int kind;   // -1: nothing to do (no segments)
   };
   std::vector<Classified> cls((size_t)(n_cols > 0 ? n_cols : 1));
-  uint32_t kinds_present = 0;
+  uint64_t kinds_present = 0;
   for (int32_t c = 0; c < n_cols; ++c) {
     const hbk_lookup_column_t& h = cols[c];
     cls[c].kind = -1;
@@ -518,15 +540,16 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
                    (h.n_runs > 0 ? 4 : 0);
     // one id per segment, plain table, wide 16-byte-chunk rows: the hot-row kernel when asked
     if (h.half_io != 0) col_kind |= 16;
+    if (h.out_slots != nullptr) col_kind |= 32;
     if (col_kind == 0 && (hot_mode > 0 || h.hot_rows != 0) && h.dim >= 64 && shape.lpr_log2 <= 6 &&
         h.dim <= kHotStageFloats && h.rows < 0xffffffffll) {
       col_kind = 8;
     }
     cls[c].kind = col_kind;
-    kinds_present |= 1u << col_kind;
+    kinds_present |= 1ull << col_kind;
   }
-  for (int kind = 0; kind < 24; ++kind) {
-    if (((kinds_present >> kind) & 1u) == 0u) continue;
+  for (int kind = 0; kind < 40; ++kind) {
+    if (((kinds_present >> kind) & 1ull) == 0ull) continue;
     int32_t c0 = 0;
     while (c0 < n_cols) {
       LookupArgs args;
@@ -562,6 +585,7 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
         d.out_stride = h.out_stride > 0 ? h.out_stride : h.dim;
         d.run_start = h.run_start;
         d.run_base = h.run_base;
+        d.out_slots = h.out_slots;
         const int64_t rpi = kWave >> d.lpr_log2;
         const int64_t per_block =
             col_kind == 8 ? kHotTile : kWavesPerBlock * rpi * (h.row_splits ? kSegIters : kU);

@@ -55,6 +55,7 @@ const OptionEntry kOptions[] = {
     {"sharded_copy_self", "HBK_SHARDED_COPY_SELF", &Options::sharded_copy_self},
     {"sharded_trace", "HBK_SHARDED_TRACE", &Options::sharded_trace},
     {"sharded_inline", "HBK_SHARDED_INLINE", &Options::sharded_inline},
+    {"sharded_p2p", "HBK_SHARDED_P2P", &Options::sharded_p2p},
     {"sharded_wire_fused", "HBK_SHARDED_WIRE_FUSED", &Options::sharded_wire_fused},
     {"sharded_pack_early", "HBK_SHARDED_PACK_EARLY", &Options::sharded_pack_early},
     {"sync_wait_ms", "HBK_SYNC_WAIT_MS", &Options::sync_wait_ms},

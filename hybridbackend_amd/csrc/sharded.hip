@@ -22,8 +22,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <chrono>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -44,6 +46,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kMaxSegs = 480;
+constexpr int kMaxPackWorldP2p = 256;   // ranks the p2p slot kernel holds offsets for
 constexpr int kCopyTileBytes = kBlock * 16 * 8;  // 32 KB per block
 
 struct Seg {
@@ -134,6 +137,62 @@ int seg_copy(const std::vector<Seg>& segs_in, hipStream_t stream) {
 __global__ void transpose_sizes_kernel(const int32_t* in, int32_t* out, int n, int w) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n * w) out[(i % w) * n + i / w] = in[i];
+}
+
+// p2p form: the OUTPUT SLOT of every id that goes on the wire.  shard_index[j] = k is the position
+// of the batch's j-th id among the column's shard-ordered ids; the run of owner q starts at
+// shard_off[c][q] there and at dst_off[c][q] in the peer-major slot buffer (same layout as the ids):
+//   slots[dst_off[c][q] + k - shard_off[c][q]] = j
+// -- the owner stores the row of that id at row j of the requester's output.
+constexpr int kSlotCols = 128;
+constexpr int kSlotTile = 2048;
+struct SlotArgs {
+  int32_t n_cols, W, col0, pad_;
+  const int64_t* shard_off;   // device [N][W]
+  const int64_t* dst_off;     // device [N][W]
+  int32_t* slots;
+  int32_t tile0[kSlotCols + 1];
+  int32_t n[kSlotCols];
+  const int32_t* idx[kSlotCols];
+};
+static_assert(sizeof(SlotArgs) <= 16384, "kernarg budget");
+
+__global__ __launch_bounds__(kBlock) void p2p_slots_kernel(const SlotArgs a) {
+  __shared__ int64_t so[kMaxPackWorldP2p], dof[kMaxPackWorldP2p];
+  int c = 0, hi = a.n_cols;
+  while (hi - c > 1) {
+    const int mid = (c + hi) >> 1;
+    if (a.tile0[mid] <= (int)blockIdx.x) {
+      c = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  const int W = a.W;
+  for (int q = (int)threadIdx.x; q < W; q += kBlock) {
+    so[q] = a.shard_off[(size_t)(a.col0 + c) * W + q];
+    dof[q] = a.dst_off[(size_t)(a.col0 + c) * W + q];
+  }
+  __syncthreads();
+  const int32_t* idx = a.idx[c];
+  const int32_t n = a.n[c];
+  const int32_t j0 = ((int)blockIdx.x - a.tile0[c]) * kSlotTile;
+#pragma unroll
+  for (int t = 0; t < kSlotTile / kBlock; ++t) {
+    const int32_t j = j0 + t * kBlock + (int)threadIdx.x;
+    if (j >= n) continue;
+    const int64_t k = idx[j];
+    int q = 0, e = W;   // last q with so[q] <= k
+    while (e - q > 1) {
+      const int mid = (q + e) >> 1;
+      if (so[mid] <= k) {
+        q = mid;
+      } else {
+        e = mid;
+      }
+    }
+    a.slots[dof[q] + k - so[q]] = j;
+  }
 }
 
 // The ids of a step go peer-major into the outgoing buffer BEFORE the host knows the sizes: the
@@ -498,7 +557,22 @@ struct hbk_sharded {
   hipEvent_t step_begin;               // caller's stream at the entry of the last forward: all
                                        // readers of the OTHER set (previous step) are before it
   bool prefetch_used;                  // a prefetch was issued at some point
-  int64_t* host_runs;   // pinned [5][N*W], column-major: run starts / bases of the stitch, then
+  // ---- p2p form of the forward (round 5; hbk_sharded_p2p_bind) ----------------------------------
+  // Every rank registered its N output tensors once; peer_out[q * N + c] is where requester q's
+  // column c lives as THIS process addresses it (the same process: its pointer; another process:
+  // a hipIpcOpenMemHandle mapping).  A step then sends (id, output slot) pairs and the owner gather
+  // stores every row straight into its place in the requester's output: no reply buffer, no rows
+  // exchange, no stitch -- one random-row pass instead of two, and the rows cross the link as the
+  // gather's own stores.
+  bool p2p_opt = false;     // option sharded_p2p, read at creation
+  bool p2p_bound = false;
+  std::vector<float*> p2p_outs;         // [N] this rank's registered outputs
+  std::vector<int32_t> p2p_strides;     // [N] their row strides (floats)
+  std::vector<float*> peer_out;         // [W][N]
+  std::vector<int32_t> peer_stride;     // [W][N]
+  std::vector<void*> ipc_opened;        // mappings to close
+  hbk::Buffer slot_send, slot_recv, token_buf, bind_buf;
+  int64_t* host_runs;   // pinned [7][N*W], column-major: run starts / bases of the stitch, then
                         // run starts / id offsets / gradient offsets of the owner-side backward
 };
 
@@ -532,6 +606,7 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
   p->trace = options().sharded_trace != 0;
   p->n_groups = options().sharded_groups;
   p->inline_x = options().sharded_inline != 0;
+  p->p2p_opt = options().sharded_p2p != 0;
   for (int32_t c = 0; c < n_cols; ++c) {
     if (cols[c].bucket <= 0 || cols[c].bucket > 0x7fffffffll) p->id32 = false;
   }
@@ -568,7 +643,7 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
   }
   if (!ok ||
       hipHostMalloc(reinterpret_cast<void**>(&p->host_runs),
-                    sizeof(int64_t) * 5 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
+                    sizeof(int64_t) * 7 * (size_t)n_cols * p->W, hipHostMallocDefault) !=
           hipSuccess) {
     hbk_sharded_destroy(p);
     return fail(HBK_INTERNAL, "sharded_create: could not create streams / events / pinned memory");
@@ -581,9 +656,12 @@ extern "C" int hbk_sharded_destroy(hbk_sharded_t p) {
   if (p == nullptr) return HBK_OK;
   if (p->pre_stream) (void)hipStreamSynchronize(p->pre_stream);
   for (hbk::Buffer* b : {&p->part_ws, &p->ids_buf, &p->rows_buf, &p->wire_ws, &p->bwd_ws,
-                         &p->runs_dev, &p->dedup_tmp}) {
+                         &p->runs_dev, &p->dedup_tmp, &p->slot_send, &p->slot_recv, &p->token_buf,
+                         &p->bind_buf}) {
     b->release();
   }
+  for (void* m : p->ipc_opened) (void)hipIpcCloseMemHandle(m);
+  p->ipc_opened.clear();
   for (auto& set : p->ps) {
     set.part_out.release();
     set.shard_index.release();
@@ -653,6 +731,7 @@ int pipeline_groups(int n_cols, int world, int requested) {
 
 // (inline exchanges: nothing runs beside them, one group is all there is to schedule)
 int step_groups(const hbk_sharded* p) {
+  if (p->p2p_bound) return 1;   // (the p2p form gathers all columns in one launch)
   return p->inline_x && !(p->n_groups >= 1 && p->n_groups <= 4)
              ? 1 : pipeline_groups(p->N, p->W, p->n_groups);
 }
@@ -800,6 +879,146 @@ int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* cons
 }  // namespace
 }  // namespace hbk
 
+namespace hbk {
+namespace {
+struct P2pRec {
+  uint64_t pid;
+  uint64_t ptr;       // the output tensor in its owner's address space
+  uint64_t offset;    // ... and inside the allocation the handle names
+  int32_t stride;
+  int32_t has_handle;
+  hipIpcMemHandle_t handle;
+};
+}  // namespace
+}  // namespace hbk
+
+// Registers this rank's N output tensors for the p2p form of the forward (collective: every rank
+// of the communicator calls it, with its own tensors).  One id per segment, no requester-side
+// dedup, fp32 wire; every later forward of the plan must be handed exactly these tensors.
+// HBK_UNIMPLEMENTED (on every rank) when some peer's memory cannot be mapped here -- the plan
+// then keeps the exchange form.
+extern "C" int hbk_sharded_p2p_bind(hbk_sharded_t p, float* const* outs, const int32_t* out_strides,
+                                    hbk_stream_t stream_) {
+  using namespace hbk;
+  HBK_REQUIRE(p != nullptr && outs != nullptr, "sharded_p2p_bind: NULL argument");
+  hipStream_t stream = as_stream(stream_);
+  const int N = p->N, W = p->W, me = p->rank;
+  p->p2p_bound = false;
+  p->ps[0].pending = p->ps[1].pending = false;   // (a prefetch packed for another group count)
+  if (!p->p2p_opt) return fail(HBK_UNIMPLEMENTED, "sharded_p2p_bind: option sharded_p2p is off");
+  HBK_REQUIRE(p->wire_dtype == HBK_FLOAT, "sharded_p2p_bind: the p2p form has no fp16 wire");
+  HBK_REQUIRE(!p->any_dedup, "sharded_p2p_bind: not with requester-side dedup");
+  HBK_REQUIRE(W <= kMaxPackWorldP2p, "sharded_p2p_bind: more than %d ranks", kMaxPackWorldP2p);
+  for (void* m : p->ipc_opened) (void)hipIpcCloseMemHandle(m);
+  p->ipc_opened.clear();
+  std::vector<P2pRec> mine((size_t)N), all((size_t)N * W);
+  const uint64_t pid = (uint64_t)getpid();
+  for (int c = 0; c < N; ++c) {
+    HBK_REQUIRE(outs[c] != nullptr, "sharded_p2p_bind: outs[%d] is NULL", c);
+    P2pRec& r = mine[c];
+    memset(&r, 0, sizeof(r));
+    r.pid = pid;
+    r.ptr = (uint64_t)(uintptr_t)outs[c];
+    r.stride = out_strides != nullptr && out_strides[c] > 0 ? out_strides[c] : p->cols[c].dim;
+    if (W > 1) {
+      hipDeviceptr_t base = nullptr;
+      size_t size = 0;
+      if (hipMemGetAddressRange(&base, &size, outs[c]) == hipSuccess && base != nullptr) {
+        r.offset = (uint64_t)((uintptr_t)outs[c] - (uintptr_t)base);
+        r.has_handle = hipIpcGetMemHandle(&r.handle, base) == hipSuccess ? 1 : 0;
+      }
+      (void)hipGetLastError();
+    }
+  }
+  int rc;
+  const size_t rec_bytes = sizeof(P2pRec) * (size_t)N;
+  if ((rc = p->bind_buf.ensure(rec_bytes * (size_t)(W + 1) + 64)) != HBK_OK) return rc;
+  char* d_mine = reinterpret_cast<char*>(p->bind_buf.ptr);
+  char* d_all = d_mine + rec_bytes;
+  HBK_HIP_OK(hipMemcpyAsync(d_mine, mine.data(), rec_bytes, hipMemcpyHostToDevice, stream));
+  std::vector<int64_t> counts((size_t)W, (int64_t)rec_bytes);
+  if ((rc = hbk_allgatherv(p->comm, HBK_UINT8, d_mine, counts.data(), d_all, stream_)) != HBK_OK) {
+    return rc;
+  }
+  HBK_HIP_OK(hipMemcpyAsync(all.data(), d_all, rec_bytes * (size_t)W, hipMemcpyDeviceToHost, stream));
+  HBK_HIP_OK(hipStreamSynchronize(stream));
+  p->peer_out.assign((size_t)W * N, nullptr);
+  p->peer_stride.assign((size_t)W * N, 0);
+  int32_t ok = 1;
+  std::vector<std::pair<hipIpcMemHandle_t, void*>> opened;
+  for (int q = 0; q < W && ok; ++q) {
+    for (int c = 0; c < N && ok; ++c) {
+      const P2pRec& r = all[(size_t)q * N + c];
+      p->peer_stride[(size_t)q * N + c] = r.stride;
+      if (q == me || r.pid == pid) {   // the same address space (in-process ranks, this rank itself)
+        p->peer_out[(size_t)q * N + c] = reinterpret_cast<float*>((uintptr_t)r.ptr);
+        continue;
+      }
+      if (!r.has_handle) {
+        ok = 0;
+        break;
+      }
+      void* base = nullptr;
+      for (auto& o : opened) {
+        if (memcmp(&o.first, &r.handle, sizeof(hipIpcMemHandle_t)) == 0) base = o.second;
+      }
+      if (base == nullptr) {
+        if (hipIpcOpenMemHandle(&base, r.handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+          (void)hipGetLastError();
+          ok = 0;
+          break;
+        }
+        opened.emplace_back(r.handle, base);
+        p->ipc_opened.push_back(base);
+      }
+      p->peer_out[(size_t)q * N + c] =
+          reinterpret_cast<float*>(reinterpret_cast<char*>(base) + r.offset);
+    }
+  }
+  // every rank must come to the same answer: the minimum over the ranks of "all mapped"
+  if (W > 1) {
+    int32_t* d_ok = reinterpret_cast<int32_t*>(d_mine);
+    HBK_HIP_OK(hipMemcpyAsync(d_ok, &ok, sizeof(ok), hipMemcpyHostToDevice, stream));
+    const void* in[1] = {d_ok};
+    void* out[1] = {d_ok + 4};
+    const int64_t one[1] = {1};
+    const size_t ws = hbk_allreduce_workspace_bytes(1, one, HBK_INT32);
+    Buffer red;
+    if ((rc = red.ensure(ws + 16)) != HBK_OK) return rc;
+    rc = hbk_allreduce_n(p->comm, 1, HBK_INT32, 3 /* min */, in, one, out, 1.0f, red.ptr, red.bytes,
+                         stream_);
+    if (rc == HBK_OK) {
+      rc = hipMemcpyAsync(&ok, d_ok + 4, sizeof(ok), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                   hipStreamSynchronize(stream) == hipSuccess
+               ? HBK_OK : HBK_INTERNAL;
+    }
+    red.release();
+    if (rc != HBK_OK) return fail(rc, "sharded_p2p_bind: could not agree on the mapping");
+  }
+  if (!ok) {
+    for (void* m : p->ipc_opened) (void)hipIpcCloseMemHandle(m);
+    p->ipc_opened.clear();
+    return fail(HBK_UNIMPLEMENTED, "sharded_p2p_bind: a peer's output memory cannot be mapped "
+                                   "(hipIpcGetMemHandle / hipIpcOpenMemHandle); the plan keeps the "
+                                   "exchange form");
+  }
+  p->p2p_outs.assign(outs, outs + N);
+  p->p2p_strides.resize((size_t)N);
+  for (int c = 0; c < N; ++c) p->p2p_strides[c] = mine[c].stride;
+  p->p2p_bound = true;
+  return HBK_OK;
+}
+
+extern "C" int hbk_sharded_p2p_unbind(hbk_sharded_t p) {
+  using namespace hbk;
+  HBK_REQUIRE(p != nullptr, "sharded_p2p_unbind: plan is NULL");
+  p->p2p_bound = false;
+  p->ps[0].pending = p->ps[1].pending = false;
+  for (void* m : p->ipc_opened) (void)hipIpcCloseMemHandle(m);
+  p->ipc_opened.clear();
+  return HBK_OK;
+}
+
 extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids,
                                       const int64_t* n_ids,
                                       const int32_t* const* row_splits,
@@ -892,6 +1111,22 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   //   compute : pack(0..G-1)      gather(0)  gather(1) ..      stitch(0)   stitch(1)
   // (inline exchanges: nothing runs beside them, one group is all there is to schedule)
   const int G = step_groups(p);
+  // p2p form (hbk_sharded_p2p_bind): the owner gather stores every row into the requester's
+  // registered output -- (id, slot) pairs out, no rows exchange, no stitch
+  const bool p2p = p->p2p_bound;
+  if (p2p) {
+    for (int c = 0; c < N; ++c) {
+      HBK_REQUIRE(p->row_splits[c] == nullptr,
+                  "sharded_lookup_fwd: column %d is ragged: a plan with registered outputs "
+                  "(hbk_sharded_p2p_bind) takes one id per segment; unbind it first", c);
+      HBK_REQUIRE(outs[c] == p->p2p_outs[c] &&
+                      (out_strides == nullptr || out_strides[c] == 0 ||
+                       out_strides[c] == p->p2p_strides[c] ||
+                       (out_strides[c] == p->cols[c].dim && p->p2p_strides[c] == p->cols[c].dim)),
+                  "sharded_lookup_fwd: column %d: not the output registered with "
+                  "hbk_sharded_p2p_bind", c);
+    }
+  }
   std::vector<Group>& groups = p->groups;
   groups.assign(G, Group());
   int64_t tot_req_ids = 0, tot_own_ids = 0, tot_own_floats = 0, tot_req_floats = 0;
@@ -950,7 +1185,12 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   }
   HBK_REQUIRE((int64_t)(rows_send_bytes / 4) + tot_req_floats < (1ll << 32),
               "sharded_lookup_fwd: more than 2^32 floats (16 GB) of rows per step on one rank");
-  if ((rc = p->runs_dev.ensure(sizeof(int64_t) * 5 * (size_t)N * W)) != HBK_OK) return rc;
+  if ((rc = p->runs_dev.ensure(sizeof(int64_t) * 7 * (size_t)N * W)) != HBK_OK) return rc;
+  if (p2p) {
+    if ((rc = p->slot_send.ensure((size_t)tot_req_ids * 4 + 16)) != HBK_OK) return rc;
+    if ((rc = p->slot_recv.ensure((size_t)tot_own_ids * 4 + 16)) != HBK_OK) return rc;
+    if ((rc = p->token_buf.ensure((size_t)W * 8 + 16)) != HBK_OK) return rc;
+  }
   char* ids_send_base = p->send_ids_p;
   char* ids_recv_base = p->recv_ids_p;
   float* rows_send_base = p->send_rows_p;
@@ -1000,7 +1240,21 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
         }
       }
     }
-    HBK_HIP_OK(hipMemcpyAsync(p->runs_dev.ptr, p->host_runs, sizeof(int64_t) * 5 * (size_t)N * W,
+    // p2p: where owner q's run of column c starts among the column's shard-ordered ids, and in the
+    // peer-major slot buffer (one group: the layout of the outgoing ids)
+    int64_t* h_soff = p->host_runs + 5 * (size_t)N * W;
+    int64_t* h_doff = p->host_runs + 6 * (size_t)N * W;
+    if (p2p) {
+      const Group& gr = groups[0];
+      for (int c = 0; c < N; ++c) {
+        for (int q = 0; q < W; ++q) {
+          h_soff[(size_t)c * W + q] = gr.lay.col_shard_off[(size_t)c * W + q];
+          h_doff[(size_t)c * W + q] = gr.id_send + gr.lay.req_id_off[(size_t)q * N + c];
+        }
+      }
+    }
+    HBK_HIP_OK(hipMemcpyAsync(p->runs_dev.ptr, p->host_runs,
+                              sizeof(int64_t) * (p2p ? 7 : 5) * (size_t)N * W,
                               hipMemcpyHostToDevice, stream));
   }
   // stage A: the ids of every group peer-major -- run_partition has done it (pack_ids_kernel, while
@@ -1023,6 +1277,38 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     }
     if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
   }
+  int32_t* const slot_send = reinterpret_cast<int32_t*>(p->slot_send.ptr);
+  int32_t* const slot_recv = reinterpret_cast<int32_t*>(p->slot_recv.ptr);
+  if (p2p) {   // the output slot of every id, peer-major like the ids
+    const int64_t* d_soff = reinterpret_cast<const int64_t*>(p->runs_dev.ptr) + 5 * (size_t)N * W;
+    const int64_t* d_doff = d_soff + (size_t)N * W;
+    int c0 = 0;
+    while (c0 < N) {
+      SlotArgs a;
+      a.W = W;
+      a.col0 = c0;
+      a.pad_ = 0;
+      a.shard_off = d_soff;
+      a.dst_off = d_doff;
+      a.slots = slot_send;
+      int k = 0;
+      int64_t tiles = 0;
+      a.tile0[0] = 0;
+      while (c0 + k < N && k < kSlotCols) {
+        a.idx[k] = idx[c0 + k];
+        a.n[k] = (int32_t)n_ids[c0 + k];
+        tiles += (n_ids[c0 + k] + kSlotTile - 1) / kSlotTile;
+        ++k;
+        a.tile0[k] = (int32_t)tiles;
+      }
+      a.n_cols = k;
+      if (tiles > 0) {
+        hipLaunchKernelGGL(p2p_slots_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, stream, a);
+        HBK_HIP_OK(hipGetLastError());
+      }
+      c0 += k;
+    }
+  }
   // one rank with its own slice left in place: nothing goes on the wire, the step stays on the
   // compute stream (no hops to the communicator's stream and back)
   const bool wire = !(W == 1 && zc);
@@ -1035,6 +1321,12 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
                   gr.lay.ids_send_peer.data(), ids_recv_base + gr.id_recv * id_bytes,
                   gr.lay.ids_recv_peer.data(), stream_, p->ev[0][0], p->ev[1][g], nullptr, 0, zc);
     if (rc != HBK_OK) return rc;
+    if (p2p) {   // the slots travel like the ids (same sizes; G = 1)
+      rc = exchange(p, HBK_INT32, HBK_INT32, slot_send + gr.id_send, gr.lay.ids_send_peer.data(),
+                    slot_recv + gr.id_recv, gr.lay.ids_recv_peer.data(), stream_, p->ev[0][0],
+                    p->ev[3][0], nullptr, 0, zc);
+      if (rc != HBK_OK) return rc;
+    }
   }
   // stage C: owner gather of group g as soon as its ids are in (N_g * W virtual columns, straight
   // into the peer-major reply), then its rows go on the wire
@@ -1042,6 +1334,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     const Group& gr = groups[g];
     const int ng = gr.c1 - gr.c0;
     if (hop) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[1][g], 0));
+    if (hop && p2p) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[3][0], 0));
     std::vector<hbk_lookup_column_t> v;
     v.reserve((size_t)ng * W);
     for (int q = 0; q < W; ++q) {
@@ -1068,7 +1361,16 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
           out_at = gr.row_recv + gr.lay.req_row_off[(size_t)q * ng + c];
           out_base = rows_recv_base;
         }
-        if (half) {   // the same element offsets inside the same buffers, two bytes each
+        if (p2p) {
+          // straight into requester q's output, row = the slot that travelled with the id
+          h.out = p->peer_out[(size_t)q * N + gr.c0 + c];
+          h.out_stride = p->peer_stride[(size_t)q * N + gr.c0 + c];
+          h.out_slots = slot_recv + gr.id_recv + gr.lay.own_id_off[(size_t)q * ng + c];
+          if (zc && q == me) {
+            h.out_slots = slot_send + gr.id_send + gr.lay.req_id_off[(size_t)q * ng + c];
+          }
+          h.hot_rows = 0;
+        } else if (half) {   // the same element offsets inside the same buffers, two bytes each
           h.out = reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(out_base) + out_at);
           h.half_io = HBK_LOOKUP_OUT_HALF;
         } else {
@@ -1081,6 +1383,18 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     if (rc != HBK_OK) return rc;
     if (!wire) continue;
     if (hop) HBK_HIP_OK(hipEventRecord(p->ev[2][g], stream));
+    if (p2p) {
+      // nothing to send back: a one-int token per peer tells every requester that this owner's
+      // stores into its output are done (the exchange is ordered behind the gather kernel, whose
+      // end releases its stores at system scope; the requester's next kernel acquires)
+      int32_t* tok = reinterpret_cast<int32_t*>(p->token_buf.ptr);
+      std::vector<int32_t> ones((size_t)W, 1);
+      rc = exchange(p, HBK_INT32, HBK_INT32, tok, ones.data(), tok + W, ones.data(), stream_,
+                    p->ev[2][g], p->ev[2][1], nullptr, 0, zc);
+      if (rc != HBK_OK) return rc;
+      if (hop) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[2][1], 0));
+      continue;
+    }
     if (half) {
       rc = exchange(p, HBK_HALF, HBK_HALF, reinterpret_cast<uint16_t*>(rows_send_base) + gr.row_send,
                     gr.lay.rows_send_peer.data(),
@@ -1098,7 +1412,7 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   // peer-major, column c is a W-run segmented table over them
   const int64_t* d_start = reinterpret_cast<const int64_t*>(p->runs_dev.ptr);
   const int64_t* d_base = d_start + (size_t)N * W;
-  for (int g = 0; g < G; ++g) {
+  for (int g = 0; g < G && !p2p; ++g) {
     const Group& gr = groups[g];
     const int ng = gr.c1 - gr.c0;
     if (hop) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[3][g], 0));

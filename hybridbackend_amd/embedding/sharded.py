@@ -170,6 +170,38 @@ class ShardedGroupLookup:
     _lib.check(self._lib.hbk_sharded_last_host_us(self._plan(), out))
     return tuple(float(v) for v in out)
 
+  def p2p_bind(self, outs):
+    """Register this rank's output tensors for the P2P FORM of the forward (round 5;
+    ``hbk_sharded_p2p_bind``) -- a COLLECTIVE: every rank calls it with its own ``outs`` (fp32
+    ``[n_ids[c], dim]`` per column, contiguous or column blocks of one wider tensor).  From then on
+    every forward of this object must be handed exactly these tensors and one id per segment; a step
+    sends (id, output row) pairs and the owner-side gather stores every row straight into the
+    requester's output -- no reply buffer, no rows Alltoallv, no stitch: one random-row pass instead
+    of two, and the gather itself is the exchange.  Returns True; False (on every rank) when some
+    peer's memory cannot be mapped, in which case the object keeps the exchange form.  Not with
+    ``dedup`` or the fp16 wire."""
+    n = len(self.shards)
+    if len(outs) != n:
+      raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, f'p2p_bind: {len(outs)} outputs for {n} columns')
+    for c, o in enumerate(outs):
+      _lib.require_device_tensor(o, 'output', row_strided=True)
+      if o.dtype != torch.float32 or o.dim() != 2 or o.shape[1] != self.dims[c]:
+        raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, f'p2p_bind: output {c} must be fp32 [*, {self.dims[c]}]')
+    strides = (C.c_int32 * n)(*[0 if o.is_contiguous() else int(o.stride(0)) for o in outs])
+    rc = self._lib.hbk_sharded_p2p_bind(self._plan(), _lib.ptr_array([o.data_ptr() for o in outs]),
+                                        strides, _lib.current_stream(self.device))
+    if rc == _lib.UNIMPLEMENTED:
+      self._p2p_keep = None
+      return False
+    _lib.check(rc)
+    self._p2p_keep = list(outs)
+    return True
+
+  def p2p_unbind(self):
+    """Back to the exchange form (every rank must do the same before its next forward)."""
+    _lib.check(self._lib.hbk_sharded_p2p_unbind(self._plan()))
+    self._p2p_keep = None
+
   def close(self):
     if getattr(self, '_plan_handle', None) is not None:
       self._lib.hbk_sharded_destroy(self._plan_handle)

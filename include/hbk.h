@@ -244,6 +244,11 @@ typedef struct {
    * segment, plain table.  HBK_LOOKUP_TABLE_HALF: `table` holds fp16 rows (sums stay fp32);
    * segmented tables only (n_runs > 0).  Offsets, strides and run bases count elements. */
   int32_t half_io;
+  /* optional output permutation (round 5): segment s is written to row out_slots[s] of `out`
+   * instead of row s (device int32 [n_segments]; one id per segment, plain table, fp32 rows).
+   * The owner gather of the sharded step's p2p form stores every row straight into its place in
+   * the requester's output this way.  NULL: rows in segment order. */
+  const int32_t* out_slots;
 } hbk_lookup_column_t;
 #define HBK_LOOKUP_OUT_HALF 1
 #define HBK_LOOKUP_TABLE_HALF 2
@@ -542,6 +547,24 @@ int hbk_sharded_prefetch(hbk_sharded_t plan, const int64_t* const* ids, const in
                          void* ids_ready_event /* hipEvent_t recorded after the ids were written,
                                                   or NULL when they are complete already */);
 int64_t hbk_sharded_owned_ids(hbk_sharded_t plan, int32_t column);
+
+/* The p2p form of the forward (round 5).  hbk_sharded_p2p_bind registers this rank's N output
+ * tensors ([n_ids[c], dim] fp32, out_strides as in hbk_sharded_lookup_fwd; NULL = dense) -- a
+ * COLLECTIVE over the plan's communicator: every rank calls it with its own tensors, the addresses
+ * are exchanged once and mapped into every peer (ranks of one process: the pointer itself; other
+ * processes: hipIpcGetMemHandle / hipIpcOpenMemHandle).  From then on hbk_sharded_lookup_fwd --
+ * which must be handed exactly these tensors, one id per segment -- sends (id, output row) pairs and
+ * the owner-side gather stores every row straight into its place in the requester's output: no
+ * reply buffer, no rows Alltoallv, no stitch (one random-row pass instead of two; the rows cross the
+ * link as the gather's own stores, so the gather IS the exchange); the ids still travel through the
+ * communicator, and a one-int token per peer orders the requester behind the owners' stores.  The
+ * exchange form stays the contract default (hbtf/embedding/sharding.py:171-205 composes the same
+ * result); requester-side dedup and the fp16 wire are not available in this form.  The backward is
+ * unchanged.  HBK_UNIMPLEMENTED on every rank when some peer's memory cannot be mapped; the plan
+ * then keeps the exchange form.  hbk_sharded_p2p_unbind returns to it (not collective). */
+int hbk_sharded_p2p_bind(hbk_sharded_t plan, float* const* outs, const int32_t* out_strides,
+                         hbk_stream_t stream);
+int hbk_sharded_p2p_unbind(hbk_sharded_t plan);
 /* diagnostics: host time of the plan's last forward in microseconds -- [0] enqueueing the
  * partition and the size exchange, [1] waiting for the sizes (the device, not host work),
  * [2] enqueueing everything else */

@@ -53,7 +53,7 @@ def main():
   ap.add_argument('--rank', type=int, required=True)
   ap.add_argument('--world', type=int, required=True)
   ap.add_argument('--dir', required=True)
-  ap.add_argument('--cases', default='kat,alltoallv,alltoall,sharded,dedup,reduce')
+  ap.add_argument('--cases', default='kat,alltoallv,alltoall,sharded,dedup,p2p,reduce')
   ap.add_argument('--local-size', type=int, default=0)
   a = ap.parse_args()
   rank, W = a.rank, a.world
@@ -284,6 +284,50 @@ def run(a, result):
     sharded_step('requester-side dedup, pipelined, fp16', 401, dedup=True, zipf=True, wire16=True,
                  options=(('sharded_inline', 0), ('sharded_groups', 2)))
     sharded_step('dedup on uniform ids', 402, dedup=True)
+
+  # ---- the p2p form: owners store rows straight into the requester's output (IPC mappings) -----
+  @case('p2p')
+  def _p2p():
+    for label, seed, options in (
+        ('p2p, inline', 600, (('sharded_inline', 1),)),
+        ('p2p, communicator stream', 601, (('sharded_inline', 0),)),
+        ('p2p, int64 ids, late pack', 602, (('sharded_id64', 1), ('sharded_pack_early', 0)))):
+      saved = [(k, _lib.set_option(k, v)) for k, v in options]
+      try:
+        rng = np.random.RandomState(seed)
+        dims = [16, 6, 128, 4]
+        rows = [50021, 211, 3000, 64]
+        n = len(dims)
+        batch = 2000
+        tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(n)]
+        ids = [[[rng.randint(0, 2**40, size=batch).astype(np.int64) for _ in range(n)]
+                for _ in range(W)] for _ in range(3)]
+        grads = [[rng.randn(batch, dims[c]).astype(np.float32) for c in range(n)] for _ in range(W)]
+        shards = [dev(t[rank::W].copy()) for t in tables]
+        drv = ShardedGroupLookup(shards, coll, buckets=rows)
+        outs = [torch.full((batch, d), float('nan'), device=DEV) for d in dims]
+        bound = drv.p2p_bind(outs)
+        result.setdefault('p2p_bound', []).append(bool(bound))
+        assert bound, 'hbk_sharded_p2p_bind could not map the peers (every rank agrees on that)'
+        for st in range(3):
+          drv([dev(i) for i in ids[st][rank]], None, outs)
+          torch.cuda.synchronize()
+          want = oracle.group_lookup_fwd(tables, ids[st][rank], [None] * n, rows, ['sum'] * n)
+          for c in range(n):
+            np.testing.assert_equal(host(outs[c]), want[c], err_msg=f'{label}: step {st}, column {c}')
+        drv.backward([dev(g) for g in grads[rank]], apply_lr=0.05, emit=False)
+        torch.cuda.synchronize()
+        for c in range(n):
+          dense = np.zeros((rows[c], dims[c]), np.float64)
+          for q in range(W):
+            np.add.at(dense, ids[2][q][c] % rows[c], grads[q][c].astype(np.float64))
+          np.testing.assert_allclose(host(shards[c]),
+                                     (tables[c].astype(np.float64) - 0.05 * dense)[rank::W],
+                                     rtol=1e-5, atol=1e-5, err_msg=f'{label}: SGD step, column {c}')
+        drv.close()
+      finally:
+        for k, v in reversed(saved):
+          _lib.set_option(k, v)
 
   # ---- (f1) gradient aggregation: Allreduce / Allgatherv -------------------------------------
   @case('reduce')

@@ -27,6 +27,7 @@ GROUPS = {
     'collectives': 'kat,alltoallv,alltoall,reduce',
     'sharded': 'sharded',
     'dedup': 'dedup',
+    'p2p': 'p2p',
 }
 
 

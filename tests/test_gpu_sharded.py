@@ -8,6 +8,7 @@ import torch
 
 import oracle
 import hybridbackend_amd as hb
+from hybridbackend_amd import _lib
 from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
 
 pytestmark = pytest.mark.gpu
@@ -334,6 +335,151 @@ def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64,
     np.testing.assert_allclose(got, dense, **tol)
   for cm in comms:
     cm.close()
+
+
+@pytest.mark.parametrize('world,inline,id64,pack_early,block', [
+    (1, 1, False, 1, False), (2, 1, False, 1, False), (4, 1, False, 1, True), (8, 1, False, 1, False),
+    (4, 0, False, 1, False), (8, 0, True, 1, True), (2, 1, True, 0, False), (4, 0, False, 0, False),
+    (3, 1, False, 1, True)])
+def test_cxx_driver_p2p_form_in_process_world(hbk_option, world, inline, id64, pack_early, block):
+  """The p2p form of the sharded forward (round 5, hbk_sharded_p2p_bind): every rank registers its
+  output tensors once, a step sends (id, output row) pairs and the owner gather stores each row
+  straight into the requester's output -- no reply buffer, no rows exchange, no stitch.  W ranks as
+  host threads of one process (same address space: the peer pointers are the tensors' own; across
+  processes they come from hipIpcOpenMemHandle, tests/test_gpu_multi.py).  Forward bit-equal to the
+  unsharded oracle over several steps with other ids, outputs as separate tensors or as the column
+  blocks of ONE [batch, sum dims] tensor (block), dims with 16-byte and 4-byte chunks; the backward
+  of such a step == dense scatter-add and the fused SGD step lands where the dense gradient says;
+  inline and communicator-stream exchanges, int32 / int64 ids on the wire, early / late id pack."""
+  import threading
+  hbk_option('sharded_inline', inline)
+  hbk_option('sharded_pack_early', pack_early)
+  if id64:
+    hbk_option('sharded_id64', 1)
+  rng = np.random.RandomState(900 + world)
+  dims = [16, 6, 128, 4, 32]
+  rows = [50021, 211, 3000, 64, 100003]
+  n = len(dims)
+  batch = 1500
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(n)]
+  steps = 3
+  ids = [[[rng.randint(0, 2**40, size=batch).astype(np.int64) for _ in range(n)]
+          for _ in range(world)] for _ in range(steps)]
+  grads = [[rng.randn(batch, dims[c]).astype(np.float32) for c in range(n)] for _ in range(world)]
+  comms = hb.distribute.Collective.local_world(world)
+  shards = [[dev(t[r::world].copy()) for t in tables] for r in range(world)]
+  results, errors = [None] * world, []
+  lr = 0.05
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        drv = ShardedGroupLookup(shards[r], comms[r], buckets=rows)
+        if block:
+          wide = torch.full((batch, sum(dims)), float('nan'), device=DEV)
+          outs, at = [], 0
+          for d in dims:
+            outs.append(wide[:, at:at + d])
+            at += d
+        else:
+          outs = [torch.full((batch, d), float('nan'), device=DEV) for d in dims]
+        assert drv.p2p_bind(outs) is True
+        fwd = []
+        for st in range(steps):
+          got = drv([dev(i) for i in ids[st][r]], None, outs)
+          assert all(g.data_ptr() == o.data_ptr() for g, o in zip(got, outs))
+          torch.cuda.current_stream().synchronize()
+          # (peers may still be writing THEIR outputs; this rank's are complete behind its stream)
+          fwd.append([o.cpu().numpy().copy() for o in outs])
+        slices = drv.backward([dev(g) for g in grads[r]], apply_lr=0.0)
+        torch.cuda.current_stream().synchronize()
+        sl = [(u.cpu().numpy()[:int(k.item())], g.cpu().numpy()[:int(k.item())])
+              for u, g, k in slices]
+        drv([dev(i) for i in ids[steps - 1][r]], None, outs)
+        drv.backward([dev(g) for g in grads[r]], apply_lr=lr, emit=False)
+        torch.cuda.current_stream().synchronize()
+        # a ragged step on a plan with registered outputs is refused, as are other outputs
+        with pytest.raises(_lib.InvalidArgumentError):
+          drv([dev(i) for i in ids[0][r]], None, [torch.empty_like(o) for o in outs])
+        results[r] = (fwd, sl)
+        drv.close()
+    except Exception as e:  # pylint: disable=broad-except
+      import traceback
+      errors.append((r, traceback.format_exc()))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=60)
+  assert not errors, errors
+  assert all(x is not None for x in results)
+  for st in range(steps):
+    for r in range(world):
+      want = oracle.group_lookup_fwd(tables, ids[st][r], [None] * n, rows, ['sum'] * n)
+      for c in range(n):
+        np.testing.assert_equal(results[r][0][st][c], want[c])
+  for c in range(n):
+    dense = np.zeros((rows[c], dims[c]), np.float64)
+    for r in range(world):
+      np.add.at(dense, ids[steps - 1][r][c] % rows[c], grads[r][c].astype(np.float64))
+    got = np.zeros_like(dense)
+    for r in range(world):
+      lr_, g_ = results[r][1][c]
+      assert len(set(lr_.tolist())) == len(lr_)
+      got[lr_ * world + r] += g_
+    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5)
+    for r in range(world):
+      np.testing.assert_allclose(shards[r][c].cpu().numpy(),
+                                 (tables[c].astype(np.float64) - lr * dense)[r::world],
+                                 rtol=1e-5, atol=1e-5)
+  for cm in comms:
+    cm.close()
+
+
+def test_sharded_p2p_through_rccl_world1_and_refusals(hbk_option):
+  """The p2p form over a real RCCL communicator of one rank (the own slice stays in place: the owner
+  gather reads the ids and slots where the pack left them), both step forms; what the form does
+  not take is refused: requester-side dedup and the fp16 wire at bind, ragged ids at the step."""
+  rng = np.random.RandomState(77)
+  coll = hb.distribute.Collective(world_size=1, rank=0)
+  try:
+    tables = [rng.uniform(-1, 1, size=(5000, d)).astype(np.float32) for d in (16, 128, 5)]
+    t_dev = [dev(t) for t in tables]
+    for inline, copy_self in ((1, 0), (0, 0), (1, 1), (0, 1)):
+      hbk_option('sharded_inline', inline)
+      hbk_option('sharded_copy_self', copy_self)
+      drv = ShardedGroupLookup(t_dev, coll, buckets=[5000] * 3)
+      outs = [torch.empty(4000, t.shape[1], device=DEV) for t in tables]
+      assert drv.p2p_bind(outs) is True
+      for step in range(3):
+        ids = [rng.randint(0, 2**40, size=4000).astype(np.int64) for _ in range(3)]
+        drv([dev(i) for i in ids], None, outs)
+        torch.cuda.synchronize()
+        want = oracle.group_lookup_fwd(tables, ids, [None] * 3, [5000] * 3, ['sum'] * 3)
+        for o, w in zip(outs, want):
+          np.testing.assert_equal(o.cpu().numpy(), w)
+      sp = dev(np.arange(0, 4001, 2, dtype=np.int32))
+      with pytest.raises(_lib.InvalidArgumentError, match='ragged'):
+        drv([dev(i) for i in ids], [sp, None, None],
+            [torch.empty(2000, 16, device=DEV), outs[1], outs[2]])
+      drv.p2p_unbind()                       # back to the exchange form: ragged ids are fine again
+      got = drv([dev(i) for i in ids], [sp, None, None])
+      torch.cuda.synchronize()
+      want = oracle.group_lookup_fwd(tables, ids, [np.arange(0, 4001, 2, dtype=np.int32), None, None],
+                                     [5000] * 3, ['sum'] * 3)
+      np.testing.assert_equal(got[0].cpu().numpy(), want[0])
+      drv.close()
+    drv = ShardedGroupLookup(t_dev, coll, buckets=[5000] * 3, dedup=True)
+    with pytest.raises(_lib.InvalidArgumentError, match='dedup'):
+      drv.p2p_bind([torch.empty(10, t.shape[1], device=DEV) for t in tables])
+    drv.close()
+    drv = ShardedGroupLookup(t_dev, coll, buckets=[5000] * 3, wire_dtype=torch.float16)
+    with pytest.raises(_lib.InvalidArgumentError, match='fp16'):
+      drv.p2p_bind([torch.empty(10, t.shape[1], device=DEV) for t in tables])
+    drv.close()
+  finally:
+    coll.close()
 
 
 @pytest.mark.parametrize('world,kind,groups,pack_early,wire16', [

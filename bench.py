@@ -84,6 +84,12 @@ def parse_args():
                       'count (option sharded_groups: 2 = exchanges of one column group overlap the '
                       'gather / stitch of the other, 1 = no pipelining, half the cross-stream '
                       'hops); the faster one runs the timed steps.  0: keep the default')
+  p.add_argument('--p2p', choices=['auto', 'on', 'off'], default='auto',
+                 help='probe the p2p form of the sharded step (owners store rows straight into the '
+                      'requester\'s registered outputs: hbk_sharded_p2p_bind) next to the exchange '
+                      'forms and run the timed steps in it when it is the fastest.  auto: at one '
+                      'rank (--sharded) only -- across processes the form maps peer memory through '
+                      'hipIpc*, which has not run on this hardware yet; on: at any N')
   p.add_argument('--no-secondary', action='store_true',
                  help='N > 1 (or --sharded): skip the two reference measurements that follow the '
                       'headline steps -- the other wire format, and every rank holding ALL tables '
@@ -438,12 +444,18 @@ def main():
     # candidates: two column groups with the exchanges on the communicator's stream beside the
     # gathers (the default until round 4), one group on the communicator's stream, and the
     # exchanges enqueued inline on the compute stream (no event hops at all; the shipped default)
-    forms = {'pipelined_2_groups': (2, 0), 'one_group': (1, 0), 'inline': (0, 1)}
+    forms = {'pipelined_2_groups': (2, 0, False), 'one_group': (1, 0, False),
+             'inline': (0, 1, False)}
+    if args.wire == 'fp32' and (args.p2p == 'on' or (args.p2p == 'auto' and world == 1)):
+      forms['p2p'] = (0, 1, True)
     groups_probe = {}
-    for name, (g, inline) in forms.items():
+    for name, (g, inline, p2p) in forms.items():
       _hbk.set_option('sharded_groups', g)
       _hbk.set_option('sharded_inline', inline)
       sharded.close()                 # the options are read when the plan is (re)created
+      if p2p and not sharded.p2p_bind(sh_outs):   # (collective; False on every rank alike)
+        groups_probe[name] = None
+        continue
       for i in range(3):
         step(i)
       torch.cuda.synchronize()
@@ -459,10 +471,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
       groups_probe[name] = round(dt / args.tune_steps * 1e3, 5)
-    best_form = min(groups_probe, key=groups_probe.get)
+    best_form = min((k for k, v in groups_probe.items() if v is not None), key=groups_probe.get)
     _hbk.set_option('sharded_groups', forms[best_form][0])
     _hbk.set_option('sharded_inline', forms[best_form][1])
     sharded.close()
+    if forms[best_form][2]:
+      sharded.p2p_bind(sh_outs)
 
   def timed_steps(step_fn, steps, warmup):
     """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides;

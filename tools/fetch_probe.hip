@@ -162,6 +162,84 @@ __global__ __launch_bounds__(256) void fetch_sload_x8(const char* table, const u
   if (acc == 12345) sink[0] = acc;
 }
 
+// ---- hybrid: a wave fetches 32 rows with vector loads AND KS rows with scalar loads per round -----
+// (does the memory side move more rows per second when part of them are 64-byte requests?)
+template <int KS>
+__device__ inline void hybrid_body(const char* table, const uint32_t* rowidx, int64_t n,
+                                   int rows_per_wave, float* sink) {
+  constexpr int PER = 32 + KS;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int lane = threadIdx.x & 63, sub = lane & 3, grp = lane >> 2;
+  int64_t s = (int64_t)wave * rows_per_wave;
+  int64_t end = s + rows_per_wave;
+  if (end > n) end = n;
+  f32x4 acc = {0, 0, 0, 0};
+  int sacc = 0;
+  for (; s + PER <= end; s += PER) {
+    // one row number per lane (PER <= 64), coalesced
+    const uint32_t mine = lane < PER ? rowidx[s + lane] : 0u;
+    const uint32_t r0 = __builtin_amdgcn_readlane(mine, 32);
+    const uint32_t r1 = __builtin_amdgcn_readlane(mine, 33);
+    const char* p0 = table + (uint64_t)r0 * 64;
+    const char* p1 = table + (uint64_t)r1 * 64;
+    i32x16 a, b, c, d;
+    if (KS == 4) {
+      const uint32_t r2 = __builtin_amdgcn_readlane(mine, 34);
+      const uint32_t r3 = __builtin_amdgcn_readlane(mine, 35);
+      const char* p2 = table + (uint64_t)r2 * 64;
+      const char* p3 = table + (uint64_t)r3 * 64;
+      asm volatile("s_load_dwordx16 %0, %4, 0x0\n s_load_dwordx16 %1, %5, 0x0\n"
+                   "s_load_dwordx16 %2, %6, 0x0\n s_load_dwordx16 %3, %7, 0x0"
+                   : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
+                   : "s"(p0), "s"(p1), "s"(p2), "s"(p3)
+                   : "memory");
+    } else {
+      asm volatile("s_load_dwordx16 %0, %2, 0x0\n s_load_dwordx16 %1, %3, 0x0"
+                   : "=&s"(a), "=&s"(b)
+                   : "s"(p0), "s"(p1)
+                   : "memory");
+    }
+    // the 32 vector rows: 2 per lane group, in flight beside the scalar loads
+    const uint32_t v0 = __shfl(mine, grp, 64), v1 = __shfl(mine, 16 + grp, 64);
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(table + (uint64_t)v0 * 64 + sub * 16);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(table + (uint64_t)v1 * 64 + sub * 16);
+    acc += x0 + x1;
+    if (KS == 4) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d)::"memory");
+      sacc += a[0] + b[5] + c[10] + d[15];
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory");
+      sacc += a[0] + b[5];
+    }
+  }
+  if (acc.x == 12345.678f || sacc == 12345) sink[0] = acc.y;
+}
+__global__ __launch_bounds__(256) void fetch_hybrid_s4(const char* table, const uint32_t* rowidx,
+                                                       int64_t n, int rows_per_wave, float* sink) {
+  hybrid_body<4>(table, rowidx, n, rows_per_wave, sink);
+}
+__global__ __launch_bounds__(256) void fetch_hybrid_s2(const char* table, const uint32_t* rowidx,
+                                                       int64_t n, int rows_per_wave, float* sink) {
+  hybrid_body<2>(table, rowidx, n, rows_per_wave, sink);
+}
+// the same loop without the scalar rows (what the loop structure itself costs)
+__global__ __launch_bounds__(256) void fetch_hybrid_s0(const char* table, const uint32_t* rowidx,
+                                                       int64_t n, int rows_per_wave, float* sink) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int lane = threadIdx.x & 63, sub = lane & 3, grp = lane >> 2;
+  int64_t s = (int64_t)wave * rows_per_wave;
+  int64_t end = s + rows_per_wave;
+  if (end > n) end = n;
+  f32x4 acc = {0, 0, 0, 0};
+  for (; s + 32 <= end; s += 32) {
+    const uint32_t mine = lane < 32 ? rowidx[s + lane] : 0u;
+    const uint32_t v0 = __shfl(mine, grp, 64), v1 = __shfl(mine, 16 + grp, 64);
+    acc += *reinterpret_cast<const f32x4*>(table + (uint64_t)v0 * 64 + sub * 16) +
+           *reinterpret_cast<const f32x4*>(table + (uint64_t)v1 * 64 + sub * 16);
+  }
+  if (acc.x == 12345.678f) sink[0] = acc.y;
+}
+
 // ---- LDS-DMA: every lane names 16 bytes of global memory, the wave's 1 KB lands in LDS ------
 constexpr int kDmaU = 4;
 template <bool BUFFER>
@@ -293,6 +371,21 @@ int main(int argc, char** argv) {
              }));
       if (quick) break;
     }
+  }
+  for (unsigned waves : {8192u, 16384u, 32768u}) {
+    char name[64];
+    auto run_h = [&](const char* what, auto kern, int per) {
+      const int rpw = (int)(((n + waves - 1) / waves + per - 1) / per * per);
+      snprintf(name, sizeof name, "%s (%u waves)", what, waves);
+      report(name, time_us(10, [&](int i) {
+               hipLaunchKernelGGL(kern, dim3(waves / 4), dim3(256), 0, 0,
+                                  reinterpret_cast<const char*>(tab), idx[i % kBatches], n, rpw, sink);
+             }));
+    };
+    run_h("hybrid 32v+0s", fetch_hybrid_s0, 32);
+    run_h("hybrid 32v+2s", fetch_hybrid_s2, 34);
+    run_h("hybrid 32v+4s", fetch_hybrid_s4, 36);
+    if (quick) break;
   }
   {
     const unsigned grid = (unsigned)((n + 4 * 16 * kDmaU - 1) / (4 * 16 * kDmaU));

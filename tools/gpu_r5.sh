@@ -81,6 +81,12 @@ for st in $STAGES; do
       unset HBK_BENCH_ITERS
       for f in pmc_rs_tcc pmc_rs_sq; do echo "== $f"; tail -1 $O/$f.log; pmc_table $O/$f.json bwd_; trim $f; done
       trim prof_ragged;;
+    p2pprof)    # kernel times of the sharded step at one rank: exchange form (inline) and p2p form
+      prof prof_p2p "" -- python $R/bench.py --sharded --steps 30 --warmup 5 --cpu-seconds 0 --no-secondary --tune-steps 0 --p2p off
+      grep -E "hbk|kernel  " $O/prof_p2p.txt | cut -c1-150 | head -16
+      HBK_BENCH_FORCE_P2P=1 true
+      prof prof_p2p_on "" -- python $R/bench.py --sharded --steps 30 --warmup 5 --cpu-seconds 0 --no-secondary --tune-steps 4 --p2p on
+      grep -E "hbk|kernel  " $O/prof_p2p_on.txt | cut -c1-150 | head -24; trim prof_p2p; trim prof_p2p_on;;
     overlap)    # the step's forms under an artificial wire (one rank, full per-rank work)
       timeout 600 python tools/overlap_model.py > $O/overlap_model.txt 2> $O/overlap_model.err; echo "rc=$?"; cat $O/overlap_model.txt; tail -5 $O/overlap_model.err;;
     bwdtest)

@@ -848,3 +848,34 @@ extern "C" int hbk_allgatherv(hbk_comm_t comm, int32_t dtype, const void* input,
   }
   return fence_out(comm, cs);
 }
+
+// HbNcclBroadcast (hbtf/distribute/nccl/nccl_broadcast.cc:31-92): every rank ends with the root's
+// `count` elements in `output` (input is read on the root only; input == output is allowed).
+extern "C" int hbk_broadcast(hbk_comm_t comm, int32_t dtype, const void* input, void* output,
+                             int64_t count, int32_t root, hbk_stream_t compute_stream) {
+  using namespace hbk;
+  HBK_REQUIRE(comm != nullptr, "broadcast: comm is NULL");
+  HBK_REQUIRE(count >= 0, "broadcast: negative count");
+  const int W = comm->world_size, me = comm->rank;
+  HBK_REQUIRE(root >= 0 && root < W, "broadcast: root %d out of [0, %d)", root, W);
+  ncclDataType_t nt;
+  HBK_REQUIRE(to_nccl(dtype, &nt), "broadcast: unsupported dtype %d", dtype);
+  if (count == 0) return HBK_OK;
+  HBK_REQUIRE(output != nullptr && (me != root || input != nullptr), "broadcast: NULL buffer");
+  const size_t esize = (size_t)dtype_size(dtype);
+  hipStream_t cs = as_stream(compute_stream);
+  if (comm->custom) {
+    // the root sends its buffer to every rank, the others send nothing
+    std::vector<int64_t> soff(W, 0), slen(W, me == root ? count : 0), roff(W, 0);
+    std::vector<int> all(W);
+    for (int r = 0; r < W; ++r) all[r] = r;
+    return custom_exchange(comm, all, me == root ? input : output, soff, slen, output, roff, esize, cs);
+  }
+  std::unique_lock<std::mutex> lock(comm->mu);
+  HBK_REQUIRE(!comm->aborted, "broadcast: communicator was aborted");
+  int rc = fence_in(comm, cs);
+  if (rc != HBK_OK) return rc;
+  HBK_NCCL_OK(ncclBroadcast(me == root ? input : output, output, (size_t)count, nt, root, comm->comm,
+                            comm->stream));
+  return fence_out(comm, cs);
+}

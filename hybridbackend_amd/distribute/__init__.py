@@ -4,6 +4,7 @@ from hybridbackend_amd.distribute.collective import Collective
 from hybridbackend_amd.distribute.collective import Topology
 from hybridbackend_amd.distribute.collective import aggregate_gradients
 from hybridbackend_amd.distribute.collective import alltoallv_offsets
+from hybridbackend_amd.distribute.collective import broadcast
 from hybridbackend_amd.distribute.collective import compute_active_ranks
 from hybridbackend_amd.distribute.partition import PartitionByModuloN
 from hybridbackend_amd.distribute.partition import partition_by_dual_modulo_n

@@ -250,6 +250,19 @@ class Collective:
     return out
 
 
+def broadcast(value, coll, root_rank=0, out=None):
+  r'''Broadcast ``value`` of rank ``root_rank`` to every rank (collective.py ``broadcast``; op
+  HbNcclBroadcast, nccl_broadcast.cc:31-92).  Every rank passes a tensor of the same shape and
+  dtype; returns the root's values.'''
+  _lib.require_device_tensor(value, 'value')
+  if out is None:
+    out = torch.empty_like(value)
+  _lib.check(coll._lib.hbk_broadcast(
+    coll._handle, _lib.torch_dtype_code(value.dtype), C.c_void_p(value.data_ptr()),
+    C.c_void_p(out.data_ptr()), value.numel(), int(root_rank), _lib.current_stream(value.device)))
+  return out
+
+
 def aggregate_gradients(grads, coll, sharded=None):
   """Cross-rank aggregation of one step's gradients -- mirror of
   hybridbackend/tensorflow/training/gradient.py:119-217.

@@ -458,6 +458,12 @@ int hbk_allreduce_n(hbk_comm_t comm, int32_t n, int32_t dtype, int32_t reduce_op
                     hbk_stream_t compute_stream);
 int hbk_allgatherv(hbk_comm_t comm, int32_t dtype, const void* input, const int64_t* counts,
                    void* output, hbk_stream_t compute_stream);
+/* HbNcclBroadcast (hbtf/distribute/nccl/nccl_broadcast.cc:31-92): every rank ends with the root's
+ * `count` elements in `output`; `input` is read on the root only (input == output is allowed).
+ * HbNcclAllgather (nccl_allgather.cc:31-101, equal counts) is hbk_allgatherv with every count the
+ * same. */
+int hbk_broadcast(hbk_comm_t comm, int32_t dtype, const void* input, void* output, int64_t count,
+                  int32_t root, hbk_stream_t compute_stream);
 
 /* A communicator over a caller-provided transport instead of RCCL (the reference's Collective is
  * an abstract class with NCCL as one implementation, hbtf/distribute/collective.h:70-201).  Every

@@ -60,6 +60,7 @@ class TensorShape {
   TensorShape(std::initializer_list<int64> dims);
   int dims() const;
   int64 dim_size(int d) const;
+  void set_dim(int d, int64 size);
 };
 class PartialTensorShape {
  public:
@@ -87,6 +88,7 @@ class Tensor {
   Tensor();
   const TensorShape& shape() const;
   int64 NumElements() const;
+  int dims() const;
   int64 dim_size(int d) const;
   template <typename T> FlatView<T> flat() const;
   template <typename T> ScalarView<T> scalar() const;
@@ -101,6 +103,7 @@ class OpInputList {
 class Stream {
  public:
   Stream& ThenMemcpy(void* host_dst, const se::DeviceMemoryBase& src, uint64 size);
+  Stream& ThenMemcpy(se::DeviceMemoryBase* dst, const void* host_src, uint64 size);
   Stream& ThenMemcpy(se::DeviceMemoryBase* dst, const se::DeviceMemoryBase& src, uint64 size);
   Status BlockHostUntilDone();
 };

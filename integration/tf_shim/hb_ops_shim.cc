@@ -608,8 +608,84 @@ class AllreduceNOp : public CollectiveAsyncOp {
 REGISTER_OP("HbNcclAllgatherv")
     .Output("output: dtype").Input("handle: resource").Input("input: dtype")
     .Attr("dtype: " HB_DTYPES).SetIsStateful();
-// Kernel: one hbk_alltoall_n of the local element count gives every rank's count, a host sync
-// sizes the output (as nccl_allgatherv.cc does), then hbk_allgatherv.
+// HbNcclAllgather (nccl_allgather.cc:31-101): every rank contributes the same shape, the output is
+// [world x dim0, ...] in rank order.  HbNcclBroadcast (nccl_broadcast.cc:31-92): the root's tensor
+// on every rank.
+REGISTER_OP("HbNcclAllgather")
+    .Output("output: dtype").Input("handle: resource").Input("input: dtype")
+    .Attr("dtype: " HB_DTYPES).SetIsStateful();
+REGISTER_OP("HbNcclBroadcast")
+    .Output("output: dtype").Input("handle: resource").Input("input: dtype")
+    .Attr("root_rank: int >= 0 = 0").Attr("dtype: " HB_DTYPES).SetIsStateful()
+    .SetShapeFn([](shape_inference::InferenceContext* c) {
+      c->set_output(0, c->input(1));
+      return Status::OK();
+    });
+
+// Allgatherv: one hbk_alltoall_n of the local element count gives every rank's count, a host sync
+// sizes the output (as nccl_allgatherv.cc:62-120 does), then hbk_allgatherv.  Allgather: the counts
+// are known (every rank the same): no exchange, no sync.
+template <typename T, bool EQUAL>
+class AllgatherOp : public CollectiveAsyncOp {
+ public:
+  using CollectiveAsyncOp::CollectiveAsyncOp;
+  void Run(OpKernelContext* ctx, HbNcclCollective* coll) override {
+    const Tensor& in = ctx->input(1);
+    const int W = hbk_comm_world_size(coll->comm());
+    std::vector<int64_t> counts(W, in.NumElements());
+    if (!EQUAL) {
+      Tensor mine, all;
+      OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_INT64, TensorShape({W}), &mine));
+      OP_REQUIRES_OK(ctx, ctx->allocate_temp(DT_INT64, TensorShape({W}), &all));
+      auto* stream = ctx->op_device_context()->stream();
+      std::vector<int64> host_mine(W, in.NumElements());
+      se::DeviceMemoryBase d_mine(mine.flat<int64>().data(), sizeof(int64) * W);
+      stream->ThenMemcpy(&d_mine, host_mine.data(), sizeof(int64) * W);
+      const void* vin[1] = {mine.flat<int64>().data()};
+      void* vout[1] = {all.flat<int64>().data()};
+      const int64_t cnt[1] = {W};
+      OP_REQUIRES_OK(ctx, HbkStatus(hbk_alltoall_n(coll->comm(), 1, HBK_INT64, HBK_TOPOLOGY_ALL, vin,
+                                                   cnt, vout, StreamOf(ctx))));
+      std::vector<int64> host_all(W);
+      se::DeviceMemoryBase d_all(all.flat<int64>().data(), sizeof(int64) * W);
+      stream->ThenMemcpy(host_all.data(), d_all, sizeof(int64) * W);
+      OP_REQUIRES_OK(ctx, stream->BlockHostUntilDone());
+      for (int r = 0; r < W; ++r) counts[r] = host_all[r];
+    }
+    int64 total = 0;
+    for (int r = 0; r < W; ++r) total += counts[r];
+    // rows along dim 0; a scalar contributes one element
+    int64 inner = 1;
+    for (int d = 1; d < in.dims(); ++d) inner *= in.dim_size(d);
+    TensorShape shape = in.dims() == 0 ? TensorShape({total}) : in.shape();
+    if (in.dims() > 0) shape.set_dim(0, inner > 0 ? total / inner : 0);
+    Tensor* out;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, shape, &out));
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_allgatherv(coll->comm(), HbkType<T>::v, in.tensor_data().data(),
+                                                 counts.data(),
+                                                 const_cast<char*>(out->tensor_data().data()),
+                                                 StreamOf(ctx))));
+  }
+};
+
+template <typename T>
+class BroadcastOp : public CollectiveAsyncOp {
+ public:
+  explicit BroadcastOp(OpKernelConstruction* ctx) : CollectiveAsyncOp(ctx) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("root_rank", &root_));
+  }
+  void Run(OpKernelContext* ctx, HbNcclCollective* coll) override {
+    const Tensor& in = ctx->input(1);
+    Tensor* out;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(0, in.shape(), &out));
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_broadcast(coll->comm(), HbkType<T>::v, in.tensor_data().data(),
+                                                const_cast<char*>(out->tensor_data().data()),
+                                                in.NumElements(), root_, StreamOf(ctx))));
+  }
+
+ private:
+  int root_;
+};
 
 #define HB_REGISTER_ALLREDUCE_KERNELS(T)                                                        \
   REGISTER_KERNEL_BUILDER(Name("HbNcclAllreduce").Device(DEVICE_GPU).TypeConstraint<T>("dtype"), \
@@ -622,6 +698,18 @@ REGISTER_OP("HbNcclAllgatherv")
 HB_REGISTER_ALLREDUCE_KERNELS(int32); HB_REGISTER_ALLREDUCE_KERNELS(int64);
 HB_REGISTER_ALLREDUCE_KERNELS(float); HB_REGISTER_ALLREDUCE_KERNELS(double);
 HB_REGISTER_ALLREDUCE_KERNELS(Eigen::half);
+
+#define HB_REGISTER_GATHER_KERNELS(T)                                                            \
+  REGISTER_KERNEL_BUILDER(Name("HbNcclAllgatherv").Device(DEVICE_GPU).TypeConstraint<T>("dtype"), \
+                          AllgatherOp<T, false>);                                                \
+  REGISTER_KERNEL_BUILDER(Name("HbNcclAllgather").Device(DEVICE_GPU).TypeConstraint<T>("dtype"),  \
+                          AllgatherOp<T, true>);                                                 \
+  REGISTER_KERNEL_BUILDER(Name("HbNcclBroadcast").Device(DEVICE_GPU).TypeConstraint<T>("dtype"),  \
+                          BroadcastOp<T>)
+HB_REGISTER_GATHER_KERNELS(int8); HB_REGISTER_GATHER_KERNELS(uint8); HB_REGISTER_GATHER_KERNELS(int32);
+HB_REGISTER_GATHER_KERNELS(uint32); HB_REGISTER_GATHER_KERNELS(int64); HB_REGISTER_GATHER_KERNELS(uint64);
+HB_REGISTER_GATHER_KERNELS(float); HB_REGISTER_GATHER_KERNELS(double);
+HB_REGISTER_GATHER_KERNELS(Eigen::half);
 
 // ============================================================================================
 // HbLookup (cache probe)

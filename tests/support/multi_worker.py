@@ -353,6 +353,10 @@ def run(a, result):
     np.testing.assert_allclose(host(agg[1][0]), np.concatenate(parts, 0) / W, rtol=1e-6)
     np.testing.assert_equal(host(agg[1][1]), np.concatenate(idx_parts))
     np.testing.assert_equal(host(agg[2]), full[rank][1])        # sharded: stays local
+    # HbNcclBroadcast: every root in turn
+    for root in range(W):
+      got = hb.distribute.broadcast(dev(full[rank][3]), coll, root_rank=root)
+      np.testing.assert_equal(host(got), full[root][3])
 
   # ---- R4: sub-group topologies (Collective::compute_active_ranks, collective.h:80-112) ---------
   @case('topology')

@@ -788,6 +788,51 @@ def test_gradient_aggregation_in_process_world(world):
     cm.close()
 
 
+@pytest.mark.parametrize('world', [1, 3, 8])
+def test_broadcast_in_process_world_and_rccl(world):
+  """HbNcclBroadcast (nccl_broadcast.cc:31-92) = hbk_broadcast: every rank ends with the root's
+  tensor, whatever it held; in-process ranks, any root, several dtypes; and through RCCL at world 1."""
+  import threading
+  rng = np.random.RandomState(61)
+  vals = [[rng.randn(1000, 4).astype(np.float32), rng.randint(-5, 5, size=7).astype(np.int64),
+           rng.randn(1).astype(np.float32)] for _ in range(world)]
+  comms = hb.distribute.Collective.local_world(world)
+  results, errors = [None] * world, []
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        got = []
+        for k, v in enumerate(vals[r]):
+          got.append(hb.distribute.broadcast(dev(v), comms[r], root_rank=(k + 1) % world))
+        x = dev(vals[r][0])
+        hb.distribute.broadcast(x, comms[r], root_rank=0, out=x)     # in place
+        torch.cuda.current_stream().synchronize()
+        results[r] = [g.cpu().numpy() for g in got] + [x.cpu().numpy()]
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((r, repr(e)))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=45)
+  assert not errors, errors
+  for r in range(world):
+    for k in range(3):
+      np.testing.assert_equal(results[r][k], vals[(k + 1) % world][k])
+    np.testing.assert_equal(results[r][3], vals[0][0])
+  for cm in comms:
+    cm.close()
+  if world == 1:
+    coll = hb.distribute.Collective(world_size=1, rank=0)
+    try:
+      x = rng.randn(513, 3).astype(np.float32)
+      np.testing.assert_equal(hb.distribute.broadcast(dev(x), coll).cpu().numpy(), x)
+    finally:
+      coll.close()
+
+
 def test_allreduce_allgather_through_rccl_world1():
   coll = hb.distribute.Collective(world_size=1, rank=0)
   try:

@@ -153,6 +153,9 @@ class GroupLookup:
     need bind()'s detailed checks (the caller then makes views and calls bind)."""
     self._call_key = None
     n = len(self.tables)
+    if len(ids) != n:        # (the same refusal as bind(): never a numpy broadcast error)
+      raise _lib.InvalidArgumentError(
+        _lib.INVALID_ARGUMENT, f'expected {n} id tensors, got {len(ids)}')
     if (n == 0 or block.dtype is not torch.float32 or not block.is_cuda or block.dim() != 2 or
         block.stride(1) != 1 or block.stride(0) % 4 != 0):
       return False
@@ -357,6 +360,8 @@ class GroupLookupGrad:
     gradients are column blocks of one tensor (DenseFeatures), addressed by arithmetic.  False:
     the general path's checks are needed."""
     n = len(self.lookup)
+    if len(ids) != n or len(row_splits) != n or (block is None and len(grads) != n):
+      return False           # (the general path raises InvalidArgumentError with the counts)
     seen = _marshal.vector_pass(ids, (torch.int32, torch.int64))
     if seen is None:
       return False
@@ -381,7 +386,8 @@ class GroupLookupGrad:
     if block is not None:
       g, offsets = block
       if (g.dtype is not torch.float32 or not g.is_cuda or g.dim() != 2 or g.stride(1) != 1 or
-          g.stride(0) % 4 != 0 or any(k != g.shape[0] for k in n_seg)):
+          g.stride(0) % 4 != 0 or any(k != g.shape[0] for k in n_seg) or len(offsets) != n or
+          any(offsets[c] < 0 or offsets[c] + dims[c] > g.shape[1] for c in range(n))):
         return False
       base, stride = g.data_ptr(), g.stride(0)
       g_ptrs = [base + 4 * o for o in offsets]

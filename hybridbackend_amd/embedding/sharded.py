@@ -417,8 +417,12 @@ class ShardedGroupLookup:
     res = []
     shapes = getattr(self, '_last_shapes', None)
     auto = bool(self._auto_hot) and outs is None
-    if auto and getattr(self, '_nu_all', None) is None:
-      self._nu_all = torch.zeros(n, dtype=torch.int32, device=self.device)
+    # the counts of THIS call: one fresh tensor per call with emitted slices (IndexedSlices kept from
+    # step k must not have their counts overwritten by step k + 1: ADVICE r04); step-only calls
+    # write into one buffer of the driver (nothing is handed out that could be kept)
+    nu_call = None
+    if outs is None and emit:
+      nu_call = torch.zeros(n, dtype=torch.int32, device=self.device)
     owned = []
     for c in range(n):
       _lib.require_device_tensor(grads[c], 'grads', row_strided=True)
@@ -443,12 +447,11 @@ class ShardedGroupLookup:
         # the counts live in one buffer of the driver, written by every call
         if getattr(self, '_nu_step', None) is None:
           self._nu_step = torch.zeros(n, dtype=torch.int32, device=self.device)
-        res.append((None, None, (self._nu_all if auto else self._nu_step)[c:c + 1]))
+        res.append((None, None, self._nu_step[c:c + 1]))
         continue
       res.append((torch.empty(k, dtype=torch.int64, device=self.device),
                   torch.empty((k, self.dims[c]), dtype=torch.float32, device=self.device),
-                  self._nu_all[c:c + 1] if auto else
-                  torch.zeros(1, dtype=torch.int32, device=self.device)))
+                  nu_call[c:c + 1]))
     self._keep_bwd = (grads, res)
     strides = (C.c_int32 * n)(*[0 if g.is_contiguous() else int(g.stride(0)) for g in grads])
     if optimizer == 'adagrad' and apply_lr != 0.0 and self.accums is None:
@@ -465,7 +468,7 @@ class ShardedGroupLookup:
       if st is None:
         st = self._auto_state = [torch.empty(n, dtype=torch.int32).pin_memory(),
                                  torch.cuda.Event(), None, False]
-      st[0].copy_(self._nu_all, non_blocking=True)
+      st[0].copy_(nu_call if nu_call is not None else self._nu_step, non_blocking=True)
       st[1].record()
       st[2], st[3] = owned, True
     return res

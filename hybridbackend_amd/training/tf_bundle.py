@@ -668,17 +668,24 @@ class BundleWriter:
     return self.prefix
 
 
-def read_reference_table(reader, name, layout='logical'):
+def read_reference_table(reader, name, layout='logical', world=None):
   """An embedding table saved by the reference as ``W`` row slices (``embedding/variables.py:
   114-141``): ``layout='reference'`` = what TF calls the full tensor (the slices back to back);
   ``'logical'`` = the table by id -- slice ``r`` (in offset order) holds the rows ``r, r + W, ..``
-  because the owner of an id is ``id mod W`` (``sharding.py:182,189``; see training/saver.py)."""
+  because the owner of an id is ``id mod W`` (``sharding.py:182,189``; see training/saver.py).
+  ``world``: the world size the checkpoint was written at.  Default: the number of slices -- right
+  for the plain variables of the reference; a checkpoint whose tables were ALSO partitioned
+  (``variables.py:131-140``: W x P slices per table) must pass it, the slice count cannot tell the
+  two apart -- such tables are refused here rather than de-interleaved wrongly."""
   parts = reader.slices(name)
   if layout == 'reference' or len(parts) <= 1:
     return reader.read(name)
   if layout != 'logical':
     raise ValueError("layout must be 'logical' or 'reference'")
   dt, shape = reader.dtype_and_shape(name)
+  if world is not None and int(world) != len(parts):
+    raise ValueError(f'{name}: {len(parts)} slices for a world of {world}: a partitioned variable '
+                     f'(W x P slices, variables.py:131-140) is not supported')
   world = len(parts)
   if any(any(ln >= 0 for _, ln in ext[1:]) for ext, _ in parts):
     raise ValueError(f'{name}: sliced along more than the rows: not a row-sharded table')

@@ -81,6 +81,49 @@ for st in $STAGES; do
       unset HBK_BENCH_ITERS
       for f in pmc_rs_tcc pmc_rs_sq; do echo "== $f"; tail -1 $O/$f.log; pmc_table $O/$f.json bwd_; trim $f; done
       trim prof_ragged;;
+    evidence)   # the round's evidence run: bench lines, kernel stats, traffic, C-ABI ops, config-5 shape x 3 processes
+      timeout 600 python bench.py --steps 50 --warmup 10 > $O/ev_bench50.log 2>&1; grep "^{" $O/ev_bench50.log | tail -1 > $O/ev_bench_lines.jsonl
+      timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $O/ev_bench20.log 2>&1; grep "^{" $O/ev_bench20.log | tail -1 >> $O/ev_bench_lines.jsonl
+      timeout 600 python bench.py --sharded --steps 50 --warmup 10 --cpu-seconds 0 > $O/ev_bench_sh.log 2>&1; grep "^{" $O/ev_bench_sh.log | tail -1 >> $O/ev_bench_lines.jsonl
+      cut -c1-400 $O/ev_bench_lines.jsonl
+      prof ev_prof_bench "" -- python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0
+      grep -E "group_lookup|kernel  " $O/ev_prof_bench.txt | cut -c1-150 | head -5
+      timeout 900 python tools/hbm_traffic.py r05 $O/hbm_traffic.json > $O/ev_traffic.log 2>&1; tail -3 $O/ev_traffic.log; cat $O/hbm_traffic.json | head -30
+      timeout 600 tools/bin/bench_ops > $O/ev_bench_ops.txt 2>&1; (for w in R r d; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk "; done) >> $O/ev_bench_ops.txt; cut -c1-170 $O/ev_bench_ops.txt
+      for i in 1 2 3; do timeout 600 python tools/sweep.py --cases h 2>/dev/null | grep "^{" > $O/ev_sweep_h_$i.jsonl; done
+      HBK_BWD_PAIRS_PACKED=0 HBK_BWD_SEG_INLINE=0 HBK_BWD_SCALE_FUSED=0 timeout 600 python tools/sweep.py --cases h 2>/dev/null | grep "^{" > $O/ev_sweep_h_old.jsonl
+      for f in $O/ev_sweep_h_1.jsonl $O/ev_sweep_h_2.jsonl $O/ev_sweep_h_3.jsonl $O/ev_sweep_h_old.jsonl; do echo "== $f"; python -c "
+import sys,json
+for l in open('$f'):
+  d=json.loads(l); print('  ',d['case'][:70].ljust(70), d['us'])"; done
+      timeout 900 python tools/sweep.py --big --cases b,c,d 2>/dev/null | grep "^{" > $O/ev_sweep_bcd.jsonl; python -c "
+import json
+for l in open('$O/ev_sweep_bcd.jsonl'):
+  d=json.loads(l)
+  if 'case' in d: print('  ',d['case'][:90].ljust(90), d['us'])";;
+    rscounters) # memory-side counters of the ragged backward's kernels (two short passes)
+      export HBK_BENCH_ITERS=2
+      prof pmc_rs_tcc_a "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/bench_ops R
+      prof pmc_rs_tcc_b "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" -- $R/tools/bin/bench_ops R
+      unset HBK_BENCH_ITERS
+      for f in pmc_rs_tcc_a pmc_rs_tcc_b; do echo "== $f"; tail -1 $O/$f.log; pmc_table $O/$f.json bwd_; trim $f; done;;
+    wab)        # walk width of the row-sorted job without an optimizer step (W0 = 12 spills 2 VGPRs; 10 / 11 do not)
+      (for rep in 1 2; do for v in shipped v_w11 v_w10; do
+         if [ $v = shipped ]; then L=$R/hybridbackend_amd/lib; else L=$R/tools/bin/$v; fi
+         for w in R b d; do LD_LIBRARY_PATH=$L timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s|^|$v  |"; done
+       done; done) > $O/wab.log 2>&1; cut -c1-180 $O/wab.log
+      export HBK_BENCH_ITERS=2
+      LD_LIBRARY_PATH=$R/tools/bin/v_w11 prof pmc_rs_w11 "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/bench_ops R
+      unset HBK_BENCH_ITERS
+      tail -1 $O/pmc_rs_w11.log; pmc_table $O/pmc_rs_w11.json bwd_rowsort; trim pmc_rs_w11;;
+    wab2)       # walk widths with the optimizer step: W1 (SGD) 6 -> 5, W2 (Adagrad) 4 -> 3 stop the VGPR spills
+      (for rep in 1 2; do for v in v_w11 v_a v_b v_c; do
+         for w in s r; do LD_LIBRARY_PATH=$R/tools/bin/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s|^|$v  |"; done
+       done; done) > $O/wab2.log 2>&1; cut -c1-180 $O/wab2.log
+      for v in v_w11 v_c v_w11 v_c; do echo "== cfg5 shape, $v"; HBK_LIBRARY=$R/tools/bin/$v/libhbk_core.so timeout 600 python tools/sweep.py --cases h 2>/dev/null | grep "^{" | python -c "
+import sys,json
+for l in sys.stdin:
+  d=json.loads(l); print('  ',d['case'][:70].ljust(70), d['us'])"; done 2>&1 | tee $O/wab2_cfg5.log;;
     p2pprof)    # kernel times of the sharded step at one rank: exchange form (inline) and p2p form
       prof prof_p2p "" -- python $R/bench.py --sharded --steps 30 --warmup 5 --cpu-seconds 0 --no-secondary --tune-steps 0 --p2p off
       grep -E "hbk|kernel  " $O/prof_p2p.txt | cut -c1-150 | head -16

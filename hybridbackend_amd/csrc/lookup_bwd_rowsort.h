@@ -75,7 +75,9 @@ __device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t
 #define HBK_RS_ROWS_FROM_ROFF 1
 #endif
 #ifndef HBK_RS_W0
-#define HBK_RS_W0 12   // (8: ragged dim 16 675 us, 12: 616 us; 16 spills)
+#define HBK_RS_W0 11   // (8: ragged dim 16 675 us, 12: 616 us; 16 spills.  Round 5: 12 spilled 2 VGPRs into the
+                       // walk -- 11 does not: ragged 561-563 -> 523-539 us in-box, 10: 547-551; with the step
+                       // W1 = 5 / W2 = 3 also stop their spills but measure the same as 6 / 4: kept)
 #endif
 #ifndef HBK_RS_W1
 #define HBK_RS_W1 6

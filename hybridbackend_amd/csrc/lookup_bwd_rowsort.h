@@ -529,7 +529,11 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   // the row numbers, sorted.  One chunk: the chunk's row index IS the output rank, and roff[] holds
   // every row's offset: consecutive lanes write consecutive entries (whole lines per store
   // instruction).  Several chunks: straight from the job's bitmap.
+#ifdef HBK_RS_NO_ROWNUM   // probe builds: what the row-number stores cost (results are then wrong)
+  if (false) {
+#else
   if (emit && one_chunk && HBK_RS_ROWS_FROM_ROFF) {
+#endif
     for (int u = tid; u < n_rows_job; u += kBlock) {
       job.out_rows[base_u + u] = (int64_t)base + (int64_t)L.roff[u];
     }

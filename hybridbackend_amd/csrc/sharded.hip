@@ -564,6 +564,12 @@ struct hbk_sharded {
   // stores every row straight into its place in the requester's output: no reply buffer, no rows
   // exchange, no stitch -- one random-row pass instead of two, and the rows cross the link as the
   // gather's own stores.
+  // the forward in two halves (hbk_sharded_lookup_fwd_begin / _end): what the second half needs
+  bool fwd_open = false;    // _begin has run, _end has not
+  bool fin_wire = false, fin_hop = false, fin_p2p = false;
+  int fin_use = 0;          // the PartSet of the open step
+  std::chrono::steady_clock::time_point fin_t0;
+  float fin_us[2] = {0.f, 0.f};
   bool p2p_opt = false;     // option sharded_p2p, read at creation
   bool p2p_bound = false;
   std::vector<float*> p2p_outs;         // [N] this rank's registered outputs
@@ -1019,14 +1025,22 @@ extern "C" int hbk_sharded_p2p_unbind(hbk_sharded_t p) {
   return HBK_OK;
 }
 
-extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids,
-                                      const int64_t* n_ids,
-                                      const int32_t* const* row_splits,
-                                      const int64_t* n_segments, float* const* outs,
-                                      const int32_t* out_strides, hbk_stream_t stream_) {
+// The forward in two halves.  _begin: everything up to and including the owner-side gather (partition
+// or its prefetched result, the step's one host wait, id exchange, gather into the reply buffer --
+// in the p2p form into the requesters' outputs, with the token exchange).  _end: rows exchange +
+// stitch + combiner into `outs`.  hbk_sharded_lookup_fwd = _begin + _end.  Two plans that share
+// a communicator and alternate  begin(B, step i + 1); end(A, step i)  put ids(i + 1) on the wire AHEAD
+// of rows(i): plan B gathers while plan A's rows travel, plan A stitches while plan B's travel --
+// the overlap of exchanges with the local gather across STEPS (forward-only use: nothing may change
+// the tables between a step's _begin and its _end).
+extern "C" int hbk_sharded_lookup_fwd_begin(hbk_sharded_t p, const int64_t* const* ids,
+                                            const int64_t* n_ids,
+                                            const int32_t* const* row_splits,
+                                            const int64_t* n_segments, hbk_stream_t stream_) {
   using namespace hbk;
   HBK_REQUIRE(p != nullptr, "sharded_lookup_fwd: plan is NULL");
-  HBK_REQUIRE(ids && n_ids && outs, "sharded_lookup_fwd: NULL argument array");
+  HBK_REQUIRE(ids && n_ids, "sharded_lookup_fwd: NULL argument array");
+  p->fwd_open = false;
   hipStream_t stream = as_stream(stream_);
   const int N = p->N, W = p->W;
   p->n_ids.assign(n_ids, n_ids + N);
@@ -1119,12 +1133,6 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
       HBK_REQUIRE(p->row_splits[c] == nullptr,
                   "sharded_lookup_fwd: column %d is ragged: a plan with registered outputs "
                   "(hbk_sharded_p2p_bind) takes one id per segment; unbind it first", c);
-      HBK_REQUIRE(outs[c] == p->p2p_outs[c] &&
-                      (out_strides == nullptr || out_strides[c] == 0 ||
-                       out_strides[c] == p->p2p_strides[c] ||
-                       (out_strides[c] == p->cols[c].dim && p->p2p_strides[c] == p->cols[c].dim)),
-                  "sharded_lookup_fwd: column %d: not the output registered with "
-                  "hbk_sharded_p2p_bind", c);
     }
   }
   std::vector<Group>& groups = p->groups;
@@ -1393,8 +1401,56 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
                     p->ev[2][g], p->ev[2][1], nullptr, 0, zc);
       if (rc != HBK_OK) return rc;
       if (hop) HBK_HIP_OK(hipStreamWaitEvent(stream, p->ev[2][1], 0));
-      continue;
     }
+  }
+  // the second half (rows exchange, stitch + combiner) is hbk_sharded_lookup_fwd_end
+  p->fin_wire = wire;
+  p->fin_hop = hop;
+  p->fin_p2p = p2p;
+  p->fin_use = use;
+  p->fin_t0 = t_begin;
+  p->fin_us[0] = (float)t_enq1;
+  p->fin_us[1] = (float)(t_sync - t_enq1);
+  p->fwd_open = true;
+  if (trace) {
+    fprintf(stderr, "hbk_sharded_lookup_fwd_begin host us: enqueue partition+sizes %.1f, sync wait "
+                    "%.1f, enqueue through the gather %.1f (G = %d, W = %d%s%s)\n",
+            t_enq1, t_sync - t_enq1, us_since(t_begin) - t_sync, G, W,
+            prefetched ? ", partition prefetched" : "", p2p ? ", p2p" : "");
+  }
+  return HBK_OK;
+}
+
+extern "C" int hbk_sharded_lookup_fwd_end(hbk_sharded_t p, float* const* outs,
+                                          const int32_t* out_strides, hbk_stream_t stream_) {
+  using namespace hbk;
+  HBK_REQUIRE(p != nullptr && outs != nullptr, "sharded_lookup_fwd_end: NULL argument");
+  HBK_REQUIRE(p->fwd_open, "sharded_lookup_fwd_end: no step is open (hbk_sharded_lookup_fwd_begin)");
+  p->fwd_open = false;
+  hipStream_t stream = as_stream(stream_);
+  const int N = p->N, W = p->W;
+  const bool wire = p->fin_wire, hop = p->fin_hop, p2p = p->fin_p2p;
+  const bool half = p->fused_half, zc = p->zero_copy_self;
+  const std::vector<Group>& groups = p->groups;
+  const int G = (int)groups.size();
+  hbk_sharded::PartSet& set = p->ps[p->fin_use];
+  const std::vector<int64_t>& n_ids = p->n_ids;
+  float* const rows_send_base = p->send_rows_p;
+  float* const rows_recv_base = p->recv_rows_p;
+  int rc;
+  if (p2p) {
+    for (int c = 0; c < N; ++c) {
+      HBK_REQUIRE(outs[c] == p->p2p_outs[c] &&
+                      (out_strides == nullptr || out_strides[c] == 0 ||
+                       out_strides[c] == p->p2p_strides[c] ||
+                       (out_strides[c] == p->cols[c].dim && p->p2p_strides[c] == p->cols[c].dim)),
+                  "sharded_lookup_fwd: column %d: not the output registered with "
+                  "hbk_sharded_p2p_bind", c);
+    }
+  }
+  // the rows of group g go on the wire (its gather has recorded ev[2][g])
+  for (int g = 0; g < G && wire && !p2p; ++g) {
+    const Group& gr = groups[g];
     if (half) {
       rc = exchange(p, HBK_HALF, HBK_HALF, reinterpret_cast<uint16_t*>(rows_send_base) + gr.row_send,
                     gr.lay.rows_send_peer.data(),
@@ -1410,6 +1466,14 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
   }
   // stage D: stitch + combiner of group g when its rows are in; the received rows stay
   // peer-major, column c is a W-run segmented table over them
+  std::vector<int32_t*> idx((size_t)N);
+  {
+    int64_t off = 0;
+    for (int c = 0; c < N; ++c) {
+      idx[c] = reinterpret_cast<int32_t*>(set.shard_index.ptr) + off;
+      off += n_ids[c];
+    }
+  }
   const int64_t* d_start = reinterpret_cast<const int64_t*>(p->runs_dev.ptr);
   const int64_t* d_base = d_start + (size_t)N * W;
   for (int g = 0; g < G && !p2p; ++g) {
@@ -1444,16 +1508,24 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
     if (rc != HBK_OK) return rc;
   }
   p->have_step = true;
-  p->host_us[0] = (float)t_enq1;
-  p->host_us[1] = (float)(t_sync - t_enq1);
-  p->host_us[2] = (float)(us_since(t_begin) - t_sync);
-  if (trace) {
-    fprintf(stderr, "hbk_sharded_lookup_fwd host us: enqueue partition+sizes %.1f, sync wait %.1f, "
-                    "enqueue rest %.1f (G = %d, W = %d%s)\n",
-            t_enq1, t_sync - t_enq1, us_since(t_begin) - t_sync, G, W,
-            prefetched ? ", partition prefetched" : "");
-  }
+  const double total = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() -
+                                                                p->fin_t0).count();
+  p->host_us[0] = p->fin_us[0];
+  p->host_us[1] = p->fin_us[1];
+  p->host_us[2] = (float)(total - p->fin_us[0] - p->fin_us[1]);
   return HBK_OK;
+}
+
+extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids,
+                                      const int64_t* n_ids,
+                                      const int32_t* const* row_splits,
+                                      const int64_t* n_segments, float* const* outs,
+                                      const int32_t* out_strides, hbk_stream_t stream_) {
+  using namespace hbk;
+  HBK_REQUIRE(outs != nullptr, "sharded_lookup_fwd: NULL argument array");
+  const int rc = hbk_sharded_lookup_fwd_begin(p, ids, n_ids, row_splits, n_segments, stream_);
+  if (rc != HBK_OK) return rc;
+  return hbk_sharded_lookup_fwd_end(p, outs, out_strides, stream_);
 }
 
 // Partition (stages 1-2) of a FUTURE step on the plan's own stream, so that it overlaps whatever

@@ -5,6 +5,7 @@ from hybridbackend_amd.embedding.hierarchical import HierarchicalGroupLookup
 from hybridbackend_amd.embedding.lookup import GroupLookup
 from hybridbackend_amd.embedding.lookup import GroupLookupGrad
 from hybridbackend_amd.embedding.lookup import group_lookup
+from hybridbackend_amd.embedding.sharded import PipelinedLookup
 from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
 from hybridbackend_amd.embedding.unique import UniqueN
 from hybridbackend_amd.embedding.unique import unique

@@ -311,6 +311,23 @@ class ShardedGroupLookup:
       self._plan(), *bound.args, _lib.current_stream(self.device)))
     return bound.outs
 
+  def launch_begin(self, bound):
+    """First half of a bound step (``hbk_sharded_lookup_fwd_begin``): partition (or its prefetched
+    result), the one host wait, id exchange, owner-side gather.  ``launch_end`` finishes it."""
+    self._keep = bound.keep
+    self._last_shapes = bound.shapes
+    a = bound.args
+    _lib.check(self._lib.hbk_sharded_lookup_fwd_begin(
+      self._plan(), a[0], a[1], a[2], a[3], _lib.current_stream(self.device)))
+
+  def launch_end(self, bound):
+    """Second half (``hbk_sharded_lookup_fwd_end``): rows exchange, stitch + combiner; returns the
+    step's outputs."""
+    a = bound.args
+    _lib.check(self._lib.hbk_sharded_lookup_fwd_end(
+      self._plan(), a[4], a[5], _lib.current_stream(self.device)))
+    return bound.outs
+
   def prefetch(self, bound, ids_ready=None):
     """Pipelining hint: run bucketize + partition + size exchange of a FUTURE step on the plan's
     own stream now, overlapping the exchanges of the step that was just launched; the next
@@ -472,3 +489,73 @@ class ShardedGroupLookup:
       st[1].record()
       st[2], st[3] = owned, True
     return res
+
+
+class PipelinedLookup:
+  """Exchanges overlapped with the local gather ACROSS STEPS (round 5; north_star's "overlapped with
+  local gather on a second HIP stream", the reference's mechanism is hbtf/common/stream.cc:83-142).
+
+  Two (or more) :class:`ShardedGroupLookup` plans over the SAME tables and the SAME communicator,
+  each on its own compute stream.  ``step(bound_next)`` begins the next step on the idle plan
+  (partition result, id exchange, owner gather: ``launch_begin``) and only then ends the step begun
+  before (rows exchange, stitch: ``launch_end``), so on the communicator the ids of step i + 1 travel
+  AHEAD of the rows of step i: plan B gathers while plan A's rows are on the wire, plan A stitches
+  while plan B's are.  A step costs ~max(wire, kernels) instead of their sum
+  (profiles/r05_overlap_model.txt).  Forward-only use (inference, or a lookup that runs ahead of the
+  trainer): nothing may update the tables between a step's begin and its end.  Every rank makes the
+  same calls in the same order.
+
+  ``plans``: the ShardedGroupLookup objects (option ``sharded_inline`` = 0 when they were created,
+  so that their exchanges run on the communicator's stream).  ``bind(k, ids, row_splits, outs)``
+  marshals a step for plan ``k``; ``step(bound)`` takes the bound steps of plans 0, 1, 0, 1 ...
+  """
+
+  def __init__(self, plans):
+    if len(plans) < 2:
+      raise ValueError('PipelinedLookup needs at least two plans')
+    self.plans = list(plans)
+    self.streams = [torch.cuda.Stream(device=p.device) for p in self.plans]
+    self._open = None      # (plan index, bound step) begun and not ended
+    self._next = 0
+    self._done = [torch.cuda.Event() for _ in self.plans]
+
+  def bind(self, k, ids, row_splits=None, outs=None):
+    return self.plans[k].bind(ids, row_splits, outs)
+
+  def next_plan(self):
+    """Index of the plan the next ``step`` uses (its bound steps must come from that plan)."""
+    return self._next
+
+  def step(self, bound, prefetch=None):
+    """Begin ``bound`` on the next plan, end the step begun by the previous call.  Returns the
+    outputs of THAT step (None the first time); the current stream waits for them.  ``prefetch``:
+    the bound step this plan will be handed next (its partition runs ahead)."""
+    k = self._next
+    self._next = (k + 1) % len(self.plans)
+    with torch.cuda.stream(self.streams[k]):
+      self.plans[k].launch_begin(bound)
+    finished = self._finish()
+    self._open = (k, bound, prefetch)
+    return finished
+
+  def _finish(self):
+    if self._open is None:
+      return None
+    k, bound, prefetch = self._open
+    self._open = None
+    with torch.cuda.stream(self.streams[k]):
+      outs = self.plans[k].launch_end(bound)
+      if prefetch is not None:
+        self.plans[k].prefetch(prefetch)
+      self._done[k].record()
+    torch.cuda.current_stream().wait_event(self._done[k])
+    return outs
+
+  def flush(self):
+    """End the step that is still open; returns its outputs."""
+    return self._finish()
+
+  def close(self):
+    self.flush()
+    for p in self.plans:
+      p.close()

@@ -544,6 +544,20 @@ int hbk_sharded_destroy(hbk_sharded_t plan);
 int hbk_sharded_lookup_fwd(hbk_sharded_t plan, const int64_t* const* ids, const int64_t* n_ids,
                            const int32_t* const* row_splits, const int64_t* n_segments,
                            float* const* outs, const int32_t* out_strides, hbk_stream_t stream);
+/* The forward in two halves (round 5).  _begin: everything up to and including the owner-side
+ * gather (the partition or its prefetched result, the step's one host wait, the id exchange, the
+ * gather into the reply buffer -- in the p2p form into the requesters' outputs).  _end: rows
+ * exchange + stitch + combiner into `outs`.  hbk_sharded_lookup_fwd = _begin + _end.  Two plans
+ * over ONE communicator that alternate  begin(B, step i + 1); end(A, step i)  put the ids of step
+ * i + 1 on the wire AHEAD of the rows of step i: B gathers while A's rows travel, A stitches while
+ * B's travel -- exchanges overlapped with the local gather across steps (hb.embedding.
+ * PipelinedLookup).  Forward-only use: nothing may change the tables between a step's _begin and
+ * its _end; every rank makes the same calls in the same order. */
+int hbk_sharded_lookup_fwd_begin(hbk_sharded_t plan, const int64_t* const* ids,
+                                 const int64_t* n_ids, const int32_t* const* row_splits,
+                                 const int64_t* n_segments, hbk_stream_t stream);
+int hbk_sharded_lookup_fwd_end(hbk_sharded_t plan, float* const* outs, const int32_t* out_strides,
+                               hbk_stream_t stream);
 /* Optional pipelining hint: partition + size exchange (stages 1-2) of a FUTURE step on the plan's
  * own stream, overlapping what the last forward still has in flight (its exchanges, gather and
  * stitch).  The next hbk_sharded_lookup_fwd with the same id pointers and counts uses it and

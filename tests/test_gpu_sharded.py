@@ -439,6 +439,92 @@ def test_cxx_driver_p2p_form_in_process_world(hbk_option, world, inline, id64, p
     cm.close()
 
 
+@pytest.mark.parametrize('world,inline,p2p', [(1, 0, False), (2, 0, False), (4, 1, False),
+                                              (4, 0, True), (8, 0, False)])
+def test_pipelined_lookup_two_plans_in_process_world(hbk_option, world, inline, p2p):
+  """hb.embedding.PipelinedLookup (round 5): two plans over the same shards and the same
+  communicator, begin(step i + 1) enqueued before end(step i) (hbk_sharded_lookup_fwd_begin /
+  _end), each plan on its own compute stream -- the ids of step i + 1 travel ahead of the rows of
+  step i.  Every step's outputs equal the unsharded oracle, ragged and scalar columns, W ranks as
+  host threads; also with the p2p form (scalar columns) and with inline exchanges."""
+  import threading
+  hbk_option('sharded_inline', inline)
+  hbk_option('sharded_groups', 1)
+  rng = np.random.RandomState(1200 + world)
+  dims = [16, 8, 128, 4]
+  rows = [50021, 211, 3000, 64]
+  combiners = ['sum'] * 4 if p2p else ['sum', 'mean', 'sqrtn', 'sum']
+  n = len(dims)
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(n)]
+  steps = 5
+  ids, splits = [], []
+  for st in range(steps):
+    sids, ssp = [], []
+    for r in range(world):
+      rid, rsp = [], []
+      for c in range(n):
+        if c % 2 == 0 or p2p:
+          sp, k = None, 1200
+        else:
+          lens = rng.poisson(3, size=300).clip(0, 12)
+          sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+          k = int(sp[-1])
+        rsp.append(sp)
+        rid.append(rng.randint(0, 2**40, size=k).astype(np.int64))
+      sids.append(rid)
+      ssp.append(rsp)
+    ids.append(sids)
+    splits.append(ssp)
+  comms = hb.distribute.Collective.local_world(world)
+  shards = [[dev(t[r::world].copy()) for t in tables] for r in range(world)]
+  results, errors = [None] * world, []
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        plans = [ShardedGroupLookup(shards[r], comms[r], buckets=rows, combiners=combiners)
+                 for _ in range(2)]
+        pipe = hb.embedding.PipelinedLookup(plans)
+        outs = [[torch.full((1200 if (c % 2 == 0 or p2p) else 300, dims[c]), float('nan'), device=DEV)
+                 for c in range(n)] for _ in range(2)]
+        if p2p:
+          for k in range(2):
+            with torch.cuda.stream(pipe.streams[k]):
+              assert plans[k].p2p_bind(outs[k]) is True
+        got = []
+        for st in range(steps):
+          k = pipe.next_plan()
+          b = pipe.bind(k, [dev(i) for i in ids[st][r]],
+                        [None if s is None else dev(s) for s in splits[st][r]], outs[k])
+          done = pipe.step(b)
+          if done is not None:
+            torch.cuda.current_stream().synchronize()
+            got.append([o.cpu().numpy().copy() for o in done])
+        done = pipe.flush()
+        torch.cuda.current_stream().synchronize()
+        got.append([o.cpu().numpy().copy() for o in done])
+        results[r] = got
+        pipe.close()
+    except Exception:  # pylint: disable=broad-except
+      import traceback
+      errors.append((r, traceback.format_exc()))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=90)
+  assert not errors, errors
+  assert all(x is not None and len(x) == steps for x in results)
+  for st in range(steps):
+    for r in range(world):
+      want = oracle.group_lookup_fwd(tables, ids[st][r], splits[st][r], rows, combiners)
+      for c in range(n):
+        np.testing.assert_equal(results[r][st][c], want[c], err_msg=f'step {st} rank {r} column {c}')
+  for cm in comms:
+    cm.close()
+
+
 def test_sharded_p2p_through_rccl_world1_and_refusals(hbk_option):
   """The p2p form over a real RCCL communicator of one rank (the own slice stays in place: the owner
   gather reads the ids and slots where the pack left them), both step forms; what the form does

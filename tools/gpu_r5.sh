@@ -124,6 +124,14 @@ for l in open('$O/ev_sweep_bcd.jsonl'):
 import sys,json
 for l in sys.stdin:
   d=json.loads(l); print('  ',d['case'][:70].ljust(70), d['us'])"; done 2>&1 | tee $O/wab2_cfg5.log;;
+    wrprobe)    # which store stream of the row-sorted job makes 15.2 M write requests where 11.9 M are expected?
+      export HBK_BENCH_ITERS=2
+      for v in v_norownum v_plainrows; do
+        LD_LIBRARY_PATH=$R/tools/bin/$v prof pmc_$v "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/bench_ops R
+        echo "== $v"; tail -1 $O/pmc_$v.log; pmc_table $O/pmc_$v.json bwd_rowsort_kernel; trim pmc_$v
+      done
+      unset HBK_BENCH_ITERS
+      for v in v_norownum v_plainrows; do LD_LIBRARY_PATH=$R/tools/bin/$v timeout 300 tools/bin/bench_ops R 2>&1 | grep group_lookup_bwd | sed "s|^|$v  |"; done;;
     p2pprof)    # kernel times of the sharded step at one rank: exchange form (inline) and p2p form
       prof prof_p2p "" -- python $R/bench.py --sharded --steps 30 --warmup 5 --cpu-seconds 0 --no-secondary --tune-steps 0 --p2p off
       grep -E "hbk|kernel  " $O/prof_p2p.txt | cut -c1-150 | head -16

@@ -12,10 +12,11 @@ seven links in parallel.  The forms of the step are timed under it:
   inline        exchanges enqueued on the compute stream (nothing overlaps)
   one_group     one column group, exchanges on the communicator's stream (two stream hops)
   pipelined_G   G column groups: gather(g) beside ids(g+1), stitch(g) beside rows(g+1)
-  two_steps     TWO plans on two compute streams share the communicator: step i + 1 computes while
-                step i's exchanges are on the wire (the wire itself stays serial: one communicator
-                stream); no dependency between consecutive forwards (inference, or a loader that
-                runs the lookup of the next batch ahead)
+  pipelined_steps  TWO plans on two compute streams share the communicator (hb.embedding.
+                PipelinedLookup): begin(step i + 1) -- ids out, owner gather -- is enqueued BEFORE
+                end(step i) -- rows back, stitch --, so ids(i + 1) are on the wire ahead of rows(i):
+                one plan gathers while the other's rows travel.  The wire itself stays serial (one
+                communicator stream).  Forward-only use (no table update between begin and end)
 
   python tools/overlap_model.py [--steps 40] > profiles/r05_overlap_model.txt
 """
@@ -87,34 +88,31 @@ def main():
       drv.close()
       comms[0].close()
     # two steps in flight: two plans (one column group each, exchanges on the communicator's
-    # stream), alternating between two compute streams
+    # stream) through hb.embedding.PipelinedLookup: begin(step i + 1) BEFORE end(step i), so the ids
+    # of step i + 1 are on the wire ahead of the rows of step i
     _lib.set_option('sharded_groups', 1)
     _lib.set_option('sharded_inline', 0)
     comms = hb.distribute.Collective.local_world(1)
     assert tlib.hbk_testing_set_wire(comms[0]._world, gbps, 3.0, 1.0 / a.links, 1) == 0
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    drvs = [hb.embedding.ShardedGroupLookup(tables, comms[0], buckets=[a.rows] * a.columns,
+                                            combiners='sum') for _ in range(2)]
+    pipe = hb.embedding.PipelinedLookup(drvs)
     outs2 = [outs, [torch.empty_like(o) for o in outs]]
-    drvs, bounds = [], []
-    for k in range(2):
-      with torch.cuda.stream(streams[k]):
-        d = hb.embedding.ShardedGroupLookup(tables, comms[0], buckets=[a.rows] * a.columns,
-                                            combiners='sum')
-        drvs.append(d)
-        bounds.append([d.bind(batches[b], None, outs2[k]) for b in range(n_batches)])
+    bounds = [[pipe.bind(k, batches[b], None, outs2[k]) for b in range(n_batches)] for k in range(2)]
 
     def step2(i):
-      k = i % 2
-      with torch.cuda.stream(streams[k]):
-        drvs[k].launch(bounds[k][i % n_batches])
-        drvs[k].prefetch(bounds[k][(i + 2) % n_batches])
+      k = pipe.next_plan()
+      pipe.step(bounds[k][i % n_batches], prefetch=bounds[k][(i + 2) % n_batches])
     for i in range(6):
       step2(i)
+    pipe.flush()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
       step2(6 + i)
+    pipe.flush()
     torch.cuda.synchronize()
-    line['two_steps'] = round((time.perf_counter() - t0) / a.steps * 1e6, 1)
+    line['pipelined_steps'] = round((time.perf_counter() - t0) / a.steps * 1e6, 1)
     for d in drvs:
       d.close()
     comms[0].close()

@@ -534,19 +534,21 @@ class PipelinedLookup:
     self._next = (k + 1) % len(self.plans)
     with torch.cuda.stream(self.streams[k]):
       self.plans[k].launch_begin(bound)
+      if prefetch is not None:
+        # right behind the begin (the plan's partition state is double buffered): the partition of
+        # this plan's NEXT step has len(plans) steps to finish before its begin waits for the sizes
+        self.plans[k].prefetch(prefetch)
     finished = self._finish()
-    self._open = (k, bound, prefetch)
+    self._open = (k, bound)
     return finished
 
   def _finish(self):
     if self._open is None:
       return None
-    k, bound, prefetch = self._open
+    k, bound = self._open
     self._open = None
     with torch.cuda.stream(self.streams[k]):
       outs = self.plans[k].launch_end(bound)
-      if prefetch is not None:
-        self.plans[k].prefetch(prefetch)
       self._done[k].record()
     torch.cuda.current_stream().wait_event(self._done[k])
     return outs

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <vector>
@@ -27,8 +28,8 @@ struct LocalWorld {
   std::vector<std::vector<int64_t>> off; // [world][n] element offset of the chunk for peer k
   std::vector<std::vector<int64_t>> len; // [world][n] elements for peer k
   std::vector<hipEvent_t> ready, done;   // [world]
-  // artificial wire (hbk_testing_set_wire): every exchange is followed, on its stream, by a kernel
-  // that waits  latency + (largest message this rank receives from a PEER) x scale / rate  -- one
+  // artificial wire (hbk_testing_set_wire): every exchange is followed, on its stream, by a host
+  // function that waits  latency + (largest message this rank receives from a PEER) x scale / rate  -- one
   // link per peer pair, all links in parallel, as over xGMI.  With `count_self` the rank's own
   // chunk counts as a peer message (a world of ONE rank then models what the same step would put
   // on a link).  0 = off.
@@ -52,10 +53,16 @@ struct RankCtx {
   int rank;
 };
 
-// one wave that watches the constant 100 MHz clock: occupies a wave slot, no bandwidth
-__global__ void wire_delay_kernel(unsigned long long ticks) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+// The wire: a HOST function in stream order (hipLaunchHostFunc) that waits for the modelled time:
+// the stream the exchange runs on is held back, every other stream -- and the whole GPU -- goes on,
+// which is what a link transfer looks like to the chip.  (A first version spun ONE WAVE on the
+// device clock instead: with it no form of the step overlapped anything and more hardware queues
+// made every form erratic -- a spinning kernel is not a good stand-in for an idle link.)
+void wire_wait(void* us_bits) {
+  const double us = (double)(uintptr_t)us_bits / 16.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < us) {
+  }
 }
 
 #define LW_HIP(expr)                      \
@@ -97,11 +104,13 @@ int lw_exchange(void* ctx_, int32_t rank, const int32_t* ranks, int32_t n_ranks,
                             (size_t)n * esize, hipMemcpyDeviceToDevice, stream));
     }
   }
-  if (w->wire_bytes_per_us > 0.0 && largest > 0) {
+  // (control messages -- the size exchange, tokens: under 64 KB -- are not modelled: HIP runs the host
+  // functions of ALL streams on one thread, so a 3 us wait for the sizes would queue behind the
+  // rows' 270 us and hold the host, which waits for the sizes, for a whole wire time)
+  if (w->wire_bytes_per_us > 0.0 && (double)largest * (double)esize * w->wire_scale >= 65536.0) {
     const double us = w->wire_latency_us +
                       (double)largest * (double)esize * w->wire_scale / w->wire_bytes_per_us;
-    hipLaunchKernelGGL(wire_delay_kernel, dim3(1), dim3(64), 0, stream,
-                       (unsigned long long)(us * 100.0));
+    LW_HIP(hipLaunchHostFunc(stream, wire_wait, (void*)(uintptr_t)(us * 16.0)));
   }
   LW_HIP(hipEventRecord(w->done[me], stream));
   w->barrier();
@@ -224,6 +233,13 @@ extern "C" int hbk_testing_set_wire(void* world, double gb_per_s, double latency
   w->wire_latency_us = latency_us;
   w->wire_scale = scale;
   w->wire_count_self = count_self != 0;
+  return 0;
+}
+
+// the wire's wait alone, on `stream` (tools/scratch/overlap_micro.py: do other streams go on?)
+extern "C" int hbk_testing_wire_wait(hbk_stream_t stream, double us) {
+  LW_HIP(hipLaunchHostFunc(reinterpret_cast<hipStream_t>(stream), wire_wait,
+                           (void*)(uintptr_t)(us * 16.0)));
   return 0;
 }
 

@@ -92,30 +92,32 @@ def main():
     # of step i + 1 are on the wire ahead of the rows of step i
     _lib.set_option('sharded_groups', 1)
     _lib.set_option('sharded_inline', 0)
-    comms = hb.distribute.Collective.local_world(1)
-    assert tlib.hbk_testing_set_wire(comms[0]._world, gbps, 3.0, 1.0 / a.links, 1) == 0
-    drvs = [hb.embedding.ShardedGroupLookup(tables, comms[0], buckets=[a.rows] * a.columns,
-                                            combiners='sum') for _ in range(2)]
-    pipe = hb.embedding.PipelinedLookup(drvs)
-    outs2 = [outs, [torch.empty_like(o) for o in outs]]
-    bounds = [[pipe.bind(k, batches[b], None, outs2[k]) for b in range(n_batches)] for k in range(2)]
+    for depth in (2, 3):
+      comms = hb.distribute.Collective.local_world(1)
+      assert tlib.hbk_testing_set_wire(comms[0]._world, gbps, 3.0, 1.0 / a.links, 1) == 0
+      drvs = [hb.embedding.ShardedGroupLookup(tables, comms[0], buckets=[a.rows] * a.columns,
+                                              combiners='sum') for _ in range(depth)]
+      pipe = hb.embedding.PipelinedLookup(drvs)
+      outs2 = [outs] + [[torch.empty_like(o) for o in outs] for _ in range(depth - 1)]
+      bounds = [[pipe.bind(k, batches[b], None, outs2[k]) for b in range(n_batches)]
+                for k in range(depth)]
 
-    def step2(i):
-      k = pipe.next_plan()
-      pipe.step(bounds[k][i % n_batches], prefetch=bounds[k][(i + 2) % n_batches])
-    for i in range(6):
-      step2(i)
-    pipe.flush()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-      step2(6 + i)
-    pipe.flush()
-    torch.cuda.synchronize()
-    line['pipelined_steps'] = round((time.perf_counter() - t0) / a.steps * 1e6, 1)
-    for d in drvs:
-      d.close()
-    comms[0].close()
+      def step2(i):
+        k = pipe.next_plan()
+        pipe.step(bounds[k][i % n_batches], prefetch=bounds[k][(i + depth) % n_batches])
+      for i in range(6):
+        step2(i)
+      pipe.flush()
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for i in range(a.steps):
+        step2(6 + i)
+      pipe.flush()
+      torch.cuda.synchronize()
+      line[f'pipelined_steps_{depth}'] = round((time.perf_counter() - t0) / a.steps * 1e6, 1)
+      for d in drvs:
+        d.close()
+      comms[0].close()
     results[wire_name] = line
     best = min(line, key=line.get)
     print(f'{wire_name:<9} (exchanges of a step: {wire_us:6.1f} us on the wire)  ' +

@@ -101,6 +101,11 @@ import json
 for l in open('$O/ev_sweep_bcd.jsonl'):
   d=json.loads(l)
   if 'case' in d: print('  ',d['case'][:90].ljust(90), d['us'])";;
+    rsstats)    # kernel times of the ragged backward (final build)
+      export HBK_BENCH_ITERS=6
+      prof prof_ragged "" -- $R/tools/bin/bench_ops R
+      unset HBK_BENCH_ITERS
+      grep -E "bwd_|kernel  " $O/prof_ragged.txt | cut -c1-150 | head -14; trim prof_ragged;;
     rscounters) # memory-side counters of the ragged backward's kernels (two short passes)
       export HBK_BENCH_ITERS=2
       prof pmc_rs_tcc_a "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/bench_ops R

@@ -139,6 +139,7 @@ def _declare(l):
     'hbk_sharded_destroy': (C.c_int, [vp]),
     'hbk_sharded_set_hot_rows': (C.c_int, [vp, vp]),
     'hbk_sharded_lookup_fwd': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    'hbk_sharded_prefetch_on': (C.c_int, [vp, vp, vp, vp]),
     'hbk_sharded_lookup_fwd_begin': (C.c_int, [vp, vp, vp, vp, vp, vp]),
     'hbk_sharded_lookup_fwd_end': (C.c_int, [vp, vp, vp, vp]),
     'hbk_sharded_prefetch': (C.c_int, [vp, vp, vp, vp]),

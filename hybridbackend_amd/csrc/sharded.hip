@@ -638,8 +638,10 @@ extern "C" int hbk_sharded_create(hbk_sharded_t* plan, hbk_comm_t comm, int32_t 
       }
     }
   }
-  bool ok = hipStreamCreateWithFlags(&p->pre_stream, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&p->step_begin, hipEventDisableTiming) == hipSuccess;
+  // (the prefetch stream is created by the first hbk_sharded_prefetch: HIP deals its streams onto a
+  // few hardware queues -- 4 by default -- and a stream that is never used should not take a slot
+  // next to the compute and communicator streams, see hbk_sharded_prefetch_on)
+  bool ok = hipEventCreateWithFlags(&p->step_begin, hipEventDisableTiming) == hipSuccess;
   for (auto& set : p->ps) {
     ok = ok && hipEventCreateWithFlags(&set.done, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&set.ready, hipEventDisableTiming) == hipSuccess &&
@@ -1094,7 +1096,10 @@ extern "C" int hbk_sharded_lookup_fwd_begin(hbk_sharded_t p, const int64_t* cons
   // just read are not valid -- THIS step fails, before anything is sized from them
   // (the partition ran on the caller's stream or, prefetched, on the plan's own)
   if ((rc = sync_check("sharded_lookup_fwd", stream)) != HBK_OK) return rc;
-  if ((rc = sync_check("sharded_lookup_fwd", p->pre_stream)) != HBK_OK) return rc;
+  if (p->pre_stream != nullptr &&
+      (rc = sync_check("sharded_lookup_fwd", p->pre_stream)) != HBK_OK) {
+    return rc;
+  }
   if (prefetched) HBK_HIP_OK(hipStreamWaitEvent(stream, set.ready, 0));
   const double t_sync = us_since(t_begin);
   p->send_sizes.assign(set.host_sizes, set.host_sizes + (size_t)N * W);
@@ -1532,10 +1537,34 @@ extern "C" int hbk_sharded_lookup_fwd(hbk_sharded_t p, const int64_t* const* ids
 // the caller's stream still has in flight (the exchanges of the step just launched).  The next
 // hbk_sharded_lookup_fwd with the same id pointers and counts picks the result up; any other
 // forward drops it.  Every rank must prefetch the same steps (the size exchange is a collective).
+// The same on a stream of the CALLER's: no stream of the plan is involved, stream order is all the
+// protection the overwritten partition state needs -- the caller enqueues this behind the _end (or
+// the whole forward) of the step BEFORE the last one begun on this plan, which read that state.
+// hb.embedding.PipelinedLookup calls it right behind a step's _begin on the plan's compute stream:
+// the partition of the plan's next step then runs before the stream reaches the wait for the
+// current step's rows, and needs no stream of its own.  (HIP maps streams onto a few hardware
+// queues -- 4 by default; two streams on one queue run in order, waits included: a prefetch stream
+// that shares its queue with a compute stream sits behind that stream's wait for the wire.)
+extern "C" int hbk_sharded_prefetch_on(hbk_sharded_t p, const int64_t* const* ids,
+                                       const int64_t* n_ids, hbk_stream_t stream_) {
+  using namespace hbk;
+  HBK_REQUIRE(p != nullptr && ids && n_ids, "sharded_prefetch_on: NULL argument");
+  hbk_sharded::PartSet& set = p->ps[p->cur ^ 1];
+  p->ps[0].pending = p->ps[1].pending = false;
+  p->prefetch_used = true;
+  int rc = run_partition(p, set, ids, n_ids, as_stream(stream_));
+  if (rc != HBK_OK) return rc;
+  set.pending = true;
+  return HBK_OK;
+}
+
 extern "C" int hbk_sharded_prefetch(hbk_sharded_t p, const int64_t* const* ids,
                                     const int64_t* n_ids, void* ids_ready_event) {
   using namespace hbk;
   HBK_REQUIRE(p != nullptr && ids && n_ids, "sharded_prefetch: NULL argument");
+  if (p->pre_stream == nullptr) {
+    HBK_HIP_OK(hipStreamCreateWithFlags(&p->pre_stream, hipStreamNonBlocking));
+  }
   hbk_sharded::PartSet& set = p->ps[p->cur ^ 1];
   p->ps[0].pending = p->ps[1].pending = false;
   p->prefetch_used = true;

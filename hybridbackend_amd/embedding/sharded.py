@@ -311,6 +311,16 @@ class ShardedGroupLookup:
       self._plan(), *bound.args, _lib.current_stream(self.device)))
     return bound.outs
 
+  def prefetch_on_current_stream(self, bound):
+    """``prefetch`` without a stream of the plan's own (``hbk_sharded_prefetch_on``): the partition +
+    size exchange of ``bound`` are enqueued on the CURRENT stream; the caller puts this behind the
+    end of the step before the last one begun on this object (PipelinedLookup: right behind a
+    step's ``launch_begin``)."""
+    a = bound.args
+    _lib.check(self._lib.hbk_sharded_prefetch_on(self._plan(), a[0], a[1],
+                                                 _lib.current_stream(self.device)))
+    self._keep_prefetch = bound.keep
+
   def launch_begin(self, bound):
     """First half of a bound step (``hbk_sharded_lookup_fwd_begin``): partition (or its prefetched
     result), the one host wait, id exchange, owner-side gather.  ``launch_end`` finishes it."""
@@ -537,7 +547,7 @@ class PipelinedLookup:
       if prefetch is not None:
         # right behind the begin (the plan's partition state is double buffered): the partition of
         # this plan's NEXT step has len(plans) steps to finish before its begin waits for the sizes
-        self.plans[k].prefetch(prefetch)
+        self.plans[k].prefetch_on_current_stream(prefetch)
     finished = self._finish()
     self._open = (k, bound)
     return finished

@@ -566,6 +566,12 @@ int hbk_sharded_lookup_fwd_end(hbk_sharded_t plan, float* const* outs, const int
 int hbk_sharded_prefetch(hbk_sharded_t plan, const int64_t* const* ids, const int64_t* n_ids,
                          void* ids_ready_event /* hipEvent_t recorded after the ids were written,
                                                   or NULL when they are complete already */);
+/* The same on a stream of the caller's (round 5): no stream of the plan is involved; the caller
+ * enqueues it behind the end of the step BEFORE the last one begun on this plan (stream order is
+ * the only protection the overwritten partition state gets).  Used by hb.embedding.PipelinedLookup
+ * right behind a step's _begin. */
+int hbk_sharded_prefetch_on(hbk_sharded_t plan, const int64_t* const* ids, const int64_t* n_ids,
+                            hbk_stream_t stream);
 int64_t hbk_sharded_owned_ids(hbk_sharded_t plan, int32_t column);
 
 /* The p2p form of the forward (round 5).  hbk_sharded_p2p_bind registers this rank's N output

@@ -28,13 +28,18 @@ struct LocalWorld {
   std::vector<std::vector<int64_t>> off; // [world][n] element offset of the chunk for peer k
   std::vector<std::vector<int64_t>> len; // [world][n] elements for peer k
   std::vector<hipEvent_t> ready, done;   // [world]
-  // artificial wire (hbk_testing_set_wire): every exchange is followed, on its stream, by a host
+  // artificial wire (hbk_testing_set_wire): every exchange is held, on its stream, by a host
   // function that waits  latency + (largest message this rank receives from a PEER) x scale / rate  -- one
   // link per peer pair, all links in parallel, as over xGMI.  With `count_self` the rank's own
   // chunk counts as a peer message (a world of ONE rank then models what the same step would put
   // on a link).  0 = off.
   double wire_bytes_per_us = 0.0, wire_latency_us = 0.0, wire_scale = 1.0;
   bool wire_count_self = false;
+  // the wait runs BESIDE the copies of the exchange (a link transfer IS the copy, it does not follow
+  // it): per rank a side stream that carries only the host functions, and the two events that fork
+  // it off the exchange's stream and join it again.  exchange = max(copies, modelled time)
+  std::vector<hipStream_t> wire_stream;  // [world], created by hbk_testing_set_wire
+  std::vector<hipEvent_t> wire_fork, wire_join;
   void barrier() {
     std::unique_lock<std::mutex> lk(mu);
     const long gen = generation;
@@ -93,10 +98,26 @@ int lw_exchange(void* ctx_, int32_t rank, const int32_t* ranks, int32_t n_ranks,
   w->barrier();
   int64_t largest = 0;   // elements of the largest message this rank receives over a "link"
   for (int k = 0; k < n_ranks; ++k) {
+    const int64_t n = w->len[ranks[k]][k_me];
+    if ((ranks[k] != me || w->wire_count_self) && n > largest) largest = n;
+  }
+  // (control messages -- the size exchange, tokens: under 64 KB -- are not modelled: HIP runs the host
+  // functions of ALL streams on one thread, so a 3 us wait for the sizes would queue behind the
+  // rows' 270 us and hold the host, which waits for the sizes, for a whole wire time)
+  const bool wired = w->wire_bytes_per_us > 0.0 && !w->wire_stream.empty() &&
+                     (double)largest * (double)esize * w->wire_scale >= 65536.0;
+  for (int k = 0; k < n_ranks; ++k) LW_HIP(hipStreamWaitEvent(stream, w->ready[ranks[k]], 0));
+  if (wired) {
+    const double us = w->wire_latency_us +
+                      (double)largest * (double)esize * w->wire_scale / w->wire_bytes_per_us;
+    LW_HIP(hipEventRecord(w->wire_fork[me], stream));
+    LW_HIP(hipStreamWaitEvent(w->wire_stream[me], w->wire_fork[me], 0));
+    LW_HIP(hipLaunchHostFunc(w->wire_stream[me], wire_wait, (void*)(uintptr_t)(us * 16.0)));
+    LW_HIP(hipEventRecord(w->wire_join[me], w->wire_stream[me]));
+  }
+  for (int k = 0; k < n_ranks; ++k) {
     const int peer = ranks[k];
-    LW_HIP(hipStreamWaitEvent(stream, w->ready[peer], 0));
     const int64_t n = w->len[peer][k_me];
-    if ((peer != me || w->wire_count_self) && n > largest) largest = n;
     if (n > 0 && !(skip_self && peer == me)) {
       LW_HIP(hipMemcpyAsync(reinterpret_cast<char*>(recvbuf) + (size_t)recv_off[k] * esize,
                             reinterpret_cast<const char*>(w->ptr[peer]) +
@@ -104,14 +125,7 @@ int lw_exchange(void* ctx_, int32_t rank, const int32_t* ranks, int32_t n_ranks,
                             (size_t)n * esize, hipMemcpyDeviceToDevice, stream));
     }
   }
-  // (control messages -- the size exchange, tokens: under 64 KB -- are not modelled: HIP runs the host
-  // functions of ALL streams on one thread, so a 3 us wait for the sizes would queue behind the
-  // rows' 270 us and hold the host, which waits for the sizes, for a whole wire time)
-  if (w->wire_bytes_per_us > 0.0 && (double)largest * (double)esize * w->wire_scale >= 65536.0) {
-    const double us = w->wire_latency_us +
-                      (double)largest * (double)esize * w->wire_scale / w->wire_bytes_per_us;
-    LW_HIP(hipLaunchHostFunc(stream, wire_wait, (void*)(uintptr_t)(us * 16.0)));
-  }
+  if (wired) LW_HIP(hipStreamWaitEvent(stream, w->wire_join[me], 0));
   LW_HIP(hipEventRecord(w->done[me], stream));
   w->barrier();
   // nobody may reuse its send buffer before every peer has copied out of it
@@ -233,6 +247,16 @@ extern "C" int hbk_testing_set_wire(void* world, double gb_per_s, double latency
   w->wire_latency_us = latency_us;
   w->wire_scale = scale;
   w->wire_count_self = count_self != 0;
+  if (gb_per_s > 0.0 && w->wire_stream.empty()) {
+    w->wire_stream.resize(w->world);
+    w->wire_fork.resize(w->world);
+    w->wire_join.resize(w->world);
+    for (int i = 0; i < w->world; ++i) {
+      LW_HIP(hipStreamCreateWithFlags(&w->wire_stream[i], hipStreamNonBlocking));
+      LW_HIP(hipEventCreateWithFlags(&w->wire_fork[i], hipEventDisableTiming));
+      LW_HIP(hipEventCreateWithFlags(&w->wire_join[i], hipEventDisableTiming));
+    }
+  }
   return 0;
 }
 
@@ -249,6 +273,12 @@ extern "C" int hbk_testing_local_world_destroy(void* world) {
   for (int i = 0; i < w->world; ++i) {
     (void)hipEventDestroy(w->ready[i]);
     (void)hipEventDestroy(w->done[i]);
+  }
+  for (size_t i = 0; i < w->wire_stream.size(); ++i) {
+    (void)hipStreamSynchronize(w->wire_stream[i]);
+    (void)hipStreamDestroy(w->wire_stream[i]);
+    (void)hipEventDestroy(w->wire_fork[i]);
+    (void)hipEventDestroy(w->wire_join[i]);
   }
   delete w;
   return 0;

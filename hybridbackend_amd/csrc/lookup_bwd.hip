@@ -260,7 +260,7 @@ struct GArgs {
   // xcd_start[k][x + 1]) -- ranges of equal WORK (mixed columns), block b = x + 8 i takes the
   // i-th of them and leaves when the range is shorter
   int32_t xcd_w;
-  int32_t pad_;
+  int32_t stage_p;           // staged scatter: LDS words per bucket array (the launch group's largest bucket count)
   int32_t xcd_start[10][9];
   GCol col[kMaxCols];
 };
@@ -750,12 +750,18 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
 // were -- the L2's request rate, not bytes.
 constexpr int kStageMaxBuckets = 1024;
 
+// LDS (round 5): the bucket arrays are sized by the launch group's largest bucket count and the
+// segment staging exists only for groups with unpacked columns -- 36.9 KB (4 workgroups per CU;
+// the kernel needs 56 VGPRs) became 16 + 4 + 8 P / 1024 KB: ~22.5 KB at 300 buckets = 7 per CU.
+// The kernel is bound by the life of a tile (loads -> LDS tickets -> barrier -> stage -> barrier ->
+// stores), not by bytes: more resident tiles are throughput.
 __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GArgs a) {
-  __shared__ int32_t counters[kStageMaxBuckets];   // pairs of the tile per bucket; then: global
+  extern __shared__ int32_t stage_dyn[];
+  int32_t* const counters = stage_dyn;             // [stage_p] pairs of the tile per bucket; then: global
                                                    // position of staged slot L of the bucket - L
-  __shared__ int32_t first[kStageMaxBuckets];      // first staged slot of the bucket
+  int32_t* const first = stage_dyn + a.stage_p;    // [stage_p] first staged slot of the bucket
+  int32_t* const st_seg = stage_dyn + 2 * a.stage_p;   // [kTile], only in groups with unpacked columns
   __shared__ int64_t st_row[kTile];                // the tile's pairs, sorted by bucket
-  __shared__ int32_t st_seg[kTile];
   __shared__ uint16_t st_b[kTile];
   __shared__ int32_t wave_cnt[kWavesPerBlock];
   __shared__ int32_t n_staged;
@@ -925,7 +931,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
   __shared__ int32_t tot_s[kGroupMaxBuckets], pre_s[kGroupMaxBuckets];   // bucket totals / before
                                                    // this tile; then position deltas / first slots
   __shared__ int64_t st_row[kTile];                          // the tile's pairs, sorted by bucket
-  __shared__ int32_t st_seg[kTile];
+  extern __shared__ int32_t st_seg[];                        // [kTile], only in groups with unpacked columns
   __shared__ uint16_t st_b[kTile];
   __shared__ int32_t wave_tot[kWavesPerBlock], wave_cnt[kWavesPerBlock];
   __shared__ int32_t n_extra, gave_up, n_staged;
@@ -3416,7 +3422,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
         ci.onepass = options().bwd_onepass != 0 && ci.p.n_buckets <= kGroupMaxBuckets &&
                      ci.p.tiles <= 64;
       }
-      if ((pass == 0) == ci.onepass) order.push_back(c);
+      if ((pass == 0) == (ci.onepass != (options().bwd_large_first != 0))) order.push_back(c);
     }
   }
   for (int32_t c = 0; c < n_cols; ++c) {
@@ -3436,7 +3442,9 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
   for (int32_t q = 1; q < live_cols; ++q) {
     mixed = mixed || info[(size_t)order[q]].onepass != info[(size_t)order[0]].onepass;
   }
-  BwdHelpers* helpers = live_cols > group_cols || mixed ? bwd_helpers(stream) : nullptr;
+  const int n_streams = options().bwd_streams < 0 ? 0 : options().bwd_streams > kHelperStreams
+                                                           ? kHelperStreams : options().bwd_streams;
+  BwdHelpers* helpers = (live_cols > group_cols || mixed) && n_streams > 0 ? bwd_helpers(stream) : nullptr;
   std::unique_lock<std::mutex> hold;   // (released on every return path)
   if (helpers != nullptr) {
     hold = std::unique_lock<std::mutex>(helpers->mu);
@@ -3451,7 +3459,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
   int group_no = 0;
   int32_t q0 = 0;
   while (q0 < live_cols && status == HBK_OK) {
-    hipStream_t ls = helpers != nullptr ? helpers->s[group_no++ % kHelperStreams] : stream;
+    hipStream_t ls = helpers != nullptr ? helpers->s[group_no++ % n_streams] : stream;
     GArgs args, seg_args;
     int4* const desc_group = reinterpret_cast<int4*>(dp);
     // the group's columns: up to group_cols of one grouping form, sorted by kind (stable)
@@ -3625,6 +3633,23 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     }
     if (status != HBK_OK) break;
     if (k == 0) continue;
+    if (options().bwd_trace != 0) {   // HBK_BWD_TRACE: the composition of every launch group on stderr
+      int64_t g_ids = 0, g_bytes = 0;
+      int by_kind[kKinds] = {0};
+      for (int32_t i = 0; i < k; ++i) {
+        g_ids += cols[members[i]].n_ids;
+        g_bytes += (int64_t)cols[members[i]].n_ids * cols[members[i]].dim * 4;
+        ++by_kind[info[(size_t)members[i]].kind];
+      }
+      fprintf(stderr, "[hbk bwd] group %d on stream %d: %d columns (%s), %lld ids, %.1f MB of gradient rows, "
+              "%lld tiles, %lld job slots; columns by kind", group_no - (helpers != nullptr ? 1 : 0),
+              helpers != nullptr ? (group_no - 1) % n_streams : -1, k, group_onepass ? "one-launch" : "large",
+              (long long)g_ids, (double)g_bytes / 1e6, (long long)tiles, (long long)buckets);
+      for (int q = 0; q < kKinds; ++q) {
+        if (by_kind[q] != 0) fprintf(stderr, " %d:%d", q, by_kind[q]);
+      }
+      fprintf(stderr, "\n");
+    }
     args.n_cols = k;
     args.lr = apply_lr;
     args.apply = apply;
@@ -3676,7 +3701,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     // launch -- the config-5 shape loses 5 % with them, so its loss above is not the imbalance
     // alone.)
     args.xcd_w = 0;
-    args.pad_ = 0;
+    args.stage_p = 0;
     int64_t xcd_grid[kKinds] = {0};
     if ((options().bwd_xcd == 4 || options().bwd_xcd == 1 || options().bwd_xcd == 3) && kTeams == 1) {
       for (int kind = 0; kind < kKinds; ++kind) {
@@ -3732,8 +3757,11 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     if (onepass) {
       // (hist, scan and scatter are this one launch)
       SyncChain chain(ls);   // never beside another kernel whose tiles wait for later tiles
-      hipLaunchKernelGGL(bwd_group_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ls, args,
-                         sync);
+      bool unpacked = false;
+      for (int32_t i = 0; i < k; ++i) unpacked = unpacked || args.col[i].packed == 0;
+      hipLaunchKernelGGL(bwd_group_kernel, dim3((unsigned)tiles), dim3(kBlock),
+                         (unpacked ? (size_t)kTile * 4 : 0) + (size_t)options().bwd_lds_pad * 1024, ls,
+                         args, sync);
     } else {
       hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist, ls,
                          args);
@@ -3745,8 +3773,12 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
         hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)k), dim3(kBlock), 0, ls, args);
       }
       if (lds_hist <= (size_t)4 * kStageMaxBuckets && options().bwd_scatter_staged != 0) {
-        hipLaunchKernelGGL(bwd_scatter_staged_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, ls,
-                           args);
+        bool unpacked = false;
+        for (int32_t i = 0; i < k; ++i) unpacked = unpacked || args.col[i].packed == 0;
+        args.stage_p = (int32_t)(lds_hist / 4);
+        hipLaunchKernelGGL(bwd_scatter_staged_kernel, dim3((unsigned)tiles), dim3(kBlock),
+                           2 * lds_hist + (unpacked ? (size_t)kTile * 4 : 0) +
+                               (size_t)options().bwd_lds_pad * 1024, ls, args);
       } else {
         hipLaunchKernelGGL(bwd_scatter_pairs_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist,
                            ls, args);

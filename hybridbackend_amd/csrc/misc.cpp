@@ -37,6 +37,10 @@ const OptionEntry kOptions[] = {
     {"bwd_scatter_staged", "HBK_BWD_SCATTER_STAGED", &Options::bwd_scatter_staged},
     {"bwd_rowsort_pos", "HBK_BWD_ROWSORT_POS", &Options::bwd_rowsort_pos},
     {"bwd_rowsort_ratio", "HBK_BWD_ROWSORT_RATIO", &Options::bwd_rowsort_ratio},
+    {"bwd_streams", "HBK_BWD_STREAMS", &Options::bwd_streams},
+    {"bwd_trace", "HBK_BWD_TRACE", &Options::bwd_trace},
+    {"bwd_lds_pad", "HBK_BWD_LDS_PAD", &Options::bwd_lds_pad},
+    {"bwd_large_first", "HBK_BWD_LARGE_FIRST", &Options::bwd_large_first},
     {"bwd_pairs_packed", "HBK_BWD_PAIRS_PACKED", &Options::bwd_pairs_packed},
     {"bwd_seg_inline", "HBK_BWD_SEG_INLINE", &Options::bwd_seg_inline},
     {"bwd_scale_fused", "HBK_BWD_SCALE_FUSED", &Options::bwd_scale_fused},

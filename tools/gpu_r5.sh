@@ -106,6 +106,9 @@ for l in open('$O/ev_sweep_bcd.jsonl'):
       prof prof_ragged "" -- $R/tools/bin/bench_ops R
       unset HBK_BENCH_ITERS
       grep -E "bwd_|kernel  " $O/prof_ragged.txt | cut -c1-150 | head -14; trim prof_ragged;;
+    c5stats)    # kernel times of the config-5 shape (forward, backward + SGD, step only, + Adagrad)
+      prof prof_cfg5 "" -- python $R/tools/sweep.py --big --cases h
+      grep -E "^\{" $O/prof_cfg5.log | cut -c1-200; head -40 $O/prof_cfg5.txt | cut -c1-170; trim prof_cfg5;;
     rscounters) # memory-side counters of the ragged backward's kernels (two short passes)
       export HBK_BENCH_ITERS=2
       prof pmc_rs_tcc_a "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/bench_ops R

@@ -138,6 +138,11 @@ __device__ inline void team_sync() {
 // scratch writes per config-2 launch (TCC_EA0_WRREQ_64B 2.85 M where the rows account for 1.86 M),
 // 117 us instead of 110.
 constexpr int kPre = HBK_BWD_PRE;
+#ifndef HBK_BWD_WIDE_W
+#define HBK_BWD_WIDE_W 5   // width of the WIDE walk (rows of >= 16 lanes, with the optimizer step).  2 x kPre = 6 spills
+                          // 28 VGPRs in the SGD instantiation, 5 spills 12: config 4 + SGD 423-428 -> 412-416 us, the
+                          // config-5 mix + SGD 3.39-3.60 -> 3.22-3.46 ms in-box (Adagrad the same)
+#endif
 constexpr int kLdsRowPairs = kCP / 8; // multi-pair slots are summed in LDS rows when they hold at
                                       // most this many pairs together
 #ifndef HBK_BWD_HOT
@@ -1940,11 +1945,11 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
         // Width of the walk with the optimizer step: as many positions as the step's table /
         // accumulator rows leave registers for (kPre with SGD, 2 with Adagrad) -- or, for WIDE rows
         // (dim >= 64: <= 16 lane groups, i.e. 10-28 rounds of two barriers and two memory round
-        // trips per chunk at the narrow width), the full 2 x kPre with the step's rows requested
+        // trips per chunk at the narrow width), HBK_BWD_WIDE_W positions with the step's rows requested
         // two positions at a time (a round finishes ~1 row per lane group).  Narrow rows lose with
         // that form (ragged dim 16: 937 vs 782 us: more dependent table round trips per round).
         if constexpr (STEP != 0 && WIDE) {
-          walk(std::integral_constant<int, 2 * kPre>());
+          walk(std::integral_constant<int, HBK_BWD_WIDE_W>());
         } else {
           walk(std::integral_constant<int, STEP == 2 ? 2 : STEP ? kPre : 2 * kPre>());
         }
@@ -3108,9 +3113,11 @@ ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged) {
   // row range fits (tests).
   {
     const int dense_opt = options().bwd_dense;
-    // narrow rows (dim <= 32) gain up to twice the ratio (config 2, rows = 15 x ids: 106 -> 93 us);
-    // wide rows with skewed ids lose there (config 4 Zipf, dim 128: 345 -> 482 us)
-    const int64_t ratio = (int64_t)options().bwd_rowsort_ratio * (dim <= 32 ? 2 : 1);
+    // narrow rows (dim <= 32) gain up to FOUR times the ratio (config 2, rows = 15 x ids: 106 -> 93 us;
+    // ragged dim 16, 10 M rows = 19 x ids, + SGD: 834-889 -> 683-703 us in-box at 32 x, 719 at 16 x,
+    // 704 at 64 x; the config-5 mix +- 1 %); wide rows with skewed ids lose there (config 4 Zipf,
+    // dim 128: 343 -> 447 us)
+    const int64_t ratio = (int64_t)options().bwd_rowsort_ratio * (dim <= 32 ? 4 : 1);
     const bool want = dense_opt == 3 || (dense_opt == 1 && ratio > 0 && rows <= ratio * n_ids);
     if (kTeam == kBlock && want && rows >= 1 && rows < (1ll << 32)) {
       int64_t rs_target = (int64_t)kRsCap * 7 / 8;

@@ -59,7 +59,13 @@ template <typename V>
 __device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t u, int sub, V v) {
   constexpr int VE = sizeof(V) / 4;
   V* o = reinterpret_cast<V*>(job.out_vals + (int64_t)u * c.dim + (int64_t)sub * VE);
-#if HBK_RS_OUT_NT
+#if defined(HBK_RS_OUT_ASM)   // probe builds: the cache policy bits of the row store, spelled out
+  if constexpr (sizeof(V) == 16) {
+    asm volatile("global_store_dwordx4 %0, %1, off " HBK_RS_OUT_ASM : : "v"(o), "v"(v) : "memory");
+  } else {
+    asm volatile("global_store_dword %0, %1, off " HBK_RS_OUT_ASM : : "v"(o), "v"(v) : "memory");
+  }
+#elif HBK_RS_OUT_NT
   __builtin_nontemporal_store(v, o);
 #else
   *o = v;

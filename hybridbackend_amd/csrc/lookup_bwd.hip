@@ -788,11 +788,11 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
   __shared__ int32_t seg_ends[2 + kWavesPerBlock];
   int32_t* const sp_lds = reinterpret_cast<int32_t*>(st_row);
   const bool seg_inline = c.splits != nullptr && c.seg_of == nullptr;   // block-uniform
-  int32_t s_lo = 0;
-  if (seg_inline) {
-    const int64_t j_last = (base + kTile < c.n_ids ? base + kTile : c.n_ids) - 1;
-    s_lo = tile_segments(c, base, j_last, sp_lds, seg_ends);
-  }
+  // everything the tile needs from memory is requested up front -- the ids and where the tile's share
+  // of every bucket starts in the pair arrays -- so the segment search below runs under those loads
+  // instead of in front of them.  (Tried: the histogram launch leaves every tile's first / last
+  // segment for this kernel, which then starts with one round trip instead of four -- no gain at 7
+  // resident tiles per CU, and the histogram launch pays for the search: 494 vs 493 us.)
   RunCursor rc;
   int64_t id[kPerThread];
   int32_t seg[kPerThread];
@@ -807,14 +807,9 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
         seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);
       }
       id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
-      if (c.seg_of != nullptr) {
-        seg[k] = c.seg_of[j];
-      } else if (seg_inline) {
-        seg[k] = s_lo + sp_lds[k * kBlock + tid];
-      }
+      if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
     }
   }
-  // where the tile's share of every bucket starts in the pair arrays (travels beside the ids)
   const int per = (P + kBlock - 1) / kBlock;   // <= 4
   const int beg = tid * per;
   const int end = beg + per < P ? beg + per : P;
@@ -824,6 +819,12 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
     const int p = beg + q;
     gpos[q] = q < per && p < end ? c.bstart[p] + c.hist[(int64_t)ctile * P + p] : 0;
   }
+  if (seg_inline) {
+    const int64_t j_last = (base + kTile < c.n_ids ? base + kTile : c.n_ids) - 1;
+    const int32_t s_lo = tile_segments(c, base, j_last, sp_lds, seg_ends);
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) seg[k] = s_lo + sp_lds[k * kBlock + tid];
+  }   // (sp_lds is the staging area: the barriers below come before its first staged pair)
   for (int p = tid; p < P; p += kBlock) counters[p] = 0;
   __syncthreads();
   int32_t br[kPerThread];   // bucket | rank << 10, -1: no row
@@ -957,11 +958,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
   __shared__ int32_t seg_ends[2 + kWavesPerBlock];
   int32_t* const sp_lds = reinterpret_cast<int32_t*>(st_row);
   const bool seg_inline = c.splits != nullptr && c.seg_of == nullptr;   // block-uniform
-  int32_t s_lo = 0;
-  if (seg_inline) {
-    const int64_t j_last = (base + kTile < c.n_ids ? base + kTile : c.n_ids) - 1;
-    s_lo = tile_segments(c, base, j_last, sp_lds, seg_ends);
-  }
+  // (the ids are requested before the segment search: they travel under it)
   RunCursor rc;
   int64_t id[kPerThread];
   int32_t seg[kPerThread];
@@ -976,12 +973,14 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
         seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);
       }
       id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
-      if (c.seg_of != nullptr) {
-        seg[k] = c.seg_of[j];
-      } else if (seg_inline) {
-        seg[k] = s_lo + sp_lds[k * kBlock + tid];
-      }
+      if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
     }
+  }
+  if (seg_inline) {
+    const int64_t j_last = (base + kTile < c.n_ids ? base + kTile : c.n_ids) - 1;
+    const int32_t s_lo = tile_segments(c, base, j_last, sp_lds, seg_ends);
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) seg[k] = s_lo + sp_lds[k * kBlock + tid];
   }
   for (int p = tid; p < P; p += kBlock) counters[p] = 0;
   if (tid == 0) {

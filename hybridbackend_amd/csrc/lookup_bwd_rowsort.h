@@ -257,7 +257,12 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
     }
   }
   __syncthreads();
+#ifdef HBK_RS_PROBE_ARRIVAL
+  const int32_t n_rows_scan = scan_bitmap(L.present, L.pre);
+  const int32_t n_rows_job = one_chunk ? n_pairs : n_rows_scan;
+#else
   const int32_t n_rows_job = scan_bitmap(L.present, L.pre);
+#endif
   // One global atomic per job claims the output range; a returning device-scope atomic takes
   // microseconds under load: its round trip runs beside C-E.  Step only: just the count is wanted.
   int32_t claimed = 0;
@@ -372,9 +377,16 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
       if (u_[k] != ~0u) {
+#ifdef HBK_RS_PROBE_ARRIVAL   // probe builds (results wrong): every pair its own row, walked in ARRIVAL order --
+                              // what the walk costs when the jobs of a column read the gradient block in step
+        const int pos = k * kBlock + tid;
+        L.sseg[pos] = seg_[k];
+        L.su[pos] = (uint16_t)pos;
+#else
         const int pos = (int)(L.cnt[u_[k]] & kRsMask) + tk_[k];
         L.sseg[pos] = seg_[k];
         L.su[pos] = (uint16_t)u_[k];
+#endif
       }
     }
     if (cb == 0 && emit && tid == kBlock - 1) L.base_u = job.out_base + claimed;

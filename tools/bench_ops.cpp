@@ -455,7 +455,9 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (argc > 1 && argv[1][0] == 'R') {  // the sweep's ragged case at fixed lengths: 26 x 65536 segments of 8 ids, 1M rows
-    bench_backward(26, 524288, 16, 1000000, 0.f, false, 8);
+    // (bench_ops R 64: 64 ids per segment -- the same pairs and output rows over a gradient block of
+    // 512 KB per column instead of 4 MB: what the reduce stage costs when its gradient reads hit L2)
+    bench_backward(26, 524288, 16, 1000000, 0.f, false, argc > 2 ? atoi(argv[2]) : 8);
     return 0;
   }
   if (argc > 1 && argv[1][0] == 'r') {  // "ragged": config-5-like columns (8 ids per sample, mean)

@@ -79,6 +79,10 @@ plan_options = st.fixed_dictionaries({
   'bwd_xcd': st.sampled_from([0, 1, 2, 4]),         # reduce jobs round robin / by rule / equal slot ranges / equal work ranges
   'fwd_xcd': st.sampled_from([0, 2]),               # lookup tiles round robin / contiguous per XCD
   'fwd_interleave': st.sampled_from([0, 3]),        # lookup tiles column first / row tile first wherever tile counts agree
+  'bwd_streams': st.sampled_from([0, 2, 4]),        # launch groups on the caller's stream / over library streams
+  'bwd_large_first': st.sampled_from([0, 1]),       # order of the launch groups
+  'bwd_rowsort_ratio': st.sampled_from([0, 8, 64]), # row-sorted buckets never / by the shipped ratio / for sparse columns too
+  'bwd_lds_pad': st.sampled_from([0, 14]),          # fewer resident tiles in the grouping launches
 })
 
 

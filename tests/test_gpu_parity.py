@@ -829,6 +829,63 @@ def test_group_lookup_backward_rowsort_buckets(hbk_option, dense, mode):
                                    rtol=RTOL, atol=1e-4 + 0.05 * atol)
 
 
+@pytest.mark.parametrize('streams,large_first', [(4, 0), (0, 0), (2, 1), (4, 1)])
+def test_group_lookup_backward_many_columns_and_sparse_narrow_rows(hbk_option, streams, large_first):
+  """70 columns = two launch groups per grouping form (round 5: options bwd_streams -- the groups on
+  the library's streams or all on the caller's -- and bwd_large_first, their order), among them
+  narrow rows over tables of 20-30 x ids (row-sorted by the x 4 ratio for dim <= 32 since round 5;
+  dim 64 at the same sparsity stays hashed), a ragged column of > 64 tiles (three-launch grouping with
+  the staged scatter's LDS sized by its bucket count) and small dense ones.  Sums against float64,
+  the SGD step bit-equal to the oracle's apply on the emitted slices."""
+  hbk_option('bwd_streams', streams)
+  hbk_option('bwd_large_first', large_first)
+  rng = np.random.RandomState(77)
+  shapes = []   # (dim, rows, n_seg, mean_len)
+  for c in range(70):
+    if c % 10 == 0:
+      shapes.append((16, 400000, 16384, 0))      # rows = 24 x ids, narrow: row-sorted
+    elif c % 10 == 1:
+      shapes.append((8, 250000, 9000, 0))        # 28 x ids
+    elif c % 10 == 2:
+      shapes.append((64, 300000, 12000, 0))      # 25 x ids, wide: hashed
+    elif c == 33:
+      shapes.append((16, 60000, 20000, 8))       # ~160 000 ids: 79 tiles
+    elif c == 34:
+      shapes.append((32, 2000000, 30000, 3))     # ragged, ~90 000 ids over 22 x as many rows
+    else:
+      shapes.append(([4, 12, 16, 24, 128][c % 5], [300, 5000, 40000][c % 3], 3000 + 37 * c, c % 4 == 3 and 2))
+  tables, ids, splits, grads = [], [], [], []
+  for d, rows, n_seg, mean_len in shapes:
+    tables.append(rng.uniform(-1, 1, size=(rows, d)).astype(np.float32))
+    sp = _ragged(rng, n_seg, mean_len, 32) if mean_len else None
+    n = n_seg if sp is None else int(sp[-1])
+    ids.append(rng.randint(0, rows, size=n).astype(np.int64))
+    splits.append(sp)
+    grads.append(rng.randn(n_seg, d).astype(np.float32))
+  t_dev = [dev(t.copy()) for t in tables]
+  lookup = hb.embedding.GroupLookup(t_dev, None, 'mean')
+  grad = hb.embedding.GroupLookupGrad(lookup)
+  res = grad([dev(i) for i in ids], [dev(g) for g in grads],
+             [None if sp is None else dev(sp) for sp in splits], apply_lr=0.05)
+  for c, (d, rows, n_seg, mean_len) in enumerate(shapes):
+    sp = splits[c] if splits[c] is not None else np.arange(ids[c].size + 1, dtype=np.int32)
+    g_id = oracle.segment_combine_grad(grads[c], sp, 'mean').astype(np.float64)
+    want = np.zeros((rows, d), np.float64)
+    np.add.at(want, ids[c], g_id)
+    nu = int(res[c][2].item())
+    uniq = np.unique(ids[c])
+    assert nu == uniq.size, c
+    urows = host(res[c][0])[:nu]
+    assert np.array_equal(np.sort(urows), uniq), c
+    got = np.zeros_like(want)
+    got[urows] = host(res[c][1])[:nu].astype(np.float64)
+    n_terms = np.bincount(ids[c], minlength=rows).max()
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=RTOL * 4 * np.sqrt(max(n_terms, 1)))
+    ref = tables[c].copy()
+    oracle.sparse_sgd_apply(ref, urows, host(res[c][1])[:nu], 0.05)
+    np.testing.assert_equal(host(t_dev[c]), ref)
+
+
 @pytest.mark.parametrize('dense', [3, 1, 0])
 @pytest.mark.parametrize('onepass', [1, 0])
 @pytest.mark.parametrize('packed,seg_inline', [(1, 1), (0, 1), (1, 0), (0, 0)])

@@ -115,31 +115,6 @@ for l in open('$O/ev_sweep_bcd.jsonl'):
       prof pmc_rs_tcc_b "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" -- $R/tools/bin/bench_ops R
       unset HBK_BENCH_ITERS
       for f in pmc_rs_tcc_a pmc_rs_tcc_b; do echo "== $f"; tail -1 $O/$f.log; pmc_table $O/$f.json bwd_; trim $f; done;;
-    wab)        # walk width of the row-sorted job without an optimizer step (W0 = 12 spills 2 VGPRs; 10 / 11 do not)
-      (for rep in 1 2; do for v in shipped v_w11 v_w10; do
-         if [ $v = shipped ]; then L=$R/hybridbackend_amd/lib; else L=$R/tools/bin/$v; fi
-         for w in R b d; do LD_LIBRARY_PATH=$L timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s|^|$v  |"; done
-       done; done) > $O/wab.log 2>&1; cut -c1-180 $O/wab.log
-      export HBK_BENCH_ITERS=2
-      LD_LIBRARY_PATH=$R/tools/bin/v_w11 prof pmc_rs_w11 "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/bench_ops R
-      unset HBK_BENCH_ITERS
-      tail -1 $O/pmc_rs_w11.log; pmc_table $O/pmc_rs_w11.json bwd_rowsort; trim pmc_rs_w11;;
-    wab2)       # walk widths with the optimizer step: W1 (SGD) 6 -> 5, W2 (Adagrad) 4 -> 3 stop the VGPR spills
-      (for rep in 1 2; do for v in v_w11 v_a v_b v_c; do
-         for w in s r; do LD_LIBRARY_PATH=$R/tools/bin/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s|^|$v  |"; done
-       done; done) > $O/wab2.log 2>&1; cut -c1-180 $O/wab2.log
-      for v in v_w11 v_c v_w11 v_c; do echo "== cfg5 shape, $v"; HBK_LIBRARY=$R/tools/bin/$v/libhbk_core.so timeout 600 python tools/sweep.py --cases h 2>/dev/null | grep "^{" | python -c "
-import sys,json
-for l in sys.stdin:
-  d=json.loads(l); print('  ',d['case'][:70].ljust(70), d['us'])"; done 2>&1 | tee $O/wab2_cfg5.log;;
-    wrprobe)    # which store stream of the row-sorted job makes 15.2 M write requests where 11.9 M are expected?
-      export HBK_BENCH_ITERS=2
-      for v in v_norownum v_plainrows; do
-        LD_LIBRARY_PATH=$R/tools/bin/$v prof pmc_$v "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/bench_ops R
-        echo "== $v"; tail -1 $O/pmc_$v.log; pmc_table $O/pmc_$v.json bwd_rowsort_kernel; trim pmc_$v
-      done
-      unset HBK_BENCH_ITERS
-      for v in v_norownum v_plainrows; do LD_LIBRARY_PATH=$R/tools/bin/$v timeout 300 tools/bin/bench_ops R 2>&1 | grep group_lookup_bwd | sed "s|^|$v  |"; done;;
     p2pprof)    # kernel times of the sharded step at one rank: exchange form (inline) and p2p form
       prof prof_p2p "" -- python $R/bench.py --sharded --steps 30 --warmup 5 --cpu-seconds 0 --no-secondary --tune-steps 0 --p2p off
       grep -E "hbk|kernel  " $O/prof_p2p.txt | cut -c1-150 | head -16

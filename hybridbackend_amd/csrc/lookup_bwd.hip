@@ -567,7 +567,11 @@ __device__ inline void scan_tiles_of_bucket(const GCol& c, int p) {
   int32_t run = 0;
   int t = 0;
   // 16 tiles per memory round trip (the loads of a step cannot pass the stores of the step before:
-  // same array; with 4 per step a 256-tile column was 64 dependent round trips, 23 us)
+  // same array; with 4 per step a 256-tile column was 64 dependent round trips, 23 us).  Round 5
+  // tried, for the ragged case's 11.6 us: 64 tiles per step (11.1 us), one wave per workgroup = four
+  // times the CUs (12.0), a WAVE per bucket with a shuffle scan over the tiles (two round trips per
+  // 256 tiles, but every lane touches a line of its own: 28.7 us) -- a thread per bucket with
+  // coalesced rows of the matrix stays.
   for (; t + 16 <= n_tiles; t += 16) {
     int32_t x[16];
 #pragma unroll

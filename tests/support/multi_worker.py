@@ -308,7 +308,9 @@ def run(a, result):
         outs = [torch.full((batch, d), float('nan'), device=DEV) for d in dims]
         bound = drv.p2p_bind(outs)
         result.setdefault('p2p_bound', []).append(bool(bound))
-        assert bound, 'hbk_sharded_p2p_bind could not map the peers (every rank agrees on that)'
+        # a box whose driver cannot map a peer's memory (hipIpcGetMemHandle / OpenMemHandle) is not a
+        # parity failure: every rank gets the same False (the bind is a collective that agrees on the
+        # minimum), the plan keeps the exchange form -- and THAT is what the steps below then check
         for st in range(3):
           drv([dev(i) for i in ids[st][rank]], None, outs)
           torch.cuda.synchronize()

@@ -102,6 +102,15 @@ def test_real_rccl_ranks(world, group, tmp_path):
     assert res is not None and res['ok'], (r, res)
     assert res['rccl_ranks_seen'] == world          # ncclCommCount: RCCL itself spans the ranks
     assert res['passed'] == wanted, (r, res['passed'])
+  if group == 'p2p':
+    # every rank comes to the same answer about the mapping (the bind agrees on the minimum); where
+    # the driver cannot map peers the steps above ran -- and were checked -- in the exchange form
+    bound = [tuple(res['p2p_bound']) for res in results]
+    assert len(set(bound)) == 1, bound
+    if not all(bound[0]):
+      import warnings
+      warnings.warn(f'world {world}: hbk_sharded_p2p_bind could not map the peers {bound[0]}: '
+                    'the p2p cases ran in the exchange form')
 
 
 @pytest.mark.parametrize('local_size,nodes', [(2, 2), (4, 2), (2, 4)])

@@ -83,6 +83,9 @@ int hbk_tables_free(void* slab);
  * HBK_PART_ONEPASS, HBK_SHARDED_GROUPS, HBK_SHARDED_ID64, HBK_SHARDED_COPY_SELF,
  * HBK_SHARDED_TRACE); no entry point reads the environment per call.
  * Names: bwd_buckets_log2, bwd_bucket_pairs, bwd_split_pairs, bwd_onepass, bwd_group_cols, bwd_dense, bwd_wide, bwd_xcd, fwd_xcd, fwd_interleave, fwd_hot_rows,
+ * bwd_pairs_packed, bwd_seg_inline, bwd_scale_fused, bwd_scatter_staged, bwd_rowsort_pos, bwd_rowsort_ratio (round 5: x 4 for dim <= 32),
+ * bwd_streams (launch groups of > 64 columns rotate over this many library streams; 0: the caller's), bwd_large_first,
+ * bwd_trace (the launch groups of every backward call on stderr), bwd_lds_pad (a probe), sharded_p2p,
  * unique_buckets_log2,
  * unique_onepass, partition_sub_tiles, partition_fixed_max, partition_onepass, sharded_groups,
  * sharded_id64, sharded_copy_self, sharded_trace, sharded_inline, sharded_wire_fused, sharded_pack_early (the sharded_* ones are taken by

@@ -72,6 +72,36 @@ __device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t
 #endif
 }
 
+// Whole-line stores for 64-byte rows (round 5, tools/store_probe.hip): a non-temporal store of HALF a
+// 128-byte line -- what a 4-lane group writes per instruction -- costs 1.33 write requests even when
+// the other half follows in the very next instruction (lg_seq nt: 14.1 M requests for 10.6 M rows,
+// 208 us; plain stores 10.6 M but they evict the gradient lines), while the two halves written by
+// ADJACENT lanes of ONE instruction are one request each (pair_line nt: 10.6 M, 122 us).  Rows that
+// finish at neighbouring positions of a lane group's share have consecutive ranks, so an even
+// half and the odd half behind it leave together: the two lane groups of an 8-lane octet take
+// turns, in turn e the octet stores the pair of its lane group e -- lanes of group e hold the
+// first row, the other group's lanes fetch the second row over DPP (row_shl / row_shr by 4).
+#ifndef HBK_RS_PAIR_STORES
+#define HBK_RS_PAIR_STORES 1
+#endif
+template <int CTRL>
+__device__ inline int rs_dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+// (__float_as_int on the elements: __builtin_bit_cast(int, v.y) of an ext-vector ELEMENT reads element 0 with this
+// compiler -- all four moves came out as one, found in the ISA)
+template <int CTRL>
+__device__ inline f32x4 rs_dpp_v(f32x4 v) {
+  f32x4 r;
+  r.x = __int_as_float(rs_dpp_i<CTRL>(__float_as_int(v.x)));
+  r.y = __int_as_float(rs_dpp_i<CTRL>(__float_as_int(v.y)));
+  r.z = __int_as_float(rs_dpp_i<CTRL>(__float_as_int(v.z)));
+  r.w = __int_as_float(rs_dpp_i<CTRL>(__float_as_int(v.w)));
+  return r;
+}
+constexpr int kDppRowShl4 = 0x104;   // lane i reads lane i + 4 of its row of 16
+constexpr int kDppRowShr4 = 0x114;   // lane i reads lane i - 4
+
 // (the row NUMBERS stay plain stores: 8-byte pieces per lane that the L2 combines into whole
 // sectors; non-temporal they went out one by one -- ragged 1M-row case 650-667 -> 830-920 us)
 #ifndef HBK_RS_ROWNUM_NT
@@ -91,6 +121,51 @@ __device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t
 #ifndef HBK_RS_W2
 #define HBK_RS_W2 4
 #endif
+
+// the finished rows of one batch of a lane group (bit w of `mine`: position w ends a run of mine, its
+// sum is in g[w], its rank among the job's rows uu[w]); half0: parity of the job's first output row
+// in its 128-byte line.  Every lane of the wave calls it.
+template <int W>
+__device__ inline void rs_store_pairs(const GCol& c, const ReduceJob& job, int32_t base_u, int half0,
+                                      const uint32_t (&uu)[W], const f32x4 (&g)[W], uint32_t mine,
+                                      int lane, int sub) {
+  const bool odd_group = (lane >> 2) & 1;
+  // (lane groups leave the walk when their share ends: a pair needs the octet's other group present)
+  const bool partner_on = (__builtin_amdgcn_ballot_w64(true) >> (lane ^ 4)) & 1ull;
+  uint32_t done = 0;
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    const int32_t R = base_u + (int32_t)uu[w];
+    bool pair = false;
+    if (w + 1 < W) {
+      pair = partner_on && ((mine >> w) & 3u) == 3u && ((R + half0) & 1) == 0 &&
+             ((done >> w) & 1u) == 0u;
+      // turn e: the octet stores the pair of its lane group e
+      // (every DPP move outside any lane-dependent condition: a source lane that is masked off reads as 0)
+      const int p_i = pair ? 1 : 0;
+      const int p_shr = rs_dpp_i<kDppRowShr4>(p_i);
+      const int p_shl = rs_dpp_i<kDppRowShl4>(p_i);
+      const int p_from_even = odd_group ? p_shr : p_i;   // group 0's flag
+      const int p_from_odd = odd_group ? p_i : p_shl;     // group 1's flag
+      if (__builtin_amdgcn_ballot_w64(p_from_even != 0) != 0ull) {   // (wave-uniform branch)
+        const f32x4 second = rs_dpp_v<kDppRowShr4>(g[w + 1]);     // group 0's g[w + 1] in group 1's lanes
+        const int32_t r_even = rs_dpp_i<kDppRowShr4>(R);
+        if (p_from_even != 0) {
+          rs_store_row<f32x4>(c, job, odd_group ? r_even + 1 : R, sub, odd_group ? second : g[w]);
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(p_from_odd != 0) != 0ull) {
+        const f32x4 second = rs_dpp_v<kDppRowShl4>(g[w + 1]);     // group 1's g[w + 1] in group 0's lanes
+        const int32_t r_odd = rs_dpp_i<kDppRowShl4>(R);
+        if (p_from_odd != 0) {
+          rs_store_row<f32x4>(c, job, odd_group ? R : r_odd + 1, sub, odd_group ? g[w] : second);
+        }
+      }
+      if (pair) done |= 3u << w;
+    }
+    if (((mine & ~done) >> w) & 1u) rs_store_row<f32x4>(c, job, R, sub, g[w]);
+  }
+}
 
 struct RsLds {
   uint32_t present[kRsWords];   // rows of the job
@@ -122,6 +197,10 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   const bool live = sub < c.chunks;
   const int groups = kBlock >> lpr_log2;
   const int my_group = tid >> lpr_log2;
+  // rows of 64 bytes (dim 16, four 16-byte chunks) leave as whole 128-byte lines where they can
+  const bool pair_rows = HBK_RS_PAIR_STORES != 0 && sizeof(V) == 16 && lpr_log2 == 2 && c.chunks == 4 &&
+                         c.dim == 16 && ((uintptr_t)job.out_vals & 63u) == 0u;
+  const int half0 = (int)(((uintptr_t)job.out_vals >> 6) & 1u);
   const int32_t n_pairs = job.n_pairs;
   if (n_pairs <= 0) return;
   const int64_t* prow = job.prow;
@@ -478,6 +557,13 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
               }
               acc = zero_v<V>();
             }
+          }
+        }
+        if constexpr (HBK_RS_PAIR_STORES && sizeof(V) == 16 && STEP == 0) {
+          // (the paired stores are cooperative: a lane group with nothing to emit lends its lanes)
+          if (pair_rows && one_chunk && !stepping) {
+            rs_store_pairs<W>(c, job, base_u, half0, uu, g, mine, lane, sub);
+            continue;
           }
         }
         if (mine == 0u || !live) continue;

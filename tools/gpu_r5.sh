@@ -101,6 +101,15 @@ import json
 for l in open('$O/ev_sweep_bcd.jsonl'):
   d=json.loads(l)
   if 'case' in d: print('  ',d['case'][:90].ljust(90), d['us'])";;
+    evidence2)  # the backward part of the evidence again (after the whole-line stores): C-ABI ops, sweeps b / c / h
+      timeout 600 tools/bin/bench_ops > $O/ev_bench_ops.txt 2>&1; (for w in R r d; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk "; done) >> $O/ev_bench_ops.txt; grep group_lookup_bwd $O/ev_bench_ops.txt | cut -c1-170
+      for i in 1 2 3; do timeout 600 python tools/sweep.py --cases h 2>/dev/null | grep "^{" > $O/ev_sweep_h_$i.jsonl; done
+      timeout 900 python tools/sweep.py --big --cases b,c,d 2>/dev/null | grep "^{" > $O/ev_sweep_bcd.jsonl
+      for f in $O/ev_sweep_h_1.jsonl $O/ev_sweep_h_2.jsonl $O/ev_sweep_h_3.jsonl $O/ev_sweep_bcd.jsonl; do echo "== $f"; python -c "
+import sys,json
+for l in open('$f'):
+  d=json.loads(l)
+  if 'case' in d: print('  ',d['case'][:90].ljust(90), d['us'])"; done;;
     rsstats)    # kernel times of the ragged backward (final build)
       export HBK_BENCH_ITERS=6
       prof prof_ragged "" -- $R/tools/bin/bench_ops R

@@ -244,6 +244,26 @@ def test_options_roundtrip_and_unknown_names():
   assert lib.hbk_get_option(None, None) == _lib.INVALID_ARGUMENT
 
 
+def test_every_option_named_in_the_header_exists_and_every_option_is_named_there():
+  """include/hbk.h lists the option names in the comment above hbk_set_option; the library's table
+  is csrc/misc.cpp.  Both directions: a documented name the library does not know, or an option
+  nobody documented, fails here."""
+  import re
+  lib = _lib.lib()
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  header = open(os.path.join(root, 'include', 'hbk.h')).read()
+  block = header[header.index(' * Names:'):header.index('int hbk_set_option(')]
+  documented = set(re.findall(r'\b((?:bwd|fwd|unique|partition|sharded|sync)_[a-z0-9_]+)\b', block))
+  table = open(os.path.join(root, 'hybridbackend_amd', 'csrc', 'misc.cpp')).read()
+  known = set(re.findall(r'\{"([a-z0-9_]+)", "HBK_[A-Z0-9_]+", &Options::', table))
+  assert known, 'option table not found in csrc/misc.cpp'
+  v = C.c_int32(0)
+  for name in sorted(documented):
+    assert lib.hbk_get_option(name.encode(), C.byref(v)) == 0, f'{name}: in hbk.h, unknown to the library'
+  missing = sorted(known - documented)
+  assert not missing, f'options without a mention in include/hbk.h: {missing}'
+
+
 def test_custom_transport_argument_checks():
   lib = _lib.lib()
   comm = C.c_void_p()

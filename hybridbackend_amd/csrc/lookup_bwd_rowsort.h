@@ -81,6 +81,10 @@ __device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t
 // half and the odd half behind it leave together: the two lane groups of an 8-lane octet take
 // turns, in turn e the octet stores the pair of its lane group e -- lanes of group e hold the
 // first row, the other group's lanes fetch the second row over DPP (row_shl / row_shr by 4).
+// (Only in the instantiation without an optimizer step.  Tried in the SGD / Adagrad ones as well, with a
+// per-batch guard "some lane group finishes two rows at neighbouring positions": config 2 + SGD 171 -> 166 us on
+// one box and 150 -> 152.6 on another, ragged 10 M rows + SGD -5 %, ragged over 100 k rows + SGD + 3 %, dim 4 / 64
+// + 1-2 % -- the extra registers spill in kernels that are already at 128: not shipped.)
 #ifndef HBK_RS_PAIR_STORES
 #define HBK_RS_PAIR_STORES 1
 #endif

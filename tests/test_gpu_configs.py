@@ -17,6 +17,7 @@ import torch
 import oracle
 import hybridbackend_amd as hb
 from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
+from tests.support.tolerance import assert_sums_close, world_grad_sums
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -192,11 +193,15 @@ def test_config3_workload_eight_ranks_in_process():
   # the shards after the fused SGD step == table - lr * (dense scatter-add over all ranks)
   for c in range(n_cols):
     dense = torch.zeros(n_rows, dim, device=DEV, dtype=torch.float64)
+    mag = torch.zeros(n_rows, dim, device=DEV, dtype=torch.float64)
     for r in range(world):
       dense.index_add_(0, torch.remainder(ids[r][c], n_rows), grads[r][c].double())
+      mag.index_add_(0, torch.remainder(ids[r][c], n_rows), grads[r][c].double().abs())
     ref = tables[c].double() - lr * dense
+    mag = tables[c].double().abs() + lr * mag
     for r in range(world):
-      torch.testing.assert_close(shards[r][c].double(), ref[r::world], rtol=1e-5, atol=1e-7)
+      assert_sums_close(host(shards[r][c]), host(ref[r::world]), host(mag[r::world]),
+                        err_msg=f'column {c}, shard {r}')
       untouched = dense[r::world].abs().sum(1) == 0
       assert torch.equal(shards[r][c][untouched], tables[c][r::world][untouched])
 
@@ -255,9 +260,10 @@ def test_config5_200_columns_lookup_and_grad_apply_single_gpu():
       sp = splits[c] if splits[c] is not None else np.arange(r.size + 1, dtype=np.int32)
       g_id = oracle.segment_combine_grad(grads[c], sp, combiners[c])
       want64 = oracle.unsorted_segment_sum(g_id, oinv, ou.size, f64=True)
+      abs64 = oracle.unsorted_segment_sum(np.abs(g_id), oinv, ou.size, f64=True)
       pos = {int(v): i for i, v in enumerate(ou.tolist())}
       perm = [pos[int(v)] for v in host(urows)[:k]]
-      np.testing.assert_allclose(host(grows)[:k], want64[perm], rtol=1e-5, atol=1e-5)
+      assert_sums_close(host(grows)[:k], want64[perm], abs64[perm], err_msg=f'{opt}, column {c}')
       t_ref, a_ref = tables[c].copy(), np.full_like(tables[c], 0.1)
       if opt == 'sgd':
         oracle.sparse_sgd_apply(t_ref, host(urows)[:k], host(grows)[:k], 0.05)
@@ -415,11 +421,9 @@ def test_config5_200_columns_eight_ranks_end_to_end_step():
     for c in range(n_cols):
       np.testing.assert_equal(res[r][c], want[c])
   for c in range(n_cols):
-    dense = np.zeros((rows[c], dims[c]), np.float64)
-    for r in range(world):
-      sp = splits[r][c] if splits[r][c] is not None else np.arange(ids[r][c].size + 1, dtype=np.int32)
-      g_id = oracle.segment_combine_grad(grads[r][c], sp, combiners[c]).astype(np.float64)
-      np.add.at(dense, ids[r][c] % rows[c], g_id)
+    dense, mag = world_grad_sums(rows[c], dims[c], [(ids[r][c], grads[r][c], splits[r][c], combiners[c])
+                                                    for r in range(world)])
     ref = tables[c].astype(np.float64) - lr * dense
     for r in range(world):
-      np.testing.assert_allclose(host(shards[r][c]), ref[r::world], rtol=1e-5, atol=1e-5)
+      assert_sums_close(host(shards[r][c]), ref[r::world], (np.abs(tables[c]) + lr * mag)[r::world],
+                        err_msg=f'column {c}, shard {r}')

@@ -11,6 +11,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+from tests.support.tolerance import (WIRE16_FLOOR, WIRE16_REL, assert_sums_close,  # noqa: E402
+                                     dense_sums, world_grad_sums)
+
 hypothesis = pytest.importorskip('hypothesis')
 from hypothesis import HealthCheck, given, settings  # noqa: E402
 from hypothesis import strategies as st  # noqa: E402
@@ -137,8 +140,7 @@ def _check_group_lookup(cols, seed):
     rows = np.asarray(ids[k], np.int64) % buckets[k]
     sp = splits[k] if splits[k] is not None else np.arange(rows.size + 1, dtype=np.int32)
     g_id = oracle.segment_combine_grad(grads[k], sp, combs[k]).astype(np.float64)
-    dense = np.zeros(tables[k].shape, np.float64)
-    np.add.at(dense, rows, g_id)
+    dense, mag = dense_sums(tables[k].shape, rows, g_id)
     u, g, nu = res[k]
     n = int(nu.item())
     got_rows = u.cpu().numpy()[:n]
@@ -146,9 +148,7 @@ def _check_group_lookup(cols, seed):
     got = np.zeros_like(dense)
     got[got_rows] = g.cpu().numpy()[:n]
     # fp32 sums in an order that is not fixed: 1e-5 relative to the magnitude of the summed terms
-    mag = np.zeros_like(dense)
-    np.add.at(mag, rows, np.abs(g_id))
-    assert np.all(np.abs(got - dense) <= 1e-5 * np.maximum(mag, 1e-30) + 1e-12)
+    assert_sums_close(got, dense, mag, floor=1e-12, err_msg=f'column {k}')
   # the fused optimizer step equals the oracle's step applied to the emitted slices, bit for bit
   opt = 'adagrad' if seed % 2 else 'sgd'
   t2 = [dev(t.copy()) for t in tables]
@@ -268,32 +268,20 @@ def test_sharded_driver_random_in_process_world(world, cols, wire16, hot, dedup,
   for cm in comms:
     cm.close()
   assert not errors, errors
-  eff, tol = tables, dict(rtol=1e-5, atol=1e-5)
+  eff, rel, floor = tables, 1e-5, 1e-6
   if wire16:
     eff = [oracle.cast_f16_to_f32(oracle.cast_f32_to_f16(t)) for t in tables]
-    tol = dict(rtol=3e-3, atol=3e-3)
+    rel, floor = WIRE16_REL, WIRE16_FLOOR
   for r in range(world):
     want = oracle.group_lookup_fwd(eff, ids[r], splits[r], rows, combs)
     for k in range(n):
       np.testing.assert_equal(results[r][0][k], want[k])
   for k in range(n):
-    dense = np.zeros((rows[k], dims[k]), np.float64)
+    dense, mag = world_grad_sums(rows[k], dims[k], [(ids[r][k], grads[r][k], splits[r][k], combs[k])
+                                                    for r in range(world)])
     got = np.zeros_like(dense)
     for r in range(world):
-      sp = splits[r][k] if splits[r][k] is not None else np.arange(ids[r][k].size + 1,
-                                                                   dtype=np.int32)
-      g_id = oracle.segment_combine_grad(grads[r][k], sp, combs[k]).astype(np.float64)
-      np.add.at(dense, ids[r][k] % rows[k], g_id)
       lr_, g_ = results[r][1][k]
       assert len(set(lr_.tolist())) == len(lr_)
       got[lr_ * world + r] += g_
-    mag = np.zeros_like(dense)
-    for r in range(world):
-      sp = splits[r][k] if splits[r][k] is not None else np.arange(ids[r][k].size + 1,
-                                                                   dtype=np.int32)
-      np.add.at(mag, ids[r][k] % rows[k],
-                np.abs(oracle.segment_combine_grad(grads[r][k], sp, combs[k]).astype(np.float64)))
-    # fp16 wire: terms below the fp16 normal range (6e-5) carry an absolute error of one
-    # denormal step (6e-8) each
-    floor = 1e-5 if wire16 else 1e-12
-    assert np.all(np.abs(got - dense) <= tol['rtol'] * np.maximum(mag, 1e-30) + floor)
+    assert_sums_close(got, dense, mag, rel=rel, floor=floor, err_msg=f'column {k}')

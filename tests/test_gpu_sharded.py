@@ -10,6 +10,7 @@ import oracle
 import hybridbackend_amd as hb
 from hybridbackend_amd import _lib
 from hybridbackend_amd.embedding.sharded import ShardedGroupLookup
+from tests.support.tolerance import WIRE16_FLOOR, WIRE16_REL, assert_sums_close, dense_sums, world_grad_sums
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -202,12 +203,8 @@ def test_sharded_backward_equals_dense_scatter(world):
     recv = [fake_alltoallv([send[q][c] for q in range(world)], sizes[c])[r] for c in range(n)]
     slices.append(drivers[r].owner_bwd(sts[r], recv))
   for c in range(n):
-    dense = np.zeros((rows[c], dims[c]), np.float64)
-    for r in range(world):
-      sp = splits[r][c] if splits[r][c] is not None else np.arange(ids[r][c].size + 1,
-                                                                   dtype=np.int32)
-      g_id = oracle.segment_combine_grad(grads[r][c], sp, combiners[c]).astype(np.float64)
-      np.add.at(dense, ids[r][c] % rows[c], g_id)
+    dense, mag = world_grad_sums(rows[c], dims[c], [(ids[r][c], grads[r][c], splits[r][c], combiners[c])
+                                                    for r in range(world)])
     got = np.zeros_like(dense)
     for r in range(world):
       urows, grows, nu = slices[r][c]
@@ -215,7 +212,7 @@ def test_sharded_backward_equals_dense_scatter(world):
       lr = urows.cpu().numpy()[:k]
       assert len(set(lr.tolist())) == k                 # deduplicated on the owner
       got[lr * world + r] += grows.cpu().numpy()[:k]
-    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5)
+    assert_sums_close(got, dense, mag)
 
 
 def test_sharded_backward_through_rccl_world1_with_apply():
@@ -230,9 +227,9 @@ def test_sharded_backward_through_rccl_world1_with_apply():
     drv([dev(ids)])
     drv.backward([dev(g)], apply_lr=0.1)
     torch.cuda.synchronize()
-    ref = table.astype(np.float64)
-    np.subtract.at(ref, ids % 3000, 0.1 * g.astype(np.float64))
-    np.testing.assert_allclose(t_dev.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    want, mag = dense_sums(table.shape, ids % 3000, g)
+    assert_sums_close(t_dev.cpu().numpy(), table.astype(np.float64) - 0.1 * want,
+                      np.abs(table) + 0.1 * mag)
   finally:
     coll.close()
 
@@ -311,28 +308,24 @@ def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64,
   assert not errors, errors
   assert all(x is not None for x in results)
   eff = tables
-  tol = dict(rtol=1e-5, atol=1e-5)
+  rel, floor = 1e-5, 1e-6
   if wire16:
     eff = [oracle.cast_f16_to_f32(oracle.cast_f32_to_f16(t)) for t in tables]
     # gradients travel as fp16 too: every rank's contribution to a row is rounded on its own
-    tol = dict(rtol=2e-3, atol=2e-3 * max(1, world // 4))
+    rel, floor = WIRE16_REL, WIRE16_FLOOR
   for r in range(world):
     want = oracle.group_lookup_fwd(eff, ids[r], splits[r], rows, combiners)
     for c in range(n):
       np.testing.assert_equal(results[r][0][c], want[c])
   for c in range(n):
-    dense = np.zeros((rows[c], dims[c]), np.float64)
-    for r in range(world):
-      sp = splits[r][c] if splits[r][c] is not None else np.arange(ids[r][c].size + 1,
-                                                                   dtype=np.int32)
-      g_id = oracle.segment_combine_grad(grads[r][c], sp, combiners[c]).astype(np.float64)
-      np.add.at(dense, ids[r][c] % rows[c], g_id)
+    dense, mag = world_grad_sums(rows[c], dims[c], [(ids[r][c], grads[r][c], splits[r][c], combiners[c])
+                                                    for r in range(world)])
     got = np.zeros_like(dense)
     for r in range(world):
       lr_, g_ = results[r][1][c]
       assert len(set(lr_.tolist())) == len(lr_)
       got[lr_ * world + r] += g_
-    np.testing.assert_allclose(got, dense, **tol)
+    assert_sums_close(got, dense, mag, rel=rel, floor=floor)
   for cm in comms:
     cm.close()
 
@@ -422,19 +415,18 @@ def test_cxx_driver_p2p_form_in_process_world(hbk_option, world, inline, id64, p
       for c in range(n):
         np.testing.assert_equal(results[r][0][st][c], want[c])
   for c in range(n):
-    dense = np.zeros((rows[c], dims[c]), np.float64)
-    for r in range(world):
-      np.add.at(dense, ids[steps - 1][r][c] % rows[c], grads[r][c].astype(np.float64))
+    dense, mag = world_grad_sums(rows[c], dims[c], [(ids[steps - 1][r][c], grads[r][c], None, 'sum')
+                                                    for r in range(world)])
     got = np.zeros_like(dense)
     for r in range(world):
       lr_, g_ = results[r][1][c]
       assert len(set(lr_.tolist())) == len(lr_)
       got[lr_ * world + r] += g_
-    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5)
+    assert_sums_close(got, dense, mag)
     for r in range(world):
-      np.testing.assert_allclose(shards[r][c].cpu().numpy(),
-                                 (tables[c].astype(np.float64) - lr * dense)[r::world],
-                                 rtol=1e-5, atol=1e-5)
+      assert_sums_close(shards[r][c].cpu().numpy(),
+                        (tables[c].astype(np.float64) - lr * dense)[r::world],
+                        (np.abs(tables[c]) + lr * mag)[r::world])
   for cm in comms:
     cm.close()
 
@@ -655,10 +647,10 @@ def test_cxx_driver_requester_dedup_in_process_world(hbk_option, world, kind, gr
   assert not errors, errors
   assert all(x is not None for x in results)
   eff = tables
-  tol = dict(rtol=1e-5, atol=2e-5)
+  rel, floor = 1e-5, 1e-6
   if wire16:
     eff = [oracle.cast_f16_to_f32(oracle.cast_f32_to_f16(t)) for t in tables]
-    tol = dict(rtol=2e-3, atol=4e-3 * max(1, world // 4))
+    rel, floor = WIRE16_REL, WIRE16_FLOOR
   for r in range(world):
     want = oracle.group_lookup_fwd(eff, ids[r], splits[r], rows, combiners)
     for c in range(n):
@@ -674,24 +666,19 @@ def test_cxx_driver_requester_dedup_in_process_world(hbk_option, world, kind, gr
         asked += np.unique(mine).size if dedup[c] else mine.size
       assert results[owner][3][c] == asked, (c, owner)
   for c in range(n):
-    dense = np.zeros((rows[c], dims[c]), np.float64)
-    for r in range(world):
-      sp = splits[r][c] if splits[r][c] is not None else np.arange(ids[r][c].size + 1,
-                                                                   dtype=np.int32)
-      g_id = oracle.segment_combine_grad(grads[r][c], sp, combiners[c]).astype(np.float64)
-      np.add.at(dense, ids[r][c] % rows[c], g_id)
+    dense, mag = world_grad_sums(rows[c], dims[c], [(ids[r][c], grads[r][c], splits[r][c], combiners[c])
+                                                    for r in range(world)])
     got = np.zeros_like(dense)
     for r in range(world):
       lr_, g_ = results[r][2][c]
       assert len(set(lr_.tolist())) == len(lr_)
       got[lr_ * world + r] += g_
-    scale = max(1.0, float(np.abs(dense).max()))
-    np.testing.assert_allclose(got, dense, rtol=tol['rtol'], atol=tol['atol'] * scale)
+    assert_sums_close(got, dense, mag, rel=rel, floor=floor)
     # the fused step of the second backward
     for r in range(world):
-      np.testing.assert_allclose(shards[r][c].cpu().numpy(),
-                                 tables[c][r::world].astype(np.float64) - lr * dense[r::world],
-                                 rtol=tol['rtol'], atol=tol['atol'] * scale * 2)
+      assert_sums_close(shards[r][c].cpu().numpy(),
+                        tables[c][r::world].astype(np.float64) - lr * dense[r::world],
+                        (np.abs(tables[c]) + lr * mag)[r::world], rel=rel, floor=floor)
   for cm in comms:
     cm.close()
 
@@ -750,17 +737,15 @@ def test_dense_features_single_gpu():
   for k, c in enumerate(cols):
     g = grads[0][:, off:off + c.dimension]
     off += c.dimension
-    sp = sps[k] if sps[k] is not None else np.arange(batch + 1, dtype=np.int32)
-    g_id = oracle.segment_combine_grad(np.ascontiguousarray(g), sp, c.combiner).astype(np.float64)
-    dense = np.zeros((c.num_buckets, c.dimension), np.float64)
-    np.add.at(dense, ids[k] % c.num_buckets, g_id)
+    dense, mag = world_grad_sums(c.num_buckets, c.dimension,
+                                 [(ids[k], np.ascontiguousarray(g), sps[k], c.combiner)])
     u, gr, nu = res[k]
     n = int(nu.item())
     got = np.zeros_like(dense)
     rows = u.cpu().numpy()[:n]
     assert len(set(rows.tolist())) == n
     got[rows] = gr.cpu().numpy()[:n]
-    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5)
+    assert_sums_close(got, dense, mag)
 
 
 def test_dense_features_sharded_and_replicated_columns_in_process_world():
@@ -803,20 +788,18 @@ def test_dense_features_sharded_and_replicated_columns_in_process_world():
     np.testing.assert_equal(results[r][0], wants[r][0])
   off = 0
   for k, c in enumerate(cols):
-    dense = np.zeros((c.num_buckets, c.dimension), np.float64)
+    dense, mag = world_grad_sums(
+      c.num_buckets, c.dimension,
+      [(wants[r][1][k], np.ascontiguousarray(grads[r][:, off:off + c.dimension]), wants[r][2][k],
+        c.combiner) for r in range(world)])
     got = np.zeros_like(dense)
     for r in range(world):
-      _, ids, sps = wants[r]
-      g = np.ascontiguousarray(grads[r][:, off:off + c.dimension])
-      sp = sps[k] if sps[k] is not None else np.arange(batch + 1, dtype=np.int32)
-      g_id = oracle.segment_combine_grad(g, sp, c.combiner).astype(np.float64)
-      np.add.at(dense, ids[k] % c.num_buckets, g_id)
       rows, vals = results[r][1][k]
       # sharded tables report local rows (global = local * W + rank); replicated ones global
       # rows, each rank its own share (summed here = the cross-rank aggregation)
       glob = rows * world + r if k != 1 else rows
       np.add.at(got, glob, vals.astype(np.float64))
-    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5)
+    assert_sums_close(got, dense, mag)
     off += c.dimension
   for cm in comms:
     cm.close()
@@ -986,16 +969,13 @@ def test_cxx_driver_empty_ranks_and_columns_in_process_world():
     for c in range(3):
       np.testing.assert_equal(results[r][0][c], want[c])
   for c in range(3):
-    dense = np.zeros((rows[c], dims[c]), np.float64)
+    dense, mag = world_grad_sums(rows[c], dims[c], [(ids[r][c], grads[r][c], splits[r][c], combiners[c])
+                                                    for r in range(world)])
     got = np.zeros_like(dense)
     for r in range(world):
-      sp = splits[r][c] if splits[r][c] is not None else np.arange(ids[r][c].size + 1,
-                                                                   dtype=np.int32)
-      g_id = oracle.segment_combine_grad(grads[r][c], sp, combiners[c]).astype(np.float64)
-      np.add.at(dense, ids[r][c] % rows[c], g_id)
       lr_, g_ = results[r][1][c]
       got[lr_ * world + r] += g_
-    np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-6)
+    assert_sums_close(got, dense, mag)
   assert results[1][1][0][0].size == 0          # owner 1 got no row of column 0
   for cm in comms:
     cm.close()
@@ -1075,23 +1055,26 @@ def test_dense_features_adagrad_sharded_in_process_world():
   assert not errors, errors
   off = 0
   for k, c in enumerate(cols):
-    per_rank = []
+    per_rank, per_rank_mag = [], []
     for r in range(world):
       _, ids, sps = _want_dense(cols, tables, feats[r])
       g = np.ascontiguousarray(grads[r][:, off:off + c.dimension])
-      sp = sps[k] if sps[k] is not None else np.arange(batch + 1, dtype=np.int32)
-      g_id = oracle.segment_combine_grad(g, sp, c.combiner).astype(np.float64)
-      dense = np.zeros((c.num_buckets, c.dimension), np.float64)
-      np.add.at(dense, ids[k] % c.num_buckets, g_id)
+      dense, mag = world_grad_sums(c.num_buckets, c.dimension, [(ids[k], g, sps[k], c.combiner)])
       per_rank.append(dense)
+      per_rank_mag.append(mag)
     t64 = tables[k].astype(np.float64)
     if k != 1:        # sharded: the owner applies the sum of both ranks' gradients once
       g = per_rank[0] + per_rank[1]
+      mag = per_rank_mag[0] + per_rank_mag[1]
       a = 0.1 + g * g
       want = t64 - 0.05 * g / np.sqrt(a)
+      # magnitudes as in test_gpu_parity.py's Adagrad bounds: d(g^2) = 2 |g| dg, and
+      # |d/dg (g / sqrt(a0 + g^2))| <= 1 / sqrt(a0)
+      var_mag = np.abs(t64) + 0.05 * (mag / np.sqrt(0.1) + 1.0)
+      acc_mag = 0.1 + g * g + 2.0 * np.abs(g) * mag
       for r in range(world):
-        np.testing.assert_allclose(results[r][0][k], want[r::world], rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(results[r][1][k], a[r::world], rtol=1e-5, atol=1e-6)
+        assert_sums_close(results[r][0][k], want[r::world], var_mag[r::world])
+        assert_sums_close(results[r][1][k], a[r::world], acc_mag[r::world])
     else:             # replicated: untouched (the replicas would diverge), slices handed back
       for r in range(world):
         np.testing.assert_equal(results[r][0][k], tables[k])
@@ -1099,7 +1082,7 @@ def test_dense_features_adagrad_sharded_in_process_world():
         rows_r, g_r = results[r][2]
         got = np.zeros_like(per_rank[r])
         got[rows_r] = g_r
-        np.testing.assert_allclose(got, per_rank[r], rtol=1e-5, atol=1e-6)
+        assert_sums_close(got, per_rank[r], per_rank_mag[r])
     off += c.dimension
 
 
@@ -1168,13 +1151,13 @@ def test_sharded_prefetch_next_step(world, dedup, form):
       for c in range(2):
         np.testing.assert_equal(results[r][s][0][c], want[c])
     for c in range(2):
-      dense = np.zeros((rows[c], dims[c]), np.float64)
+      dense, mag = world_grad_sums(rows[c], dims[c], [(ids[r][s][c], grads[r][s][c], None, 'sum')
+                                                      for r in range(world)])
       got = np.zeros_like(dense)
       for r in range(world):
-        np.add.at(dense, ids[r][s][c] % rows[c], grads[r][s][c].astype(np.float64))
         lr_, g_ = results[r][s][1][c]
         got[lr_ * world + r] += g_
-      np.testing.assert_allclose(got, dense, rtol=1e-5, atol=1e-5)
+      assert_sums_close(got, dense, mag)
 
 
 # ----------------------------------------------------------------------------------

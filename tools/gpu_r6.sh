@@ -1,0 +1,69 @@
+#!/bin/bash
+# Round-6 GPU-box visits: stages picked on the command line, everything lands under gpurun_out/.
+#   tools/gpu_r6.sh "test seed400"        (see the case labels)
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+STAGES=${1:-"test"}
+prof() {  # prof <name> <pmc counters or ""> -- cmd...   (counters in their own pass, kernel-trace only)
+  local name=$1; shift
+  local ctrs=$1; shift
+  shift
+  rm -rf $O/$name
+  if [ -n "$ctrs" ]; then
+    (cd /tmp && export TMPDIR=/tmp && timeout ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log)
+    python tools/prof_summary.py pmc $O/$name > $O/$name.json 2>> $O/$name.log
+  else
+    (cd /tmp && export TMPDIR=/tmp && timeout ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o p -- "$@" > $O/$name.log 2>&1; echo "rc=$?" >> $O/$name.log)
+    python tools/prof_summary.py stats $O/$name > $O/$name.txt 2>> $O/$name.log
+  fi
+}
+trim() { find $O/$1 -name "*.csv" -size +2M -delete; }
+pmc_table() {   # pmc_table <json> <kernel-name filter>: one line per kernel, counters side by side
+  python - "$1" "$2" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+for k,v in sorted(d.items()):
+  if sys.argv[2] in k: print(k[:44].ljust(44), {c.replace('TCC_EA0_','').replace('_sum',''):round(x['mean']) for c,x in v.items()})
+PY
+}
+for st in $STAGES; do
+  case $st in
+    test)       # the driver's command (with -x), then the tail
+      timeout 2400 python -m pytest tests -x -q -m gpu --durations=15 > $O/test.log 2>&1; echo "pytest rc=$?" >> $O/test.log; tail -25 $O/test.log;;
+    repeats)    # the whole -m gpu suite 5 x in fresh processes WITHOUT -x
+      : > $O/gputest_repeats.txt
+      for i in 1 2 3 4 5; do
+        timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider > $O/test_rep$i.log 2>&1; rc=$?
+        echo "== run $i: rc=$rc" >> $O/gputest_repeats.txt; tail -4 $O/test_rep$i.log >> $O/gputest_repeats.txt
+        grep -E "^(FAILED|ERROR)" $O/test_rep$i.log >> $O/gputest_repeats.txt
+      done; cat $O/gputest_repeats.txt;;
+    seed400)    # the r05 failure (dedup, seed 400) in 24 fresh processes, worst |diff| / sum|g| logged
+      rm -f $O/seed400_ratios.txt
+      for i in $(seq 1 24); do
+        d=$(mktemp -d); HBK_TEST_RATIO_LOG=$O/seed400_ratios.txt timeout 300 python tests/support/multi_worker.py --rank 0 --world 1 --dir $d --cases dedup > $O/seed400_last.log 2>&1 || { echo "process $i FAILED"; tail -20 $O/seed400_last.log; }
+        rm -rf $d
+      done
+      python - <<PY
+import re
+rows=[l for l in open('$O/seed400_ratios.txt')]
+r=[float(re.search(r'worst_ratio=([0-9.e+-]+)',l).group(1)) for l in rows]
+pids={l.split()[0] for l in rows}
+print(f'{len(rows)} checks in {len(pids)} processes; worst |diff| / sum|terms| overall = {max(r):.3e} (bound 1e-5); ')
+bd=[l for l in rows if 'backward' in l and 'Zipf' in l]
+rb=[float(re.search(r'worst_ratio=([0-9.e+-]+)',l).group(1)) for l in bd]
+print(f'seed-400 backward checks: {len(bd)}, worst ratio {max(rb):.3e}, median {sorted(rb)[len(rb)//2]:.3e}')
+PY
+      ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -3 $O/smoke.log;;
+    bench)
+      timeout 600 python bench.py --steps 50 --warmup 10 > $O/bench.log 2>&1; echo "bench rc=$?" >> $O/bench.log; tail -3 $O/bench.log;;
+    t_*)        # t_<file stem>[:<-k expression>]: one test file, e.g. t_test_gpu_sync or t_test_gpu_parity:rowsort
+      spec=${st#t_}; f=${spec%%:*}; k=""; [ "$spec" != "$f" ] && k=${spec#*:}
+      timeout 1500 python -m pytest tests/$f.py -x -q -m gpu ${k:+-k "$k"} --durations=5 > $O/$f.log 2>&1; echo "pytest rc=$?" >> $O/$f.log; tail -15 $O/$f.log;;
+    *) echo "unknown stage $st";;
+  esac
+done

@@ -52,7 +52,7 @@ template <typename... A> Status InvalidArgument(A...);
 template <typename... A> Status Internal(A...);
 }  // namespace errors
 
-enum DataType { DT_INT8, DT_INT32, DT_INT64, DT_FLOAT };
+enum DataType { DT_INT8, DT_INT32, DT_INT64, DT_FLOAT, DT_HALF, DT_RESOURCE };
 
 class TensorShape {
  public:
@@ -99,6 +99,11 @@ class OpInputList {
   int size() const;
   const Tensor& operator[](int i) const;
 };
+class OpMutableInputList {   // Ref-typed list inputs (op_kernel.h)
+ public:
+  int size() const;
+  Tensor at(int i, bool lock_held);
+};
 
 class Stream {
  public:
@@ -124,6 +129,8 @@ class OpKernelContext {
   const Tensor& input(int i);
   int num_inputs() const;
   Status input_list(const char* name, OpInputList* list);
+  Status input(const char* name, const Tensor** tensor);
+  Status mutable_input_list(const char* name, OpMutableInputList* list);
   Status allocate_output(int i, const TensorShape& shape, Tensor** out);
   Status allocate_temp(DataType dt, const TensorShape& shape, Tensor* out);
   template <typename D> const D& eigen_device() const;
@@ -152,6 +159,13 @@ class ResourceBase {
   void Unref() const;
 };
 struct ResourceHandle {};
+namespace core {
+class ScopedUnref {
+ public:
+  explicit ScopedUnref(const ResourceBase* o);
+  ~ScopedUnref();
+};
+}  // namespace core
 template <typename T> class ResourceHandleOp : public OpKernel {
  public:
   explicit ResourceHandleOp(OpKernelConstruction* ctx);
@@ -160,6 +174,11 @@ template <typename T> class ResourceHandleOp : public OpKernel {
 const ResourceHandle& HandleFromInput(OpKernelContext* ctx, int input);
 template <typename T> Status LookupResource(OpKernelContext* ctx, const ResourceHandle& h, T** out);
 template <typename T> Status CreateResource(OpKernelContext* ctx, const ResourceHandle& h, T* value);
+template <typename T>
+ResourceHandle MakeResourceHandle(OpKernelContext* ctx, const string& container, const string& name);
+template <typename T>
+Status LookupOrCreateResource(OpKernelContext* ctx, const ResourceHandle& h, T** value,
+                              std::function<Status(T**)> creator);
 
 class Env {
  public:
@@ -176,8 +195,10 @@ class ThreadPool {
 
 namespace shape_inference {
 struct ShapeHandle {};
+struct DimensionHandle {};
 struct DimensionOrConstant {
   DimensionOrConstant(int64 v);
+  DimensionOrConstant(DimensionHandle d);
 };
 class InferenceContext {
  public:
@@ -187,6 +208,9 @@ class InferenceContext {
   void set_output(int i, ShapeHandle s);
   ShapeHandle Vector(DimensionOrConstant dim);
   ShapeHandle Scalar();
+  ShapeHandle Matrix(DimensionOrConstant rows, DimensionOrConstant cols);
+  DimensionHandle Dim(ShapeHandle s, int64 idx);
+  Status Subtract(DimensionHandle first, DimensionOrConstant second, DimensionHandle* out);
   Status MakeShapeFromPartialTensorShape(const PartialTensorShape& p, ShapeHandle* out);
   Status Concatenate(ShapeHandle a, ShapeHandle b, ShapeHandle* out);
 };

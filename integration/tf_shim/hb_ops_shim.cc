@@ -424,6 +424,12 @@ class CollectiveAsyncOp : public AsyncOpKernel {
   void ComputeAsync(OpKernelContext* ctx, DoneCallback done) override {
     HbNcclCollective* coll = nullptr;
     OP_REQUIRES_OK_ASYNC(ctx, LookupResource(ctx, HandleFromInput(ctx, 0), &coll), done);
+    // an asynchronous RCCL error aborts the communicator and fails the step here instead of
+    // hanging it (the reference polls ncclCommGetAsyncError from a thread of its own,
+    // nccl_collective.cc:434-465)
+    const Status healthy = HbkStatus(hbk_comm_check_async(coll->comm()));
+    if (!healthy.ok()) coll->Unref();
+    OP_REQUIRES_OK_ASYNC(ctx, healthy, done);
     coll->pool()->Schedule([this, ctx, coll, done]() {
       Run(ctx, coll);
       coll->Unref();
@@ -840,16 +846,539 @@ REGISTER_KERNEL_BUILDER(Name("HbGroupLookup").Device(DEVICE_GPU).TypeConstraint<
 REGISTER_KERNEL_BUILDER(Name("HbGroupLookup").Device(DEVICE_GPU).TypeConstraint<int64>("Tids"),
                         GroupLookupOp<int64>);
 
+// --------------------------------------------------------------------------------------------
+// HbGroupLookupGrad: the gradient of HbGroupLookup with respect to `weights` as IndexedSlices
+// (hbk_group_lookup_bwd): unique_rows / grad_rows have the capacity of the column's ids, the first
+// n_unique[i][0] entries are valid; n_unique stays on the device.  The Python side ties it to
+// HbGroupLookup with ops.RegisterGradient (INTEGRATION.md "Gradients"), the way the reference
+// attaches its exchange gradients (hbtf/distribute/collective.py:334-347).
+// HbGroupLookupGradApply: the same backward with the sparse optimizer step fused and NO
+// IndexedSlices written ("step only": hbk_group_lookup_bwd_apply with unique_rows = grad_rows =
+// NULL) -- sharded variables skip cross-rank aggregation (hbtf/training/gradient.py:193-217), so
+// the step can be taken where the deduplicated sums sit in registers.
+// --------------------------------------------------------------------------------------------
+static Status GroupLookupGradShape(InferenceContext* c) {
+  int64 n;
+  TF_RETURN_IF_ERROR(c->GetAttr("N", &n));
+  for (int64 i = 0; i < n; ++i) {      // inputs: weights [0,n), ids [n,2n), row_splits, grads
+    c->set_output(i, c->Vector(c->Dim(c->input(n + i), 0)));
+    c->set_output(n + i, c->Matrix(c->Dim(c->input(n + i), 0), c->Dim(c->input(i), 1)));
+    c->set_output(2 * n + i, c->Vector(1));
+  }
+  return Status::OK();
+}
+
 REGISTER_OP("HbGroupLookupGrad")
     .Output("unique_rows: N * int64").Output("grad_rows: N * float").Output("n_unique: N * int32")
     .Input("weights: N * float").Input("ids: N * Tids").Input("row_splits: N * int32")
     .Input("grads: N * float")
     .Attr("N: int >= 1").Attr("Tids: {int32, int64}")
     .Attr("buckets: list(int)").Attr("combiners: list(int)").Attr("ragged: list(bool)")
-    .Attr("divisor: int = 1").Attr("apply_lr: float = 0.0");
-// Kernel: fills hbk_lookup_grad_column_t per column exactly as GroupLookupOp does (outputs of
-// capacity n_ids; workspace from hbk_group_lookup_bwd_workspace_bytes via allocate_temp) and
-// calls hbk_group_lookup_bwd; n_unique stays on the device (gradient consumers slice with it).
+    .Attr("divisor: int = 1")
+    .SetShapeFn(GroupLookupGradShape);
+
+REGISTER_OP("HbGroupLookupGradApply")
+    .Output("n_unique: N * int32")
+    .Input("weights: Ref(N * float)").Input("accums: Ref(M * float)")
+    .Input("ids: N * Tids").Input("row_splits: N * int32").Input("grads: N * float")
+    .Input("lr: float")
+    .Attr("N: int >= 1").Attr("M: int >= 0 = 0").Attr("Tids: {int32, int64}")
+    .Attr("buckets: list(int)").Attr("combiners: list(int)").Attr("ragged: list(bool)")
+    .Attr("divisor: int = 1").Attr("optimizer: {'sgd', 'adagrad'} = 'sgd'")
+    .SetIsStateful()
+    .SetShapeFn([](InferenceContext* c) {
+      int64 n;
+      TF_RETURN_IF_ERROR(c->GetAttr("N", &n));
+      for (int64 i = 0; i < n; ++i) c->set_output(i, c->Vector(1));
+      return Status::OK();
+    });
+
+// the attributes both gradient ops share with HbGroupLookup, and the per-column descriptor
+struct GroupLookupAttrs {
+  std::vector<int64> buckets;
+  std::vector<int32> combiners;
+  std::vector<bool> ragged;
+  int32 divisor;
+  Status Read(OpKernelConstruction* ctx) {
+    TF_RETURN_IF_ERROR(ctx->GetAttr("buckets", &buckets));
+    TF_RETURN_IF_ERROR(ctx->GetAttr("combiners", &combiners));
+    TF_RETURN_IF_ERROR(ctx->GetAttr("ragged", &ragged));
+    return ctx->GetAttr("divisor", &divisor);
+  }
+  Status Check(int n) const {
+    if (static_cast<int>(buckets.size()) != n || static_cast<int>(combiners.size()) != n ||
+        static_cast<int>(ragged.size()) != n) {
+      return errors::InvalidArgument("buckets, combiners and ragged must have N = ", n, " entries");
+    }
+    return Status::OK();
+  }
+  template <typename Tids>
+  Status Fill(int i, const Tensor& weight, const Tensor& ids, const Tensor& splits,
+              const Tensor& grad, hbk_lookup_grad_column_t* c) const {
+    const int64 n_seg = ragged[i] ? splits.NumElements() - 1 : ids.NumElements();
+    if (weight.dims() != 2 || grad.dims() != 2 || grad.dim_size(0) != n_seg ||
+        grad.dim_size(1) != weight.dim_size(1)) {
+      return errors::InvalidArgument("column ", i, ": grads must be [segments, dim] = [", n_seg,
+                                     ", ", weight.dim_size(1), "]");
+    }
+    std::memset(c, 0, sizeof(*c));
+    c->table = const_cast<float*>(weight.flat<float>().data());
+    c->rows = weight.dim_size(0);
+    c->dim = static_cast<int32_t>(weight.dim_size(1));
+    c->ids_dtype = HbkType<Tids>::v;
+    c->ids = ids.flat<Tids>().data();
+    c->n_ids = ids.NumElements();
+    c->row_splits = ragged[i] ? splits.flat<int32>().data() : nullptr;
+    c->n_segments = n_seg;
+    c->bucket = buckets[i];
+    c->divisor = divisor;
+    c->combiner = combiners[i];
+    c->grad_out = grad.flat<float>().data();
+    return Status::OK();
+  }
+};
+
+template <typename Tids>
+class GroupLookupGradOp : public OpKernel {
+ public:
+  explicit GroupLookupGradOp(OpKernelConstruction* ctx) : OpKernel(ctx) {
+    OP_REQUIRES_OK(ctx, attrs_.Read(ctx));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    OpInputList w, ids, splits, grads;
+    OP_REQUIRES_OK(ctx, ctx->input_list("weights", &w));
+    OP_REQUIRES_OK(ctx, ctx->input_list("ids", &ids));
+    OP_REQUIRES_OK(ctx, ctx->input_list("row_splits", &splits));
+    OP_REQUIRES_OK(ctx, ctx->input_list("grads", &grads));
+    const int n = w.size();
+    OP_REQUIRES_OK(ctx, attrs_.Check(n));
+    std::vector<hbk_lookup_grad_column_t> cols(n);
+    for (int i = 0; i < n; ++i) {
+      OP_REQUIRES_OK(ctx, attrs_.Fill<Tids>(i, w[i], ids[i], splits[i], grads[i], &cols[i]));
+      Tensor *u, *g, *k;
+      const int64 cap = ids[i].NumElements();
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, TensorShape({cap}), &u));
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(n + i, TensorShape({cap, w[i].dim_size(1)}), &g));
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(2 * n + i, TensorShape({1}), &k));
+      cols[i].unique_rows = reinterpret_cast<int64_t*>(u->flat<int64>().data());
+      cols[i].grad_rows = g->flat<float>().data();
+      cols[i].n_unique = k->flat<int32>().data();
+    }
+    const size_t ws_bytes = hbk_group_lookup_bwd_workspace_bytes(n, cols.data());
+    Tensor ws;
+    OP_REQUIRES_OK(ctx, AllocScratch(ctx, ws_bytes, &ws));
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_group_lookup_bwd(n, cols.data(), 0.0f, ws.flat<int8>().data(),
+                                                       ws_bytes + 16, StreamOf(ctx))));
+  }
+
+ private:
+  GroupLookupAttrs attrs_;
+};
+REGISTER_KERNEL_BUILDER(Name("HbGroupLookupGrad").Device(DEVICE_GPU).TypeConstraint<int32>("Tids"),
+                        GroupLookupGradOp<int32>);
+REGISTER_KERNEL_BUILDER(Name("HbGroupLookupGrad").Device(DEVICE_GPU).TypeConstraint<int64>("Tids"),
+                        GroupLookupGradOp<int64>);
+
+static Status OptimizerCode(const string& name, int32_t* apply) {
+  if (name == "sgd") { *apply = HBK_APPLY_SGD; return Status::OK(); }
+  if (name == "adagrad") { *apply = HBK_APPLY_ADAGRAD; return Status::OK(); }
+  return errors::InvalidArgument("optimizer must be 'sgd' or 'adagrad', got ", name);
+}
+
+template <typename Tids>
+class GroupLookupGradApplyOp : public OpKernel {
+ public:
+  explicit GroupLookupGradApplyOp(OpKernelConstruction* ctx) : OpKernel(ctx) {
+    OP_REQUIRES_OK(ctx, attrs_.Read(ctx));
+    string optimizer;
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("optimizer", &optimizer));
+    OP_REQUIRES_OK(ctx, OptimizerCode(optimizer, &apply_));
+  }
+  void Compute(OpKernelContext* ctx) override {
+    OpMutableInputList w, accums;
+    OpInputList ids, splits, grads;
+    OP_REQUIRES_OK(ctx, ctx->mutable_input_list("weights", &w));
+    OP_REQUIRES_OK(ctx, ctx->mutable_input_list("accums", &accums));
+    OP_REQUIRES_OK(ctx, ctx->input_list("ids", &ids));
+    OP_REQUIRES_OK(ctx, ctx->input_list("row_splits", &splits));
+    OP_REQUIRES_OK(ctx, ctx->input_list("grads", &grads));
+    const Tensor* lr;
+    OP_REQUIRES_OK(ctx, ctx->input("lr", &lr));
+    const int n = w.size();
+    OP_REQUIRES_OK(ctx, attrs_.Check(n));
+    OP_REQUIRES(ctx, accums.size() == (apply_ == HBK_APPLY_ADAGRAD ? n : 0),
+                errors::InvalidArgument("accums: N accumulators for adagrad, none for sgd"));
+    std::vector<hbk_lookup_grad_column_t> cols(n);
+    for (int i = 0; i < n; ++i) {
+      Tensor weight = w.at(i, /*lock_held=*/false);
+      OP_REQUIRES_OK(ctx, attrs_.Fill<Tids>(i, weight, ids[i], splits[i], grads[i], &cols[i]));
+      if (apply_ == HBK_APPLY_ADAGRAD) {
+        Tensor accum = accums.at(i, /*lock_held=*/false);
+        OP_REQUIRES(ctx, accum.NumElements() == weight.NumElements(),
+                    errors::InvalidArgument("accumulator ", i, " must have its variable's shape"));
+        cols[i].accum = accum.flat<float>().data();
+      }
+      Tensor* k;
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, TensorShape({1}), &k));
+      cols[i].n_unique = k->flat<int32>().data();      // unique_rows = grad_rows = NULL: step only
+    }
+    const size_t ws_bytes = hbk_group_lookup_bwd_workspace_bytes(n, cols.data());
+    Tensor ws;
+    OP_REQUIRES_OK(ctx, AllocScratch(ctx, ws_bytes, &ws));
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_group_lookup_bwd_apply(
+                            n, cols.data(), apply_, lr->scalar<float>()(), ws.flat<int8>().data(),
+                            ws_bytes + 16, StreamOf(ctx))));
+  }
+
+ private:
+  GroupLookupAttrs attrs_;
+  int32_t apply_;
+};
+REGISTER_KERNEL_BUILDER(Name("HbGroupLookupGradApply").Device(DEVICE_GPU).HostMemory("lr")
+                            .TypeConstraint<int32>("Tids"),
+                        GroupLookupGradApplyOp<int32>);
+REGISTER_KERNEL_BUILDER(Name("HbGroupLookupGradApply").Device(DEVICE_GPU).HostMemory("lr")
+                            .TypeConstraint<int64>("Tids"),
+                        GroupLookupGradApplyOp<int64>);
+
+// ============================================================================================
+// HbUniqueN / HbCastN (new, additive N-ary ops): the owner-side `array_ops.unique` of
+// hbtf/embedding/sharding.py:186 for N columns in one set of launches (TensorFlow 1.15 has no GPU
+// kernel for Unique: the stock op costs a device -> host -> device round trip per column), and the
+// fp32 <-> fp16 wire casts of hbtf/common/cast.cu.cc:84-285 as a graph-level op (the exchange ops
+// above cast inside hbk_alltoallv_n; this one serves graphs that keep fp16 rows around).
+// ============================================================================================
+REGISTER_OP("HbUniqueN")
+    .Output("unique: N * int64").Output("index: N * int32").Output("n_unique: N * int32")
+    .Input("inputs: N * int64").Attr("N: int >= 1 = 1")
+    .SetShapeFn([](InferenceContext* c) {
+      int64 n;
+      TF_RETURN_IF_ERROR(c->GetAttr("N", &n));
+      for (int64 i = 0; i < n; ++i) {     // capacity outputs: the first n_unique[i][0] ids are valid
+        c->set_output(i, c->input(i));
+        c->set_output(n + i, c->input(i));
+        c->set_output(2 * n + i, c->Vector(1));
+      }
+      return Status::OK();
+    });
+
+class UniqueNOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    OpInputList in;
+    OP_REQUIRES_OK(ctx, ctx->input_list("inputs", &in));
+    const int n = in.size();
+    std::vector<const int64_t*> src(n);
+    std::vector<int64_t*> uniq(n);
+    std::vector<int32_t*> index(n), count(n);
+    std::vector<int64_t> lens(n);
+    for (int i = 0; i < n; ++i) {
+      OP_REQUIRES(ctx, TensorShapeUtils::IsVector(in[i].shape()),
+                  errors::InvalidArgument("Input must be a vector"));
+      Tensor *u, *x, *k;
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, in[i].shape(), &u));
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(n + i, in[i].shape(), &x));
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(2 * n + i, TensorShape({1}), &k));
+      src[i] = reinterpret_cast<const int64_t*>(in[i].flat<int64>().data());
+      uniq[i] = reinterpret_cast<int64_t*>(u->flat<int64>().data());
+      index[i] = x->flat<int32>().data();
+      count[i] = k->flat<int32>().data();
+      lens[i] = in[i].NumElements();
+    }
+    const size_t ws_bytes = hbk_unique_workspace_bytes(n, lens.data());
+    Tensor ws;
+    OP_REQUIRES_OK(ctx, AllocScratch(ctx, ws_bytes, &ws));
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_unique_n(n, src.data(), lens.data(), uniq.data(), index.data(),
+                                               count.data(), ws.flat<int8>().data(), ws_bytes + 16,
+                                               StreamOf(ctx))));
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("HbUniqueN").Device(DEVICE_GPU), UniqueNOp);
+
+REGISTER_OP("HbCastN")
+    .Output("outputs: N * DstT").Input("inputs: N * SrcT")
+    .Attr("N: int >= 1 = 1").Attr("SrcT: {half, float}").Attr("DstT: {half, float}")
+    .SetShapeFn([](InferenceContext* c) {
+      int64 n;
+      TF_RETURN_IF_ERROR(c->GetAttr("N", &n));
+      for (int64 i = 0; i < n; ++i) c->set_output(i, c->input(i));
+      return Status::OK();
+    });
+
+template <typename Src, typename Dst>
+class CastNOp : public OpKernel {
+ public:
+  using OpKernel::OpKernel;
+  void Compute(OpKernelContext* ctx) override {
+    OpInputList in;
+    OP_REQUIRES_OK(ctx, ctx->input_list("inputs", &in));
+    const int n = in.size();
+    std::vector<const void*> src(n);
+    std::vector<void*> dst(n);
+    std::vector<int64_t> lens(n);
+    for (int i = 0; i < n; ++i) {
+      Tensor* o;
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, in[i].shape(), &o));
+      src[i] = in[i].flat<Src>().data();
+      dst[i] = o->flat<Dst>().data();
+      lens[i] = in[i].NumElements();
+    }
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_cast_n(n, HbkType<Src>::v, HbkType<Dst>::v, src.data(),
+                                             lens.data(), dst.data(), StreamOf(ctx))));
+  }
+};
+REGISTER_KERNEL_BUILDER(Name("HbCastN").Device(DEVICE_GPU).TypeConstraint<float>("SrcT")
+                            .TypeConstraint<Eigen::half>("DstT"),
+                        CastNOp<float, Eigen::half>);
+REGISTER_KERNEL_BUILDER(Name("HbCastN").Device(DEVICE_GPU).TypeConstraint<Eigen::half>("SrcT")
+                            .TypeConstraint<float>("DstT"),
+                        CastNOp<Eigen::half, float>);
+
+// ============================================================================================
+// HbShardedGroupLookup / HbShardedGroupLookupGrad / HbShardedGroupLookupGradApply (new, additive):
+// the whole composition of hbtf/embedding/sharding.py:171-205 for N columns as ONE op per
+// direction -- hbk_sharded_lookup_fwd / _bwd, the path every sharded number in profiles/ measures.
+// Conventions of the exchange ops they replace (nccl_alltoallv.cc:359-387): first input = the
+// communicator resource, N-ary lists, run on the communicator's thread pool because the forward
+// waits for the size exchange on the host once.  The forward creates (once, by shared_name) an
+// HbShardedPlan resource that owns the hbk_sharded_t, and hands its handle to the gradient op as
+// an output: the data dependency also orders the backward behind ITS forward.
+// ============================================================================================
+class HbShardedPlan : public ResourceBase {
+ public:
+  HbShardedPlan() : plan_(nullptr) {}
+  ~HbShardedPlan() override {
+    if (plan_ != nullptr) hbk_sharded_destroy(plan_);
+  }
+  // (re)creates the plan when the shards it was made for have moved or changed shape
+  Status Ensure(hbk_comm_t comm, const std::vector<hbk_sharded_column_t>& cols, int32_t wire_dtype) {
+    bool same = plan_ != nullptr && cols.size() == cols_.size();
+    for (size_t i = 0; same && i < cols.size(); ++i) {
+      same = cols[i].shard == cols_[i].shard && cols[i].rows_local == cols_[i].rows_local &&
+             cols[i].dim == cols_[i].dim && cols[i].accum == cols_[i].accum;
+    }
+    if (same) return Status::OK();
+    if (plan_ != nullptr) TF_RETURN_IF_ERROR(HbkStatus(hbk_sharded_destroy(plan_)));
+    plan_ = nullptr;
+    TF_RETURN_IF_ERROR(HbkStatus(
+        hbk_sharded_create(&plan_, comm, static_cast<int32_t>(cols.size()), cols.data(), wire_dtype)));
+    cols_ = cols;
+    return Status::OK();
+  }
+  hbk_sharded_t plan() const { return plan_; }
+  const std::vector<hbk_sharded_column_t>& cols() const { return cols_; }
+  string DebugString() const override { return "HbShardedPlan(libhbk_core)"; }
+
+ private:
+  hbk_sharded_t plan_;
+  std::vector<hbk_sharded_column_t> cols_;
+};
+
+REGISTER_OP("HbShardedGroupLookup")
+    .Output("outputs: N * float").Output("plan: resource")
+    .Input("handle: resource").Input("shards: N * float").Input("accums: M * float")
+    .Input("ids: N * int64").Input("row_splits: N * int32")
+    .Attr("N: int >= 1").Attr("M: int >= 0 = 0")
+    .Attr("buckets: list(int)").Attr("combiners: list(int)").Attr("ragged: list(bool)")
+    .Attr("dedup: list(bool) = []").Attr("hot_rows: list(bool) = []")
+    .Attr("wire_dtype: " HB_WIRE_DTYPES " = DT_FLOAT")
+    .Attr("container: string = ''").Attr("shared_name: string")
+    .SetIsStateful()
+    .SetShapeFn([](InferenceContext* c) {
+      int64 n, m;
+      TF_RETURN_IF_ERROR(c->GetAttr("N", &n));
+      TF_RETURN_IF_ERROR(c->GetAttr("M", &m));
+      std::vector<bool> ragged;
+      TF_RETURN_IF_ERROR(c->GetAttr("ragged", &ragged));
+      for (int64 i = 0; i < n; ++i) {   // inputs: handle, shards [1, 1+n), accums, ids, row_splits
+        shape_inference::ShapeHandle ids = c->input(1 + n + m + i);
+        shape_inference::ShapeHandle splits = c->input(1 + 2 * n + m + i);
+        shape_inference::DimensionHandle segs = c->Dim(ids, 0);
+        if (i < static_cast<int64>(ragged.size()) && ragged[i]) {
+          TF_RETURN_IF_ERROR(c->Subtract(c->Dim(splits, 0), 1, &segs));
+        }
+        c->set_output(i, c->Matrix(segs, c->Dim(c->input(1 + i), 1)));
+      }
+      c->set_output(n, c->Scalar());
+      return Status::OK();
+    });
+
+class ShardedGroupLookupOp : public CollectiveAsyncOp {
+ public:
+  explicit ShardedGroupLookupOp(OpKernelConstruction* ctx) : CollectiveAsyncOp(ctx) {
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("buckets", &buckets_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("combiners", &combiners_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("ragged", &ragged_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("dedup", &dedup_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("hot_rows", &hot_rows_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("container", &container_));
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("shared_name", &name_));
+    DataType wire;
+    OP_REQUIRES_OK(ctx, ctx->GetAttr("wire_dtype", &wire));
+    wire_dtype_ = wire == DT_HALF ? HBK_HALF : HBK_FLOAT;
+  }
+  void Run(OpKernelContext* ctx, HbNcclCollective* coll) override {
+    OpInputList shards, accums, ids, splits;
+    OP_REQUIRES_OK(ctx, ctx->input_list("shards", &shards));
+    OP_REQUIRES_OK(ctx, ctx->input_list("accums", &accums));
+    OP_REQUIRES_OK(ctx, ctx->input_list("ids", &ids));
+    OP_REQUIRES_OK(ctx, ctx->input_list("row_splits", &splits));
+    const int n = shards.size();
+    OP_REQUIRES(ctx, static_cast<int>(buckets_.size()) == n &&
+                         static_cast<int>(combiners_.size()) == n &&
+                         static_cast<int>(ragged_.size()) == n,
+                errors::InvalidArgument("buckets, combiners and ragged must have N entries"));
+    OP_REQUIRES(ctx, accums.size() == 0 || accums.size() == n,
+                errors::InvalidArgument("accums: none, or one accumulator per shard"));
+    std::vector<hbk_sharded_column_t> cols(n);
+    for (int i = 0; i < n; ++i) {
+      std::memset(&cols[i], 0, sizeof(cols[i]));
+      cols[i].shard = shards[i].flat<float>().data();
+      cols[i].rows_local = shards[i].dim_size(0);
+      cols[i].dim = static_cast<int32_t>(shards[i].dim_size(1));
+      cols[i].combiner = combiners_[i];
+      cols[i].bucket = buckets_[i];
+      cols[i].accum = accums.size() ? const_cast<float*>(accums[i].flat<float>().data()) : nullptr;
+      cols[i].hot_rows = i < static_cast<int>(hot_rows_.size()) && hot_rows_[i] ? 1 : 0;
+      cols[i].dedup = i < static_cast<int>(dedup_.size()) && dedup_[i] ? 1 : 0;
+    }
+    const ResourceHandle handle = MakeResourceHandle<HbShardedPlan>(ctx, container_, name_);
+    HbShardedPlan* plan = nullptr;
+    OP_REQUIRES_OK(ctx, LookupOrCreateResource<HbShardedPlan>(
+                            ctx, handle, &plan, [](HbShardedPlan** p) {
+                              *p = new HbShardedPlan();
+                              return Status::OK();
+                            }));
+    core::ScopedUnref unref(plan);
+    OP_REQUIRES_OK(ctx, plan->Ensure(coll->comm(), cols, wire_dtype_));
+    std::vector<const int64_t*> id_ptrs(n);
+    std::vector<const int32_t*> split_ptrs(n);
+    std::vector<int64_t> n_ids(n), n_seg(n);
+    std::vector<float*> outs(n);
+    for (int i = 0; i < n; ++i) {
+      id_ptrs[i] = reinterpret_cast<const int64_t*>(ids[i].flat<int64>().data());
+      n_ids[i] = ids[i].NumElements();
+      split_ptrs[i] = ragged_[i] ? splits[i].flat<int32>().data() : nullptr;
+      n_seg[i] = ragged_[i] ? splits[i].NumElements() - 1 : n_ids[i];
+      Tensor* o;
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(i, TensorShape({n_seg[i], shards[i].dim_size(1)}), &o));
+      outs[i] = o->flat<float>().data();
+    }
+    Tensor* plan_out;
+    OP_REQUIRES_OK(ctx, ctx->allocate_output(n, TensorShape({}), &plan_out));
+    plan_out->scalar<ResourceHandle>()() = handle;
+    OP_REQUIRES_OK(ctx, HbkStatus(hbk_sharded_lookup_fwd(plan->plan(), id_ptrs.data(), n_ids.data(),
+                                                         split_ptrs.data(), n_seg.data(), outs.data(),
+                                                         nullptr, StreamOf(ctx))));
+  }
+
+ private:
+  std::vector<int64> buckets_;
+  std::vector<int32> combiners_;
+  std::vector<bool> ragged_, dedup_, hot_rows_;
+  string container_, name_;
+  int32_t wire_dtype_;
+};
+REGISTER_KERNEL_BUILDER(Name("HbShardedGroupLookup").Device(DEVICE_GPU).HostMemory("plan"),
+                        ShardedGroupLookupOp);
+
+// The backward differentiates the plan's LAST forward (hbk.h): unique_rows / grad_rows have the
+// capacity hbk_sharded_owned_ids(plan, c) -- the ids this rank's shard was asked for -- known on
+// the host after that forward, so the outputs are sized exactly and no host sync happens here.
+REGISTER_OP("HbShardedGroupLookupGrad")
+    .Output("unique_rows: N * int64").Output("grad_rows: N * float").Output("n_unique: N * int32")
+    .Input("handle: resource").Input("plan: resource").Input("grads: N * float")
+    .Attr("N: int >= 1").SetIsStateful()
+    .SetShapeFn([](InferenceContext* c) {
+      int64 n;
+      TF_RETURN_IF_ERROR(c->GetAttr("N", &n));
+      for (int64 i = 0; i < n; ++i) {
+        c->set_output(i, c->Vector(InferenceContext::kUnknownDim));
+        c->set_output(n + i, c->Matrix(InferenceContext::kUnknownDim, c->Dim(c->input(2 + i), 1)));
+        c->set_output(2 * n + i, c->Vector(1));
+      }
+      return Status::OK();
+    });
+REGISTER_OP("HbShardedGroupLookupGradApply")
+    .Output("n_unique: N * int32")
+    .Input("handle: resource").Input("plan: resource").Input("grads: N * float").Input("lr: float")
+    .Attr("N: int >= 1").Attr("optimizer: {'sgd', 'adagrad'} = 'sgd'").SetIsStateful()
+    .SetShapeFn([](InferenceContext* c) {
+      int64 n;
+      TF_RETURN_IF_ERROR(c->GetAttr("N", &n));
+      for (int64 i = 0; i < n; ++i) c->set_output(i, c->Vector(1));
+      return Status::OK();
+    });
+
+template <bool APPLY>
+class ShardedGroupLookupGradOp : public CollectiveAsyncOp {
+ public:
+  explicit ShardedGroupLookupGradOp(OpKernelConstruction* ctx)
+      : CollectiveAsyncOp(ctx), apply_(HBK_APPLY_SGD) {
+    if (APPLY) {
+      string optimizer;
+      OP_REQUIRES_OK(ctx, ctx->GetAttr("optimizer", &optimizer));
+      OP_REQUIRES_OK(ctx, OptimizerCode(optimizer, &apply_));
+    }
+  }
+  void Run(OpKernelContext* ctx, HbNcclCollective* coll) override {
+    HbShardedPlan* plan = nullptr;
+    OP_REQUIRES_OK(ctx, LookupResource(ctx, HandleFromInput(ctx, 1), &plan));
+    core::ScopedUnref unref(plan);
+    OpInputList grads;
+    OP_REQUIRES_OK(ctx, ctx->input_list("grads", &grads));
+    const int n = grads.size();
+    OP_REQUIRES(ctx, plan->plan() != nullptr && static_cast<int>(plan->cols().size()) == n,
+                errors::InvalidArgument("plan was made for ", plan->cols().size(), " columns, got ", n,
+                                        " gradients"));
+    std::vector<const float*> g(n);
+    std::vector<int64_t*> urows(n, nullptr);
+    std::vector<float*> grows(n, nullptr);
+    std::vector<int32_t*> counts(n);
+    for (int i = 0; i < n; ++i) {
+      OP_REQUIRES(ctx, grads[i].dims() == 2 && grads[i].dim_size(1) == plan->cols()[i].dim,
+                  errors::InvalidArgument("gradient ", i, " must be [segments, ", plan->cols()[i].dim, "]"));
+      g[i] = grads[i].flat<float>().data();
+      Tensor* k;
+      if (!APPLY) {
+        const int64 cap = hbk_sharded_owned_ids(plan->plan(), i);
+        OP_REQUIRES(ctx, cap >= 0, errors::Internal("no forward to differentiate: ", hbk_last_error()));
+        Tensor *u, *r;
+        OP_REQUIRES_OK(ctx, ctx->allocate_output(i, TensorShape({cap}), &u));
+        OP_REQUIRES_OK(ctx, ctx->allocate_output(n + i, TensorShape({cap, plan->cols()[i].dim}), &r));
+        urows[i] = reinterpret_cast<int64_t*>(u->flat<int64>().data());
+        grows[i] = r->flat<float>().data();
+      }
+      OP_REQUIRES_OK(ctx, ctx->allocate_output(APPLY ? i : 2 * n + i, TensorShape({1}), &k));
+      counts[i] = k->flat<int32>().data();
+    }
+    float lr = 0.0f;
+    if (APPLY) {
+      const Tensor* t;
+      OP_REQUIRES_OK(ctx, ctx->input("lr", &t));
+      lr = t->scalar<float>()();
+    }
+    if (APPLY) {   // step only: no IndexedSlices are written
+      OP_REQUIRES_OK(ctx, HbkStatus(hbk_sharded_lookup_bwd_apply(plan->plan(), g.data(), nullptr, apply_,
+                                                               lr, nullptr, nullptr, counts.data(),
+                                                               StreamOf(ctx))));
+    } else {
+      OP_REQUIRES_OK(ctx, HbkStatus(hbk_sharded_lookup_bwd(plan->plan(), g.data(), nullptr, 0.0f,
+                                                         urows.data(), grows.data(), counts.data(),
+                                                         StreamOf(ctx))));
+    }
+  }
+
+ private:
+  int32_t apply_;
+};
+REGISTER_KERNEL_BUILDER(
+    Name("HbShardedGroupLookupGrad").Device(DEVICE_GPU).HostMemory("plan"),
+    ShardedGroupLookupGradOp<false>);
+REGISTER_KERNEL_BUILDER(
+    Name("HbShardedGroupLookupGradApply").Device(DEVICE_GPU).HostMemory("plan").HostMemory("lr"),
+    ShardedGroupLookupGradOp<true>);
 
 }  // namespace hybridbackend
 }  // namespace tensorflow

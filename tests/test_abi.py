@@ -355,6 +355,60 @@ def test_tf_shim_parses_and_type_checks():
   assert r.returncode == 0, r.stdout + r.stderr
 
 
+# "C-ABI surface the replacement must export ... the *set* is the contract" -- and
+# north_star: "the C++ REGISTER_OP/REGISTER_KERNEL_BUILDER shim is the only FFI layer", so every
+# entry of that set has to be REACHED by the shim (hbk_cache_lookup is the op-shaped form of
+# hbk_cache_probe: four compacted lists instead of a per-key slot).
+_SECTION_8B = ['hbk_partition_by_modulo_n', 'hbk_partition_by_dual_modulo_n', 'hbk_comm_get_id',
+               'hbk_comm_create', 'hbk_comm_destroy', 'hbk_comm_check_async', 'hbk_alltoall_n',
+               'hbk_alltoallv_n', 'hbk_cast_n', ('hbk_cache_probe', 'hbk_cache_lookup'),
+               'hbk_group_lookup_fwd', 'hbk_group_lookup_bwd', 'hbk_group_lookup_bwd_apply',
+               'hbk_sharded_create', 'hbk_sharded_destroy', 'hbk_sharded_lookup_fwd',
+               'hbk_sharded_lookup_bwd', 'hbk_sharded_lookup_bwd_apply', 'hbk_sharded_owned_ids',
+               'hbk_unique_n', 'hbk_allreduce_n', 'hbk_allgatherv', 'hbk_broadcast',
+               'hbk_partition_workspace_bytes', 'hbk_group_lookup_bwd_workspace_bytes',
+               'hbk_unique_workspace_bytes', 'hbk_alltoallv_wire_workspace_bytes',
+               'hbk_allreduce_workspace_bytes', 'hbk_cache_lookup_workspace_bytes', 'hbk_last_error']
+
+
+def test_tf_shim_registers_a_kernel_for_every_op_and_reaches_the_whole_c_abi():
+  """After preprocessing (the op names of the partition / collective families are built by macros):
+  every REGISTER_OP name has at least one REGISTER_KERNEL_BUILDER -- an op registration without a
+  kernel reads as done and is not (VERDICT r05 "missing" 2: HbGroupLookupGrad was one) -- every
+  kernel names a registered op, and every entry of SURVEY 8(b)'s C-ABI set is called."""
+  import re
+  import shutil
+  import subprocess
+  hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+  if not os.path.exists(hipcc):
+    pytest.skip('no hipcc')
+  shim = os.path.join(ROOT, 'integration', 'tf_shim')
+  r = subprocess.run([hipcc, '-std=c++14', '-E', '-P', '-x', 'c++', '-I' + os.path.join(shim, 'check'),
+                      '-I' + os.path.join(ROOT, 'include'), os.path.join(shim, 'hb_ops_shim.cc')],
+                     capture_output=True, text=True, timeout=300)
+  assert r.returncode == 0, r.stderr
+  text = r.stdout[r.stdout.index('namespace hybridbackend'):]     # (past the headers)
+  lit = r'((?:\s*"[^"]*")+)'
+
+  def names(pattern):
+    return [''.join(re.findall(r'"([^"]*)"', m)) for m in re.findall(pattern + r'\(' + lit, text)]
+  ops = names(r'OpDefBuilderWrapper')
+  kernels = names(r'\bName')
+  assert len(ops) == len(set(ops)) and len(ops) >= 29, ops
+  for must in ('HbPartitionByModuloN', 'HbPartitionByDualModuloStageTwoN', 'HbNcclAlltoallvN',
+               'HbGroupLookup', 'HbGroupLookupGrad', 'HbGroupLookupGradApply', 'HbShardedGroupLookup',
+               'HbShardedGroupLookupGrad', 'HbShardedGroupLookupGradApply', 'HbUniqueN', 'HbCastN',
+               'HbLookup', 'HbNcclCollectiveHandleOp'):
+    assert must in ops, must
+  assert sorted(set(ops) - set(kernels)) == [], 'ops registered without a kernel'
+  assert sorted(set(kernels) - set(ops)) == [], 'kernels for ops that are not registered'
+  body = open(os.path.join(shim, 'hb_ops_shim.cc')).read()
+  body = re.sub(r'//[^\n]*', '', body)                             # calls, not comments
+  for entry in _SECTION_8B:
+    alternatives = entry if isinstance(entry, tuple) else (entry,)
+    assert any(re.search(r'\b' + e + r'\(', body) for e in alternatives), f'{entry} is never called'
+
+
 def test_tables_layout_puts_every_table_on_a_2mb_boundary():
   """hbk_tables_layout (host arithmetic of hbk_tables_alloc / hb.embedding.allocate_tables): one
   slab, 2 MB-aligned offsets -- the policy profiles/r05_placement.txt measured as the fastest."""

@@ -46,15 +46,19 @@ for st in $STAGES; do
         d=$(mktemp -d); HBK_TEST_RATIO_LOG=$O/seed400_ratios.txt timeout 300 python tests/support/multi_worker.py --rank 0 --world 1 --dir $d --cases dedup > $O/seed400_last.log 2>&1 || { echo "process $i FAILED"; tail -20 $O/seed400_last.log; }
         rm -rf $d
       done
-      python - <<PY
+      python - <<PY | tee $O/seed400_summary.txt
 import re
 rows=[l for l in open('$O/seed400_ratios.txt')]
-r=[float(re.search(r'worst_ratio=([0-9.e+-]+)',l).group(1)) for l in rows]
+ratio=lambda l: float(re.search(r'worst_ratio=([0-9.e+-]+)',l).group(1))
 pids={l.split()[0] for l in rows}
-print(f'{len(rows)} checks in {len(pids)} processes; worst |diff| / sum|terms| overall = {max(r):.3e} (bound 1e-5); ')
+f16=[l for l in rows if 'fp16' in l]; f32=[l for l in rows if 'fp16' not in l]
+print(f'{len(rows)} checks in {len(pids)} fresh processes (tests/support/multi_worker.py --world 1 --cases dedup)')
+print(f'fp32 checks: {len(f32)}, worst |diff| / sum|terms| = {max(map(ratio,f32)):.3e} (bound 1e-5 + 1e-6 floor)')
+print(f'fp16-wire checks: {len(f16)}, worst = {max(map(ratio,f16)):.3e} (bound 2e-3)')
 bd=[l for l in rows if 'backward' in l and 'Zipf' in l]
-rb=[float(re.search(r'worst_ratio=([0-9.e+-]+)',l).group(1)) for l in bd]
-print(f'seed-400 backward checks: {len(bd)}, worst ratio {max(rb):.3e}, median {sorted(rb)[len(rb)//2]:.3e}')
+rb=sorted(map(ratio,bd))
+print(f"seed-400 backward checks (the r05 failure, 'requester-side dedup, Zipf ids'): {len(bd)}, worst ratio {rb[-1]:.3e}, median {rb[len(rb)//2]:.3e}")
+w=max(bd,key=ratio); print('worst line:', w.strip())
 PY
       ;;
     smoke)

@@ -91,7 +91,9 @@ def parse_args():
                       'rank (--sharded) only -- across processes the form maps peer memory through '
                       'hipIpc*, which has not run on this hardware yet; on: at any N')
   p.add_argument('--no-secondary', action='store_true',
-                 help='N > 1 (or --sharded): skip the two reference measurements that follow the '
+                 help='N = 1: skip the backward family behind the headline (config.secondary_steps: '
+                      'emit / + SGD / step only / ragged, ~2 s).  '
+                      'N > 1 (or --sharded): skip the two reference measurements that follow the '
                       'headline steps -- the other wire format, and every rank holding ALL tables '
                       '(replicated, no exchange: SURVEY 8e "report replicated as a reference line")')
   p.add_argument('--link-probe-mb', type=float, default=16.0,
@@ -284,6 +286,83 @@ def cpu_baseline(args, tables, id_batch, budget_s):
     'single_thread': {
       'value': round(p1 * cols * args.batch / el1 / 1e6, 3), 'unit': 'M-lookups/sec', 'cores': 1,
       'sample': f'{p1} passes of the same batch on one thread ({el1:.1f} s)'}}
+
+
+def backward_secondary(args, hb, tables, batches, device, timed_steps, steps=20, warmup=5):
+  """The backward family behind the headline, in the driver-timed line (north_star
+  names "the backward scatter-add" as a hot-path function): config 2's backward through the same
+  bracket as the headline steps --
+
+    bwd_emit       d(combiner) -> duplicate-row reduction -> IndexedSlices (unique rows, summed rows)
+    bwd_sgd        the same + the fused sparse SGD step on the tables
+    bwd_step_only  the fused step alone, no IndexedSlices written
+    bwd_ragged     26 columns x batch segments of Poisson(8) ids clipped to [0, 32] (SURVEY 8d's
+                   multi-hot variant), mean combiner, IndexedSlices
+
+  Every call reads another resident id batch (tables 1.66 GB, 4-8 batches: nothing is served from the
+  Infinity Cache by repetition).  `frac` = algorithmic bytes / time / 8 TB/s with SURVEY 8(d)'s
+  bytes_bwd = n*8 (ids) + S*4D (gradient rows read) + u*(2*4D) (row read-modify-write), u = the
+  distinct rows the call itself reported (n_unique); a case that writes IndexedSlices moves
+  u*(4D + 8) for them (instead of, or with the step, on top of, the read-modify-write); ragged adds
+  the (S+1)*4 row splits."""
+  cols, dim, batch = args.columns, args.dim, args.batch
+  pool = min(len(batches), 8)
+  gen = torch.Generator(device=device)
+  gen.manual_seed(777)
+  out = {}
+
+  def run(name, ids_pool, splits, n_seg, combiner, lr, emit):
+    grads = [torch.randn(n_seg[c], dim, device=device, generator=gen) for c in range(cols)]
+    lookup = hb.embedding.GroupLookup(tables, buckets=[args.rows] * cols, combiners=combiner)
+    # one gradient object per resident batch: handed the same tensors again, a call re-binds nothing
+    objs = [hb.embedding.GroupLookupGrad(lookup) for _ in ids_pool]
+
+    def step(i):
+      k = i % len(ids_pool)
+      objs[k](ids_pool[k], grads, splits, apply_lr=lr, emit=emit)
+    el, ms = timed_steps(step, steps, warmup)
+    res = objs[0](ids_pool[0], grads, splits, apply_lr=lr, emit=emit)
+    torch.cuda.synchronize()
+    n = sum(int(i.numel()) for i in ids_pool[0])
+    seg = sum(n_seg)
+    u = sum(int(r[2].item()) for r in res)
+    nbytes = n * 8 + seg * 4 * dim + (0 if splits is None else 4 * (seg + cols))
+    if emit:
+      nbytes += u * (4 * dim + 8)
+    if lr != 0.0:
+      nbytes += u * 2 * 4 * dim
+    wall_ms = el / steps * 1e3
+    out[name] = {'ms': round(wall_ms, 5), 'event_ms': round(ms / steps, 5), 'ids': n,
+                 'distinct_rows': u, 'bytes': nbytes,
+                 'frac': round(nbytes / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del objs, grads
+
+  flat = [batches[b] for b in range(pool)]
+  one = [batch] * cols
+  run('bwd_emit', flat, None, one, 'sum', 0.0, True)
+  run('bwd_sgd', flat, None, one, 'sum', 1e-4, True)
+  run('bwd_step_only', flat, None, one, 'sum', 1e-4, False)
+  # ragged: Poisson(8) clipped to [0, 32] ids per segment (the splits are shared by the batches)
+  rng = np.random.RandomState(4242)
+  splits, counts = [], []
+  for c in range(cols):
+    lens = rng.poisson(8, size=batch).clip(0, 32)
+    sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    splits.append(torch.from_numpy(sp).to(device))
+    counts.append(int(sp[-1]))
+  ragged = []
+  for b in range(min(pool, 4)):
+    g = torch.Generator(device=device)
+    g.manual_seed(9000 + b)
+    ragged.append([torch.randint(0, 1 << 40, (counts[c],), device=device, dtype=torch.int64,
+                                 generator=g) for c in range(cols)])
+  run('bwd_ragged', ragged, splits, one, 'mean', 0.0, True)
+  out['steps'] = steps
+  out['warmup'] = warmup
+  out['id_batches'] = pool
+  out['bytes_formula'] = ('n*8 + S*4D + [emit] u*(4D+8) + [step] u*2*4D (+ (S+1)*4 per ragged '
+                          'column); SURVEY 8(d) bytes_bwd, u = n_unique of the call')
+  return out
 
 
 def load_traffic(config_key):
@@ -619,6 +698,13 @@ def main():
         'link_probe': probe,
         'rccl': rccl_versions(),
         'note': 'the sharded step is link-bound (DESIGN.md 5): one xGMI link per peer pair'}
+    if world == 1 and not args.sharded and not args.no_secondary:
+      # the backward family through the same bracket (after the headline: the SGD cases step the tables)
+      try:
+        result['config']['secondary_steps'] = backward_secondary(args, hb, tables, batches, device,
+                                                                 timed_steps)
+      except Exception as e:  # pylint: disable=broad-except
+        result['config']['secondary_error'] = f'{type(e).__name__}: {e}'[:300]
     if world == 1 and not args.sharded and args.cpu_seconds > 0:
       result['cpu_baseline'] = cpu_baseline(args, tables, batches[0], args.cpu_seconds)
     else:
@@ -661,7 +747,7 @@ def main():
         'other_wire': other,
         'other_wire_M_lookups_per_s': round(per_step * sec_steps / el2 / 1e6, 3),
         'other_wire_ms_per_step': round(el2 / sec_steps * 1e3, 5),
-        'secondary_steps': sec_steps}
+        'secondary_steps': {'steps': sec_steps, 'warmup': sec_warm}}
       del r_plans, full
     except Exception as e:  # pylint: disable=broad-except
       # (every rank runs the same code on the same shapes: an error here is the same error on

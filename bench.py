@@ -56,6 +56,42 @@ SECONDARY_KEYS = ('replicated_M_lookups_per_s', 'replicated_ms_per_step',
                   'secondary_steps')
 
 
+# the step forms the probe in front of the timed steps runs at N > 1 (or --sharded); the timed steps
+# run in the fastest of the first four, 'pipelined_steps_3' (three plans, begin(i + 1) before end(i):
+# outputs arrive one step late, forward-only use) is a reference
+FORM_KEYS = ('pipelined_2_groups', 'one_group', 'inline', 'p2p', 'pipelined_steps_3')
+# what an N > 1 line carries under 'xgmi'
+XGMI_KEYS = ('bytes_out_per_rank_per_step', 'links_per_rank', 'achieved_GBps_per_rank_each_way',
+             'link_probe', 'link_bound', 'rccl', 'note')
+
+
+def multi_gpu_skeleton():
+  """Every key a measured N > 1 line carries next to the headline, with nothing measured: what
+  `--dry-run` prints (tests/test_bench_launcher.py checks the names for N = 2, 4, 8, so the first
+  multi-GPU box cannot be met by a line that lacks one)."""
+  config = {key: None for key in SECONDARY_KEYS}
+  config.update({'rccl_ranks_seen': None, 'sharded_form': None,
+                 'sharded_form_probe_ms_per_step': {key: None for key in FORM_KEYS},
+                 'value_at_shipped_default_M_lookups_per_s': None, 'wire': None,
+                 'prefetch_next_partition': None})
+  return config, {key: None for key in XGMI_KEYS}
+
+
+def link_bound(args, world, probe, lookups_per_step_per_rank):
+  """The ceiling the measured links put on the sharded step: uniform ids send 1/W of a
+  rank's lookups to every peer over that peer's own link -- int32 ids out, fp32 | fp16 rows back
+  (each way carries ids + rows of one of the two ranks) -- at the per-link rate the probe measured."""
+  if not probe or not probe.get('GBps_per_link_each_way'):
+    return None
+  id_b = 4 if args.rows <= 0x7fffffff else 8
+  row_b = args.dim * (2 if args.wire == 'fp16' else 4)
+  per_peer = lookups_per_step_per_rank / world * (id_b + row_b)
+  sec = per_peer / (probe['GBps_per_link_each_way'] * 1e9)
+  return {'bytes_per_link_each_way_per_step': int(per_peer), 'us_per_step': round(sec * 1e6, 1),
+          'M_lookups_per_s': round(lookups_per_step_per_rank * world / sec / 1e6, 1),
+          'from': 'link_probe.GBps_per_link_each_way'}
+
+
 def parse_args():
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
@@ -445,7 +481,7 @@ def main():
       line['dry_run'] = True
       line['ranks'] = world
       # the keys a measured N > 1 line carries next to the headline (nothing measured here)
-      line['config'] = {key: None for key in SECONDARY_KEYS}
+      line['config'], line['xgmi'] = multi_gpu_skeleton()
       line['max_rank_sleep_ms'] = round(el * 1e3, 2)
       print(json.dumps(line), flush=True)
     if use_dist:
@@ -555,6 +591,46 @@ def main():
         dt = float(t.item())
       groups_probe[name] = round(dt / args.tune_steps * 1e3, 5)
     best_form = min((k for k, v in groups_probe.items() if v is not None), key=groups_probe.get)
+    # reference: three plans over the one communicator, begin(step i + 1) before end(step i)
+    # (hb.embedding.PipelinedLookup): ids(i + 1) travel ahead of rows(i).  Outputs arrive one step
+    # late (forward-only use), so the timed steps never run in this form.
+    groups_probe['pipelined_steps_3'] = None
+    try:
+      sharded.close()
+      _hbk.set_option('sharded_groups', 1)
+      plans3 = [hb.embedding.ShardedGroupLookup(
+          tables, coll, buckets=[args.rows] * args.columns, combiners='sum',
+          wire_dtype=torch.float16 if args.wire == 'fp16' else None) for _ in range(3)]
+      pipe = hb.embedding.PipelinedLookup(plans3)
+      outs3 = [sh_outs] + [[torch.empty_like(o) for o in sh_outs] for _ in range(2)]
+      nb3 = min(n_batches, 8)
+      bounds3 = [[pipe.bind(k, batches[b], None, outs3[k]) for b in range(nb3)] for k in range(3)]
+
+      def step3(i):
+        k = pipe.next_plan()
+        pipe.step(bounds3[k][i % nb3], prefetch=None if args.no_prefetch else bounds3[k][(i + 3) % nb3])
+      for i in range(6):
+        step3(i)
+      pipe.flush()
+      torch.cuda.synchronize()
+      barrier()
+      t_probe = time.perf_counter()
+      for i in range(args.tune_steps):
+        step3(6 + i)
+      pipe.flush()
+      torch.cuda.synchronize()
+      barrier()
+      dt = time.perf_counter() - t_probe
+      if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+      groups_probe['pipelined_steps_3'] = round(dt / args.tune_steps * 1e3, 5)
+      pipe.close()
+      del plans3, pipe, outs3, bounds3
+    except Exception as e:  # pylint: disable=broad-except
+      # (the same code on every rank: the same error on every rank; a reference only)
+      groups_probe['pipelined_steps_3_error'] = f'{type(e).__name__}: {e}'[:200]
     _hbk.set_option('sharded_groups', forms[best_form][0])
     _hbk.set_option('sharded_inline', forms[best_form][1])
     sharded.close()
@@ -696,6 +772,8 @@ def main():
         'bytes_out_per_rank_per_step': int(link_bytes), 'links_per_rank': world - 1,
         'achieved_GBps_per_rank_each_way': round(link_bytes / (elapsed / args.steps) / 1e9, 2),
         'link_probe': probe,
+        # what those links allow at best, to read the value against
+        'link_bound': link_bound(args, world, probe, lookups_per_step_per_rank),
         'rccl': rccl_versions(),
         'note': 'the sharded step is link-bound (DESIGN.md 5): one xGMI link per peer pair'}
     if world == 1 and not args.sharded and not args.no_secondary:

@@ -90,7 +90,7 @@ def _declare(l):
     'hbk_get_option': (C.c_int, [C.c_char_p, vp]),
     'hbk_comm_rccl_ranks': (C.c_int, [vp]),
     'hbk_broadcast': (C.c_int, [vp, i32, vp, vp, i64, i32, vp]),
-    'hbk_sharded_p2p_bind': (C.c_int, [vp, vp, vp, vp]),
+    'hbk_sharded_p2p_bind': (C.c_int, [vp, vp, vp, vp, vp]),
     'hbk_sharded_p2p_unbind': (C.c_int, [vp]),
     'hbk_sync_check': (C.c_int, []),
     'hbk_sync_check_stream': (C.c_int, [C.c_void_p]),

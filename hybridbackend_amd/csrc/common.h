@@ -173,6 +173,8 @@ struct Options {
                                  // modelled wire the column-group pipeline (0) lost to it in every case -- a cross-stream hop costs ~11 us, three per group, more than a group hides
                                  // (profiles/r05_overlap_model.txt)
   int sharded_p2p = 1;           // HBK_SHARDED_P2P: plans whose outputs were registered (hbk_sharded_p2p_bind) run the p2p form of the step (0: never)
+  int sharded_p2p_test_refuse = -1;  // HBK_SHARDED_P2P_TEST_REFUSE: test hook, the rank whose hbk_sharded_p2p_bind finds "a peer's memory cannot be mapped"
+                                     // (what a driver without hipIpc* support answers): every rank must then fall back to the exchange form
   int sync_wait_ms = 2000;       // HBK_SYNC_WAIT_MS: bound of a wait between the tiles of a one-launch kernel
   int sync_onepass_off = 0;      // HBK_SYNC_ONEPASS_OFF: 1 = multi-launch forms only (set by a wait that ran out)
   int sync_test_withhold = -1;   // HBK_SYNC_TEST_WITHHOLD: test hook, the tile that never publishes its counts

@@ -60,6 +60,7 @@ const OptionEntry kOptions[] = {
     {"sharded_trace", "HBK_SHARDED_TRACE", &Options::sharded_trace},
     {"sharded_inline", "HBK_SHARDED_INLINE", &Options::sharded_inline},
     {"sharded_p2p", "HBK_SHARDED_P2P", &Options::sharded_p2p},
+    {"sharded_p2p_test_refuse", "HBK_SHARDED_P2P_TEST_REFUSE", &Options::sharded_p2p_test_refuse},
     {"sharded_wire_fused", "HBK_SHARDED_WIRE_FUSED", &Options::sharded_wire_fused},
     {"sharded_pack_early", "HBK_SHARDED_PACK_EARLY", &Options::sharded_pack_early},
     {"sync_wait_ms", "HBK_SYNC_WAIT_MS", &Options::sync_wait_ms},
@@ -123,6 +124,10 @@ extern "C" const char* hbk_version(void) { return "hbk 0.1.0 gfx950"; }
 extern "C" size_t hbk_tables_layout(int32_t n, const size_t* bytes, size_t* offsets) {
   const size_t kAlign = (size_t)2 << 20;
   size_t total = 0;
+  if (n > 0 && bytes == nullptr) {   // (the size is the only return value: 0 = nothing laid out)
+    (void)hbk::fail(HBK_INVALID_ARGUMENT, "tables_layout: bytes is NULL");
+    return 0;
+  }
   for (int32_t i = 0; i < n; ++i) {
     if (offsets != nullptr) offsets[i] = total;
     total += (bytes[i] + kAlign - 1) / kAlign * kAlign;

@@ -25,6 +25,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <random>
 #include <utility>
 #include <vector>
 
@@ -574,6 +575,7 @@ struct hbk_sharded {
   bool p2p_bound = false;
   std::vector<float*> p2p_outs;         // [N] this rank's registered outputs
   std::vector<int32_t> p2p_strides;     // [N] their row strides (floats)
+  std::vector<int64_t> p2p_rows;        // [N] their rows: remote owners store at slots < n_ids[c]
   std::vector<float*> peer_out;         // [W][N]
   std::vector<int32_t> peer_stride;     // [W][N]
   std::vector<void*> ipc_opened;        // mappings to close
@@ -890,13 +892,48 @@ int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* cons
 namespace hbk {
 namespace {
 struct P2pRec {
+  // who owns the tensor: pid alone is not an identity (ranks in different containers or pid
+  // namespaces collide on small pids), so a record also carries a hash of the host's boot id /
+  // name and a random number drawn once per process; two ranks share an address space only when
+  // all three agree
   uint64_t pid;
+  uint64_t host;
+  uint64_t nonce;
+  int32_t device;     // the owner's HIP device (ranks of one process may sit on different ones)
+  int32_t pad;
+  int64_t rows;       // rows of the registered tensor
   uint64_t ptr;       // the output tensor in its owner's address space
   uint64_t offset;    // ... and inside the allocation the handle names
   int32_t stride;
   int32_t has_handle;
   hipIpcMemHandle_t handle;
 };
+uint64_t fnv1a(const char* s, size_t n, uint64_t h = 1469598103934665603ull) {
+  for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)s[i]) * 1099511628211ull;
+  return h;
+}
+// (boot id of the kernel this process runs on + host name: equal for the ranks of one machine)
+uint64_t host_identity() {
+  char buf[256];
+  uint64_t h = 1469598103934665603ull;
+  FILE* f = fopen("/proc/sys/kernel/random/boot_id", "r");
+  if (f != nullptr) {
+    const size_t n = fread(buf, 1, sizeof(buf), f);
+    fclose(f);
+    h = fnv1a(buf, n, h);
+  }
+  if (gethostname(buf, sizeof(buf)) == 0) h = fnv1a(buf, strnlen(buf, sizeof(buf)), h);
+  return h;
+}
+uint64_t process_nonce() {
+  static const uint64_t nonce = [] {
+    std::random_device rd;
+    uint64_t v = ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+    v ^= (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9e3779b97f4a7c15ull;
+    return v | 1ull;
+  }();
+  return nonce;
+}
 }  // namespace
 }  // namespace hbk
 
@@ -906,9 +943,10 @@ struct P2pRec {
 // HBK_UNIMPLEMENTED (on every rank) when some peer's memory cannot be mapped here -- the plan
 // then keeps the exchange form.
 extern "C" int hbk_sharded_p2p_bind(hbk_sharded_t p, float* const* outs, const int32_t* out_strides,
-                                    hbk_stream_t stream_) {
+                                    const int64_t* out_rows, hbk_stream_t stream_) {
   using namespace hbk;
-  HBK_REQUIRE(p != nullptr && outs != nullptr, "sharded_p2p_bind: NULL argument");
+  HBK_REQUIRE(p != nullptr && outs != nullptr && out_rows != nullptr,
+              "sharded_p2p_bind: NULL argument");
   hipStream_t stream = as_stream(stream_);
   const int N = p->N, W = p->W, me = p->rank;
   p->p2p_bound = false;
@@ -920,12 +958,19 @@ extern "C" int hbk_sharded_p2p_bind(hbk_sharded_t p, float* const* outs, const i
   for (void* m : p->ipc_opened) (void)hipIpcCloseMemHandle(m);
   p->ipc_opened.clear();
   std::vector<P2pRec> mine((size_t)N), all((size_t)N * W);
-  const uint64_t pid = (uint64_t)getpid();
+  const uint64_t pid = (uint64_t)getpid(), host = host_identity(), nonce = process_nonce();
+  int my_device = 0;
+  HBK_HIP_OK(hipGetDevice(&my_device));
   for (int c = 0; c < N; ++c) {
     HBK_REQUIRE(outs[c] != nullptr, "sharded_p2p_bind: outs[%d] is NULL", c);
+    HBK_REQUIRE(out_rows[c] >= 0 && out_rows[c] < (1ll << 31), "sharded_p2p_bind: bad out_rows[%d]", c);
     P2pRec& r = mine[c];
     memset(&r, 0, sizeof(r));
     r.pid = pid;
+    r.host = host;
+    r.nonce = nonce;
+    r.device = my_device;
+    r.rows = out_rows[c];
     r.ptr = (uint64_t)(uintptr_t)outs[c];
     r.stride = out_strides != nullptr && out_strides[c] > 0 ? out_strides[c] : p->cols[c].dim;
     if (W > 1) {
@@ -958,9 +1003,28 @@ extern "C" int hbk_sharded_p2p_bind(hbk_sharded_t p, float* const* outs, const i
     for (int c = 0; c < N && ok; ++c) {
       const P2pRec& r = all[(size_t)q * N + c];
       p->peer_stride[(size_t)q * N + c] = r.stride;
-      if (q == me || r.pid == pid) {   // the same address space (in-process ranks, this rank itself)
+      const bool same_process = r.pid == pid && r.host == host && r.nonce == nonce;
+      if (q == me || same_process) {   // the same address space (in-process ranks, this rank itself)
+        if (r.device != my_device) {
+          // an in-process rank on another GPU: its pointer is valid here only with peer access
+          int can = 0;
+          hipError_t e = hipDeviceCanAccessPeer(&can, my_device, r.device);
+          if (e == hipSuccess && can) {
+            e = hipDeviceEnablePeerAccess(r.device, 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
+          }
+          (void)hipGetLastError();
+          if (e != hipSuccess || !can) {
+            ok = 0;
+            break;
+          }
+        }
         p->peer_out[(size_t)q * N + c] = reinterpret_cast<float*>((uintptr_t)r.ptr);
         continue;
+      }
+      if (r.host != host) {   // another machine: nothing to map (IPC handles are per host)
+        ok = 0;
+        break;
       }
       if (!r.has_handle) {
         ok = 0;
@@ -983,6 +1047,7 @@ extern "C" int hbk_sharded_p2p_bind(hbk_sharded_t p, float* const* outs, const i
           reinterpret_cast<float*>(reinterpret_cast<char*>(base) + r.offset);
     }
   }
+  if (options().sharded_p2p_test_refuse == me) ok = 0;   // test hook: "hipIpcOpenMemHandle refused"
   // every rank must come to the same answer: the minimum over the ranks of "all mapped"
   if (W > 1) {
     int32_t* d_ok = reinterpret_cast<int32_t*>(d_mine);
@@ -1012,6 +1077,7 @@ extern "C" int hbk_sharded_p2p_bind(hbk_sharded_t p, float* const* outs, const i
   }
   p->p2p_outs.assign(outs, outs + N);
   p->p2p_strides.resize((size_t)N);
+  p->p2p_rows.assign(out_rows, out_rows + N);
   for (int c = 0; c < N; ++c) p->p2p_strides[c] = mine[c].stride;
   p->p2p_bound = true;
   return HBK_OK;
@@ -1138,6 +1204,11 @@ extern "C" int hbk_sharded_lookup_fwd_begin(hbk_sharded_t p, const int64_t* cons
       HBK_REQUIRE(p->row_splits[c] == nullptr,
                   "sharded_lookup_fwd: column %d is ragged: a plan with registered outputs "
                   "(hbk_sharded_p2p_bind) takes one id per segment; unbind it first", c);
+      // the owners store row j of this step at slot j of the REGISTERED tensor, from other ranks:
+      // a batch larger than what was registered would be written out of bounds in this rank's memory
+      HBK_REQUIRE(n_ids[c] <= p->p2p_rows[c],
+                  "sharded_lookup_fwd: column %d: %lld ids for a registered output of %lld rows "
+                  "(hbk_sharded_p2p_bind)", c, (long long)n_ids[c], (long long)p->p2p_rows[c]);
     }
   }
   std::vector<Group>& groups = p->groups;

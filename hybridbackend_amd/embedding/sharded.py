@@ -24,6 +24,7 @@ cost tens of microseconds).  The compute phases also exist as separate methods s
 drive W virtual ranks through the kernels with its own transport.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -41,6 +42,12 @@ class _Step:
   def __init__(self):
     for s in self.__slots__:
       setattr(self, s, None)
+
+
+# plans read the process-wide sharded_* options when they are created: creating one under a
+# temporarily changed option (PipelinedLookup) must not interleave with another thread's creation
+# (in-process ranks are host threads)
+_PLAN_LOCK = threading.RLock()
 
 
 class _BoundStep:
@@ -141,27 +148,31 @@ class ShardedGroupLookup:
   # ---- the whole forward: ONE C-ABI call (hbk_sharded_lookup_fwd, csrc/sharded.hip) ----------
   def _plan(self):
     if getattr(self, '_plan_handle', None) is None:
-      from hybridbackend_amd.embedding.lookup import _combiner_code
-      n = len(self.shards)
-      combs = self.combiners
-      if isinstance(combs, (str, int)) or combs is None:
-        combs = [combs] * n
-      cols = (_lib.ShardedColumn * n)()
-      for c, t in enumerate(self.shards):
-        cols[c].shard = t.data_ptr()
-        cols[c].rows_local = t.shape[0]
-        cols[c].dim = t.shape[1]
-        cols[c].combiner = _combiner_code(combs[c])
-        cols[c].bucket = self.buckets[c]
-        cols[c].hot_rows = 1 if self.hot_rows[c] else 0
-        cols[c].dedup = 1 if self.dedup[c] else 0
-        if self.accums is not None:
-          cols[c].accum = self.accums[c].data_ptr()
-      self._plan_handle = C.c_void_p()
-      wire = _lib.HALF if self.wire_dtype == torch.float16 else _lib.FLOAT
-      _lib.check(self._lib.hbk_sharded_create(
-        C.byref(self._plan_handle), self.coll._handle, n, cols, wire))
+      with _PLAN_LOCK:
+        self._create_plan()
     return self._plan_handle
+
+  def _create_plan(self):
+    from hybridbackend_amd.embedding.lookup import _combiner_code
+    n = len(self.shards)
+    combs = self.combiners
+    if isinstance(combs, (str, int)) or combs is None:
+      combs = [combs] * n
+    cols = (_lib.ShardedColumn * n)()
+    for c, t in enumerate(self.shards):
+      cols[c].shard = t.data_ptr()
+      cols[c].rows_local = t.shape[0]
+      cols[c].dim = t.shape[1]
+      cols[c].combiner = _combiner_code(combs[c])
+      cols[c].bucket = self.buckets[c]
+      cols[c].hot_rows = 1 if self.hot_rows[c] else 0
+      cols[c].dedup = 1 if self.dedup[c] else 0
+      if self.accums is not None:
+        cols[c].accum = self.accums[c].data_ptr()
+    self._plan_handle = C.c_void_p()
+    wire = _lib.HALF if self.wire_dtype == torch.float16 else _lib.FLOAT
+    _lib.check(self._lib.hbk_sharded_create(
+      C.byref(self._plan_handle), self.coll._handle, n, cols, wire))
 
   def last_host_us(self):
     """Host time of the last forward step in microseconds: (enqueueing the partition and the
@@ -188,8 +199,9 @@ class ShardedGroupLookup:
       if o.dtype != torch.float32 or o.dim() != 2 or o.shape[1] != self.dims[c]:
         raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, f'p2p_bind: output {c} must be fp32 [*, {self.dims[c]}]')
     strides = (C.c_int32 * n)(*[0 if o.is_contiguous() else int(o.stride(0)) for o in outs])
+    rows = _lib.i64_array([int(o.shape[0]) for o in outs])
     rc = self._lib.hbk_sharded_p2p_bind(self._plan(), _lib.ptr_array([o.data_ptr() for o in outs]),
-                                        strides, _lib.current_stream(self.device))
+                                        strides, rows, _lib.current_stream(self.device))
     if rc == _lib.UNIMPLEMENTED:
       self._p2p_keep = None
       return False
@@ -515,15 +527,35 @@ class PipelinedLookup:
   trainer): nothing may update the tables between a step's begin and its end.  Every rank makes the
   same calls in the same order.
 
-  ``plans``: the ShardedGroupLookup objects (option ``sharded_inline`` = 0 when they were created,
-  so that their exchanges run on the communicator's stream).  ``bind(k, ids, row_splits, outs)``
-  marshals a step for plan ``k``; ``step(bound)`` takes the bound steps of plans 0, 1, 0, 1 ...
+  ``plans``: the ShardedGroupLookup objects.  Their exchanges must run on the communicator's stream
+  (option ``sharded_inline`` = 0, read when a plan is created; the library's default is 1): the
+  constructor (re)creates every plan under that option and restores the caller's value, so a
+  pipeline built with defaults overlaps instead of silently serialising.
+  ``bind(k, ids, row_splits, outs)`` marshals a step for plan ``k``; ``step(bound)`` takes the bound
+  steps of plans 0, 1, 0, 1 ...
+
+  Stream order: every plan runs on a private stream.  ``step`` makes that stream wait
+  for the caller's current stream first -- the ids, row splits and outputs handed to ``bind`` may
+  have been produced there -- and marks the step's tensors as used on the private stream
+  (``record_stream``), so the caching allocator cannot hand them out again before the step is done.
   """
 
-  def __init__(self, plans):
+  def __init__(self, plans, stream_exchanges=True):
+    """stream_exchanges=False keeps the plans as they were created (e.g. inline exchanges: the
+    pipeline is then correct but serialises)."""
     if len(plans) < 2:
       raise ValueError('PipelinedLookup needs at least two plans')
     self.plans = list(plans)
+    if stream_exchanges:
+      with _PLAN_LOCK:
+        old = _lib.set_option('sharded_inline', 0)
+        try:
+          for p in self.plans:
+            if getattr(p, '_p2p_keep', None) is None:
+              p.close()      # (a plan with registered outputs keeps them: its step has no rows exchange)
+            p._plan()        # pylint: disable=protected-access
+        finally:
+          _lib.set_option('sharded_inline', old)
     self.streams = [torch.cuda.Stream(device=p.device) for p in self.plans]
     self._open = None      # (plan index, bound step) begun and not ended
     self._next = 0
@@ -542,6 +574,11 @@ class PipelinedLookup:
     the bound step this plan will be handed next (its partition runs ahead)."""
     k = self._next
     self._next = (k + 1) % len(self.plans)
+    caller = torch.cuda.current_stream(self.plans[k].device)
+    self.streams[k].wait_stream(caller)       # the step's inputs may still be in flight there
+    for b in (bound, prefetch):
+      if b is not None:
+        self._used_on(b, self.streams[k])
     with torch.cuda.stream(self.streams[k]):
       self.plans[k].launch_begin(bound)
       if prefetch is not None:
@@ -551,6 +588,13 @@ class PipelinedLookup:
     finished = self._finish()
     self._open = (k, bound)
     return finished
+
+  @staticmethod
+  def _used_on(bound, stream):
+    for group in bound.keep:
+      for t in group:
+        if t is not None and t.is_cuda:
+          t.record_stream(stream)
 
   def _finish(self):
     if self._open is None:

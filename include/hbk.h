@@ -86,6 +86,7 @@ int hbk_tables_free(void* slab);
  * bwd_pairs_packed, bwd_seg_inline, bwd_scale_fused, bwd_scatter_staged, bwd_rowsort_pos, bwd_rowsort_ratio (round 5: x 4 for dim <= 32),
  * bwd_streams (launch groups of > 64 columns rotate over this many library streams; 0: the caller's), bwd_large_first,
  * bwd_trace (the launch groups of every backward call on stderr), bwd_lds_pad (a probe), sharded_p2p,
+ * sharded_p2p_test_refuse (test hook: the rank whose hbk_sharded_p2p_bind behaves as if a peer's memory could not be mapped),
  * unique_buckets_log2,
  * unique_onepass, partition_sub_tiles, partition_fixed_max, partition_onepass, sharded_groups,
  * sharded_id64, sharded_copy_self, sharded_trace, sharded_inline, sharded_wire_fused, sharded_pack_early (the sharded_* ones are taken by
@@ -112,7 +113,16 @@ int hbk_sync_check(void);
  * kept per (device, stream) -- the stream the failed call was made on -- so a failure on stream A
  * is reported to the next entry call on A (or to this function with A) and is neither seen nor
  * consumed by calls on stream B.  hbk_sync_check() above reports -- and clears -- whatever any
- * stream has raised. */
+ * stream has raised.
+ * Key semantics: a status word (one 64-byte line of pinned memory) and the poll buffers belong to
+ * the PAIR (device, hipStream_t value) and live as long as the process: the library cannot see a
+ * stream being destroyed.  A new stream that the runtime gives the handle value of a destroyed one
+ * inherits that key -- including a failure the destroyed stream never had reported -- so a caller
+ * that destroys streams calls hbk_sync_check_stream(stream) (or hbk_sync_check()) before
+ * hipStreamDestroy; frameworks with a fixed set of compute streams (TensorFlow, torch) never get
+ * there.  The stream to name is the one the failed ENTRY CALL was made on: work the library put on
+ * its own helper streams (the backward's launch groups, the sharded plan's prefetch) reports to
+ * that caller stream, and asking with any other stream reports nothing. */
 int hbk_sync_check_stream(hbk_stream_t stream);
 /* the kernels' divide-free floor-mod / floor-div (multiply-high by a
  * host-computed magic) evaluated on the host, so the integer arithmetic can be checked
@@ -580,8 +590,11 @@ int64_t hbk_sharded_owned_ids(hbk_sharded_t plan, int32_t column);
 /* The p2p form of the forward (round 5).  hbk_sharded_p2p_bind registers this rank's N output
  * tensors ([n_ids[c], dim] fp32, out_strides as in hbk_sharded_lookup_fwd; NULL = dense) -- a
  * COLLECTIVE over the plan's communicator: every rank calls it with its own tensors, the addresses
- * are exchanged once and mapped into every peer (ranks of one process: the pointer itself; other
- * processes: hipIpcGetMemHandle / hipIpcOpenMemHandle).  From then on hbk_sharded_lookup_fwd --
+ * are exchanged once and mapped into every peer (ranks of one process -- told apart by pid + host
+ * boot id + a per-process random number, since pids repeat across containers: the pointer itself,
+ * with hipDeviceEnablePeerAccess when they sit on different devices; other processes of the same
+ * host: hipIpcGetMemHandle / hipIpcOpenMemHandle).  out_rows[c] = rows of outs[c]: a later forward
+ * with more ids than that is refused (remote owners would store outside the tensor).  From then on hbk_sharded_lookup_fwd --
  * which must be handed exactly these tensors, one id per segment -- sends (id, output row) pairs and
  * the owner-side gather stores every row straight into its place in the requester's output: no
  * reply buffer, no rows Alltoallv, no stitch (one random-row pass instead of two; the rows cross the
@@ -592,7 +605,7 @@ int64_t hbk_sharded_owned_ids(hbk_sharded_t plan, int32_t column);
  * unchanged.  HBK_UNIMPLEMENTED on every rank when some peer's memory cannot be mapped; the plan
  * then keeps the exchange form.  hbk_sharded_p2p_unbind returns to it (not collective). */
 int hbk_sharded_p2p_bind(hbk_sharded_t plan, float* const* outs, const int32_t* out_strides,
-                         hbk_stream_t stream);
+                         const int64_t* out_rows, hbk_stream_t stream);
 int hbk_sharded_p2p_unbind(hbk_sharded_t plan);
 /* diagnostics: host time of the plan's last forward in microseconds -- [0] enqueueing the
  * partition and the size exchange, [1] waiting for the sizes (the device, not host work),

@@ -293,7 +293,9 @@ def run(a, result):
     for label, seed, options in (
         ('p2p, inline', 600, (('sharded_inline', 1),)),
         ('p2p, communicator stream', 601, (('sharded_inline', 0),)),
-        ('p2p, int64 ids, late pack', 602, (('sharded_id64', 1), ('sharded_pack_early', 0)))):
+        ('p2p, int64 ids, late pack', 602, (('sharded_id64', 1), ('sharded_pack_early', 0))),
+        # the last rank's bind "cannot map a peer" (injected): every rank falls back together
+        ('p2p refused by one rank', 603, (('sharded_p2p_test_refuse', W - 1),))):
       saved = [(k, _lib.set_option(k, v)) for k, v in options]
       try:
         rng = np.random.RandomState(seed)
@@ -309,7 +311,10 @@ def run(a, result):
         drv = ShardedGroupLookup(shards, coll, buckets=rows)
         outs = [torch.full((batch, d), float('nan'), device=DEV) for d in dims]
         bound = drv.p2p_bind(outs)
-        result.setdefault('p2p_bound', []).append(bool(bound))
+        if any(k == 'sharded_p2p_test_refuse' for k, _ in options):
+          assert bound is False, 'a refused mapping must unbind every rank'
+        else:
+          result.setdefault('p2p_bound', []).append(bool(bound))
         # a box whose driver cannot map a peer's memory (hipIpcGetMemHandle / OpenMemHandle) is not a
         # parity failure: every rank gets the same False (the bind is a collective that agrees on the
         # minimum), the plan keeps the exchange form -- and THAT is what the steps below then check

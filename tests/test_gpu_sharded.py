@@ -330,11 +330,13 @@ def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64,
     cm.close()
 
 
-@pytest.mark.parametrize('world,inline,id64,pack_early,block', [
-    (1, 1, False, 1, False), (2, 1, False, 1, False), (4, 1, False, 1, True), (8, 1, False, 1, False),
-    (4, 0, False, 1, False), (8, 0, True, 1, True), (2, 1, True, 0, False), (4, 0, False, 0, False),
-    (3, 1, False, 1, True)])
-def test_cxx_driver_p2p_form_in_process_world(hbk_option, world, inline, id64, pack_early, block):
+@pytest.mark.parametrize('world,inline,id64,pack_early,block,refuse', [
+    (1, 1, False, 1, False, -1), (2, 1, False, 1, False, -1), (4, 1, False, 1, True, -1),
+    (8, 1, False, 1, False, -1), (4, 0, False, 1, False, -1), (8, 0, True, 1, True, -1),
+    (2, 1, True, 0, False, -1), (4, 0, False, 0, False, -1), (3, 1, False, 1, True, -1),
+    (2, 1, False, 1, False, 1), (4, 0, False, 1, True, 2)])
+def test_cxx_driver_p2p_form_in_process_world(hbk_option, world, inline, id64, pack_early, block,
+                                              refuse):
   """The p2p form of the sharded forward (round 5, hbk_sharded_p2p_bind): every rank registers its
   output tensors once, a step sends (id, output row) pairs and the owner gather stores each row
   straight into the requester's output -- no reply buffer, no rows exchange, no stitch.  W ranks as
@@ -343,9 +345,13 @@ def test_cxx_driver_p2p_form_in_process_world(hbk_option, world, inline, id64, p
   unsharded oracle over several steps with other ids, outputs as separate tensors or as the column
   blocks of ONE [batch, sum dims] tensor (block), dims with 16-byte and 4-byte chunks; the backward
   of such a step == dense scatter-add and the fused SGD step lands where the dense gradient says;
-  inline and communicator-stream exchanges, int32 / int64 ids on the wire, early / late id pack."""
+  inline and communicator-stream exchanges, int32 / int64 ids on the wire, early / late id pack.
+  refuse >= 0 (round 6): that rank's bind finds a peer it cannot map (the answer of a driver without
+  hipIpc* support, injected by option sharded_p2p_test_refuse) -- EVERY rank's bind then returns
+  False (they agree on the minimum), the plans keep the exchange form and the same checks hold."""
   import threading
   hbk_option('sharded_inline', inline)
+  hbk_option('sharded_p2p_test_refuse', refuse)
   hbk_option('sharded_pack_early', pack_early)
   if id64:
     hbk_option('sharded_id64', 1)
@@ -378,7 +384,7 @@ def test_cxx_driver_p2p_form_in_process_world(hbk_option, world, inline, id64, p
             at += d
         else:
           outs = [torch.full((batch, d), float('nan'), device=DEV) for d in dims]
-        assert drv.p2p_bind(outs) is True
+        assert drv.p2p_bind(outs) is (refuse < 0)
         fwd = []
         for st in range(steps):
           got = drv([dev(i) for i in ids[st][r]], None, outs)
@@ -394,8 +400,10 @@ def test_cxx_driver_p2p_form_in_process_world(hbk_option, world, inline, id64, p
         drv.backward([dev(g) for g in grads[r]], apply_lr=lr, emit=False)
         torch.cuda.current_stream().synchronize()
         # a ragged step on a plan with registered outputs is refused, as are other outputs
-        with pytest.raises(_lib.InvalidArgumentError):
-          drv([dev(i) for i in ids[0][r]], None, [torch.empty_like(o) for o in outs])
+        # (every rank fails before its first exchange: nobody is left waiting)
+        if refuse < 0:
+          with pytest.raises(_lib.InvalidArgumentError):
+            drv([dev(i) for i in ids[0][r]], None, [torch.empty_like(o) for o in outs])
         results[r] = (fwd, sl)
         drv.close()
     except Exception as e:  # pylint: disable=broad-except
@@ -476,7 +484,8 @@ def test_pipelined_lookup_two_plans_in_process_world(hbk_option, world, inline, 
       with torch.cuda.stream(torch.cuda.Stream()):
         plans = [ShardedGroupLookup(shards[r], comms[r], buckets=rows, combiners=combiners)
                  for _ in range(2)]
-        pipe = hb.embedding.PipelinedLookup(plans)
+        # (inline = 1: the plans keep their inline exchanges -- correct, but nothing overlaps)
+        pipe = hb.embedding.PipelinedLookup(plans, stream_exchanges=not inline)
         outs = [[torch.full((1200 if (c % 2 == 0 or p2p) else 300, dims[c]), float('nan'), device=DEV)
                  for c in range(n)] for _ in range(2)]
         if p2p:
@@ -539,6 +548,11 @@ def test_sharded_p2p_through_rccl_world1_and_refusals(hbk_option):
         want = oracle.group_lookup_fwd(tables, ids, [None] * 3, [5000] * 3, ['sum'] * 3)
         for o, w in zip(outs, want):
           np.testing.assert_equal(o.cpu().numpy(), w)
+      # a batch larger than the registered outputs is refused at the step (remote owners would
+      # store outside the tensor): the bind carries the rows of every output
+      big = [dev(rng.randint(0, 2**40, size=4001).astype(np.int64)) for _ in range(3)]
+      with pytest.raises(_lib.InvalidArgumentError, match='registered output of 4000 rows'):
+        drv(big, None, outs)
       sp = dev(np.arange(0, 4001, 2, dtype=np.int32))
       with pytest.raises(_lib.InvalidArgumentError, match='ragged'):
         drv([dev(i) for i in ids], [sp, None, None],
@@ -550,6 +564,19 @@ def test_sharded_p2p_through_rccl_world1_and_refusals(hbk_option):
                                      [5000] * 3, ['sum'] * 3)
       np.testing.assert_equal(got[0].cpu().numpy(), want[0])
       drv.close()
+    # a driver that cannot map a peer's memory (hipIpcGetMemHandle / hipIpcOpenMemHandle refused),
+    # injected: the bind answers False, the plan keeps the exchange form and its results stay right
+    hbk_option('sharded_p2p_test_refuse', 0)
+    drv = ShardedGroupLookup(t_dev, coll, buckets=[5000] * 3)
+    outs = [torch.empty(4000, t.shape[1], device=DEV) for t in tables]
+    assert drv.p2p_bind(outs) is False
+    ids = [rng.randint(0, 2**40, size=4000).astype(np.int64) for _ in range(3)]
+    drv([dev(i) for i in ids], None, outs)
+    torch.cuda.synchronize()
+    for o, w in zip(outs, oracle.group_lookup_fwd(tables, ids, [None] * 3, [5000] * 3, ['sum'] * 3)):
+      np.testing.assert_equal(o.cpu().numpy(), w)
+    drv.close()
+    hbk_option('sharded_p2p_test_refuse', -1)
     drv = ShardedGroupLookup(t_dev, coll, buckets=[5000] * 3, dedup=True)
     with pytest.raises(_lib.InvalidArgumentError, match='dedup'):
       drv.p2p_bind([torch.empty(10, t.shape[1], device=DEV) for t in tables])

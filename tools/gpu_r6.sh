@@ -65,6 +65,10 @@ PY
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -3 $O/smoke.log;;
     bench)
       timeout 600 python bench.py --steps 50 --warmup 10 > $O/bench.log 2>&1; echo "bench rc=$?" >> $O/bench.log; tail -3 $O/bench.log;;
+    stamps)     # where the host returns from the launches of the bench's steps (headline + the backward cases)
+      HBK_BENCH_STAMPS=1 timeout 600 python bench.py --steps 10 --warmup 3 --cpu-seconds 0 > $O/stamps.log 2>&1; echo "rc=$?" >> $O/stamps.log; grep -E "bench stamps|^rc" $O/stamps.log | cut -c1-400;;
+    benchsh)    # the sharded step at one rank through RCCL: forms, p2p, three plans pipelined, references
+      timeout 900 python bench.py --sharded --steps 50 --warmup 10 --cpu-seconds 0 > $O/bench_sh.log 2>&1; echo "rc=$?" >> $O/bench_sh.log; tail -2 $O/bench_sh.log | cut -c1-3000;;
     t_*)        # t_<file stem>[:<-k expression>]: one test file, e.g. t_test_gpu_sync or t_test_gpu_parity:rowsort
       spec=${st#t_}; f=${spec%%:*}; k=""; [ "$spec" != "$f" ] && k=${spec#*:}
       timeout 1500 python -m pytest tests/$f.py -x -q -m gpu ${k:+-k "$k"} --durations=5 > $O/$f.log 2>&1; echo "pytest rc=$?" >> $O/$f.log; tail -15 $O/$f.log;;

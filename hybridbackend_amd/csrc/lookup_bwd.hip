@@ -77,6 +77,14 @@
 #endif
 
 namespace hbk {
+// det_prims.hip: the stable radix sort and the scan of the deterministic backward (rocPRIM)
+size_t det_sort_temp_bytes(size_t n, int end_bit);
+int det_sort_pairs(void* temp, size_t temp_bytes, const uint64_t* keys_in, uint64_t* keys_out,
+                   const uint32_t* vals_in, uint32_t* vals_out, size_t n, int end_bit,
+                   hipStream_t stream);
+size_t det_scan_temp_bytes(size_t n);
+int det_scan(void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, size_t n,
+             hipStream_t stream);
 namespace {
 
 constexpr int kBlock = 256;
@@ -2967,6 +2975,8 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_rowsort_merge_kernel(const GArg
   merge_done(c, blocks);
 }
 
+#include "lookup_bwd_det.h"
+
 // ---- d(stitch + combiner): permutation scatter (hbk_group_stitch_bwd) ----------------------
 constexpr int kIters = 4;
 constexpr int kMaxStitchCols = 128;
@@ -3214,6 +3224,143 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
   return b;
 }
 
+// ---- host side of the deterministic backward (lookup_bwd_det.h) -----------------------------------
+struct DetLayout {
+  size_t keys, skeys, vals, svals, heads, ranks, temp, temp_bytes, total;
+};
+inline int bits_for(uint64_t v) {   // bits that hold every value in [0, v]
+  int b = 1;
+  while (b < 64 && (v >> b) != 0) ++b;
+  return b;
+}
+// the call's launch groups run one after the other on the caller's stream and share one set of
+// arrays sized for the largest of them (at most the call's ids)
+DetLayout det_layout(int32_t n_cols, const hbk_lookup_grad_column_t* cols) {
+  size_t n = 0;
+  uint64_t max_rows = 1;
+  for (int32_t c = 0; c < n_cols; ++c) {
+    if (cols[c].n_ids <= 0) continue;
+    n += (size_t)cols[c].n_ids;
+    if ((uint64_t)cols[c].rows > max_rows) max_rows = (uint64_t)cols[c].rows;
+  }
+  DetLayout l = {};
+  if (n == 0) return l;
+  const int end_bit = bits_for(max_rows) + bits_for(kMaxCols - 1);
+  const size_t t_sort = det_sort_temp_bytes(n, end_bit < 64 ? end_bit : 64);
+  const size_t t_scan = det_scan_temp_bytes(n);
+  size_t at = 256;
+  auto take = [&](size_t bytes) {
+    const size_t here = at;
+    at += (bytes + 255) & ~(size_t)255;
+    return here;
+  };
+  l.keys = take(n * 8);
+  l.skeys = take(n * 8);
+  l.vals = take(n * 4);
+  l.svals = take(n * 4);
+  l.heads = take(n * 4);
+  l.ranks = take(n * 4);
+  l.temp_bytes = t_sort > t_scan ? t_sort : t_scan;
+  l.temp = take(l.temp_bytes);
+  l.total = at;
+  return l;
+}
+
+int det_backward(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int32_t apply, float lr,
+                 void* workspace, hipStream_t stream) {
+  const DetLayout l = det_layout(n_cols, cols);
+  for (int32_t c = 0; c < n_cols; ++c) {
+    if (cols[c].n_ids == 0) HBK_HIP_OK(hipMemsetAsync(cols[c].n_unique, 0, sizeof(int32_t), stream));
+  }
+  if (l.total == 0) return HBK_OK;
+  HBK_REQUIRE(l.temp_bytes > 256, "deterministic backward: the sort / scan primitives cannot be "
+                                  "sized on this device");
+  char* ws = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  uint64_t* keys = reinterpret_cast<uint64_t*>(ws + l.keys);
+  uint64_t* skeys = reinterpret_cast<uint64_t*>(ws + l.skeys);
+  uint32_t* vals = reinterpret_cast<uint32_t*>(ws + l.vals);
+  uint32_t* svals = reinterpret_cast<uint32_t*>(ws + l.svals);
+  int32_t* heads = reinterpret_cast<int32_t*>(ws + l.heads);
+  int32_t* ranks = reinterpret_cast<int32_t*>(ws + l.ranks);
+  int32_t c0 = 0;
+  while (c0 < n_cols) {
+    DArgs a;
+    memset(&a, 0, sizeof(a));
+    int k = 0;
+    int64_t total = 0, tiles = 0;
+    uint64_t max_rows = 1;
+    while (c0 < n_cols && k < kMaxCols) {
+      const hbk_lookup_grad_column_t& h = cols[c0++];
+      if (h.n_ids <= 0) continue;
+      HBK_REQUIRE(h.dim <= kDetLanes * kDetMaxE, "deterministic backward: dim %d > %d", h.dim,
+                  kDetLanes * kDetMaxE);
+      HBK_REQUIRE(h.rows < (1ll << 40), "deterministic backward: more than 2^40 rows");
+      DCol& d = a.col[k];
+      d.ids = h.ids;
+      d.grad = h.grad_out;
+      d.splits = h.row_splits;
+      d.unique_rows = h.unique_rows;
+      d.grad_rows = h.grad_rows;
+      d.table = h.table;
+      d.accum = h.accum;
+      d.run_start = h.run_start;
+      d.run_ids = h.run_ids;
+      d.run_grads = h.run_grads;
+      d.map = make_idmap(h.bucket, h.divisor, h.rows);
+      d.n_ids = h.n_ids;
+      d.n_seg = h.n_segments;
+      d.dim = h.dim;
+      d.grad_stride = h.grad_stride > 0 ? h.grad_stride : h.dim;
+      d.n_runs = h.n_runs;
+      d.ids64 = h.ids_dtype == HBK_INT64;
+      d.combiner = (uint8_t)h.combiner;
+      a.n_unique[k] = h.n_unique;
+      a.tile0[k] = (int32_t)tiles;
+      a.base[k] = (int32_t)total;
+      tiles += (h.n_ids + kDetTile - 1) / kDetTile;
+      total += h.n_ids;
+      if ((uint64_t)h.rows > max_rows) max_rows = (uint64_t)h.rows;
+      ++k;
+    }
+    if (k == 0) continue;
+    HBK_REQUIRE(total < (1ll << 31), "deterministic backward: more than 2^31-1 ids in one launch group");
+    for (int q = k; q <= kMaxCols; ++q) a.base[q] = (int32_t)total;
+    a.n_cols = k;
+    a.row_bits = bits_for(max_rows);        // the all-ones row field (> every row) marks "no row"
+    a.apply = apply;
+    a.lr = lr;
+    a.total = total;
+    const int end_bit = a.row_bits + (k > 1 ? bits_for((uint64_t)k - 1) : 0);
+    // 1 keys in id order
+    a.keys = keys;
+    a.vals = vals;
+    a.heads = heads;
+    a.ranks = ranks;
+    hipLaunchKernelGGL(det_keys_kernel, dim3((unsigned)tiles), dim3(kBlock), 0, stream, a);
+    HBK_HIP_OK(hipGetLastError());
+    // 2 stable sort by (column, row)
+    int rc = det_sort_pairs(ws + l.temp, l.temp_bytes, keys, skeys, vals, svals, (size_t)total, end_bit,
+                            stream);
+    if (rc != HBK_OK) return rc;
+    // 3 heads and their ranks
+    a.keys = skeys;
+    a.vals = svals;
+    const unsigned tiles_p = (unsigned)((total + kDetTile - 1) / kDetTile);
+    hipLaunchKernelGGL(det_heads_kernel, dim3(tiles_p), dim3(kBlock), 0, stream, a);
+    HBK_HIP_OK(hipGetLastError());
+    rc = det_scan(ws + l.temp, l.temp_bytes, heads, ranks, (size_t)total, stream);
+    if (rc != HBK_OK) return rc;
+    // 4 every row's run, front to back
+    constexpr int kGroups = kBlock / kDetLanes;
+    hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((total + kGroups - 1) / kGroups)), dim3(kBlock),
+                       0, stream, a);
+    HBK_HIP_OK(hipGetLastError());
+    hipLaunchKernelGGL(det_counts_kernel, dim3(1), dim3(kWave), 0, stream, a);
+    HBK_HIP_OK(hipGetLastError());
+  }
+  return HBK_OK;
+}
+
 }  // namespace
 }  // namespace hbk
 
@@ -3254,6 +3401,10 @@ extern "C" int hbk_debug_bwd_trace(unsigned long long* out, int reset) {
 extern "C" size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
                                                        const hbk_lookup_grad_column_t* cols) {
   if (n_cols <= 0 || cols == nullptr) return 0;
+  if (hbk::options().bwd_deterministic != 0) {
+    const size_t det = hbk::det_layout(n_cols, cols).total;
+    return det == 0 ? 0 : det + 256;
+  }
   size_t total = 0;
   for (int32_t c = 0; c < n_cols; ++c) total += hbk::col_workspace(cols[c]);
   return total == 0 ? 0 : total + 256;  // the head (counters, descriptors) is aligned inside
@@ -3380,6 +3531,10 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
   {
     const int rc = sync_check("group_lookup_bwd", stream);
     if (rc != HBK_OK) return rc;
+  }
+  // option bwd_deterministic: sort + in-order walk instead of everything below (lookup_bwd_det.h)
+  if (options().bwd_deterministic != 0) {
+    return det_backward(n_cols, cols, apply, apply_lr, workspace, stream);
   }
   // head of the workspace: the job descriptors of all columns (16-byte aligned), then the
   // per-column buffers

@@ -37,6 +37,7 @@ const OptionEntry kOptions[] = {
     {"bwd_scatter_staged", "HBK_BWD_SCATTER_STAGED", &Options::bwd_scatter_staged},
     {"bwd_rowsort_pos", "HBK_BWD_ROWSORT_POS", &Options::bwd_rowsort_pos},
     {"bwd_rowsort_ratio", "HBK_BWD_ROWSORT_RATIO", &Options::bwd_rowsort_ratio},
+    {"bwd_deterministic", "HBK_BWD_DETERMINISTIC", &Options::bwd_deterministic},
     {"bwd_streams", "HBK_BWD_STREAMS", &Options::bwd_streams},
     {"bwd_trace", "HBK_BWD_TRACE", &Options::bwd_trace},
     {"bwd_lds_pad", "HBK_BWD_LDS_PAD", &Options::bwd_lds_pad},

@@ -996,6 +996,158 @@ def test_group_lookup_backward_split_buckets(hbk_option, split, log2p, onepass, 
                       np.abs(table) + 0.01 * mag, rel=RTOL)
 
 
+def _in_order_slices(rows, grads, splits, combiner, n_rows):
+  """What bwd_deterministic = 1 promises: the distinct valid rows ascending, and for each the
+  sequential fp32 sum of its terms in id order (oracle.unsorted_segment_sum, the restatement of
+  TF's CPU UnsortedSegmentSum over d(combiner) per id)."""
+  sp = splits if splits is not None else np.arange(rows.size + 1, dtype=np.int32)
+  g_id = oracle.segment_combine_grad(grads, sp, combiner)
+  ok = (rows >= 0) & (rows < n_rows)
+  uniq = np.unique(rows[ok])
+  inv = np.full(rows.size, -1, np.int32)
+  inv[ok] = np.searchsorted(uniq, rows[ok]).astype(np.int32)
+  return uniq, oracle.unsorted_segment_sum(g_id, inv, uniq.size)
+
+
+@pytest.mark.parametrize('mode', ['emit', 'sgd', 'adagrad', 'step_only'])
+def test_group_lookup_backward_deterministic_is_the_in_order_sum(hbk_option, mode):
+  """Option bwd_deterministic (round 6): a stable sort of the batch's (row,
+  gradient row) pairs and one lane group walking every row's run front to back.  The emitted sums
+  are BIT-EQUAL to the sequential fp32 sum in id order -- not "within 1e-5" -- the rows leave sorted,
+  the fused SGD / Adagrad steps are bit-equal to the oracle's apply on those slices, and two calls
+  give the same bits.  Shapes: scalar and ragged columns with every combiner, a Zipf head, one row
+  that owns a whole column, ids outside the table, odd dims, `// W` row numbers, int32 ids, an
+  empty column, more columns than one launch group."""
+  hbk_option('bwd_deterministic', 1)
+  rng = np.random.RandomState(606)
+  #        dim  rows    n_seg  mean-len combiner ids
+  cases = [(16, 50000, 30000, 8, 'mean', 'uniform'),
+           (16, 3000, 40000, 0, 'sum', 'uniform'),
+           (128, 700, 9000, 0, 'sum', 'zipf'),
+           (4, 100, 20000, 3, 'sqrtn', 'uniform'),
+           (6, 9000, 15000, 2, 'mean', 'zipf'),
+           (64, 20000, 9000, 4, 'sum', 'outside'),
+           (32, 1, 5000, 0, 'sum', 'uniform'),
+           (5, 10, 0, 0, 'sum', 'uniform'),
+           (256, 40, 300, 5, 'sqrtn', 'uniform'),
+           (8, 150000, 60000, 0, 'sum', 'uniform')]
+  cases += [(4, 97, 500 + 3 * k, k % 3, ['sum', 'mean', 'sqrtn'][k % 3], 'uniform') for k in range(70)]
+  tables, accums, ids, splits, grads, combs = [], [], [], [], [], []
+  for d, rows, n_seg, mean_len, comb, kind in cases:
+    tables.append(rng.uniform(-1, 1, size=(rows, d)).astype(np.float32))
+    accums.append(np.full((rows, d), 0.1, np.float32))
+    sp = _ragged(rng, n_seg, mean_len, 32) if mean_len else None
+    n = n_seg if sp is None else int(sp[-1])
+    if kind == 'zipf':
+      i = (rng.zipf(1.2, size=n) % rows).astype(np.int64)
+    elif kind == 'outside':
+      i = rng.randint(-rows, 3 * rows, size=n).astype(np.int64)
+    else:
+      i = rng.randint(0, rows, size=n).astype(np.int64)
+    ids.append(i)
+    splits.append(sp)
+    grads.append(rng.randn(n_seg, d).astype(np.float32))
+    combs.append(comb)
+  for comb in ('sum', 'mean', 'sqrtn'):
+    sel = [c for c in range(len(cases)) if combs[c] == comb]
+    results = []
+    for rep in range(2):
+      t_dev = [dev(tables[c].copy()) for c in sel]
+      a_dev = [dev(accums[c].copy()) for c in sel]
+      lookup = hb.embedding.GroupLookup(t_dev, None, comb)
+      grad = hb.embedding.GroupLookupGrad(lookup, accums=a_dev if mode == 'adagrad' else None)
+      lr = 0.0 if mode == 'emit' else 0.05
+      res = grad([dev(ids[c]) for c in sel], [dev(grads[c]) for c in sel],
+                 [None if splits[c] is None else dev(splits[c]) for c in sel], apply_lr=lr,
+                 optimizer='adagrad' if mode == 'adagrad' else 'sgd', emit=mode != 'step_only')
+      torch.cuda.synchronize()
+      results.append(([int(r[2].item()) for r in res],
+                      [None if r[0] is None else host(r[0])[:int(r[2].item())].copy() for r in res],
+                      [None if r[1] is None else host(r[1])[:int(r[2].item())].copy() for r in res],
+                      [host(t) for t in t_dev], [host(x) for x in a_dev]))
+    for k, c in enumerate(sel):
+      rows_n, d = tables[c].shape
+      want_rows, want_sums = _in_order_slices(ids[c], grads[c], splits[c], comb, rows_n)
+      nu, urows, grows, t_end, a_end = (x[k] for x in results[0])
+      assert nu == want_rows.size, (c, nu, want_rows.size)
+      if mode != 'step_only':
+        np.testing.assert_equal(urows, want_rows, err_msg=f'column {c}: rows (sorted)')
+        np.testing.assert_equal(grows, want_sums, err_msg=f'column {c}: in-order fp32 sums')
+      ref_t, ref_a = tables[c].copy(), accums[c].copy()
+      if mode in ('sgd', 'step_only'):
+        oracle.sparse_sgd_apply(ref_t, want_rows, want_sums, 0.05)
+      elif mode == 'adagrad':
+        oracle.sparse_adagrad_apply(ref_t, ref_a, want_rows, want_sums, 0.05)
+      np.testing.assert_equal(t_end, ref_t, err_msg=f'column {c}: table')
+      np.testing.assert_equal(a_end, ref_a, err_msg=f'column {c}: accumulator')
+      # the second call: the same bits
+      for x, y in zip(results[0], results[1]):
+        if x[k] is not None and not isinstance(x[k], int):
+          np.testing.assert_equal(x[k], y[k])
+        else:
+          assert x[k] == y[k]
+
+
+def test_group_lookup_backward_deterministic_segmented_inputs_and_divisor(hbk_option):
+  """bwd_deterministic through the C ABI's other inputs: ids and gradient rows as runs inside larger
+  buffers (the owner side of the sharded backward), `// W` row numbers with a bucket, int32 ids."""
+  hbk_option('bwd_deterministic', 1)
+  rng = np.random.RandomState(607)
+  # // W row numbers, bucket, int32 ids (through the Python layer)
+  rows_full, W, d, n = 10007, 4, 16, 30000
+  table = rng.uniform(-1, 1, size=(rows_full // W + 1, d)).astype(np.float32)
+  ids32 = rng.randint(0, 2**31 - 1, size=n).astype(np.int32)
+  g = rng.randn(n, d).astype(np.float32)
+  lookup = hb.embedding.GroupLookup([dev(table)], [rows_full], 'sum', divisor=W)
+  urows, grows, nu = hb.embedding.GroupLookupGrad(lookup)([dev(ids32)], [dev(g)])[0]
+  local = (ids32.astype(np.int64) % rows_full) // W
+  want_rows, want_sums = _in_order_slices(local, g, None, 'sum', table.shape[0])
+  k = int(nu.item())
+  np.testing.assert_equal(host(urows)[:k], want_rows)
+  np.testing.assert_equal(host(grows)[:k], want_sums)
+  # segmented inputs through the C ABI
+  lib = _lib.lib()
+  d, rows, lens = 6, 90, [10, 501, 2, 3000]
+  n = sum(lens)
+  ids = rng.randint(0, rows, size=n).astype(np.int64)
+  grads = rng.randn(n, d).astype(np.float32)
+  id_buf = np.full(n + 64 * len(lens), -7, np.int64)
+  g_buf = np.full(n * d + 64 * len(lens), np.nan, np.float32)
+  run_start, run_ids, run_grads, io, go, st = [], [], [], 5, 8, 0
+  for k_ in reversed(range(len(lens))):
+    run_ids.insert(0, io)
+    run_grads.insert(0, go)
+    io += lens[k_] + 3
+    go += (lens[k_] * d + 3) // 4 * 4 + 4
+  for k_, ln in enumerate(lens):
+    run_start.append(st)
+    id_buf[run_ids[k_]:run_ids[k_] + ln] = ids[st:st + ln]
+    g_buf[run_grads[k_]:run_grads[k_] + ln * d] = grads[st:st + ln].reshape(-1)
+    st += ln
+  ids_dev, g_dev = dev(id_buf), dev(g_buf)
+  tabs = [dev(np.array(x, np.int64)) for x in (run_start, run_ids, run_grads)]
+  urows = torch.empty(n, dtype=torch.int64, device=DEV)
+  grows = torch.empty(n, d, device=DEV)
+  nu = torch.zeros(1, dtype=torch.int32, device=DEV)
+  col = (_lib.LookupGradColumn * 1)()
+  c = col[0]
+  c.table, c.rows, c.dim, c.ids_dtype = None, rows, d, _lib.INT64
+  c.ids, c.n_ids, c.n_segments, c.divisor = ids_dev.data_ptr(), n, n, 1
+  c.combiner = 0
+  c.grad_out, c.unique_rows, c.grad_rows = g_dev.data_ptr(), urows.data_ptr(), grows.data_ptr()
+  c.n_unique = nu.data_ptr()
+  c.run_start, c.run_ids, c.run_grads = (t.data_ptr() for t in tabs)
+  c.n_runs = len(lens)
+  need = lib.hbk_group_lookup_bwd_workspace_bytes(1, col)
+  ws = torch.empty(max(need, 8), dtype=torch.uint8, device=DEV)
+  _lib.check(lib.hbk_group_lookup_bwd(1, col, C.c_float(0.0), C.c_void_p(ws.data_ptr()),
+                                      C.c_size_t(ws.numel()), _lib.current_stream(DEV)))
+  want_rows, want_sums = _in_order_slices(ids, grads, None, 'sum', rows)
+  k = int(nu.item())
+  np.testing.assert_equal(host(urows)[:k], want_rows)
+  np.testing.assert_equal(host(grows)[:k], want_sums)
+
+
 def test_group_lookup_backward_segmented_inputs():
   """C ABI: ids and gradient rows handed over as runs inside larger buffers (what the owner side
   of the sharded backward gets from the exchange) give the same IndexedSlices as contiguous

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <chrono>
 #include <functional>
 #include <vector>
 
@@ -55,6 +56,9 @@ static T* dev_alloc(size_t n) {
   return d;
 }
 
+// host time per call of the last time_us (the calls return before the device is done: what the
+// entry point costs its caller -- a step is host-bound when this exceeds the device time)
+static double g_host_us = 0.0;
 static float time_us(int iters, const std::function<void(int)>& f) {
   if (const char* it = getenv("HBK_BENCH_ITERS")) {   // (counter passes: a few calls are enough)
     if (atoi(it) > 0) iters = atoi(it);
@@ -65,7 +69,9 @@ static float time_us(int iters, const std::function<void(int)>& f) {
   for (int i = 0; i < 3; ++i) f(i);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0, 0));
+  const auto h0 = std::chrono::steady_clock::now();
   for (int i = 0; i < iters; ++i) f(i + 3);
+  g_host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count() / iters;
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -256,7 +262,7 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
   snprintf(what, sizeof(what), "group_lookup_bwd %d x %lld ids%s, dim %d, %lld rows%s", n_cols,
            (long long)B, H > 0 ? " (ragged mean)" : "", dim, (long long)rows,
            step_only ? ", SGD step only" : lr != 0.f ? " + SGD apply" : "");
-  printf("%-66s %9.2f us  %8.1f M lookups/s\n", what, us, n / us);
+  printf("%-66s %9.2f us  %8.1f M lookups/s   (host %.1f us per call)\n", what, us, n / us, g_host_us);
   {  // probe build: stamps of the grouping kernel's workgroups
     typedef int (*trace_fn)(unsigned long long*, int);
     trace_fn fn = (trace_fn)dlsym(RTLD_DEFAULT, "hbk_debug_grp_trace");

@@ -69,6 +69,11 @@ PY
       HBK_BENCH_STAMPS=1 timeout 600 python bench.py --steps 10 --warmup 3 --cpu-seconds 0 > $O/stamps.log 2>&1; echo "rc=$?" >> $O/stamps.log; grep -E "bench stamps|^rc" $O/stamps.log | cut -c1-400;;
     benchsh)    # the sharded step at one rank through RCCL: forms, p2p, three plans pipelined, references
       timeout 900 python bench.py --sharded --steps 50 --warmup 10 --cpu-seconds 0 > $O/bench_sh.log 2>&1; echo "rc=$?" >> $O/bench_sh.log; tail -2 $O/bench_sh.log | cut -c1-3000;;
+    det)        # the deterministic backward: parity, then its cost next to the default on the same box
+      timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k deterministic --durations=5 > $O/det_test.log 2>&1; echo "pytest rc=$?" >> $O/det_test.log; tail -12 $O/det_test.log
+      (for w in b s R; do for det in 0 1; do HBK_BWD_DETERMINISTIC=$det timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/deterministic=$det  /"; done; done) > $O/det_cost.txt 2>&1; cut -c1-200 $O/det_cost.txt;;
+    hosttime)   # host time of the backward entry per call (C ABI, no Python)
+      (for w in b s R r; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd; done) > $O/hosttime.txt 2>&1; cut -c1-200 $O/hosttime.txt;;
     t_*)        # t_<file stem>[:<-k expression>]: one test file, e.g. t_test_gpu_sync or t_test_gpu_parity:rowsort
       spec=${st#t_}; f=${spec%%:*}; k=""; [ "$spec" != "$f" ] && k=${spec#*:}
       timeout 1500 python -m pytest tests/$f.py -x -q -m gpu ${k:+-k "$k"} --durations=5 > $O/$f.log 2>&1; echo "pytest rc=$?" >> $O/$f.log; tail -15 $O/$f.log;;

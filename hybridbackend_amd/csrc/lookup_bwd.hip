@@ -3289,6 +3289,8 @@ int det_backward(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int32_t a
     int k = 0;
     int64_t total = 0, tiles = 0;
     uint64_t max_rows = 1;
+    int max_dim = 1;
+    bool vec4 = true;     // every row of the group in 16-byte chunks (dims, strides, addresses)
     while (c0 < n_cols && k < kMaxCols) {
       const hbk_lookup_grad_column_t& h = cols[c0++];
       if (h.n_ids <= 0) continue;
@@ -3320,6 +3322,11 @@ int det_backward(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int32_t a
       tiles += (h.n_ids + kDetTile - 1) / kDetTile;
       total += h.n_ids;
       if ((uint64_t)h.rows > max_rows) max_rows = (uint64_t)h.rows;
+      if (h.dim > max_dim) max_dim = h.dim;
+      uintptr_t bits = (uintptr_t)h.grad_out | (uintptr_t)h.grad_rows |
+                       ((uintptr_t)(uint32_t)d.grad_stride * 4);
+      if (lr != 0.0f) bits |= (uintptr_t)h.table | (uintptr_t)h.accum;
+      vec4 = vec4 && h.dim % 4 == 0 && bits % 16 == 0 && h.n_runs == 0;
       ++k;
     }
     if (k == 0) continue;
@@ -3351,9 +3358,11 @@ int det_backward(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int32_t a
     rc = det_scan(ws + l.temp, l.temp_bytes, heads, ranks, (size_t)total, stream);
     if (rc != HBK_OK) return rc;
     // 4 every row's run, front to back
-    constexpr int kGroups = kBlock / kDetLanes;
-    hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((total + kGroups - 1) / kGroups)), dim3(kBlock),
-                       0, stream, a);
+    if (vec4) {
+      det_launch_reduce<f32x4>(a, max_dim / 4, stream);
+    } else {
+      det_launch_reduce<float>(a, max_dim, stream);
+    }
     HBK_HIP_OK(hipGetLastError());
     hipLaunchKernelGGL(det_counts_kernel, dim3(1), dim3(kWave), 0, stream, a);
     HBK_HIP_OK(hipGetLastError());

@@ -18,8 +18,8 @@
 // and a walk that is as long as the hottest row (measured in DESIGN.md 4.4): a reproducibility
 // tool -- TF_DETERMINISTIC_OPS' analogue -- not the fast path.
 constexpr int kDetTile = 2048;          // pairs per workgroup in the key / head kernels
-constexpr int kDetLanes = 16;           // lanes that walk one row (element d of a row: lane d % 16)
-constexpr int kDetMaxE = 16;            // row elements per lane: dim <= 256 (make_rowshape's bound)
+constexpr int kDetLanes = 16;           // most lanes that walk one row
+constexpr int kDetMaxE = 16;            // most row chunks per lane: dim <= 256 (make_rowshape's bound)
 constexpr int kDetW = 4;                // pairs of a run requested together
 
 struct DCol {
@@ -127,13 +127,26 @@ __global__ void det_counts_kernel(const DArgs a) {
 }
 
 // 4: one lane group per sorted position; the group of a row's FIRST pair walks the row's run in
-// order.  Element d of the row belongs to lane d % 16 of the group (4-byte loads: 64-byte pieces of a
-// row per group and instruction), so any dim, stride and alignment takes the same path.
+// order.  A row is split into chunks of V (16 bytes when every column of the launch group has
+// 16-byte rows, else 4) over L = 2^L_LOG2 lanes, E chunks per lane (chunk sub + e * L): the host
+// picks the smallest (L, E) that covers the group's widest row.
+template <typename V>
+__device__ inline V det_div(V g, float by);
+template <>
+__device__ inline float det_div<float>(float g, float by) { return g / by; }
+template <>
+__device__ inline f32x4 det_div<f32x4>(f32x4 g, float by) {
+  return f32x4{g.x / by, g.y / by, g.z / by, g.w / by};
+}
+
+template <typename V, int L_LOG2, int E>
 __global__ __launch_bounds__(kBlock) void det_reduce_kernel(const DArgs a) {
-  constexpr int kGroups = kBlock / kDetLanes;
+  constexpr int L = 1 << L_LOG2;
+  constexpr int VE = sizeof(V) / 4;
+  constexpr int kGroups = kBlock / L;
   const int tid = (int)threadIdx.x;
-  const int sub = tid & (kDetLanes - 1);
-  const int64_t p = (int64_t)blockIdx.x * kGroups + (tid >> 4);
+  const int sub = tid & (L - 1);
+  const int64_t p = (int64_t)blockIdx.x * kGroups + (tid >> L_LOG2);
   if (p >= a.total || a.heads[p] == 0) return;
   const uint64_t key = a.keys[p];
   const uint64_t none = (1ull << a.row_bits) - 1ull;
@@ -141,85 +154,134 @@ __global__ __launch_bounds__(kBlock) void det_reduce_kernel(const DArgs a) {
   const int64_t row = (int64_t)(key & none);
   const DCol& c = a.col[ci];
   const int64_t end = a.base[ci + 1];
-  const int dim = c.dim;
+  const int chunks = c.dim / VE;
   const bool offsets = c.n_runs > 0;
   const bool scaled = c.splits != nullptr && c.combiner != HBK_COMBINER_SUM;
-  float acc[kDetMaxE];
-#pragma unroll
-  for (int e = 0; e < kDetMaxE; ++e) acc[e] = 0.0f;
-  // (the keys / values of the NEXT kDetW pairs are requested together with the gradient rows of the
-  // current ones: one memory round trip per kDetW terms of a long run instead of two)
-  uint32_t seg[kDetW];
-  bool same[kDetW];
-  auto fetch = [&](int64_t q, uint32_t (&sg)[kDetW], bool (&sm)[kDetW]) {
-#pragma unroll
-    for (int w = 0; w < kDetW; ++w) {
-      const int64_t qq = q + w < end ? q + w : end - 1;
-      sm[w] = q + w < end && a.keys[qq] == key;   // sorted: the row's pairs are a prefix
-      sg[w] = a.vals[qq];
-    }
+  // the gradient row (chunk e of this lane) of the pair at sorted position q, divided as the
+  // combiner asks -- the term of the sum
+  auto term = [&](uint32_t seg, int e) -> V {
+    const int64_t off = offsets ? (int64_t)seg : (int64_t)seg * c.grad_stride;
+    return *reinterpret_cast<const V*>(c.grad + off + (int64_t)(sub + e * L) * VE);
   };
-  fetch(p, seg, same);
-  for (int64_t q = p;; q += kDetW) {
-    uint32_t seg_n[kDetW];
-    bool same_n[kDetW];
-    fetch(q + kDetW, seg_n, same_n);
-    float g[kDetW][kDetMaxE];
-    float div[kDetW];
+  auto divisor = [&](uint32_t seg) -> float {
+    const int32_t n = c.splits[seg + 1] - c.splits[seg];
+    return c.combiner == HBK_COMBINER_MEAN ? (float)n : sqrtf((float)n);
+  };
+  V acc[E];
 #pragma unroll
-    for (int w = 0; w < kDetW; ++w) {
-      div[w] = 1.0f;
-      const int64_t off = offsets ? (int64_t)seg[w] : (int64_t)seg[w] * c.grad_stride;
+  for (int e = 0; e < E; ++e) acc[e] = zero_v<V>();
+  // the run goes on while the next pair has the same key (the ids outside the table sit behind the
+  // column's last row with a key of their own and no head flag: the flags cannot tell)
+  const bool single = p + 1 >= end || a.keys[p + 1] != key;
+  if (single) {   // (most rows of most batches: one term, no loop)
+    const uint32_t seg = a.vals[p];
+    const float by = scaled ? divisor(seg) : 1.0f;
 #pragma unroll
-      for (int e = 0; e < kDetMaxE; ++e) {
-        const int d = sub + e * kDetLanes;
-        g[w][e] = same[w] && d < dim ? c.grad[off + d] : 0.0f;
-      }
-      if (same[w] && scaled) {
-        const int32_t n = c.splits[seg[w] + 1] - c.splits[seg[w]];
-        div[w] = c.combiner == HBK_COMBINER_MEAN ? (float)n : sqrtf((float)n);
-      }
-    }
-    // the terms join the sum one after the other, in id order: the order IS the contract
-#pragma unroll
-    for (int w = 0; w < kDetW; ++w) {
-      if (!same[w]) continue;
-#pragma unroll
-      for (int e = 0; e < kDetMaxE; ++e) {
-        const float term = scaled ? g[w][e] / div[w] : g[w][e];
-        acc[e] = acc[e] + term;
+    for (int e = 0; e < E; ++e) {
+      if (sub + e * L < chunks) {
+        const V g = term(seg, e);
+        acc[e] = acc[e] + (scaled ? det_div<V>(g, by) : g);
       }
     }
-    if (!same[kDetW - 1]) break;
+  } else {
+    // kDetW pairs per round; the flags / values of the NEXT round are requested together with the
+    // gradient rows of this one: one memory round trip per kDetW terms of a long run
+    uint32_t seg[kDetW];
+    bool same[kDetW];
+    auto fetch = [&](int64_t q, uint32_t (&sg)[kDetW], bool (&sm)[kDetW]) {
 #pragma unroll
-    for (int w = 0; w < kDetW; ++w) {
-      seg[w] = seg_n[w];
-      same[w] = same_n[w];
+      for (int w = 0; w < kDetW; ++w) {
+        const int64_t qq = q + w < end ? q + w : end - 1;
+        sm[w] = q + w < end && a.keys[qq] == key;   // sorted: the row's pairs are a prefix
+        sg[w] = a.vals[qq];
+      }
+    };
+    fetch(p, seg, same);
+    for (int64_t q = p;; q += kDetW) {
+      uint32_t seg_n[kDetW];
+      bool same_n[kDetW];
+      fetch(q + kDetW, seg_n, same_n);
+      V g[kDetW][E];
+      float by[kDetW];
+#pragma unroll
+      for (int w = 0; w < kDetW; ++w) {
+        by[w] = same[w] && scaled ? divisor(seg[w]) : 1.0f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          g[w][e] = same[w] && sub + e * L < chunks ? term(seg[w], e) : zero_v<V>();
+        }
+      }
+      // the terms join the sum one after the other, in id order: the order IS the contract
+#pragma unroll
+      for (int w = 0; w < kDetW; ++w) {
+        if (!same[w]) continue;
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = acc[e] + (scaled ? det_div<V>(g[w][e], by[w]) : g[w][e]);
+      }
+      if (!same[kDetW - 1] || !same_n[0]) break;
+#pragma unroll
+      for (int w = 0; w < kDetW; ++w) {
+        seg[w] = seg_n[w];
+        same[w] = same_n[w];
+      }
     }
   }
   const int32_t u = a.ranks[p] - a.ranks[a.base[ci]];
   if (c.unique_rows != nullptr) {
     if (sub == 0) c.unique_rows[u] = row;
 #pragma unroll
-    for (int e = 0; e < kDetMaxE; ++e) {
-      const int d = sub + e * kDetLanes;
-      if (d < dim) c.grad_rows[(int64_t)u * dim + d] = acc[e];
+    for (int e = 0; e < E; ++e) {
+      const int ch = sub + e * L;
+      if (ch < chunks) *reinterpret_cast<V*>(c.grad_rows + (int64_t)u * c.dim + (int64_t)ch * VE) = acc[e];
     }
   }
   if (a.lr != 0.0f) {
     // the sparse optimizer step from the finished sum (the arithmetic of step_row)
 #pragma unroll
-    for (int e = 0; e < kDetMaxE; ++e) {
-      const int d = sub + e * kDetLanes;
-      if (d >= dim) continue;
-      const int64_t t = row * dim + d;
+    for (int e = 0; e < E; ++e) {
+      const int ch = sub + e * L;
+      if (ch >= chunks) continue;
+      const int64_t t = row * c.dim + (int64_t)ch * VE;
+      V* tp = reinterpret_cast<V*>(c.table + t);
       if (a.apply == HBK_APPLY_ADAGRAD) {
-        const float ac = c.accum[t] + acc[e] * acc[e];
-        c.accum[t] = ac;
-        c.table[t] = c.table[t] - (a.lr * acc[e]) * (1.0f / sqrtf(ac));
+        V* ap = reinterpret_cast<V*>(c.accum + t);
+        const V ac = *ap + acc[e] * acc[e];
+        *ap = ac;
+        *tp = *tp - (a.lr * acc[e]) * rsqrt_v<V>(ac);
       } else {
-        c.table[t] = c.table[t] - a.lr * acc[e];
+        *tp = *tp - a.lr * acc[e];
       }
     }
   }
+}
+
+// (V, L, E) for a launch group whose widest row has `chunks` chunks of V
+template <typename V>
+inline void det_launch_reduce(const DArgs& a, int chunks, hipStream_t stream) {
+  int l_log2 = 0;
+  while (l_log2 < 4 && (1 << l_log2) < chunks) ++l_log2;
+  const int e = (chunks + (1 << l_log2) - 1) >> l_log2;
+  const auto grid = [&](int groups) { return dim3((unsigned)((a.total + groups - 1) / groups)); };
+#define HBK_DET_CASE(LL, EE)                                                                      \
+  hipLaunchKernelGGL((det_reduce_kernel<V, LL, EE>), grid(kBlock >> LL), dim3(kBlock), 0, stream, a)
+  if (l_log2 == 0) {
+    HBK_DET_CASE(0, 1);
+  } else if (l_log2 == 1) {
+    HBK_DET_CASE(1, 1);
+  } else if (l_log2 == 2) {
+    HBK_DET_CASE(2, 1);
+  } else if (l_log2 == 3) {
+    HBK_DET_CASE(3, 1);
+  } else if (e <= 1) {
+    HBK_DET_CASE(4, 1);
+  } else if (e <= 2) {
+    HBK_DET_CASE(4, 2);
+  } else if (e <= 4) {
+    HBK_DET_CASE(4, 4);
+  } else if (e <= 8) {
+    HBK_DET_CASE(4, 8);
+  } else {
+    HBK_DET_CASE(4, 16);
+  }
+#undef HBK_DET_CASE
 }

@@ -72,6 +72,12 @@ PY
     det)        # the deterministic backward: parity, then its cost next to the default on the same box
       timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k deterministic --durations=5 > $O/det_test.log 2>&1; echo "pytest rc=$?" >> $O/det_test.log; tail -12 $O/det_test.log
       (for w in b s R; do for det in 0 1; do HBK_BWD_DETERMINISTIC=$det timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/deterministic=$det  /"; done; done) > $O/det_cost.txt 2>&1; cut -c1-200 $O/det_cost.txt;;
+    detprof)    # kernel times of the deterministic backward (config 2 emit, ragged)
+      export HBK_BENCH_ITERS=4
+      HBK_BWD_DETERMINISTIC=1 prof prof_det_b "" -- $R/tools/bin/bench_ops b
+      HBK_BWD_DETERMINISTIC=1 prof prof_det_R "" -- $R/tools/bin/bench_ops R
+      unset HBK_BENCH_ITERS
+      head -14 $O/prof_det_b.txt | cut -c1-160; head -14 $O/prof_det_R.txt | cut -c1-160; trim prof_det_b; trim prof_det_R;;
     hosttime)   # host time of the backward entry per call (C ABI, no Python)
       (for w in b s R r; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd; done) > $O/hosttime.txt 2>&1; cut -c1-200 $O/hosttime.txt;;
     t_*)        # t_<file stem>[:<-k expression>]: one test file, e.g. t_test_gpu_sync or t_test_gpu_parity:rowsort

@@ -528,4 +528,28 @@ class GroupLookupGrad:
       C.c_size_t(self._ws.numel()), _lib.current_stream(dev)))
     if self.lookup._auto_hot:
       self.lookup.note_backward(self._nu, [int(i.numel()) for i in ids])
+    self._bound_call = (emit, [int(i.numel()) for i in ids])
+    return list(self._views)
+
+  def launch(self, apply_lr=0.0, optimizer='sgd'):
+    """The backward of the LAST call again, on the same tensors (a training loop over resident
+    buffers that are refilled in place; bench.py): the descriptors and the workspace of that call are
+    still right, so this is ONE foreign call -- no validation, no marshalling (the counterpart of
+    ``GroupLookup.launch``).  Same emit mode as that call; returns the same result views."""
+    bound = getattr(self, '_bound_call', None)
+    if bound is None:
+      raise _lib.HbkError(_lib.INTERNAL, 'launch() needs a call that bound the tensors first')
+    emit, n_ids = bound
+    if not emit and apply_lr == 0.0:
+      raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, 'emit=False needs apply_lr != 0')
+    if optimizer == 'adagrad' and apply_lr != 0.0 and self.accums is None:
+      raise _lib.InvalidArgumentError(
+        _lib.INVALID_ARGUMENT, "optimizer='adagrad' needs GroupLookupGrad(lookup, accums=...)")
+    dev = self.lookup.tables[0].device if len(self.lookup) else None
+    _lib.check(self._lib.hbk_group_lookup_bwd_apply(
+      len(self.lookup), self._cols, _lib.APPLY_ADAGRAD if optimizer == 'adagrad' else _lib.APPLY_SGD,
+      C.c_float(apply_lr), C.c_void_p(self._ws.data_ptr()), C.c_size_t(self._ws.numel()),
+      _lib.current_stream(dev)))
+    if self.lookup._auto_hot:
+      self.lookup.note_backward(self._nu, n_ids)
     return list(self._views)

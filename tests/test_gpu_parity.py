@@ -1270,6 +1270,38 @@ def test_group_lookup_backward_fused_adagrad_apply(hbk_option, hook, dense):
                                          optimizer='adagrad')
 
 
+def test_group_lookup_backward_launch_repeats_the_bound_call(hbk_option):
+  """GroupLookupGrad.launch(): the backward of the last call again as ONE foreign call (resident
+  buffers refilled in place) -- same slices as a full call on the refilled tensors, the fused step
+  applied once per launch.  Checked exactly under bwd_deterministic."""
+  hbk_option('bwd_deterministic', 1)
+  rng = np.random.RandomState(12)
+  rows, d, n = 3000, 16, 20000
+  table = rng.uniform(-1, 1, size=(rows, d)).astype(np.float32)
+  ids = dev(rng.randint(0, 2**40, size=n).astype(np.int64))
+  grads = dev(rng.randn(n, d).astype(np.float32))
+  t_dev = dev(table.copy())
+  lookup = hb.embedding.GroupLookup([t_dev], [rows], 'sum')
+  grad = hb.embedding.GroupLookupGrad(lookup)
+  with pytest.raises(hb.HbkError):
+    grad.launch()
+  grad([ids], [grads], apply_lr=0.1)
+  # refill in place, launch twice
+  ids2 = rng.randint(0, 2**40, size=n).astype(np.int64)
+  g2 = rng.randn(n, d).astype(np.float32)
+  ids.copy_(dev(ids2))
+  grads.copy_(dev(g2))
+  want_t = host(t_dev).copy()
+  for _ in range(2):
+    urows, grows, nu = grad.launch(apply_lr=0.1)[0]
+    k = int(nu.item())
+    want_rows, want_sums = _in_order_slices(ids2 % rows, g2, None, 'sum', rows)
+    np.testing.assert_equal(host(urows)[:k], want_rows)
+    np.testing.assert_equal(host(grows)[:k], want_sums)
+    oracle.sparse_sgd_apply(want_t, want_rows, want_sums, 0.1)
+    np.testing.assert_equal(host(t_dev), want_t)
+
+
 def test_group_lookup_backward_fused_sgd_apply():
   rng = np.random.RandomState(11)
   table = rng.uniform(-1, 1, size=(5000, 16)).astype(np.float32)

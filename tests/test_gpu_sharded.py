@@ -330,6 +330,88 @@ def test_cxx_driver_multi_rank_in_process_world(hbk_option, world, wire16, id64,
     cm.close()
 
 
+@pytest.mark.parametrize('world', [1, 2, 4])
+def test_cxx_driver_deterministic_backward_equals_the_unsharded_in_order_sum(hbk_option, world):
+  """bwd_deterministic through the sharded step (round 6): the owner sums the gradient rows it
+  receives in the order they arrive in the exchange buffer -- requester 0's ids in id order, then
+  requester 1's, ... (the partition is stable) -- so the IndexedSlices of the W shards are BIT-EQUAL
+  to the sequential fp32 sum over the ranks' batches concatenated in rank order, i.e. to what ONE
+  unsharded table would accumulate; the fused SGD step lands bit-equal to the oracle's apply of
+  those sums.  Ragged mean / sqrtn and scalar columns, fp32 wire, no requester-side dedup (which
+  sums a requester's duplicates first: another association, by design)."""
+  import threading
+  hbk_option('bwd_deterministic', 1)
+  rng = np.random.RandomState(1700 + world)
+  dims, rows = [16, 8, 32, 4], [5003, 300, 64, 1000]
+  combiners = ['sum', 'mean', 'sqrtn', 'sum']
+  n = len(dims)
+  tables = [rng.uniform(-1, 1, size=(rows[c], dims[c])).astype(np.float32) for c in range(n)]
+  ids, splits, grads = [], [], []
+  for r in range(world):
+    rid, rsp, rg = [], [], []
+    for c in range(n):
+      if c in (0, 3):
+        sp, k = None, 1500
+      else:
+        lens = rng.poisson(3, size=400).clip(0, 12)
+        sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        k = int(sp[-1])
+      rsp.append(sp)
+      rid.append((rng.zipf(1.3, size=k) % rows[c]).astype(np.int64) if c == 3
+                 else rng.randint(0, 2**40, size=k).astype(np.int64))
+      rg.append(rng.randn(k if sp is None else sp.size - 1, dims[c]).astype(np.float32))
+    ids.append(rid)
+    splits.append(rsp)
+    grads.append(rg)
+  comms = hb.distribute.Collective.local_world(world)
+  shards = [[dev(t[r::world].copy()) for t in tables] for r in range(world)]
+  results, errors = [None] * world, []
+  lr = 0.05
+
+  def run(r):
+    try:
+      with torch.cuda.stream(torch.cuda.Stream()):
+        drv = ShardedGroupLookup(shards[r], comms[r], buckets=rows, combiners=combiners)
+        d_ids = [dev(i) for i in ids[r]]
+        d_sp = [None if s is None else dev(s) for s in splits[r]]
+        drv(d_ids, d_sp)
+        sl = drv.backward([dev(g) for g in grads[r]], apply_lr=lr)
+        torch.cuda.current_stream().synchronize()
+        results[r] = [(u.cpu().numpy()[:int(k.item())], g.cpu().numpy()[:int(k.item())])
+                      for u, g, k in sl]
+        drv.close()
+    except Exception:  # pylint: disable=broad-except
+      import traceback
+      errors.append((r, traceback.format_exc()))
+
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=60)
+  for cm in comms:
+    cm.close()
+  assert not errors, errors
+  for c in range(n):
+    # the ranks' per-id gradients, concatenated in rank order
+    g_id = np.concatenate([oracle.segment_combine_grad(
+        grads[r][c], splits[r][c] if splits[r][c] is not None
+        else np.arange(ids[r][c].size + 1, dtype=np.int32), combiners[c]) for r in range(world)])
+    row = np.concatenate([ids[r][c] % rows[c] for r in range(world)])
+    for owner in range(world):
+      mine = row % world == owner
+      local = row[mine] // world
+      uniq = np.unique(local)
+      want = oracle.unsorted_segment_sum(g_id[mine], np.searchsorted(uniq, local).astype(np.int32),
+                                         uniq.size)
+      got_rows, got_sums = results[owner][c]
+      np.testing.assert_equal(got_rows, uniq, err_msg=f'column {c}, owner {owner}')
+      np.testing.assert_equal(got_sums, want, err_msg=f'column {c}, owner {owner}')
+      ref = tables[c][owner::world].copy()
+      oracle.sparse_sgd_apply(ref, uniq, want, lr)
+      np.testing.assert_equal(shards[owner][c].cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize('world,inline,id64,pack_early,block,refuse', [
     (1, 1, False, 1, False, -1), (2, 1, False, 1, False, -1), (4, 1, False, 1, True, -1),
     (8, 1, False, 1, False, -1), (4, 0, False, 1, False, -1), (8, 0, True, 1, True, -1),

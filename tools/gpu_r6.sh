@@ -80,6 +80,23 @@ PY
       head -14 $O/prof_det_b.txt | cut -c1-160; head -14 $O/prof_det_R.txt | cut -c1-160; trim prof_det_b; trim prof_det_R;;
     hosttime)   # host time of the backward entry per call (C ABI, no Python)
       (for w in b s R r; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd; done) > $O/hosttime.txt 2>&1; cut -c1-200 $O/hosttime.txt;;
+    evidence)   # the round's evidence run: bench lines, kernel stats of the same command, traffic, C-ABI ops
+      timeout 600 python bench.py --steps 50 --warmup 10 > $O/ev_bench50.log 2>&1; grep "^{" $O/ev_bench50.log | tail -1 > $O/ev_bench_lines.jsonl
+      timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 > $O/ev_bench20.log 2>&1; grep "^{" $O/ev_bench20.log | tail -1 >> $O/ev_bench_lines.jsonl
+      timeout 600 python bench.py --sharded --steps 50 --warmup 10 --cpu-seconds 0 > $O/ev_bench_sh.log 2>&1; grep "^{" $O/ev_bench_sh.log | tail -1 >> $O/ev_bench_lines.jsonl
+      cut -c1-300 $O/ev_bench_lines.jsonl
+      prof ev_prof_bench "" -- python $R/bench.py --steps 50 --warmup 10 --cpu-seconds 0
+      head -16 $O/ev_prof_bench.txt | cut -c1-160
+      timeout 900 python tools/hbm_traffic.py r06 $O/hbm_traffic.json > $O/ev_traffic.log 2>&1; tail -3 $O/ev_traffic.log; head -30 $O/hbm_traffic.json
+      timeout 600 tools/bin/bench_ops > $O/ev_bench_ops.txt 2>&1; (for w in R r d; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk "; done) >> $O/ev_bench_ops.txt; cut -c1-190 $O/ev_bench_ops.txt
+      trim ev_prof_bench;;
+    cfg5)       # config-5 shape x 3 processes (sweep h): forward, backward + SGD, step only, + Adagrad
+      for i in 1 2 3; do timeout 600 python tools/sweep.py --cases h 2>/dev/null | grep "^{" > $O/ev_sweep_h_$i.jsonl; done
+      for i in 1 2 3; do echo "== process $i"; python -c "
+import sys,json
+for l in open('$O/ev_sweep_h_$i.jsonl'):
+  d=json.loads(l)
+  if 'case' in d: print('  ',d['case'][:90].ljust(90), d['us'])"; done;;
     t_*)        # t_<file stem>[:<-k expression>]: one test file, e.g. t_test_gpu_sync or t_test_gpu_parity:rowsort
       spec=${st#t_}; f=${spec%%:*}; k=""; [ "$spec" != "$f" ] && k=${spec#*:}
       timeout 1500 python -m pytest tests/$f.py -x -q -m gpu ${k:+-k "$k"} --durations=5 > $O/$f.log 2>&1; echo "pytest rc=$?" >> $O/$f.log; tail -15 $O/$f.log;;

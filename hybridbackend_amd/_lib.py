@@ -54,7 +54,7 @@ class LookupGradColumn(C.Structure):
               ('unique_rows', C.c_void_p), ('grad_rows', C.c_void_p),
               ('n_unique', C.c_void_p), ('run_start', C.c_void_p), ('run_ids', C.c_void_p),
               ('run_grads', C.c_void_p), ('n_runs', C.c_int32), ('grad_stride', C.c_int32),
-              ('accum', C.c_void_p)]
+              ('accum', C.c_void_p), ('table_pitch', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class ShardedColumn(C.Structure):

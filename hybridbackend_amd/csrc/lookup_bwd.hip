@@ -250,8 +250,10 @@ struct GCol {
   uint32_t dense_mul;        // != 0: DENSE column -- a bucket is a row RANGE, bucket =
                              // mulhi(row, dense_mul), and the reduce stage indexes its LDS tables
                              // directly with row - first row of the range (4b); 0: hashed buckets
-  int32_t rowsort;           // dense column whose buckets take the row-sorted reduce (4c)
-  int32_t packed;            // row-sorted columns (rows < 2^32): a pair is ONE word of pair_row[],
+  int32_t tpitch;            // floats between rows of table / accum (hbk_lookup_grad_column_t.table_pitch; dim by default)
+  uint8_t rowsort;           // dense column whose buckets take the row-sorted reduce (4c)
+  uint8_t pad_[2];
+  uint8_t packed;            // row-sorted columns (rows < 2^32): a pair is ONE word of pair_row[],
                              // row << 32 | gradient row (segment / float offset); pair_seg[] is not used
 };
 
@@ -1378,7 +1380,7 @@ __device__ inline void emit_step_row(const GCol& c, const ReduceJob& job, float 
   if (!(STEP && job.no_emit)) emit_row<V>(c, job, u, is_new, sub, v);
   if (STEP && lr != 0.0f) {
     constexpr bool adagrad = STEP == 2;
-    const int64_t toff = row * c.dim + (int64_t)sub * VE;
+    const int64_t toff = row * c.tpitch + (int64_t)sub * VE;
     const V tv = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
     V av = zero_v<V>();
     if (adagrad) av = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.accum + toff));
@@ -1730,7 +1732,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
               }
               if (STEP && is_single && lr_now != 0.0f) {
                 // the table (and accumulator) row of the step travels with the gradient
-                const int64_t toff = (int64_t)L.keys[sidx] * c.dim + (int64_t)sub * VE;
+                const int64_t toff = (int64_t)L.keys[sidx] * c.tpitch + (int64_t)sub * VE;
                 tv[STEP ? k : 0] =
                     HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
                 if (STEP == 2) {
@@ -1760,7 +1762,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
               emit_row<V>(c, job, base_u + (-2 - L.slot_out[sidx]), true, sub, pre[k]);
             }
             if (STEP && lr_now != 0.0f) {
-              const int64_t toff = (int64_t)L.keys[sidx] * c.dim + (int64_t)sub * VE;
+              const int64_t toff = (int64_t)L.keys[sidx] * c.tpitch + (int64_t)sub * VE;
               step_row<V>(c, adagrad, lr_now, toff, pre[k], tv[STEP ? k : 0],
                           STEP == 2 ? av[STEP == 2 ? k : 0] : zero_v<V>());
             }
@@ -1919,7 +1921,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
                   const int w = w0 + b;
                   tv[b] = zero_v<V>();
                   if (w < kW && (fin >> w & 1u)) {
-                    const int64_t toff = (int64_t)L.keys[sl[w]] * c.dim + (int64_t)sub * VE;
+                    const int64_t toff = (int64_t)L.keys[sl[w]] * c.tpitch + (int64_t)sub * VE;
                     tv[b] = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
                     if (STEP == 2) {
                       av[STEP == 2 ? b : 0] =
@@ -1935,7 +1937,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
                     if (!job.no_emit) {
                       emit_row<V>(c, job, L.slot_out[s], (L.cnt[s] & kNewBit) != 0, sub, g[w]);
                     }
-                    const int64_t toff = (int64_t)L.keys[s] * c.dim + (int64_t)sub * VE;
+                    const int64_t toff = (int64_t)L.keys[s] * c.tpitch + (int64_t)sub * VE;
                     step_row<V>(c, adagrad, lr_now, toff, g[w], tv[b],
                                 STEP == 2 ? av[STEP == 2 ? b : 0] : zero_v<V>());
                   }
@@ -1999,7 +2001,7 @@ __device__ inline void bucket_reduce(const GCol& c, const ReduceJob& job, Reduce
           g[k] = tv[k] = av[k] = zero_v<V>();
           if (i < n_emitted && live) {
             const int s = L.emitted[i];
-            toff[k] = (int64_t)L.keys[s] * c.dim + (int64_t)sub * VE;
+            toff[k] = (int64_t)L.keys[s] * c.tpitch + (int64_t)sub * VE;
             g[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(
                 job.out_vals + (int64_t)L.slot_out[s] * c.dim + (int64_t)sub * VE));
             tv[k] = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff[k]));
@@ -2256,7 +2258,7 @@ __device__ inline void dense_walk(const WalkArgs w_, DenseLds& L) {
           u_[w] = base_u + (int32_t)(L.pre[ww] & 0xffffu) +
                   __builtin_popcount(L.present[ww] & ((1u << (off & 31u)) - 1u));
           if (STEP && lr != 0.0f) {
-            const int64_t toff = (int64_t)(base + off) * c.dim + (int64_t)sub * VE;
+            const int64_t toff = (int64_t)(base + off) * c.tpitch + (int64_t)sub * VE;
             tv[STEP ? w : 0] =
                 HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
             if (STEP == 2) {
@@ -2271,7 +2273,7 @@ __device__ inline void dense_walk(const WalkArgs w_, DenseLds& L) {
         if ((fin >> w & 1u) && live) {
           if (emit) emit_row<V>(c, job, u_[w], true, sub, g[w]);
           if (STEP && lr != 0.0f) {
-            const int64_t toff = (int64_t)(base + off_[w]) * c.dim + (int64_t)sub * VE;
+            const int64_t toff = (int64_t)(base + off_[w]) * c.tpitch + (int64_t)sub * VE;
             step_row<V>(c, adagrad, lr, toff, g[w], tv[STEP ? w : 0],
                         STEP == 2 ? av[STEP == 2 ? w : 0] : zero_v<V>());
           }
@@ -2591,7 +2593,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
                 mask |= 1u << k;
                 g[k] = load_grad_raw<V>(c, job, L.seg[i], sub, &n_[k]);
                 if (STEP && lr != 0.0f) {
-                  const int64_t toff = (int64_t)(base + L.off[i]) * c.dim + (int64_t)sub * VE;
+                  const int64_t toff = (int64_t)(base + L.off[i]) * c.tpitch + (int64_t)sub * VE;
                   tv[STEP ? k : 0] =
                       HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
                   if (STEP == 2) {
@@ -2630,7 +2632,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
             }
             if (emit) emit_row<V>(c, job, base_u + L.code[i], true, sub, g[k]);
             if (STEP && lr != 0.0f) {
-              const int64_t toff = (int64_t)(base + L.off[i]) * c.dim + (int64_t)sub * VE;
+              const int64_t toff = (int64_t)(base + L.off[i]) * c.tpitch + (int64_t)sub * VE;
               step_row<V>(c, adagrad, lr, toff, g[k], tv[STEP ? k : 0],
                           STEP == 2 ? av[STEP == 2 ? k : 0] : zero_v<V>());
             }
@@ -3313,6 +3315,7 @@ int det_backward(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int32_t a
       d.n_seg = h.n_segments;
       d.dim = h.dim;
       d.grad_stride = h.grad_stride > 0 ? h.grad_stride : h.dim;
+      d.tpitch = h.table_pitch > 0 ? h.table_pitch : h.dim;
       d.n_runs = h.n_runs;
       d.ids64 = h.ids_dtype == HBK_INT64;
       d.combiner = (uint8_t)h.combiner;
@@ -3325,7 +3328,7 @@ int det_backward(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int32_t a
       if (h.dim > max_dim) max_dim = h.dim;
       uintptr_t bits = (uintptr_t)h.grad_out | (uintptr_t)h.grad_rows |
                        ((uintptr_t)(uint32_t)d.grad_stride * 4);
-      if (lr != 0.0f) bits |= (uintptr_t)h.table | (uintptr_t)h.accum;
+      if (lr != 0.0f) bits |= (uintptr_t)h.table | (uintptr_t)h.accum | ((uintptr_t)(uint32_t)h.table_pitch * 4);
       vec4 = vec4 && h.dim % 4 == 0 && bits % 16 == 0 && h.n_runs == 0;
       ++k;
     }
@@ -3525,6 +3528,9 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     HBK_REQUIRE(apply_lr == 0.0f || apply != HBK_APPLY_ADAGRAD || h.accum != nullptr ||
                     h.n_ids == 0,
                 "group_lookup_bwd: column %d: Adagrad needs the accumulator table", c);
+    HBK_REQUIRE(h.table_pitch == 0 || h.table_pitch >= h.dim,
+                "group_lookup_bwd: column %d: table_pitch %d is smaller than dim %d", c, h.table_pitch,
+                h.dim);
     HBK_REQUIRE(h.n_runs >= 0, "group_lookup_bwd: column %d: n_runs must be >= 0", c);
     HBK_REQUIRE(h.n_runs == 0 || (h.row_splits == nullptr && h.run_start && h.run_ids &&
                                   h.run_grads),
@@ -3583,7 +3589,8 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
         HBK_REQUIRE(make_rowshape(h.dim,
                                   (uintptr_t)h.grad_out | (uintptr_t)h.grad_rows |
                                       ((uintptr_t)(uint32_t)h.grad_stride * 4) |
-                                      (apply_lr != 0.0f ? (uintptr_t)h.table | (uintptr_t)h.accum : 0),
+                                      (apply_lr != 0.0f ? (uintptr_t)h.table | (uintptr_t)h.accum |
+                                                              ((uintptr_t)(uint32_t)h.table_pitch * 4) : 0),
                                   &ci.shape),
                     "group_lookup_bwd: dim %d needs more than 64 lanes per row", h.dim);
         // bucket kind: 0 dense, 1 dense with sorted duplicates, 2 hashed, 3 hashed with the wide
@@ -3743,6 +3750,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       d.n_ids = h.n_ids;
       d.n_seg = h.n_segments;
       d.dim = h.dim;
+      d.tpitch = h.table_pitch > 0 ? h.table_pitch : h.dim;
       d.chunks = ci.shape.chunks;
       d.lpr_log2 = ci.shape.lpr_log2;
       d.vec4 = ci.shape.vec4;

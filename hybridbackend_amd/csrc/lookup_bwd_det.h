@@ -39,6 +39,7 @@ struct DCol {
   int32_t dim;
   int32_t grad_stride;
   int32_t n_runs;
+  int32_t tpitch;            // floats between rows of table / accum
   uint8_t ids64, combiner, pad_[2];
 };
 
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void det_reduce_kernel(const DArgs a) {
     for (int e = 0; e < E; ++e) {
       const int ch = sub + e * L;
       if (ch >= chunks) continue;
-      const int64_t t = row * c.dim + (int64_t)ch * VE;
+      const int64_t t = row * c.tpitch + (int64_t)ch * VE;
       V* tp = reinterpret_cast<V*>(c.table + t);
       if (a.apply == HBK_APPLY_ADAGRAD) {
         V* ap = reinterpret_cast<V*>(c.accum + t);

@@ -539,7 +539,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
             tv[STEP ? w : 0] = zero_v<V>();
             if (STEP == 2) av[STEP == 2 ? w : 0] = zero_v<V>();
             if ((mine >> w & 1u) && live) {
-              const int64_t toff = (int64_t)(base + L.roff[uu[w]]) * c.dim + (int64_t)sub * VE;
+              const int64_t toff = (int64_t)(base + L.roff[uu[w]]) * c.tpitch + (int64_t)sub * VE;
               tv[STEP ? w : 0] = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
               if (STEP == 2) {
                 av[STEP == 2 ? w : 0] = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.accum + toff));
@@ -576,7 +576,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
           for (int w = 0; w < W; ++w) {
             if (mine >> w & 1u) {
               if (emit) rs_store_row<V>(c, job, base_u + (int32_t)uu[w], sub, g[w]);
-              const int64_t toff = (int64_t)(base + L.roff[uu[w]]) * c.dim + (int64_t)sub * VE;
+              const int64_t toff = (int64_t)(base + L.roff[uu[w]]) * c.tpitch + (int64_t)sub * VE;
               step_row<V>(c, adagrad, lr, toff, g[w], tv[STEP ? w : 0],
                           STEP == 2 ? av[STEP == 2 ? w : 0] : zero_v<V>());
             }
@@ -614,7 +614,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
         }
         if (one_chunk && stepping) {
           if (emit) rs_store_row<V>(c, job, base_u + (int32_t)u, sub, acc);
-          const int64_t toff = (int64_t)(base + L.roff[u]) * c.dim + (int64_t)sub * VE;
+          const int64_t toff = (int64_t)(base + L.roff[u]) * c.tpitch + (int64_t)sub * VE;
           const V tv = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
           V av = zero_v<V>();
           if (adagrad) av = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.accum + toff));
@@ -677,7 +677,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
         g[k] = tv[k] = av[k] = zero_v<V>();
         if (i < n_rows_job && live) {
           const int64_t row = __builtin_nontemporal_load(job.out_rows + base_u + i);
-          toff[k] = row * c.dim + (int64_t)sub * VE;
+          toff[k] = row * c.tpitch + (int64_t)sub * VE;
           g[k] = __builtin_nontemporal_load(reinterpret_cast<const V*>(
               job.out_vals + (int64_t)(base_u + i) * c.dim + (int64_t)sub * VE));
           tv[k] = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff[k]));

@@ -328,18 +328,28 @@ class GroupLookupGrad:
   hybridbackend/tensorflow/training/gradient.py:193-217).
   """
 
-  def __init__(self, lookup, accums=None):
+  def __init__(self, lookup, accums=None, interleaved=None):
     """accums: per column the Adagrad accumulator table (fp32, same shape as the weights,
-    filled with ``initial_accumulator_value``), needed for ``optimizer='adagrad'``."""
+    filled with ``initial_accumulator_value``), needed for ``optimizer='adagrad'``.
+
+    interleaved: per column an fp32 ``[rows, 2 * dim]`` tensor that holds every row's weights AND
+    accumulator side by side (``[:, :dim]`` the weights, ``[:, dim:]`` the accumulator): the fused
+    optimizer step then works on THAT storage instead of ``lookup.tables`` / ``accums``
+    (``hbk_lookup_grad_column_t.table_pitch`` = 2 dim) -- for dim <= 16 a row's weights and
+    accumulator share one 128-byte line.  The forward keeps reading ``lookup.tables``: a trainer
+    that uses this keeps the weights there in sync itself (a probe of the layout)."""
     self._lib = _lib.lib()
     self.lookup = lookup
     n = len(lookup)
     self.accums = list(accums) if accums is not None else None
+    self.interleaved = list(interleaved) if interleaved is not None else None
+    if self.interleaved is not None and self.accums is None:
+      self.accums = [b[:, b.shape[1] // 2:] for b in self.interleaved]   # (views: "accumulators exist")
     self._cols = (_lib.LookupGradColumn * n)()
     self._cols_np = np.frombuffer(self._cols, dtype=np.dtype(_lib.LookupGradColumn)) if n else None
     for c, t in enumerate(lookup.tables):
       col = self._cols[c]
-      if self.accums is not None:
+      if self.accums is not None and self.interleaved is None:
         a = self.accums[c]
         _lib.require_device_tensor(a, 'accumulator')
         if a.dtype != torch.float32 or a.shape != t.shape:
@@ -349,6 +359,15 @@ class GroupLookupGrad:
       col.table = t.data_ptr()
       col.rows = t.shape[0]
       col.dim = t.shape[1]
+      if interleaved is not None:
+        b = interleaved[c]
+        _lib.require_device_tensor(b, 'interleaved weights + accumulator')
+        if b.dtype != torch.float32 or tuple(b.shape) != (t.shape[0], 2 * t.shape[1]):
+          raise _lib.InvalidArgumentError(
+            _lib.INVALID_ARGUMENT, f'interleaved {c} must be fp32 [{t.shape[0]}, {2 * t.shape[1]}]')
+        col.table = b.data_ptr()
+        col.accum = b.data_ptr() + 4 * t.shape[1]
+        col.table_pitch = 2 * t.shape[1]
       col.bucket = lookup.buckets[c]
       col.divisor = lookup.divisor
       col.combiner = lookup.combiners[c]

@@ -319,6 +319,13 @@ typedef struct {
   int32_t n_runs;
   int32_t grad_stride;       /* row stride of grad_out in floats; 0 = dim (see out_stride) */
   float* accum;              /* Adagrad accumulator [rows, dim] (HBK_APPLY_ADAGRAD), else NULL */
+  /* floats between consecutive rows of `table` AND of `accum` (round 6); 0 = dim.  Lets a caller
+   * keep weights and accumulator interleaved row by row (table = buf, accum = buf + dim,
+   * table_pitch = 2 dim): a dim-16 row's weights and accumulator then share ONE 128-byte line, the
+   * Adagrad step fetches it with one request instead of two.  Only the optimizer step reads it
+   * (the forward takes contiguous rows): measured on the config-5 shape in DESIGN.md 4.4. */
+  int32_t table_pitch;
+  int32_t reserved_;
 } hbk_lookup_grad_column_t;
 
 size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,

@@ -350,6 +350,20 @@ def case_cfg5():
   us = timed(lambda i: grad_a(ids, gouts, splits, apply_lr=0.01, optimizer='adagrad'), iters=5,
              warmup=2)
   report(f'cfg5 bwd + Adagrad apply 200 cols mixed dims B={B}', us, n_ids, n_bytes, ids=n_ids)
+  # lever (d) of VERDICT r04 / r05: weights and accumulator interleaved row by row (table_pitch = 2 dim)
+  del accums, grad_a
+  inter = [torch.empty(rows[c], 2 * dims[c], device=DEV) for c in range(n)]
+  for c in range(n):
+    inter[c][:, :dims[c]].copy_(tables[c])
+    inter[c][:, dims[c]:].fill_(0.1)
+  grad_i = hb.embedding.GroupLookupGrad(lookup, interleaved=inter)
+  us = timed(lambda i: grad_i(ids, gouts, splits, apply_lr=0.01, optimizer='adagrad'), iters=5,
+             warmup=2)
+  report(f'cfg5 bwd + Adagrad apply, weights + accumulator interleaved per row, B={B}', us, n_ids,
+         n_bytes, ids=n_ids)
+  us = timed(lambda i: grad_i(ids, gouts, splits, apply_lr=0.01, optimizer='adagrad', emit=False),
+             iters=5, warmup=2)
+  report(f'cfg5 bwd Adagrad step only, interleaved, B={B}', us, n_ids, n_bytes, ids=n_ids)
 
 
 def case_dense_block():

@@ -2120,6 +2120,7 @@ struct WalkArgs {
   int32_t stride, dim, chunks, n_dl, d0, base_u;
   uint32_t base;
   float lr;
+  int32_t tpitch;
   uint8_t lpr_log2, combiner, seg_is_offset, scale, one_chunk, no_emit;
 };
 
@@ -2133,6 +2134,7 @@ __device__ inline void dense_walk(const WalkArgs w_, DenseLds& L) {
   c.table = w_.table;
   c.accum = w_.accum;
   c.dim = w_.dim;
+  c.tpitch = w_.tpitch;
   c.chunks = w_.chunks;
   c.lpr_log2 = w_.lpr_log2;
   c.combiner = w_.combiner;
@@ -2656,6 +2658,7 @@ __device__ inline void dense_reduce(const GCol& c, const ReduceJob& job, DenseLd
         wa.accum = c.accum;
         wa.stride = job.stride;
         wa.dim = c.dim;
+        wa.tpitch = c.tpitch;
         wa.chunks = c.chunks;
         wa.n_dl = n_dl;
         wa.d0 = d0;

@@ -215,6 +215,12 @@ struct PackArgs {
   int64_t dst_items;       // bound of every store (S is garbage when the partition gave up)
   int32_t n_cols, W, narrow, pad_;
   const int64_t* src[kMaxPackCols];   // shard-ordered ids of the column
+  // p2p form (round 6): the same launch also writes the OUTPUT SLOT of every outgoing id -- the
+  // batch position j of the id that the partition put at shard-ordered position idx[j] -- at the id's
+  // own place in the peer-major layout (what p2p_slots_kernel did from host-made offsets AFTER the
+  // step's host wait: a launch and a table copy off the critical path).  NULL: ids only.
+  int32_t* slots;
+  const int32_t* idx[kMaxPackCols];   // the partition's `indices` of the column (slots != NULL)
   int64_t gbase[kMaxPackCols];        // first item of the column's group in dst
   int32_t n[kMaxPackCols];
   int32_t tile0[kMaxPackCols];
@@ -283,6 +289,28 @@ __global__ __launch_bounds__(kBlock) void pack_ids_kernel(const PackArgs a) {
     } else {
       reinterpret_cast<int64_t*>(a.dst)[at] = v;
     }
+  }
+  if (a.slots == nullptr) return;   // (uniform)
+  // slots[place of the id at shard-ordered position idx[j]] = j
+  const int32_t* idx = a.idx[c];
+#pragma unroll
+  for (int k = 0; k < kPackTile / kBlock; ++k) {
+    const int32_t j = e0 + k * kBlock + tid;
+    if (j >= n) break;
+    const int32_t e = __builtin_nontemporal_load(idx + j);
+    if (e < 0 || e >= cum[W]) continue;   // (garbage when the partition gave up)
+    int q = 0, qh = W;
+    while (qh - q > 1) {
+      const int mid = (q + qh) >> 1;
+      if (cum[mid] <= e) {
+        q = mid;
+      } else {
+        qh = mid;
+      }
+    }
+    const int64_t at = base[q] + (e - cum[q]);
+    if (at < 0 || at >= a.dst_items) continue;
+    a.slots[at] = j;
   }
 }
 
@@ -546,6 +574,8 @@ struct hbk_sharded {
                                           // inverse index, their counts (device), unique's workspace
     hbk::Buffer packed;                // the step's outgoing ids, peer-major per column group
     bool packed_early = false;         // ... written by run_partition (else by the forward)
+    hbk::Buffer slots;                 // p2p form: the output slot of every outgoing id, same layout
+    bool has_slots = false;            // ... written by run_partition's pack launch (round 6)
     int32_t* host_sizes = nullptr;     // pinned [3][N*W]: S, S^T, R as they sit on the device
     hipEvent_t done = nullptr;         // partition + size exchange + D2H copy finished
     hipEvent_t ready = nullptr;        // ... and the ids packed: the whole set is written
@@ -681,6 +711,7 @@ extern "C" int hbk_sharded_destroy(hbk_sharded_t p) {
     set.nu.release();
     set.uniq_ws.release();
     set.packed.release();
+    set.slots.release();
     if (set.host_sizes) (void)hipHostFree(set.host_sizes);
     if (set.done) (void)hipEventDestroy(set.done);
     if (set.ready) (void)hipEventDestroy(set.ready);
@@ -851,8 +882,15 @@ int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* cons
   HBK_HIP_OK(hipEventRecord(set.done, stream));
   // the ids go peer-major into the outgoing buffer while the host waits for `done` (pack_ids_kernel)
   set.packed_early = p->pack_early && N <= kMaxPackCols && W <= kMaxPackWorld && total > 0;
+  set.has_slots = false;
   if (set.packed_early) {
     PackArgs a;
+    a.slots = nullptr;
+    if (p->p2p_bound) {   // the p2p form: slots ride with the pack (one column group)
+      if ((rc = set.slots.ensure((size_t)total * 4 + 16)) != HBK_OK) return rc;
+      a.slots = reinterpret_cast<int32_t*>(set.slots.ptr);
+      set.has_slots = true;
+    }
     a.S = sizes_dev;
     a.dst = set.packed.ptr;
     a.dst_items = total;
@@ -867,6 +905,7 @@ int run_partition(hbk_sharded* p, hbk_sharded::PartSet& set, const int64_t* cons
       int64_t in_group = 0;
       for (int c = c0; c < c1; ++c) {
         a.src[c] = id_src[c];
+        a.idx[c] = idx[c];
         a.gbase[c] = gbase;
         a.n[c] = (int32_t)n_ids[c];
         a.tile0[c] = (int32_t)tiles;
@@ -1361,9 +1400,11 @@ extern "C" int hbk_sharded_lookup_fwd_begin(hbk_sharded_t p, const int64_t* cons
     }
     if ((rc = seg_copy(segs, stream)) != HBK_OK) return rc;
   }
-  int32_t* const slot_send = reinterpret_cast<int32_t*>(p->slot_send.ptr);
+  // (the pack launch of run_partition has written the slots next to the ids: nothing to do here)
+  const bool slots_packed = p2p && set.packed_early && set.has_slots;
+  int32_t* const slot_send = reinterpret_cast<int32_t*>(slots_packed ? set.slots.ptr : p->slot_send.ptr);
   int32_t* const slot_recv = reinterpret_cast<int32_t*>(p->slot_recv.ptr);
-  if (p2p) {   // the output slot of every id, peer-major like the ids
+  if (p2p && !slots_packed) {   // the output slot of every id, peer-major like the ids
     const int64_t* d_soff = reinterpret_cast<const int64_t*>(p->runs_dev.ptr) + 5 * (size_t)N * W;
     const int64_t* d_doff = d_soff + (size_t)N * W;
     int c0 = 0;

@@ -78,6 +78,9 @@ PY
       HBK_BWD_DETERMINISTIC=1 prof prof_det_R "" -- $R/tools/bin/bench_ops R
       unset HBK_BENCH_ITERS
       head -14 $O/prof_det_b.txt | cut -c1-160; head -14 $O/prof_det_R.txt | cut -c1-160; trim prof_det_b; trim prof_det_R;;
+    p2pprof)    # kernel times of the sharded step at one rank in the p2p form
+      prof prof_p2p_on "" -- python $R/bench.py --sharded --steps 30 --warmup 5 --cpu-seconds 0 --no-secondary --tune-steps 4 --p2p on
+      grep -E "hbk|kernel  " $O/prof_p2p_on.txt | cut -c1-150 | head -24; trim prof_p2p_on;;
     hosttime)   # host time of the backward entry per call (C ABI, no Python)
       (for w in b s R r; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd; done) > $O/hosttime.txt 2>&1; cut -c1-200 $O/hosttime.txt;;
     evidence)   # the round's evidence run: bench lines, kernel stats of the same command, traffic, C-ABI ops

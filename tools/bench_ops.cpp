@@ -10,6 +10,7 @@
 
 #include <chrono>
 #include <functional>
+#include <random>
 #include <vector>
 
 #include "../include/hbk.h"
@@ -205,14 +206,29 @@ static void bench_unique(int n_cols, int64_t len, uint64_t mod) {
 }
 
 // H > 0: every sample holds H ids (row_splits 0, H, 2H, ...), combiner mean; n_ids = B
+// H < 0: B / |H| samples of Poisson(|H|) ids clipped to [0, 4 |H|] (SURVEY 8d's multi-hot variant; the
+//        case bench.py times as config.secondary_steps.bwd_ragged), one split array for all columns
 static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float lr,
                            bool step_only = false, int H = 0) {
   const int kPool = 4;
-  const int64_t n_seg = H > 0 ? B / H : B;
+  const int aH = H < 0 ? -H : H;
+  const int64_t n_seg = aH > 0 ? B / aH : B;
   int32_t* splits = nullptr;
-  if (H > 0) {
+  if (aH > 0) {
     std::vector<int32_t> hs((size_t)n_seg + 1);
-    for (int64_t i = 0; i <= n_seg; ++i) hs[(size_t)i] = (int32_t)(i * H);
+    if (H > 0) {
+      for (int64_t i = 0; i <= n_seg; ++i) hs[(size_t)i] = (int32_t)(i * H);
+    } else {
+      std::mt19937 gen(4242);
+      std::poisson_distribution<int> pd((double)aH);
+      hs[0] = 0;
+      for (int64_t i = 0; i < n_seg; ++i) {
+        int len = pd(gen);
+        len = len > 4 * aH ? 4 * aH : len;
+        hs[(size_t)i + 1] = hs[(size_t)i] + len;
+      }
+      B = hs[(size_t)n_seg];     // ids per column
+    }
     splits = dev_alloc<int32_t>((size_t)n_seg + 1);
     CK(hipMemcpy(splits, hs.data(), ((size_t)n_seg + 1) * 4, hipMemcpyHostToDevice));
   }
@@ -243,7 +259,7 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
       h.row_splits = splits;
       h.bucket = rows;
       h.divisor = 1;
-      h.combiner = H > 0 ? HBK_COMBINER_MEAN : HBK_COMBINER_SUM;
+      h.combiner = aH > 0 ? HBK_COMBINER_MEAN : HBK_COMBINER_SUM;
       h.grad_out = gout + (size_t)c * n_seg * dim;
       h.unique_rows = step_only ? nullptr : urows + (size_t)c * B;
       h.grad_rows = step_only ? nullptr : grows + (size_t)c * B * dim;
@@ -260,7 +276,7 @@ static void bench_backward(int n_cols, int64_t B, int dim, int64_t rows, float l
   const double n = (double)n_cols * B;
   char what[128];
   snprintf(what, sizeof(what), "group_lookup_bwd %d x %lld ids%s, dim %d, %lld rows%s", n_cols,
-           (long long)B, H > 0 ? " (ragged mean)" : "", dim, (long long)rows,
+           (long long)B, H > 0 ? " (ragged mean)" : H < 0 ? " (ragged Poisson lengths, mean)" : "", dim, (long long)rows,
            step_only ? ", SGD step only" : lr != 0.f ? " + SGD apply" : "");
   printf("%-66s %9.2f us  %8.1f M lookups/s   (host %.1f us per call)\n", what, us, n / us, g_host_us);
   {  // probe build: stamps of the grouping kernel's workgroups
@@ -464,6 +480,10 @@ int main(int argc, char** argv) {
     // (bench_ops R 64: 64 ids per segment -- the same pairs and output rows over a gradient block of
     // 512 KB per column instead of 4 MB: what the reduce stage costs when its gradient reads hit L2)
     bench_backward(26, 524288, 16, 1000000, 0.f, false, argc > 2 ? atoi(argv[2]) : 8);
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'Q') {  // the ragged case with Poisson(8) lengths clipped to [0, 32]: bench.py's bwd_ragged
+    bench_backward(26, 524288, 16, 1000000, 0.f, false, -8);
     return 0;
   }
   if (argc > 1 && argv[1][0] == 'r') {  // "ragged": config-5-like columns (8 ids per sample, mean)

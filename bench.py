@@ -351,7 +351,9 @@ def backward_secondary(args, hb, tables, batches, device, timed_steps, steps=20,
     grads = [torch.randn(n_seg[c], dim, device=device, generator=gen) for c in range(cols)]
     lookup = hb.embedding.GroupLookup(tables, buckets=[args.rows] * cols, combiners=combiner)
     # one gradient object per resident batch: handed the same tensors again, a call re-binds nothing
-    objs = [hb.embedding.GroupLookupGrad(lookup) for _ in ids_pool]
+    objs = []
+    for _ in ids_pool:     # (one workspace for all of them: they run one after the other)
+      objs.append(hb.embedding.GroupLookupGrad(lookup, workspace_of=objs[0] if objs else None))
 
     for k, obj in enumerate(objs):      # binds the batch's tensors (validation + marshalling, once)
       obj(ids_pool[k], grads, splits, apply_lr=lr, emit=emit)

@@ -328,7 +328,7 @@ class GroupLookupGrad:
   hybridbackend/tensorflow/training/gradient.py:193-217).
   """
 
-  def __init__(self, lookup, accums=None, interleaved=None):
+  def __init__(self, lookup, accums=None, interleaved=None, workspace_of=None):
     """accums: per column the Adagrad accumulator table (fp32, same shape as the weights,
     filled with ``initial_accumulator_value``), needed for ``optimizer='adagrad'``.
 
@@ -337,7 +337,11 @@ class GroupLookupGrad:
     optimizer step then works on THAT storage instead of ``lookup.tables`` / ``accums``
     (``hbk_lookup_grad_column_t.table_pitch`` = 2 dim) -- for dim <= 16 a row's weights and
     accumulator share one 128-byte line.  The forward keeps reading ``lookup.tables``: a trainer
-    that uses this keeps the weights there in sync itself (a probe of the layout)."""
+    that uses this keeps the weights there in sync itself (a probe of the layout).
+
+    workspace_of: another GroupLookupGrad whose scratch memory this one uses too (objects bound to
+    different resident batches that run one after the other on one stream need one workspace, not
+    one each)."""
     self._lib = _lib.lib()
     self.lookup = lookup
     n = len(lookup)
@@ -371,7 +375,15 @@ class GroupLookupGrad:
       col.bucket = lookup.buckets[c]
       col.divisor = lookup.divisor
       col.combiner = lookup.combiners[c]
-    self._ws = None
+    self._ws_box = workspace_of._ws_box if workspace_of is not None else [None]
+
+  @property
+  def _ws(self):
+    return self._ws_box[0]
+
+  @_ws.setter
+  def _ws(self, t):
+    self._ws_box[0] = t
 
   def _bind_fresh(self, ids, grads, row_splits, emit, block):
     """The descriptors of a step with tensors never seen before, in one pass and written field by
@@ -535,6 +547,7 @@ class GroupLookupGrad:
     need = self._lib.hbk_group_lookup_bwd_workspace_bytes(n, self._cols)   # (depends on options too)
     if self._ws is None or self._ws.numel() < need:
       self._ws = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
+    self._ws_bound = self._ws       # (launch(): the workspace this binding was sized for)
     self._keep = (ids, grads, row_splits)
     if optimizer not in ('sgd', 'adagrad'):
       raise _lib.InvalidArgumentError(_lib.INVALID_ARGUMENT, "optimizer must be 'sgd' or 'adagrad'")
@@ -567,8 +580,8 @@ class GroupLookupGrad:
     dev = self.lookup.tables[0].device if len(self.lookup) else None
     _lib.check(self._lib.hbk_group_lookup_bwd_apply(
       len(self.lookup), self._cols, _lib.APPLY_ADAGRAD if optimizer == 'adagrad' else _lib.APPLY_SGD,
-      C.c_float(apply_lr), C.c_void_p(self._ws.data_ptr()), C.c_size_t(self._ws.numel()),
-      _lib.current_stream(dev)))
+      C.c_float(apply_lr), C.c_void_p(self._ws_bound.data_ptr()),
+      C.c_size_t(self._ws_bound.numel()), _lib.current_stream(dev)))
     if self.lookup._auto_hot:
       self.lookup.note_backward(self._nu, n_ids)
     return list(self._views)

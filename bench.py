@@ -596,10 +596,21 @@ def main():
         dt = float(t.item())
       groups_probe[name] = round(dt / args.tune_steps * 1e3, 5)
     best_form = min((k for k, v in groups_probe.items() if v is not None), key=groups_probe.get)
-    # reference: three plans over the one communicator, begin(step i + 1) before end(step i)
-    # (hb.embedding.PipelinedLookup): ids(i + 1) travel ahead of rows(i).  Outputs arrive one step
-    # late (forward-only use), so the timed steps never run in this form.
-    groups_probe['pipelined_steps_3'] = None
+    groups_probe['pipelined_steps_3'] = None   # (measured behind the headline steps, see below)
+    _hbk.set_option('sharded_groups', forms[best_form][0])
+    _hbk.set_option('sharded_inline', forms[best_form][1])
+    sharded.close()
+    if forms[best_form][2]:
+      sharded.p2p_bind(sh_outs)
+
+  def probe_pipelined_steps_3():
+    """Reference form: three plans over the one communicator, begin(step i + 1) before end(step i)
+    (hb.embedding.PipelinedLookup): ids(i + 1) travel ahead of rows(i).  Outputs arrive one step
+    late (forward-only use), so the timed steps never run in this form -- and it is measured BEHIND
+    them: a first contact with a multi-GPU box that goes wrong here costs a reference figure, not
+    the headline (the watchdog then prints the line without it)."""
+    from hybridbackend_amd import _lib as _hbk
+    old_groups = _hbk.get_option('sharded_groups')
     try:
       sharded.close()
       _hbk.set_option('sharded_groups', 1)
@@ -620,7 +631,8 @@ def main():
       torch.cuda.synchronize()
       barrier()
       t_probe = time.perf_counter()
-      for i in range(args.tune_steps):
+      n3 = max(args.tune_steps, 6)
+      for i in range(n3):
         step3(6 + i)
       pipe.flush()
       torch.cuda.synchronize()
@@ -630,17 +642,13 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-      groups_probe['pipelined_steps_3'] = round(dt / args.tune_steps * 1e3, 5)
       pipe.close()
-      del plans3, pipe, outs3, bounds3
+      return round(dt / n3 * 1e3, 5), None
     except Exception as e:  # pylint: disable=broad-except
       # (the same code on every rank: the same error on every rank; a reference only)
-      groups_probe['pipelined_steps_3_error'] = f'{type(e).__name__}: {e}'[:200]
-    _hbk.set_option('sharded_groups', forms[best_form][0])
-    _hbk.set_option('sharded_inline', forms[best_form][1])
-    sharded.close()
-    if forms[best_form][2]:
-      sharded.p2p_bind(sh_outs)
+      return None, f'{type(e).__name__}: {e}'[:200]
+    finally:
+      _hbk.set_option('sharded_groups', old_groups)
 
   def timed_steps(step_fn, steps, warmup):
     """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides;
@@ -832,6 +840,11 @@ def main():
         'other_wire_ms_per_step': round(el2 / sec_steps * 1e3, 5),
         'secondary_steps': {'steps': sec_steps, 'warmup': sec_warm}}
       del r_plans, full
+      if groups_probe is not None:
+        ms3, err3 = probe_pipelined_steps_3()
+        groups_probe['pipelined_steps_3'] = ms3
+        if err3:
+          groups_probe['pipelined_steps_3_error'] = err3
     except Exception as e:  # pylint: disable=broad-except
       # (every rank runs the same code on the same shapes: an error here is the same error on
       # every rank; the headline steps are measured and their line goes out regardless)

@@ -105,6 +105,72 @@ def test_group_lookup_random_plans(cols, opts, seed):
       _lib.set_option(k, v)
 
 
+@_cfg(40)
+@given(cols=st.lists(st.one_of(big_column, column), min_size=1, max_size=6),
+       seed=st.integers(0, 2**31 - 1))
+def test_group_lookup_deterministic_random(cols, seed):
+  """Option bwd_deterministic over the same random columns (round 6): the emitted rows are the
+  distinct valid rows ascending, their sums BIT-EQUAL to the sequential fp32 sum in id order, the
+  fused step (SGD or Adagrad by the seed, on contiguous tables or -- every third draw -- on weights and
+  accumulator interleaved per row) bit-equal to the oracle's apply of those sums."""
+  import oracle
+  import hybridbackend_amd as hb
+  from hybridbackend_amd import _lib
+  rng = np.random.RandomState(seed)
+  tables, ids, splits, buckets, combs, grads = [], [], [], [], [], []
+  for c in cols:
+    if c['dim'] % 4 != 0 and c['dim'] > 64:
+      c = dict(c, dim=64)
+    tables.append(rng.uniform(-1, 1, size=(c['rows'], c['dim'])).astype(np.float32))
+    if c['ragged']:
+      lens = rng.randint(0, c['max_len'] + 1, size=c['n_seg'])
+      sp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+      n = int(sp[-1])
+    else:
+      sp, n = None, c['n_seg']
+    splits.append(sp)
+    ids.append(np.asarray(_ids(rng, n, c['rows'], c['skew']), np.int64))
+    buckets.append(c['rows'])
+    combs.append(c['combiner'])
+    grads.append(rng.randn(c['n_seg'], c['dim']).astype(np.float32))
+  opt = 'adagrad' if seed % 2 else 'sgd'
+  interleaved = seed % 3 == 0
+  old = _lib.set_option('bwd_deterministic', 1)
+  try:
+    t_dev = [dev(t.copy()) for t in tables]
+    a_dev = [torch.full_like(t, 0.1) for t in t_dev]
+    inter = [dev(np.concatenate([t, np.full_like(t, 0.1)], axis=1)) for t in tables]
+    lookup = hb.embedding.GroupLookup(t_dev, buckets, combs)
+    grad = (hb.embedding.GroupLookupGrad(lookup, interleaved=inter) if interleaved
+            else hb.embedding.GroupLookupGrad(lookup, accums=a_dev))
+    res = grad([dev(i) for i in ids], [dev(g) for g in grads],
+               [None if s is None else dev(s) for s in splits], apply_lr=0.03, optimizer=opt)
+    for k in range(len(cols)):
+      rows = ids[k] % buckets[k]
+      sp = splits[k] if splits[k] is not None else np.arange(rows.size + 1, dtype=np.int32)
+      g_id = oracle.segment_combine_grad(grads[k], sp, combs[k])
+      uniq = np.unique(rows)
+      want = oracle.unsorted_segment_sum(g_id, np.searchsorted(uniq, rows).astype(np.int32),
+                                         uniq.size)
+      u, g, nu = res[k]
+      n = int(nu.item())
+      assert n == uniq.size
+      np.testing.assert_equal(u.cpu().numpy()[:n], uniq)
+      np.testing.assert_equal(g.cpu().numpy()[:n], want)
+      want_t, want_a = tables[k].copy(), np.full(tables[k].shape, 0.1, np.float32)
+      if opt == 'adagrad':
+        oracle.sparse_adagrad_apply(want_t, want_a, uniq, want, 0.03)
+      else:
+        oracle.sparse_sgd_apply(want_t, uniq, want, 0.03)
+      d = tables[k].shape[1]
+      got_t = inter[k].cpu().numpy()[:, :d] if interleaved else t_dev[k].cpu().numpy()
+      got_a = inter[k].cpu().numpy()[:, d:] if interleaved else a_dev[k].cpu().numpy()
+      np.testing.assert_equal(got_t, want_t)
+      np.testing.assert_equal(got_a, want_a)
+  finally:
+    _lib.set_option('bwd_deterministic', old)
+
+
 def _check_group_lookup(cols, seed):
   import oracle
   import hybridbackend_amd as hb

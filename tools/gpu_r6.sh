@@ -81,6 +81,8 @@ PY
     p2pprof)    # kernel times of the sharded step at one rank in the p2p form
       prof prof_p2p_on "" -- python $R/bench.py --sharded --steps 30 --warmup 5 --cpu-seconds 0 --no-secondary --tune-steps 4 --p2p on
       grep -E "hbk|kernel  " $O/prof_p2p_on.txt | cut -c1-150 | head -24; trim prof_p2p_on;;
+    fuzzhunt)   # the fuzz tests with fresh random draws, 6 x the committed example counts
+      HBK_FUZZ_RANDOM=1 HBK_FUZZ_SCALE=6 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu --durations=6 > $O/fuzzhunt.log 2>&1; echo "pytest rc=$?" >> $O/fuzzhunt.log; tail -14 $O/fuzzhunt.log;;
     hosttime)   # host time of the backward entry per call (C ABI, no Python)
       (for w in b s R r; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd; done) > $O/hosttime.txt 2>&1; cut -c1-200 $O/hosttime.txt;;
     evidence)   # the round's evidence run: bench lines, kernel stats of the same command, traffic, C-ABI ops

@@ -88,6 +88,9 @@ __device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t
 #ifndef HBK_RS_PAIR_STORES
 #define HBK_RS_PAIR_STORES 1
 #endif
+#ifndef HBK_RS_PAIR_DIST
+#define HBK_RS_PAIR_DIST 3   // positions between two rows of one lane group that still leave as one line (1: round 5)
+#endif
 template <int CTRL>
 __device__ inline int rs_dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
@@ -142,8 +145,20 @@ __device__ inline void rs_store_pairs(const GCol& c, const ReduceJob& job, int32
     const int32_t R = base_u + (int32_t)uu[w];
     bool pair = false;
     if (w + 1 < W) {
-      pair = partner_on && ((mine >> w) & 3u) == 3u && ((R + half0) & 1) == 0 &&
+      // the NEXT row this lane group finishes in the batch sits at the next set bit of `mine`; rows
+      // finish in rank order, so it is row R + 1 -- the other half of R's line when R is the even one.
+      // Round 5 paired only rows finishing at ADJACENT positions (the second row a single pair):
+      // 45 % of the even rows of the ragged case; up to HBK_RS_PAIR_DIST positions apart covers runs of
+      // up to that many pairs.
+      const uint32_t ahead = ((mine & ~done) >> (w + 1)) & ((1u << HBK_RS_PAIR_DIST) - 1u);
+      const int d = ahead != 0u ? __builtin_ctz(ahead) + 1 : 0;
+      pair = partner_on && ((mine >> w) & 1u) != 0u && d != 0 && ((R + half0) & 1) == 0 &&
              ((done >> w) & 1u) == 0u;
+      f32x4 nxt = g[w + 1];
+#pragma unroll
+      for (int k = 2; k <= HBK_RS_PAIR_DIST; ++k) {
+        if (w + k < W && d == k) nxt = g[w + k];
+      }
       // turn e: the octet stores the pair of its lane group e
       // (every DPP move outside any lane-dependent condition: a source lane that is masked off reads as 0)
       const int p_i = pair ? 1 : 0;
@@ -152,20 +167,20 @@ __device__ inline void rs_store_pairs(const GCol& c, const ReduceJob& job, int32
       const int p_from_even = odd_group ? p_shr : p_i;   // group 0's flag
       const int p_from_odd = odd_group ? p_i : p_shl;     // group 1's flag
       if (__builtin_amdgcn_ballot_w64(p_from_even != 0) != 0ull) {   // (wave-uniform branch)
-        const f32x4 second = rs_dpp_v<kDppRowShr4>(g[w + 1]);     // group 0's g[w + 1] in group 1's lanes
+        const f32x4 second = rs_dpp_v<kDppRowShr4>(nxt);          // group 0's next row in group 1's lanes
         const int32_t r_even = rs_dpp_i<kDppRowShr4>(R);
         if (p_from_even != 0) {
           rs_store_row<f32x4>(c, job, odd_group ? r_even + 1 : R, sub, odd_group ? second : g[w]);
         }
       }
       if (__builtin_amdgcn_ballot_w64(p_from_odd != 0) != 0ull) {
-        const f32x4 second = rs_dpp_v<kDppRowShl4>(g[w + 1]);     // group 1's g[w + 1] in group 0's lanes
+        const f32x4 second = rs_dpp_v<kDppRowShl4>(nxt);          // group 1's next row in group 0's lanes
         const int32_t r_odd = rs_dpp_i<kDppRowShl4>(R);
         if (p_from_odd != 0) {
           rs_store_row<f32x4>(c, job, odd_group ? R : r_odd + 1, sub, odd_group ? g[w] : second);
         }
       }
-      if (pair) done |= 3u << w;
+      if (pair) done |= (1u << w) | (1u << (w + d));
     }
     if (((mine & ~done) >> w) & 1u) rs_store_row<f32x4>(c, job, R, sub, g[w]);
   }

@@ -83,6 +83,17 @@ PY
       grep -E "hbk|kernel  " $O/prof_p2p_on.txt | cut -c1-150 | head -24; trim prof_p2p_on;;
     fuzzhunt)   # the fuzz tests with fresh random draws, 6 x the committed example counts
       HBK_FUZZ_RANDOM=1 HBK_FUZZ_SCALE=6 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu --durations=6 > $O/fuzzhunt.log 2>&1; echo "pytest rc=$?" >> $O/fuzzhunt.log; tail -14 $O/fuzzhunt.log;;
+    pairab)     # paired output stores of the row-sorted reduce: rows up to HBK_RS_PAIR_DIST positions apart (probe builds)
+      (for rep in 1 2; do for v in ${VARIANTS:-base d2 d3 d3w10 d2w10}; do
+         for w in R Q b; do LD_LIBRARY_PATH=$R/tools/bin/variants/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/$v  /"; done
+       done; done) > $O/pairab.txt 2>&1; cut -c1-150 $O/pairab.txt;;
+    pairpmc)    # write / read requests of the ragged backward's reduce kernel per variant
+      export HBK_BENCH_ITERS=2
+      for v in ${VARIANTS:-base d3}; do
+        LD_LIBRARY_PATH=$R/tools/bin/variants/$v prof pmc_pair_$v "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" -- $R/tools/bin/bench_ops R
+        echo "== $v"; tail -1 $O/pmc_pair_$v.log; pmc_table $O/pmc_pair_$v.json bwd_rowsort; trim pmc_pair_$v
+      done
+      unset HBK_BENCH_ITERS;;
     hosttime)   # host time of the backward entry per call (C ABI, no Python)
       (for w in b s R r; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd; done) > $O/hosttime.txt 2>&1; cut -c1-200 $O/hosttime.txt;;
     evidence)   # the round's evidence run: bench lines, kernel stats of the same command, traffic, C-ABI ops

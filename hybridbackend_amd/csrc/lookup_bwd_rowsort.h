@@ -89,7 +89,7 @@ __device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t
 #define HBK_RS_PAIR_STORES 1
 #endif
 #ifndef HBK_RS_PAIR_DIST
-#define HBK_RS_PAIR_DIST 3   // positions between two rows of one lane group that still leave as one line (1: round 5)
+#define HBK_RS_PAIR_DIST 1   // positions between two rows of one lane group that still leave as one line; 2 and 3: probe builds (round 6, see below)
 #endif
 template <int CTRL>
 __device__ inline int rs_dpp_i(int v) {

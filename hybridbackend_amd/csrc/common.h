@@ -150,9 +150,10 @@ struct Options {
   int bwd_pairs_packed = 1;    // HBK_BWD_PAIRS_PACKED: row-sorted columns: a pair is ONE 8-byte word (row << 32 | gradient row) instead of an int64 + an int32 array (0: two arrays)
   int bwd_seg_inline = 1;      // HBK_BWD_SEG_INLINE: ragged columns: the segment of an id is found inside the grouping kernels (row splits of the tile in LDS); 0: a seg-of array written by a launch of its own
   int bwd_scale_fused = 1;     // HBK_BWD_SCALE_FUSED: large ragged mean / sqrtn columns: the segments' gradient rows are scaled by the histogram launch (0: by a launch of their own)
-  int bwd_deterministic = 0;   // HBK_BWD_DETERMINISTIC: 1 = every row's gradient is summed in id order by ONE lane group (stable sort of the
-                               // batch's (row, gradient row) pairs + sequential walk, lookup_bwd_det.h): bit-identical from run to run and
-                               // equal to the in-order fp32 sum; slower (a full sort)
+  int bwd_deterministic = 0;   // HBK_BWD_DETERMINISTIC: every row's gradient is summed in id order by ONE lane group: bit-identical from run
+                               // to run and equal to the in-order fp32 sum, rows ascending.  1 = the row-sorted jobs' in-order form
+                               // (lookup_bwd_rowsort.h: DET) for the columns whose row range fits them, the sort for the others;
+                               // 2 = a stable sort of the batch's (row, gradient row) pairs + sequential walk for every column (lookup_bwd_det.h)
   int bwd_streams = 4;         // HBK_BWD_STREAMS: launch groups of a backward of > 64 (or mixed) columns rotate over this many library streams (0: all on the caller's stream)
   int bwd_lds_pad = 0;         // HBK_BWD_LDS_PAD: a probe: KB of unused LDS added to the grouping launches (fewer resident tiles)
   int bwd_trace = 0;           // HBK_BWD_TRACE: the composition of every launch group of a backward call on stderr

@@ -252,7 +252,9 @@ struct GCol {
                              // directly with row - first row of the range (4b); 0: hashed buckets
   int32_t tpitch;            // floats between rows of table / accum (hbk_lookup_grad_column_t.table_pitch; dim by default)
   uint8_t rowsort;           // dense column whose buckets take the row-sorted reduce (4c)
-  uint8_t pad_[2];
+  uint8_t det;               // deterministic jobs (option bwd_deterministic, lookup_bwd_rowsort.h): the one-launch
+                             // grouping leaves every tile's offset inside its buckets in hist[], like the scan
+  uint8_t pad_;
   uint8_t packed;            // row-sorted columns (rows < 2^32): a pair is ONE word of pair_row[],
                              // row << 32 | gradient row (segment / float offset); pair_seg[] is not used
 };
@@ -1105,6 +1107,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
   for (int p = beg; p < end; ++p) {
     const int32_t n_b = tot_s[p];
     const int32_t n_c = counters[p];
+    if (c.det) c.hist[(int64_t)ctile * P + p] = pre_s[p];   // where the tile's share of the bucket begins
     tot_s[p] = run + pre_s[p] - run_c;   // global position of the tile's pair at staged slot L: + L
     pre_s[p] = run_c;                    // first staged slot of the bucket
     if (first_tile) {
@@ -3136,7 +3139,11 @@ ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged) {
     // 704 at 64 x; the config-5 mix +- 1 %); wide rows with skewed ids lose there (config 4 Zipf,
     // dim 128: 343 -> 447 us)
     const int64_t ratio = (int64_t)options().bwd_rowsort_ratio * (dim <= 32 ? 4 : 1);
-    const bool want = dense_opt == 3 || (dense_opt == 1 && ratio > 0 && rows <= ratio * n_ids);
+    // deterministic mode (bwd_deterministic = 1): row-sorted jobs wherever the row range fits -- the one
+    // reduce kind with an in-order form (lookup_bwd_rowsort.h) -- and no bucket is split over
+    // workgroups (partial sums joined by a merge are not the sequential sum)
+    const bool det = options().bwd_deterministic == 1;
+    const bool want = det || dense_opt == 3 || (dense_opt == 1 && ratio > 0 && rows <= ratio * n_ids);
     if (kTeam == kBlock && want && rows >= 1 && rows < (1ll << 32)) {
       int64_t rs_target = (int64_t)kRsCap * 7 / 8;
       // wide rows: a lane group is 16-64 lanes, a workgroup holds 4-16 of them, and a job of 1792
@@ -3169,6 +3176,7 @@ ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged) {
           int64_t t = 2 * ((n_ids + P - 1) / P) + 128;
           if (t < 2 * kRsCap) t = 2 * kRsCap;
           if (options().bwd_split_pairs > 0) t = options().bwd_split_pairs;
+          if (det) t = 0x7fffffff;
           p.split_t = (int32_t)t;
           p.e_max = (int32_t)(n_ids / t + 1);
           return p;
@@ -3227,6 +3235,20 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
     b += align8((size_t)h.n_ids * h.dim * 4) + 16;         // chunks, split buckets)
   }
   return b;
+}
+
+// deterministic mode, option value 1: the columns whose buckets fit the row-sorted jobs take their
+// in-order form (lookup_bwd_rowsort.h); the others -- tables too sparse or too large for row-range
+// buckets, segmented inputs (their gradient rows need not ascend with the ids) -- and everything
+// under option value 2 go through the sort of lookup_bwd_det.h
+inline bool det_rowsort(const hbk_lookup_grad_column_t& h) {
+  if (options().bwd_deterministic != 1 || h.n_ids <= 0 || h.n_runs > 0) return false;
+  return plan_of(h.n_ids, h.dim, h.rows, h.row_splits != nullptr).rowsort;
+}
+inline void det_split(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
+                      std::vector<hbk_lookup_grad_column_t>* fast,
+                      std::vector<hbk_lookup_grad_column_t>* slow) {
+  for (int32_t c = 0; c < n_cols; ++c) (det_rowsort(cols[c]) ? fast : slow)->push_back(cols[c]);
 }
 
 // ---- host side of the deterministic backward (lookup_bwd_det.h) -----------------------------------
@@ -3417,8 +3439,13 @@ extern "C" size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
                                                        const hbk_lookup_grad_column_t* cols) {
   if (n_cols <= 0 || cols == nullptr) return 0;
   if (hbk::options().bwd_deterministic != 0) {
-    const size_t det = hbk::det_layout(n_cols, cols).total;
-    return det == 0 ? 0 : det + 256;
+    std::vector<hbk_lookup_grad_column_t> fast, slow;
+    hbk::det_split(n_cols, cols, &fast, &slow);
+    size_t total = hbk::det_layout((int32_t)slow.size(), slow.data()).total;
+    if (total != 0) total += 256;
+    size_t planned = 0;
+    for (const hbk_lookup_grad_column_t& h : fast) planned += hbk::col_workspace(h);
+    return total + (planned == 0 ? 0 : planned + 256);
   }
   size_t total = 0;
   for (int32_t c = 0; c < n_cols; ++c) total += hbk::col_workspace(cols[c]);
@@ -3494,6 +3521,9 @@ BwdHelpers* bwd_helpers(hipStream_t caller) {
 }  // namespace
 }  // namespace hbk
 
+static int bwd_planned(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int32_t apply,
+                       float apply_lr, void* workspace, hipStream_t stream, bool det);
+
 extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
                                           int32_t apply, float apply_lr, void* workspace,
                                           size_t workspace_bytes, hbk_stream_t stream_) {
@@ -3550,10 +3580,28 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     const int rc = sync_check("group_lookup_bwd", stream);
     if (rc != HBK_OK) return rc;
   }
-  // option bwd_deterministic: sort + in-order walk instead of everything below (lookup_bwd_det.h)
+  // option bwd_deterministic: the in-order forms -- row-sorted jobs where they fit (1), the sort + walk
+  // of lookup_bwd_det.h for the other columns (and for all of them under 2)
   if (options().bwd_deterministic != 0) {
-    return det_backward(n_cols, cols, apply, apply_lr, workspace, stream);
+    std::vector<hbk_lookup_grad_column_t> fast, slow;
+    det_split(n_cols, cols, &fast, &slow);
+    size_t slow_bytes = det_layout((int32_t)slow.size(), slow.data()).total;
+    if (slow_bytes != 0) slow_bytes += 256;
+    if (!slow.empty()) {
+      const int rc = det_backward((int32_t)slow.size(), slow.data(), apply, apply_lr, workspace, stream);
+      if (rc != HBK_OK) return rc;
+    }
+    if (fast.empty()) return HBK_OK;
+    return bwd_planned((int32_t)fast.size(), fast.data(), apply, apply_lr,
+                       reinterpret_cast<char*>(workspace) + slow_bytes, stream, true);
   }
+  return bwd_planned(n_cols, cols, apply, apply_lr, workspace, stream, false);
+}
+
+// the bucket plans: grouping, reduce, merge (everything but the sort path of the deterministic mode)
+static int bwd_planned(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int32_t apply,
+                       float apply_lr, void* workspace, hipStream_t stream, bool det) {
+  using namespace hbk;
   // head of the workspace: the job descriptors of all columns (16-byte aligned), then the
   // per-column buffers
   char* cp = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -3737,6 +3785,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
       d.e_max = p.e_max;
       d.dense_mul = p.dense_mul;
       d.rowsort = p.rowsort ? 1 : 0;
+      d.det = det ? 1 : 0;
       d.merge0 = (int32_t)merges;
       const int64_t merge_blocks = p.e_max < kMergeBlocks ? p.e_max : kMergeBlocks;
       d.scan0 = (int32_t)scans;
@@ -3847,7 +3896,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     // above the mean.  Option bwd_xcd: 0 never, 1 this rule, 2 always.
     args.xcd = 0;
     for (int kind = 0; kind < kKinds; ++kind) {
-      if (!have_kind[kind] || options().bwd_xcd == 0) continue;
+      if (!have_kind[kind] || options().bwd_xcd == 0 || det) continue;   // (deterministic: job slots in block order)
       bool even = options().bwd_xcd == 2;
       if (!even) {
         const int64_t per = kind >= 4 && kind < 8 ? kTeams : 1;
@@ -3888,7 +3937,7 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     args.xcd_w = 0;
     args.stage_p = 0;
     int64_t xcd_grid[kKinds] = {0};
-    if ((options().bwd_xcd == 4 || options().bwd_xcd == 1 || options().bwd_xcd == 3) && kTeams == 1) {
+    if ((options().bwd_xcd == 4 || options().bwd_xcd == 1 || options().bwd_xcd == 3) && kTeams == 1 && !det) {
       for (int kind = 0; kind < kKinds; ++kind) {
         if (!have_kind[kind]) continue;
         if (options().bwd_xcd != 4 && !((args.xcd >> kind) & 1)) continue;
@@ -4010,11 +4059,23 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
          &bwd_rowsort_merge_kernel<f32x4, 2>},
         {&bwd_rowsort_merge_kernel<float, 0>, &bwd_rowsort_merge_kernel<float, 1>,
          &bwd_rowsort_merge_kernel<float, 2>}};
+    static const reduce_fn kReduceDet[2][3] = {
+        {&bwd_rowsort_det_kernel<f32x4, 0>, &bwd_rowsort_det_kernel<f32x4, 1>, &bwd_rowsort_det_kernel<f32x4, 2>},
+        {&bwd_rowsort_det_kernel<float, 0>, &bwd_rowsort_det_kernel<float, 1>, &bwd_rowsort_det_kernel<float, 2>}};
     for (int kind = 0; kind < kKinds; ++kind) {
       if (!have_kind[kind]) continue;
       const int64_t n_slots = slot_hi[kind] - slot_lo[kind];
       const int64_t per = kind >= 4 && kind < 8 ? kTeams : 1;   // job slots per workgroup
       const int64_t grid = xcd_grid[kind] > 0 ? xcd_grid[kind] : (n_slots + per - 1) / per;
+      if (det) {
+        if (kind < 8) {
+          status = fail(HBK_INTERNAL, "group_lookup_bwd: a deterministic column without row-sorted buckets");
+          break;
+        }
+        hipLaunchKernelGGL(kReduceDet[kind - 8][step], dim3((unsigned)n_slots), dim3(kBlock), 0, ls, args,
+                           desc_group, (int)slot_lo[kind], (int)slot_hi[kind], poison);
+        continue;
+      }
       hipLaunchKernelGGL(kReduce[kind][step], dim3((unsigned)grid),
                          dim3(kBlock), 0, ls, args, desc_group, (int)slot_lo[kind],
                          (int)slot_hi[kind], poison);

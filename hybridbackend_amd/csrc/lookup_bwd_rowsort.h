@@ -33,6 +33,7 @@ constexpr int kRsWPT = kRsWords / kBlock;        // bitmap words per thread in t
 constexpr int kRsBits = 13;                      // start / count fields of a row's counter word
 constexpr uint32_t kRsMask = (1u << kRsBits) - 1u;
 constexpr uint16_t kRsNoRow = 0xffff;
+constexpr int kRsDetRank = 16;                // deterministic jobs: runs up to this many pairs are ordered by counting
 static_assert(kRsCap % kBlock == 0 && kRsCap <= (1 << (kRsBits - 1)), "counter fields");
 static_assert(kRsWords % kBlock == 0, "whole bitmap words per thread");
 static_assert(kRsSpan <= 65536, "16-bit row offsets");
@@ -199,9 +200,67 @@ struct RsLds {
   float red[kBlock * 4];        // per lane group: what it holds of a run that began in an earlier group's share
   int32_t wave_tot[kWavesPerBlock];
   int32_t n_sorted, base_u;
+  int32_t det_end, det_tile, det_long;   // deterministic jobs: end of the chunk, its last tile + 1, "a long run"
 };
 
-template <typename V, int STEP>
+// Deterministic jobs (option bwd_deterministic): the output range of bucket b begins where the rows
+// of the buckets in front of it end -- buckets are row ranges in row order and a job's rows leave
+// sorted, so the column's rows leave ASCENDING and at the same positions on every run.  One pass,
+// a chained scan with look-back over the column's status words (pcount[]: cleared by the grouping
+// stage, not otherwise used without split buckets): a job publishes its row count as soon as it has
+// it (A + B, before anything waits), then adds up the counts in front of it, 64 buckets per step,
+// until it meets a bucket that has published its inclusive sum.  A job only ever waits for jobs
+// with SMALLER block indices -- the deterministic launch takes its job slots in block order, the
+// hardware starts blocks in that order, and the publishing half of a job waits for nothing -- so
+// every wait ends; the bound turns a broken assumption into a loud failure instead of a hang.
+// Called by the lanes of ONE wave; returns the rows in front of the bucket (wave-uniform).
+constexpr uint32_t kRsDetVal = (1u << 30) - 1u;                 // (a column has < 2^30 ids)
+constexpr unsigned long long kRsDetTicks = 400000000ull;        // 4 s of the 100 MHz clock
+__device__ inline int32_t det_claim(const GCol& c, int bucket, int32_t n_rows, int lane) {
+  int32_t* st = c.pcount;
+  if (lane == 0) {
+    __hip_atomic_store(st + bucket, (int32_t)((bucket == 0 ? 2u << 30 : 1u << 30) | (uint32_t)n_rows),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  int32_t before = 0;
+  if (bucket > 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int pos = bucket - 1;
+    for (;;) {
+      const int b = pos - lane;
+      uint32_t s = 2u << 30;   // in front of bucket 0: nothing
+      if (b >= 0) {
+        s = (uint32_t)__hip_atomic_load(st + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const unsigned long long incl = __ballot((s >> 30) == 2u);
+      const unsigned long long none = __ballot((s >> 30) == 0u);
+      const int first = incl != 0ull ? __builtin_ctzll(incl) : kWave - 1;
+      const unsigned long long need = first >= kWave - 1 ? ~0ull : (2ull << first) - 1ull;   // lanes 0 .. first
+      if ((none & need) != 0ull) {   // (uniform) a bucket in between has not published yet
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kRsDetTicks) __builtin_trap();
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      int32_t v = (need >> lane) & 1ull ? (int32_t)(s & kRsDetVal) : 0;
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+      before += v;
+      if (incl != 0ull) break;
+      pos -= kWave;
+    }
+    if (lane == 0) {
+      __hip_atomic_store(st + bucket, (int32_t)((2u << 30) | (uint32_t)(before + n_rows)),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // the column's row count: what the last bucket ends at (merge_done hands it to the caller)
+  if (lane == 0 && bucket == c.n_buckets - 1) {
+    __hip_atomic_store(c.counter, before + n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return before;
+}
+
+template <typename V, int STEP, bool DET = false>
 __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds& L, int bucket) {
   constexpr int VE = sizeof(V) / 4;
   constexpr int PT = kRsPT;
@@ -239,7 +298,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   const bool pairs_nt = c.splits != nullptr && (packed || pseg != nullptr);   // ragged column, not a merge job
   uint32_t off_[PT];   // row - base of my pairs of the chunk, ~0u: none
   int32_t seg_[PT];
-  auto load_pairs = [&](int32_t cb) {
+  auto load_pairs = [&](int32_t cb, int32_t ce) {   // the pairs [cb, ce) (<= kRsCap of them)
     // all loads first, in one straight line (indices behind the end are clamped and masked
     // afterwards): with the range check and the sign test inside the loop the compiler waited for
     // every pair before it requested the next -- 8 memory round trips, the job's first 8 us
@@ -252,13 +311,13 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
 #pragma unroll
       for (int k = 0; k < PT; ++k) {
         const int32_t e = cb + k * kBlock + tid;
-        r_[k] = __builtin_nontemporal_load(prow + (e < n_pairs ? e : n_pairs - 1));
+        r_[k] = __builtin_nontemporal_load(prow + (e < ce ? e : ce - 1));
       }
     } else {
 #pragma unroll
       for (int k = 0; k < PT; ++k) {
         const int32_t e = cb + k * kBlock + tid;
-        r_[k] = HBK_PAIR_LOAD(prow + (e < n_pairs ? e : n_pairs - 1));
+        r_[k] = HBK_PAIR_LOAD(prow + (e < ce ? e : ce - 1));
       }
     }
     if (packed) {
@@ -268,13 +327,13 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
 #pragma unroll
       for (int k = 0; k < PT; ++k) {
         const int32_t e = cb + k * kBlock + tid;
-        seg_[k] = __builtin_nontemporal_load(pseg + (e < n_pairs ? e : n_pairs - 1));
+        seg_[k] = __builtin_nontemporal_load(pseg + (e < ce ? e : ce - 1));
       }
     } else if (pseg != nullptr) {
 #pragma unroll
       for (int k = 0; k < PT; ++k) {
         const int32_t e = cb + k * kBlock + tid;
-        seg_[k] = HBK_PAIR_LOAD(pseg + (e < n_pairs ? e : n_pairs - 1));
+        seg_[k] = HBK_PAIR_LOAD(pseg + (e < ce ? e : ce - 1));
       }
     } else {
 #pragma unroll
@@ -284,9 +343,9 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
     for (int k = 0; k < PT; ++k) {
       const int32_t e = cb + k * kBlock + tid;
       if (packed) {
-        off_[k] = e < n_pairs ? (uint32_t)((uint64_t)r_[k] >> 32) - base : ~0u;
+        off_[k] = e < ce ? (uint32_t)((uint64_t)r_[k] >> 32) - base : ~0u;
       } else {
-        off_[k] = e < n_pairs && r_[k] >= 0 ? (uint32_t)r_[k] - base : ~0u;
+        off_[k] = e < ce && r_[k] >= 0 ? (uint32_t)r_[k] - base : ~0u;
       }
     }
   };
@@ -335,7 +394,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
     return (int32_t)total;
   };
 
-  load_pairs(0);       // they travel while the tables are cleared
+  load_pairs(0, n_pairs);       // they travel while the tables are cleared
   __syncthreads();     // a workgroup may run several jobs (merge): the previous one is done with L
   for (int w = tid; w < words; w += kBlock) {
     L.present[w] = 0u;
@@ -350,7 +409,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
     mark(L.present);
   } else {
     for (int32_t cb = 0; cb < n_pairs; cb += kRsCap) {
-      if (cb > 0) load_pairs(cb);
+      if (cb > 0) load_pairs(cb, n_pairs);
       mark(L.present);
     }
   }
@@ -364,7 +423,11 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   // One global atomic per job claims the output range; a returning device-scope atomic takes
   // microseconds under load: its round trip runs beside C-E.  Step only: just the count is wanted.
   int32_t claimed = 0;
-  if (tid == kBlock - 1) {
+  if (DET && c.no_emit == 0) {
+    // deterministic: the output ranges follow the buckets -- the column's rows leave ascending, at the
+    // same positions on every run -- instead of the order in which the jobs get here
+    if (wave == kWavesPerBlock - 1) claimed = det_claim(c, bucket, n_rows_job, lane);
+  } else if (tid == kBlock - 1) {
     if (!emit) {
       __hip_atomic_fetch_add(job.out_counter, n_rows_job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -374,13 +437,52 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   int32_t base_u = 0;
   HBK_STAMP(3);
 
-  for (int32_t cb = 0; cb < n_pairs; cb += kRsCap) {
+  // Deterministic jobs of several chunks: a chunk is a run of WHOLE tile shares of the bucket.  The
+  // grouping stage lays the tiles' shares of a bucket one behind the other in the pair arrays (tile
+  // order = id order; INSIDE a share the order comes from LDS tickets), so the gradient rows of such
+  // a chunk all lie behind every earlier chunk's: sorting a row's pairs inside each chunk and taking
+  // the chunks in turn visits the row's terms in id order.  hist[t][bucket] = where tile t's share
+  // begins (left by the scan over the tiles / by the one-launch grouping).  A share is <= kTile <=
+  // kRsCap pairs, so every chunk takes at least one.
+  static_assert(kTile <= kRsCap, "a tile's share of a bucket fits one chunk");
+  int det_tile = 0;   // the tile whose share begins the next chunk
+  auto det_chunk_end = [&](int32_t cb) -> int32_t {
+    const int P = c.n_buckets;
+    const int n_tiles = (int)((c.n_ids + kTile - 1) / kTile);
+    const int32_t* tp = c.hist + bucket;
+    int32_t end = cb;
+    for (;;) {
+      const int tt = det_tile + 1 + tid;   // the chunk may end where this tile's share begins
+      const int32_t v = tt < n_tiles ? tp[(int64_t)tt * P] : n_pairs;
+      const unsigned long long fits = __ballot(v - cb <= kRsCap);   // (monotone over the threads)
+      if (lane == 0) L.wave_tot[wave] = (int32_t)__builtin_popcountll(fits);
+      __syncthreads();
+      int n_fit = 0;
+#pragma unroll
+      for (int w = 0; w < kWavesPerBlock; ++w) n_fit += L.wave_tot[w];
+      if (tid == n_fit - 1) L.det_end = v;
+      __syncthreads();
+      if (n_fit > 0) end = L.det_end;
+      det_tile += n_fit;
+      if (end > cb || det_tile >= n_tiles || n_fit == 0) break;   // (shares without a pair of this bucket: on)
+    }
+    if (end <= cb) end = cb + kRsCap < n_pairs ? cb + kRsCap : n_pairs;   // (unreachable: keeps the loop finite)
+    return end;
+  };
+
+  int32_t ce = n_pairs;
+  for (int32_t cb = 0; cb < n_pairs; cb = ce) {
     const uint32_t* bm = L.present;
     const uint32_t* pr = L.pre;
     int32_t n_rows = n_rows_job;
     if (!one_chunk) {
+      if (DET) {
+        ce = det_chunk_end(cb);
+      } else {
+        ce = cb + kRsCap < n_pairs ? cb + kRsCap : n_pairs;
+      }
       __syncthreads();   // the chunk before is done with cnt / sseg / su / cmap (pre[] is visible)
-      load_pairs(cb);
+      load_pairs(cb, ce);
       for (int w = tid; w < words; w += kBlock) L.cmap[w] = 0u;
       if (cb > 0) {
         for (int i = tid; i < kRsCap; i += kBlock) L.cnt[i] = 0u;
@@ -488,9 +590,76 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
       }
     }
     if (cb == 0 && emit && tid == kBlock - 1) L.base_u = job.out_base + claimed;
+    if (DET && tid == 0) L.det_long = 0;
     __syncthreads();
     if (cb == 0 && emit) base_u = L.base_u;
     if (cb == 0) HBK_STAMP(5);
+
+    // E' (deterministic): the pairs of a row stand in ticket order -- put them in GRADIENT-ROW order,
+    // which is id order (a segment's number grows with the id's position; two pairs of one row with
+    // the same gradient row are the same term).  Short runs (nearly all): every pair counts the
+    // pairs of its run that go in front of it; a chunk with a longer run: one bitonic sort of the
+    // chunk's (row, gradient row) words.
+    if (DET) {
+      int32_t np_[PT];
+      bool long_run = false;
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        np_[k] = -1;
+        if (u_[k] != ~0u) {
+          const uint32_t cv = L.cnt[u_[k]];
+          const int start = (int)(cv & kRsMask), n = (int)((cv >> kRsBits) & kRsMask);
+          if (n > kRsDetRank) {
+            long_run = true;
+          } else if (n > 1) {
+            const int pos = start + tk_[k];
+            const int32_t mine = seg_[k];
+            int before = 0;
+            for (int q = start; q < start + n; ++q) {
+              const int32_t other = L.sseg[q];
+              before += ((uint32_t)other < (uint32_t)mine || (other == mine && q < pos)) ? 1 : 0;
+            }
+            np_[k] = start + before;
+          }
+        }
+      }
+      if (long_run) L.det_long = 1;   // (benign race: every writer stores 1)
+      __syncthreads();                 // every count is taken
+      if (L.det_long == 0) {           // uniform
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+          if (np_[k] >= 0) L.sseg[np_[k]] = seg_[k];
+        }
+      } else {
+        const int n_sorted = L.n_sorted;
+        for (int i = n_sorted + tid; i < kRsCap; i += kBlock) {   // behind the pairs: the largest word
+          L.su[i] = kRsNoRow;
+          L.sseg[i] = 0x7fffffff;
+        }
+        __syncthreads();
+        for (int len = 2; len <= kRsCap; len <<= 1) {
+          for (int j = len >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int e = 0; e < kRsCap / 2 / kBlock; ++e) {
+              const int t = e * kBlock + tid;              // compare-exchange number t of this step
+              const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+              const int x = i | j;
+              const uint64_t a = ((uint64_t)L.su[i] << 32) | (uint32_t)L.sseg[i];
+              const uint64_t b = ((uint64_t)L.su[x] << 32) | (uint32_t)L.sseg[x];
+              const bool up = (i & len) == 0;
+              if ((a > b) == up) {
+                L.su[i] = (uint16_t)(b >> 32);
+                L.sseg[i] = (int32_t)(uint32_t)b;
+                L.su[x] = (uint16_t)(a >> 32);
+                L.sseg[x] = (int32_t)(uint32_t)a;
+              }
+            }
+            __syncthreads();
+          }
+        }
+      }
+      __syncthreads();
+    }
 
     // a finished row leaves: (one chunk) straight to its output row, with the optimizer step;
     // (several chunks) into its output row, which an earlier chunk may have started
@@ -513,11 +682,52 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
     // in LDS for the group where the run began); runs that begin in my share are mine: the ones
     // that end there leave at once, the last one -- if it goes on -- waits in `acc` for the heads
     // of the groups it goes on in (G).
-    {
+    if (DET && !one_chunk) {
+      // Deterministic, several chunks: every run of the chunk front to back by ONE lane group, on top
+      // of what the earlier chunks left in the row's output (the chunks visit a row's terms in id
+      // order, see det_chunk_end): acc = ((earlier + t1) + t2) + ...  -- the sequential sum.  Jobs like
+      // this are the hot buckets of skewed ids; the walk is short on loads in flight, not on exactness.
+      constexpr int WD = 4;
+      for (int u = my_group; u < n_rows; u += groups) {
+        const uint32_t cv = L.cnt[u];
+        const int start = (int)(cv & kRsMask), n = (int)((cv >> kRsBits) & kRsMask);
+        const int32_t oi = out_index((uint32_t)u);
+        V* o = reinterpret_cast<V*>(job.out_vals + (int64_t)oi * c.dim + (int64_t)sub * VE);
+        V acc = zero_v<V>();
+        if (live && !is_first((uint32_t)u)) acc = __builtin_nontemporal_load(o);
+        for (int p = start; p < start + n; p += WD) {
+          V g[WD];
+#pragma unroll
+          for (int w = 0; w < WD; ++w) {
+            const int q = p + w < start + n ? p + w : start + n - 1;
+            g[w] = rs_load_grad<V>(job, L.sseg[q], sub, live);
+          }
+#pragma unroll
+          for (int w = 0; w < WD; ++w) {
+            if (p + w < start + n) acc = acc + g[w];
+          }
+        }
+        if (live) *o = acc;
+      }
+    } else {
       const int n_sorted = L.n_sorted;
       const int per = (n_sorted + groups - 1) / groups;
-      const int lo = my_group * per < n_sorted ? my_group * per : n_sorted;
-      const int hi = lo + per < n_sorted ? lo + per : n_sorted;
+      int lo = my_group * per < n_sorted ? my_group * per : n_sorted;
+      int hi = lo + per < n_sorted ? lo + per : n_sorted;
+      if (DET && lo < hi) {
+        // Deterministic: a run is walked by ONE lane group, front to back -- the group in whose share
+        // it begins takes all of it, the groups it runs through begin behind it.  (Shares are then
+        // as unequal as the ids are skewed; no heads, no tails: in_head and tail below stay false.)
+        if (lo > 0 && L.su[lo - 1] == L.su[lo]) {
+          const uint32_t cv = L.cnt[L.su[lo]];
+          lo = (int)(cv & kRsMask) + (int)((cv >> kRsBits) & kRsMask);
+        }
+        if (hi < n_sorted && L.su[hi - 1] == L.su[hi]) {
+          const uint32_t cv = L.cnt[L.su[hi]];
+          hi = (int)(cv & kRsMask) + (int)((cv >> kRsBits) & kRsMask);
+        }
+        if (lo > hi) lo = hi;
+      }
       bool in_head = lo < hi && lo > 0 && L.su[lo - 1] == L.su[lo];
       V acc = zero_v<V>();
       for (int p = lo; p < hi; p += W) {
@@ -737,4 +947,32 @@ __global__ __launch_bounds__(kBlock, STEP == 2 ? HBK_RS_LB2 : 4) void bwd_rowsor
   HBK_STAMP(1);
   rowsort_reduce<V, STEP>(a.col[ci], job, lds, d.z);
   HBK_STAMP(7);
+}
+
+// The deterministic launch (option bwd_deterministic): job slots in BLOCK order (det_claim), no XCD
+// dealing; an empty bucket still takes its (empty) place in the column's output order.
+template <typename V, int STEP>
+__global__ __launch_bounds__(kBlock, STEP == 2 ? HBK_RS_LB2 : 4) void bwd_rowsort_det_kernel(const GArgs a, const int4* desc,
+                                                                                     int slot0, int total,
+                                                                                     const int32_t* poison) {
+  __shared__ RsLds lds;
+  if (poisoned(poison)) return;   // the grouping launch gave up: no descriptors, no pairs
+  const int lane = (int)threadIdx.x & (kWave - 1);
+  const int vb = slot0 + (int)blockIdx.x;
+  if (vb >= total) return;
+  const int4 d = desc[vb];
+  const int my_b0 = lane < a.n_cols ? a.bucket0[lane] : 0x7fffffff;
+  if (d.z >= 0 && d.y <= 0) {   // (uniform) a bucket without pairs
+    int ci = (int)__builtin_popcountll(__ballot(my_b0 <= vb)) - 1;
+    ci = __builtin_amdgcn_readfirstlane(ci);
+    const GCol& c = a.col[ci];
+    if (c.rowsort != 0 && (c.vec4 != 0) == (sizeof(V) == 16) && c.no_emit == 0 && threadIdx.x < kWave) {
+      (void)det_claim(c, d.z, 0, lane);
+    }
+    return;
+  }
+  ReduceJob job;
+  int ci;
+  if (!decode_job<V, 2>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
+  rowsort_reduce<V, STEP, true>(a.col[ci], job, lds, d.z);
 }

@@ -83,9 +83,11 @@ int hbk_tables_free(void* slab);
  * HBK_PART_ONEPASS, HBK_SHARDED_GROUPS, HBK_SHARDED_ID64, HBK_SHARDED_COPY_SELF,
  * HBK_SHARDED_TRACE); no entry point reads the environment per call.
  * Names: bwd_buckets_log2, bwd_bucket_pairs, bwd_split_pairs, bwd_onepass, bwd_group_cols, bwd_dense, bwd_wide, bwd_xcd, fwd_xcd, fwd_interleave, fwd_hot_rows,
- * bwd_deterministic (1: the duplicate-row reduction sums every row's terms in ID ORDER by one lane group -- a stable sort of the
- * batch's (row, gradient row) pairs and a sequential walk -- so IndexedSlices and stepped tables are bit-identical from run to run and
- * equal to the sequential fp32 sum (TF's CPU UnsortedSegmentSum); rows leave sorted; a reproducibility mode, slower than the default),
+ * bwd_deterministic (1 or 2: the duplicate-row reduction sums every row's terms in ID ORDER by one lane group, so IndexedSlices and stepped
+ * tables are bit-identical from run to run and equal to the sequential fp32 sum (TF's CPU UnsortedSegmentSum), and rows leave ascending;
+ * 1: columns whose row range fits the row-sorted jobs take those jobs' in-order form -- a row's pairs ordered by gradient row inside the
+ * job, output ranges in bucket order, no bucket split over workgroups -- and the other columns the sort of 2; 2: a stable sort of the
+ * batch's (row, gradient row) pairs and a sequential walk for every column; the reproducibility mode, TF_DETERMINISTIC_OPS' analogue),
  * bwd_pairs_packed, bwd_seg_inline, bwd_scale_fused, bwd_scatter_staged, bwd_rowsort_pos, bwd_rowsort_ratio (round 5: x 4 for dim <= 32),
  * bwd_streams (launch groups of > 64 columns rotate over this many library streams; 0: the caller's), bwd_large_first,
  * bwd_trace (the launch groups of every backward call on stderr), bwd_lds_pad (a probe), sharded_p2p,

@@ -135,7 +135,11 @@ def test_group_lookup_deterministic_random(cols, seed):
     grads.append(rng.randn(c['n_seg'], c['dim']).astype(np.float32))
   opt = 'adagrad' if seed % 2 else 'sgd'
   interleaved = seed % 3 == 0
-  old = _lib.set_option('bwd_deterministic', 1)
+  # (mostly the row-sorted jobs' in-order form, with the grouping form and the bucket count drawn too --
+  # one bucket per column makes jobs of many chunks; every fifth draw the sort for every column)
+  opts = {'bwd_deterministic': 2 if seed % 5 == 4 else 1, 'bwd_onepass': (seed // 5) % 2,
+          'bwd_buckets_log2': (-1, -1, 0, 3)[(seed // 10) % 4]}
+  old = {k: _lib.set_option(k, v) for k, v in opts.items()}
   try:
     t_dev = [dev(t.copy()) for t in tables]
     a_dev = [torch.full_like(t, 0.1) for t in t_dev]
@@ -168,7 +172,8 @@ def test_group_lookup_deterministic_random(cols, seed):
       np.testing.assert_equal(got_t, want_t)
       np.testing.assert_equal(got_a, want_a)
   finally:
-    _lib.set_option('bwd_deterministic', old)
+    for k, v in old.items():
+      _lib.set_option(k, v)
 
 
 def _check_group_lookup(cols, seed):

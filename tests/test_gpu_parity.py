@@ -1009,16 +1009,20 @@ def _in_order_slices(rows, grads, splits, combiner, n_rows):
   return uniq, oracle.unsorted_segment_sum(g_id, inv, uniq.size)
 
 
+@pytest.mark.parametrize('det', [1, 2])
 @pytest.mark.parametrize('mode', ['emit', 'sgd', 'adagrad', 'step_only'])
-def test_group_lookup_backward_deterministic_is_the_in_order_sum(hbk_option, mode):
-  """Option bwd_deterministic (round 6): a stable sort of the batch's (row,
-  gradient row) pairs and one lane group walking every row's run front to back.  The emitted sums
+def test_group_lookup_backward_deterministic_is_the_in_order_sum(hbk_option, mode, det):
+  """Option bwd_deterministic (round 6).  1: the row-sorted jobs in their in-order
+  form (a row's pairs ordered by gradient row inside the job, one lane group per run, output ranges
+  in bucket order) for every column whose row range fits them, the sort for the others; 2: a stable
+  sort of the batch's (row, gradient row) pairs and one lane group walking every row's run front to
+  back, for every column.  The emitted sums
   are BIT-EQUAL to the sequential fp32 sum in id order -- not "within 1e-5" -- the rows leave sorted,
   the fused SGD / Adagrad steps are bit-equal to the oracle's apply on those slices, and two calls
   give the same bits.  Shapes: scalar and ragged columns with every combiner, a Zipf head, one row
   that owns a whole column, ids outside the table, odd dims, `// W` row numbers, int32 ids, an
   empty column, more columns than one launch group."""
-  hbk_option('bwd_deterministic', 1)
+  hbk_option('bwd_deterministic', det)
   rng = np.random.RandomState(606)
   #        dim  rows    n_seg  mean-len combiner ids
   cases = [(16, 50000, 30000, 8, 'mean', 'uniform'),
@@ -1086,6 +1090,66 @@ def test_group_lookup_backward_deterministic_is_the_in_order_sum(hbk_option, mod
           np.testing.assert_equal(x[k], y[k])
         else:
           assert x[k] == y[k]
+
+
+@pytest.mark.parametrize('onepass', [1, 0])
+@pytest.mark.parametrize('log2p', [None, 0, 2])
+def test_group_lookup_backward_deterministic_rowsorted_jobs_of_several_chunks(hbk_option, log2p, onepass):
+  """The in-order form of the row-sorted jobs (bwd_deterministic = 1) where it has to work for it:
+  buckets of many chunks (chunks are whole tile shares of the bucket, a row's sum carries over from
+  chunk to chunk), runs longer than the counting order takes (the bitonic sort of a chunk), one row
+  that owns a column, a Zipf head, a bucket whose pairs begin behind > 256 tiles without any, both
+  grouping forms.  Bit-equal to the sequential fp32 sum in id order, rows ascending, the Adagrad
+  step bit-equal to the oracle's apply, and twice the same bits."""
+  hbk_option('bwd_deterministic', 1)
+  hbk_option('bwd_onepass', onepass)
+  if log2p is not None:
+    hbk_option('bwd_buckets_log2', log2p)
+  rng = np.random.RandomState(611 + (log2p or 7))
+  #        dim  rows   n_seg   mean-len combiner ids
+  cases = [(16, 300, 30000, 0, 'sum', 'uniform'),
+           (128, 1000, 40000, 0, 'sum', 'hot'),
+           (16, 300, 30000, 0, 'sum', 'mixed'),
+           (16, 5000, 40000, 8, 'mean', 'zipf'),
+           (8, 16000, 600000, 0, 'sum', 'ascending'),
+           (6, 50, 9000, 2, 'sqrtn', 'uniform'),
+           (64, 2000, 20000, 0, 'sum', 'zipf')]
+  for d, rows, n_seg, mean_len, comb, kind in cases:
+    sp = _ragged(rng, n_seg, mean_len, 32) if mean_len else None
+    n = n_seg if sp is None else int(sp[-1])
+    if kind == 'hot':
+      ids = np.full(n, 7, np.int64)
+    elif kind == 'mixed':
+      ids = np.where(rng.rand(n) < 0.6, 3, rng.randint(0, rows, size=n)).astype(np.int64)
+    elif kind == 'zipf':
+      ids = (rng.zipf(1.2, size=n) % rows).astype(np.int64)
+    elif kind == 'ascending':   # the last buckets' pairs come from the last tiles only
+      ids = np.sort(rng.randint(0, rows, size=n)).astype(np.int64)
+    else:
+      ids = rng.randint(0, rows, size=n).astype(np.int64)
+    table = rng.uniform(-1, 1, size=(rows, d)).astype(np.float32)
+    accum = np.full((rows, d), 0.1, np.float32)
+    grads = rng.randn(n_seg, d).astype(np.float32)
+    want_rows, want_sums = _in_order_slices(ids, grads, sp, comb, rows)
+    seen = []
+    for rep in range(2):
+      t_dev, a_dev = dev(table.copy()), dev(accum.copy())
+      lookup = hb.embedding.GroupLookup([t_dev], None, comb)
+      grad = hb.embedding.GroupLookupGrad(lookup, accums=[a_dev])
+      urows, grows, nu = grad([dev(ids)], [dev(grads)], [None if sp is None else dev(sp)],
+                              apply_lr=0.05, optimizer='adagrad')[0]
+      k = int(nu.item())
+      seen.append((k, host(urows)[:k].copy(), host(grows)[:k].copy(), host(t_dev), host(a_dev)))
+    k, urows, grows, t_end, a_end = seen[0]
+    assert k == want_rows.size, (kind, d, k, want_rows.size)
+    np.testing.assert_equal(urows, want_rows, err_msg=f'{kind} dim {d}: rows (sorted)')
+    np.testing.assert_equal(grows, want_sums, err_msg=f'{kind} dim {d}: in-order fp32 sums')
+    ref_t, ref_a = table.copy(), accum.copy()
+    oracle.sparse_adagrad_apply(ref_t, ref_a, want_rows, want_sums, 0.05)
+    np.testing.assert_equal(t_end, ref_t, err_msg=f'{kind} dim {d}: table')
+    np.testing.assert_equal(a_end, ref_a, err_msg=f'{kind} dim {d}: accumulator')
+    for x, y in zip(seen[0], seen[1]):
+      np.testing.assert_equal(x, y)
 
 
 def test_group_lookup_backward_deterministic_segmented_inputs_and_divisor(hbk_option):

@@ -70,8 +70,8 @@ PY
     benchsh)    # the sharded step at one rank through RCCL: forms, p2p, three plans pipelined, references
       timeout 900 python bench.py --sharded --steps 50 --warmup 10 --cpu-seconds 0 > $O/bench_sh.log 2>&1; echo "rc=$?" >> $O/bench_sh.log; tail -2 $O/bench_sh.log | cut -c1-3000;;
     det)        # the deterministic backward: parity, then its cost next to the default on the same box
-      timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sharded.py -x -q -m gpu -k "deterministic or launch_repeats" --durations=5 > $O/det_test.log 2>&1; echo "pytest rc=$?" >> $O/det_test.log; tail -12 $O/det_test.log
-      (for w in b s R; do for det in 0 1; do HBK_BWD_DETERMINISTIC=$det timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/deterministic=$det  /"; done; done) > $O/det_cost.txt 2>&1; cut -c1-200 $O/det_cost.txt;;
+      timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sharded.py tests/test_gpu_fuzz.py -x -q -m gpu -k "deterministic or launch_repeats or interleaved" --durations=5 > $O/det_test.log 2>&1; echo "pytest rc=$?" >> $O/det_test.log; tail -12 $O/det_test.log
+      (for w in b s R Q d w; do for det in 0 1 2; do HBK_BWD_DETERMINISTIC=$det timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/deterministic=$det  /"; done; done) > $O/det_cost.txt 2>&1; cut -c1-200 $O/det_cost.txt;;
     detprof)    # kernel times of the deterministic backward (config 2 emit, ragged)
       export HBK_BENCH_ITERS=4
       HBK_BWD_DETERMINISTIC=1 prof prof_det_b "" -- $R/tools/bin/bench_ops b

@@ -2897,6 +2897,16 @@ constexpr int kMergeBlocks = 8;
 // returned before the block counts itself done, so the last one reads the final count.
 __device__ inline void merge_done(const GCol& c, int blocks) {
   __syncthreads();
+  if (c.det) {   // (uniform) deterministic: the sum of the buckets' row counts (bwd_rowsort_count_kernel); one merge block
+    if (threadIdx.x < kWave) {
+      int32_t n = 0;
+      for (int p = (int)threadIdx.x; p < c.n_buckets; p += kWave) n += c.pcount[p];
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) n += __shfl_xor(n, o, kWave);
+      if (threadIdx.x == 0) *c.n_unique = n;
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
     const int32_t done = __hip_atomic_fetch_add(c.counter + 1, 1, __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);
@@ -3896,7 +3906,7 @@ static int bwd_planned(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int
     // above the mean.  Option bwd_xcd: 0 never, 1 this rule, 2 always.
     args.xcd = 0;
     for (int kind = 0; kind < kKinds; ++kind) {
-      if (!have_kind[kind] || options().bwd_xcd == 0 || det) continue;   // (deterministic: job slots in block order)
+      if (!have_kind[kind] || options().bwd_xcd == 0) continue;
       bool even = options().bwd_xcd == 2;
       if (!even) {
         const int64_t per = kind >= 4 && kind < 8 ? kTeams : 1;
@@ -3937,7 +3947,7 @@ static int bwd_planned(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int
     args.xcd_w = 0;
     args.stage_p = 0;
     int64_t xcd_grid[kKinds] = {0};
-    if ((options().bwd_xcd == 4 || options().bwd_xcd == 1 || options().bwd_xcd == 3) && kTeams == 1 && !det) {
+    if ((options().bwd_xcd == 4 || options().bwd_xcd == 1 || options().bwd_xcd == 3) && kTeams == 1) {
       for (int kind = 0; kind < kKinds; ++kind) {
         if (!have_kind[kind]) continue;
         if (options().bwd_xcd != 4 && !((args.xcd >> kind) & 1)) continue;
@@ -4060,8 +4070,12 @@ static int bwd_planned(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int
         {&bwd_rowsort_merge_kernel<float, 0>, &bwd_rowsort_merge_kernel<float, 1>,
          &bwd_rowsort_merge_kernel<float, 2>}};
     static const reduce_fn kReduceDet[2][3] = {
-        {&bwd_rowsort_det_kernel<f32x4, 0>, &bwd_rowsort_det_kernel<f32x4, 1>, &bwd_rowsort_det_kernel<f32x4, 2>},
-        {&bwd_rowsort_det_kernel<float, 0>, &bwd_rowsort_det_kernel<float, 1>, &bwd_rowsort_det_kernel<float, 2>}};
+        {&bwd_rowsort_kernel<f32x4, 0, true>, &bwd_rowsort_kernel<f32x4, 1, true>, &bwd_rowsort_kernel<f32x4, 2, true>},
+        {&bwd_rowsort_kernel<float, 0, true>, &bwd_rowsort_kernel<float, 1, true>, &bwd_rowsort_kernel<float, 2, true>}};
+    if (det) {   // where every bucket's rows begin in its column's output (lookup_bwd_rowsort.h)
+      hipLaunchKernelGGL(bwd_rowsort_count_kernel, dim3((unsigned)buckets), dim3(kBlock), 0, ls, args, desc_group,
+                         (int)buckets, poison);
+    }
     for (int kind = 0; kind < kKinds; ++kind) {
       if (!have_kind[kind]) continue;
       const int64_t n_slots = slot_hi[kind] - slot_lo[kind];
@@ -4072,7 +4086,7 @@ static int bwd_planned(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int
           status = fail(HBK_INTERNAL, "group_lookup_bwd: a deterministic column without row-sorted buckets");
           break;
         }
-        hipLaunchKernelGGL(kReduceDet[kind - 8][step], dim3((unsigned)n_slots), dim3(kBlock), 0, ls, args,
+        hipLaunchKernelGGL(kReduceDet[kind - 8][step], dim3((unsigned)grid), dim3(kBlock), 0, ls, args,
                            desc_group, (int)slot_lo[kind], (int)slot_hi[kind], poison);
         continue;
       }

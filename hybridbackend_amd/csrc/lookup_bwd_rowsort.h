@@ -203,63 +203,6 @@ struct RsLds {
   int32_t det_end, det_tile, det_long;   // deterministic jobs: end of the chunk, its last tile + 1, "a long run"
 };
 
-// Deterministic jobs (option bwd_deterministic): the output range of bucket b begins where the rows
-// of the buckets in front of it end -- buckets are row ranges in row order and a job's rows leave
-// sorted, so the column's rows leave ASCENDING and at the same positions on every run.  One pass,
-// a chained scan with look-back over the column's status words (pcount[]: cleared by the grouping
-// stage, not otherwise used without split buckets): a job publishes its row count as soon as it has
-// it (A + B, before anything waits), then adds up the counts in front of it, 64 buckets per step,
-// until it meets a bucket that has published its inclusive sum.  A job only ever waits for jobs
-// with SMALLER block indices -- the deterministic launch takes its job slots in block order, the
-// hardware starts blocks in that order, and the publishing half of a job waits for nothing -- so
-// every wait ends; the bound turns a broken assumption into a loud failure instead of a hang.
-// Called by the lanes of ONE wave; returns the rows in front of the bucket (wave-uniform).
-constexpr uint32_t kRsDetVal = (1u << 30) - 1u;                 // (a column has < 2^30 ids)
-constexpr unsigned long long kRsDetTicks = 400000000ull;        // 4 s of the 100 MHz clock
-__device__ inline int32_t det_claim(const GCol& c, int bucket, int32_t n_rows, int lane) {
-  int32_t* st = c.pcount;
-  if (lane == 0) {
-    __hip_atomic_store(st + bucket, (int32_t)((bucket == 0 ? 2u << 30 : 1u << 30) | (uint32_t)n_rows),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  int32_t before = 0;
-  if (bucket > 0) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    int pos = bucket - 1;
-    for (;;) {
-      const int b = pos - lane;
-      uint32_t s = 2u << 30;   // in front of bucket 0: nothing
-      if (b >= 0) {
-        s = (uint32_t)__hip_atomic_load(st + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      const unsigned long long incl = __ballot((s >> 30) == 2u);
-      const unsigned long long none = __ballot((s >> 30) == 0u);
-      const int first = incl != 0ull ? __builtin_ctzll(incl) : kWave - 1;
-      const unsigned long long need = first >= kWave - 1 ? ~0ull : (2ull << first) - 1ull;   // lanes 0 .. first
-      if ((none & need) != 0ull) {   // (uniform) a bucket in between has not published yet
-        if (__builtin_amdgcn_s_memrealtime() - t0 > kRsDetTicks) __builtin_trap();
-        __builtin_amdgcn_s_sleep(2);
-        continue;
-      }
-      int32_t v = (need >> lane) & 1ull ? (int32_t)(s & kRsDetVal) : 0;
-#pragma unroll
-      for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-      before += v;
-      if (incl != 0ull) break;
-      pos -= kWave;
-    }
-    if (lane == 0) {
-      __hip_atomic_store(st + bucket, (int32_t)((2u << 30) | (uint32_t)(before + n_rows)),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  // the column's row count: what the last bucket ends at (merge_done hands it to the caller)
-  if (lane == 0 && bucket == c.n_buckets - 1) {
-    __hip_atomic_store(c.counter, before + n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  return before;
-}
-
 template <typename V, int STEP, bool DET = false>
 __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds& L, int bucket) {
   constexpr int VE = sizeof(V) / 4;
@@ -423,10 +366,19 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   // One global atomic per job claims the output range; a returning device-scope atomic takes
   // microseconds under load: its round trip runs beside C-E.  Step only: just the count is wanted.
   int32_t claimed = 0;
-  if (DET && c.no_emit == 0) {
-    // deterministic: the output ranges follow the buckets -- the column's rows leave ascending, at the
-    // same positions on every run -- instead of the order in which the jobs get here
-    if (wave == kWavesPerBlock - 1) claimed = det_claim(c, bucket, n_rows_job, lane);
+  if (DET) {
+    // deterministic: the output ranges follow the buckets -- buckets are row ranges in row order and a
+    // job's rows leave sorted, so the column's rows leave ASCENDING, at the same positions on every
+    // run.  bwd_rowsort_count_kernel (below) has left every bucket's row count in pcount[]: the rows
+    // in front of this bucket are the sum of the counts in front of it (the last wave adds them up
+    // beside C; no atomic, nobody waits for another job).
+    if (wave == kWavesPerBlock - 1) {
+      int32_t before = 0;
+      for (int p = lane; p < bucket; p += kWave) before += c.pcount[p];
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) before += __shfl_xor(before, o, kWave);
+      claimed = before;
+    }
   } else if (tid == kBlock - 1) {
     if (!emit) {
       __hip_atomic_fetch_add(job.out_counter, n_rows_job, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -920,7 +872,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
 #ifndef HBK_RS_LB2
 #define HBK_RS_LB2 4   // workgroups per CU the Adagrad instantiation is compiled for
 #endif
-template <typename V, int STEP>
+template <typename V, int STEP, bool DET = false>
 __global__ __launch_bounds__(kBlock, STEP == 2 ? HBK_RS_LB2 : 4) void bwd_rowsort_kernel(const GArgs a, const int4* desc,
                                                                int slot0, int total,
                                                                const int32_t* poison) {
@@ -945,34 +897,78 @@ __global__ __launch_bounds__(kBlock, STEP == 2 ? HBK_RS_LB2 : 4) void bwd_rowsor
   int ci;
   if (!decode_job<V, 2>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
   HBK_STAMP(1);
-  rowsort_reduce<V, STEP>(a.col[ci], job, lds, d.z);
+  rowsort_reduce<V, STEP, DET>(a.col[ci], job, lds, d.z);
   HBK_STAMP(7);
 }
 
-// The deterministic launch (option bwd_deterministic): job slots in BLOCK order (det_claim), no XCD
-// dealing; an empty bucket still takes its (empty) place in the column's output order.
-template <typename V, int STEP>
-__global__ __launch_bounds__(kBlock, STEP == 2 ? HBK_RS_LB2 : 4) void bwd_rowsort_det_kernel(const GArgs a, const int4* desc,
-                                                                                     int slot0, int total,
-                                                                                     const int32_t* poison) {
-  __shared__ RsLds lds;
-  if (poisoned(poison)) return;   // the grouping launch gave up: no descriptors, no pairs
-  const int lane = (int)threadIdx.x & (kWave - 1);
-  const int vb = slot0 + (int)blockIdx.x;
+// Deterministic mode (option bwd_deterministic = 1), in front of the reduce launch: the DISTINCT ROWS
+// of every bucket -- one workgroup per bucket marks its pairs' rows in an LDS bitmap and counts the
+// bits.  The reduce jobs then take their output ranges from the counts in front of them, without an
+// atomic and without waiting for each other, and the merge launch adds up the column's row count.
+// (Tried first: a chained scan with look-back inside the reduce launch -- the jobs' polling of each
+// other's status words cost the ragged case 85 us and forbade dealing the jobs to the XCDs, another
+// 50 us; then this kernel with the prefix taken by the column's last workgroup behind an acq_rel
+// atomic at agent scope -- every workgroup's release wrote the L2 back: 41 / 249 us for config 2 / the
+// ragged case instead of the few microseconds the counting takes.)
+__global__ __launch_bounds__(kBlock) void bwd_rowsort_count_kernel(const GArgs a, const int4* desc, int total,
+                                                                   const int32_t* poison) {
+  __shared__ uint32_t bm[kRsWords];
+  __shared__ int32_t wave_tot[kWavesPerBlock];
+  if (poisoned(poison)) return;
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int vb = (int)blockIdx.x;
   if (vb >= total) return;
   const int4 d = desc[vb];
+  if (d.z < 0) return;   // (uniform) a spare slot
   const int my_b0 = lane < a.n_cols ? a.bucket0[lane] : 0x7fffffff;
-  if (d.z >= 0 && d.y <= 0) {   // (uniform) a bucket without pairs
-    int ci = (int)__builtin_popcountll(__ballot(my_b0 <= vb)) - 1;
-    ci = __builtin_amdgcn_readfirstlane(ci);
-    const GCol& c = a.col[ci];
-    if (c.rowsort != 0 && (c.vec4 != 0) == (sizeof(V) == 16) && c.no_emit == 0 && threadIdx.x < kWave) {
-      (void)det_claim(c, d.z, 0, lane);
+  int ci = (int)__builtin_popcountll(__ballot(my_b0 <= vb)) - 1;
+  ci = __builtin_amdgcn_readfirstlane(ci);
+  const GCol& c = a.col[ci];
+  const int bucket = d.z;
+  const int32_t n_pairs = d.y;
+  const int64_t* prow = c.pair_row[0] + d.x;
+  const bool packed = c.packed != 0;
+  const uint32_t M = c.dense_mul;
+  const uint32_t base = (uint32_t)dense_first_row(M, bucket);
+  uint64_t lim = dense_first_row(M, bucket + 1);
+  if (lim > c.map.rows) lim = c.map.rows;
+  const int words = (int)((lim - base + 31) >> 5);
+  for (int w = tid; w < words; w += kBlock) bm[w] = 0u;
+  __syncthreads();
+  constexpr int kIn = 8;   // pairs in flight per thread
+  for (int32_t e0 = 0; e0 < n_pairs; e0 += kIn * kBlock) {
+    int64_t r_[kIn];
+#pragma unroll
+    for (int k = 0; k < kIn; ++k) {
+      const int32_t e = e0 + k * kBlock + tid;
+      r_[k] = __builtin_nontemporal_load(prow + (e < n_pairs ? e : n_pairs - 1));
     }
-    return;
+#pragma unroll
+    for (int k = 0; k < kIn; ++k) {
+      const int32_t e = e0 + k * kBlock + tid;
+      uint32_t off = ~0u;
+      if (packed) {
+        if (e < n_pairs) off = (uint32_t)((uint64_t)r_[k] >> 32) - base;
+      } else if (e < n_pairs && r_[k] >= 0) {
+        off = (uint32_t)r_[k] - base;
+      }
+      if (off != ~0u) {
+        const uint32_t bit = 1u << (off & 31u);
+        if ((bm[off >> 5] & bit) == 0u) atomicOr(&bm[off >> 5], bit);
+      }
+    }
   }
-  ReduceJob job;
-  int ci;
-  if (!decode_job<V, 2>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
-  rowsort_reduce<V, STEP, true>(a.col[ci], job, lds, d.z);
+  __syncthreads();
+  int32_t n = 0;
+  for (int w = tid; w < words; w += kBlock) n += __builtin_popcount(bm[w]);
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) n += __shfl_xor(n, o, kWave);
+  if (lane == 0) wave_tot[wave] = n;
+  __syncthreads();
+  if (tid == 0) {
+    int32_t rows = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) rows += wave_tot[w];
+    c.pcount[bucket] = rows;
+  }
 }

@@ -72,12 +72,24 @@ PY
     det)        # the deterministic backward: parity, then its cost next to the default on the same box
       timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sharded.py tests/test_gpu_fuzz.py -x -q -m gpu -k "deterministic or launch_repeats or interleaved" --durations=5 > $O/det_test.log 2>&1; echo "pytest rc=$?" >> $O/det_test.log; tail -12 $O/det_test.log
       (for w in b s R Q d w; do for det in 0 1 2; do HBK_BWD_DETERMINISTIC=$det timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/deterministic=$det  /"; done; done) > $O/det_cost.txt 2>&1; cut -c1-200 $O/det_cost.txt;;
+    detab)      # what the pieces of the deterministic row-sorted jobs cost (probe builds: tools/bin/variants/<name>/)
+      (for rep in 1 2; do
+         for w in ${WORK:-b R}; do
+           HBK_BWD_DETERMINISTIC=0 timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/default   /"
+           HBK_BWD_DETERMINISTIC=1 timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/det       /"
+           for v in ${VARIANTS:-nosort atomic atomxcd all}; do
+             HBK_BWD_DETERMINISTIC=1 LD_LIBRARY_PATH=$R/tools/bin/variants/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/$(printf %-10s $v)/"
+           done
+         done
+       done) > $O/detab.txt 2>&1; cut -c1-150 $O/detab.txt;;
     detprof)    # kernel times of the deterministic backward (config 2 emit, ragged)
       export HBK_BENCH_ITERS=4
-      HBK_BWD_DETERMINISTIC=1 prof prof_det_b "" -- $R/tools/bin/bench_ops b
-      HBK_BWD_DETERMINISTIC=1 prof prof_det_R "" -- $R/tools/bin/bench_ops R
-      unset HBK_BENCH_ITERS
-      head -14 $O/prof_det_b.txt | cut -c1-160; head -14 $O/prof_det_R.txt | cut -c1-160; trim prof_det_b; trim prof_det_R;;
+      for det in ${DETS:-0 1}; do
+        HBK_BWD_DETERMINISTIC=$det prof prof_det${det}_b "" -- $R/tools/bin/bench_ops b
+        HBK_BWD_DETERMINISTIC=$det prof prof_det${det}_R "" -- $R/tools/bin/bench_ops R
+        echo "== deterministic=$det"; head -12 $O/prof_det${det}_b.txt | cut -c1-160; head -14 $O/prof_det${det}_R.txt | cut -c1-160; trim prof_det${det}_b; trim prof_det${det}_R
+      done
+      unset HBK_BENCH_ITERS;;
     p2pprof)    # kernel times of the sharded step at one rank in the p2p form
       prof prof_p2p_on "" -- python $R/bench.py --sharded --steps 30 --warmup 5 --cpu-seconds 0 --no-secondary --tune-steps 4 --p2p on
       grep -E "hbk|kernel  " $O/prof_p2p_on.txt | cut -c1-150 | head -24; trim prof_p2p_on;;

@@ -33,7 +33,10 @@ constexpr int kRsWPT = kRsWords / kBlock;        // bitmap words per thread in t
 constexpr int kRsBits = 13;                      // start / count fields of a row's counter word
 constexpr uint32_t kRsMask = (1u << kRsBits) - 1u;
 constexpr uint16_t kRsNoRow = 0xffff;
-constexpr int kRsDetRank = 16;                // deterministic jobs: runs up to this many pairs are ordered by counting
+constexpr int kRsDetRank = 16;                // deterministic jobs: runs up to this many pairs are ordered by counting (48: the same times)
+constexpr int kRsDetLong = 256;               // deterministic jobs: runs from this many pairs on are summed by the whole workgroup
+constexpr uint16_t kRsLongBit = 0x8000;       //   (their positions carry this bit in su[]: the lane groups' walk steps over them)
+static_assert(kRsCap < kRsLongBit, "row indices of a chunk leave bit 15 free");
 static_assert(kRsCap % kBlock == 0 && kRsCap <= (1 << (kRsBits - 1)), "counter fields");
 static_assert(kRsWords % kBlock == 0, "whole bitmap words per thread");
 static_assert(kRsSpan <= 65536, "16-bit row offsets");
@@ -106,6 +109,16 @@ __device__ inline f32x4 rs_dpp_v(f32x4 v) {
   r.z = __int_as_float(rs_dpp_i<CTRL>(__float_as_int(v.z)));
   r.w = __int_as_float(rs_dpp_i<CTRL>(__float_as_int(v.w)));
   return r;
+}
+// lane `src`'s value (any lane of the wave)
+template <typename V>
+__device__ inline V rs_shfl_v(V v, int src);
+template <>
+__device__ inline float rs_shfl_v<float>(float v, int src) { return __shfl(v, src, kWave); }
+template <>
+__device__ inline f32x4 rs_shfl_v<f32x4>(f32x4 v, int src) {
+  return f32x4{__shfl(v.x, src, kWave), __shfl(v.y, src, kWave), __shfl(v.z, src, kWave),
+               __shfl(v.w, src, kWave)};
 }
 constexpr int kDppRowShl4 = 0x104;   // lane i reads lane i + 4 of its row of 16
 constexpr int kDppRowShr4 = 0x114;   // lane i reads lane i - 4
@@ -200,8 +213,128 @@ struct RsLds {
   float red[kBlock * 4];        // per lane group: what it holds of a run that began in an earlier group's share
   int32_t wave_tot[kWavesPerBlock];
   int32_t n_sorted, base_u;
-  int32_t det_end, det_tile, det_long;   // deterministic jobs: end of the chunk, its last tile + 1, "a long run"
+  int32_t det_end, det_tile, det_long;   // deterministic jobs: end of the chunk, its last tile + 1, "a run above kRsDetRank"
+  int32_t n_long;                        //   runs of >= kRsDetLong pairs in the chunk, their rows
+  uint16_t det_list[kRsCap / kRsDetLong + 2];
 };
+
+// Deterministic jobs: the LONG runs of a chunk (rowsort_reduce, below), summed one after the other by
+// the whole workgroup.  A function of its own, not inlined: its registers (WB rows in flight per lane)
+// stay out of the budget of the walk every job takes.  (Its arguments by value, in registers: a
+// reference to a column or a job would make the caller keep the kernel's whole argument block in
+// scratch memory -- 24 KB per lane.)
+struct RsLongArgs {
+  const float* grad;
+  float* out_vals;
+  float* table;
+  float* accum;
+  int32_t stride, dim, tpitch, base_u;
+  uint32_t base;
+  float lr;
+  int32_t sub, lpr_log2;
+  bool seg_is_offset, one_chunk, emit, live;
+};
+template <typename V, int STEP>
+__device__ __attribute__((noinline)) void rs_long_runs(RsLds& L, const RsLongArgs a) {
+  constexpr int VE = sizeof(V) / 4;
+  constexpr bool adagrad = STEP == 2;
+  constexpr int WB = 8;   // terms a lane holds of a round (twice that in flight; 4: Zipf / one hot row at dim 128 1178 / 5795 us)
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid >> 6;
+  const int lpr_log2 = a.lpr_log2, sub = a.sub;
+  const bool stepping = STEP && a.lr != 0.0f;
+  const int R = kWave >> lpr_log2;               // rows of one wave load
+  const int grp = lane >> lpr_log2;
+  const int T = WB * R;                          // terms of a wave per round
+  V* carry = reinterpret_cast<V*>(L.red);        // [lanes of a row]
+  const int n_long = L.n_long;
+  for (int li = 0; li < n_long; ++li) {
+    const uint32_t u = L.det_list[li];
+    const uint32_t cv = L.cnt[u];
+    const int start = (int)(cv & kRsMask), end = start + (int)((cv >> kRsBits) & kRsMask);
+    // the row's place in the output; (several chunks) what the earlier chunks left there
+    int32_t oi = a.base_u + (int32_t)u;
+    bool first = true;
+    if (!a.one_chunk) {
+      const uint32_t off = L.roff[u];
+      const int w = (int)(off >> 5);
+      oi = a.base_u + (int32_t)L.pre[w] + __builtin_popcount(L.present[w] & ((1u << (off & 31u)) - 1u));
+      first = ((L.seen[w] >> (off & 31u)) & 1u) == 0u;
+    }
+    V* o = reinterpret_cast<V*>(a.out_vals + (int64_t)oi * a.dim + (int64_t)sub * VE);
+    __syncthreads();   // (the run before is done with carry)
+    if (wave == 0 && grp == 0) {
+      V a0 = zero_v<V>();
+      if (a.live && !first) a0 = __builtin_nontemporal_load(o);
+      carry[sub] = a0;
+    }
+    __syncthreads();
+    // lane group j of a wave holds WB CONSECUTIVE terms: it adds them to the sum that reaches it without
+    // a lane permute per term; the sum goes from lane group to lane group (one permute per WB terms)
+    // and from wave to wave (LDS).  The next round's terms are requested before this round's turns.
+    auto request = [&](V (&g)[WB], int p) {
+#pragma unroll
+      for (int b = 0; b < WB; ++b) {
+        const int q = p + wave * T + grp * WB + b;
+        const int32_t seg = L.sseg[q < end ? q : end - 1];
+        const uint64_t off = a.seg_is_offset ? (uint64_t)(uint32_t)seg : (uint64_t)(uint32_t)seg * (uint32_t)a.stride;
+        g[b] = zero_v<V>();
+        if (a.live && q < end) g[b] = HBK_GRAD_LOAD(reinterpret_cast<const V*>(a.grad + off + (uint64_t)sub * VE));
+      }
+    };
+    V g[WB], gn[WB];
+    request(g, start);
+    for (int p = start; p < end; p += kWavesPerBlock * T) {
+      const int p_w = p + wave * T;
+      if (p + kWavesPerBlock * T < end) {   // (uniform)
+        request(gn, p + kWavesPerBlock * T);
+      }
+      for (int turn = 0; turn < kWavesPerBlock; ++turn) {
+        if (wave == turn && p_w < end) {   // (wave-uniform)
+          V acc = carry[sub];
+          for (int j = 0; j < R && p_w + j * WB < end; ++j) {
+            V mine = acc;
+#pragma unroll
+            for (int b = 0; b < WB; ++b) {
+              if (p_w + j * WB + b < end) mine = mine + g[b];   // (right in lane group j, whose terms these are)
+            }
+            acc = rs_shfl_v<V>(mine, (j << lpr_log2) + sub);
+          }
+          if (grp == 0) carry[sub] = acc;
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int b = 0; b < WB; ++b) g[b] = gn[b];
+    }
+    if (wave == 0 && grp == 0 && a.live) {
+      const V acc = carry[sub];
+      if (a.one_chunk && (a.emit || !stepping)) {   // (written once, not read again by this kernel: rs_store_row)
+#if HBK_RS_OUT_NT
+        __builtin_nontemporal_store(acc, o);
+#else
+        *o = acc;
+#endif
+      } else if (!a.one_chunk) {
+        *o = acc;   // (the step of a row of several chunks is taken once, behind the last chunk)
+      }
+      if (a.one_chunk && stepping) {
+        const int64_t toff = (int64_t)(a.base + L.roff[u]) * a.tpitch + (int64_t)sub * VE;
+        const V tv = HBK_STEP_LOAD(reinterpret_cast<const V*>(a.table + toff));
+        V av = zero_v<V>();
+        if (adagrad) av = HBK_STEP_LOAD(reinterpret_cast<const V*>(a.accum + toff));
+        // (step_row, lookup_bwd.hip)
+        if (adagrad) {
+          const V acc2 = av + acc * acc;
+          *reinterpret_cast<V*>(a.accum + toff) = acc2;
+          *reinterpret_cast<V*>(a.table + toff) = tv - (a.lr * acc) * rsqrt_v<V>(acc2);
+        } else {
+          *reinterpret_cast<V*>(a.table + toff) = tv - a.lr * acc;
+        }
+      }
+    }
+  }
+}
 
 template <typename V, int STEP, bool DET = false>
 __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds& L, int bucket) {
@@ -609,9 +742,22 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
             __syncthreads();
           }
         }
+        // the runs the whole workgroup will sum (below): listed, their positions marked
+        if (tid == 0) L.n_long = 0;
+        __syncthreads();
+        for (int u = tid; u < n_rows; u += kBlock) {
+          if ((int)((L.cnt[u] >> kRsBits) & kRsMask) >= kRsDetLong) {
+            L.det_list[atomicAdd(&L.n_long, 1)] = (uint16_t)u;   // (any order: the runs are summed one by one)
+          }
+        }
+        for (int q = tid; q < n_sorted; q += kBlock) {
+          const uint16_t u = L.su[q];
+          if ((int)((L.cnt[u] >> kRsBits) & kRsMask) >= kRsDetLong) L.su[q] = u | kRsLongBit;
+        }
       }
       __syncthreads();
     }
+    const bool has_long = DET && L.det_long != 0 && L.n_long > 0;   // (uniform)
 
     // a finished row leaves: (one chunk) straight to its output row, with the optimizer step;
     // (several chunks) into its output row, which an earlier chunk may have started
@@ -643,6 +789,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
       for (int u = my_group; u < n_rows; u += groups) {
         const uint32_t cv = L.cnt[u];
         const int start = (int)(cv & kRsMask), n = (int)((cv >> kRsBits) & kRsMask);
+        if (has_long && n >= kRsDetLong) continue;   // (the whole workgroup's, below)
         const int32_t oi = out_index((uint32_t)u);
         V* o = reinterpret_cast<V*>(job.out_vals + (int64_t)oi * c.dim + (int64_t)sub * VE);
         V acc = zero_v<V>();
@@ -671,11 +818,11 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
         // it begins takes all of it, the groups it runs through begin behind it.  (Shares are then
         // as unequal as the ids are skewed; no heads, no tails: in_head and tail below stay false.)
         if (lo > 0 && L.su[lo - 1] == L.su[lo]) {
-          const uint32_t cv = L.cnt[L.su[lo]];
+          const uint32_t cv = L.cnt[L.su[lo] & ~kRsLongBit];
           lo = (int)(cv & kRsMask) + (int)((cv >> kRsBits) & kRsMask);
         }
         if (hi < n_sorted && L.su[hi - 1] == L.su[hi]) {
-          const uint32_t cv = L.cnt[L.su[hi]];
+          const uint32_t cv = L.cnt[L.su[hi] & ~kRsLongBit];
           hi = (int)(cv & kRsMask) + (int)((cv >> kRsBits) & kRsMask);
         }
         if (lo > hi) lo = hi;
@@ -683,6 +830,11 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
       bool in_head = lo < hi && lo > 0 && L.su[lo - 1] == L.su[lo];
       V acc = zero_v<V>();
       for (int p = lo; p < hi; p += W) {
+        if (has_long && (L.su[p] & kRsLongBit) != 0) {   // a run of the whole workgroup's (below): on behind it
+          const uint32_t cv = L.cnt[L.su[p] & ~kRsLongBit];
+          p = (int)(cv & kRsMask) + (int)((cv >> kRsBits) & kRsMask) - W;
+          continue;
+        }
         V g[W];
         int32_t sg[W];
         uint32_t uu[W];
@@ -695,7 +847,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
           const int q = p + w < hi ? p + w : hi - 1;
           uu[w] = L.su[q];
           sg[w] = L.sseg[q];
-          if (p + w < hi) {
+          if (p + w < hi && !(has_long && (uu[w] & kRsLongBit) != 0)) {
             val |= 1u << w;
             if (L.su[q + 1] != (uint16_t)uu[w]) fin |= 1u << w;
           }
@@ -802,6 +954,35 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
           emit_row<V>(c, job, out_index(u), is_first(u), sub, acc);
         }
       }
+    }
+
+    // Deterministic: the LONG runs of the chunk (a hot row: the Zipf head, a table of a few rows), one
+    // after the other, by the whole workgroup.  A sequential sum has one chain of additions, but its
+    // terms can arrive from everywhere: every wave requests WB x (rows per wave load) terms of the
+    // run per round -- all lanes loading, as in the equal shares of the default walk -- and the waves
+    // take turns adding theirs, in order, to the running sum they hand on through LDS (a term
+    // reaches every lane of its wave's rows by a lane permute; the lane groups of a wave all hold the
+    // same sum).  acc = ((carry + t_i) + t_i+1) + ...: the same chain as one lane group walking the
+    // run, at a workgroup's loads in flight.
+    if (has_long) {
+      RsLongArgs la;
+      la.grad = job.grad;
+      la.out_vals = job.out_vals;
+      la.table = c.table;
+      la.accum = c.accum;
+      la.stride = job.stride;
+      la.dim = c.dim;
+      la.tpitch = c.tpitch;
+      la.base_u = base_u;
+      la.base = base;
+      la.lr = lr;
+      la.sub = sub;
+      la.lpr_log2 = lpr_log2;
+      la.seg_is_offset = job.seg_is_offset;
+      la.one_chunk = one_chunk;
+      la.emit = emit;
+      la.live = live;
+      rs_long_runs<V, STEP>(L, la);
     }
 
     if (cb == 0) HBK_STAMP(6);

@@ -82,6 +82,14 @@ PY
            done
          done
        done) > $O/detab.txt 2>&1; cut -c1-150 $O/detab.txt;;
+    detquick)   # the deterministic mode next to the default: config 2, ragged, the duplicate-heavy cases (C ABI), twice
+      (for rep in 1 2; do for w in ${WORK:-b s R d}; do for det in 0 1; do HBK_BWD_DETERMINISTIC=$det timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/deterministic=$det  /"; done; done; done) > $O/detquick.txt 2>&1; cut -c1-150 $O/detquick.txt;;
+    detskew)    # the deterministic modes under skew: dim 128, 26 x 65536 ids -- uniform / Zipf(1.2) / one row with 20 % / one row with all
+      (for det in ${DETS:-0 1 2}; do HBK_BWD_DETERMINISTIC=$det timeout 600 python tools/sweep.py --cases f 2>/dev/null | grep "^{" | python -c "
+import sys,json
+for l in sys.stdin:
+  d=json.loads(l)
+  if 'case' in d: print('deterministic=$det  ', d['case'].ljust(40), d['us'])"; done) > $O/detskew.txt 2>&1; cat $O/detskew.txt;;
     detprof)    # kernel times of the deterministic backward (config 2 emit, ragged)
       export HBK_BENCH_ITERS=4
       for det in ${DETS:-0 1}; do

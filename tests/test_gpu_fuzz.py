@@ -138,7 +138,9 @@ def test_group_lookup_deterministic_random(cols, seed):
   # (mostly the row-sorted jobs' in-order form, with the grouping form and the bucket count drawn too --
   # one bucket per column makes jobs of many chunks; every fifth draw the sort for every column)
   opts = {'bwd_deterministic': 2 if seed % 5 == 4 else 1, 'bwd_onepass': (seed // 5) % 2,
-          'bwd_buckets_log2': (-1, -1, 0, 3)[(seed // 10) % 4]}
+          'bwd_buckets_log2': (-1, -1, 0, 3)[(seed // 10) % 4], 'bwd_pairs_packed': (seed // 40) % 2,
+          'bwd_seg_inline': (seed // 80) % 2, 'bwd_scatter_staged': (seed // 160) % 2,
+          'bwd_scale_fused': (seed // 320) % 2}
   old = {k: _lib.set_option(k, v) for k, v in opts.items()}
   try:
     t_dev = [dev(t.copy()) for t in tables]

@@ -334,6 +334,7 @@ def backward_secondary(args, hb, tables, batches, device, timed_steps, steps=20,
     bwd_step_only  the fused step alone, no IndexedSlices written
     bwd_ragged     26 columns x batch segments of Poisson(8) ids clipped to [0, 32] (SURVEY 8d's
                    multi-hot variant), mean combiner, IndexedSlices
+    bwd_emit_det / bwd_ragged_det   the first and the last under option bwd_deterministic = 1
 
   Every call reads another resident id batch (tables 1.66 GB, 4-8 batches: nothing is served from the
   Infinity Cache by repetition).  `frac` = algorithmic bytes / time / 8 TB/s with SURVEY 8(d)'s
@@ -347,7 +348,15 @@ def backward_secondary(args, hb, tables, batches, device, timed_steps, steps=20,
   gen.manual_seed(777)
   out = {}
 
-  def run(name, ids_pool, splits, n_seg, combiner, lr, emit):
+  def run(name, ids_pool, splits, n_seg, combiner, lr, emit, deterministic=0):
+    from hybridbackend_amd import _lib
+    old_det = _lib.set_option('bwd_deterministic', deterministic)
+    try:
+      run_case(name, ids_pool, splits, n_seg, combiner, lr, emit)
+    finally:
+      _lib.set_option('bwd_deterministic', old_det)
+
+  def run_case(name, ids_pool, splits, n_seg, combiner, lr, emit):
     grads = [torch.randn(n_seg[c], dim, device=device, generator=gen) for c in range(cols)]
     lookup = hb.embedding.GroupLookup(tables, buckets=[args.rows] * cols, combiners=combiner)
     # one gradient object per resident batch: handed the same tensors again, a call re-binds nothing
@@ -398,6 +407,10 @@ def backward_secondary(args, hb, tables, batches, device, timed_steps, steps=20,
     ragged.append([torch.randint(0, 1 << 40, (counts[c],), device=device, dtype=torch.int64,
                                  generator=g) for c in range(cols)])
   run('bwd_ragged', ragged, splits, one, 'mean', 0.0, True)
+  # the reproducible mode (option bwd_deterministic = 1: sums in id order, bit-equal to the oracle's
+  # in-order fp32 sum, rows ascending) on the same two shapes: what exactness costs
+  run('bwd_emit_det', flat, None, one, 'sum', 0.0, True, deterministic=1)
+  run('bwd_ragged_det', ragged, splits, one, 'mean', 0.0, True, deterministic=1)
   out['steps'] = steps
   out['warmup'] = warmup
   out['id_batches'] = pool

@@ -61,6 +61,9 @@
 // GArgs.xcd / xcd_w) so that both rows of a gradient line -- and the pieces of a pair-array line
 // -- meet in ONE L2.
 // Summation order inside a row is not fixed (pair order comes from LDS tickets): 1e-5 relative.
+// Option bwd_deterministic fixes it -- id order, the sequential fp32 sum, rows ascending: 1 = the row-sorted
+// jobs in their in-order form (lookup_bwd_rowsort.h, DET) with a count launch in front of the reduce,
+// 2 (and the columns 1 does not fit) = a stable sort of the batch's pairs (lookup_bwd_det.h).
 #include <alloca.h>
 #include <stdlib.h>
 #include <string.h>

@@ -1,9 +1,10 @@
-// ---- 5: the DETERMINISTIC backward (round 6; option bwd_deterministic) -- included by
+// ---- 5: the DETERMINISTIC backward by sorting (round 6; option bwd_deterministic = 2, and under = 1 the
+// columns the row-sorted jobs' in-order form does not fit: lookup_bwd_rowsort.h DET) -- included by
 // lookup_bwd.hip, inside its namespace -------------------------------------------------------------
 // The default backward takes pair slots by LDS atomics, splits hot buckets over workgroups and
 // joins partial sums: every row's sum is right to rounding, but the ORDER of its terms -- hence
 // its last bits -- changes from run to run (the reference's TF path, unsorted_segment_sum on a
-// GPU, behaves the same).  With bwd_deterministic = 1 a call instead
+// GPU, behaves the same).  This form
 //   1  turns every id into a key (column, row) and a value (its gradient row),      [det_keys_kernel]
 //   2  sorts the pairs by key with a STABLE radix sort (det_prims.hip): a row's terms end up
 //      side by side IN ID ORDER,
@@ -13,10 +14,11 @@
 //      and take the optimizer step from the finished sum.                           [det_reduce_kernel]
 // The sum of a row is then the same bits on every run and EQUAL to the sequential fp32 sum in id
 // order -- oracle.unsorted_segment_sum, TF's CPU kernel -- whatever the column holds (hot rows,
-// ragged segments, ids outside the table, segmented inputs).  One path for every column: nothing
-// here depends on the bucket plans of the default backward.  Cost: a full sort of the batch's pairs
-// and a walk that is as long as the hottest row (measured in DESIGN.md 4.4): a reproducibility
-// tool -- TF_DETERMINISTIC_OPS' analogue -- not the fast path.
+// ragged segments, ids outside the table, segmented inputs, tables of any size).  Nothing here
+// depends on the bucket plans of the default backward: the general form, and the second
+// implementation the in-order row-sorted jobs are tested against.  Cost: a full sort of the batch's
+// pairs and a walk that is as long as the hottest row (3.5 - 4.4 x the default, 50 x under heavy
+// skew).
 constexpr int kDetTile = 2048;          // pairs per workgroup in the key / head kernels
 constexpr int kDetLanes = 16;           // most lanes that walk one row
 constexpr int kDetMaxE = 16;            // most row chunks per lane: dim <= 256 (make_rowshape's bound)

@@ -26,6 +26,12 @@
 // per chunk; a row that an earlier chunk emitted is added to (this workgroup owns it), and the
 // optimizer step is taken once per row after the last chunk, from the finished sums.
 // (kRsCap, pairs per chunk: lookup_bwd.hip)
+// DET (round 6, option bwd_deterministic = 1): the same job with every row's terms added IN ID ORDER by
+// one chain of additions -- E' orders the pairs of a run by gradient row, F gives a run to ONE lane
+// group (shares snapped to run boundaries; runs of >= kRsDetLong pairs to the whole workgroup,
+// rs_long_runs), a job of several chunks cuts them at tile shares of the bucket and continues a row
+// from what the earlier chunks left, and the output range comes from bwd_rowsort_count_kernel's
+// bucket counts instead of an atomic: bit-equal to the sequential fp32 sum, rows ascending.
 constexpr int kRsPT = kRsCap / kBlock;           // pairs per thread and chunk
 constexpr int kRsSpan = 16384;                   // rows of a bucket's range (bits of the bitmap)
 constexpr int kRsWords = kRsSpan / 32;

@@ -15,6 +15,7 @@
 //   hybridbackend/tensorflow/distribute/nccl/nccl_alltoall.cc:169-180,242-258
 //   hybridbackend/tensorflow/distribute/nccl/nccl_alltoallv.cc:200-223,359-387
 //   hybridbackend/tensorflow/embedding/lookup_ops.cc:38-58
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -48,6 +49,19 @@ HBK_TYPE(int8, HBK_INT8); HBK_TYPE(uint8, HBK_UINT8); HBK_TYPE(int32, HBK_INT32)
 HBK_TYPE(uint32, HBK_UINT32); HBK_TYPE(int64, HBK_INT64); HBK_TYPE(uint64, HBK_UINT64);
 HBK_TYPE(Eigen::half, HBK_HALF); HBK_TYPE(float, HBK_FLOAT); HBK_TYPE(double, HBK_DOUBLE);
 #undef HBK_TYPE
+
+// TF_DETERMINISTIC_OPS=1 (TensorFlow's switch for bit-reproducible GPU kernels; the reference's
+// gradient of the lookup is TF's UnsortedSegmentSum, which that switch makes deterministic): the
+// backward's duplicate-row reduction sums every row's terms in id order -- bit-equal to TF's CPU
+// kernel, rows ascending (hbk option bwd_deterministic = 1, include/hbk.h).  Read once, when the op
+// library is loaded; HBK_BWD_DETERMINISTIC in the environment, if set, has already chosen.
+static const bool kDeterministicOps = [] {
+  const char* tf = std::getenv("TF_DETERMINISTIC_OPS");
+  const bool on = tf != nullptr && (std::strcmp(tf, "1") == 0 || std::strcmp(tf, "true") == 0 ||
+                                    std::strcmp(tf, "True") == 0);
+  if (on && std::getenv("HBK_BWD_DETERMINISTIC") == nullptr) (void)hbk_set_option("bwd_deterministic", 1);
+  return on;
+}();
 
 static Status AllocScratch(OpKernelContext* ctx, size_t bytes, Tensor* t) {
   return ctx->allocate_temp(DT_INT8, TensorShape({static_cast<int64>(bytes) + 16}), t);

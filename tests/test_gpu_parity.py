@@ -1152,6 +1152,34 @@ def test_group_lookup_backward_deterministic_rowsorted_jobs_of_several_chunks(hb
       np.testing.assert_equal(x, y)
 
 
+def test_group_lookup_backward_deterministic_sparse_batch_over_a_large_table(hbk_option):
+  """bwd_deterministic = 1 where the row-sorted buckets are nearly all empty: 3000 ids (a tenth of them
+  repeated) over 30 M rows are 1832 buckets of <= 16383 rows -- the three-launch grouping, a count
+  launch of mostly empty buckets, output ranges summed over up to 1831 counts -- and over 300 M rows
+  (more buckets than the jobs take) the sort, through the same option value."""
+  hbk_option('bwd_deterministic', 1)
+  rng = np.random.RandomState(612)
+  for rows in (30_000_000, 300_000_000):
+    d, n = 4, 3000
+    ids = rng.randint(0, rows, size=n).astype(np.int64)
+    ids[::10] = ids[5::10][:ids[::10].size]          # repeated rows, far apart in the batch
+    grads = rng.randn(n, d).astype(np.float32)
+    table = torch.zeros(rows, d, device=DEV)
+    lookup = hb.embedding.GroupLookup([table], None, 'sum')
+    seen = []
+    for rep in range(2):
+      urows, grows, nu = hb.embedding.GroupLookupGrad(lookup)([dev(ids)], [dev(grads)])[0]
+      k = int(nu.item())
+      seen.append((k, host(urows)[:k].copy(), host(grows)[:k].copy()))
+    want_rows, want_sums = _in_order_slices(ids, grads, None, 'sum', rows)
+    assert seen[0][0] == want_rows.size
+    np.testing.assert_equal(seen[0][1], want_rows)
+    np.testing.assert_equal(seen[0][2], want_sums)
+    np.testing.assert_equal(seen[0][1], seen[1][1])
+    np.testing.assert_equal(seen[0][2], seen[1][2])
+    del table, lookup
+
+
 def test_group_lookup_backward_deterministic_segmented_inputs_and_divisor(hbk_option):
   """bwd_deterministic through the C ABI's other inputs: ids and gradient rows as runs inside larger
   buffers (the owner side of the sharded backward), `// W` row numbers with a bucket, int32 ids."""

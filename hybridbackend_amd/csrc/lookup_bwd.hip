@@ -730,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void bwd_scatter_pairs_kernel(const GArgs a
         if (c.n_runs > 0) {
           // the pair carries the float offset of its gradient row (host checks < 2^32)
           run_seek(c, j, rc);
-          seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);
+          if (!c.det) seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);   // (deterministic: the position, see rowsort_reduce)
         }
         id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
         if (c.seg_of != nullptr) {
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
     if (j < c.n_ids) {
       if (c.n_runs > 0) {
         run_seek(c, j, rc);
-        seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);
+        if (!c.det) seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);   // (deterministic: the position, see rowsort_reduce)
       }
       id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
       if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
     if (j < c.n_ids) {
       if (c.n_runs > 0) {
         run_seek(c, j, rc);
-        seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);
+        if (!c.det) seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);   // (deterministic: the position, see rowsort_reduce)
       }
       id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
       if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
@@ -3251,11 +3251,10 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
 }
 
 // deterministic mode, option value 1: the columns whose buckets fit the row-sorted jobs take their
-// in-order form (lookup_bwd_rowsort.h); the others -- tables too sparse or too large for row-range
-// buckets, segmented inputs (their gradient rows need not ascend with the ids) -- and everything
-// under option value 2 go through the sort of lookup_bwd_det.h
+// in-order form (lookup_bwd_rowsort.h); the others -- tables too large for row-range buckets -- and
+// everything under option value 2 go through the sort of lookup_bwd_det.h
 inline bool det_rowsort(const hbk_lookup_grad_column_t& h) {
-  if (options().bwd_deterministic != 1 || h.n_ids <= 0 || h.n_runs > 0) return false;
+  if (options().bwd_deterministic != 1 || h.n_ids <= 0) return false;
   return plan_of(h.n_ids, h.dim, h.rows, h.row_splits != nullptr).rowsort;
 }
 inline void det_split(int32_t n_cols, const hbk_lookup_grad_column_t* cols,

@@ -764,6 +764,20 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
       __syncthreads();
     }
     const bool has_long = DET && L.det_long != 0 && L.n_long > 0;   // (uniform)
+    // Deterministic, segmented inputs (the owner side of the sharded backward: ids and gradient rows
+    // as runs inside larger buffers): the pairs carry the id's POSITION -- what E' has just ordered
+    // them by, the gradient rows of two runs need not ascend -- and become float offsets of the
+    // gradient rows here, for the walks (job.seg_is_offset).
+    if (DET && c.n_runs > 0) {
+      const int n_sorted = L.n_sorted;
+      for (int q = tid; q < n_sorted; q += kBlock) {
+        const int64_t j = (int64_t)(uint32_t)L.sseg[q];
+        int k = 0;
+        for (int r = 1; r < c.n_runs; ++r) k = j >= c.run_start[r] ? r : k;
+        L.sseg[q] = (int32_t)(uint32_t)(c.run_grads[k] + (j - c.run_start[k]) * c.dim);
+      }
+      __syncthreads();
+    }
 
     // a finished row leaves: (one chunk) straight to its output row, with the optimizer step;
     // (several chunks) into its output row, which an earlier chunk may have started

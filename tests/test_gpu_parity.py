@@ -1230,14 +1230,21 @@ def test_group_lookup_backward_deterministic_segmented_inputs_and_divisor(hbk_op
   c.n_unique = nu.data_ptr()
   c.run_start, c.run_ids, c.run_grads = (t.data_ptr() for t in tabs)
   c.n_runs = len(lens)
-  need = lib.hbk_group_lookup_bwd_workspace_bytes(1, col)
-  ws = torch.empty(max(need, 8), dtype=torch.uint8, device=DEV)
-  _lib.check(lib.hbk_group_lookup_bwd(1, col, C.c_float(0.0), C.c_void_p(ws.data_ptr()),
-                                      C.c_size_t(ws.numel()), _lib.current_stream(DEV)))
   want_rows, want_sums = _in_order_slices(ids, grads, None, 'sum', rows)
-  k = int(nu.item())
-  np.testing.assert_equal(host(urows)[:k], want_rows)
-  np.testing.assert_equal(host(grows)[:k], want_sums)
+  # (the runs lie in the buffers in REVERSE order: a pair ordered by its gradient row's address would
+  # be out of id order; one bucket per column = a job of two chunks; option value 2 = the sort)
+  for det, log2p in ((1, None), (1, 0), (2, None)):
+    hbk_option('bwd_deterministic', det)
+    hbk_option('bwd_buckets_log2', -1 if log2p is None else log2p)
+    urows.fill_(-1)
+    grows.fill_(float('nan'))
+    need = lib.hbk_group_lookup_bwd_workspace_bytes(1, col)
+    ws = torch.empty(max(need, 8), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.hbk_group_lookup_bwd(1, col, C.c_float(0.0), C.c_void_p(ws.data_ptr()),
+                                        C.c_size_t(ws.numel()), _lib.current_stream(DEV)))
+    k = int(nu.item())
+    np.testing.assert_equal(host(urows)[:k], want_rows, err_msg=f'option {det}, log2p {log2p}')
+    np.testing.assert_equal(host(grows)[:k], want_sums, err_msg=f'option {det}, log2p {log2p}')
 
 
 def test_group_lookup_backward_segmented_inputs():

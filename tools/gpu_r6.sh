@@ -126,6 +126,9 @@ for l in sys.stdin:
       timeout 900 python tools/hbm_traffic.py r06 $O/hbm_traffic.json > $O/ev_traffic.log 2>&1; tail -3 $O/ev_traffic.log; head -30 $O/hbm_traffic.json
       timeout 600 tools/bin/bench_ops > $O/ev_bench_ops.txt 2>&1; (for w in R r d; do timeout 300 tools/bin/bench_ops $w 2>&1 | grep -v "^hbk "; done) >> $O/ev_bench_ops.txt; cut -c1-190 $O/ev_bench_ops.txt
       trim ev_prof_bench;;
+    cfg5prof)   # kernel times of the config-5 shape sweep (forward, backward + SGD, step only, + Adagrad x 3)
+      prof prof_cfg5 "" -- python $R/tools/sweep.py --cases h
+      head -40 $O/prof_cfg5.txt | cut -c1-170; trim prof_cfg5;;
     cfg5)       # config-5 shape x 3 processes (sweep h): forward, backward + SGD, step only, + Adagrad
       for i in 1 2 3; do timeout 600 python tools/sweep.py --cases h 2>/dev/null | grep "^{" > $O/ev_sweep_h_$i.jsonl; done
       for i in 1 2 3; do echo "== process $i"; python -c "

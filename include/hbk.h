@@ -284,7 +284,9 @@ int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* cols,
  *   nothing.  No global atomics on the data path: ids are grouped by a hash of their row and
  *   each group is reduced by one workgroup (LDS hash table of the distinct rows, sums in
  *   registers; a group holding a hot row is split over several workgroups and merged), so the
- *   summation order is not fixed: tolerance 1e-5 relative.  unique_rows[c][0..u) are DISTINCT
+ *   summation order is not fixed: tolerance 1e-5 relative (option bwd_deterministic fixes it: every
+ *   row's terms in id order, bit-equal to the sequential fp32 sum, unique_rows ascending -- see
+ *   hbk_set_option).  unique_rows[c][0..u) are DISTINCT
  *   whatever the column holds: a group with more distinct rows than the workgroup's LDS table
  *   takes further passes over its pairs (rows handled in one pass are struck out), so every row
  *   is emitted -- and stepped by the fused optimizer -- exactly once.

@@ -37,7 +37,7 @@ for st in $STAGES; do
       : > $O/gputest_repeats.txt
       for i in 1 2 3 4 5; do
         timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider > $O/test_rep$i.log 2>&1; rc=$?
-        echo "== run $i: rc=$rc" >> $O/gputest_repeats.txt; tail -4 $O/test_rep$i.log >> $O/gputest_repeats.txt
+        echo "== run $i: rc=$rc" >> $O/gputest_repeats.txt; grep -E "passed|failed" $O/test_rep$i.log | tail -1 >> $O/gputest_repeats.txt
         grep -E "^(FAILED|ERROR)" $O/test_rep$i.log >> $O/gputest_repeats.txt
       done; cat $O/gputest_repeats.txt;;
     seed400)    # the r05 failure (dedup, seed 400) in 24 fresh processes, worst |diff| / sum|g| logged

@@ -56,9 +56,11 @@ SECONDARY_KEYS = ('replicated_M_lookups_per_s', 'replicated_ms_per_step',
                   'secondary_steps')
 
 
-# the step forms the probe in front of the timed steps runs at N > 1 (or --sharded); the timed steps
-# run in the fastest of the first four, 'pipelined_steps_3' (three plans, begin(i + 1) before end(i):
-# outputs arrive one step late, forward-only use) is a reference
+# the step forms the probe BEHIND the timed steps runs at N > 1 (or --sharded): the timed steps run in
+# the shipped default ('inline') first, and again in the fastest of the first four when the probe
+# finds one more than 3 % faster (config.sharded_form says which measurement `value` is);
+# 'pipelined_steps_3' (three plans, begin(i + 1) before end(i): outputs arrive one step late,
+# forward-only use) is a reference
 FORM_KEYS = ('pipelined_2_groups', 'one_group', 'inline', 'p2p', 'pipelined_steps_3')
 # what an N > 1 line carries under 'xgmi'
 XGMI_KEYS = ('bytes_out_per_rank_per_step', 'links_per_rank', 'achieved_GBps_per_rank_each_way',
@@ -563,35 +565,31 @@ def main():
     if use_dist:
       dist.barrier()
 
-  probe = None
-  if world > 1 and args.link_probe_mb > 0:
-    try:
-      probe = link_probe(coll, device, world, args.link_probe_mb, dist)
-    except Exception as e:  # pylint: disable=broad-except
-      # (a pre-measurement: the same error on every rank, the timed steps still run)
-      probe = {'error': f'{type(e).__name__}: {e}'[:300]}
+  # The step forms of the sharded step (a hardware question: a cross-stream hop costs ~11 us on this
+  # chip, an owner gather ~33 us, profiles/r02_hop_probe.txt): two column groups with the exchanges
+  # on the communicator's stream beside the gathers (the default until round 4), one group on the
+  # communicator's stream, the exchanges enqueued inline on the compute stream (no event hops; the
+  # shipped default), and the p2p form (owners store rows straight into the requester's outputs).
+  forms = {'pipelined_2_groups': (2, 0, False), 'one_group': (1, 0, False), 'inline': (0, 1, False)}
+  if args.wire == 'fp32' and (args.p2p == 'on' or (args.p2p == 'auto' and world == 1)):
+    forms['p2p'] = (0, 1, True)
 
-  # The pipeline group count of the sharded step is a hardware question (a cross-stream hop costs
-  # ~11 us on this chip, an owner gather ~33 us: profiles/r02_hop_probe.txt): both forms run a few
-  # untimed steps on the machine at hand, every rank takes the one whose slowest rank was faster.
-  groups_probe = None
-  best_form = None
-  if (world > 1 or args.sharded) and args.tune_steps > 0:
+  def set_form(name):
+    """(Re)creates the plan in form `name`; False when the p2p form cannot be bound (a collective
+    answer: the same on every rank)."""
     from hybridbackend_amd import _lib as _hbk
-    # candidates: two column groups with the exchanges on the communicator's stream beside the
-    # gathers (the default until round 4), one group on the communicator's stream, and the
-    # exchanges enqueued inline on the compute stream (no event hops at all; the shipped default)
-    forms = {'pipelined_2_groups': (2, 0, False), 'one_group': (1, 0, False),
-             'inline': (0, 1, False)}
-    if args.wire == 'fp32' and (args.p2p == 'on' or (args.p2p == 'auto' and world == 1)):
-      forms['p2p'] = (0, 1, True)
-    groups_probe = {}
-    for name, (g, inline, p2p) in forms.items():
-      _hbk.set_option('sharded_groups', g)
-      _hbk.set_option('sharded_inline', inline)
-      sharded.close()                 # the options are read when the plan is (re)created
-      if p2p and not sharded.p2p_bind(sh_outs):   # (collective; False on every rank alike)
-        groups_probe[name] = None
+    g, inline, p2p = forms[name]
+    _hbk.set_option('sharded_groups', g)
+    _hbk.set_option('sharded_inline', inline)
+    sharded.close()                 # the options are read when the plan is (re)created
+    return sharded.p2p_bind(sh_outs) if p2p else True
+
+  def probe_forms():
+    """A few untimed steps + args.tune_steps timed ones in every form, MAX over the ranks."""
+    out = {}
+    for name in forms:
+      if not set_form(name):
+        out[name] = None
         continue
       for i in range(3):
         step(i)
@@ -607,14 +605,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-      groups_probe[name] = round(dt / args.tune_steps * 1e3, 5)
-    best_form = min((k for k, v in groups_probe.items() if v is not None), key=groups_probe.get)
-    groups_probe['pipelined_steps_3'] = None   # (measured behind the headline steps, see below)
-    _hbk.set_option('sharded_groups', forms[best_form][0])
-    _hbk.set_option('sharded_inline', forms[best_form][1])
-    sharded.close()
-    if forms[best_form][2]:
-      sharded.p2p_bind(sh_outs)
+      out[name] = round(dt / args.tune_steps * 1e3, 5)
+    return out
 
   def probe_pipelined_steps_3():
     """Reference form: three plans over the one communicator, begin(step i + 1) before end(step i)
@@ -730,11 +722,30 @@ def main():
       el = float(t.item())
     return el, ms
 
+  # The K timed steps FIRST, in the library's shipped default form (round 6): at N > 1 the link probe,
+  # the form probe and every reference measurement run BEHIND them -- the first contact of this code
+  # with a multi-GPU box may go wrong in any of those, and then costs a reference figure (the
+  # watchdog prints the line that is already measured), not the line.  If the form probe finds a
+  # form more than 3 % faster on the machine at hand, the K steps are timed again in that form and
+  # the faster measurement becomes `value` (config.sharded_form names it; the shipped default's
+  # figure stays in config.value_at_shipped_default_M_lookups_per_s).
+  if world > 1 or args.sharded:
+    set_form('inline')
   elapsed, gpu_ms = timed_steps(step, args.steps, args.warmup)
+  probe, groups_probe = None, None
+  best_form = 'inline' if (world > 1 or args.sharded) else None
+
+  def headline_fields(elapsed, gpu_ms):
+    total_lookups = lookups_per_step_per_rank * world * args.steps
+    launch_s = gpu_ms / 1e3 / args.steps                 # avg duration of the dominant kernel
+    achieved = lookups_per_step_per_rank * (8 + 4 * args.dim + 4 * args.dim) / launch_s / 1e9
+    return (round(total_lookups / elapsed / 1e6, 3), round(elapsed / args.steps * 1e3, 5), launch_s,
+            achieved)
 
   total_lookups = lookups_per_step_per_rank * world * args.steps
   value = total_lookups / elapsed / 1e6
   ms_per_step = elapsed / args.steps * 1e3
+  result = None
 
   if rank == 0:
     bytes_per_lookup = 8 + 4 * args.dim + 4 * args.dim  # id + row read + output write
@@ -763,11 +774,9 @@ def main():
                  # runs that do not tune (--tune-steps 0)
                  'rccl_ranks_seen': (rccl_ranks_seen if (world > 1 or args.sharded) else None),
                  'sharded_form': best_form,
-                 'sharded_form_probe_ms_per_step': groups_probe,
+                 'sharded_form_probe_ms_per_step': None,      # (filled behind the headline steps)
                  'value_at_shipped_default_M_lookups_per_s': (
-                     round(lookups_per_step_per_rank * world /
-                           groups_probe['inline'] / 1e3, 3)
-                     if groups_probe else None),
+                     round(value, 3) if (world > 1 or args.sharded) else None),
                  **{key: None for key in SECONDARY_KEYS}},
       'roofline': {
         'bound': 'hbm',
@@ -797,9 +806,7 @@ def main():
       result['xgmi'] = {
         'bytes_out_per_rank_per_step': int(link_bytes), 'links_per_rank': world - 1,
         'achieved_GBps_per_rank_each_way': round(link_bytes / (elapsed / args.steps) / 1e9, 2),
-        'link_probe': probe,
-        # what those links allow at best, to read the value against
-        'link_bound': link_bound(args, world, probe, lookups_per_step_per_rank),
+        'link_probe': None, 'link_bound': None,   # (measured behind the headline steps)
         'rccl': rccl_versions(),
         'note': 'the sharded step is link-bound (DESIGN.md 5): one xGMI link per peer pair'}
     if world == 1 and not args.sharded and not args.no_secondary:
@@ -816,11 +823,54 @@ def main():
     headline['line'] = result
   headline['done'] = True
   if use_dist:
-    # from here on a hang costs the reference measurements only, and not 15 minutes
+    # from here on a hang costs the probes and reference measurements only, and not 15 minutes
     watchdog.cancel()
-    watchdog = threading.Timer(min(args.watchdog, 180.0), _abort)
+    watchdog = threading.Timer(min(args.watchdog, 300.0), _abort)
     watchdog.daemon = True
     watchdog.start()
+
+
+  # ---- behind the headline steps (a hang from here on costs what follows, not the line) ----------
+  if world > 1 and args.link_probe_mb > 0:
+    try:
+      probe = link_probe(coll, device, world, args.link_probe_mb, dist)
+    except Exception as e:  # pylint: disable=broad-except
+      # (the same error on every rank)
+      probe = {'error': f'{type(e).__name__}: {e}'[:300]}
+    if rank == 0:
+      result['xgmi']['link_probe'] = probe
+      # what those links allow at best, to read the value against
+      result['xgmi']['link_bound'] = link_bound(args, world, probe, lookups_per_step_per_rank)
+  if (world > 1 or args.sharded) and args.tune_steps > 0:
+    try:
+      groups_probe = probe_forms()
+      fastest = min((k for k, v in groups_probe.items() if v is not None), key=groups_probe.get)
+      groups_probe['pipelined_steps_3'] = None   # (measured last, see probe_pipelined_steps_3)
+      if rank == 0:
+        result['config']['sharded_form_probe_ms_per_step'] = groups_probe
+      # (the probe's times are MAX over the ranks: every rank takes the same decision)
+      if fastest != 'inline' and groups_probe[fastest] < 0.97 * groups_probe['inline'] and set_form(fastest):
+        el2, ms2 = timed_steps(step, args.steps, args.warmup)
+        if el2 < elapsed:
+          best_form = fastest
+          if rank == 0:
+            v2, ms_step2, launch2, achieved2 = headline_fields(el2, ms2)
+            result['value'], result['ms_per_step'] = v2, ms_step2
+            result['config']['sharded_form'] = fastest
+            result['roofline']['achieved'] = round(achieved2, 2)
+            result['roofline']['frac'] = round(achieved2 / HBM_PEAK_GBS, 4)
+            result['roofline']['avg_launch_us'] = round(launch2 * 1e6, 3)
+            if world > 1:
+              result['xgmi']['achieved_GBps_per_rank_each_way'] = round(
+                  result['xgmi']['bytes_out_per_rank_per_step'] / (el2 / args.steps) / 1e9, 2)
+        else:
+          set_form('inline')
+      else:
+        set_form('inline')
+    except Exception as e:  # pylint: disable=broad-except
+      # (the same code on every rank: the same error on every rank; the line is measured)
+      if rank == 0:
+        result['config']['sharded_form_probe_error'] = f'{type(e).__name__}: {e}'[:300]
 
   # Reference measurements next to the sharded headline, same run, same batches:
   #  * the OTHER wire format of the embedding exchange (fp16 when the headline is fp32: the

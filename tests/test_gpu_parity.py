@@ -1684,11 +1684,14 @@ def test_partition_from_concurrent_streams():
   assert not errors, errors
 
 
-@pytest.mark.parametrize('which', ['partition', 'unique', 'backward'])
-def test_ops_inside_a_captured_graph(which):
+@pytest.mark.parametrize('which', ['partition', 'unique', 'backward', 'backward_deterministic'])
+def test_ops_inside_a_captured_graph(which, hbk_option):
   """hipGraph capture of the id-grouping ops: a graph replays ONE recorded launch, so the
   one-launch kernels cannot alternate the halves of their sync words between calls -- under
-  capture partition, unique and the backward record their multi-launch forms.  Replays with new ids in the same buffers stay equal to the oracle."""
+  capture partition, unique and the backward record their multi-launch forms.  Replays with new ids in the same buffers stay equal to the oracle
+  (the backward also under bwd_deterministic = 1: grouping, count launch, in-order reduce -- exact)."""
+  if which == 'backward_deterministic':
+    hbk_option('bwd_deterministic', 1)
   rng = np.random.RandomState(99)
   n, P, rows, d = 30000, 8, 5000, 16
   ids_dev = torch.zeros(n, dtype=torch.int64, device=DEV)
@@ -1700,7 +1703,7 @@ def test_ops_inside_a_captured_graph(which):
   def step():
     part = hb.distribute.partition_by_modulo_n([ids_dev], P) if which == 'partition' else None
     uniq = hb.embedding.unique_n([ids_dev]) if which == 'unique' else None
-    slices = grad([ids_dev], [g_dev]) if which == 'backward' else None
+    slices = grad([ids_dev], [g_dev]) if which.startswith('backward') else None
     return part, uniq, slices
 
   side = torch.cuda.Stream()
@@ -1728,5 +1731,10 @@ def test_ops_inside_a_captured_graph(which):
       assert k == ou.size
       np.testing.assert_equal(host(uniq[0][0])[:k], ou)
       np.testing.assert_equal(host(uniq[0][1]), oidx)
+    elif which == 'backward_deterministic':
+      want_rows, want_sums = _in_order_slices(ids % rows, grads, None, 'sum', rows)
+      k = int(slices[0][2].item())
+      np.testing.assert_equal(host(slices[0][0])[:k], want_rows)
+      np.testing.assert_equal(host(slices[0][1])[:k], want_sums)
     else:
       _check_slices(slices[0], ids % rows, grads, None, 'sum')

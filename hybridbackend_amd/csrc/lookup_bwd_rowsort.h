@@ -702,7 +702,9 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
           const int start = (int)(cv & kRsMask), n = (int)((cv >> kRsBits) & kRsMask);
           if (n > kRsDetRank) {
             long_run = true;
-          } else if (n > 1) {
+          } else if (n > 1) {   // (also runs of two: a + b == b + a, but a job of several chunks continues
+                                // the row from what the earlier chunks left -- (e + a) + b != (e + b) + a;
+                                // skipping them in one-chunk jobs measured no gain)
             const int pos = start + tk_[k];
             const int32_t mine = seg_[k];
             int before = 0;

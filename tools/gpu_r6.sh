@@ -90,6 +90,12 @@ import sys,json
 for l in sys.stdin:
   d=json.loads(l)
   if 'case' in d: print('deterministic=$det  ', d['case'].ljust(40), d['us'])"; done) > $O/detskew.txt 2>&1; cat $O/detskew.txt;;
+    detsharded) # the sharded step (W = 1 through RCCL) forward + backward under the deterministic modes: the owner's backward reads segmented inputs
+      (for det in ${DETS:-0 1 2}; do HBK_BWD_DETERMINISTIC=$det timeout 600 python tools/sweep.py --cases g 2>/dev/null | grep "^{" | python -c "
+import sys,json
+for l in sys.stdin:
+  d=json.loads(l)
+  if 'case' in d and 'bwd' in d['case'] or 'step only' in d.get('case',''): print('deterministic=$det  ', d['case'].ljust(75), d['us'])"; done) > $O/detsharded.txt 2>&1; cat $O/detsharded.txt;;
     detprof)    # kernel times of the deterministic backward (config 2 emit, ragged)
       export HBK_BENCH_ITERS=4
       for det in ${DETS:-0 1}; do

@@ -96,6 +96,8 @@ import sys,json
 for l in sys.stdin:
   d=json.loads(l)
   if 'case' in d and 'bwd' in d['case'] or 'step only' in d.get('case',''): print('deterministic=$det  ', d['case'].ljust(75), d['us'])"; done) > $O/detsharded.txt 2>&1; cat $O/detsharded.txt;;
+    scaleab)    # ragged mean columns: the scaling inside the histogram launch (1) vs in front (0) (vs 2 = on a side stream: a probe build of round 6, removed)
+      (for rep in 1 2; do for w in ${WORK:-R Q r}; do for v in 1 2 0; do HBK_BWD_SCALE_FUSED=$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/scale_fused=$v  /"; done; done; done) > $O/scaleab.txt 2>&1; cut -c1-150 $O/scaleab.txt;;
     detprof)    # kernel times of the deterministic backward (config 2 emit, ragged)
       export HBK_BENCH_ITERS=4
       for det in ${DETS:-0 1}; do

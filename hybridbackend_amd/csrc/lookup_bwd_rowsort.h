@@ -224,6 +224,51 @@ struct RsLds {
   uint16_t det_list[kRsCap / kRsDetLong + 2];
 };
 
+// Deterministic jobs, a chunk with a run above kRsDetRank pairs: one bitonic sort of the chunk's (row,
+// gradient row) words, then the runs the whole workgroup will sum are listed and their positions
+// marked.  Not inlined (rare; its code stays out of the job every bucket takes).
+__device__ __attribute__((noinline)) void rs_det_sort_chunk(RsLds& L, int n_rows) {
+  const int tid = (int)threadIdx.x;
+  const int n_sorted = L.n_sorted;
+  for (int i = n_sorted + tid; i < kRsCap; i += kBlock) {   // behind the pairs: the largest word
+    L.su[i] = kRsNoRow;
+    L.sseg[i] = 0x7fffffff;
+  }
+  __syncthreads();
+  for (int len = 2; len <= kRsCap; len <<= 1) {
+    for (int j = len >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int e = 0; e < kRsCap / 2 / kBlock; ++e) {
+        const int t = e * kBlock + tid;              // compare-exchange number t of this step
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int x = i | j;
+        const uint64_t a = ((uint64_t)L.su[i] << 32) | (uint32_t)L.sseg[i];
+        const uint64_t b = ((uint64_t)L.su[x] << 32) | (uint32_t)L.sseg[x];
+        const bool up = (i & len) == 0;
+        if ((a > b) == up) {
+          L.su[i] = (uint16_t)(b >> 32);
+          L.sseg[i] = (int32_t)(uint32_t)b;
+          L.su[x] = (uint16_t)(a >> 32);
+          L.sseg[x] = (int32_t)(uint32_t)a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // the runs the whole workgroup will sum (below): listed, their positions marked
+  if (tid == 0) L.n_long = 0;
+  __syncthreads();
+  for (int u = tid; u < n_rows; u += kBlock) {
+    if ((int)((L.cnt[u] >> kRsBits) & kRsMask) >= kRsDetLong) {
+      L.det_list[atomicAdd(&L.n_long, 1)] = (uint16_t)u;   // (any order: the runs are summed one by one)
+    }
+  }
+  for (int q = tid; q < n_sorted; q += kBlock) {
+    const uint16_t u = L.su[q];
+    if ((int)((L.cnt[u] >> kRsBits) & kRsMask) >= kRsDetLong) L.su[q] = u | kRsLongBit;
+  }
+}
+
 // Deterministic jobs: the LONG runs of a chunk (rowsort_reduce, below), summed one after the other by
 // the whole workgroup.  A function of its own, not inlined: its registers (WB rows in flight per lane)
 // stay out of the budget of the walk every job takes.  (Its arguments by value, in registers: a
@@ -724,44 +769,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
           if (np_[k] >= 0) L.sseg[np_[k]] = seg_[k];
         }
       } else {
-        const int n_sorted = L.n_sorted;
-        for (int i = n_sorted + tid; i < kRsCap; i += kBlock) {   // behind the pairs: the largest word
-          L.su[i] = kRsNoRow;
-          L.sseg[i] = 0x7fffffff;
-        }
-        __syncthreads();
-        for (int len = 2; len <= kRsCap; len <<= 1) {
-          for (int j = len >> 1; j > 0; j >>= 1) {
-#pragma unroll
-            for (int e = 0; e < kRsCap / 2 / kBlock; ++e) {
-              const int t = e * kBlock + tid;              // compare-exchange number t of this step
-              const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-              const int x = i | j;
-              const uint64_t a = ((uint64_t)L.su[i] << 32) | (uint32_t)L.sseg[i];
-              const uint64_t b = ((uint64_t)L.su[x] << 32) | (uint32_t)L.sseg[x];
-              const bool up = (i & len) == 0;
-              if ((a > b) == up) {
-                L.su[i] = (uint16_t)(b >> 32);
-                L.sseg[i] = (int32_t)(uint32_t)b;
-                L.su[x] = (uint16_t)(a >> 32);
-                L.sseg[x] = (int32_t)(uint32_t)a;
-              }
-            }
-            __syncthreads();
-          }
-        }
-        // the runs the whole workgroup will sum (below): listed, their positions marked
-        if (tid == 0) L.n_long = 0;
-        __syncthreads();
-        for (int u = tid; u < n_rows; u += kBlock) {
-          if ((int)((L.cnt[u] >> kRsBits) & kRsMask) >= kRsDetLong) {
-            L.det_list[atomicAdd(&L.n_long, 1)] = (uint16_t)u;   // (any order: the runs are summed one by one)
-          }
-        }
-        for (int q = tid; q < n_sorted; q += kBlock) {
-          const uint16_t u = L.su[q];
-          if ((int)((L.cnt[u] >> kRsBits) & kRsMask) >= kRsDetLong) L.su[q] = u | kRsLongBit;
-        }
+        rs_det_sort_chunk(L, n_rows);
       }
       __syncthreads();
     }

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get('HBK_LIBRARY') or os.path.join(_HERE, 'lib', 'libhbk_c
 # dtype codes of include/hbk.h
 INT8, UINT8, INT32, UINT32, INT64, UINT64, HALF, FLOAT, DOUBLE = range(9)
 APPLY_SGD, APPLY_ADAGRAD = 0, 2
+GRAD_DETERMINISTIC = 1   # hbk_lookup_grad_column_t.flags
 COMBINER_SUM, COMBINER_MEAN, COMBINER_SQRTN = 0, 1, 2
 OK, INVALID_ARGUMENT, UNIMPLEMENTED, INTERNAL = 0, 3, 12, 13
 COMM_ID_BYTES = 128
@@ -54,7 +55,7 @@ class LookupGradColumn(C.Structure):
               ('unique_rows', C.c_void_p), ('grad_rows', C.c_void_p),
               ('n_unique', C.c_void_p), ('run_start', C.c_void_p), ('run_ids', C.c_void_p),
               ('run_grads', C.c_void_p), ('n_runs', C.c_int32), ('grad_stride', C.c_int32),
-              ('accum', C.c_void_p), ('table_pitch', C.c_int32), ('reserved_', C.c_int32)]
+              ('accum', C.c_void_p), ('table_pitch', C.c_int32), ('flags', C.c_int32)]
 
 
 class ShardedColumn(C.Structure):

@@ -3109,7 +3109,7 @@ struct ColPlan {
 // keeps hashed buckets for every column
 int forced_log2p() { return options().bwd_buckets_log2; }
 
-ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged) {
+ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged, bool det = false) {
   ColPlan p;
   // Aim at 7/8 of a chunk per bucket: bucket sizes are Poisson around the aim, so ~0.1 % of the
   // buckets need a second (short) chunk, while the per-workgroup fixed cost (table init,
@@ -3152,10 +3152,9 @@ ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged) {
     // 704 at 64 x; the config-5 mix +- 1 %); wide rows with skewed ids lose there (config 4 Zipf,
     // dim 128: 343 -> 447 us)
     const int64_t ratio = (int64_t)options().bwd_rowsort_ratio * (dim <= 32 ? 4 : 1);
-    // deterministic mode (bwd_deterministic = 1): row-sorted jobs wherever the row range fits -- the one
+    // deterministic columns (`det`: option bwd_deterministic = 1 or the column's flag): row-sorted jobs wherever the row range fits -- the one
     // reduce kind with an in-order form (lookup_bwd_rowsort.h) -- and no bucket is split over
     // workgroups (partial sums joined by a merge are not the sequential sum)
-    const bool det = options().bwd_deterministic == 1;
     const bool want = det || dense_opt == 3 || (dense_opt == 1 && ratio > 0 && rows <= ratio * n_ids);
     if (kTeam == kBlock && want && rows >= 1 && rows < (1ll << 32)) {
       int64_t rs_target = (int64_t)kRsCap * 7 / 8;
@@ -3224,9 +3223,9 @@ ColPlan plan_of(int64_t n_ids, int32_t dim, int64_t rows, bool ragged) {
 // row-sorted columns keep a pair as ONE word (GCol.packed)
 inline bool pairs_packed(const ColPlan& p) { return p.rowsort && options().bwd_pairs_packed != 0; }
 
-size_t col_workspace(const hbk_lookup_grad_column_t& h) {
+size_t col_workspace(const hbk_lookup_grad_column_t& h, bool det = false) {
   if (h.n_ids <= 0) return 0;
-  const ColPlan p = plan_of(h.n_ids, h.dim, h.rows, h.row_splits != nullptr);
+  const ColPlan p = plan_of(h.n_ids, h.dim, h.rows, h.row_splits != nullptr, det);
   size_t b = align8(((size_t)p.tiles * p.n_buckets) * 4);   // hist
   b += align8(((size_t)p.n_buckets + 1) * 4);          // bstart
   b += (size_t)h.n_ids * 8;                                // pair_row
@@ -3253,14 +3252,33 @@ size_t col_workspace(const hbk_lookup_grad_column_t& h) {
 // deterministic mode, option value 1: the columns whose buckets fit the row-sorted jobs take their
 // in-order form (lookup_bwd_rowsort.h); the others -- tables too large for row-range buckets -- and
 // everything under option value 2 go through the sort of lookup_bwd_det.h
-inline bool det_rowsort(const hbk_lookup_grad_column_t& h) {
-  if (options().bwd_deterministic != 1 || h.n_ids <= 0) return false;
-  return plan_of(h.n_ids, h.dim, h.rows, h.row_splits != nullptr).rowsort;
+// 0: the default forms; 1: in id order, by the row-sorted jobs where they fit; 2: in id order, by sorting
+inline int det_mode(const hbk_lookup_grad_column_t& h) {
+  const int opt = options().bwd_deterministic;
+  if (opt != 0) return opt;
+  return (h.flags & HBK_GRAD_DETERMINISTIC) != 0 ? 1 : 0;
 }
+inline bool det_rowsort(const hbk_lookup_grad_column_t& h) {
+  if (det_mode(h) != 1 || h.n_ids <= 0) return false;
+  return plan_of(h.n_ids, h.dim, h.rows, h.row_splits != nullptr, true).rowsort;
+}
+// the columns of a call by the form they take: `fast` the in-order row-sorted jobs, `slow` the sort,
+// `plain` the default forms (empty columns of a deterministic call ride with the sort, which clears
+// their counts)
 inline void det_split(int32_t n_cols, const hbk_lookup_grad_column_t* cols,
                       std::vector<hbk_lookup_grad_column_t>* fast,
-                      std::vector<hbk_lookup_grad_column_t>* slow) {
-  for (int32_t c = 0; c < n_cols; ++c) (det_rowsort(cols[c]) ? fast : slow)->push_back(cols[c]);
+                      std::vector<hbk_lookup_grad_column_t>* slow,
+                      std::vector<hbk_lookup_grad_column_t>* plain) {
+  for (int32_t c = 0; c < n_cols; ++c) {
+    (det_mode(cols[c]) == 0 ? plain : det_rowsort(cols[c]) ? fast : slow)->push_back(cols[c]);
+  }
+}
+inline bool any_deterministic(int32_t n_cols, const hbk_lookup_grad_column_t* cols) {
+  if (options().bwd_deterministic != 0) return true;
+  for (int32_t c = 0; c < n_cols; ++c) {
+    if ((cols[c].flags & HBK_GRAD_DETERMINISTIC) != 0) return true;
+  }
+  return false;
 }
 
 // ---- host side of the deterministic backward (lookup_bwd_det.h) -----------------------------------
@@ -3450,13 +3468,16 @@ extern "C" int hbk_debug_bwd_trace(unsigned long long* out, int reset) {
 extern "C" size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
                                                        const hbk_lookup_grad_column_t* cols) {
   if (n_cols <= 0 || cols == nullptr) return 0;
-  if (hbk::options().bwd_deterministic != 0) {
-    std::vector<hbk_lookup_grad_column_t> fast, slow;
-    hbk::det_split(n_cols, cols, &fast, &slow);
+  if (hbk::any_deterministic(n_cols, cols)) {
+    std::vector<hbk_lookup_grad_column_t> fast, slow, plain;
+    hbk::det_split(n_cols, cols, &fast, &slow, &plain);
     size_t total = hbk::det_layout((int32_t)slow.size(), slow.data()).total;
     if (total != 0) total += 256;
     size_t planned = 0;
-    for (const hbk_lookup_grad_column_t& h : fast) planned += hbk::col_workspace(h);
+    for (const hbk_lookup_grad_column_t& h : fast) planned += hbk::col_workspace(h, true);
+    total += planned == 0 ? 0 : planned + 256;
+    planned = 0;
+    for (const hbk_lookup_grad_column_t& h : plain) planned += hbk::col_workspace(h);
     return total + (planned == 0 ? 0 : planned + 256);
   }
   size_t total = 0;
@@ -3576,6 +3597,8 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
     HBK_REQUIRE(h.table_pitch == 0 || h.table_pitch >= h.dim,
                 "group_lookup_bwd: column %d: table_pitch %d is smaller than dim %d", c, h.table_pitch,
                 h.dim);
+    HBK_REQUIRE((h.flags & ~HBK_GRAD_DETERMINISTIC) == 0, "group_lookup_bwd: column %d: unknown flags 0x%x", c,
+                (unsigned)h.flags);
     HBK_REQUIRE(h.n_runs >= 0, "group_lookup_bwd: column %d: n_runs must be >= 0", c);
     HBK_REQUIRE(h.n_runs == 0 || (h.row_splits == nullptr && h.run_start && h.run_ids &&
                                   h.run_grads),
@@ -3594,18 +3617,25 @@ extern "C" int hbk_group_lookup_bwd_apply(int32_t n_cols, const hbk_lookup_grad_
   }
   // option bwd_deterministic: the in-order forms -- row-sorted jobs where they fit (1), the sort + walk
   // of lookup_bwd_det.h for the other columns (and for all of them under 2)
-  if (options().bwd_deterministic != 0) {
-    std::vector<hbk_lookup_grad_column_t> fast, slow;
-    det_split(n_cols, cols, &fast, &slow);
-    size_t slow_bytes = det_layout((int32_t)slow.size(), slow.data()).total;
-    if (slow_bytes != 0) slow_bytes += 256;
+  if (any_deterministic(n_cols, cols)) {
+    std::vector<hbk_lookup_grad_column_t> fast, slow, plain;
+    det_split(n_cols, cols, &fast, &slow, &plain);
+    char* at = reinterpret_cast<char*>(workspace);
     if (!slow.empty()) {
-      const int rc = det_backward((int32_t)slow.size(), slow.data(), apply, apply_lr, workspace, stream);
+      const int rc = det_backward((int32_t)slow.size(), slow.data(), apply, apply_lr, at, stream);
       if (rc != HBK_OK) return rc;
+      const size_t slow_bytes = det_layout((int32_t)slow.size(), slow.data()).total;
+      at += slow_bytes == 0 ? 0 : slow_bytes + 256;
     }
-    if (fast.empty()) return HBK_OK;
-    return bwd_planned((int32_t)fast.size(), fast.data(), apply, apply_lr,
-                       reinterpret_cast<char*>(workspace) + slow_bytes, stream, true);
+    if (!fast.empty()) {
+      const int rc = bwd_planned((int32_t)fast.size(), fast.data(), apply, apply_lr, at, stream, true);
+      if (rc != HBK_OK) return rc;
+      size_t planned = 0;
+      for (const hbk_lookup_grad_column_t& h : fast) planned += col_workspace(h, true);
+      at += planned == 0 ? 0 : planned + 256;
+    }
+    if (plain.empty()) return HBK_OK;
+    return bwd_planned((int32_t)plain.size(), plain.data(), apply, apply_lr, at, stream, false);
   }
   return bwd_planned(n_cols, cols, apply, apply_lr, workspace, stream, false);
 }
@@ -3624,7 +3654,7 @@ static int bwd_planned(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int
   char* wp = dp;
   for (int32_t c = 0; c < n_cols; ++c) {
     if (cols[c].n_ids <= 0) continue;
-    const ColPlan p = plan_of(cols[c].n_ids, cols[c].dim, cols[c].rows, cols[c].row_splits != nullptr);
+    const ColPlan p = plan_of(cols[c].n_ids, cols[c].dim, cols[c].rows, cols[c].row_splits != nullptr, det);
     wp += ((size_t)p.n_buckets + p.e_max) * sizeof(int4);
   }
 
@@ -3646,7 +3676,7 @@ static int bwd_planned(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int
       if (h.n_ids <= 0) continue;
       ColInfo& ci = info[(size_t)c];
       if (pass == 0) {
-        ci.p = plan_of(h.n_ids, h.dim, h.rows, h.row_splits != nullptr);
+        ci.p = plan_of(h.n_ids, h.dim, h.rows, h.row_splits != nullptr, det);
         HBK_REQUIRE(h.grad_stride == 0 || (h.grad_stride >= h.dim && h.n_runs == 0),
                     "group_lookup_bwd: column %d: bad grad_stride %d", c, h.grad_stride);
         HBK_REQUIRE(make_rowshape(h.dim,

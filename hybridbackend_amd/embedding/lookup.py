@@ -328,8 +328,14 @@ class GroupLookupGrad:
   hybridbackend/tensorflow/training/gradient.py:193-217).
   """
 
-  def __init__(self, lookup, accums=None, interleaved=None, workspace_of=None):
-    """accums: per column the Adagrad accumulator table (fp32, same shape as the weights,
+  def __init__(self, lookup, accums=None, interleaved=None, workspace_of=None, deterministic=False):
+    """deterministic: every row's gradient terms are summed in id order (``HBK_GRAD_DETERMINISTIC`` on
+    every column): IndexedSlices and stepped tables have the same bits on every run, equal to the
+    sequential fp32 sum -- TF's CPU ``UnsortedSegmentSum`` -- and the rows leave ascending.  What the
+    process-wide option ``bwd_deterministic`` = 1 (``TF_DETERMINISTIC_OPS`` through the TF shim) does
+    for every call, chosen for this object only.
+
+    accums: per column the Adagrad accumulator table (fp32, same shape as the weights,
     filled with ``initial_accumulator_value``), needed for ``optimizer='adagrad'``.
 
     interleaved: per column an fp32 ``[rows, 2 * dim]`` tensor that holds every row's weights AND
@@ -375,6 +381,7 @@ class GroupLookupGrad:
       col.bucket = lookup.buckets[c]
       col.divisor = lookup.divisor
       col.combiner = lookup.combiners[c]
+      col.flags = _lib.GRAD_DETERMINISTIC if deterministic else 0
     self._ws_box = workspace_of._ws_box if workspace_of is not None else [None]
 
   @property

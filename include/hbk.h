@@ -329,8 +329,12 @@ typedef struct {
    * Adagrad step fetches it with one request instead of two.  Only the optimizer step reads it
    * (the forward takes contiguous rows): measured on the config-5 shape in DESIGN.md 4.4. */
   int32_t table_pitch;
-  int32_t reserved_;
+  /* HBK_GRAD_DETERMINISTIC: this column's rows are summed in id order -- what option
+   * bwd_deterministic = 1 does for every column of every call (and the option, when set, still does):
+   * the reproducible mode chosen per call instead of per process.  Other bits: 0. */
+  int32_t flags;
 } hbk_lookup_grad_column_t;
+#define HBK_GRAD_DETERMINISTIC 1
 
 size_t hbk_group_lookup_bwd_workspace_bytes(int32_t n_cols,
                                             const hbk_lookup_grad_column_t* cols);

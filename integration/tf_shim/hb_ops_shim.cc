@@ -889,6 +889,7 @@ REGISTER_OP("HbGroupLookupGrad")
     .Attr("N: int >= 1").Attr("Tids: {int32, int64}")
     .Attr("buckets: list(int)").Attr("combiners: list(int)").Attr("ragged: list(bool)")
     .Attr("divisor: int = 1")
+    .Attr("deterministic: bool = false")   // sums in id order for this op (HBK_GRAD_DETERMINISTIC); TF_DETERMINISTIC_OPS=1 does it for all
     .SetShapeFn(GroupLookupGradShape);
 
 REGISTER_OP("HbGroupLookupGradApply")
@@ -899,6 +900,7 @@ REGISTER_OP("HbGroupLookupGradApply")
     .Attr("N: int >= 1").Attr("M: int >= 0 = 0").Attr("Tids: {int32, int64}")
     .Attr("buckets: list(int)").Attr("combiners: list(int)").Attr("ragged: list(bool)")
     .Attr("divisor: int = 1").Attr("optimizer: {'sgd', 'adagrad'} = 'sgd'")
+    .Attr("deterministic: bool = false")
     .SetIsStateful()
     .SetShapeFn([](InferenceContext* c) {
       int64 n;
@@ -913,10 +915,12 @@ struct GroupLookupAttrs {
   std::vector<int32> combiners;
   std::vector<bool> ragged;
   int32 divisor;
+  bool deterministic = false;
   Status Read(OpKernelConstruction* ctx) {
     TF_RETURN_IF_ERROR(ctx->GetAttr("buckets", &buckets));
     TF_RETURN_IF_ERROR(ctx->GetAttr("combiners", &combiners));
     TF_RETURN_IF_ERROR(ctx->GetAttr("ragged", &ragged));
+    if (!ctx->GetAttr("deterministic", &deterministic).ok()) deterministic = false;   // (ops without the attr)
     return ctx->GetAttr("divisor", &divisor);
   }
   Status Check(int n) const {
@@ -948,6 +952,7 @@ struct GroupLookupAttrs {
     c->divisor = divisor;
     c->combiner = combiners[i];
     c->grad_out = grad.flat<float>().data();
+    c->flags = deterministic ? HBK_GRAD_DETERMINISTIC : 0;
     return Status::OK();
   }
 };

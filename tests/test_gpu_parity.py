@@ -1152,6 +1152,44 @@ def test_group_lookup_backward_deterministic_rowsorted_jobs_of_several_chunks(hb
       np.testing.assert_equal(x, y)
 
 
+def test_group_lookup_backward_deterministic_per_call_flag():
+  """HBK_GRAD_DETERMINISTIC on a column (GroupLookupGrad(deterministic=True)) without the process-wide
+  option: that object's sums are the in-order fp32 sums, rows ascending; a call that MIXES flagged and
+  plain columns (set through the descriptors) gives the flagged ones exactly, the plain ones within
+  the tolerance of an unordered fp32 sum; the option stays 0 throughout."""
+  assert _lib.get_option('bwd_deterministic') == 0
+  rng = np.random.RandomState(613)
+  shapes = [(16, 3000, 40000), (8, 150000, 60000), (128, 700, 9000), (4, 97, 5000)]
+  tables, ids, grads = [], [], []
+  for d, rows, n in shapes:
+    tables.append(rng.uniform(-1, 1, size=(rows, d)).astype(np.float32))
+    ids.append((rng.zipf(1.3, size=n) % rows).astype(np.int64))
+    grads.append(rng.randn(n, d).astype(np.float32))
+  lookup = hb.embedding.GroupLookup([dev(t) for t in tables], None, 'sum')
+  want = [_in_order_slices(ids[c], grads[c], None, 'sum', tables[c].shape[0]) for c in range(len(shapes))]
+  # every column flagged
+  grad = hb.embedding.GroupLookupGrad(lookup, deterministic=True)
+  for rep in range(2):
+    res = grad([dev(i) for i in ids], [dev(g) for g in grads])
+    for c, (urows, grows, nu) in enumerate(res):
+      k = int(nu.item())
+      np.testing.assert_equal(host(urows)[:k], want[c][0])
+      np.testing.assert_equal(host(grows)[:k], want[c][1])
+  # columns 0 and 2 flagged, 1 and 3 plain
+  mixed = hb.embedding.GroupLookupGrad(lookup)
+  for c in (0, 2):
+    mixed._cols[c].flags = _lib.GRAD_DETERMINISTIC
+  res = mixed([dev(i) for i in ids], [dev(g) for g in grads])
+  for c, (urows, grows, nu) in enumerate(res):
+    k = int(nu.item())
+    if c in (0, 2):
+      np.testing.assert_equal(host(urows)[:k], want[c][0])
+      np.testing.assert_equal(host(grows)[:k], want[c][1])
+    else:
+      _check_slices((urows, grows, nu), ids[c], grads[c], None, 'sum')
+  assert _lib.get_option('bwd_deterministic') == 0
+
+
 def test_group_lookup_backward_deterministic_sparse_batch_over_a_large_table(hbk_option):
   """bwd_deterministic = 1 where the row-sorted buckets are nearly all empty: 3000 ids (a tenth of them
   repeated) over 30 M rows are 1832 buckets of <= 16383 rows -- the three-launch grouping, a count

@@ -387,7 +387,7 @@ __device__ __attribute__((noinline)) void rs_long_runs(RsLds& L, const RsLongArg
   }
 }
 
-template <typename V, int STEP, bool DET = false>
+template <typename V, int STEP, bool DET = false, int OC = -1>
 __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds& L, int bucket) {
   constexpr int VE = sizeof(V) / 4;
   constexpr int PT = kRsPT;
@@ -410,7 +410,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   if (n_pairs <= 0) return;
   const int64_t* prow = job.prow;
   const int32_t* pseg = job.pseg;
-  const bool one_chunk = n_pairs <= kRsCap;
+  const bool one_chunk = OC < 0 ? n_pairs <= kRsCap : OC != 0;   // (OC >= 0: the caller has looked)
   const float lr = STEP ? job.lr : 0.0f;
   const bool stepping = STEP && lr != 0.0f;
   const bool emit = !(STEP && job.no_emit);    // (no_emit only for jobs of one chunk: decode_job)
@@ -1108,7 +1108,18 @@ __global__ __launch_bounds__(kBlock, STEP == 2 ? HBK_RS_LB2 : 4) void bwd_rowsor
   int ci;
   if (!decode_job<V, 2>(a, my_b0, vb, d, a.lr, &ci, &job)) return;
   HBK_STAMP(1);
-  rowsort_reduce<V, STEP, DET>(a.col[ci], job, lds, d.z);
+  // Two copies of the job (round 6): buckets of ONE chunk -- nearly all -- run a copy in which everything
+  // that serves jobs of several chunks (per-chunk bitmaps, rows seen earlier, read-modify-write
+  // emission, the deferred optimizer step) is compiled out; the others run the general copy.  Same
+  // source, `one_chunk` a constant in each: ragged 495 -> 478 us, config 2 emit / + SGD / step only
+  // 86.5 / 154 / 128.5 -> 83.9 / 151.5 / 126.5, the deterministic forms 106 / 175 / 149 / 557 -> 99 /
+  // 164 / 141.5 / 526 (probe build alternating with the one-copy build in one visit,
+  // profiles/r06_split_one_chunk.txt).
+  if (job.n_pairs <= kRsCap) {
+    rowsort_reduce<V, STEP, DET, 1>(a.col[ci], job, lds, d.z);
+  } else {
+    rowsort_reduce<V, STEP, DET, 0>(a.col[ci], job, lds, d.z);
+  }
   HBK_STAMP(7);
 }
 

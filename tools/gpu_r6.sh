@@ -84,6 +84,11 @@ PY
        done) > $O/detab.txt 2>&1; cut -c1-150 $O/detab.txt;;
     detquick)   # the deterministic mode next to the default: config 2, ragged, the duplicate-heavy cases (C ABI), twice
       (for rep in 1 2; do for w in ${WORK:-b s R d}; do for det in 0 1; do HBK_BWD_DETERMINISTIC=$det timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/deterministic=$det  /"; done; done; done) > $O/detquick.txt 2>&1; cut -c1-150 $O/detquick.txt;;
+    defvar)     # the DEFAULT backward of the current build next to probe builds (tools/bin/variants/<name>/), alternating in one visit
+      (for rep in 1 2 3; do for w in ${WORK:-b s R}; do
+         timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/current   /"
+         for v in ${VARIANTS:-splitoc}; do LD_LIBRARY_PATH=$R/tools/bin/variants/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/$(printf %-10s $v)/"; done
+       done; done) > $O/defvar.txt 2>&1; cut -c1-140 $O/defvar.txt;;
     detvar)     # the deterministic mode of the current build next to probe builds of the library (tools/bin/variants/<name>/), alternating in one visit
       (for rep in 1 2 3; do for w in ${WORK:-b s R}; do
          HBK_BWD_DETERMINISTIC=1 timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/current   /"

@@ -49,10 +49,10 @@ static_assert(kRsSpan <= 65536, "16-bit row offsets");
 
 // A gradient row chunk.  Ragged columns with mean / sqrtn hand their rows over already scaled (the
 // seg-of launch divides every segment's row once, lookup_bwd.hip): no combiner arithmetic here.
-template <typename V>
+template <typename V, bool F16 = false>
 __device__ inline V rs_load_grad(const ReduceJob& job, int32_t seg, int sub, bool live) {
   constexpr int VE = sizeof(V) / 4;
-  const uint64_t off = job.seg_is_offset ? (uint64_t)(uint32_t)seg
+  const uint64_t off = !F16 && job.seg_is_offset ? (uint64_t)(uint32_t)seg
                                          : (uint64_t)(uint32_t)seg * (uint32_t)job.stride;
   V g = zero_v<V>();
   if (live) g = HBK_GRAD_LOAD(reinterpret_cast<const V*>(job.grad + off + (uint64_t)sub * VE));
@@ -65,10 +65,10 @@ __device__ inline V rs_load_grad(const ReduceJob& job, int32_t seg, int sub, boo
 #ifndef HBK_RS_OUT_NT
 #define HBK_RS_OUT_NT 1
 #endif
-template <typename V>
+template <typename V, bool F16 = false>
 __device__ inline void rs_store_row(const GCol& c, const ReduceJob& job, int32_t u, int sub, V v) {
   constexpr int VE = sizeof(V) / 4;
-  V* o = reinterpret_cast<V*>(job.out_vals + (int64_t)u * c.dim + (int64_t)sub * VE);
+  V* o = reinterpret_cast<V*>(job.out_vals + (int64_t)u * (F16 ? 16 : c.dim) + (int64_t)sub * VE);
 #if defined(HBK_RS_OUT_ASM)   // probe builds: the cache policy bits of the row store, spelled out
   if constexpr (sizeof(V) == 16) {
     asm volatile("global_store_dwordx4 %0, %1, off " HBK_RS_OUT_ASM : : "v"(o), "v"(v) : "memory");
@@ -152,7 +152,7 @@ constexpr int kDppRowShr4 = 0x114;   // lane i reads lane i - 4
 // the finished rows of one batch of a lane group (bit w of `mine`: position w ends a run of mine, its
 // sum is in g[w], its rank among the job's rows uu[w]); half0: parity of the job's first output row
 // in its 128-byte line.  Every lane of the wave calls it.
-template <int W>
+template <int W, bool F16 = false>
 __device__ inline void rs_store_pairs(const GCol& c, const ReduceJob& job, int32_t base_u, int half0,
                                       const uint32_t (&uu)[W], const f32x4 (&g)[W], uint32_t mine,
                                       int lane, int sub) {
@@ -190,19 +190,19 @@ __device__ inline void rs_store_pairs(const GCol& c, const ReduceJob& job, int32
         const f32x4 second = rs_dpp_v<kDppRowShr4>(nxt);          // group 0's next row in group 1's lanes
         const int32_t r_even = rs_dpp_i<kDppRowShr4>(R);
         if (p_from_even != 0) {
-          rs_store_row<f32x4>(c, job, odd_group ? r_even + 1 : R, sub, odd_group ? second : g[w]);
+          rs_store_row<f32x4, F16>(c, job, odd_group ? r_even + 1 : R, sub, odd_group ? second : g[w]);
         }
       }
       if (__builtin_amdgcn_ballot_w64(p_from_odd != 0) != 0ull) {
         const f32x4 second = rs_dpp_v<kDppRowShl4>(nxt);          // group 1's next row in group 0's lanes
         const int32_t r_odd = rs_dpp_i<kDppRowShl4>(R);
         if (p_from_odd != 0) {
-          rs_store_row<f32x4>(c, job, odd_group ? R : r_odd + 1, sub, odd_group ? g[w] : second);
+          rs_store_row<f32x4, F16>(c, job, odd_group ? R : r_odd + 1, sub, odd_group ? g[w] : second);
         }
       }
       if (pair) done |= (1u << w) | (1u << (w + d));
     }
-    if (((mine & ~done) >> w) & 1u) rs_store_row<f32x4>(c, job, R, sub, g[w]);
+    if (((mine & ~done) >> w) & 1u) rs_store_row<f32x4, F16>(c, job, R, sub, g[w]);
   }
 }
 
@@ -387,7 +387,7 @@ __device__ __attribute__((noinline)) void rs_long_runs(RsLds& L, const RsLongArg
   }
 }
 
-template <typename V, int STEP, bool DET = false, int OC = -1>
+template <typename V, int STEP, bool DET = false, int OC = -1, bool F16 = false>
 __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds& L, int bucket) {
   constexpr int VE = sizeof(V) / 4;
   constexpr int PT = kRsPT;
@@ -397,14 +397,15 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   constexpr int W = STEP == 2 ? HBK_RS_W2 : STEP == 1 ? HBK_RS_W1 : HBK_RS_W0;
   const int tid = (int)threadIdx.x;
   const int lane = tid & (kWave - 1), wave = tid >> 6;
-  const int lpr_log2 = c.lpr_log2;
+  // (F16: the caller has looked -- rows of 16 floats in four 16-byte chunks, packed pairs, gradient rows by number)
+  const int lpr_log2 = F16 ? 2 : c.lpr_log2;
   const int sub = lane & ((1 << lpr_log2) - 1);
-  const bool live = sub < c.chunks;
+  const bool live = F16 ? true : sub < c.chunks;
   const int groups = kBlock >> lpr_log2;
   const int my_group = tid >> lpr_log2;
   // rows of 64 bytes (dim 16, four 16-byte chunks) leave as whole 128-byte lines where they can
-  const bool pair_rows = HBK_RS_PAIR_STORES != 0 && sizeof(V) == 16 && lpr_log2 == 2 && c.chunks == 4 &&
-                         c.dim == 16 && ((uintptr_t)job.out_vals & 63u) == 0u;
+  const bool pair_rows = HBK_RS_PAIR_STORES != 0 && sizeof(V) == 16 && (F16 || (lpr_log2 == 2 && c.chunks == 4 &&
+                         c.dim == 16)) && ((uintptr_t)job.out_vals & 63u) == 0u;
   const int half0 = (int)(((uintptr_t)job.out_vals >> 6) & 1u);
   const int32_t n_pairs = job.n_pairs;
   if (n_pairs <= 0) return;
@@ -421,7 +422,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
   if (lim > c.map.rows) lim = c.map.rows;
   const int words = (int)((lim - base + 31) >> 5);   // <= kRsWords (host: plan_of)
 
-  const bool packed = job.packed;   // uniform: one word per pair, row << 32 | gradient row
+  const bool packed = F16 ? true : job.packed;   // uniform: one word per pair, row << 32 | gradient row
   const bool pairs_nt = c.splits != nullptr && (packed || pseg != nullptr);   // ragged column, not a merge job
   uint32_t off_[PT];   // row - base of my pairs of the chunk, ~0u: none
   int32_t seg_[PT];
@@ -829,7 +830,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
 #pragma unroll
           for (int w = 0; w < WD; ++w) {
             const int q = p + w < start + n ? p + w : start + n - 1;
-            g[w] = rs_load_grad<V>(job, L.sseg[q], sub, live);
+            g[w] = rs_load_grad<V, F16>(job, L.sseg[q], sub, live);
           }
 #pragma unroll
           for (int w = 0; w < WD; ++w) {
@@ -891,7 +892,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
         // trip per batch: config-5 shape + Adagrad, W = 4: two round trips per four positions.)
         V tv[STEP ? W : 1], av[STEP == 2 ? W : 1];
 #pragma unroll
-        for (int w = 0; w < W; ++w) g[w] = rs_load_grad<V>(job, sg[w], sub, live);
+        for (int w = 0; w < W; ++w) g[w] = rs_load_grad<V, F16>(job, sg[w], sub, live);
         if (STEP && one_chunk && stepping) {
 #pragma unroll
           for (int w = 0; w < W; ++w) {
@@ -925,7 +926,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
         if constexpr (HBK_RS_PAIR_STORES && sizeof(V) == 16 && STEP == 0) {
           // (the paired stores are cooperative: a lane group with nothing to emit lends its lanes)
           if (pair_rows && one_chunk && !stepping) {
-            rs_store_pairs<W>(c, job, base_u, half0, uu, g, mine, lane, sub);
+            rs_store_pairs<W, F16>(c, job, base_u, half0, uu, g, mine, lane, sub);
             continue;
           }
         }
@@ -934,7 +935,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
 #pragma unroll
           for (int w = 0; w < W; ++w) {
             if (mine >> w & 1u) {
-              if (emit) rs_store_row<V>(c, job, base_u + (int32_t)uu[w], sub, g[w]);
+              if (emit) rs_store_row<V, F16>(c, job, base_u + (int32_t)uu[w], sub, g[w]);
               const int64_t toff = (int64_t)(base + L.roff[uu[w]]) * c.tpitch + (int64_t)sub * VE;
               step_row<V>(c, adagrad, lr, toff, g[w], tv[STEP ? w : 0],
                           STEP == 2 ? av[STEP == 2 ? w : 0] : zero_v<V>());
@@ -943,7 +944,7 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
         } else if (one_chunk) {
 #pragma unroll
           for (int w = 0; w < W; ++w) {
-            if (mine >> w & 1u) rs_store_row<V>(c, job, base_u + (int32_t)uu[w], sub, g[w]);
+            if (mine >> w & 1u) rs_store_row<V, F16>(c, job, base_u + (int32_t)uu[w], sub, g[w]);
           }
         } else {
 #pragma unroll
@@ -972,14 +973,14 @@ __device__ inline void rowsort_reduce(const GCol& c, const ReduceJob& job, RsLds
           acc = acc + *reinterpret_cast<const V*>(&L.red[(((size_t)gp << lpr_log2) + sub) * VE]);
         }
         if (one_chunk && stepping) {
-          if (emit) rs_store_row<V>(c, job, base_u + (int32_t)u, sub, acc);
+          if (emit) rs_store_row<V, F16>(c, job, base_u + (int32_t)u, sub, acc);
           const int64_t toff = (int64_t)(base + L.roff[u]) * c.tpitch + (int64_t)sub * VE;
           const V tv = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.table + toff));
           V av = zero_v<V>();
           if (adagrad) av = HBK_STEP_LOAD(reinterpret_cast<const V*>(c.accum + toff));
           step_row<V>(c, adagrad, lr, toff, acc, tv, av);
         } else if (one_chunk) {
-          rs_store_row<V>(c, job, base_u + (int32_t)u, sub, acc);
+          rs_store_row<V, F16>(c, job, base_u + (int32_t)u, sub, acc);
         } else {
           emit_row<V>(c, job, out_index(u), is_first(u), sub, acc);
         }
@@ -1116,7 +1117,16 @@ __global__ __launch_bounds__(kBlock, STEP == 2 ? HBK_RS_LB2 : 4) void bwd_rowsor
   // 164 / 141.5 / 526 (probe build alternating with the one-copy build in one visit,
   // profiles/r06_split_one_chunk.txt).
   if (job.n_pairs <= kRsCap) {
-    rowsort_reduce<V, STEP, DET, 1>(a.col[ci], job, lds, d.z);
+    // ... and of those, without an optimizer step, a third copy for rows of 16 floats (four 16-byte chunks, packed
+    // pairs, gradient rows by number: config 2, the ragged benchmark columns) with lanes per row, row size and pair
+    // layout as constants: config 2 emit 84.2 -> 80.6 us, ragged 479 - 509 -> 464 - 502, deterministic emit 99.8 ->
+    // 96.5 (with the step: +- 1 %, not instantiated; profiles/r06_split_one_chunk.txt)
+    if (STEP == 0 && sizeof(V) == 16 && a.col[ci].lpr_log2 == 2 && a.col[ci].chunks == 4 && a.col[ci].dim == 16 &&
+        job.packed && !job.seg_is_offset) {
+      rowsort_reduce<V, STEP, DET, 1, STEP == 0 && sizeof(V) == 16>(a.col[ci], job, lds, d.z);
+    } else {
+      rowsort_reduce<V, STEP, DET, 1>(a.col[ci], job, lds, d.z);
+    }
   } else {
     rowsort_reduce<V, STEP, DET, 0>(a.col[ci], job, lds, d.z);
   }

@@ -154,6 +154,7 @@ struct Options {
                                // to run and equal to the in-order fp32 sum, rows ascending.  1 = the row-sorted jobs' in-order form
                                // (lookup_bwd_rowsort.h: DET) for the columns whose row range fits them, the sort for the others;
                                // 2 = a stable sort of the batch's (row, gradient row) pairs + sequential walk for every column (lookup_bwd_det.h)
+  int bwd_simple = 1;          // HBK_BWD_SIMPLE: launch groups whose columns are all plain (no segmented inputs, packed pairs, int64 ids, row-range buckets) take the grouping kernels' instantiation with those questions compiled out (0: the general one; A/B)
   int bwd_streams = 4;         // HBK_BWD_STREAMS: launch groups of a backward of > 64 (or mixed) columns rotate over this many library streams (0: all on the caller's stream)
   int bwd_lds_pad = 0;         // HBK_BWD_LDS_PAD: a probe: KB of unused LDS added to the grouping launches (fewer resident tiles)
   int bwd_trace = 0;           // HBK_BWD_TRACE: the composition of every launch group of a backward call on stderr

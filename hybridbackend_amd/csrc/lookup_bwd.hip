@@ -506,6 +506,7 @@ __global__ __launch_bounds__(kBlock) void bwd_segof_kernel(const GArgs a) {
 }
 
 // ---- 1: per-tile bucket histogram ---------------------------------------------------------
+template <bool SIMPLE>   // (see bwd_group_kernel)
 __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
   extern __shared__ int32_t counters[];
   HBK_FIND_COL(a, tile0)
@@ -521,8 +522,8 @@ __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
       const int64_t j = base + (int64_t)(k0 + k) * kBlock + tid;
       id[k] = 0;
       if (j < c.n_ids) {
-        if (c.n_runs > 0) run_seek(c, j, rc);
-        id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
+        if (!SIMPLE && c.n_runs > 0) run_seek(c, j, rc);
+        id[k] = load_id(c.ids, SIMPLE ? 1 : c.ids64, SIMPLE ? j : j + rc.id_delta);
       }
     }
   };
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(kBlock) void bwd_hist_kernel(const GArgs a) {
       const int64_t j = base + (int64_t)(k0 + k) * kBlock + tid;
       if (j < c.n_ids) {
         const uint64_t r = id_to_row(c.map, id[k]);
-        if (r != kNoRow) atomicAdd(&counters[bucket_of(c, r)], 1);
+        if (r != kNoRow) atomicAdd(&counters[SIMPLE ? (int)__umulhi((uint32_t)r, c.dense_mul) : bucket_of(c, r)], 1);
       }
     }
   }
@@ -779,6 +780,7 @@ constexpr int kStageMaxBuckets = 1024;
 // the kernel needs 56 VGPRs) became 16 + 4 + 8 P / 1024 KB: ~22.5 KB at 300 buckets = 7 per CU.
 // The kernel is bound by the life of a tile (loads -> LDS tickets -> barrier -> stage -> barrier ->
 // stores), not by bytes: more resident tiles are throughput.
+template <bool SIMPLE>   // (see bwd_group_kernel)
 __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GArgs a) {
   extern __shared__ int32_t stage_dyn[];
   int32_t* const counters = stage_dyn;             // [stage_p] pairs of the tile per bucket; then: global
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
   // area, which is only filled after the segments have been found
   __shared__ int32_t seg_ends[2 + kWavesPerBlock];
   int32_t* const sp_lds = reinterpret_cast<int32_t*>(st_row);
-  const bool seg_inline = c.splits != nullptr && c.seg_of == nullptr;   // block-uniform
+  const bool seg_inline = c.splits != nullptr && (SIMPLE || c.seg_of == nullptr);   // block-uniform
   // everything the tile needs from memory is requested up front -- the ids and where the tile's share
   // of every bucket starts in the pair arrays -- so the segment search below runs under those loads
   // instead of in front of them.  (Tried: the histogram launch leaves every tile's first / last
@@ -821,12 +823,12 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
     id[k] = 0;
     seg[k] = (int32_t)j;
     if (j < c.n_ids) {
-      if (c.n_runs > 0) {
+      if (!SIMPLE && c.n_runs > 0) {
         run_seek(c, j, rc);
         if (!c.det) seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);   // (deterministic: the position, see rowsort_reduce)
       }
-      id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
-      if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
+      id[k] = load_id(c.ids, SIMPLE ? 1 : c.ids64, SIMPLE ? j : j + rc.id_delta);
+      if (!SIMPLE && c.seg_of != nullptr) seg[k] = c.seg_of[j];
     }
   }
   const int per = (P + kBlock - 1) / kBlock;   // <= 4
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
       const uint64_t r = id_to_row(c.map, id[k]);
       id[k] = (int64_t)r;
       if (r != kNoRow) {
-        const int b = bucket_of(c, r);
+        const int b = SIMPLE ? (int)__umulhi((uint32_t)r, c.dense_mul) : bucket_of(c, r);
         br[k] = b | (atomicAdd(&counters[b], 1) << 10);
       }
     }
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
     if (br[k] >= 0) {
       const int b = br[k] & 1023;
       const int L = first[b] + (br[k] >> 10);
-      if (c.packed) {   // (block-uniform) one word per pair: row << 32 | gradient row
+      if (SIMPLE || c.packed) {   // (block-uniform) one word per pair: row << 32 | gradient row
         st_row[L] = (int64_t)(((uint64_t)id[k] << 32) | (uint64_t)(uint32_t)seg[k]);
       } else {
         st_row[L] = id[k];
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
     if (L < n_st) {
       const int32_t pos = counters[st_b[L]] + L;
       c.pair_row[0][pos] = st_row[L];
-      if (!c.packed) c.pair_seg[0][pos] = st_seg[L];
+      if (!SIMPLE && !c.packed) c.pair_seg[0][pos] = st_seg[L];
     }
   }
 }
@@ -951,6 +953,10 @@ struct GSync {
 // (5 waves per SIMD: all 832 workgroups of a 26 x 65536 call resident at once; at 145 VGPRs the
 // last 64 started 21 us late and the kernel took as long as the three launches it replaces;
 // with the staged scatter's 28 KB of LDS four workgroups fit a CU: 1024 slots)
+// SIMPLE (the host has looked at every column of the launch group): no segmented inputs, no seg-of
+// arrays, packed pairs, int64 ids, row-range buckets -- config 2, the benchmark's ragged columns:
+// those questions are constants in this instantiation.
+template <bool SIMPLE>
 __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, const GSync y) {
   __shared__ int32_t counters[kGroupMaxBuckets];   // pairs of the tile per bucket
   __shared__ int32_t tot_s[kGroupMaxBuckets], pre_s[kGroupMaxBuckets];   // bucket totals / before
@@ -976,7 +982,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
   // only filled after the wait)
   __shared__ int32_t seg_ends[2 + kWavesPerBlock];
   int32_t* const sp_lds = reinterpret_cast<int32_t*>(st_row);
-  const bool seg_inline = c.splits != nullptr && c.seg_of == nullptr;   // block-uniform
+  const bool seg_inline = c.splits != nullptr && (SIMPLE || c.seg_of == nullptr);   // block-uniform
   // (the ids are requested before the segment search: they travel under it)
   RunCursor rc;
   int64_t id[kPerThread];
@@ -987,12 +993,12 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
     id[k] = 0;
     seg[k] = (int32_t)j;
     if (j < c.n_ids) {
-      if (c.n_runs > 0) {
+      if (!SIMPLE && c.n_runs > 0) {
         run_seek(c, j, rc);
         if (!c.det) seg[k] = (int32_t)(uint32_t)(rc.grad_delta + j * c.dim);   // (deterministic: the position, see rowsort_reduce)
       }
-      id[k] = load_id(c.ids, c.ids64, j + rc.id_delta);
-      if (c.seg_of != nullptr) seg[k] = c.seg_of[j];
+      id[k] = load_id(c.ids, SIMPLE ? 1 : c.ids64, SIMPLE ? j : j + rc.id_delta);
+      if (!SIMPLE && c.seg_of != nullptr) seg[k] = c.seg_of[j];
     }
   }
   if (seg_inline) {
@@ -1017,7 +1023,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
       const uint64_t r = id_to_row(c.map, id[k]);
       id[k] = (int64_t)r;
       if (r != kNoRow) {
-        const int b = bucket_of(c, r);
+        const int b = SIMPLE ? (int)__umulhi((uint32_t)r, c.dense_mul) : bucket_of(c, r);
         br[k] = b | (atomicAdd(&counters[b], 1) << 10);
       }
     }
@@ -1151,7 +1157,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
     if (br[k] >= 0) {
       const int b = br[k] & 1023;
       const int L = pre_s[b] + (br[k] >> 10);
-      if (c.packed) {   // (block-uniform) one word per pair: row << 32 | gradient row
+      if (SIMPLE || c.packed) {   // (block-uniform) one word per pair: row << 32 | gradient row
         st_row[L] = (int64_t)(((uint64_t)id[k] << 32) | (uint64_t)(uint32_t)seg[k]);
       } else {
         st_row[L] = id[k];
@@ -1168,7 +1174,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_group_kernel(const GArgs a, con
     if (L < n_st) {
       const int32_t pos = tot_s[st_b[L]] + L;
       c.pair_row[0][pos] = st_row[L];
-      if (!c.packed) c.pair_seg[0][pos] = st_seg[L];
+      if (!SIMPLE && !c.packed) c.pair_seg[0][pos] = st_seg[L];
     }
   }
   HBK_GSTAMP(6);            // stores issued
@@ -4016,13 +4022,21 @@ static int bwd_planned(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int
       hipLaunchKernelGGL(bwd_segof_kernel, dim3((unsigned)segtiles), dim3(kBlock), 0, ls,
                          seg_args);
     }
+    // every column of the group: no segmented inputs, no seg-of array, packed pairs, int64 ids, row-range buckets
+    bool simple_group = options().bwd_simple != 0;
+    for (int32_t i = 0; i < k; ++i) {
+      const GCol& g = args.col[i];
+      simple_group = simple_group && g.n_runs == 0 && g.seg_of == nullptr && g.packed != 0 && g.ids64 != 0 &&
+                     g.dense_mul != 0;
+    }
     GSync sync;
     memset(&sync, 0, sizeof(sync));
     bool onepass = group_onepass && sync_words < (1ll << 30);
     if (onepass) {
       SyncTake take;
       onepass = sync_take(ls, (size_t)sync_words, &take,
-                          reinterpret_cast<const void*>(&bwd_group_kernel), kBlock, 64, stream);
+                          reinterpret_cast<const void*>(simple_group ? &bwd_group_kernel<true> : &bwd_group_kernel<false>),
+                          kBlock, 64, stream);
       if (onepass) {
         sync.hist = take.words;
         sync.zero = take.zero;
@@ -4035,12 +4049,20 @@ static int bwd_planned(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int
       SyncChain chain(ls);   // never beside another kernel whose tiles wait for later tiles
       bool unpacked = false;
       for (int32_t i = 0; i < k; ++i) unpacked = unpacked || args.col[i].packed == 0;
-      hipLaunchKernelGGL(bwd_group_kernel, dim3((unsigned)tiles), dim3(kBlock),
-                         (unpacked ? (size_t)kTile * 4 : 0) + (size_t)options().bwd_lds_pad * 1024, ls,
-                         args, sync);
+      if (simple_group) {
+        hipLaunchKernelGGL(bwd_group_kernel<true>, dim3((unsigned)tiles), dim3(kBlock),
+                           (size_t)options().bwd_lds_pad * 1024, ls, args, sync);
+      } else {
+        hipLaunchKernelGGL(bwd_group_kernel<false>, dim3((unsigned)tiles), dim3(kBlock),
+                           (unpacked ? (size_t)kTile * 4 : 0) + (size_t)options().bwd_lds_pad * 1024, ls,
+                           args, sync);
+      }
     } else {
-      hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist, ls,
-                         args);
+      if (simple_group) {
+        hipLaunchKernelGGL(bwd_hist_kernel<true>, dim3((unsigned)tiles), dim3(kBlock), lds_hist, ls, args);
+      } else {
+        hipLaunchKernelGGL(bwd_hist_kernel<false>, dim3((unsigned)tiles), dim3(kBlock), lds_hist, ls, args);
+      }
       if (small_scan) {
         hipLaunchKernelGGL(bwd_scan_fused_kernel, dim3((unsigned)k), dim3(kBlock), 0, ls, args);
       } else {
@@ -4052,9 +4074,14 @@ static int bwd_planned(int32_t n_cols, const hbk_lookup_grad_column_t* cols, int
         bool unpacked = false;
         for (int32_t i = 0; i < k; ++i) unpacked = unpacked || args.col[i].packed == 0;
         args.stage_p = (int32_t)(lds_hist / 4);
-        hipLaunchKernelGGL(bwd_scatter_staged_kernel, dim3((unsigned)tiles), dim3(kBlock),
-                           2 * lds_hist + (unpacked ? (size_t)kTile * 4 : 0) +
-                               (size_t)options().bwd_lds_pad * 1024, ls, args);
+        if (simple_group) {
+          hipLaunchKernelGGL(bwd_scatter_staged_kernel<true>, dim3((unsigned)tiles), dim3(kBlock),
+                             2 * lds_hist + (size_t)options().bwd_lds_pad * 1024, ls, args);
+        } else {
+          hipLaunchKernelGGL(bwd_scatter_staged_kernel<false>, dim3((unsigned)tiles), dim3(kBlock),
+                             2 * lds_hist + (unpacked ? (size_t)kTile * 4 : 0) +
+                                 (size_t)options().bwd_lds_pad * 1024, ls, args);
+        }
       } else {
         hipLaunchKernelGGL(bwd_scatter_pairs_kernel, dim3((unsigned)tiles), dim3(kBlock), lds_hist,
                            ls, args);

@@ -89,6 +89,10 @@ PY
          timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/current   /"
          for v in ${VARIANTS:-splitoc}; do LD_LIBRARY_PATH=$R/tools/bin/variants/$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/$(printf %-10s $v)/"; done
        done; done) > $O/defvar.txt 2>&1; cut -c1-140 $O/defvar.txt;;
+    optab)      # a library option A/B-ed per process, alternating: OPT=HBK_BWD_SIMPLE VALS="1 0" WORK="b s R"
+      (for rep in 1 2 3; do for w in ${WORK:-b s R}; do for v in ${VALS:-1 0}; do
+         env ${OPT:-HBK_BWD_SIMPLE}=$v timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/${OPT:-HBK_BWD_SIMPLE}=$v  /"
+       done; done; done) > $O/optab.txt 2>&1; cut -c1-150 $O/optab.txt;;
     detvar)     # the deterministic mode of the current build next to probe builds of the library (tools/bin/variants/<name>/), alternating in one visit
       (for rep in 1 2 3; do for w in ${WORK:-b s R}; do
          HBK_BWD_DETERMINISTIC=1 timeout 300 tools/bin/bench_ops $w 2>&1 | grep group_lookup_bwd | sed "s/^/current   /"

@@ -160,6 +160,7 @@ struct Options {
   int bwd_trace = 0;           // HBK_BWD_TRACE: the composition of every launch group of a backward call on stderr
   int bwd_large_first = 0;     // HBK_BWD_LARGE_FIRST: the launch groups of the large columns (histogram / scan / scatter chain) are enqueued before the one-launch groups
   int bwd_rowsort_ratio = 8;   // HBK_BWD_ROWSORT_RATIO: row-sorted buckets for columns of rows <= ratio x ids (four times that for dim <= 32; 0: never)
+  int fwd_d16 = 1;             // HBK_FWD_D16: one-id-per-segment columns of 16 floats with int64 ids take the gather's instantiation with those as constants (0: the general one; A/B)
   int fwd_interleave = 2;      // HBK_FWD_INTERLEAVE: lookup tiles of one dense output block ordered row tile first (lookup_fwd.hip)
   int fwd_hot_rows = 0;        // HBK_FWD_HOT: forward of wide one-id-per-sample columns: 1 = 256-segment tiles with
                                // repeated rows staged in LDS, 2 = the large tiles alone (probe), 0 = per-wave gather

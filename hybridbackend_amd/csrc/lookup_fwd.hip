@@ -112,11 +112,11 @@ static_assert(sizeof(LookupArgs) <= 24576, "kernarg budget");
 
 // ---------------------------------------------------------------------------------
 // one id per segment (Criteo scalar columns): out[s,:] = table[row(ids[s]),:]
-template <typename V, int U, bool RUNS, int HALF, bool SLOT = false>
+template <typename V, int U, bool RUNS, int HALF, bool SLOT = false, bool D16 = false>
 __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
   constexpr int VE = sizeof(V) / 4;
   const int lane = lane_id();
-  const int lpr_log2 = c.lpr_log2;
+  const int lpr_log2 = D16 ? 2 : c.lpr_log2;   // (D16: the host has looked -- rows of 16 floats, int64 ids)
   const int rpi = kWave >> lpr_log2;  // rows per wave instruction
   const int sub = lane & ((1 << lpr_log2) - 1);
   const int grp = lane >> lpr_log2;
@@ -133,13 +133,13 @@ __device__ inline void gather_rows(const ColArg& c, int64_t wave_row0) {
     const int q = k * kWave + lane;
     const int64_t s = wave_row0 + q;
     if (q < n_slots && s < n_seg) {
-      rowreg[k] = id_to_row(c.map, load_id(c.ids, c.ids64, s));
+      rowreg[k] = id_to_row(c.map, load_id(c.ids, D16 ? 1 : c.ids64, s));
       if (SLOT) slotreg[k] = __builtin_nontemporal_load(c.out_slots + s);
     }
   }
 
   V v[U];
-  const bool live = sub < c.chunks;
+  const bool live = D16 ? true : sub < c.chunks;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int q0 = u * rpi;  // multiple of rpi (a power of two <= 64): q0>>6 is uniform
@@ -240,7 +240,7 @@ __device__ inline void combine_segments(const ColArg& c, int64_t wave_seg0) {
 // One instantiation per (ragged?, 16-byte chunks?, segmented table?) so that the common case --
 // one id per sample, dim % 4 == 0, plain table -- carries none of the other paths' code; the host
 // launches each kind present in the call with the columns of that kind.
-template <bool CSR, typename V, bool RUNS, int HALF = 0, bool SLOT = false>
+template <bool CSR, typename V, bool RUNS, int HALF = 0, bool SLOT = false, bool D16 = false>
 __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupArgs a) {
   const int b = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, a.xcd);
   // last column whose first tile is <= b.  A binary search over the kernel-argument table is
@@ -264,11 +264,11 @@ __global__ __launch_bounds__(kBlock) void group_lookup_fwd_kernel(const LookupAr
   }
   const ColArg& c = a.col[ci];
   const int wave = (int)(threadIdx.x >> 6);
-  const int rpi = kWave >> c.lpr_log2;
+  const int rpi = D16 ? 16 : kWave >> c.lpr_log2;
   if (!CSR) {
     const int64_t row0 = (tile * kWavesPerBlock + wave) * (int64_t)(kU * rpi);
     if (row0 >= c.n_seg) return;
-    gather_rows<V, kU, RUNS, HALF, SLOT>(c, row0);
+    gather_rows<V, kU, RUNS, HALF, SLOT, D16>(c, row0);
   } else {
     const int64_t seg0 = (tile * kWavesPerBlock + wave) * (int64_t)(kSegIters * rpi);
     if (seg0 >= c.n_seg) return;
@@ -440,6 +440,11 @@ void launch_kind(const LookupArgs& args, unsigned tiles, hipStream_t stream) {
 }
 
 void launch_by_kind(int kind, const LookupArgs& args, unsigned tiles, hipStream_t stream) {
+  if (kind == 39) {  // kind 0 with every column 16 floats wide and int64 ids (the headline's shape): constants
+    hipLaunchKernelGGL((group_lookup_fwd_kernel<false, f32x4, false, 0, false, true>), dim3(tiles), dim3(kBlock), 0,
+                       stream, args);
+    return;
+  }
   if (kind == 8) {  // wide rows through the hot-row kernel (option fwd_hot_rows)
     hipLaunchKernelGGL(group_lookup_fwd_hot_kernel, dim3(tiles), dim3(kBlock), 0, stream, args);
     return;
@@ -544,6 +549,10 @@ extern "C" int hbk_group_lookup_fwd(int32_t n_cols, const hbk_lookup_column_t* c
     if (col_kind == 0 && (hot_mode > 0 || h.hot_rows != 0) && h.dim >= 64 && shape.lpr_log2 <= 6 &&
         h.dim <= kHotStageFloats && h.rows < 0xffffffffll) {
       col_kind = 8;
+    }
+    if (col_kind == 0 && options().fwd_d16 != 0 && h.dim == 16 && h.ids_dtype == HBK_INT64 && shape.lpr_log2 == 2 &&
+        shape.chunks == 4) {
+      col_kind = 39;
     }
     cls[c].kind = col_kind;
     kinds_present |= 1ull << col_kind;

@@ -46,6 +46,7 @@ const OptionEntry kOptions[] = {
     {"bwd_seg_inline", "HBK_BWD_SEG_INLINE", &Options::bwd_seg_inline},
     {"bwd_scale_fused", "HBK_BWD_SCALE_FUSED", &Options::bwd_scale_fused},
     {"bwd_simple", "HBK_BWD_SIMPLE", &Options::bwd_simple},
+    {"fwd_d16", "HBK_FWD_D16", &Options::fwd_d16},
     {"bwd_wide", "HBK_BWD_WIDE", &Options::bwd_wide},
     {"bwd_xcd", "HBK_BWD_XCD", &Options::bwd_xcd},
     {"fwd_xcd", "HBK_FWD_XCD", &Options::fwd_xcd},

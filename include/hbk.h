@@ -88,7 +88,7 @@ int hbk_tables_free(void* slab);
  * 1: columns whose row range fits the row-sorted jobs take those jobs' in-order form -- a row's pairs ordered by gradient row inside the
  * job, output ranges in bucket order, no bucket split over workgroups -- and the other columns the sort of 2; 2: a stable sort of the
  * batch's (row, gradient row) pairs and a sequential walk for every column; the reproducibility mode, TF_DETERMINISTIC_OPS' analogue),
- * bwd_pairs_packed, bwd_seg_inline, bwd_scale_fused, bwd_simple (0: the general instantiation of the grouping kernels for every launch group), bwd_scatter_staged, bwd_rowsort_pos, bwd_rowsort_ratio (round 5: x 4 for dim <= 32),
+ * bwd_pairs_packed, bwd_seg_inline, bwd_scale_fused, bwd_simple (0: the general instantiation of the grouping kernels for every launch group), fwd_d16 (0: the general gather for columns of 16 floats too), bwd_scatter_staged, bwd_rowsort_pos, bwd_rowsort_ratio (round 5: x 4 for dim <= 32),
  * bwd_streams (launch groups of > 64 columns rotate over this many library streams; 0: the caller's), bwd_large_first,
  * bwd_trace (the launch groups of every backward call on stderr), bwd_lds_pad (a probe), sharded_p2p,
  * sharded_p2p_test_refuse (test hook: the rank whose hbk_sharded_p2p_bind behaves as if a peer's memory could not be mapped),

@@ -86,6 +86,8 @@ plan_options = st.fixed_dictionaries({
   'bwd_large_first': st.sampled_from([0, 1]),       # order of the launch groups
   'bwd_rowsort_ratio': st.sampled_from([0, 8, 64]), # row-sorted buckets never / by the shipped ratio / for sparse columns too
   'bwd_lds_pad': st.sampled_from([0, 14]),          # fewer resident tiles in the grouping launches
+  'bwd_simple': st.sampled_from([0, 1]),            # the grouping kernels' general instantiation / the one for plain columns
+  'fwd_d16': st.sampled_from([0, 1]),               # the gather's general instantiation / the one for rows of 16 floats
 })
 
 

@@ -788,7 +788,8 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
   int32_t* const first = stage_dyn + a.stage_p;    // [stage_p] first staged slot of the bucket
   int32_t* const st_seg = stage_dyn + 2 * a.stage_p;   // [kTile], only in groups with unpacked columns
   __shared__ int64_t st_row[kTile];                // the tile's pairs, sorted by bucket
-  __shared__ uint16_t st_b[kTile];
+  // (SIMPLE: a staged pair's bucket is recomputed from its row -- 4 KB of LDS less: 8 resident tiles per CU instead of 7)
+  __shared__ uint16_t st_b[SIMPLE ? 1 : kTile];
   __shared__ int32_t wave_cnt[kWavesPerBlock];
   __shared__ int32_t n_staged;
   const int blk = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, (a.xcd >> kXcdScatterBit) & 1);
@@ -902,7 +903,7 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
         st_row[L] = id[k];
         st_seg[L] = seg[k];
       }
-      st_b[L] = (uint16_t)b;
+      if (!SIMPLE) st_b[L] = (uint16_t)b;
     }
   }
   __syncthreads();
@@ -911,7 +912,8 @@ __global__ __launch_bounds__(kBlock, 4) void bwd_scatter_staged_kernel(const GAr
   for (int k = 0; k < kPerThread; ++k) {
     const int L = k * kBlock + tid;
     if (L < n_st) {
-      const int32_t pos = counters[st_b[L]] + L;
+      const int sb = SIMPLE ? (int)__umulhi((uint32_t)((uint64_t)st_row[L] >> 32), c.dense_mul) : (int)st_b[L];
+      const int32_t pos = counters[sb] + L;
       c.pair_row[0][pos] = st_row[L];
       if (!SIMPLE && !c.packed) c.pair_seg[0][pos] = st_seg[L];
     }

@@ -1157,7 +1157,8 @@ def test_group_lookup_backward_deterministic_per_call_flag():
   option: that object's sums are the in-order fp32 sums, rows ascending; a call that MIXES flagged and
   plain columns (set through the descriptors) gives the flagged ones exactly, the plain ones within
   the tolerance of an unordered fp32 sum; the option stays 0 throughout."""
-  assert _lib.get_option('bwd_deterministic') == 0
+  if _lib.get_option('bwd_deterministic') != 0:
+    pytest.skip('HBK_BWD_DETERMINISTIC is set for the whole process: nothing per call to tell apart')
   rng = np.random.RandomState(613)
   shapes = [(16, 3000, 40000), (8, 150000, 60000), (128, 700, 9000), (4, 97, 5000)]
   tables, ids, grads = [], [], []
